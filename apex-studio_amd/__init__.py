@@ -1,0 +1,15 @@
+"""apex-studio_amd — MI355X (gfx950) denoise hot path for Apex Studio's render pipeline.
+
+Layout (only what the hot path needs):
+  csrc/        hand-written HIP kernels + the C-ABI (include/apexmi.h) -> libapex_mi355.so
+  lib.py       ctypes binding of the C-ABI (fails loudly when the library is missing)
+  ops.py       torch.Tensor-level wrappers over the C-ABI (device memory + streams are plumbing)
+  register.py  FunctionRegister / ClassRegister mirrors of the reference's plug-in registries
+  attention_backend.py  the "hip_mfma" entry for attention_register
+  flux.py      FluxTransformer2DModel drop-in ("flux.mi355") on the HIP ops
+  schedulers.py  FlowMatch-Euler sampler step (the loop stays in Python)
+  render_queue.py  one-clip-per-GPU sharding + RCCL broadcast of shared weights
+"""
+__version__ = "0.1.0"
+
+from . import lib  # noqa: F401

@@ -1,0 +1,405 @@
+// Attention forward for the denoise path: softmax(q k^T * scale) v, no mask, non-causal.
+// Replaces the callable behind attention_register.call (reference attention/functions.py:84,
+// default "sdpa" :338-377) at the call sites flux/base/attention.py:89-94,
+// wan/base/attention.py:397-399 and qwenimage/base/model.py:555-562.
+//
+// MFMA kernel (bf16, D = 128), per workgroup 4 waves x 32 query rows, KV tile = 64 keys:
+//   S^T = K Q^T      (MFMA "A" = K rows from LDS, "B" = Q rows held in registers)
+//   O^T = V^T P^T    (MFMA "A" = V^T rows from LDS, "B" = P, straight out of the S^T accumulators)
+// Both products are "swapped" so lane l owns query row (l & 31): the row max / row sum of the
+// online softmax are 31 in-lane ops + one v_permlane32_swap with lane l^32, and the O rescale
+// is lane-local.  K tiles are staged with their rows permuted (bits 2 and 3 of the row index
+// swapped) so that the 8 scores a lane holds for one PV k-step are 8 CONSECUTIVE keys: the
+// V^T fragment is then a single ds_read_b128 and P needs no cross-lane shuffle at all.
+// V arrives pre-transposed ([B,H,128,Skp], produced by apexmi_qkv_prepare / apexmi_v_transpose),
+// so K and V^T tiles are both contraction-contiguous and are staged by 16-byte global_load_lds
+// into a double-buffered 64 KiB LDS image, XOR-swizzled on the source address and the read.
+// Workgroup ids are remapped so all query blocks of one (batch, head) run on one XCD and share
+// its L2 copy of K / V^T.
+#include "common.h"
+
+namespace {
+
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KV = 64;    // keys per tile
+constexpr int HD = 128;   // head dim
+constexpr int K_TILE_BYTES = KV * HD * 2;   // 16 KiB
+constexpr int V_TILE_BYTES = HD * KV * 2;   // 16 KiB
+constexpr int ATT_STAGE = K_TILE_BYTES + V_TILE_BYTES;
+
+// row i of a 32-row K sub-tile holds key perm32(i): swap bits 2 and 3
+APEXMI_DEVICE int perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int s = xcd_remap(blockIdx.x, total);
+    const int hb = s / nqb, qb = s % nqb;
+    const int b = hb / H, h = hb % H;
+
+    const bf16_t* Qp = Q + (int64_t)hb * Sq * HD;
+    const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
+    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
+
+    const int qrow = qb * QB + wave * 32 + l31;
+    const int qrow_c = min(qrow, Sq - 1);
+
+    // Q fragments: B operand of S^T, lane supplies Q[qrow][16 ks + 8 hi .. +7]
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        qf[ks] = *(const bf16x8*)(Qp + (int64_t)qrow_c * HD + ks * 16 + hi * 8);
+
+    // staging sources. K image: [64 rows][16 chunks], chunk ^= row & 15, row i <- key perm(i).
+    // V^T image: [128 rows (d)][8 chunks], chunk ^= (row >> 1) & 7.
+    int k_key[4], k_c[4];
+    const char* v_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (wave * 4 + i) * 64 + lane;
+        {
+            const int row = p >> 4, pc = p & 15;
+            k_c[i] = (pc ^ (row & 15)) * 8;
+            k_key[i] = (row & 32) + perm32(row & 31);
+        }
+        {
+            const int row = p >> 3, pc = p & 7;
+            const int c = pc ^ ((row >> 1) & 7);
+            v_src[i] = (const char*)(Vp + (int64_t)row * Skp + c * 8);
+        }
+    }
+
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * ATT_STAGE + wave * 4096;
+        const int kv0 = t * KV;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = min(kv0 + k_key[i], Sk - 1);
+            glds16(Kp + (int64_t)key * HD + k_c[i], base + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * 1024);
+    };
+
+    // LDS read offsets
+    int k_off[2], k_sw[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int row = kt * 32 + l31;
+        k_off[kt] = row * 256;
+        k_sw[kt] = row & 15;
+    }
+    int v_off[4], v_sw[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int row = dt * 32 + l31;
+        v_off[dt] = row * 128;
+        v_sw[dt] = (row >> 1) & 7;
+    }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+    float m_run = -1.0e30f;  // running max, already in the scaled (log2) domain
+    float l_run = 0.0f;      // this lane's partial row sum (its 32 keys of every tile)
+
+    const int nt = (Sk + KV - 1) / KV;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* Ks = smem + (t & 1) * ATT_STAGE;
+        const char* Vs = Ks + K_TILE_BYTES;
+
+        // ---- S^T = K Q^T : sacc[kt][r] = score(q = l31, key row i = (r&3) + 8 (r>>2) + 4 hi) ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = ks * 2 + hi;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + k_off[kt] + ((c ^ k_sw[kt]) << 4));
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+            }
+        }
+
+        // ---- mask keys past Sk (last tile only; wave-uniform branch) ----
+        if (t == nt - 1 && (Sk & (KV - 1)) != 0) {
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int a = r >> 2, bb = r & 3;
+                    const int key = kv0 + kt * 32 + 16 * (a >> 1) + 8 * hi + 4 * (a & 1) + bb;
+                    if (key >= Sk) sacc[kt][r] = -1.0e30f;
+                }
+        }
+
+        // ---- online softmax (base-2 domain: p = 2^(s*c - m)) ----
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+        mx = max_xor32(mx);
+        const float m_new = fmaxf(m_run, mx * scale_log2e);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_new));
+                sacc[kt][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+
+        // ---- P -> bf16 B-fragments: k-step kk takes regs 8 (kk & 1) .. +7 of sacc[kk >> 1],
+        //      which are keys 16 kk + 8 hi .. +7 of the tile ----
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kk][j] = (__bf16)sacc[kk >> 1][8 * (kk & 1) + j];
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk * 2 + hi;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(Vs + v_off[dt] + ((c ^ v_sw[dt]) << 4));
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
+    const float l_tot = sum_xor32(l_run);
+    const float inv = 1.0f / l_tot;
+    if (qrow < Sq) {
+        bf16_t* op = O + (int64_t)b * o_sb + (int64_t)qrow * o_ss + (int64_t)h * o_sh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+                *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
+            }
+    }
+}
+
+// ---- generic fallback: any D <= 256, bf16 / f16 / f32, strided views; one workgroup per query row.
+// Exists so the operator survives the reference's backend verification probe
+// (B,H,S,D = 1,2,8,64 fp16; attention/functions.py:1999-2251) and odd head sizes (VAE C = 384 is
+// handled by splitting is not needed: D <= 512 threads).  Not a performance path.
+template <typename T>
+APEXMI_DEVICE float ld_elem(const T* p);
+template <>
+APEXMI_DEVICE float ld_elem<uint16_t>(const uint16_t* p) { return bf16_to_f32(*p); }
+template <>
+APEXMI_DEVICE float ld_elem<_Float16>(const _Float16* p) { return (float)*p; }
+template <>
+APEXMI_DEVICE float ld_elem<float>(const float* p) { return *p; }
+template <typename T>
+APEXMI_DEVICE void st_elem(T* p, float v);
+template <>
+APEXMI_DEVICE void st_elem<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+template <>
+APEXMI_DEVICE void st_elem<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
+template <>
+APEXMI_DEVICE void st_elem<float>(float* p, float v) { *p = v; }
+
+constexpr int GEN_THREADS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(GEN_THREADS) void attn_fwd_generic_kernel(
+    const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V, T* __restrict__ O,
+    int H, int Sq, int Sk, int D, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+    int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale) {
+    __shared__ float qs[512];
+    __shared__ float ps[GEN_THREADS];
+    __shared__ float red[GEN_THREADS / 64];
+    __shared__ float bc[2];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const T* qp = Q + b * q_sb + h * q_sh + q * q_ss;
+    for (int d = tid; d < D; d += GEN_THREADS) qs[d] = ld_elem<T>(qp + d) * scale;
+    __syncthreads();
+    float m_run = -1.0e30f, l_run = 0.0f, acc = 0.0f;
+    for (int k0 = 0; k0 < Sk; k0 += GEN_THREADS) {
+        const int key = k0 + tid;
+        float sc = -1.0e30f;
+        if (key < Sk) {
+            const T* kp = K + b * k_sb + h * k_sh + key * k_ss;
+            float a = 0.0f;
+            for (int d = 0; d < D; ++d) a = fmaf(qs[d], ld_elem<T>(kp + d), a);
+            sc = a;
+        }
+        float mx = wave_max(sc);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float mm = red[0];
+            for (int i = 1; i < GEN_THREADS / 64; ++i) mm = fmaxf(mm, red[i]);
+            bc[0] = mm;
+        }
+        __syncthreads();
+        const float m_new = fmaxf(m_run, bc[0]);
+        const float alpha = __expf(m_run - m_new);
+        const float p = (key < Sk) ? __expf(sc - m_new) : 0.0f;
+        ps[tid] = p;
+        float sm = wave_sum(p);
+        __syncthreads();  // everyone has read bc[0]; ps complete after the next barrier
+        if ((tid & 63) == 0) red[tid >> 6] = sm;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int i = 0; i < GEN_THREADS / 64; ++i) tot += red[i];
+        l_run = l_run * alpha + tot;
+        m_run = m_new;
+        if (tid < D) {
+            acc *= alpha;
+            const int nk = min(GEN_THREADS, Sk - k0);
+            const T* vp = V + b * v_sb + h * v_sh + (int64_t)k0 * v_ss + tid;
+            for (int j = 0; j < nk; ++j) acc = fmaf(ps[j], ld_elem<T>(vp + (int64_t)j * v_ss), acc);
+        }
+        __syncthreads();
+    }
+    if (tid < D) st_elem<T>(O + b * o_sb + q * o_ss + h * o_sh + tid, acc / l_run);
+}
+
+template <typename T>
+int launch_generic(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq,
+                   int Sk, int D, const int64_t* qs, const int64_t* ks, const int64_t* vs,
+                   const int64_t* os, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(attn_fwd_generic_kernel<T>, dim3(Sq, H, B), dim3(GEN_THREADS), 0, stream,
+                       (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, D, qs[0], qs[1],
+                       qs[2], ks[0], ks[1], ks[2], vs[0], vs[1], vs[2], os[0], os[1], os[2], scale);
+    return apexmi_check_launch("attn_fwd_generic");
+}
+
+// contiguity test for the MFMA path's packed [B,H,S,128] operands
+bool packed_bhsd(const int64_t* st, int H, int S, int D) {
+    return st[2] == D && st[1] == (int64_t)S * D && st[0] == (int64_t)H * S * D;
+}
+
+}  // namespace
+
+extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void* out,
+                                        int B, int H, int Sq, int Sk, int Skp,
+                                        const int64_t o_strides[3], float softmax_scale,
+                                        apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && vt && out, "attn_fwd_prepared: null operand");
+    APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attn_fwd_prepared: empty problem");
+    APEXMI_REQUIRE(Skp % KV == 0 && Skp >= Sk, "attn_fwd_prepared: Skp=%d must be Sk=%d rounded up to 64", Skp, Sk);
+    APEXMI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 &&
+                       ((uintptr_t)out % 8) == 0,
+                   "attn_fwd_prepared: operands must be 16-byte aligned");
+    APEXMI_REQUIRE(o_strides[0] % 4 == 0 && o_strides[1] % 4 == 0 && o_strides[2] % 4 == 0,
+                   "attn_fwd_prepared: output strides must be multiples of 4 elements");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        attr_set = true;
+    }
+    const int nqb = (Sq + QB - 1) / QB;
+    const int total = nqb * H * B;
+    const float c = softmax_scale * 1.4426950408889634f;
+    ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * HD,
+                         2.0 * B * H * HD * (2.0 * Sq + 2.0 * Sk));
+    hipLaunchKernelGGL(attn_fwd_d128_kernel, dim3(total), dim3(256), 2 * ATT_STAGE, stream,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
+                       Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
+    return apexmi_check_launch("attn_fwd_d128");
+}
+
+extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
+    if (dtype != APEXMI_BF16 || D != HD) return 0;
+    const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
+    // V^T plus packed copies of q and k (used only when the caller's views are not packed)
+    return (size_t)B * H * HD * skp * 2 + (size_t)B * H * ((size_t)Sq + Sk) * HD * 2;
+}
+
+int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int D, void* out,
+                     hipStream_t stream);
+
+extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void* out, int B, int H,
+                               int Sq, int Sk, int D, const int64_t q_strides[3],
+                               const int64_t k_strides[3], const int64_t v_strides[3],
+                               const int64_t o_strides[3], float softmax_scale, int dtype,
+                               void* workspace, size_t workspace_bytes, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && v && out, "attn_fwd: null operand");
+    APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0 && D > 0, "attn_fwd: empty problem");
+    if (dtype == APEXMI_BF16 && D == HD) {
+        const size_t need = apexmi_attn_workspace_bytes(B, H, Sq, Sk, D, dtype);
+        APEXMI_REQUIRE(workspace && workspace_bytes >= need,
+                       "attn_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+        const int skp = ((Sk + KV - 1) / KV) * KV;
+        char* ws = (char*)workspace;
+        void* vt = ws;
+        ws += (size_t)B * H * HD * skp * 2;
+        const void* qp = q;
+        const void* kp = k;
+        if (!packed_bhsd(q_strides, H, Sq, D)) {
+            if (int rc = apexmi_pack_bhsd(q, q_strides, B, H, Sq, D, ws, stream)) return rc;
+            qp = ws;
+        }
+        ws += (size_t)B * H * Sq * HD * 2;
+        if (!packed_bhsd(k_strides, H, Sk, D)) {
+            if (int rc = apexmi_pack_bhsd(k, k_strides, B, H, Sk, D, ws, stream)) return rc;
+            kp = ws;
+        }
+        for (int b = 0; b < B; ++b) {
+            const bf16_t* vb = (const bf16_t*)v + b * v_strides[0];
+            bf16_t* vtb = (bf16_t*)vt + (size_t)b * H * HD * skp;
+            if (int rc = apexmi_v_transpose(vb, v_strides[1], v_strides[2], Sk, H, D, vtb, skp, 0, stream))
+                return rc;
+        }
+        return apexmi_attn_fwd_prepared(qp, kp, vt, out, B, H, Sq, Sk, skp, o_strides, softmax_scale,
+                                        stream);
+    }
+    APEXMI_REQUIRE(D <= GEN_THREADS, "attn_fwd: head dim %d > %d unsupported", D, GEN_THREADS);
+    ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * D, 0.0);
+    switch (dtype) {
+        case APEXMI_BF16:
+            return launch_generic<uint16_t>(q, k, v, out, B, H, Sq, Sk, D, q_strides, k_strides,
+                                            v_strides, o_strides, softmax_scale, stream);
+        case APEXMI_F16:
+            return launch_generic<_Float16>(q, k, v, out, B, H, Sq, Sk, D, q_strides, k_strides,
+                                            v_strides, o_strides, softmax_scale, stream);
+        case APEXMI_F32:
+            return launch_generic<float>(q, k, v, out, B, H, Sq, Sk, D, q_strides, k_strides,
+                                         v_strides, o_strides, softmax_scale, stream);
+        default:
+            apexmi_set_error("attn_fwd: unknown dtype %d", dtype);
+            return 1;
+    }
+}

@@ -1,0 +1,127 @@
+// Shared device/host helpers for libapex_mi355.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/apexmi.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+typedef uint16_t bf16_t;  // storage type at the C-ABI
+
+#define APEXMI_DEVICE __device__ __forceinline__
+
+APEXMI_DEVICE float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+APEXMI_DEVICE float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+APEXMI_DEVICE float bf16_to_f32(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// round-to-nearest-even pack of two floats into one dword (lowers to v_cvt_pk_bf16_f32)
+APEXMI_DEVICE uint32_t pack_bf16(float a, float b) {
+    bf16x2 r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, r);
+}
+APEXMI_DEVICE bf16_t f32_to_bf16(float a) {
+    __bf16 r = (__bf16)a;
+    return __builtin_bit_cast(bf16_t, r);
+}
+
+// unpack 8 bf16 held in a u32x4 into 8 floats
+APEXMI_DEVICE void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf16_lo(v[i]);
+        f[2 * i + 1] = bf16_hi(v[i]);
+    }
+}
+APEXMI_DEVICE u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// exchange with lane ^ 32 via v_permlane32_swap; returns {value of the low-half lane, value of
+// the high-half lane} so max(r0,r1) / r0+r1 are the 2-lane reductions without a select.
+APEXMI_DEVICE void swap32(float x, float& a, float& b) {
+    uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+APEXMI_DEVICE float max_xor32(float x) {
+    float a, b;
+    swap32(x, a, b);
+    return fmaxf(a, b);
+}
+APEXMI_DEVICE float sum_xor32(float x) {
+    float a, b;
+    swap32(x, a, b);
+    return a + b;
+}
+
+APEXMI_DEVICE float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+APEXMI_DEVICE float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+APEXMI_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+APEXMI_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+APEXMI_DEVICE float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2 / (exp(2u) + 1); clamp keeps exp finite
+    float e = __expf(fminf(2.0f * u, 80.0f));
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+
+// async 16-byte global -> LDS copy: LDS destination is wave-uniform `lds` + lane*16
+APEXMI_DEVICE void glds16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// bijective XCD-aware remap of a 1-D block id: workgroup b is observed to run on XCD b % 8;
+// give each XCD a contiguous chunk of the logical tile list so neighbours share its L2.
+APEXMI_DEVICE int xcd_remap(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+void apexmi_set_error(const char* fmt, ...);
+int apexmi_check_launch(const char* what);
+
+struct ApexmiProfScope {
+    int cls;
+    hipStream_t stream;
+    int slot;
+    ApexmiProfScope(int cls, hipStream_t s, double flops, double bytes);
+    ~ApexmiProfScope();
+};
+
+#define APEXMI_REQUIRE(cond, ...)              \
+    do {                                       \
+        if (!(cond)) {                         \
+            apexmi_set_error(__VA_ARGS__);     \
+            return 1;                          \
+        }                                      \
+    } while (0)

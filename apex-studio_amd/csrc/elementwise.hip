@@ -1,0 +1,506 @@
+// HBM-bound kernels of the denoise path: AdaLN-style modulated LayerNorm / RMSNorm, the
+// q/k RMSNorm + RoPE + layout pass, V transpose, conditioning GEMV, timestep embedding, casts and
+// the Euler scheduler axpy.  All of them move 16 bytes per lane and keep statistics in f32.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// out = LN(x) [* gamma + beta] [* (1 + scale) + shift]   or   RMSNorm(x) * gamma
+// One wave per row, the whole row in registers (C <= 8192), two-pass statistics.
+// Reference: AdaLayerNormZero / Single / Continuous, flux model.py:299-302,
+// wan model.py:56-165 (FP32LayerNorm + scale/shift), efficiency/mod.py:24-35 (RMSNorm).
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_IT = 16;  // 16 * 64 lanes * 8 elements = 8192
+
+__global__ __launch_bounds__(256) void ln_modulate_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = C >> 3;
+    const bf16_t* xp = x + (int64_t)row * ldx;
+    float v[LN_MAX_IT][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nchunk) {
+            const u32x4 raw = *(const u32x4*)(xp + c * 8);
+            unpack8(raw, v[it]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[it][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[it][j] = 0.0f;
+        }
+    }
+    float mean = 0.0f;
+    if (!rms) mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[it][j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    bf16_t* op = out + (int64_t)row * ldo;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nchunk) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (v[it][j] - mean) * rstd;
+            if (gamma != nullptr) {
+                float g[8];
+                unpack8(*(const u32x4*)(gamma + c * 8), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] *= g[j];
+            }
+            if (beta != nullptr) {
+                float bt[8];
+                unpack8(*(const u32x4*)(beta + c * 8), bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] += bt[j];
+            }
+            if (scale != nullptr) {
+                const f32x4 s0 = *(const f32x4*)(scale + c * 8);
+                const f32x4 s1 = *(const f32x4*)(scale + c * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] *= 1.0f + s0[j];
+                    y[j + 4] *= 1.0f + s1[j];
+                }
+            }
+            if (shift != nullptr) {
+                const f32x4 s0 = *(const f32x4*)(shift + c * 8);
+                const f32x4 s1 = *(const f32x4*)(shift + c * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] += s0[j];
+                    y[j + 4] += s1[j];
+                }
+            }
+            *(u32x4*)(op + c * 8) = pack8(y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k: per-head RMSNorm (f32) * weight, rotary embedding, write [H, S_out, 128].
+// 16 lanes per (row, which, head) unit, 8 elements (4 rotary pairs) per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+    const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
+    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
+    bf16_t* __restrict__ ko, int S_out, int row0) {
+    constexpr int D = 128;
+    const int64_t unit = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const int64_t nunit = (int64_t)S * 2 * H;
+    const bool live = unit < nunit;
+    const int64_t u = live ? unit : nunit - 1;
+    const int s = (int)(u / (2 * H));
+    const int rem = (int)(u % (2 * H));
+    const int which = rem / H, h = rem % H;
+    const int d = l16 * 8;
+    const bf16_t* src = (which ? k : q) + (int64_t)s * ld_in + h * D + d;
+    float x[8];
+    unpack8(*(const u32x4*)src, x);
+    const bf16_t* w = which ? (s < split ? wk2 : wk) : (s < split ? wq2 : wq);
+    if (w != nullptr) {
+        float sq = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq += x[j] * x[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float r = rsqrtf(sq * (1.0f / D) + eps);
+        float wv[8];
+        unpack8(*(const u32x4*)(w + d), wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = x[j] * r * wv[j];
+    }
+    const int srow = row0 + s;
+    float y[8];
+    if (rope_mode == APEXMI_ROPE_INTERLEAVED) {
+        const float* cp = rope + (int64_t)srow * D + d;
+        const float* sp = rope + (int64_t)S_out * D + (int64_t)srow * D + d;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+        float cs[8], sn[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs[j] = c0[j];
+            cs[j + 4] = c1[j];
+            sn[j] = s0[j];
+            sn[j + 4] = s1[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            y[2 * i] = x[2 * i] * cs[2 * i] - x[2 * i + 1] * sn[2 * i];
+            y[2 * i + 1] = x[2 * i + 1] * cs[2 * i + 1] + x[2 * i] * sn[2 * i + 1];
+        }
+    } else if (rope_mode == APEXMI_ROPE_COMPLEX) {
+        const float* tp = rope + ((int64_t)srow * (D / 2) + l16 * 4) * 2;
+        const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
+        const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+        const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            y[2 * i] = x[2 * i] * cs[i] - x[2 * i + 1] * sn[i];
+            y[2 * i + 1] = x[2 * i] * sn[i] + x[2 * i + 1] * cs[i];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = x[j];
+    }
+    if (live) {
+        bf16_t* dst = (which ? ko : qo) + ((int64_t)h * S_out + srow) * D + d;
+        *(u32x4*)dst = pack8(y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vt[h][d][col0 + s] = v[s][h][d]; columns in [S, round_up(S, 64)) are zero-filled (the attention
+// kernel multiplies them by p = 0, so they must be finite).  64 x 128 tile through LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v,
+                                                          int64_t v_sh, int64_t v_ss, int S, int D,
+                                                          bf16_t* __restrict__ vt, int Skp,
+                                                          int col0) {
+    constexpr int LDW = 136;  // padded LDS row (elements)
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDW];
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;
+        const int r = idx >> 4, dc = idx & 15;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (s0 + r < S) val = *(const u32x4*)(v + (int64_t)h * v_sh + (int64_t)(s0 + r) * v_ss + dc * 8);
+        *(u32x4*)(tile + r * LDW + dc * 8) = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;
+        const int d = idx >> 3, sc = idx & 7;
+        bf16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = tile[(sc * 8 + j) * LDW + d];
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+        *(u32x4*)(vt + ((int64_t)h * D + d) * Skp + col0 + s0 + sc * 8) = o;
+    }
+}
+
+// strided [B,H,S,D] view -> packed copy
+__global__ __launch_bounds__(256) void pack_bhsd_kernel(const bf16_t* __restrict__ x, int64_t sb,
+                                                        int64_t sh, int64_t ss, int H, int S,
+                                                        int D, bf16_t* __restrict__ out,
+                                                        int64_t nchunk) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nchunk) return;
+    const int dc = D >> 3;
+    const int c = (int)(idx % dc);
+    int64_t r = idx / dc;
+    const int s = (int)(r % S);
+    r /= S;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    *(u32x4*)(out + idx * 8) = *(const u32x4*)(x + b * sb + h * sh + s * ss + c * 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[m][n] = post(dot(W[n,:], pre(x[m,:])) + bias[n]); one wave per output row, x in LDS (f32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, int64_t ldw,
+                                                   const bf16_t* __restrict__ bias,
+                                                   const float* __restrict__ x, int64_t ldx,
+                                                   float* __restrict__ y, int64_t ldy, int N, int K,
+                                                   int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;
+    const int m = blockIdx.y;
+    const float* xp = x + (int64_t)m * ldx;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        float v = xp[i];
+        if (flags & APEXMI_GEMV_PRE_SILU) v = silu_f(v);
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    const int nchunk = K >> 3;
+    for (int n = gw; n < N; n += nw) {
+        const bf16_t* wp = W + (int64_t)n * ldw;
+        float acc = 0.0f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float w[8];
+            unpack8(*(const u32x4*)(wp + c * 8), w);
+            const f32x4 x0 = *(const f32x4*)(xs + c * 8);
+            const f32x4 x1 = *(const f32x4*)(xs + c * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = fmaf(w[j], x0[j], acc);
+                acc = fmaf(w[j + 4], x1[j], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (bias != nullptr) acc += bf16_to_f32(bias[n]);
+            if (flags & APEXMI_GEMV_POST_SILU) acc = silu_f(acc);
+            if (flags & APEXMI_GEMV_POST_GELU) acc = gelu_tanh_f(acc);
+            float* yp = y + (int64_t)m * ldy + n;
+            if (flags & APEXMI_GEMV_ACCUM) acc += *yp;
+            *yp = acc;
+        }
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out,
+                                          int M, int dim, float scale, int flip, float shift) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * half) return;
+    const int m = idx / half, i = idx % half;
+    // exponent = -ln(10000) * i / (half - shift)
+    const float e = expf(-9.210340371976184f * (float)i / ((float)half - shift));
+    const float a = t[m] * e * scale;
+    const float sn = sinf(a), cs = cosf(a);
+    float* o = out + (int64_t)m * dim;
+    if (flip) {
+        o[i] = cs;
+        o[half + i] = sn;
+    } else {
+        o[i] = sn;
+        o[half + i] = cs;
+    }
+}
+
+struct AxesDims {
+    int n;
+    int dim[4];
+};
+__global__ void rope_table_axes_kernel(const float* __restrict__ ids, int S, AxesDims ax, int D,
+                                       double log_theta, float* __restrict__ out) {
+    const int half = D / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * half) return;
+    const int s = idx / half;
+    int j = idx % half;  // pair index inside the row
+    int a = 0;
+    while (a < ax.n - 1 && j >= ax.dim[a] / 2) {
+        j -= ax.dim[a] / 2;
+        ++a;
+    }
+    // freq = 1 / theta^(2j / dim_a), angle = pos * freq, all in f64
+    const double freq = exp(-log_theta * (double)(2 * j) / (double)ax.dim[a]);
+    const double ang = (double)ids[(int64_t)s * ax.n + a] * freq;
+    const float c = (float)cos(ang), sn = (float)sin(ang);
+    const int col = 2 * (idx % half);
+    float* cp = out + (int64_t)s * D + col;
+    float* sp = out + (int64_t)S * D + (int64_t)s * D + col;
+    cp[0] = c;
+    cp[1] = c;
+    sp[0] = sn;
+    sp[1] = sn;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = f32_to_bf16(x[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = bf16_to_f32(x[i]);
+}
+
+// prev = sample + dt * model_output (f32 math); FlowMatchEulerDiscreteScheduler.step
+template <int F32>
+__global__ void euler_step_kernel(const void* __restrict__ sample, const bf16_t* __restrict__ v,
+                                  void* __restrict__ out, int64_t n, float dt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (F32) {
+        ((float*)out)[i] = ((const float*)sample)[i] + dt * bf16_to_f32(v[i]);
+    } else {
+        const float sv = bf16_to_f32(((const bf16_t*)sample)[i]);
+        ((bf16_t*)out)[i] = f32_to_bf16(sv + dt * bf16_to_f32(v[i]));
+    }
+}
+
+}  // namespace
+
+extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                                  const float* scale, const float* shift, const void* gamma,
+                                  const void* beta, float eps, int rms, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out, "ln_modulate: null operand");
+    APEXMI_REQUIRE(M > 0 && C > 0, "ln_modulate: empty problem");
+    APEXMI_REQUIRE(C % 8 == 0 && C <= LN_MAX_IT * 512, "ln_modulate: C=%d must be a multiple of 8 and <= %d", C,
+                   LN_MAX_IT * 512);
+    APEXMI_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                   "ln_modulate: rows must be 16-byte aligned");
+    APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
+                   "ln_modulate: scale/shift must be 16-byte aligned");
+    ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)M * C);
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x,
+                       ldx, (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,
+                       (const bf16_t*)beta, eps, rms);
+    return apexmi_check_launch("ln_modulate");
+}
+
+extern "C" int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H,
+                                  int D, void* vt, int Skp, int row0, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(v && vt, "v_transpose: null operand");
+    APEXMI_REQUIRE(D == 128, "v_transpose: D=%d unsupported (128 only)", D);
+    APEXMI_REQUIRE(row0 % 64 == 0 && Skp % 64 == 0 && row0 + ((S + 63) / 64) * 64 <= Skp,
+                   "v_transpose: row0=%d S=%d Skp=%d not tile aligned", row0, S, Skp);
+    APEXMI_REQUIRE(v_stride_h % 8 == 0 && v_stride_s % 8 == 0 && ((uintptr_t)v % 16) == 0 &&
+                       ((uintptr_t)vt % 16) == 0,
+                   "v_transpose: rows must be 16-byte aligned");
+    ApexmiProfScope prof(4, stream, 0.0, 4.0 * (double)S * H * D);
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, H), dim3(256), 0, stream,
+                       (const bf16_t*)v, v_stride_h, v_stride_s, S, D, (bf16_t*)vt, Skp, row0);
+    return apexmi_check_launch("v_transpose");
+}
+
+int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int D, void* out,
+                     hipStream_t stream) {
+    APEXMI_REQUIRE(D % 8 == 0 && st[0] % 8 == 0 && st[1] % 8 == 0 && st[2] % 8 == 0 &&
+                       ((uintptr_t)x % 16) == 0,
+                   "attn_fwd: strided operand rows must be 16-byte aligned");
+    const int64_t nchunk = (int64_t)B * H * S * (D / 8);
+    ApexmiProfScope prof(4, stream, 0.0, 4.0 * (double)B * H * S * D);
+    hipLaunchKernelGGL(pack_bhsd_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)x, st[0], st[1], st[2], H, S, D, (bf16_t*)out, nchunk);
+    return apexmi_check_launch("pack_bhsd");
+}
+
+extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_in, int S,
+                                  int H, int D, int split, const void* wq, const void* wk,
+                                  const void* wq2, const void* wk2, float eps, const float* rope,
+                                  int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
+                                  int row0, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && qo && ko, "qkv_prepare: null operand");
+    APEXMI_REQUIRE(D == 128, "qkv_prepare: D=%d unsupported (128 only)", D);
+    APEXMI_REQUIRE(S > 0 && H > 0 && row0 >= 0 && row0 + S <= S_out, "qkv_prepare: bad row range");
+    APEXMI_REQUIRE(ld_in % 8 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0,
+                   "qkv_prepare: rows must be 16-byte aligned");
+    APEXMI_REQUIRE(rope_mode == APEXMI_ROPE_NONE || (rope && ((uintptr_t)rope % 16) == 0),
+                   "qkv_prepare: rope table missing or misaligned");
+    APEXMI_REQUIRE(split <= 0 || (wq2 && wk2) || (!wq && !wk), "qkv_prepare: split needs the second weight set");
+    {
+        ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D);
+        const int64_t nunit = (int64_t)S * 2 * H;
+        hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
+                           (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
+                           (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
+                           rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
+        if (int rc = apexmi_check_launch("qk_norm_rope")) return rc;
+    }
+    if (v != nullptr && vt != nullptr)
+        return apexmi_v_transpose(v, D, ld_in, S, H, D, vt, Skp, row0, stream_);
+    return 0;
+}
+
+extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, int M, int N, int K, int flags,
+                           apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(W && x && y, "gemv: null operand");
+    APEXMI_REQUIRE(M > 0 && M <= 8 && N > 0 && K > 0, "gemv: bad shape M=%d N=%d K=%d", M, N, K);
+    APEXMI_REQUIRE(K % 8 == 0 && K <= 16384, "gemv: K=%d must be a multiple of 8 and <= 16384", K);
+    APEXMI_REQUIRE(ldw % 8 == 0 && ((uintptr_t)W % 16) == 0, "gemv: W rows must be 16-byte aligned");
+    int grid = (N + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    ApexmiProfScope prof(2, stream, 2.0 * M * (double)N * K, 2.0 * (double)N * K);
+    hipLaunchKernelGGL(gemv_kernel, dim3(grid, M), dim3(256), (size_t)K * 4, stream, (const bf16_t*)W,
+                       ldw, (const bf16_t*)bias, x, ldx, y, ldy, N, K, flags);
+    return apexmi_check_launch("gemv");
+}
+
+extern "C" int apexmi_timestep_embedding(const float* t, float* out, int M, int dim, float scale,
+                                         int flip_sin_to_cos, float downscale_freq_shift,
+                                         apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(t && out && M > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments");
+    const int n = M * (dim / 2);
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * M * dim);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, out,
+                       M, dim, scale, flip_sin_to_cos, downscale_freq_shift);
+    return apexmi_check_launch("timestep_embedding");
+}
+
+extern "C" int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const int* axes_dim,
+                                      float theta, float* out, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(ids && out && axes_dim && S > 0, "rope_table_axes: bad arguments");
+    APEXMI_REQUIRE(n_axes >= 1 && n_axes <= 4, "rope_table_axes: n_axes=%d unsupported", n_axes);
+    AxesDims ax;
+    ax.n = n_axes;
+    int D = 0;
+    for (int i = 0; i < 4; ++i) {
+        ax.dim[i] = i < n_axes ? axes_dim[i] : 0;
+        D += ax.dim[i];
+        APEXMI_REQUIRE(ax.dim[i] % 2 == 0, "rope_table_axes: odd axis dim");
+    }
+    const int n = S * (D / 2);
+    ApexmiProfScope prof(5, stream, 0.0, 8.0 * S * D);
+    hipLaunchKernelGGL(rope_table_axes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, S, ax, D,
+                       log((double)theta), out);
+    return apexmi_check_launch("rope_table_axes");
+}
+
+extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out && n > 0, "cast_f32_to_bf16: bad arguments");
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x,
+                       (bf16_t*)out, n);
+    return apexmi_check_launch("cast_f32_to_bf16");
+}
+
+extern "C" int apexmi_cast_bf16_to_f32(const void* x, float* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out && n > 0, "cast_bf16_to_f32: bad arguments");
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)x, out, n);
+    return apexmi_check_launch("cast_bf16_to_f32");
+}
+
+extern "C" int apexmi_euler_step(const void* sample, const void* model_out, void* out, int64_t n,
+                                 float dt, int sample_dtype, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(sample && model_out && out && n > 0, "euler_step: bad arguments");
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (sample_dtype == APEXMI_F32)
+        hipLaunchKernelGGL(euler_step_kernel<1>, grid, dim3(256), 0, stream, sample,
+                           (const bf16_t*)model_out, out, n, dt);
+    else if (sample_dtype == APEXMI_BF16)
+        hipLaunchKernelGGL(euler_step_kernel<0>, grid, dim3(256), 0, stream, sample,
+                           (const bf16_t*)model_out, out, n, dt);
+    else {
+        apexmi_set_error("euler_step: unsupported sample dtype %d", sample_dtype);
+        return 1;
+    }
+    return apexmi_check_launch("euler_step");
+}

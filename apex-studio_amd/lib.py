@@ -1,0 +1,113 @@
+"""ctypes binding of libapex_mi355.so (the C-ABI declared in include/apexmi.h).
+
+There is no CPU fallback: every product entry point goes through this library, and
+`load()` raises if it has not been built (run `python __graft_entry__.py` / `build.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libapex_mi355.so")
+
+_lib = None
+
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.c_void_p  # device pointers travel as plain addresses
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/apexmi.h one-to-one
+SIGNATURES = {
+    "apexmi_version": (C.c_int, []),
+    "apexmi_last_error": (C.c_char_p, []),
+    "apexmi_attn_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "apexmi_attn_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  c_i64p, c_i64p, c_i64p, c_i64p, C.c_float, C.c_int, vp,
+                                  C.c_size_t, vp]),
+    "apexmi_attn_fwd_prepared": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, c_i64p, C.c_float, vp]),
+    "apexmi_gemm_bf16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, vp, vp, C.c_int64, vp]),
+    "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
+                              C.c_int, C.c_int, vp]),
+    "apexmi_ln_modulate": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp,
+                                     C.c_float, C.c_int, vp]),
+    "apexmi_qkv_prepare": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                     vp, vp, C.c_float, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                     C.c_int, vp]),
+    "apexmi_v_transpose": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int,
+                                     C.c_int, vp]),
+    "apexmi_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                                            vp]),
+    "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
+    "apexmi_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "apexmi_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "apexmi_euler_step": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_int, vp]),
+    "apexmi_prof_enable": (C.c_int, [C.c_int]),
+    "apexmi_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
+    "apexmi_prof_reset": (C.c_int, []),
+}
+
+NCLASS = 6
+PROF_CLASSES = ("gemm", "attention", "gemv", "ln_modulate", "qkv_prepare", "other")
+
+BF16, F16, F32 = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES = 0, 1, 2
+GEMV_PRE_SILU, GEMV_POST_SILU, GEMV_POST_GELU, GEMV_ACCUM = 1, 2, 4, 8
+ROPE_INTERLEAVED, ROPE_COMPLEX, ROPE_NONE = 0, 1, 2
+
+
+class ApexMIError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ApexMIError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python __graft_entry__.py` or apex_studio_amd.build.build()). "
+            "There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().apexmi_last_error().decode("utf-8", "replace")
+        raise ApexMIError(f"{what or 'apexmi'} failed (rc={rc}): {msg}")
+
+
+def i64x3(vals):
+    return (C.c_int64 * 3)(*[int(v) for v in vals])
+
+
+def prof_enable(on: bool) -> None:
+    check(load().apexmi_prof_enable(1 if on else 0))
+
+
+def prof_reset() -> None:
+    check(load().apexmi_prof_reset())
+
+
+def prof_read() -> dict:
+    ms = (C.c_double * NCLASS)()
+    n = (C.c_int64 * NCLASS)()
+    fl = (C.c_double * NCLASS)()
+    by = (C.c_double * NCLASS)()
+    check(load().apexmi_prof_read(ms, n, fl, by), "prof_read")
+    return {
+        PROF_CLASSES[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i], "bytes": by[i]}
+        for i in range(NCLASS)
+    }

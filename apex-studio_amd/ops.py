@@ -1,0 +1,281 @@
+"""torch.Tensor-level wrappers over the C-ABI (include/apexmi.h).
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic happens in
+libapex_mi355.so.  Every wrapper refuses CPU tensors: the product path has no fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise _l.ApexMIError(f"{name}: expected a ROCm device tensor, got {t.device} (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise _l.ApexMIError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+_EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES}
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, epilogue: str = "bias",
+         gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  2-D bf16 operands, last dim contiguous."""
+    _req(a, torch.bfloat16, "gemm.a")
+    _req(w, torch.bfloat16, "gemm.w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    else:
+        _req(out, torch.bfloat16, "gemm.out")
+        assert out.shape == (M, N) and out.stride(1) == 1
+    if bias is not None:
+        _req(bias, torch.bfloat16, "gemm.bias")
+        assert bias.is_contiguous() and bias.numel() == N
+    ldr = 0
+    if epilogue == "gate_res":
+        _req(gate, torch.float32, "gemm.gate")
+        _req(residual, torch.bfloat16, "gemm.residual")
+        assert gate.is_contiguous() and gate.numel() == N
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    rc = _l.load().apexmi_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
+                                    out.data_ptr(), out.stride(0), M, N, K, _EPI[epilogue],
+                                    _ptr(gate), _ptr(residual), ldr, _stream())
+    _l.check(rc, "gemm_bf16")
+    return out
+
+
+def gemv(w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, pre_silu: bool = False, post: Optional[str] = None,
+         accum: bool = False) -> torch.Tensor:
+    """y[M,N] (f32) = post(pre(x[M,K] f32) @ w[N,K]^T (bf16) + bias)."""
+    _req(w, torch.bfloat16, "gemv.w")
+    _req(x, torch.float32, "gemv.x")
+    assert w.dim() == 2 and w.stride(1) == 1 and x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        assert not accum
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, torch.float32, "gemv.out")
+        assert out.shape == (M, N) and out.stride(1) == 1
+    if bias is not None:
+        _req(bias, torch.bfloat16, "gemv.bias")
+    flags = 0
+    if pre_silu:
+        flags |= _l.GEMV_PRE_SILU
+    if post == "silu":
+        flags |= _l.GEMV_POST_SILU
+    elif post == "gelu":
+        flags |= _l.GEMV_POST_GELU
+    elif post is not None:
+        raise ValueError(post)
+    if accum:
+        flags |= _l.GEMV_ACCUM
+    rc = _l.load().apexmi_gemv(w.data_ptr(), w.stride(0), _ptr(bias), x.data_ptr(), x.stride(0),
+                               out.data_ptr(), out.stride(0), M, N, K, flags, _stream())
+    _l.check(rc, "gemv")
+    return out
+
+
+def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                eps: float = 1e-6, rms: bool = False) -> torch.Tensor:
+    """out = LayerNorm(x) [*gamma + beta] * (1 + scale) + shift, or RMSNorm(x) * gamma."""
+    _req(x, torch.bfloat16, "ln_modulate.x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.bfloat16, device=x.device)
+    else:
+        _req(out, torch.bfloat16, "ln_modulate.out")
+        assert out.shape == (M, Cc) and out.stride(1) == 1
+    for t, nm in ((scale, "scale"), (shift, "shift")):
+        if t is not None:
+            _req(t, torch.float32, "ln_modulate." + nm)
+            assert t.is_contiguous() and t.numel() == Cc
+    for t, nm in ((gamma, "gamma"), (beta, "beta")):
+        if t is not None:
+            _req(t, torch.bfloat16, "ln_modulate." + nm)
+            assert t.is_contiguous() and t.numel() == Cc
+    rc = _l.load().apexmi_ln_modulate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, Cc,
+                                      _ptr(scale), _ptr(shift), _ptr(gamma), _ptr(beta), float(eps),
+                                      1 if rms else 0, _stream())
+    _l.check(rc, "ln_modulate")
+    return out
+
+
+def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: int,
+                qo: torch.Tensor, ko: torch.Tensor, vt: Optional[torch.Tensor],
+                wq: Optional[torch.Tensor] = None, wk: Optional[torch.Tensor] = None,
+                wq2: Optional[torch.Tensor] = None, wk2: Optional[torch.Tensor] = None,
+                split: int = 0, eps: float = 1e-6, rope: Optional[torch.Tensor] = None,
+                rope_mode: int = _l.ROPE_NONE, row0: int = 0) -> None:
+    """q,k,v: [S, H*128] row views sharing one row stride; qo,ko: [H, S_out, 128]; vt: [H,128,Skp]."""
+    _req(q, torch.bfloat16, "qkv_prepare.q")
+    S = q.shape[0]
+    D = q.shape[1] // H
+    ld = q.stride(0)
+    assert k.stride(0) == ld and (v is None or v.stride(0) == ld)
+    assert qo.is_contiguous() and ko.is_contiguous() and qo.shape == ko.shape and qo.shape[0] == H
+    S_out = qo.shape[1]
+    Skp = 0
+    if vt is not None:
+        assert vt.is_contiguous() and vt.shape[0] == H and vt.shape[1] == D
+        Skp = vt.shape[2]
+    if rope is not None:
+        _req(rope, torch.float32, "qkv_prepare.rope")
+        assert rope.is_contiguous()
+    rc = _l.load().apexmi_qkv_prepare(q.data_ptr(), k.data_ptr(), _ptr(v), ld, S, H, D, split,
+                                      _ptr(wq), _ptr(wk), _ptr(wq2), _ptr(wk2), float(eps),
+                                      _ptr(rope), rope_mode, qo.data_ptr(), ko.data_ptr(), _ptr(vt),
+                                      S_out, Skp, row0, _stream())
+    _l.check(rc, "qkv_prepare")
+
+
+def v_transpose(v: torch.Tensor, vt: torch.Tensor) -> None:
+    """v: [S, H, 128] view (any row/head stride) -> vt [H, 128, Skp] zero padded."""
+    _req(v, torch.bfloat16, "v_transpose.v")
+    S, H, D = v.shape
+    assert v.stride(2) == 1 and vt.is_contiguous()
+    rc = _l.load().apexmi_v_transpose(v.data_ptr(), v.stride(1), v.stride(0), S, H, D, vt.data_ptr(),
+                                      vt.shape[2], 0, _stream())
+    _l.check(rc, "v_transpose")
+
+
+def attention_prepared(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor,
+                       Sk: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q [B,H,Sq,128], k [B,H,Sk,128], vt [B,H,128,Skp] packed; out [B,Sq,H,128] (strided ok)."""
+    _req(q, torch.bfloat16, "attention.q")
+    B, H, Sq, D = q.shape
+    assert D == 128 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    assert out.shape == (B, Sq, H, D) and out.stride(3) == 1
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    rc = _l.load().apexmi_attn_fwd_prepared(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(),
+                                            B, H, Sq, Sk, vt.shape[3],
+                                            _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
+                                            float(scale), _stream())
+    _l.check(rc, "attn_fwd_prepared")
+    return out
+
+
+_DT = {torch.bfloat16: _l.BF16, torch.float16: _l.F16, torch.float32: _l.F32}
+_ws_cache: dict = {}
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+              softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T scale) v for q:[B,H,Sq,D], k,v:[B,H,Sk,D] (permuted views welcome).
+    Returns a [B,H,Sq,D] view of a [B,Sq,H,D] buffer, i.e. `.permute(0,2,1,3)` by the caller
+    (flux/base/attention.py:95) is a no-copy view and `.flatten(2,3)` stays a view."""
+    _req(q, None, "attention.q")
+    if q.dtype not in _DT or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise _l.ApexMIError(f"attention: unsupported dtypes {q.dtype}/{k.dtype}/{v.dtype}")
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    if q.stride(3) != 1:
+        q = q.contiguous()
+    if k.stride(3) != 1:
+        k = k.contiguous()
+    if v.stride(3) != 1:
+        v = v.contiguous()
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(D)
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    lib = _l.load()
+    need = lib.apexmi_attn_workspace_bytes(B, H, Sq, Sk, D, _DT[q.dtype])
+    ws = None
+    if need:
+        key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            _ws_cache[key] = ws
+    rc = lib.apexmi_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Sq, Sk, D,
+                             _l.i64x3((q.stride(0), q.stride(1), q.stride(2))),
+                             _l.i64x3((k.stride(0), k.stride(1), k.stride(2))),
+                             _l.i64x3((v.stride(0), v.stride(1), v.stride(2))),
+                             _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
+                             float(softmax_scale), _DT[q.dtype], _ptr(ws), need, _stream())
+    _l.check(rc, "attn_fwd")
+    return out.permute(0, 2, 1, 3)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, scale: float = 1.0, flip_sin_to_cos: bool = True,
+                       downscale_freq_shift: float = 0.0) -> torch.Tensor:
+    _req(t, torch.float32, "timestep_embedding.t")
+    t = t.contiguous()
+    M = t.numel()
+    out = torch.empty((M, dim), dtype=torch.float32, device=t.device)
+    rc = _l.load().apexmi_timestep_embedding(t.data_ptr(), out.data_ptr(), M, dim, float(scale),
+                                             1 if flip_sin_to_cos else 0, float(downscale_freq_shift),
+                                             _stream())
+    _l.check(rc, "timestep_embedding")
+    return out
+
+
+def rope_table_axes(ids: torch.Tensor, axes_dim, theta: float = 10000.0) -> torch.Tensor:
+    """ids f32 [S, n_axes] -> f32 [2, S, sum(axes_dim)] (cos plane, sin plane)."""
+    import ctypes as C
+    _req(ids, torch.float32, "rope_table_axes.ids")
+    ids = ids.contiguous()
+    S, n = ids.shape
+    D = int(sum(axes_dim))
+    out = torch.empty((2, S, D), dtype=torch.float32, device=ids.device)
+    arr = (C.c_int * n)(*[int(a) for a in axes_dim])
+    rc = _l.load().apexmi_rope_table_axes(ids.data_ptr(), S, n, arr, float(theta), out.data_ptr(), _stream())
+    _l.check(rc, "rope_table_axes")
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float32, "to_bf16.x")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().apexmi_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()))
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.bfloat16, "to_f32.x")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _l.check(_l.load().apexmi_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()))
+    return out
+
+
+def euler_step(sample: torch.Tensor, model_output: torch.Tensor, dt: float,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """prev = sample + dt * model_output in f32, stored in sample's dtype (bf16 or f32)."""
+    _req(model_output, torch.bfloat16, "euler_step.model_output")
+    _req(sample, None, "euler_step.sample")
+    assert sample.is_contiguous() and model_output.is_contiguous()
+    assert sample.numel() == model_output.numel()
+    if out is None:
+        out = torch.empty_like(sample)
+    rc = _l.load().apexmi_euler_step(sample.data_ptr(), model_output.data_ptr(), out.data_ptr(),
+                                     sample.numel(), float(dt), _DT[sample.dtype], _stream())
+    _l.check(rc, "euler_step")
+    return out

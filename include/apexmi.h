@@ -1,0 +1,181 @@
+/*
+ * apexmi.h — C-ABI of libapex_mi355.so, the MI355X (gfx950) denoise hot path for
+ * Apex Studio's render pipeline.
+ *
+ * Plain pointers, sizes and strides only: no torch types, no allocation inside the
+ * library (callers pass outputs and workspace), every entry point enqueues on the
+ * hipStream_t it is handed and returns without a host sync.  Return value: 0 = ok,
+ * non-zero = error (apexmi_last_error() gives the text; the Python shim raises
+ * RuntimeError with it, mirroring how exceptions propagate through
+ * engine.run -> _run_engine_from_manifest_impl in the reference,
+ * apps/api/src/api/ray_tasks.py:2677).
+ *
+ * Each entry point cites the reference interface (apps/api/src/...) it replaces.
+ * All device pointers are bf16 (uint16 storage) unless stated; "f32" = float.
+ */
+#ifndef APEXMI_H
+#define APEXMI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* apexmi_stream_t; /* a hipStream_t; NULL = the null stream */
+
+/* dtype codes (apexmi_attn_fwd generic path) */
+#define APEXMI_BF16 0
+#define APEXMI_F16 1
+#define APEXMI_F32 2
+
+/* GEMM epilogues */
+#define APEXMI_EPI_BIAS 0          /* C = A W^T + b                                   */
+#define APEXMI_EPI_BIAS_GELU 1     /* C = gelu_tanh(A W^T + b)                        */
+#define APEXMI_EPI_BIAS_GATE_RES 2 /* C = R + gate[n] * (A W^T + b)   (R may alias C) */
+
+/* GEMV flags */
+#define APEXMI_GEMV_PRE_SILU 1   /* x <- silu(x) before the dot product           */
+#define APEXMI_GEMV_POST_SILU 2  /* y <- silu(y)                                  */
+#define APEXMI_GEMV_POST_GELU 4  /* y <- gelu_tanh(y)                             */
+#define APEXMI_GEMV_ACCUM 8      /* y <- y_in + result                            */
+
+/* qk_norm_rope modes */
+#define APEXMI_ROPE_INTERLEAVED 0 /* pairs (2i,2i+1), cos/sin f32 [S, D] repeat-interleaved:
+                                     diffusers apply_rotary_emb(use_real=True, unbind_dim=-1),
+                                     called at transformer/flux/base/attention.py:86-87 */
+#define APEXMI_ROPE_COMPLEX 1     /* pairs (2i,2i+1) times complex table f32 [S, D/2, 2]:
+                                     apply_rotary_emb_qwen(use_real=False),
+                                     transformer/qwenimage/base/model.py:100-151;
+                                     wan rope, transformer/efficiency/ops.py:112-160 */
+#define APEXMI_ROPE_NONE 2
+
+int apexmi_version(void);
+const char* apexmi_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention operator.  Replaces the callable registered in attention_register
+ * (apps/api/src/attention/functions.py:84; default "sdpa" :338-377):
+ *     fn(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, softmax_scale=None)
+ * with q:[B,H,Sq,D], k,v:[B,H,Sk,D] possibly permuted views, result [B,H,Sq,D].
+ * Strides are in ELEMENTS for (b, h, s); the D axis must be contiguous.
+ * out is written as [B,Sq,H,D] with the given strides (so the caller can hand the
+ * flux/wan processors the `.permute(0,2,1,3)` view they expect without a copy).
+ * No mask, no dropout, non-causal (all hot-path call sites: SURVEY.md §2.4).
+ * workspace: at least apexmi_attn_workspace_bytes(...) bytes of device memory
+ * (holds V^T for the MFMA path); may be NULL when that returns 0.
+ * ------------------------------------------------------------------------------------------- */
+size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype);
+int apexmi_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                    int B, int H, int Sq, int Sk, int D,
+                    const int64_t q_strides[3], const int64_t k_strides[3],
+                    const int64_t v_strides[3], const int64_t o_strides[3],
+                    float softmax_scale, int dtype,
+                    void* workspace, size_t workspace_bytes, apexmi_stream_t stream);
+
+/* MFMA flash-attention forward on prepared operands (bf16, D = 128):
+ *   q  [B,H,Sq,128]  k [B,H,Sk,128]  vt [B,H,128,Skp]  (Skp = Sk rounded up to 64, zero padded)
+ *   out[B,Sq,H,128] with element strides o_strides (b, s, h).
+ * Same arithmetic as apexmi_attn_fwd; this is what the fused model path calls. */
+int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void* out,
+                             int B, int H, int Sq, int Sk, int Skp,
+                             const int64_t o_strides[3], float softmax_scale,
+                             apexmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear layers.  Replace torch.nn.Linear on the denoise path
+ * (to_q/to_k/to_v/to_out, ff.net.0.proj/net.2, proj_mlp/proj_out:
+ *  transformer/flux/base/model.py:106-129,180-182,258-263; wan model.py:551-712).
+ * C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N]);  A,W,C,R bf16 row-major with leading
+ * dimensions lda/ldw/ldc/ldr (elements); bias bf16 [N] or NULL; gate f32 [N].
+ * Requires K % 64 == 0 and 16-byte aligned rows.
+ * ------------------------------------------------------------------------------------------- */
+int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                     void* C, int64_t ldc, int M, int N, int K, int epilogue,
+                     const float* gate, const void* R, int64_t ldr, apexmi_stream_t stream);
+
+/* y[m, n] = post( dot(W[n, :], pre(x[m, :])) + bias[n] ) for tiny M (conditioning vectors:
+ * time_text_embed, norm*.linear AdaLN projections — diffusers layers restated in
+ * SURVEY.md App. A; call sites flux model.py:179,242-243,430-437,464).
+ * W bf16 [N,K] (ldw), bias bf16 [N] or NULL, x f32 [M,K], y f32 [M,N] (ldy). M <= 8. */
+int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const float* x, int64_t ldx,
+                float* y, int64_t ldy, int M, int N, int K, int flags, apexmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdaLN family: out = LayerNorm(x; eps, no affine) * (1 + scale[c]) + shift[c]
+ * (AdaLayerNormZero/Single/Continuous and `norm2 * (1+scale) + shift`,
+ *  flux model.py:273-279,299-302,647; wan model.py:56-116 `_chunked_modulated_norm`).
+ * x,out bf16 [M,C] (ldx/ldo); scale,shift f32 [C] or NULL (=> plain LayerNorm);
+ * gamma,beta bf16 [C] or NULL (affine FP32LayerNorm, wan norm2). stats in f32.
+ * rms != 0 selects RMSNorm (x * rsqrt(mean(x^2)+eps) * gamma) instead
+ * (InplaceRMSNorm, transformer/efficiency/mod.py:24-35 intended semantics; qwen txt_norm).
+ * ------------------------------------------------------------------------------------------- */
+int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                       const float* scale, const float* shift, const void* gamma,
+                       const void* beta, float eps, int rms, apexmi_stream_t stream);
+
+/* Per-head RMSNorm on q,k + rotary embedding, written in attention layout, and V transposed.
+ * Replaces the unflatten / norm_q / norm_k / cat / apply_rotary_emb / permute chain of
+ * FluxAttnProcessor.__call__ (transformer/flux/base/attention.py:62-94).
+ *   q,k,v : bf16 [S, H*D] row pointers with row stride ld_in (elements) each (a fused
+ *           [S, 3*H*D] projection output passes three offsets into one buffer)
+ *   wq,wk : bf16 [D] RMSNorm weights used for rows >= split;  wq2,wk2 for rows < split
+ *           (the text stream's norm_added_q/k; pass split = 0 to use only wq,wk). NULL = no norm.
+ *   rope  : f32 table, layout per rope_mode, indexed by row s
+ *   qo,ko : bf16 [H, S_out, D] at row offset row0 (so two streams can fill one joint buffer)
+ *   vt    : bf16 [H, D, Skp]   (column s + row0)
+ * D must be 128. */
+int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_in,
+                       int S, int H, int D, int split,
+                       const void* wq, const void* wk, const void* wq2, const void* wk2,
+                       float eps, const float* rope, int rope_mode,
+                       void* qo, void* ko, void* vt, int S_out, int Skp, int row0,
+                       apexmi_stream_t stream);
+
+/* V^T only: v bf16 [S, H*D] (row stride ld, head stride D) -> vt [H, D, Skp] at column row0.
+ * Generic strides (elements): v_strides = (h, s). */
+int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H, int D,
+                       void* vt, int Skp, int row0, apexmi_stream_t stream);
+
+/* Sinusoidal timestep embedding (diffusers Timesteps(num_channels, flip_sin_to_cos=True,
+ * downscale_freq_shift=0, scale); in-tree copy transformer/qwenimage/base/model.py:46-97).
+ * t f32 [M] (device), out f32 [M, dim]. */
+int apexmi_timestep_embedding(const float* t, float* out, int M, int dim, float scale,
+                              int flip_sin_to_cos, float downscale_freq_shift,
+                              apexmi_stream_t stream);
+
+/* Rotary table for multi-axis positions (FluxPosEmbed.forward, flux model.py:338-359, i.e.
+ * diffusers get_1d_rotary_pos_embed(use_real=True, repeat_interleave_real=True, freqs_dtype=f64)
+ * per axis, concatenated): ids f32 [S, n_axes] (device), axes_dim host ints (sum = D),
+ * out f32 [2, S, D] = cos plane then sin plane (the APEXMI_ROPE_INTERLEAVED layout).
+ * Angles are computed in f64 like the reference. */
+int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const int* axes_dim, float theta,
+                           float* out, apexmi_stream_t stream);
+
+/* f32 <-> bf16 helpers for the small conditioning vectors. */
+int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);
+int apexmi_cast_bf16_to_f32(const void* x, float* out, int64_t n, apexmi_stream_t stream);
+
+/* Scheduler step on device (the loop stays in Python; this is the per-step axpy of
+ * FlowMatchEulerDiscreteScheduler.step: prev = sample + dt * model_output in f32,
+ * cast back).  sample/out: bf16 or f32 per sample_dtype; v bf16. */
+int apexmi_euler_step(const void* sample, const void* model_out, void* out, int64_t n,
+                      float dt, int sample_dtype, apexmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Built-in kernel timer (HIP events on the launch stream) used by bench.py's roofline leg.
+ * classes: 0 gemm, 1 attention, 2 gemv, 3 ln_modulate, 4 qkv_prepare, 5 other.
+ * ------------------------------------------------------------------------------------------- */
+#define APEXMI_NCLASS 6
+int apexmi_prof_enable(int on);
+/* Synchronises, then fills ms[c] = summed kernel time, launches[c], flops[c], bytes[c]
+ * (algorithmic) per class since the last reset. */
+int apexmi_prof_read(double ms[APEXMI_NCLASS], int64_t launches[APEXMI_NCLASS],
+                     double flops[APEXMI_NCLASS], double bytes[APEXMI_NCLASS]);
+int apexmi_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APEXMI_H */
