@@ -1,0 +1,420 @@
+"""FluxTransformer2DModel on the MI355X HIP ops — drop-in for registry key "flux.base".
+
+Mirrors the interface of the reference class (apps/api/src/transformer/flux/base/model.py:362-657):
+same constructor config, same state-dict keys (transformer_blocks.N.attn.to_q.weight, ...), same
+keyword forward returning a 1-tuple when return_dict=False, `.config` with attribute/`.get`
+access, `.dtype`/`.device`, `cache_context(name)`, `from_config`.  Underneath, a denoise step is
+a fixed sequence of libapex_mi355.so kernels over one joint [S_txt + S_img, dim] residual buffer
+(text rows first), so none of the reference's torch.cat / split / permute copies exist:
+
+  per step      : timestep/guidance/pooled embeds (gemv) -> ONE batched gemv for every block's AdaLN
+                  modulation vectors -> rope table
+  double block  : ln_modulate x2 -> QKV gemm x2 (img / txt weights, one joint output)
+                  -> qkv_prepare (per-head RMSNorm + RoPE + V^T) -> attention
+                  -> out-proj gemm x2 with fused gate*y + residual -> ln_modulate x2
+                  -> MLP-up gemm (+GELU) x2 -> MLP-down gemm x2 with fused gate + residual
+  single block  : ln_modulate -> QKV gemm + MLP gemm(+GELU) into the concat buffer -> qkv_prepare
+                  -> attention (writes into the concat buffer) -> 15360->3072 gemm with fused
+                  gate + residual
+
+Weights are packed once after loading (fused QKV, all modulation projections in one matrix) and the
+original nn.Parameters are re-pointed at views of the packed storage, so state_dict()/load_state_dict
+keep working and memory is not doubled.
+"""
+from __future__ import annotations
+
+import contextlib
+from types import SimpleNamespace
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import lib as _l
+from . import ops
+
+
+class _Config(SimpleNamespace):
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    def __contains__(self, key):
+        return hasattr(self, key)
+
+
+class _Linear(nn.Module):
+    """Parameter holder with nn.Linear's names/shapes (weight [out,in], bias [out])."""
+
+    def __init__(self, in_features: int, out_features: int, device=None, dtype=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, device=device, dtype=dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Norm(nn.Module):
+    def __init__(self, dim: int, device=None, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype), requires_grad=False)
+
+
+class _AdaNorm(nn.Module):
+    def __init__(self, dim: int, mult: int, cond_dim: Optional[int] = None, **kw):
+        super().__init__()
+        self.linear = _Linear(cond_dim or dim, mult * dim, **kw)
+
+
+class _FF(nn.Module):
+    def __init__(self, dim: int, inner: int, **kw):
+        super().__init__()
+        proj = nn.Module()
+        proj.proj = _Linear(dim, inner, **kw)
+        self.net = nn.ModuleList([proj, nn.Identity(), _Linear(inner, dim, **kw)])
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim: int, heads: int, head_dim: int, joint: bool, pre_only: bool, **kw):
+        super().__init__()
+        inner = heads * head_dim
+        self.heads, self.head_dim = heads, head_dim
+        self.norm_q, self.norm_k = _Norm(head_dim, **kw), _Norm(head_dim, **kw)
+        self.to_q, self.to_k, self.to_v = (_Linear(dim, inner, **kw), _Linear(dim, inner, **kw),
+                                           _Linear(dim, inner, **kw))
+        if not pre_only:
+            self.to_out = nn.ModuleList([_Linear(inner, dim, **kw), nn.Identity()])
+        if joint:
+            self.norm_added_q, self.norm_added_k = _Norm(head_dim, **kw), _Norm(head_dim, **kw)
+            self.add_q_proj, self.add_k_proj, self.add_v_proj = (
+                _Linear(dim, inner, **kw), _Linear(dim, inner, **kw), _Linear(dim, inner, **kw))
+            self.to_add_out = _Linear(inner, dim, **kw)
+
+
+class _DoubleBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, head_dim: int, **kw):
+        super().__init__()
+        self.norm1 = _AdaNorm(dim, 6, **kw)
+        self.norm1_context = _AdaNorm(dim, 6, **kw)
+        self.attn = _Attn(dim, heads, head_dim, joint=True, pre_only=False, **kw)
+        self.ff = _FF(dim, 4 * dim, **kw)
+        self.ff_context = _FF(dim, 4 * dim, **kw)
+
+
+class _SingleBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, head_dim: int, mlp_ratio: float = 4.0, **kw):
+        super().__init__()
+        self.mlp_hidden_dim = int(dim * mlp_ratio)
+        self.norm = _AdaNorm(dim, 3, **kw)
+        self.proj_mlp = _Linear(dim, self.mlp_hidden_dim, **kw)
+        self.proj_out = _Linear(dim + self.mlp_hidden_dim, dim, **kw)
+        self.attn = _Attn(dim, heads, head_dim, joint=False, pre_only=True, **kw)
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim: int, dim: int, **kw):
+        super().__init__()
+        self.linear_1 = _Linear(in_dim, dim, **kw)
+        self.linear_2 = _Linear(dim, dim, **kw)
+
+
+class _TimeTextEmbed(nn.Module):
+    def __init__(self, dim: int, pooled_dim: int, guidance: bool, **kw):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbedding(256, dim, **kw)
+        if guidance:
+            self.guidance_embedder = _TimestepEmbedding(256, dim, **kw)
+        self.text_embedder = _TimestepEmbedding(pooled_dim, dim, **kw)
+
+
+def _repoint(params, packed_rows):
+    """Copy each parameter into its slice of `packed_rows` and make the parameter a view of it."""
+    r = 0
+    for p in params:
+        n = p.shape[0]
+        dst = packed_rows[r:r + n]
+        dst.copy_(p.data)
+        p.data = dst
+        r += n
+    assert r == packed_rows.shape[0]
+
+
+class FluxTransformer2DModel(nn.Module):
+    _supports_gradient_checkpointing = False
+    _no_split_modules = ["_DoubleBlock", "_SingleBlock"]
+
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, out_channels: Optional[int] = None,
+                 num_layers: int = 19, num_single_layers: int = 38, attention_head_dim: int = 128,
+                 num_attention_heads: int = 24, joint_attention_dim: int = 4096,
+                 pooled_projection_dim: int = 768, guidance_embeds: bool = False,
+                 axes_dims_rope: Tuple[int, int, int] = (16, 56, 56), device=None,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if attention_head_dim != 128:
+            raise _l.ApexMIError("flux.mi355: attention_head_dim must be 128 (MFMA attention tile)")
+        self.config = _Config(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
+                              num_layers=num_layers, num_single_layers=num_single_layers,
+                              attention_head_dim=attention_head_dim,
+                              num_attention_heads=num_attention_heads,
+                              joint_attention_dim=joint_attention_dim,
+                              pooled_projection_dim=pooled_projection_dim,
+                              guidance_embeds=guidance_embeds, axes_dims_rope=tuple(axes_dims_rope))
+        kw = dict(device=device, dtype=dtype)
+        self.out_channels = out_channels or in_channels
+        self.inner_dim = dim = num_attention_heads * attention_head_dim
+        self.time_text_embed = _TimeTextEmbed(dim, pooled_projection_dim, guidance_embeds, **kw)
+        self.context_embedder = _Linear(joint_attention_dim, dim, **kw)
+        self.x_embedder = _Linear(in_channels, dim, **kw)
+        self.transformer_blocks = nn.ModuleList(
+            [_DoubleBlock(dim, num_attention_heads, attention_head_dim, **kw) for _ in range(num_layers)])
+        self.single_transformer_blocks = nn.ModuleList(
+            [_SingleBlock(dim, num_attention_heads, attention_head_dim, **kw)
+             for _ in range(num_single_layers)])
+        self.norm_out = _AdaNorm(dim, 2, **kw)
+        self.proj_out = _Linear(dim, patch_size * patch_size * self.out_channels, **kw)
+        self._packed = False
+        self._ws: Dict[Any, Any] = {}
+
+    # ---- reference-compatible plumbing -------------------------------------------------------
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = dict(config) if isinstance(config, dict) else dict(vars(config))
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    _from_config = from_config
+
+    @property
+    def dtype(self):
+        return self.x_embedder.weight.dtype
+
+    @property
+    def device(self):
+        return self.x_embedder.weight.device
+
+    @contextlib.contextmanager
+    def cache_context(self, name: str):
+        yield
+
+    def _apply(self, fn, *a, **k):
+        self._packed = False
+        self._ws = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = False
+        return super().load_state_dict(*a, **k)
+
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 0, std: float = 0.02):
+        """N(0, std^2) weights, unit norm weights, small biases (SURVEY.md §8d synthetic inputs)."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or \
+                    name.endswith("norm_added_q.weight") or name.endswith("norm_added_k.weight"):
+                p.data.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.data.copy_((torch.randn(p.shape, generator=g, device=p.device) * 0.01).to(p.dtype))
+            else:
+                # chunked to keep the f32 temporary small for the 12B-parameter model
+                flat = p.data.view(-1)
+                step = 1 << 26
+                for i in range(0, flat.numel(), step):
+                    n = min(step, flat.numel() - i)
+                    flat[i:i + n] = (torch.randn(n, generator=g, device=p.device) * std).to(p.dtype)
+        self._packed = False
+        return self
+
+    # ---- weight packing ----------------------------------------------------------------------
+    @torch.no_grad()
+    def pack(self):
+        if self._packed:
+            return
+        dev, dt = self.device, self.dtype
+        if dev.type != "cuda" or dt != torch.bfloat16:
+            raise _l.ApexMIError(f"flux.mi355 needs bf16 weights on a ROCm device (got {dt} on {dev}); "
+                                 "there is no CPU fallback")
+        dim = self.inner_dim
+        mods_w, mods_b = [], []
+        self._mod_off = {}
+        off = 0
+
+        def reg(key, lin):
+            nonlocal off
+            mods_w.append(lin.weight)
+            mods_b.append(lin.bias)
+            self._mod_off[key] = off
+            off += lin.weight.shape[0]
+
+        for i, blk in enumerate(self.transformer_blocks):
+            a = blk.attn
+            blk._wqkv = torch.empty(3 * dim, dim, device=dev, dtype=dt)
+            blk._bqkv = torch.empty(3 * dim, device=dev, dtype=dt)
+            _repoint([a.to_q.weight, a.to_k.weight, a.to_v.weight], blk._wqkv)
+            _repoint([a.to_q.bias, a.to_k.bias, a.to_v.bias], blk._bqkv)
+            blk._wqkv_c = torch.empty(3 * dim, dim, device=dev, dtype=dt)
+            blk._bqkv_c = torch.empty(3 * dim, device=dev, dtype=dt)
+            _repoint([a.add_q_proj.weight, a.add_k_proj.weight, a.add_v_proj.weight], blk._wqkv_c)
+            _repoint([a.add_q_proj.bias, a.add_k_proj.bias, a.add_v_proj.bias], blk._bqkv_c)
+            reg(("d", i, "img"), blk.norm1.linear)
+            reg(("d", i, "txt"), blk.norm1_context.linear)
+        for i, blk in enumerate(self.single_transformer_blocks):
+            a = blk.attn
+            blk._wqkv = torch.empty(3 * dim, dim, device=dev, dtype=dt)
+            blk._bqkv = torch.empty(3 * dim, device=dev, dtype=dt)
+            _repoint([a.to_q.weight, a.to_k.weight, a.to_v.weight], blk._wqkv)
+            _repoint([a.to_q.bias, a.to_k.bias, a.to_v.bias], blk._bqkv)
+            reg(("s", i), blk.norm.linear)
+        reg(("out",), self.norm_out.linear)
+        self._mod_w = torch.empty(off, dim, device=dev, dtype=dt)
+        self._mod_b = torch.empty(off, device=dev, dtype=dt)
+        _repoint(mods_w, self._mod_w)
+        _repoint(mods_b, self._mod_b)
+        self._mod_total = off
+        self._packed = True
+
+    def _workspace(self, s_txt: int, s_img: int):
+        key = (s_txt, s_img)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, dim = self.device, self.inner_dim
+        H = self.config.num_attention_heads
+        S = s_txt + s_img
+        skp = (S + 63) // 64 * 64
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        mlp = 4 * dim
+        ws = SimpleNamespace(
+            X=torch.empty(S, dim, **bf), XN=torch.empty(S, dim, **bf), QKV=torch.empty(S, 3 * dim, **bf),
+            Q=torch.empty(1, H, S, 128, **bf), K=torch.empty(1, H, S, 128, **bf),
+            VT=torch.zeros(1, H, 128, skp, **bf), CAT=torch.empty(S, dim + mlp, **bf),
+            FFH=torch.empty(S, mlp, **bf), MOD=torch.empty(1, self._mod_total, **f32),
+            TEMB=torch.empty(1, dim, **f32), OUT=torch.empty(s_img, self.proj_out.out_features, **bf),
+        )
+        self._ws = {key: ws}  # one shape resident at a time
+        return ws
+
+    # ---- the denoise step --------------------------------------------------------------------
+    def _mod(self, ws, key, idx):
+        off = self._mod_off[key] + idx * self.inner_dim
+        return ws.MOD[0, off:off + self.inner_dim]
+
+    def _embed_t(self, emb: _TimestepEmbedding, proj: torch.Tensor, out: torch.Tensor, accum: bool):
+        h = ops.gemv(emb.linear_1.weight, proj, emb.linear_1.bias, post="silu")
+        ops.gemv(emb.linear_2.weight, h, emb.linear_2.bias, out=out, accum=accum)
+
+    @torch.no_grad()
+    def _forward_one(self, hidden_states, encoder_hidden_states, pooled, timestep, img_ids, txt_ids,
+                     guidance):
+        cfg = self.config
+        dim, H = self.inner_dim, cfg.num_attention_heads
+        s_img, s_txt = hidden_states.shape[0], encoder_hidden_states.shape[0]
+        S = s_txt + s_img
+        ws = self._workspace(s_txt, s_img)
+        X, XN, QKV, CAT, FFH = ws.X, ws.XN, ws.QKV, ws.CAT, ws.FFH
+        Xt, Xi = X[:s_txt], X[s_txt:]
+        XNt, XNi = XN[:s_txt], XN[s_txt:]
+
+        ops.gemm(hidden_states, self.x_embedder.weight, self.x_embedder.bias, out=Xi)
+        ops.gemm(encoder_hidden_states, self.context_embedder.weight, self.context_embedder.bias, out=Xt)
+
+        # conditioning vector (f32): timestep.to(dtype) * 1000 as the reference does (model.py:535)
+        tte = self.time_text_embed
+        t = (timestep.to(self.dtype) * 1000).float().reshape(1)
+        self._embed_t(tte.timestep_embedder, ops.timestep_embedding(t, 256), ws.TEMB, accum=False)
+        if cfg.guidance_embeds:
+            if guidance is None:
+                raise ValueError("guidance_embeds=True model called without `guidance`")
+            g = (guidance.to(self.dtype) * 1000).float().reshape(1)
+            self._embed_t(tte.guidance_embedder, ops.timestep_embedding(g, 256), ws.TEMB, accum=True)
+        self._embed_t(tte.text_embedder, pooled.float().reshape(1, -1), ws.TEMB, accum=True)
+        # every AdaLN projection of every block in one weight-streaming pass
+        ops.gemv(self._mod_w, ws.TEMB, self._mod_b, out=ws.MOD, pre_silu=True)
+
+        ids = torch.cat((txt_ids, img_ids), dim=0).float()
+        rope = ops.rope_table_axes(ids, cfg.axes_dims_rope, 10000.0)
+
+        q_in, k_in, v_in = QKV[:, :dim], QKV[:, dim:2 * dim], QKV[:, 2 * dim:]
+        Qp, Kp, VT = ws.Q, ws.K, ws.VT
+        att = CAT[:, :dim]
+        att_v = att.unflatten(-1, (H, 128)).unsqueeze(0)  # [1, S, H, 128] strided view
+
+        for i, blk in enumerate(self.transformer_blocks):
+            a = blk.attn
+            mi = lambda j: self._mod(ws, ("d", i, "img"), j)  # noqa: E731
+            mt = lambda j: self._mod(ws, ("d", i, "txt"), j)  # noqa: E731
+            # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+            ops.ln_modulate(Xi, mi(1), mi(0), out=XNi)
+            ops.ln_modulate(Xt, mt(1), mt(0), out=XNt)
+            ops.gemm(XNi, blk._wqkv, blk._bqkv, out=QKV[s_txt:])
+            ops.gemm(XNt, blk._wqkv_c, blk._bqkv_c, out=QKV[:s_txt])
+            ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
+                            wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
+                            split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
+            ops.attention_prepared(Qp, Kp, VT, att_v, S)
+            ops.gemm(att[s_txt:], a.to_out[0].weight, a.to_out[0].bias, out=Xi, epilogue="gate_res",
+                     gate=mi(2), residual=Xi)
+            ops.gemm(att[:s_txt], a.to_add_out.weight, a.to_add_out.bias, out=Xt, epilogue="gate_res",
+                     gate=mt(2), residual=Xt)
+            ops.ln_modulate(Xi, mi(4), mi(3), out=XNi)
+            ops.ln_modulate(Xt, mt(4), mt(3), out=XNt)
+            ff, ffc = blk.ff.net, blk.ff_context.net
+            ops.gemm(XNi, ff[0].proj.weight, ff[0].proj.bias, out=FFH[s_txt:], epilogue="gelu")
+            ops.gemm(XNt, ffc[0].proj.weight, ffc[0].proj.bias, out=FFH[:s_txt], epilogue="gelu")
+            ops.gemm(FFH[s_txt:], ff[2].weight, ff[2].bias, out=Xi, epilogue="gate_res", gate=mi(5),
+                     residual=Xi)
+            ops.gemm(FFH[:s_txt], ffc[2].weight, ffc[2].bias, out=Xt, epilogue="gate_res", gate=mt(5),
+                     residual=Xt)
+
+        for i, blk in enumerate(self.single_transformer_blocks):
+            a = blk.attn
+            ms = lambda j: self._mod(ws, ("s", i), j)  # noqa: E731  (shift, scale, gate)
+            ops.ln_modulate(X, ms(1), ms(0), out=XN)
+            ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
+            ops.gemm(XN, blk.proj_mlp.weight, blk.proj_mlp.bias, out=CAT[:, dim:], epilogue="gelu")
+            ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
+                            wk=a.norm_k.weight, split=0, eps=1e-6, rope=rope,
+                            rope_mode=_l.ROPE_INTERLEAVED)
+            ops.attention_prepared(Qp, Kp, VT, att_v, S)
+            ops.gemm(CAT, blk.proj_out.weight, blk.proj_out.bias, out=X, epilogue="gate_res", gate=ms(2),
+                     residual=X)
+
+        # AdaLayerNormContinuous: scale first, then shift
+        ops.ln_modulate(Xi, self._mod(ws, ("out",), 0), self._mod(ws, ("out",), 1), out=XNi)
+        out = torch.empty(s_img, self.proj_out.out_features, device=X.device, dtype=torch.bfloat16)
+        ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias, out=out)
+        return out
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None,
+                img_ids: torch.Tensor = None, txt_ids: torch.Tensor = None,
+                guidance: torch.Tensor = None, joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+                controlnet_block_samples=None, controlnet_single_block_samples=None,
+                return_dict: bool = True, controlnet_blocks_repeat: bool = False):
+        if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
+            raise NotImplementedError("flux.mi355: controlnet residuals are outside the hot-path scope")
+        if joint_attention_kwargs and "ip_adapter_image_embeds" in joint_attention_kwargs:
+            raise NotImplementedError("flux.mi355: IP-adapter is outside the hot-path scope")
+        self.pack()
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        B = hidden_states.shape[0]
+        hs = hidden_states.to(torch.bfloat16)
+        enc = encoder_hidden_states.to(torch.bfloat16)
+        outs = []
+        for b in range(B):
+            outs.append(self._forward_one(
+                hs[b].contiguous(), enc[b].contiguous(), pooled_projections[b], timestep[b:b + 1],
+                img_ids, txt_ids, None if guidance is None else guidance[b:b + 1]))
+        out = torch.stack(outs, dim=0).to(hidden_states.dtype)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)

@@ -1,0 +1,105 @@
+"""One-clip-per-GPU render queue over an 8x MI355X node.
+
+The reference's only multi-GPU mechanism is data parallelism over JOBS: one long-lived engine-runner
+actor per GPU fed from a FIFO, GPU picked by free VRAM (apps/api/src/api/ray_tasks.py:181-306,
+ray_resources.py:81-111, settings.py:8 MAX_JOBS_PER_GPU=1).  Here that is one process per GPU under
+torch.distributed (backend "nccl" = RCCL over xGMI), a deterministic longest-processing-time
+assignment of clips to ranks, and exactly ONE exchange step: a broadcast of the weights every clip
+shares (text encoders, VAE) and of shared prompt embeddings at queue start.  No collective inside a
+denoise step.
+
+xGMI is point-to-point (7 links per GPU), so a root->all broadcast of a large buffer is done as
+scatter (root sends 1/N to each peer over its own link) + all-gather (full mesh), which keeps every
+link busy instead of funnelling N-1 full copies through ring hops.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def _sync(t: torch.Tensor):
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
+def broadcast_shared(tensors: Sequence[torch.Tensor], src: int = 0, group=None,
+                     big_bytes: int = 8 << 20) -> Dict[str, float]:
+    """In-place broadcast of `tensors` from rank `src`.  Large contiguous tensors go
+    scatter + all-gather, small ones a plain broadcast.  Returns bytes / seconds / GB/s."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {"bytes": 0, "seconds": 0.0, "gbps": 0.0, "world": 1}
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nbytes = 0
+    if tensors:
+        _sync(tensors[0])
+    t0 = time.perf_counter()
+    for t in tensors:
+        assert t.is_contiguous(), "broadcast_shared needs contiguous tensors"
+        n = t.numel() * t.element_size()
+        nbytes += n
+        flat = t.view(-1).view(torch.uint8)
+        if n < big_bytes or n % world != 0:
+            dist.broadcast(flat, src=src, group=group)
+            continue
+        chunk = n // world
+        mine = torch.empty(chunk, dtype=torch.uint8, device=t.device)
+        if rank == src:
+            dist.scatter(mine, scatter_list=list(flat.split(chunk)), src=src, group=group)
+        else:
+            dist.scatter(mine, scatter_list=None, src=src, group=group)
+        dist.all_gather_into_tensor(flat, mine, group=group)
+    if tensors:
+        _sync(tensors[0])
+    dt = time.perf_counter() - t0
+    return {"bytes": nbytes, "seconds": dt, "gbps": (nbytes / dt / 1e9) if dt > 0 else 0.0, "world": world}
+
+
+def assign_clips(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of clip indices to ranks; deterministic, identical on
+    every rank (ties broken by index).  Puts the long (video) clips on distinct GPUs first, which is
+    what bounds the makespan of a mixed image/video queue."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return out
+
+
+def run_queue(clips: Sequence[dict], runner: Callable[[dict], object], costs: Sequence[float] = None,
+              group=None) -> Dict[str, object]:
+    """Each rank renders the clips assigned to it with `runner(clip)`; returns (on every rank) the
+    per-clip seconds, the per-rank busy time and the makespan."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    costs = list(costs) if costs is not None else [float(c.get("cost", 1.0)) for c in clips]
+    mine = assign_clips(costs, world)[rank]
+    if dist.is_initialized():
+        dist.barrier(group=group)
+    t_start = time.perf_counter()
+    times = {}
+    for i in mine:
+        t0 = time.perf_counter()
+        runner(clips[i])
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        times[i] = time.perf_counter() - t0
+    busy = time.perf_counter() - t_start
+    if dist.is_initialized():
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "times": times, "busy": busy}, group=group)
+    else:
+        gathered = [{"rank": 0, "times": times, "busy": busy}]
+    clip_seconds = {}
+    for g in gathered:
+        clip_seconds.update(g["times"])
+    makespan = max(g["busy"] for g in gathered)
+    return {"clip_seconds": clip_seconds, "busy": [g["busy"] for g in gathered], "makespan": makespan,
+            "clips_per_hour": 3600.0 * len(clips) / makespan if makespan > 0 else 0.0}

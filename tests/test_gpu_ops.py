@@ -1,0 +1,325 @@
+"""Parity of every HIP op (called through the C-ABI via apex_studio_amd.ops) against the CPU oracle /
+a plain PyTorch fp32 reference on the same seeded inputs.  Tolerances are stated per test: outputs are
+stored in bf16 (8 bits of mantissa, ulp = 2^-8 relative), accumulation is f32."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import layers as OL
+from tests.golden.seeded import seeded
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from apex_studio_amd import ops
+    return ops
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+def _check(out, ref, rel_tol, what, ulp=2.0):
+    """rel L2 error, plus max-abs within `ulp` bf16 ulps of the largest reference magnitude."""
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    rel = _rel(out, ref)
+    mx = float((out - ref).abs().max())
+    bound = ulp * 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    assert rel < rel_tol, f"{what}: rel L2 {rel:.3e} >= {rel_tol}"
+    assert mx <= bound, f"{what}: max abs {mx:.3e} > {bound:.3e}"
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 192), (16, 64, 3072),
+                                   (4096, 3072, 64), (1000, 768, 1024)])
+def test_gemm_bias(M, N, K):
+    ops = _ops()
+    a, w, b = _bf(seeded((M, K), 1)), _bf(seeded((N, K), 2, scale=K ** -0.5)), _bf(seeded((N,), 3))
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV))
+    ref = a.float() @ w.float().T + b.float()
+    _check(out, ref, 3e-3, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_no_bias_and_asymmetric():
+    # A = identity-like selector against an asymmetric W catches operand / output transposes
+    ops = _ops()
+    M = N = 128
+    K = 128
+    a = torch.eye(M, K)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125.0
+    out = ops.gemm(_bf(a).to(DEV), _bf(w).to(DEV))
+    assert torch.equal(out.float().cpu(), _bf(w).float().T.contiguous())
+
+
+def test_gemm_gelu_epilogue():
+    ops = _ops()
+    M, N, K = 300, 512, 256
+    a, w, b = _bf(seeded((M, K), 4)), _bf(seeded((N, K), 5, scale=K ** -0.5)), _bf(seeded((N,), 6))
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue="gelu")
+    ref = torch.nn.functional.gelu(a.float() @ w.float().T + b.float(), approximate="tanh")
+    _check(out, ref, 3e-3, "gemm+gelu")
+
+
+def test_gemm_gate_residual_inplace_and_strided():
+    ops = _ops()
+    M, N, K = 260, 256, 320
+    big = _bf(seeded((M, K + 64), 7)).to(DEV)
+    a = big[:, 32:32 + K]                       # lda > K, 64-byte offset
+    assert a.stride(0) == K + 64
+    w, b = _bf(seeded((N, K), 8, scale=K ** -0.5)), _bf(seeded((N,), 9))
+    gate = seeded((N,), 10).to(DEV)
+    xbuf = _bf(seeded((M, N + 128), 11)).to(DEV)
+    x = xbuf[:, 64:64 + N]                      # strided residual/output, updated in place
+    x0 = x.float().cpu().clone()
+    ops.gemm(a, w.to(DEV), b.to(DEV), out=x, epilogue="gate_res", gate=gate, residual=x)
+    ref = x0 + gate.cpu() * (a.float().cpu() @ w.float().T + b.float())
+    _check(x, ref, 3e-3, "gemm+gate_res")
+    # columns outside the view untouched
+    assert torch.equal(xbuf[:, :64].cpu(), _bf(seeded((M, N + 128), 11))[:, :64])
+
+
+def test_gemm_flux_shapes_against_gpu_fp32():
+    ops = _ops()
+    for (M, N, K) in [(4608, 9216, 3072), (4608, 3072, 15360), (512, 12288, 3072)]:
+        a = _bf(seeded((M, K), 21)).to(DEV)
+        w = _bf(seeded((N, K), 22, scale=K ** -0.5)).to(DEV)
+        b = _bf(seeded((N,), 23)).to(DEV)
+        out = ops.gemm(a, w, b)
+        ref = a.float() @ w.float().T + b.float()
+        _check(out, ref, 3e-3, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_rejects_bad_shapes():
+    ops = _ops()
+    from apex_studio_amd.lib import ApexMIError
+    a = torch.zeros(128, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ApexMIError):
+        ops.gemm(a, a)  # K % 64 != 0
+
+
+# ------------------------------------------------------------------------------------------- GEMV
+@pytest.mark.parametrize("N,K,pre,post", [(256, 256, False, None), (3072, 256, False, "silu"),
+                                          (18432, 3072, True, None), (1000, 768, False, "gelu")])
+def test_gemv(N, K, pre, post):
+    ops = _ops()
+    w, b, x = _bf(seeded((N, K), 31, scale=K ** -0.5)), _bf(seeded((N,), 32)), seeded((1, K), 33)
+    y = ops.gemv(w.to(DEV), x.to(DEV), b.to(DEV), pre_silu=pre, post=post)
+    xi = torch.nn.functional.silu(x) if pre else x
+    ref = xi @ w.float().T + b.float()
+    if post == "silu":
+        ref = torch.nn.functional.silu(ref)
+    if post == "gelu":
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert torch.allclose(y.cpu(), ref, atol=2e-4, rtol=2e-4), float((y.cpu() - ref).abs().max())
+    y2 = ops.gemv(w.to(DEV), x.to(DEV), b.to(DEV), out=y.clone(), pre_silu=pre, post=post, accum=True)
+    assert torch.allclose(y2.cpu(), 2 * ref, atol=4e-4, rtol=4e-4)
+
+
+# ------------------------------------------------------------------------------------ LN / modulate
+@pytest.mark.parametrize("M,C", [(5, 256), (131, 3072), (64, 5120), (33, 3584)])
+def test_ln_modulate(M, C):
+    ops = _ops()
+    x = _bf(seeded((M, C), 41) * 3 + 0.5)
+    scale, shift = seeded((C,), 42) * 0.3, seeded((C,), 43) * 0.3
+    out = ops.ln_modulate(x.to(DEV), scale.to(DEV), shift.to(DEV), eps=1e-6)
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6) * (1 + scale) + shift
+    _check(out, ref, 3e-3, f"ln_modulate {M}x{C}")
+    out = ops.ln_modulate(x.to(DEV), eps=1e-6)
+    _check(out, torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6), 3e-3, "plain LN")
+    g, bt = _bf(1 + 0.1 * seeded((C,), 44)), _bf(0.1 * seeded((C,), 45))
+    out = ops.ln_modulate(x.to(DEV), gamma=g.to(DEV), beta=bt.to(DEV), eps=1e-6)
+    _check(out, torch.nn.functional.layer_norm(x.float(), (C,), g.float(), bt.float(), 1e-6), 3e-3, "affine LN")
+    out = ops.ln_modulate(x.to(DEV), gamma=g.to(DEV), eps=1e-6, rms=True)
+    n = OL.RMSNorm(C, 1e-6)
+    with torch.no_grad():
+        n.weight.copy_(g.float())
+    _check(out, n(x.float()), 3e-3, "rmsnorm")
+
+
+def test_rmsnorm_matches_reference_golden(golden_dir):
+    ops = _ops()
+    c = torch.load(os.path.join(golden_dir, "efficiency_ops.pt"), weights_only=False)["rmsnorm_bf16"]
+    x = c["x"][0]
+    out = ops.ln_modulate(x.to(DEV), gamma=_bf(c["weight"]).to(DEV), eps=c["eps"], rms=True)
+    # the reference rounds the normalisation factor to bf16 before the multiply (mod.py:31-33)
+    assert torch.allclose(out.float().cpu(), c["out"][0].float(), atol=3e-2, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------- qkv_prepare
+def _qkv_ref(qkv, H, wq, wk, wq2, wk2, split, cos, sin):
+    S = qkv.shape[0]
+    dim = H * 128
+    q, k, v = (qkv[:, i * dim:(i + 1) * dim].float().reshape(1, S, H, 128) for i in range(3))
+
+    def rn(x, w):
+        n = OL.RMSNorm(128, 1e-6)
+        with torch.no_grad():
+            n.weight.copy_(w.float())
+        return n(x)
+
+    def norm(x, w, w2):
+        if split:
+            return torch.cat([rn(x[:, :split], w2), rn(x[:, split:], w)], dim=1)
+        return rn(x, w)
+
+    q, k = norm(q, wq, wq2), norm(k, wk, wk2)
+    q = OL.apply_rotary_emb(q, (cos, sin), sequence_dim=1)
+    k = OL.apply_rotary_emb(k, (cos, sin), sequence_dim=1)
+    return q[0].permute(1, 0, 2), k[0].permute(1, 0, 2), v[0].permute(1, 2, 0)  # [H,S,D],[H,S,D],[H,D,S]
+
+
+@pytest.mark.parametrize("S,H,split", [(80, 2, 16), (200, 3, 0), (64, 24, 7)])
+def test_qkv_prepare(S, H, split):
+    ops = _ops()
+    from apex_studio_amd import lib
+    from oracle.flux import flux_pos_embed
+    dim = H * 128
+    qkv = _bf(seeded((S, 3 * dim), 51))
+    ws = [_bf(1 + 0.1 * seeded((128,), 52 + i)) for i in range(4)]
+    ids = torch.zeros(S, 3)
+    ids[:, 1] = torch.arange(S) // 8
+    ids[:, 2] = torch.arange(S) % 8
+    cos, sin = flux_pos_embed(ids, (16, 56, 56))
+    rope = ops.rope_table_axes(ids.to(DEV), (16, 56, 56))
+    assert torch.allclose(rope[0].cpu(), cos, atol=1e-6) and torch.allclose(rope[1].cpu(), sin, atol=1e-6)
+    skp = (S + 63) // 64 * 64
+    qo = torch.empty(H, S, 128, dtype=torch.bfloat16, device=DEV)
+    ko = torch.empty_like(qo)
+    vt = torch.full((H, 128, skp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    g = qkv.to(DEV)
+    ops.qkv_prepare(g[:, :dim], g[:, dim:2 * dim], g[:, 2 * dim:], H, qo, ko, vt,
+                    wq=ws[0].to(DEV), wk=ws[1].to(DEV), wq2=ws[2].to(DEV), wk2=ws[3].to(DEV),
+                    split=split, eps=1e-6, rope=rope, rope_mode=lib.ROPE_INTERLEAVED)
+    rq, rk, rvt = _qkv_ref(qkv, H, ws[0], ws[1], ws[2], ws[3], split, cos, sin)
+    _check(qo, rq, 3e-3, "q norm+rope")
+    _check(ko, rk, 3e-3, "k norm+rope")
+    assert torch.equal(vt[:, :, :S].float().cpu(), rvt), "V^T must be an exact transpose"
+    assert torch.equal(vt[:, :, S:].float().cpu(), torch.zeros(H, 128, skp - S)), "V^T pad must be zero"
+
+
+def test_rope_complex_mode_equals_interleaved():
+    ops = _ops()
+    from apex_studio_amd import lib
+    S, H = 96, 2
+    dim = H * 128
+    qkv = _bf(seeded((S, 3 * dim), 61)).to(DEV)
+    ang = seeded((S, 64), 62) * 3
+    cplx = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()          # [S, 64, 2]
+    inter = torch.stack([ang.cos().repeat_interleave(2, 1), ang.sin().repeat_interleave(2, 1)]).contiguous()
+    outs = []
+    for table, mode in ((cplx, lib.ROPE_COMPLEX), (inter, lib.ROPE_INTERLEAVED)):
+        qo = torch.empty(H, S, 128, dtype=torch.bfloat16, device=DEV)
+        ko = torch.empty_like(qo)
+        ops.qkv_prepare(qkv[:, :dim], qkv[:, dim:2 * dim], None, H, qo, ko, None, rope=table.to(DEV),
+                        rope_mode=mode)
+        outs.append((qo.clone(), ko.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# --------------------------------------------------------------------------------------- attention
+def test_attention_reference_goldens(golden_dir):
+    """reference `sdpa` outputs (attention/functions.py:338-377) on the committed seeds."""
+    ops = _ops()
+    cases = torch.load(os.path.join(golden_dir, "attention_sdpa.pt"), weights_only=False)
+    for c in cases:
+        dt = torch.float32 if "float32" in c["dtype"] else torch.bfloat16
+        q = seeded(c["q_shape"], c["seed"], dt)
+        k = seeded(c["k_shape"], c["seed"] + 100, dt)
+        v = seeded(c["k_shape"], c["seed"] + 200, dt)
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+        assert out.shape == c["out"].shape
+        if dt == torch.float32:
+            assert torch.allclose(out.cpu(), c["out"], atol=2e-5, rtol=2e-5), c["q_shape"]
+        else:
+            # bf16: P is rounded to bf16 before P V (as flash kernels do) -> ~1e-2 rel of |out|max
+            _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attn {c['q_shape']}", ulp=3.0)
+            assert torch.allclose(out.float().cpu(), c["out"].float(), atol=3e-2, rtol=3e-2)
+
+
+def test_attention_verification_probe_shape():
+    """B,H,S,D = 1,2,8,64 fp16 — the reference's backend self-test (functions.py:1999-2251)."""
+    ops = _ops()
+    q, k, v = (seeded((1, 2, 8, 64), 70 + i, torch.float16) for i in range(3))
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    ref = OL.sdpa(q.float(), k.float(), v.float())
+    assert torch.allclose(out.float().cpu(), ref, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 128, 64), (1, 3, 200, 333), (2, 2, 64, 1000), (1, 24, 1536, 1536)])
+def test_attention_mfma_vs_oracle(B, H, Sq, Sk):
+    ops = _ops()
+    q = seeded((B, H, Sq, 128), 81, torch.bfloat16)
+    k = seeded((B, H, Sk, 128), 82, torch.bfloat16)
+    v = seeded((B, H, Sk, 128), 83, torch.bfloat16)
+    # permuted [B,S,H,D]-backed views, as the flux processor passes them
+    qv = q.permute(0, 2, 1, 3).contiguous().to(DEV).permute(0, 2, 1, 3)
+    kv = k.permute(0, 2, 1, 3).contiguous().to(DEV).permute(0, 2, 1, 3)
+    vv = v.permute(0, 2, 1, 3).contiguous().to(DEV).permute(0, 2, 1, 3)
+    out = ops.attention(qv, kv, vv)
+    assert out.permute(0, 2, 1, 3).is_contiguous()
+    if Sq * Sk * H <= 4_000_000:
+        ref = OL.sdpa(q.float(), k.float(), v.float())
+    else:
+        ref = OL.sdpa(q.float().to(DEV), k.float().to(DEV), v.float().to(DEV)).cpu()
+    _check(out, ref, 1e-2, f"attention {B}x{H}x{Sq}x{Sk}", ulp=3.0)
+
+
+def test_attention_online_softmax_rescale_spike():
+    """Force the running max to jump at a late KV tile (guide §5.4 rule 26)."""
+    ops = _ops()
+    H, S = 2, 512
+    q = seeded((1, H, S, 128), 91, torch.bfloat16)
+    k = seeded((1, H, S, 128), 92, torch.bfloat16)
+    v = seeded((1, H, S, 128), 93, torch.bfloat16)
+    k[0, :, 400] = (q[0, :, 17].float() * 4).to(torch.bfloat16)  # key 400 dominates query 17
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    ref = OL.sdpa(q.float(), k.float(), v.float())
+    _check(out, ref, 1e-2, "attention spike", ulp=3.0)
+
+
+def test_attention_flux_shape_properties():
+    """Full Flux-1024 shape: linearity in V and row-stochasticity (V = 1 -> out = 1)."""
+    ops = _ops()
+    B, H, S = 1, 24, 4608
+    q = seeded((B, H, S, 128), 101, torch.bfloat16).to(DEV)
+    k = seeded((B, H, S, 128), 102, torch.bfloat16).to(DEV)
+    ones = torch.ones(B, H, S, 128, dtype=torch.bfloat16, device=DEV)
+    out = ops.attention(q, k, ones)
+    assert torch.allclose(out.float(), torch.ones_like(out.float()), atol=8e-3)
+    v = seeded((B, H, S, 128), 103, torch.bfloat16).to(DEV)
+    o1 = ops.attention(q, k, v).float()
+    o2 = ops.attention(q, k, (v.float() * 2).to(torch.bfloat16)).float()
+    assert torch.allclose(o2, 2 * o1, atol=2e-2, rtol=2e-2)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    _check(o1, ref, 1e-2, "attention flux-1024 shape", ulp=3.0)
+
+
+# ------------------------------------------------------------------------------------------- misc
+def test_timestep_embedding():
+    ops = _ops()
+    t = torch.tensor([0.0, 1.0, 718.75, 1000.0])
+    out = ops.timestep_embedding(t.to(DEV), 256)
+    ref = OL.get_timestep_embedding(t, 256, flip_sin_to_cos=True, downscale_freq_shift=0)
+    assert torch.allclose(out.cpu(), ref, atol=2e-4), float((out.cpu() - ref).abs().max())
+
+
+def test_euler_step_and_casts():
+    ops = _ops()
+    s, v = seeded((1, 4096, 64), 111), _bf(seeded((1, 4096, 64), 112))
+    out = ops.euler_step(s.to(DEV), v.to(DEV), -0.0357)
+    assert torch.allclose(out.cpu(), s + (-0.0357) * v.float(), atol=1e-6)
+    sb = _bf(s)
+    out = ops.euler_step(sb.to(DEV), v.to(DEV), -0.0357)
+    assert torch.equal(out.cpu(), (sb.float() + (-0.0357) * v.float()).to(torch.bfloat16))
+    assert torch.equal(ops.to_bf16(s.to(DEV)).cpu(), sb)
+    assert torch.equal(ops.to_f32(sb.to(DEV)).cpu(), sb.float())

@@ -1,0 +1,84 @@
+"""Pin the oracle (CPU restatement) against outputs of the REFERENCE run in the build container
+(tests/golden/*.pt, produced by tests/golden/make_golden.py).  CPU only."""
+import os
+
+import pytest
+import torch
+
+from oracle import layers as OL
+from oracle import flux as OF
+from tests.golden.seeded import seeded, synthetic_state_dict
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_sdpa_matches_reference(golden_dir):
+    cases = _load(golden_dir, "attention_sdpa.pt")
+    assert len(cases) == 8
+    for c in cases:
+        dt = torch.float32 if "float32" in c["dtype"] else torch.bfloat16
+        q = seeded(c["q_shape"], c["seed"], dt)
+        k = seeded(c["k_shape"], c["seed"] + 100, dt)
+        v = seeded(c["k_shape"], c["seed"] + 200, dt)
+        out = OL.sdpa(q, k, v)
+        ref = c["out"]
+        tol = 2e-6 if dt == torch.float32 else 8e-3  # bf16: one output ulp
+        assert out.dtype == ref.dtype
+        assert torch.allclose(out.float(), ref.float(), atol=tol, rtol=tol), c["q_shape"]
+
+
+def test_efficiency_ops_match_reference(golden_dir):
+    g = _load(golden_dir, "efficiency_ops.pt")
+    # apply_gate_inplace: x *= gate   (efficiency/ops.py:19-34)
+    c = g["gate"]
+    assert torch.equal((c["x"] * c["gate"]), c["out"])
+    # apply_scale_shift_inplace: x + x*scale + shift in bf16 (ops.py:37-56)
+    c = g["scale_shift"]
+    x = c["x"].clone()
+    x = x + x * c["scale"]
+    x = x + c["shift"]
+    assert torch.allclose(x.float(), c["out"].float(), atol=4e-2, rtol=2e-2)
+    # InplaceRMSNorm on bf16 input == intended RMSNorm semantics to bf16 rounding (App. B-2)
+    c = g["rmsnorm_bf16"]
+    n = OL.RMSNorm(256, eps=c["eps"])
+    with torch.no_grad():
+        n.weight.copy_(c["weight"])
+    y = n(c["x"])
+    assert torch.allclose(y.float(), c["out"].float(), atol=3e-2, rtol=2e-2)
+
+
+def test_flux_wiring_matches_reference_blocks(golden_dir):
+    g = _load(golden_dir, "flux_hybrid.pt")
+    model = OF.FluxTransformer2DModel(**g["config"]).eval()
+    assert sorted(model.state_dict().keys()) == g["keys"]
+    model.load_state_dict(synthetic_state_dict(model, g["seed"]), strict=True)
+    inp = g["inputs"]
+    out = model(inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"],
+                inp["timestep"], inp["img_ids"], inp["txt_ids"], inp["guidance"])
+    ref = g["out"]
+    rel = (out - ref).norm() / ref.norm()
+    assert rel < 1e-5, rel
+    assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_bf16_storage_policy_is_close_to_fp32(golden_dir):
+    g = _load(golden_dir, "flux_hybrid.pt")
+    model = OF.FluxTransformer2DModel(**g["config"]).eval()
+    model.load_state_dict(synthetic_state_dict(model, g["seed"]), strict=True)
+    inp = g["inputs"]
+    args = (inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"],
+            inp["timestep"], inp["img_ids"], inp["txt_ids"], inp["guidance"])
+    a = model(*args)
+    b = model(*args, policy=OL.BF16_STORAGE)
+    rel = (a - b).norm() / a.norm()
+    assert 0 < rel < 3e-2, rel
+
+
+def test_pack_unpack_roundtrip():
+    x = torch.arange(2 * 16 * 8 * 12, dtype=torch.float32).reshape(2, 16, 8, 12)
+    p = OF.pack_latents(x)
+    assert p.shape == (2, 4 * 6, 64)
+    assert torch.equal(OF.unpack_latents(p, 64, 96, 8), x)
+    assert abs(OF.calculate_shift(4096) - 1.15) < 1e-9 and abs(OF.calculate_shift(256) - 0.5) < 1e-9

@@ -1,0 +1,68 @@
+"""N>1 path of the render queue on CPU: world_size-2 gloo processes (RCCL is the same code path with
+backend "nccl" on the GPU box)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    big = torch.arange(1 << 22, dtype=torch.int32) if rank == 0 else torch.zeros(1 << 22, dtype=torch.int32)
+    small = torch.full((7,), 3.0) if rank == 0 else torch.zeros(7)
+    odd = torch.arange(8 * 1024 * 1024 + 1, dtype=torch.uint8) if rank == 0 else \
+        torch.zeros(8 * 1024 * 1024 + 1, dtype=torch.uint8)
+    stats = rq.broadcast_shared([big, small, odd], src=0)
+    ok = bool(torch.equal(big, torch.arange(1 << 22, dtype=torch.int32)) and
+              torch.equal(small, torch.full((7,), 3.0)) and
+              torch.equal(odd, torch.arange(8 * 1024 * 1024 + 1, dtype=torch.uint8)))
+    clips = [{"id": i, "cost": c} for i, c in enumerate([5.0, 1.0, 1.0, 5.0, 1.0])]
+    done = []
+    res = rq.run_queue(clips, lambda c: done.append(c["id"]))
+    q.put((rank, ok, stats["bytes"], sorted(done), sorted(res["clip_seconds"].keys())))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_queue_world2():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ok0, n0, done0, all0), (r1, ok1, n1, done1, all1) = out
+    assert ok0 and ok1 and n0 == n1 > 0
+    # the two 5.0-cost clips land on different ranks; every clip rendered exactly once
+    assert sorted(done0 + done1) == [0, 1, 2, 3, 4] and all0 == all1 == [0, 1, 2, 3, 4]
+    assert (0 in done0) != (3 in done0)
+
+
+def test_assign_clips_lpt():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.render_queue import assign_clips
+    # 4 video clips (cost 100) + 4 image clips (cost 2) on 8 GPUs: one clip each
+    a = assign_clips([2, 2, 2, 2, 100, 100, 100, 100], 8)
+    assert sorted(len(x) for x in a) == [1] * 8
+    # on 4 GPUs each rank gets one video + one image
+    a = assign_clips([2, 2, 2, 2, 100, 100, 100, 100], 4)
+    assert all(len(x) == 2 and sum(1 for i in x if i >= 4) == 1 for x in a)
+    assert assign_clips([], 2) == [[], []]
