@@ -74,6 +74,11 @@ def load():
             "(run `python __graft_entry__.py` or apex_studio_amd.build.build()). "
             "There is no CPU fallback for the product path."
         )
+    # torch's bundled HIP runtime must be the one in the process before this library resolves
+    # libamdhip64: the streams handed to the C-ABI are torch's, so both must share ONE runtime.
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing

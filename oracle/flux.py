@@ -159,9 +159,12 @@ class FluxTransformer2DModel(nn.Module):
                 txt_ids, guidance=None, policy: Policy = FP32):
         pol = policy
         x = pol.r(self.x_embedder(hidden_states))
-        timestep = timestep.to(hidden_states.dtype) * 1000
+        # reference: `timestep.to(hidden_states.dtype) * 1000` (model.py:535-537) — with bf16 hidden
+        # states that product is rounded to bf16; the bf16 policy reproduces it.
+        tdt = torch.bfloat16 if pol.emulate_bf16 else hidden_states.dtype
+        timestep = (timestep.to(tdt) * 1000).to(hidden_states.dtype)
         if guidance is not None:
-            guidance = guidance.to(hidden_states.dtype) * 1000
+            guidance = (guidance.to(tdt) * 1000).to(hidden_states.dtype)
             temb = self.time_text_embed(timestep, guidance, pooled_projections)
         else:
             temb = self.time_text_embed(timestep, pooled_projections)

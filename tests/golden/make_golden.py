@@ -212,7 +212,7 @@ def tiny_flux_inputs(s_img_hw=(8, 8), s_txt=16, seed=31):
         hidden_states=seeded((1, h2 * w2, cfg["in_channels"]), seed),
         encoder_hidden_states=seeded((1, s_txt, cfg["joint_attention_dim"]), seed + 1),
         pooled_projections=seeded((1, cfg["pooled_projection_dim"]), seed + 2),
-        timestep=torch.tensor([0.71875]), guidance=torch.tensor([3.5]),
+        timestep=torch.tensor([0.5]), guidance=torch.tensor([4.0]),
         img_ids=latent_image_ids(h2, w2), txt_ids=torch.zeros(s_txt, 3))
 
 

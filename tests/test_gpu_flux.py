@@ -34,7 +34,7 @@ def _inputs(cfg, hw, s_txt, seed=31):
     return dict(hidden_states=seeded((1, h2 * w2, cfg["in_channels"]), seed),
                 encoder_hidden_states=seeded((1, s_txt, cfg["joint_attention_dim"]), seed + 1),
                 pooled_projections=seeded((1, cfg["pooled_projection_dim"]), seed + 2),
-                timestep=torch.tensor([0.71875]), guidance=torch.tensor([3.5]),
+                timestep=torch.tensor([0.5]), guidance=torch.tensor([4.0]),
                 img_ids=OF.latent_image_ids(h2, w2), txt_ids=torch.zeros(s_txt, 3))
 
 
