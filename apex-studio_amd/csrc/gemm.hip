@@ -7,182 +7,336 @@
 // proj_mlp / proj_out of the single block (:180-182), x_embedder / context_embedder (:439-440),
 // and the gate * y + residual tails of FluxTransformerBlock.forward (:296-297, :305-307).
 //
-// Tiling (gfx950): 128x128x64 block tile, 256 threads = 4 waves (2 x 2), each wave a 64x64
-// sub-tile as 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Both operands are K-contiguous, so
-// the A and W tiles are staged identically with 16-byte global_load_lds into a double-buffered
-// 64 KiB LDS image; the XOR swizzle (chunk ^= row & 7) is applied on the per-lane SOURCE address
-// and again on the ds_read_b128 address (the LDS destination of an LDS-DMA is lane-linear).
-// Operands are fed swapped (MFMA "A" = W rows, "B" = activation rows) so a lane holds four
-// consecutive output columns of one row -> 8-byte epilogue accesses.
-// Block ids are remapped so each XCD owns a contiguous run of tiles, grouped 8 tiles tall.
+// One kernel template, three tilings (gfx950, v_mfma_f32_32x32x16_bf16, BK = 64):
+//   CFG_128  : 128x128 block, 4 waves (2x2), wave tile 64x64,  2 blocks/CU — small / ragged problems
+//   CFG_256  : 256x256 block, 8 waves (2x4), wave tile 128x64, 1 block/CU  — the large Flux GEMMs
+//   CFG_256P : CFG_256 with a ping-pong schedule: the K-tile is cut into 4 quadrant phases of
+//              {ds_read sub-tile | barrier | 8 MFMA | barrier}; the M-halves of the block (waves w and
+//              w+4 share a SIMD) run one barrier apart, so on every SIMD one wave is in its MFMA segment
+//              while its partner is in its LDS/DMA segment, and the next K-tile's LDS-DMA stays in
+//              flight for three phases behind a counted wait.
+// Both operands are K-contiguous, so A and W tiles are staged identically with 16-byte
+// global_load_lds into a double-buffered LDS image; the XOR swizzle (chunk ^= row & 7) is applied on
+// the per-lane SOURCE address and again on the ds_read_b128 address (an LDS-DMA destination is
+// lane-linear).  Operands are fed swapped (MFMA "A" = W rows, "B" = activation rows) so a lane holds
+// four consecutive output columns of one row -> 8-byte epilogue accesses.
+// Up to 4 problems sharing (N, K, epilogue) run in ONE launch (the img / txt streams of a double
+// block), tile ids are remapped so each XCD owns a contiguous run of tiles, grouped 8 tiles tall.
 #include "common.h"
+
+#include <cstring>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
+constexpr int MAX_GROUPS = 4;
+
+struct GemmProblem {
+    const bf16_t* A;
+    const bf16_t* W;
+    const bf16_t* bias;
+    bf16_t* C;
+    const float* gate;
+    const bf16_t* R;
+    int64_t lda, ldw, ldc, ldr;
+    int M, nm, tile0;
+};
+struct GemmGroup {
+    GemmProblem p[MAX_GROUPS];
+    int count, N, K, nn, total;
+};
+
+template <int BM_, int BN_, int WM_, int WN_, bool PP_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr bool PP = PP_;
+    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 MFMA tiles per wave
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    static constexpr int STAGE = A_BYTES + W_BYTES;
+    static constexpr int LDS = 2 * STAGE;
+    static constexpr int A_LD = BM * 8 / NT, W_LD = BN * 8 / NT;  // glds per thread per K-tile
+    static constexpr int OCC = (LDS <= 80 * 1024 && NT == 256) ? 2 : (NT == 512 ? 2 : 1);
+};
+using CFG_128 = Cfg<128, 128, 2, 2, false>;
+using CFG_256 = Cfg<256, 256, 2, 4, false>;
+using CFG_256P = Cfg<256, 256, 2, 4, true>;
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
-    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-    const bf16_t* __restrict__ bias, bf16_t* C, int64_t ldc, int M, int N, int K,
-    const float* __restrict__ gate, const bf16_t* R, int64_t ldr, int nm, int nn) {
+APEXMI_DEVICE void store_tile(const f32x16& acc, const GemmProblem& P, int N, int m, int nbase, int hi) {
+    // lane holds C[m][nbase + 8 g + 4 hi + (0..3)] for g = 0..3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = nbase + 8 * g + 4 * hi;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j];
+        if (P.bias != nullptr) {
+            const u32x2 b = *(const u32x2*)(P.bias + n);
+            v[0] += bf16_lo(b[0]);
+            v[1] += bf16_hi(b[0]);
+            v[2] += bf16_lo(b[1]);
+            v[3] += bf16_hi(b[1]);
+        }
+        if (EPI == APEXMI_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+        }
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+            const f32x4 gt = *(const f32x4*)(P.gate + n);
+            const u32x2 rr = *(const u32x2*)(P.R + (int64_t)m * P.ldr + n);
+            v[0] = bf16_lo(rr[0]) + gt[0] * v[0];
+            v[1] = bf16_hi(rr[0]) + gt[1] * v[1];
+            v[2] = bf16_lo(rr[1]) + gt[2] * v[2];
+            v[3] = bf16_hi(rr[1]) + gt[3] * v[3];
+        }
+        u32x2 o;
+        o[0] = pack_bf16(v[0], v[1]);
+        o[1] = pack_bf16(v[2], v[3]);
+        *(u32x2*)(P.C + (int64_t)m * P.ldc + n) = o;
+    }
+}
+
+template <typename CFG, int EPI>
+__global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const GemmGroup G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- tile id -> (pm, pn): XCD-contiguous, grouped GROUP_M tall ----
-    const int total = nm * nn;
-    const int s = xcd_remap(blockIdx.x, total);
+    // ---- tile id -> problem, (pm, pn): XCD-contiguous, grouped GROUP_M tall ----
+    int s = xcd_remap(blockIdx.x, G.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUPS; ++i)
+        if (i < G.count && s >= G.p[i].tile0) gi = i;
+    const GemmProblem& P = G.p[gi];
+    s -= P.tile0;
+    const int nn = G.nn, N = G.N, M = P.M;
     const int width = GROUP_M * nn;
-    const int group = s / width;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(nm - first_m, GROUP_M);
+    const int first_m = (s / width) * GROUP_M;
+    const int gsz = min(P.nm - first_m, GROUP_M);
     const int pm = first_m + (s % width) % gsz;
     const int pn = (s % width) / gsz;
     const int m0 = pm * BM, n0 = pn * BN;
 
-    // ---- per-lane staging sources (row clamped at the edges; OOB rows are never stored) ----
-    const char* a_src[4];
-    const char* w_src[4];
+    // ---- per-lane staging sources (rows clamped at the edges; OOB rows are never stored) ----
+    const char* a_src[CFG::A_LD];
+    const char* w_src[CFG::W_LD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (wave * 4 + i) * 64 + lane;  // 16-byte chunk index inside the tile image
-        const int row = p >> 3, pc = p & 7;
-        const int c = pc ^ (row & 7);
-        const int ar = min(m0 + row, M - 1);
-        const int wr = min(n0 + row, N - 1);
-        a_src[i] = (const char*)(A + (int64_t)ar * lda + c * 8);
-        w_src[i] = (const char*)(W + (int64_t)wr * ldw + c * 8);
+    for (int i = 0; i < CFG::A_LD; ++i) {
+        const int p = (i * CFG::NW + wave) * 64 + lane;  // 16-byte chunk index inside the tile image
+        const int row = p >> 3, c = (p & 7) ^ (row & 7);
+        a_src[i] = (const char*)(P.A + (int64_t)min(m0 + row, M - 1) * P.lda + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < CFG::W_LD; ++i) {
+        const int p = (i * CFG::NW + wave) * 64 + lane;
+        const int row = p >> 3, c = (p & 7) ^ (row & 7);
+        w_src[i] = (const char*)(P.W + (int64_t)min(n0 + row, N - 1) * P.ldw + c * 8);
     }
 
-    f32x16 acc[2][2];  // [nt][mt]
+    f32x16 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nkt = K / BK;
+    const int nkt = G.K / BK;
 
     auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE_BYTES + wave * 4096;
+        char* base = smem + buf * CFG::STAGE + wave * 1024;
         const int64_t koff = (int64_t)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src[i] + koff, base + i * 1024);
+        for (int i = 0; i < CFG::A_LD; ++i) glds16(a_src[i] + koff, base + i * (CFG::NW * 1024));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(w_src[i] + koff, base + TILE_BYTES + i * 1024);
+        for (int i = 0; i < CFG::W_LD; ++i)
+            glds16(w_src[i] + koff, base + CFG::A_BYTES + i * (CFG::NW * 1024));
     };
 
-    // fragment read offsets (bytes) inside a tile image, for k-step 0; k-step ks adds a chunk xor
-    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+    // fragment read offsets (bytes) inside a tile image; k-step ks selects chunk (2 ks + hi) ^ sw
+    int a_off[TM], a_sw[TM], w_off[TN], w_sw[TN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + l31;
-        const int rw = wn * 64 + t * 32 + l31;
-        a_off[t] = ra * 128;
-        a_sw[t] = ra & 7;
-        w_off[t] = rw * 128;
-        w_sw[t] = rw & 7;
+    for (int t = 0; t < TM; ++t) {
+        const int r = wm * (BM / CFG::WM) + t * 32 + l31;
+        a_off[t] = r * 128;
+        a_sw[t] = r & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int r = wn * (BN / CFG::WN) + t * 32 + l31;
+        w_off[t] = r * 128;
+        w_sw[t] = r & 7;
     }
 
-    stage(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // tile kt landed (vmcnt(0) by the compiler) and the other buffer is free
-        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-        const char* As = smem + (kt & 1) * STAGE_BYTES;
-        const char* Ws = As + TILE_BYTES;
+    if constexpr (!CFG::PP) {
+        stage(0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();  // tile kt landed (vmcnt(0) by the compiler) and the other buffer is free
+            if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+            const char* As = smem + (kt & 1) * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = ks * 2 + hi;
-            bf16x8 af[2], wf[2];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = ks * 2 + hi;
+                bf16x8 af[TM], wf[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
-                wf[t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
+                for (int t = 0; t < TM; ++t) af[t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
             }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
+    } else {
+        // ---- ping-pong schedule (TM = 4, TN = 2): 4 phases per K-tile ----
+        static_assert(!CFG::PP || (TM == 4 && TN == 2), "ping-pong schedule is written for 128x64 wave tiles");
+        bf16x8 af[2][4], wf[4];  // [m-tile in half][k-step], [k-step]
+        auto rd_a = [&](const char* As, int half) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    af[t][ks] = *(const bf16x8*)(As + a_off[half * 2 + t] + (((ks * 2 + hi) ^ a_sw[half * 2 + t]) << 4));
+        };
+        auto rd_w = [&](const char* Ws, int nt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                wf[ks] = *(const bf16x8*)(Ws + w_off[nt] + (((ks * 2 + hi) ^ w_sw[nt]) << 4));
+        };
+        auto mma = [&](int half, int nt) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[nt][half * 2 + t] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[t][ks], acc[nt][half * 2 + t], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+#define PP_SYNC()                                          \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+#define PP_BAR()                               \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR();                 // tile 0 visible to every wave
+        if (wm == 1) PP_BAR();    // M-half 1 runs one barrier behind M-half 0
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* As = smem + (kt & 1) * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
+            // phase 1: quadrant (m-half 0, n-tile 0); next tile's DMA goes out here
+            rd_a(As, 0);
+            rd_w(Ws, 0);
+            if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+            PP_SYNC();
+            mma(0, 0);
+            PP_BAR();
+            // phase 2: (m-half 0, n-tile 1)
+            rd_w(Ws, 1);
+            PP_SYNC();
+            mma(0, 1);
+            PP_BAR();
+            // phase 3: (m-half 1, n-tile 1)
+            rd_a(As, 1);
+            PP_SYNC();
+            mma(1, 1);
+            PP_BAR();
+            // phase 4: (m-half 1, n-tile 0); the DMA issued in phase 1 must have landed before the
+            // barrier that precedes any wave's first read of the next tile
+            rd_w(Ws, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_SYNC();
+            mma(1, 0);
+            PP_BAR();
+        }
+        if (wm == 0) PP_BAR();    // balance the barrier count of the two halves
+#undef PP_SYNC
+#undef PP_BAR
     }
 
-    // ---- epilogue: lane holds, per (nt, mt, g), C[m][n .. n+3] ----
+    // ---- epilogue ----
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wm * 64 + mt * 32 + l31;
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
         if (m >= M) continue;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * hi;
-                if (n >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
-                if (bias != nullptr) {
-                    const u32x2 b = *(const u32x2*)(bias + n);
-                    v[0] += bf16_lo(b[0]);
-                    v[1] += bf16_hi(b[0]);
-                    v[2] += bf16_lo(b[1]);
-                    v[3] += bf16_hi(b[1]);
-                }
-                if (EPI == APEXMI_EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
-                }
-                if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
-                    const f32x4 gt = *(const f32x4*)(gate + n);
-                    const u32x2 rr = *(const u32x2*)(R + (int64_t)m * ldr + n);
-                    v[0] = bf16_lo(rr[0]) + gt[0] * v[0];
-                    v[1] = bf16_hi(rr[0]) + gt[1] * v[1];
-                    v[2] = bf16_lo(rr[1]) + gt[2] * v[2];
-                    v[3] = bf16_hi(rr[1]) + gt[3] * v[3];
-                }
-                u32x2 o;
-                o[0] = pack_bf16(v[0], v[1]);
-                o[1] = pack_bf16(v[2], v[3]);
-                *(u32x2*)(C + (int64_t)m * ldc + n) = o;
-            }
-        }
+        for (int nt = 0; nt < TN; ++nt)
+            store_tile<EPI>(acc[nt][mt], P, N, m, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
     }
 }
 
-template <int EPI>
-int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C,
-                int64_t ldc, int M, int N, int K, const float* gate, const void* R, int64_t ldr,
-                hipStream_t stream) {
+int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P
+
+template <typename CFG, int EPI>
+int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<CFG, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
         attr_set = true;
     }
-    const int nm = (M + BM - 1) / BM, nn = (N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream,
-                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (bf16_t*)C, ldc, M, N, K, gate, (const bf16_t*)R, ldr, nm, nn);
+    G.nn = (G.N + CFG::BN - 1) / CFG::BN;
+    int t = 0;
+    for (int i = 0; i < G.count; ++i) {
+        G.p[i].M = Ms[i];
+        G.p[i].nm = (Ms[i] + CFG::BM - 1) / CFG::BM;
+        G.p[i].tile0 = t;
+        t += G.p[i].nm * G.nn;
+    }
+    G.total = t;
+    hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }
 
-}  // namespace
+template <int EPI>
+int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
+    int cfg = g_force_cfg;
+    if (cfg == 0) {
+        int64_t mtot = 0;
+        for (int i = 0; i < G.count; ++i) mtot += Ms[i];
+        // large problems: 256x256 tiles, one per CU per round; otherwise the 128x128 tiling
+        cfg = (mtot >= 1024 && G.N >= 1024 && G.K >= 256) ? 3 : 1;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
+        case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
+        default: return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
+    }
+}
 
-extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
-                                const void* bias, void* C, int64_t ldc, int M, int N, int K,
-                                int epilogue, const float* gate, const void* R, int64_t ldr,
-                                apexmi_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+int launch_group(GemmGroup& G, const int* Ms, int epilogue, hipStream_t stream) {
+    switch (epilogue) {
+        case APEXMI_EPI_BIAS: return launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
+        case APEXMI_EPI_BIAS_GELU: return launch_epi<APEXMI_EPI_BIAS_GELU>(G, Ms, stream);
+        case APEXMI_EPI_BIAS_GATE_RES: return launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream);
+        default: apexmi_set_error("gemm_bf16: unknown epilogue %d", epilogue); return 1;
+    }
+}
+
+int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
+                  int N, int K, int epilogue, const float* gate, const void* R, int64_t ldr) {
     APEXMI_REQUIRE(A && W && C, "gemm_bf16: null operand");
     APEXMI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     APEXMI_REQUIRE(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -196,20 +350,61 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
         APEXMI_REQUIRE(ldr % 4 == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)R % 8) == 0,
                        "gemm_bf16: gate/R alignment");
     }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                const void* bias, void* C, int64_t ldc, int M, int N, int K,
+                                int epilogue, const float* gate, const void* R, int64_t ldr,
+                                apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
+    GemmGroup G;
+    G.count = 1;
+    G.N = N;
+    G.K = K;
+    G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, gate,
+                         (const bf16_t*)R, lda, ldw, ldc, ldr, M, 0, 0};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
-    switch (epilogue) {
-        case APEXMI_EPI_BIAS:
-            return launch_gemm<APEXMI_EPI_BIAS>(A, lda, W, ldw, bias, C, ldc, M, N, K, gate, R, ldr,
-                                                stream);
-        case APEXMI_EPI_BIAS_GELU:
-            return launch_gemm<APEXMI_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gate, R,
-                                                     ldr, stream);
-        case APEXMI_EPI_BIAS_GATE_RES:
-            return launch_gemm<APEXMI_EPI_BIAS_GATE_RES>(A, lda, W, ldw, bias, C, ldc, M, N, K, gate,
-                                                         R, ldr, stream);
-        default:
-            apexmi_set_error("gemm_bf16: unknown epilogue %d", epilogue);
-            return 1;
+    return launch_group(G, &M, epilogue, stream);
+}
+
+extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda,
+                                        const void* const* W, const int64_t* ldw,
+                                        const void* const* bias, void* const* C, const int64_t* ldc,
+                                        const int* M, int N, int K, int epilogue,
+                                        const float* const* gate, const void* const* R,
+                                        const int64_t* ldr, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(count >= 1 && count <= MAX_GROUPS, "gemm_bf16_grouped: count=%d not in [1,%d]", count, MAX_GROUPS);
+    GemmGroup G;
+    G.count = count;
+    G.N = N;
+    G.K = K;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        const float* g = gate ? gate[i] : nullptr;
+        const void* r = R ? R[i] : nullptr;
+        const int64_t lr = ldr ? ldr[i] : 0;
+        if (int rc = check_problem(A[i], lda[i], W[i], ldw[i], C[i], ldc[i], M[i], N, K, epilogue, g, r, lr))
+            return rc;
+        G.p[i] = GemmProblem{(const bf16_t*)A[i], (const bf16_t*)W[i], (const bf16_t*)(bias ? bias[i] : nullptr),
+                             (bf16_t*)C[i], g, (const bf16_t*)r, lda[i], ldw[i], ldc[i], lr, M[i], 0, 0};
+        flops += 2.0 * M[i] * N * (double)K;
+        bytes += 2.0 * ((double)M[i] * K + (double)N * K + (double)M[i] * N);
     }
+    ApexmiProfScope prof(0, stream, flops, bytes);
+    return launch_group(G, M, epilogue, stream);
+}
+
+extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (key && !strcmp(key, "gemm.config")) {
+        g_force_cfg = value;
+        return 0;
+    }
+    apexmi_set_error("tune_set: unknown key");
+    return 1;
 }

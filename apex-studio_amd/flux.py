@@ -351,25 +351,24 @@ class FluxTransformer2DModel(nn.Module):
             # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             ops.ln_modulate(Xi, mi(1), mi(0), out=XNi)
             ops.ln_modulate(Xt, mt(1), mt(0), out=XNt)
-            ops.gemm(XNi, blk._wqkv, blk._bqkv, out=QKV[s_txt:])
-            ops.gemm(XNt, blk._wqkv_c, blk._bqkv_c, out=QKV[:s_txt])
+            ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
+                             [QKV[s_txt:], QKV[:s_txt]])
             ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
                             wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
                             split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(Qp, Kp, VT, att_v, S)
-            ops.gemm(att[s_txt:], a.to_out[0].weight, a.to_out[0].bias, out=Xi, epilogue="gate_res",
-                     gate=mi(2), residual=Xi)
-            ops.gemm(att[:s_txt], a.to_add_out.weight, a.to_add_out.bias, out=Xt, epilogue="gate_res",
-                     gate=mt(2), residual=Xt)
+            ops.gemm_grouped([att[s_txt:], att[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
+                             [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",
+                             gate_list=[mi(2), mt(2)], residual_list=[Xi, Xt])
             ops.ln_modulate(Xi, mi(4), mi(3), out=XNi)
             ops.ln_modulate(Xt, mt(4), mt(3), out=XNt)
             ff, ffc = blk.ff.net, blk.ff_context.net
-            ops.gemm(XNi, ff[0].proj.weight, ff[0].proj.bias, out=FFH[s_txt:], epilogue="gelu")
-            ops.gemm(XNt, ffc[0].proj.weight, ffc[0].proj.bias, out=FFH[:s_txt], epilogue="gelu")
-            ops.gemm(FFH[s_txt:], ff[2].weight, ff[2].bias, out=Xi, epilogue="gate_res", gate=mi(5),
-                     residual=Xi)
-            ops.gemm(FFH[:s_txt], ffc[2].weight, ffc[2].bias, out=Xt, epilogue="gate_res", gate=mt(5),
-                     residual=Xt)
+            ops.gemm_grouped([XNi, XNt], [ff[0].proj.weight, ffc[0].proj.weight],
+                             [ff[0].proj.bias, ffc[0].proj.bias], [FFH[s_txt:], FFH[:s_txt]],
+                             epilogue="gelu")
+            ops.gemm_grouped([FFH[s_txt:], FFH[:s_txt]], [ff[2].weight, ffc[2].weight],
+                             [ff[2].bias, ffc[2].bias], [Xi, Xt], epilogue="gate_res",
+                             gate_list=[mi(5), mt(5)], residual_list=[Xi, Xt])
 
         for i, blk in enumerate(self.single_transformer_blocks):
             a = blk.attn

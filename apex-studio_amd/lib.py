@@ -29,6 +29,11 @@ SIGNATURES = {
                                            C.c_int, c_i64p, C.c_float, vp]),
     "apexmi_gemm_bf16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, vp, C.c_int64, vp]),
+    "apexmi_gemm_bf16_grouped": (C.c_int, [C.c_int, C.POINTER(vp), c_i64p, C.POINTER(vp), c_i64p,
+                                           C.POINTER(vp), C.POINTER(vp), c_i64p, C.POINTER(C.c_int),
+                                           C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp),
+                                           c_i64p, vp]),
+    "apexmi_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                               C.c_int, C.c_int, vp]),
     "apexmi_ln_modulate": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp,
@@ -96,6 +101,10 @@ def check(rc: int, what: str = "") -> None:
 
 def i64x3(vals):
     return (C.c_int64 * 3)(*[int(v) for v in vals])
+
+
+def tune_set(key: str, value: int) -> None:
+    check(load().apexmi_tune_set(key.encode(), int(value)), "tune_set")
 
 
 def prof_enable(on: bool) -> None:

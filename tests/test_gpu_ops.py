@@ -88,6 +88,68 @@ def test_gemm_gate_residual_inplace_and_strided():
     assert torch.equal(xbuf[:, :64].cpu(), _bf(seeded((M, N + 128), 11))[:, :64])
 
 
+@pytest.fixture
+def gemm_config():
+    from apex_studio_amd import lib
+    yield lambda v: lib.tune_set("gemm.config", v)
+    lib.tune_set("gemm.config", 0)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 192), (1024, 1024, 1024), (77, 3072, 256)])
+def test_gemm_every_tiling(cfg, M, N, K, gemm_config):
+    """128x128, 256x256 and the 256x256 ping-pong schedule must agree with the fp32 reference."""
+    ops = _ops()
+    gemm_config(cfg)
+    a, w, b = _bf(seeded((M, K), 1)), _bf(seeded((N, K), 2, scale=K ** -0.5)), _bf(seeded((N,), 3))
+    gate, r = seeded((N,), 4), _bf(seeded((M, N), 5))
+    ref = a.float() @ w.float().T + b.float()
+    _check(ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV)), ref, 3e-3, f"cfg{cfg} bias")
+    _check(ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue="gelu"),
+           torch.nn.functional.gelu(ref, approximate="tanh"), 3e-3, f"cfg{cfg} gelu")
+    x = r.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=x, epilogue="gate_res", gate=gate.to(DEV), residual=x)
+    _check(x, r.float() + gate * ref, 3e-3, f"cfg{cfg} gate_res")
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_pingpong_race_screen(cfg, gemm_config):
+    """Repeat a deep-K problem: a staging/barrier race shows up as run-to-run differences."""
+    ops = _ops()
+    gemm_config(cfg)
+    M, N, K = 1024, 2048, 4096
+    a = _bf(seeded((M, K), 11)).to(DEV)
+    w = _bf(seeded((N, K), 12, scale=K ** -0.5)).to(DEV)
+    ref = a.float() @ w.float().T
+    first = ops.gemm(a, w)
+    _check(first, ref, 3e-3, f"cfg{cfg} deep-K")
+    for _ in range(10):
+        assert torch.equal(ops.gemm(a, w), first), "non-deterministic result: LDS staging race"
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_gemm_grouped(cfg, gemm_config):
+    """img + txt streams in one launch, writing row ranges of one joint buffer."""
+    ops = _ops()
+    gemm_config(cfg)
+    K, N, Mi, Mt = 512, 768, 700, 80
+    ai, at = _bf(seeded((Mi, K), 1)), _bf(seeded((Mt, K), 2))
+    wi, wt = _bf(seeded((N, K), 3, scale=K ** -0.5)), _bf(seeded((N, K), 4, scale=K ** -0.5))
+    bi, bt = _bf(seeded((N,), 5)), _bf(seeded((N,), 6))
+    out = torch.zeros(Mt + Mi, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_grouped([ai.to(DEV), at.to(DEV)], [wi.to(DEV), wt.to(DEV)], [bi.to(DEV), bt.to(DEV)],
+                     [out[Mt:], out[:Mt]])
+    _check(out[Mt:], ai.float() @ wi.float().T + bi.float(), 3e-3, "grouped img")
+    _check(out[:Mt], at.float() @ wt.float().T + bt.float(), 3e-3, "grouped txt")
+    gi, gt = seeded((N,), 7).to(DEV), seeded((N,), 8).to(DEV)
+    x = _bf(seeded((Mt + Mi, N), 9)).to(DEV)
+    x0 = x.float().cpu().clone()
+    ops.gemm_grouped([ai.to(DEV), at.to(DEV)], [wi.to(DEV), wt.to(DEV)], [bi.to(DEV), bt.to(DEV)],
+                     [x[Mt:], x[:Mt]], epilogue="gate_res", gate_list=[gi, gt], residual_list=[x[Mt:], x[:Mt]])
+    _check(x[Mt:], x0[Mt:] + gi.cpu() * (ai.float() @ wi.float().T + bi.float()), 3e-3, "grouped img gate")
+    _check(x[:Mt], x0[:Mt] + gt.cpu() * (at.float() @ wt.float().T + bt.float()), 3e-3, "grouped txt gate")
+
+
 def test_gemm_flux_shapes_against_gpu_fp32():
     ops = _ops()
     for (M, N, K) in [(4608, 9216, 3072), (4608, 3072, 15360), (512, 12288, 3072)]:
