@@ -16,7 +16,8 @@
 //              while its partner is in its LDS/DMA segment, and the next K-tile's LDS-DMA stays in
 //              flight for three phases behind a counted wait.
 // Both operands are K-contiguous, so A and W tiles are staged identically with 16-byte
-// global_load_lds into a double-buffered LDS image; the XOR swizzle (chunk ^= row & 7) is applied on
+// global_load_lds into a double-buffered LDS image; the XOR swizzle (chunk ^= (row >> 1) & 7: two 128-byte rows share a 256-byte bank
+// row, and a 32-row MFMA fragment read must spread each 16-lane group over all 16 slots) is applied on
 // the per-lane SOURCE address and again on the ds_read_b128 address (an LDS-DMA destination is
 // lane-linear).  Operands are fed swapped (MFMA "A" = W rows, "B" = activation rows) so a lane holds
 // four consecutive output columns of one row -> 8-byte epilogue accesses.
@@ -47,8 +48,9 @@ struct GemmGroup {
     int count, N, K, nn, total;
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool PP_>
+template <int BM_, int BN_, int WM_, int WN_, bool PP_, int V_ = 0>
 struct Cfg {
+    static constexpr int V = V_;  // schedule variant bits (ping-pong only), see PP_SYNC / L-segment order
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr bool PP = PP_;
     static constexpr int NW = WM * WN, NT = NW * 64;
@@ -61,41 +63,71 @@ struct Cfg {
 };
 using CFG_128 = Cfg<128, 128, 2, 2, false>;
 using CFG_256 = Cfg<256, 256, 2, 4, false>;
-using CFG_256P = Cfg<256, 256, 2, 4, true>;
+template <int V>
+using CFG_256P = Cfg<256, 256, 2, 4, true, V>;
+
+// exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
+// columns: low half-wave gets [a_lo | a_hi] = cols 8g..8g+7, high half-wave [b_lo | b_hi] = cols
+// 8(g+1)..8(g+1)+7.  The exchange is an involution, so it also maps a 16-byte residual load back to
+// the accumulator layout.
+APEXMI_DEVICE void swap_pair(u32x2& a, u32x2& b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(a[i], b[i], false, false);
+        a[i] = r[0];
+        b[i] = r[1];
+    }
+}
 
 template <int EPI>
 APEXMI_DEVICE void store_tile(const f32x16& acc, const GemmProblem& P, int N, int m, int nbase, int hi) {
-    // lane holds C[m][nbase + 8 g + 4 hi + (0..3)] for g = 0..3
+    // accumulator layout: lane holds C[m][nbase + 8 g + 4 hi + (0..3)] for g = 0..3
+    const bool row_ok = m >= 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int n = nbase + 8 * g + 4 * hi;
-        if (n >= N) continue;
-        float v[4];
+    for (int g = 0; g < 4; g += 2) {
+        const int nst = nbase + 8 * (g + hi);  // first of the 8 columns this lane stores
+        float v[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j];
-        if (P.bias != nullptr) {
-            const u32x2 b = *(const u32x2*)(P.bias + n);
-            v[0] += bf16_lo(b[0]);
-            v[1] += bf16_hi(b[0]);
-            v[2] += bf16_lo(b[1]);
-            v[3] += bf16_hi(b[1]);
-        }
-        if (EPI == APEXMI_EPI_BIAS_GELU) {
+        for (int q = 0; q < 2; ++q) {
+            const int n = nbase + 8 * (g + q) + 4 * hi;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+            for (int j = 0; j < 4; ++j) v[q][j] = acc[4 * (g + q) + j];
+            if (P.bias != nullptr && n < N) {
+                const u32x2 b = *(const u32x2*)(P.bias + n);
+                v[q][0] += bf16_lo(b[0]);
+                v[q][1] += bf16_hi(b[0]);
+                v[q][2] += bf16_lo(b[1]);
+                v[q][3] += bf16_hi(b[1]);
+            }
+            if (EPI == APEXMI_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[q][j] = gelu_tanh_f(v[q][j]);
+            }
         }
         if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
-            const f32x4 gt = *(const f32x4*)(P.gate + n);
-            const u32x2 rr = *(const u32x2*)(P.R + (int64_t)m * P.ldr + n);
-            v[0] = bf16_lo(rr[0]) + gt[0] * v[0];
-            v[1] = bf16_hi(rr[0]) + gt[1] * v[1];
-            v[2] = bf16_lo(rr[1]) + gt[2] * v[2];
-            v[3] = bf16_hi(rr[1]) + gt[3] * v[3];
+            u32x4 rr = {0u, 0u, 0u, 0u};
+            if (row_ok && nst < N) rr = *(const u32x4*)(P.R + (int64_t)m * P.ldr + nst);
+            u32x2 ra = {rr[0], rr[1]}, rb = {rr[2], rr[3]};
+            swap_pair(ra, rb);  // back to the accumulator layout
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n = nbase + 8 * (g + q) + 4 * hi;
+                const u32x2 r2 = q ? rb : ra;
+                f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+                if (n < N) gt = *(const f32x4*)(P.gate + n);
+                v[q][0] = bf16_lo(r2[0]) + gt[0] * v[q][0];
+                v[q][1] = bf16_hi(r2[0]) + gt[1] * v[q][1];
+                v[q][2] = bf16_lo(r2[1]) + gt[2] * v[q][2];
+                v[q][3] = bf16_hi(r2[1]) + gt[3] * v[q][3];
+            }
         }
-        u32x2 o;
-        o[0] = pack_bf16(v[0], v[1]);
-        o[1] = pack_bf16(v[2], v[3]);
-        *(u32x2*)(P.C + (int64_t)m * P.ldc + n) = o;
+        u32x2 oa = {pack_bf16(v[0][0], v[0][1]), pack_bf16(v[0][2], v[0][3])};
+        u32x2 ob = {pack_bf16(v[1][0], v[1][1]), pack_bf16(v[1][2], v[1][3])};
+        swap_pair(oa, ob);
+        if (row_ok && nst < N) {
+            const u32x4 o = {oa[0], oa[1], ob[0], ob[1]};
+            *(u32x4*)(P.C + (int64_t)m * P.ldc + nst) = o;
+        }
     }
 }
 
@@ -132,13 +164,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
     for (int i = 0; i < CFG::A_LD; ++i) {
         const int p = (i * CFG::NW + wave) * 64 + lane;  // 16-byte chunk index inside the tile image
-        const int row = p >> 3, c = (p & 7) ^ (row & 7);
+        const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
         a_src[i] = (const char*)(P.A + (int64_t)min(m0 + row, M - 1) * P.lda + c * 8);
     }
 #pragma unroll
     for (int i = 0; i < CFG::W_LD; ++i) {
         const int p = (i * CFG::NW + wave) * 64 + lane;
-        const int row = p >> 3, c = (p & 7) ^ (row & 7);
+        const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
         w_src[i] = (const char*)(P.W + (int64_t)min(n0 + row, N - 1) * P.ldw + c * 8);
     }
 
@@ -168,13 +200,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     for (int t = 0; t < TM; ++t) {
         const int r = wm * (BM / CFG::WM) + t * 32 + l31;
         a_off[t] = r * 128;
-        a_sw[t] = r & 7;
+        a_sw[t] = (r >> 1) & 7;
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int r = wn * (BN / CFG::WN) + t * 32 + l31;
         w_off[t] = r * 128;
-        w_sw[t] = r & 7;
+        w_sw[t] = (r >> 1) & 7;
     }
 
     if constexpr (!CFG::PP) {
@@ -225,12 +257,12 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
                         __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[t][ks], acc[nt][half * 2 + t], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-#define PP_SYNC()                                          \
-    do {                                                   \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                 \
-        __builtin_amdgcn_s_barrier();                      \
-        __builtin_amdgcn_sched_barrier(0);                 \
+#define PP_SYNC()                                                                   \
+    do {                                                                            \
+        if constexpr (CFG::V & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        __builtin_amdgcn_s_barrier();                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
     } while (0)
 #define PP_BAR()                               \
     do {                                       \
@@ -239,39 +271,95 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Region-wise staging: the tile image is cut into the four sub-tiles the phases read
+        //   RA0/RA1 = activation rows with (row & 64) == 0 / != 0   (m-half 0 / 1 of every wave)
+        //   RW0/RW1 = weight rows with (row & 32) == 0 / != 0       (n-tile 0 / 1 of every wave)
+        // 16 KiB each = 2 LDS-DMA per thread.  Phase 1 issues the next tile's RA0, phase 2 RW0, phase 3
+        // RW1, phase 4 RA1, so at most three regions are in flight and every L segment carries 2 DMA.
+        const char* ra_src[2][2];
+        const char* rw_src[2][2];
+        int ra_lds[2][2], rw_lds[2][2];
+#pragma unroll
+        for (int reg = 0; reg < 2; ++reg)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = j * 8 + wave;  // 1 KiB slot (8 rows) inside the region
+                const int ra0 = (q < 8 ? q * 8 : 128 + (q - 8) * 8) + reg * 64;
+                const int rw0 = (q >> 2) * 64 + reg * 32 + (q & 3) * 8;
+                const int ra = ra0 + (lane >> 3), rw = rw0 + (lane >> 3);
+                ra_src[reg][j] = (const char*)(P.A + (int64_t)min(m0 + ra, M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) * 8));
+                rw_src[reg][j] = (const char*)(P.W + (int64_t)min(n0 + rw, N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) * 8));
+                ra_lds[reg][j] = ra0 * 128;
+                rw_lds[reg][j] = CFG::A_BYTES + rw0 * 128;
+            }
+        auto stage_a = [&](int buf, int kt, int reg) {
+            char* base = smem + buf * CFG::STAGE;
+            const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(ra_src[reg][j] + koff, base + ra_lds[reg][j]);
+        };
+        auto stage_w = [&](int buf, int kt, int reg) {
+            char* base = smem + buf * CFG::STAGE;
+            const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(rw_src[reg][j] + koff, base + rw_lds[reg][j]);
+        };
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+        stage_a(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(0, 0, 1);
+        stage_a(0, 0, 1);
+        VMCNT(0);
         PP_BAR();                 // tile 0 visible to every wave
         if (wm == 1) PP_BAR();    // M-half 1 runs one barrier behind M-half 0
         for (int kt = 0; kt < nkt; ++kt) {
             const char* As = smem + (kt & 1) * CFG::STAGE;
             const char* Ws = As + CFG::A_BYTES;
-            // phase 1: quadrant (m-half 0, n-tile 0); next tile's DMA goes out here
+            const bool more = kt + 1 < nkt;
+            const int nb = (kt + 1) & 1;
+            // Each wait leaves only the two most recent regions in flight: the region the NEXT phase
+            // reads was issued three phases ago.  All waves pass the wait before the barrier that
+            // precedes the first reader (the other M-half runs one barrier behind).  The fragment
+            // reads are issued before the barrier and waited for after it (their latency hides
+            // under the partner's MFMA segment); every region is re-staged >= 2 phases after its last
+            // read, so no read can still be in flight when its slot is overwritten.
+            // phase 1: quadrant (m-half 0, n-tile 0)
+            if constexpr (CFG::V & 2) { if (more) stage_a(nb, kt + 1, 0); }
             rd_a(As, 0);
             rd_w(Ws, 0);
-            if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+            if constexpr (!(CFG::V & 2)) { if (more) stage_a(nb, kt + 1, 0); }
+            if (more) { VMCNT(4); } else { VMCNT(2); }
             PP_SYNC();
             mma(0, 0);
             PP_BAR();
             // phase 2: (m-half 0, n-tile 1)
+            if constexpr (CFG::V & 2) { if (more) stage_w(nb, kt + 1, 0); }
             rd_w(Ws, 1);
+            if constexpr (!(CFG::V & 2)) { if (more) stage_w(nb, kt + 1, 0); }
+            if (more) { VMCNT(4); } else { VMCNT(0); }
             PP_SYNC();
             mma(0, 1);
             PP_BAR();
             // phase 3: (m-half 1, n-tile 1)
+            if constexpr (CFG::V & 2) { if (more) stage_w(nb, kt + 1, 1); }
             rd_a(As, 1);
+            if constexpr (!(CFG::V & 2)) { if (more) stage_w(nb, kt + 1, 1); }
+            if (more) VMCNT(4);
             PP_SYNC();
             mma(1, 1);
             PP_BAR();
-            // phase 4: (m-half 1, n-tile 0); the DMA issued in phase 1 must have landed before the
-            // barrier that precedes any wave's first read of the next tile
+            // phase 4: (m-half 1, n-tile 0)
+            if constexpr (CFG::V & 2) { if (more) stage_a(nb, kt + 1, 1); }
             rd_w(Ws, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!(CFG::V & 2)) { if (more) stage_a(nb, kt + 1, 1); }
+            if (more) VMCNT(4);
             PP_SYNC();
             mma(1, 0);
             PP_BAR();
         }
         if (wm == 0) PP_BAR();    // balance the barrier count of the two halves
+#undef VMCNT
 #undef PP_SYNC
 #undef PP_BAR
     }
@@ -279,8 +367,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     // ---- epilogue ----
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-        const int m = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
-        if (m >= M) continue;
+        int m = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
+        if (m >= M) m = -1;  // keep the lane alive for the cross-lane exchange, store nothing
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
             store_tile<EPI>(acc[nt][mt], P, N, m, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
@@ -288,6 +376,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 }
 
 int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P
+int g_variant = 1;    // ping-pong schedule variant (bit0: lgkm wait before barrier, bit1: DMA first)
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -322,7 +411,13 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
         case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
-        default: return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
+        default:
+            switch (g_variant & 3) {
+                case 0: return launch_cfg<CFG_256P<0>, EPI>(G, Ms, stream);
+                case 1: return launch_cfg<CFG_256P<1>, EPI>(G, Ms, stream);
+                case 2: return launch_cfg<CFG_256P<2>, EPI>(G, Ms, stream);
+                default: return launch_cfg<CFG_256P<3>, EPI>(G, Ms, stream);
+            }
     }
 }
 
@@ -403,6 +498,10 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
 extern "C" int apexmi_tune_set(const char* key, int value) {
     if (key && !strcmp(key, "gemm.config")) {
         g_force_cfg = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "gemm.variant")) {
+        g_variant = value;
         return 0;
     }
     apexmi_set_error("tune_set: unknown key");

@@ -368,7 +368,12 @@ def test_attention_flux_shape_properties():
     o1 = ops.attention(q, k, v).float()
     o2 = ops.attention(q, k, (v.float() * 2).to(torch.bfloat16)).float()
     assert torch.allclose(o2, 2 * o1, atol=2e-2, rtol=2e-2)
-    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert torch.equal(ops.attention(q, k, v).float(), o1), "attention must be deterministic (race screen)"
+    # explicit-math f64 reference, one head at a time (independent of torch's SDPA backend choice)
+    ref = torch.empty_like(o1)
+    for h in range(H):
+        sc = (q[0, h].double() @ k[0, h].double().T) / math.sqrt(128)
+        ref[0, h] = (torch.softmax(sc, dim=-1) @ v[0, h].double()).float()
     _check(o1, ref, 1e-2, "attention flux-1024 shape", ulp=3.0)
 
 
