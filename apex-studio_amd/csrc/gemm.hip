@@ -48,9 +48,8 @@ struct GemmGroup {
     int count, N, K, nn, total;
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool PP_, int V_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, bool PP_>
 struct Cfg {
-    static constexpr int V = V_;  // schedule variant bits (ping-pong only), see PP_SYNC / L-segment order
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr bool PP = PP_;
     static constexpr int NW = WM * WN, NT = NW * 64;
@@ -63,8 +62,7 @@ struct Cfg {
 };
 using CFG_128 = Cfg<128, 128, 2, 2, false>;
 using CFG_256 = Cfg<256, 256, 2, 4, false>;
-template <int V>
-using CFG_256P = Cfg<256, 256, 2, 4, true, V>;
+using CFG_256P = Cfg<256, 256, 2, 4, true>;
 
 // exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
 // columns: low half-wave gets [a_lo | a_hi] = cols 8g..8g+7, high half-wave [b_lo | b_hi] = cols
@@ -259,7 +257,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         };
 #define PP_SYNC()                                                                   \
     do {                                                                            \
-        if constexpr (CFG::V & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
         __builtin_amdgcn_sched_barrier(0);                                          \
         __builtin_amdgcn_s_barrier();                                               \
         __builtin_amdgcn_sched_barrier(0);                                          \
@@ -320,39 +318,36 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
             const int nb = (kt + 1) & 1;
             // Each wait leaves only the two most recent regions in flight: the region the NEXT phase
             // reads was issued three phases ago.  All waves pass the wait before the barrier that
-            // precedes the first reader (the other M-half runs one barrier behind).  The fragment
-            // reads are issued before the barrier and waited for after it (their latency hides
-            // under the partner's MFMA segment); every region is re-staged >= 2 phases after its last
-            // read, so no read can still be in flight when its slot is overwritten.
+            // precedes the first reader (the other M-half runs one barrier behind).  The DMA goes out
+            // AFTER the fragment reads of the segment (measured: DMA-first costs 15 %, the LDS-DMA
+            // issue back-pressures the ds_reads behind it), and every region is re-staged >= 2 phases
+            // after its last read.  Ablation on 8192^3 (profiles/r01_gemm_ablation.md): waits +3 %,
+            // DMA issue +20 %, fragment reads +13 % of the MFMA-only schedule (1.72 PF).
             // phase 1: quadrant (m-half 0, n-tile 0)
-            if constexpr (CFG::V & 2) { if (more) stage_a(nb, kt + 1, 0); }
             rd_a(As, 0);
             rd_w(Ws, 0);
-            if constexpr (!(CFG::V & 2)) { if (more) stage_a(nb, kt + 1, 0); }
+            if (more) stage_a(nb, kt + 1, 0);
             if (more) { VMCNT(4); } else { VMCNT(2); }
             PP_SYNC();
             mma(0, 0);
             PP_BAR();
             // phase 2: (m-half 0, n-tile 1)
-            if constexpr (CFG::V & 2) { if (more) stage_w(nb, kt + 1, 0); }
             rd_w(Ws, 1);
-            if constexpr (!(CFG::V & 2)) { if (more) stage_w(nb, kt + 1, 0); }
+            if (more) stage_w(nb, kt + 1, 0);
             if (more) { VMCNT(4); } else { VMCNT(0); }
             PP_SYNC();
             mma(0, 1);
             PP_BAR();
             // phase 3: (m-half 1, n-tile 1)
-            if constexpr (CFG::V & 2) { if (more) stage_w(nb, kt + 1, 1); }
             rd_a(As, 1);
-            if constexpr (!(CFG::V & 2)) { if (more) stage_w(nb, kt + 1, 1); }
+            if (more) stage_w(nb, kt + 1, 1);
             if (more) VMCNT(4);
             PP_SYNC();
             mma(1, 1);
             PP_BAR();
             // phase 4: (m-half 1, n-tile 0)
-            if constexpr (CFG::V & 2) { if (more) stage_a(nb, kt + 1, 1); }
             rd_w(Ws, 0);
-            if constexpr (!(CFG::V & 2)) { if (more) stage_a(nb, kt + 1, 1); }
+            if (more) stage_a(nb, kt + 1, 1);
             if (more) VMCNT(4);
             PP_SYNC();
             mma(1, 0);
@@ -376,7 +371,6 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 }
 
 int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P
-int g_variant = 1;    // ping-pong schedule variant (bit0: lgkm wait before barrier, bit1: DMA first)
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -412,12 +406,7 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
         case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
         default:
-            switch (g_variant & 3) {
-                case 0: return launch_cfg<CFG_256P<0>, EPI>(G, Ms, stream);
-                case 1: return launch_cfg<CFG_256P<1>, EPI>(G, Ms, stream);
-                case 2: return launch_cfg<CFG_256P<2>, EPI>(G, Ms, stream);
-                default: return launch_cfg<CFG_256P<3>, EPI>(G, Ms, stream);
-            }
+            return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
     }
 }
 
@@ -498,10 +487,6 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
 extern "C" int apexmi_tune_set(const char* key, int value) {
     if (key && !strcmp(key, "gemm.config")) {
         g_force_cfg = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "gemm.variant")) {
-        g_variant = value;
         return 0;
     }
     apexmi_set_error("tune_set: unknown key");

@@ -44,17 +44,14 @@ def main():
         out = torch.randn(M, N, generator=g, device=DEV).to(torch.bfloat16)
         res = {}
         for rnd in range(2):
-            for cfg in (2, 30, 31, 32, 33):
-                lib.tune_set("gemm.config", min(cfg, 3) if cfg < 30 else 3)
-                if cfg >= 30:
-                    lib.tune_set("gemm.variant", cfg - 30)
+            for cfg in (1, 2, 3):
+                lib.tune_set("gemm.config", cfg)
                 kw = dict(epilogue=epi)
                 if epi == "gate_res":
                     kw.update(gate=gate, residual=out)
                 ms = timeit(lambda: ops.gemm(a, w, b, out=out, **kw))
                 res.setdefault(cfg, []).append(2.0 * M * N * K / (ms * 1e-3) / 1e12)
         lib.tune_set("gemm.config", 0)
-        lib.tune_set("gemm.variant", 1)
         ref_ms = timeit(lambda: torch.matmul(a, w.t()))
         print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "epi": epi,
                           "tflops": {f"cfg{c}": [round(x, 1) for x in v] for c, v in res.items()},

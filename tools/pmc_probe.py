@@ -18,7 +18,6 @@ if what in ("all", "gemm"):
         w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
         for cfg, var in ((2, 1), (3, 1)):
             lib.tune_set("gemm.config", cfg)
-            lib.tune_set("gemm.variant", var)
             for _ in range(3):
                 ops.gemm(a, w)
     lib.tune_set("gemm.config", 0)
