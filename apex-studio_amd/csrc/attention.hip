@@ -20,7 +20,6 @@
 
 namespace {
 
-constexpr int QB = 128;   // query rows per workgroup
 constexpr int KV = 64;    // keys per tile
 constexpr int HD = 128;   // head dim
 constexpr int K_TILE_BYTES = KV * HD * 2;   // 16 KiB
@@ -30,7 +29,16 @@ constexpr int ATT_STAGE = K_TILE_BYTES + V_TILE_BYTES;
 // row i of a 32-row K sub-tile holds key perm32(i): swap bits 2 and 3
 APEXMI_DEVICE int perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
+// NW = waves per workgroup (4 or 8); every wave owns 32 query rows and reads the whole K / V^T tile,
+// so 8 waves halve the LDS-DMA instructions each wave has to issue per tile.
+// Online softmax with a deferred rescale: the running max is only raised (and O, l rescaled) when
+// some row's tile max exceeds it by more than DEFER (log2 units), so p = 2^(s c - m) stays <= 2^DEFER;
+// in steady state the 64-register O rescale is skipped.  Every P of a tile is exponentiated after the
+// decision that covers it (no pending P V is split by a rescale).
+constexpr float DEFER = 6.0f;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
     int64_t o_ss, int64_t o_sh, float scale_log2e) {
@@ -49,6 +57,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
     const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
     const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
 
+    constexpr int QB = NW * 32;
+    constexpr int LD = 1024 / (NW * 64);  // 16-byte chunks per thread per tile image (1024 chunks)
     const int qrow = qb * QB + wave * 32 + l31;
     const int qrow_c = min(qrow, Sq - 1);
 
@@ -60,11 +70,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
 
     // staging sources. K image: [64 rows][16 chunks], chunk ^= row & 15, row i <- key perm(i).
     // V^T image: [128 rows (d)][8 chunks], chunk ^= (row >> 1) & 7.
-    int k_key[4], k_c[4];
-    const char* v_src[4];
+    int k_key[LD], k_c[LD];
+    const char* v_src[LD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (wave * 4 + i) * 64 + lane;
+    for (int i = 0; i < LD; ++i) {
+        const int p = (wave * LD + i) * 64 + lane;
         {
             const int row = p >> 4, pc = p & 15;
             k_c[i] = (pc ^ (row & 15)) * 8;
@@ -78,15 +88,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
     }
 
     auto stage = [&](int buf, int t) {
-        char* base = smem + buf * ATT_STAGE + wave * 4096;
+        char* base = smem + buf * ATT_STAGE + wave * (LD * 1024);
         const int kv0 = t * KV;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LD; ++i) {
             const int key = min(kv0 + k_key[i], Sk - 1);
             glds16(Kp + (int64_t)key * HD + k_c[i], base + i * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LD; ++i)
             glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * 1024);
     };
 
@@ -117,6 +127,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
     const int nt = (Sk + KV - 1) / KV;
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
+        // Tile t's LDS-DMA must have landed before the barrier.  hipcc does NOT reliably add the
+        // vmcnt(0) to __syncthreads() for LDS-DMA in this loop (observed in the .s: bare s_barrier;
+        // symptom: rare run-to-run differences at the full Flux shape), so the wait is explicit.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         const char* Ks = smem + (t & 1) * ATT_STAGE;
@@ -157,24 +171,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d128_kernel(
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
-        mx = max_xor32(mx);
-        const float m_new = fmaxf(m_run, mx * scale_log2e);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
+        mx = max_xor32(mx) * scale_log2e;
+        if (__any(mx > m_run + DEFER)) {  // wave-uniform; always taken on the first tile
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
         float psum = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_new));
+                const float p = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_run));
                 sacc[kt][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        l_run += psum;
 
         // ---- P -> bf16 B-fragments: k-step kk takes regs 8 (kk & 1) .. +7 of sacc[kk >> 1],
         //      which are keys 16 kk + 8 hi .. +7 of the tile ----
@@ -303,6 +320,8 @@ int launch_generic(const void* q, const void* k, const void* v, void* out, int B
     return apexmi_check_launch("attn_fwd_generic");
 }
 
+int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
+
 // contiguity test for the MFMA path's packed [B,H,S,128] operands
 bool packed_bhsd(const int64_t* st, int H, int S, int D) {
     return st[2] == D && st[1] == (int64_t)S * D && st[0] == (int64_t)H * S * D;
@@ -325,20 +344,34 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
                    "attn_fwd_prepared: output strides must be multiples of 4 elements");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel,
+        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<8>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         attr_set = true;
     }
-    const int nqb = (Sq + QB - 1) / QB;
-    const int total = nqb * H * B;
     const float c = softmax_scale * 1.4426950408889634f;
     ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * HD,
                          2.0 * B * H * HD * (2.0 * Sq + 2.0 * Sk));
-    hipLaunchKernelGGL(attn_fwd_d128_kernel, dim3(total), dim3(256), 2 * ATT_STAGE, stream,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
-                       Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
+    // 8-wave workgroups (256 query rows) once there are enough of them to fill the chip
+    const bool big = g_attn_waves == 8 || (g_attn_waves == 0 && (int64_t)((Sq + 255) / 256) * H * B >= 256);
+    if (big) {
+        const int nqb = (Sq + 255) / 256;
+        const int total = nqb * H * B;
+        hipLaunchKernelGGL(attn_fwd_d128_kernel<8>, dim3(total), dim3(512), 2 * ATT_STAGE, stream,
+                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
+                           Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
+    } else {
+        const int nqb = (Sq + 127) / 128;
+        const int total = nqb * H * B;
+        hipLaunchKernelGGL(attn_fwd_d128_kernel<4>, dim3(total), dim3(256), 2 * ATT_STAGE, stream,
+                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
+                           Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
+    }
     return apexmi_check_launch("attn_fwd_d128");
 }
+
+void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype != APEXMI_BF16 || D != HD) return 0;

@@ -13,6 +13,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAX_IT = 16;  // 16 * 64 lanes * 8 elements = 8192
 
+// NIT = 16-byte chunks per lane (ceil(C / 512)); a template parameter so a 3072-wide row costs 48
+// data registers instead of 128 and 7-8 waves per SIMD keep enough loads in flight for HBM.
+template <int NIT>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -22,10 +25,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     if (row >= M) return;
     const int nchunk = C >> 3;
     const bf16_t* xp = x + (int64_t)row * ldx;
-    float v[LN_MAX_IT][8];
+    float v[NIT][8];
     float sum = 0.0f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nchunk) {
             const u32x4 raw = *(const u32x4*)(xp + c * 8);
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     if (!rms) mean = wave_sum(sum) / (float)C;
     float sq = 0.0f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nchunk) {
 #pragma unroll
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
     bf16_t* op = out + (int64_t)row * ldo;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nchunk) {
             float y[8];
@@ -358,9 +361,20 @@ extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t
     APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
                    "ln_modulate: scale/shift must be 16-byte aligned");
     ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)M * C);
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x,
-                       ldx, (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,
-                       (const bf16_t*)beta, eps, rms);
+    const int nit = (C / 8 + 63) / 64;
+#define LN_LAUNCH(N)                                                                                     \
+    hipLaunchKernelGGL(ln_modulate_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, \
+                       ldx, (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,                 \
+                       (const bf16_t*)beta, eps, rms)
+    if (nit <= 1) LN_LAUNCH(1);
+    else if (nit <= 2) LN_LAUNCH(2);
+    else if (nit <= 4) LN_LAUNCH(4);
+    else if (nit <= 6) LN_LAUNCH(6);
+    else if (nit <= 8) LN_LAUNCH(8);
+    else if (nit <= 10) LN_LAUNCH(10);
+    else if (nit <= 12) LN_LAUNCH(12);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
     return apexmi_check_launch("ln_modulate");
 }
 

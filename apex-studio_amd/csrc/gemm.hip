@@ -41,11 +41,11 @@ struct GemmProblem {
     const float* gate;
     const bf16_t* R;
     int64_t lda, ldw, ldc, ldr;
-    int M, nm, tile0;
+    int M, N, nm, nn, tile0, gelu;
 };
 struct GemmGroup {
     GemmProblem p[MAX_GROUPS];
-    int count, N, K, nn, total;
+    int count, K, total;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, bool PP_>
@@ -77,56 +77,73 @@ APEXMI_DEVICE void swap_pair(u32x2& a, u32x2& b) {
     }
 }
 
-template <int EPI>
-APEXMI_DEVICE void store_tile(const f32x16& acc, const GemmProblem& P, int N, int m, int nbase, int hi) {
-    // accumulator layout: lane holds C[m][nbase + 8 g + 4 hi + (0..3)] for g = 0..3
-    const bool row_ok = m >= 0;
+// Epilogue for one n-tile (32 columns) of a wave: ALL loads (bias, gate, residual rows of every
+// m-tile) are issued before the first store, so the wave pays one memory round trip per n-tile instead
+// of one per 8-byte group (C may alias R, so the compiler cannot hoist loads above stores itself).
+// Accumulator layout: lane holds C[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3; pairs of groups are
+// exchanged with the other half-wave into 8 consecutive columns -> 16-byte accesses.
+template <int EPI, int TM>
+APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, int N, const int (&m)[TM],
+                               int nbase, int hi) {
+    float bs[4][4];
+    f32x4 gt[4];
 #pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-        const int nst = nbase + 8 * (g + hi);  // first of the 8 columns this lane stores
-        float v[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int n = nbase + 8 * (g + q) + 4 * hi;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[q][j] = acc[4 * (g + q) + j];
-            if (P.bias != nullptr && n < N) {
-                const u32x2 b = *(const u32x2*)(P.bias + n);
-                v[q][0] += bf16_lo(b[0]);
-                v[q][1] += bf16_hi(b[0]);
-                v[q][2] += bf16_lo(b[1]);
-                v[q][3] += bf16_hi(b[1]);
-            }
-            if (EPI == APEXMI_EPI_BIAS_GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[q][j] = gelu_tanh_f(v[q][j]);
-            }
-        }
-        if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
-            u32x4 rr = {0u, 0u, 0u, 0u};
-            if (row_ok && nst < N) rr = *(const u32x4*)(P.R + (int64_t)m * P.ldr + nst);
-            u32x2 ra = {rr[0], rr[1]}, rb = {rr[2], rr[3]};
-            swap_pair(ra, rb);  // back to the accumulator layout
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int n = nbase + 8 * (g + q) + 4 * hi;
-                const u32x2 r2 = q ? rb : ra;
-                f32x4 gt = {0.f, 0.f, 0.f, 0.f};
-                if (n < N) gt = *(const f32x4*)(P.gate + n);
-                v[q][0] = bf16_lo(r2[0]) + gt[0] * v[q][0];
-                v[q][1] = bf16_hi(r2[0]) + gt[1] * v[q][1];
-                v[q][2] = bf16_lo(r2[1]) + gt[2] * v[q][2];
-                v[q][3] = bf16_hi(r2[1]) + gt[3] * v[q][3];
-            }
-        }
-        u32x2 oa = {pack_bf16(v[0][0], v[0][1]), pack_bf16(v[0][2], v[0][3])};
-        u32x2 ob = {pack_bf16(v[1][0], v[1][1]), pack_bf16(v[1][2], v[1][3])};
-        swap_pair(oa, ob);
-        if (row_ok && nst < N) {
-            const u32x4 o = {oa[0], oa[1], ob[0], ob[1]};
-            *(u32x4*)(P.C + (int64_t)m * P.ldc + nst) = o;
-        }
+    for (int g = 0; g < 4; ++g) {
+        // loads are unconditional on clamped addresses (a predicated load makes hipcc branch around
+        // it and drain vmcnt(0) per element); out-of-range lanes compute garbage and store nothing
+        const int n = min(nbase + 8 * g + 4 * hi, N - 4);
+        u32x2 b = {0u, 0u};
+        if (P.bias != nullptr) b = *(const u32x2*)(P.bias + n);  // uniform condition
+        bs[g][0] = bf16_lo(b[0]);
+        bs[g][1] = bf16_hi(b[0]);
+        bs[g][2] = bf16_lo(b[1]);
+        bs[g][3] = bf16_hi(b[1]);
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[g] = *(const f32x4*)(P.gate + n);
     }
+    u32x4 rr[TM][2];
+    if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nst = min(nbase + 8 * (2 * pr + hi), N - 8);
+                rr[mt][pr] = *(const u32x4*)(P.R + (int64_t)max(m[mt], 0) * P.ldr + nst);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int g0 = 2 * pr;
+            const int nst = nbase + 8 * (g0 + hi);  // first of the 8 columns this lane stores
+            float v[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[q][j] = acc[mt][4 * (g0 + q) + j] + bs[g0 + q][j];
+                    if (EPI == APEXMI_EPI_BIAS && P.gelu) v[q][j] = gelu_tanh_f(v[q][j]);  // block-uniform
+                }
+            if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+                u32x2 ra = {rr[mt][pr][0], rr[mt][pr][1]}, rb = {rr[mt][pr][2], rr[mt][pr][3]};
+                swap_pair(ra, rb);  // 16-byte row segment -> accumulator layout
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x2 r2 = q ? rb : ra;
+                    v[q][0] = bf16_lo(r2[0]) + gt[g0 + q][0] * v[q][0];
+                    v[q][1] = bf16_hi(r2[0]) + gt[g0 + q][1] * v[q][1];
+                    v[q][2] = bf16_lo(r2[1]) + gt[g0 + q][2] * v[q][2];
+                    v[q][3] = bf16_hi(r2[1]) + gt[g0 + q][3] * v[q][3];
+                }
+            }
+            u32x2 oa = {pack_bf16(v[0][0], v[0][1]), pack_bf16(v[0][2], v[0][3])};
+            u32x2 ob = {pack_bf16(v[1][0], v[1][1]), pack_bf16(v[1][2], v[1][3])};
+            swap_pair(oa, ob);
+            if (m[mt] >= 0 && nst < N) {
+                const u32x4 o = {oa[0], oa[1], ob[0], ob[1]};
+                *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;
+            }
+        }
 }
 
 template <typename CFG, int EPI>
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         if (i < G.count && s >= G.p[i].tile0) gi = i;
     const GemmProblem& P = G.p[gi];
     s -= P.tile0;
-    const int nn = G.nn, N = G.N, M = P.M;
+    const int nn = P.nn, N = P.N, M = P.M;
     const int width = GROUP_M * nn;
     const int first_m = (s / width) * GROUP_M;
     const int gsz = min(P.nm - first_m, GROUP_M);
@@ -210,7 +227,10 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     if constexpr (!CFG::PP) {
         stage(0, 0);
         for (int kt = 0; kt < nkt; ++kt) {
-            __syncthreads();  // tile kt landed (vmcnt(0) by the compiler) and the other buffer is free
+            // tile kt's LDS-DMA landed (explicit: hipcc's __syncthreads() does not reliably wait for
+            // LDS-DMA, see attention.hip) and the other buffer is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
             const char* As = smem + (kt & 1) * CFG::STAGE;
             const char* Ws = As + CFG::A_BYTES;
@@ -360,14 +380,15 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     }
 
     // ---- epilogue ----
+    int mrow[TM];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-        int m = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
-        if (m >= M) m = -1;  // keep the lane alive for the cross-lane exchange, store nothing
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-            store_tile<EPI>(acc[nt][mt], P, N, m, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
+        mrow[mt] = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
+        if (mrow[mt] >= M) mrow[mt] = -1;  // lane stays alive for the cross-lane exchange, stores nothing
     }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+        store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
 }
 
 int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P
@@ -380,13 +401,13 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
         attr_set = true;
     }
-    G.nn = (G.N + CFG::BN - 1) / CFG::BN;
     int t = 0;
     for (int i = 0; i < G.count; ++i) {
         G.p[i].M = Ms[i];
         G.p[i].nm = (Ms[i] + CFG::BM - 1) / CFG::BM;
+        G.p[i].nn = (G.p[i].N + CFG::BN - 1) / CFG::BN;
         G.p[i].tile0 = t;
-        t += G.p[i].nm * G.nn;
+        t += G.p[i].nm * G.p[i].nn;
     }
     G.total = t;
     hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t), dim3(CFG::NT), CFG::LDS, stream, G);
@@ -398,9 +419,13 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     int cfg = g_force_cfg;
     if (cfg == 0) {
         int64_t mtot = 0;
-        for (int i = 0; i < G.count; ++i) mtot += Ms[i];
+        int nmax = 0;
+        for (int i = 0; i < G.count; ++i) {
+            mtot += Ms[i];
+            nmax = G.p[i].N > nmax ? G.p[i].N : nmax;
+        }
         // large problems: 256x256 tiles, one per CU per round; otherwise the 128x128 tiling
-        cfg = (mtot >= 1024 && G.N >= 1024 && G.K >= 256) ? 3 : 1;
+        cfg = (mtot >= 1024 && nmax >= 1024 && G.K >= 256) ? 3 : 1;
     }
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
@@ -410,13 +435,9 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     }
 }
 
-int launch_group(GemmGroup& G, const int* Ms, int epilogue, hipStream_t stream) {
-    switch (epilogue) {
-        case APEXMI_EPI_BIAS: return launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
-        case APEXMI_EPI_BIAS_GELU: return launch_epi<APEXMI_EPI_BIAS_GELU>(G, Ms, stream);
-        case APEXMI_EPI_BIAS_GATE_RES: return launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream);
-        default: apexmi_set_error("gemm_bf16: unknown epilogue %d", epilogue); return 1;
-    }
+int launch_group(GemmGroup& G, const int* Ms, bool gate_res, hipStream_t stream) {
+    return gate_res ? launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream)
+                    : launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
 }
 
 int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
@@ -445,46 +466,56 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                                 apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
+    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 2, "gemm_bf16: unknown epilogue %d", epilogue);
     GemmGroup G;
     G.count = 1;
-    G.N = N;
     G.K = K;
     G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, gate,
-                         (const bf16_t*)R, lda, ldw, ldc, ldr, M, 0, 0};
+                         (const bf16_t*)R, lda, ldw, ldc, ldr, M, N, 0, 0, 0,
+                         epilogue == APEXMI_EPI_BIAS_GELU};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch_group(G, &M, epilogue, stream);
+    return launch_group(G, &M, epilogue == APEXMI_EPI_BIAS_GATE_RES, stream);
 }
 
 extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda,
                                         const void* const* W, const int64_t* ldw,
                                         const void* const* bias, void* const* C, const int64_t* ldc,
-                                        const int* M, int N, int K, int epilogue,
+                                        const int* M, const int* N, int K, const int* epilogue,
                                         const float* const* gate, const void* const* R,
                                         const int64_t* ldr, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(count >= 1 && count <= MAX_GROUPS, "gemm_bf16_grouped: count=%d not in [1,%d]", count, MAX_GROUPS);
     GemmGroup G;
     G.count = count;
-    G.N = N;
     G.K = K;
     double flops = 0, bytes = 0;
+    const bool gate_res = epilogue[0] == APEXMI_EPI_BIAS_GATE_RES;
     for (int i = 0; i < count; ++i) {
+        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 2 && (epilogue[i] == APEXMI_EPI_BIAS_GATE_RES) == gate_res,
+                       "gemm_bf16_grouped: gate/residual problems cannot be mixed with bias/gelu ones");
         const float* g = gate ? gate[i] : nullptr;
         const void* r = R ? R[i] : nullptr;
         const int64_t lr = ldr ? ldr[i] : 0;
-        if (int rc = check_problem(A[i], lda[i], W[i], ldw[i], C[i], ldc[i], M[i], N, K, epilogue, g, r, lr))
+        if (int rc = check_problem(A[i], lda[i], W[i], ldw[i], C[i], ldc[i], M[i], N[i], K, epilogue[i], g, r, lr))
             return rc;
         G.p[i] = GemmProblem{(const bf16_t*)A[i], (const bf16_t*)W[i], (const bf16_t*)(bias ? bias[i] : nullptr),
-                             (bf16_t*)C[i], g, (const bf16_t*)r, lda[i], ldw[i], ldc[i], lr, M[i], 0, 0};
-        flops += 2.0 * M[i] * N * (double)K;
-        bytes += 2.0 * ((double)M[i] * K + (double)N * K + (double)M[i] * N);
+                             (bf16_t*)C[i], g, (const bf16_t*)r, lda[i], ldw[i], ldc[i], lr, M[i], N[i], 0, 0, 0,
+                             epilogue[i] == APEXMI_EPI_BIAS_GELU};
+        flops += 2.0 * M[i] * N[i] * (double)K;
+        bytes += 2.0 * ((double)M[i] * K + (double)N[i] * K + (double)M[i] * N[i]);
     }
     ApexmiProfScope prof(0, stream, flops, bytes);
-    return launch_group(G, M, epilogue, stream);
+    return launch_group(G, M, gate_res, stream);
 }
 
+void apexmi_set_attn_waves(int v);
+
 extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (key && !strcmp(key, "attn.waves")) {
+        apexmi_set_attn_waves(value);
+        return 0;
+    }
     if (key && !strcmp(key, "gemm.config")) {
         g_force_cfg = value;
         return 0;

@@ -374,8 +374,9 @@ class FluxTransformer2DModel(nn.Module):
             a = blk.attn
             ms = lambda j: self._mod(ws, ("s", i), j)  # noqa: E731  (shift, scale, gate)
             ops.ln_modulate(X, ms(1), ms(0), out=XN)
-            ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
-            ops.gemm(XN, blk.proj_mlp.weight, blk.proj_mlp.bias, out=CAT[:, dim:], epilogue="gelu")
+            # QKV and MLP-up read the same XN: one launch, 1512 tiles = 5.9 rounds of the 256 CUs
+            ops.gemm_grouped([XN, XN], [blk._wqkv, blk.proj_mlp.weight], [blk._bqkv, blk.proj_mlp.bias],
+                             [QKV, CAT[:, dim:]], epilogue=["bias", "gelu"])
             ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
                             wk=a.norm_k.weight, split=0, eps=1e-6, rope=rope,
                             rope_mode=_l.ROPE_INTERLEAVED)

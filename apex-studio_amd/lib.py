@@ -31,8 +31,8 @@ SIGNATURES = {
                                    C.c_int, C.c_int, vp, vp, C.c_int64, vp]),
     "apexmi_gemm_bf16_grouped": (C.c_int, [C.c_int, C.POINTER(vp), c_i64p, C.POINTER(vp), c_i64p,
                                            C.POINTER(vp), C.POINTER(vp), c_i64p, C.POINTER(C.c_int),
-                                           C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp),
-                                           c_i64p, vp]),
+                                           C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(vp),
+                                           C.POINTER(vp), c_i64p, vp]),
     "apexmi_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                               C.c_int, C.c_int, vp]),

@@ -63,35 +63,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     return out
 
 
-def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue: str = "bias", gate_list=None,
+def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list=None,
                  residual_list=None) -> None:
-    """Several gemm() problems sharing (N, K, epilogue) in one launch (img/txt streams)."""
+    """Several gemm() problems sharing K in one launch (img/txt streams; QKV + MLP-up of a single
+    block).  `epilogue` is one name or a list with one name per problem."""
     import ctypes as C
     n = len(a_list)
-    N, K = w_list[0].shape
+    K = w_list[0].shape[1]
+    epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
     for a, w, o in zip(a_list, w_list, out_list):
         _req(a, torch.bfloat16, "gemm_grouped.a")
         _req(w, torch.bfloat16, "gemm_grouped.w")
         _req(o, torch.bfloat16, "gemm_grouped.out")
         assert a.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and o.stride(1) == 1
-        assert w.shape == (N, K) and a.shape[1] == K and o.shape == (a.shape[0], N)
+        assert w.shape[1] == K and a.shape[1] == K and o.shape == (a.shape[0], w.shape[0])
     VP = C.c_void_p * n
     I64 = C.c_int64 * n
+    INT = C.c_int * n
     none = [None] * n
     bias_list = bias_list or none
     gate_list = gate_list or none
     residual_list = residual_list or none
-    if epilogue == "gate_res":
-        for g, r, o in zip(gate_list, residual_list, out_list):
+    for e, g, r, o, w in zip(epis, gate_list, residual_list, out_list, w_list):
+        if e == "gate_res":
             _req(g, torch.float32, "gemm_grouped.gate")
             _req(r, torch.bfloat16, "gemm_grouped.residual")
-            assert g.is_contiguous() and g.numel() == N and r.shape == o.shape and r.stride(1) == 1
+            assert g.is_contiguous() and g.numel() == w.shape[0] and r.shape == o.shape and r.stride(1) == 1
     rc = _l.load().apexmi_gemm_bf16_grouped(
         n, VP(*[a.data_ptr() for a in a_list]), I64(*[a.stride(0) for a in a_list]),
         VP(*[w.data_ptr() for w in w_list]), I64(*[w.stride(0) for w in w_list]),
         VP(*[_ptr(b) for b in bias_list]), VP(*[o.data_ptr() for o in out_list]),
-        I64(*[o.stride(0) for o in out_list]), (C.c_int * n)(*[a.shape[0] for a in a_list]), N, K,
-        _EPI[epilogue], VP(*[_ptr(g) for g in gate_list]), VP(*[_ptr(r) for r in residual_list]),
+        I64(*[o.stride(0) for o in out_list]), INT(*[a.shape[0] for a in a_list]),
+        INT(*[w.shape[0] for w in w_list]), K, INT(*[_EPI[e] for e in epis]),
+        VP(*[_ptr(g) for g in gate_list]), VP(*[_ptr(r) for r in residual_list]),
         I64(*[(r.stride(0) if r is not None else 0) for r in residual_list]), _stream())
     _l.check(rc, "gemm_bf16_grouped")
 

@@ -95,18 +95,24 @@ int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, con
                      void* C, int64_t ldc, int M, int N, int K, int epilogue,
                      const float* gate, const void* R, int64_t ldr, apexmi_stream_t stream);
 
-/* Up to 4 problems that share (N, K, epilogue) in ONE launch: the image and text streams of an
- * MM-DiT double block have separate weights but identical shapes (flux model.py:245-263), and
- * launching them together fills the 256 CUs instead of leaving the 512-row text GEMM on 28 % of
- * the chip.  Arrays are host arrays of length `count`; bias/gate/R/ldr may be NULL. */
+/* Up to 4 problems that share K in ONE launch (per-problem M, N and epilogue; gate/residual
+ * problems cannot be mixed with bias/gelu ones).  Two uses on the Flux path:
+ *  - the image and text streams of an MM-DiT double block have separate weights but identical
+ *    shapes (flux model.py:245-263); together they fill the 256 CUs instead of leaving the 512-row
+ *    text GEMM on 28 % of the chip;
+ *  - the single block's QKV projection and its MLP-up projection read the same normalised input
+ *    (model.py:207-214); as one launch they are 1512 tiles = 5.9 rounds of 256 CUs instead of
+ *    3 + 4 rounds.
+ * Arrays are host arrays of length `count`; bias/gate/R/ldr may be NULL. */
 int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda,
                              const void* const* W, const int64_t* ldw, const void* const* bias,
-                             void* const* C, const int64_t* ldc, const int* M, int N, int K,
-                             int epilogue, const float* const* gate, const void* const* R,
+                             void* const* C, const int64_t* ldc, const int* M, const int* N, int K,
+                             const int* epilogue, const float* const* gate, const void* const* R,
                              const int64_t* ldr, apexmi_stream_t stream);
 
 /* Tuning knobs for A/B measurements (bench.py, tests): "gemm.config" = 0 auto | 1 128x128 |
- * 2 256x256 | 3 256x256 ping-pong. Returns non-zero for an unknown key. */
+ * 2 256x256 | 3 256x256 ping-pong; "attn.waves" = 0 auto | 4 | 8 waves per attention workgroup.
+ * Returns non-zero for an unknown key. */
 int apexmi_tune_set(const char* key, int value);
 
 /* y[m, n] = post( dot(W[n, :], pre(x[m, :])) + bias[n] ) for tiny M (conditioning vectors:

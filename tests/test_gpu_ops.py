@@ -150,6 +150,26 @@ def test_gemm_grouped(cfg, gemm_config):
     _check(x[:Mt], x0[:Mt] + gt.cpu() * (at.float() @ wt.float().T + bt.float()), 3e-3, "grouped txt gate")
 
 
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_gemm_grouped_mixed_n_and_epilogue(cfg, gemm_config):
+    """QKV (bias) + MLP-up (gelu) of a single block: same input, different N, one launch."""
+    ops = _ops()
+    gemm_config(cfg)
+    M, K, N1, N2 = 1100, 256, 768, 1024
+    a = _bf(seeded((M, K), 1))
+    w1, w2 = _bf(seeded((N1, K), 2, scale=K ** -0.5)), _bf(seeded((N2, K), 3, scale=K ** -0.5))
+    b1, b2 = _bf(seeded((N1,), 4)), _bf(seeded((N2,), 5))
+    o1 = torch.empty(M, N1, dtype=torch.bfloat16, device=DEV)
+    cat = torch.zeros(M, 256 + N2, dtype=torch.bfloat16, device=DEV)
+    ag = a.to(DEV)
+    ops.gemm_grouped([ag, ag], [w1.to(DEV), w2.to(DEV)], [b1.to(DEV), b2.to(DEV)], [o1, cat[:, 256:]],
+                     epilogue=["bias", "gelu"])
+    _check(o1, a.float() @ w1.float().T + b1.float(), 3e-3, "grouped qkv")
+    _check(cat[:, 256:], torch.nn.functional.gelu(a.float() @ w2.float().T + b2.float(), approximate="tanh"),
+           3e-3, "grouped mlp")
+    assert torch.equal(cat[:, :256].cpu(), torch.zeros(M, 256, dtype=torch.bfloat16))
+
+
 def test_gemm_flux_shapes_against_gpu_fp32():
     ops = _ops()
     for (M, N, K) in [(4608, 9216, 3072), (4608, 3072, 15360), (512, 12288, 3072)]:
@@ -342,6 +362,21 @@ def test_attention_mfma_vs_oracle(B, H, Sq, Sk):
     _check(out, ref, 1e-2, f"attention {B}x{H}x{Sq}x{Sk}", ulp=3.0)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
+def test_attention_workgroup_sizes(waves):
+    from apex_studio_amd import lib
+    ops = _ops()
+    q = seeded((1, 2, 700, 128), 85, torch.bfloat16)
+    k = seeded((1, 2, 333, 128), 86, torch.bfloat16)
+    v = seeded((1, 2, 333, 128), 87, torch.bfloat16)
+    lib.tune_set("attn.waves", waves)
+    try:
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    finally:
+        lib.tune_set("attn.waves", 0)
+    _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention {waves} waves", ulp=3.0)
+
+
 def test_attention_online_softmax_rescale_spike():
     """Force the running max to jump at a late KV tile (guide §5.4 rule 26)."""
     ops = _ops()
@@ -350,6 +385,7 @@ def test_attention_online_softmax_rescale_spike():
     k = seeded((1, H, S, 128), 92, torch.bfloat16)
     v = seeded((1, H, S, 128), 93, torch.bfloat16)
     k[0, :, 400] = (q[0, :, 17].float() * 4).to(torch.bfloat16)  # key 400 dominates query 17
+    k[0, :, 130] = (q[0, :, 300].float() * 0.6).to(torch.bfloat16)  # modest jump (below the defer threshold)
     out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     ref = OL.sdpa(q.float(), k.float(), v.float())
     _check(out, ref, 1e-2, "attention spike", ulp=3.0)

@@ -61,10 +61,15 @@ def main():
         k = torch.randn(1, H, S, 128, generator=g, device=DEV).to(torch.bfloat16)
         vt = torch.randn(1, H, 128, S, generator=g, device=DEV).to(torch.bfloat16)
         o = torch.empty(1, S, H, 128, device=DEV, dtype=torch.bfloat16)
+        res = {}
+        for w in (4, 8):
+            lib.tune_set("attn.waves", w)
+            res[w] = round(4.0 * H * S * S * 128 / (timeit(lambda: ops.attention_prepared(q, k, vt, o, S)) * 1e-3) / 1e12, 1)
+        lib.tune_set("attn.waves", 0)
         ms = timeit(lambda: ops.attention_prepared(q, k, vt, o, S))
         v = vt.transpose(2, 3).contiguous()
         ref_ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v), iters=5)
-        print(json.dumps({"attention": [H, S], "tflops": round(4.0 * H * S * S * 128 / (ms * 1e-3) / 1e12, 1),
+        print(json.dumps({"attention": [H, S], "tflops": round(4.0 * H * S * S * 128 / (ms * 1e-3) / 1e12, 1), "by_waves": res,
                           "torch_sdpa_tflops": round(4.0 * H * S * S * 128 / (ref_ms * 1e-3) / 1e12, 1)}), flush=True)
 
 
