@@ -11,25 +11,39 @@ namespace {
 // Reference: AdaLayerNormZero / Single / Continuous, flux model.py:299-302,
 // wan model.py:56-165 (FP32LayerNorm + scale/shift), efficiency/mod.py:24-35 (RMSNorm).
 // ------------------------------------------------------------------------------------------------
-constexpr int LN_MAX_IT = 16;  // 16 * 64 lanes * 8 elements = 8192
+constexpr int LN_MAX_C = 8192;
 
-// NIT = 16-byte chunks per lane (ceil(C / 512)); a template parameter so a 3072-wide row costs 48
-// data registers instead of 128 and 7-8 waves per SIMD keep enough loads in flight for HBM.
+// One 256-thread workgroup per row; NIT = 16-byte chunks per thread (ceil(C / 2048)).  A row per
+// workgroup (instead of a row per wave) puts 4x more waves on the chip for the 4608-row Flux buffers,
+// which is what an HBM-latency-bound pass needs; the two statistics cost two LDS reductions.
+APEXMI_DEVICE float block_sum_256(float x, float* red) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from the previous reduction's readers
+    if ((threadIdx.x & 63) == 0) red[w] = x;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
 template <int NIT>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
     const float* __restrict__ scale, const float* __restrict__ shift,
-    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms, int split,
+    const float* __restrict__ scale2, const float* __restrict__ shift2) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    if (row < split) {  // rows [0, split) take the second modulation set (text stream of a joint buffer)
+        scale = scale2;
+        shift = shift2;
+    }
     const int nchunk = C >> 3;
     const bf16_t* xp = x + (int64_t)row * ldx;
     float v[NIT][8];
     float sum = 0.0f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane;
+        const int c = it * 256 + threadIdx.x;
         if (c < nchunk) {
             const u32x4 raw = *(const u32x4*)(xp + c * 8);
             unpack8(raw, v[it]);
@@ -41,11 +55,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
         }
     }
     float mean = 0.0f;
-    if (!rms) mean = wave_sum(sum) / (float)C;
+    if (!rms) mean = block_sum_256(sum, red) / (float)C;
     float sq = 0.0f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane;
+        const int c = it * 256 + threadIdx.x;
         if (c < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -54,11 +68,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = rsqrtf(block_sum_256(sq, red) / (float)C + eps);
     bf16_t* op = out + (int64_t)row * ldo;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane;
+        const int c = it * 256 + threadIdx.x;
         if (c < nchunk) {
             float y[8];
 #pragma unroll
@@ -351,29 +365,36 @@ __global__ void euler_step_kernel(const void* __restrict__ sample, const bf16_t*
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
                                   const float* scale, const float* shift, const void* gamma,
                                   const void* beta, float eps, int rms, apexmi_stream_t stream_) {
+    return apexmi_ln_modulate2(x, ldx, out, ldo, M, C, scale, shift, gamma, beta, eps, rms, 0, nullptr,
+                               nullptr, stream_);
+}
+
+extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                                   const float* scale, const float* shift, const void* gamma,
+                                   const void* beta, float eps, int rms, int split,
+                                   const float* scale2, const float* shift2, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(split >= 0 && split <= M, "ln_modulate: split=%d outside [0, M]", split);
+    APEXMI_REQUIRE(split == 0 || ((!scale2 || ((uintptr_t)scale2 % 16) == 0) && (!shift2 || ((uintptr_t)shift2 % 16) == 0)),
+                   "ln_modulate: scale2/shift2 must be 16-byte aligned");
     APEXMI_REQUIRE(x && out, "ln_modulate: null operand");
     APEXMI_REQUIRE(M > 0 && C > 0, "ln_modulate: empty problem");
-    APEXMI_REQUIRE(C % 8 == 0 && C <= LN_MAX_IT * 512, "ln_modulate: C=%d must be a multiple of 8 and <= %d", C,
-                   LN_MAX_IT * 512);
+    APEXMI_REQUIRE(C % 8 == 0 && C <= LN_MAX_C, "ln_modulate: C=%d must be a multiple of 8 and <= %d", C,
+                   LN_MAX_C);
     APEXMI_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0,
                    "ln_modulate: rows must be 16-byte aligned");
     APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
                    "ln_modulate: scale/shift must be 16-byte aligned");
     ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)M * C);
-    const int nit = (C / 8 + 63) / 64;
-#define LN_LAUNCH(N)                                                                                     \
-    hipLaunchKernelGGL(ln_modulate_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, \
-                       ldx, (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,                 \
-                       (const bf16_t*)beta, eps, rms)
+    const int nit = (C / 8 + 255) / 256;
+#define LN_LAUNCH(N)                                                                                  \
+    hipLaunchKernelGGL(ln_modulate_kernel<N>, dim3(M), dim3(256), 0, stream, (const bf16_t*)x, ldx,   \
+                       (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,                   \
+                       (const bf16_t*)beta, eps, rms, split, scale2, shift2)
     if (nit <= 1) LN_LAUNCH(1);
     else if (nit <= 2) LN_LAUNCH(2);
-    else if (nit <= 4) LN_LAUNCH(4);
-    else if (nit <= 6) LN_LAUNCH(6);
-    else if (nit <= 8) LN_LAUNCH(8);
-    else if (nit <= 10) LN_LAUNCH(10);
-    else if (nit <= 12) LN_LAUNCH(12);
-    else LN_LAUNCH(16);
+    else if (nit <= 3) LN_LAUNCH(3);
+    else LN_LAUNCH(4);
 #undef LN_LAUNCH
     return apexmi_check_launch("ln_modulate");
 }

@@ -176,6 +176,7 @@ class FluxTransformer2DModel(nn.Module):
         self.proj_out = _Linear(dim, patch_size * patch_size * self.out_channels, **kw)
         self._packed = False
         self._ws: Dict[Any, Any] = {}
+        self._side = None
 
     # ---- reference-compatible plumbing -------------------------------------------------------
     @classmethod
@@ -275,6 +276,11 @@ class FluxTransformer2DModel(nn.Module):
         _repoint(mods_w, self._mod_w)
         _repoint(mods_b, self._mod_b)
         self._mod_total = off
+        # rows of the first block that runs (its modulation is needed before the side stream is joined)
+        offs = sorted(self._mod_off.values())
+        self._mod_first = offs[1] if len(offs) > 1 else off
+        if self.transformer_blocks and len(offs) > 2:
+            self._mod_first = offs[2]  # img + txt projections of double block 0
         self._packed = True
 
     def _workspace(self, s_txt: int, s_img: int):
@@ -333,8 +339,24 @@ class FluxTransformer2DModel(nn.Module):
             g = (guidance.to(self.dtype) * 1000).float().reshape(1)
             self._embed_t(tte.guidance_embedder, ops.timestep_embedding(g, 256), ws.TEMB, accum=True)
         self._embed_t(tte.text_embedder, pooled.float().reshape(1, -1), ws.TEMB, accum=True)
-        # every AdaLN projection of every block in one weight-streaming pass
-        ops.gemv(self._mod_w, ws.TEMB, self._mod_b, out=ws.MOD, pre_silu=True)
+        # Every AdaLN projection of every block is one weight-streaming GEMV (6.4 GB for FLUX-dev).
+        # Only the first block's slice is needed right away: the rest streams on a side HIP stream
+        # underneath the first block's MFMA-bound GEMMs and is joined before the second block.
+        n_first = self._mod_first
+        ops.gemv(self._mod_w[:n_first], ws.TEMB, self._mod_b[:n_first], out=ws.MOD[:, :n_first], pre_silu=True)
+        mod_ready = None
+        if n_first < self._mod_total:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                ops.gemv(self._mod_w[n_first:], ws.TEMB, self._mod_b[n_first:], out=ws.MOD[:, n_first:],
+                         pre_silu=True)
+                mod_ready = torch.cuda.Event()
+                mod_ready.record(self._side)
 
         ids = torch.cat((txt_ids, img_ids), dim=0).float()
         rope = ops.rope_table_axes(ids, cfg.axes_dims_rope, 10000.0)
@@ -344,13 +366,23 @@ class FluxTransformer2DModel(nn.Module):
         att = CAT[:, :dim]
         att_v = att.unflatten(-1, (H, 128)).unsqueeze(0)  # [1, S, H, 128] strided view
 
+        nblk = 0
+
+        def join_mod():
+            nonlocal mod_ready
+            if mod_ready is not None:
+                torch.cuda.current_stream().wait_event(mod_ready)
+                mod_ready = None
+
         for i, blk in enumerate(self.transformer_blocks):
+            if nblk == 1:
+                join_mod()
+            nblk += 1
             a = blk.attn
             mi = lambda j: self._mod(ws, ("d", i, "img"), j)  # noqa: E731
             mt = lambda j: self._mod(ws, ("d", i, "txt"), j)  # noqa: E731
             # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-            ops.ln_modulate(Xi, mi(1), mi(0), out=XNi)
-            ops.ln_modulate(Xt, mt(1), mt(0), out=XNt)
+            ops.ln_modulate(X, mi(1), mi(0), out=XN, split=s_txt, scale2=mt(1), shift2=mt(0))
             ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
                              [QKV[s_txt:], QKV[:s_txt]])
             ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
@@ -360,8 +392,7 @@ class FluxTransformer2DModel(nn.Module):
             ops.gemm_grouped([att[s_txt:], att[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
                              [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",
                              gate_list=[mi(2), mt(2)], residual_list=[Xi, Xt])
-            ops.ln_modulate(Xi, mi(4), mi(3), out=XNi)
-            ops.ln_modulate(Xt, mt(4), mt(3), out=XNt)
+            ops.ln_modulate(X, mi(4), mi(3), out=XN, split=s_txt, scale2=mt(4), shift2=mt(3))
             ff, ffc = blk.ff.net, blk.ff_context.net
             ops.gemm_grouped([XNi, XNt], [ff[0].proj.weight, ffc[0].proj.weight],
                              [ff[0].proj.bias, ffc[0].proj.bias], [FFH[s_txt:], FFH[:s_txt]],
@@ -371,6 +402,9 @@ class FluxTransformer2DModel(nn.Module):
                              gate_list=[mi(5), mt(5)], residual_list=[Xi, Xt])
 
         for i, blk in enumerate(self.single_transformer_blocks):
+            if nblk == 1:
+                join_mod()
+            nblk += 1
             a = blk.attn
             ms = lambda j: self._mod(ws, ("s", i), j)  # noqa: E731  (shift, scale, gate)
             ops.ln_modulate(X, ms(1), ms(0), out=XN)
@@ -384,6 +418,7 @@ class FluxTransformer2DModel(nn.Module):
             ops.gemm(CAT, blk.proj_out.weight, blk.proj_out.bias, out=X, epilogue="gate_res", gate=ms(2),
                      residual=X)
 
+        join_mod()
         # AdaLayerNormContinuous: scale first, then shift
         ops.ln_modulate(Xi, self._mod(ws, ("out",), 0), self._mod(ws, ("out",), 1), out=XNi)
         out = torch.empty(s_img, self.proj_out.out_features, device=X.device, dtype=torch.bfloat16)

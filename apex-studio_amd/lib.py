@@ -38,6 +38,8 @@ SIGNATURES = {
                               C.c_int, C.c_int, vp]),
     "apexmi_ln_modulate": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp,
                                      C.c_float, C.c_int, vp]),
+    "apexmi_ln_modulate2": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp,
+                                      C.c_float, C.c_int, C.c_int, vp, vp, vp]),
     "apexmi_qkv_prepare": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                      vp, vp, C.c_float, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                      C.c_int, vp]),

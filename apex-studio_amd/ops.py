@@ -138,8 +138,10 @@ def gemv(w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None,
 def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-                eps: float = 1e-6, rms: bool = False) -> torch.Tensor:
-    """out = LayerNorm(x) [*gamma + beta] * (1 + scale) + shift, or RMSNorm(x) * gamma."""
+                eps: float = 1e-6, rms: bool = False, split: int = 0,
+                scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = LayerNorm(x) [*gamma + beta] * (1 + scale) + shift, or RMSNorm(x) * gamma.
+    Rows [0, split) use (scale2, shift2) instead (text rows of a joint buffer)."""
     _req(x, torch.bfloat16, "ln_modulate.x")
     assert x.dim() == 2 and x.stride(1) == 1
     M, Cc = x.shape
@@ -148,7 +150,7 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
     else:
         _req(out, torch.bfloat16, "ln_modulate.out")
         assert out.shape == (M, Cc) and out.stride(1) == 1
-    for t, nm in ((scale, "scale"), (shift, "shift")):
+    for t, nm in ((scale, "scale"), (shift, "shift"), (scale2, "scale2"), (shift2, "shift2")):
         if t is not None:
             _req(t, torch.float32, "ln_modulate." + nm)
             assert t.is_contiguous() and t.numel() == Cc
@@ -156,9 +158,9 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
         if t is not None:
             _req(t, torch.bfloat16, "ln_modulate." + nm)
             assert t.is_contiguous() and t.numel() == Cc
-    rc = _l.load().apexmi_ln_modulate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, Cc,
-                                      _ptr(scale), _ptr(shift), _ptr(gamma), _ptr(beta), float(eps),
-                                      1 if rms else 0, _stream())
+    rc = _l.load().apexmi_ln_modulate2(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, Cc,
+                                       _ptr(scale), _ptr(shift), _ptr(gamma), _ptr(beta), float(eps),
+                                       1 if rms else 0, int(split), _ptr(scale2), _ptr(shift2), _stream())
     _l.check(rc, "ln_modulate")
     return out
 

@@ -135,6 +135,13 @@ int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M
                        const float* scale, const float* shift, const void* gamma,
                        const void* beta, float eps, int rms, apexmi_stream_t stream);
 
+/* Same, over a joint [text rows | image rows] buffer: rows < split use (scale2, shift2) — the two
+ * streams of an MM-DiT double block in one launch (norm1/norm1_context, norm2/norm2_context). */
+int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                        const float* scale, const float* shift, const void* gamma, const void* beta,
+                        float eps, int rms, int split, const float* scale2, const float* shift2,
+                        apexmi_stream_t stream);
+
 /* Per-head RMSNorm on q,k + rotary embedding, written in attention layout, and V transposed.
  * Replaces the unflatten / norm_q / norm_k / cat / apply_rotary_emb / permute chain of
  * FluxAttnProcessor.__call__ (transformer/flux/base/attention.py:62-94).

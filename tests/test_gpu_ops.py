@@ -228,6 +228,17 @@ def test_ln_modulate(M, C):
     _check(out, n(x.float()), 3e-3, "rmsnorm")
 
 
+def test_ln_modulate_split_streams():
+    ops = _ops()
+    M, C, split = 150, 3072, 37
+    x = _bf(seeded((M, C), 46) * 2)
+    sc, sh, sc2, sh2 = (seeded((C,), 47 + i) * 0.3 for i in range(4))
+    out = ops.ln_modulate(x.to(DEV), sc.to(DEV), sh.to(DEV), split=split, scale2=sc2.to(DEV), shift2=sh2.to(DEV))
+    ln = torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6)
+    ref = torch.cat([ln[:split] * (1 + sc2) + sh2, ln[split:] * (1 + sc) + sh])
+    _check(out, ref, 3e-3, "ln_modulate split")
+
+
 def test_rmsnorm_matches_reference_golden(golden_dir):
     ops = _ops()
     c = torch.load(os.path.join(golden_dir, "efficiency_ops.pt"), weights_only=False)["rmsnorm_bf16"]
