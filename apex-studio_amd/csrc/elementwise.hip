@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
     constexpr int D = 128;
     const int64_t unit = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
-    const int64_t nunit = (int64_t)S * 2 * H;
+    const int nk = (k != nullptr) ? 2 : 1;  // q only (cross-attention query / key sides are separate calls)
+    const int64_t nunit = (int64_t)S * nk * H;
     const bool live = unit < nunit;
     const int64_t u = live ? unit : nunit - 1;
-    const int s = (int)(u / (2 * H));
-    const int rem = (int)(u % (2 * H));
+    const int s = (int)(u / (nk * H));
+    const int rem = (int)(u % (nk * H));
     const int which = rem / H, h = rem % H;
     const int d = l16 * 8;
     const bf16_t* src = (which ? k : q) + (int64_t)s * ld_in + h * D + d;
@@ -337,6 +338,13 @@ __global__ void rope_table_axes_kernel(const float* __restrict__ ids, int S, Axe
     sp[1] = sn;
 }
 
+// out[l][i] = a[l][i] + b[i]  (per-block modulation tables + the step's timestep projection)
+__global__ void add_bcast_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                     float* __restrict__ out, int64_t rows, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * n) out[i] = a[i] + b[i % n];
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ o, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = f32_to_bf16(x[i]);
@@ -433,17 +441,17 @@ extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, i
                                   int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
                                   int row0, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    APEXMI_REQUIRE(q && k && qo && ko, "qkv_prepare: null operand");
+    APEXMI_REQUIRE(q && qo && (!k || ko), "qkv_prepare: null operand");
     APEXMI_REQUIRE(D == 128, "qkv_prepare: D=%d unsupported (128 only)", D);
     APEXMI_REQUIRE(S > 0 && H > 0 && row0 >= 0 && row0 + S <= S_out, "qkv_prepare: bad row range");
-    APEXMI_REQUIRE(ld_in % 8 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0,
+    APEXMI_REQUIRE(ld_in % 8 == 0 && ((uintptr_t)q % 16) == 0 && (!k || ((uintptr_t)k % 16) == 0),
                    "qkv_prepare: rows must be 16-byte aligned");
     APEXMI_REQUIRE(rope_mode == APEXMI_ROPE_NONE || (rope && ((uintptr_t)rope % 16) == 0),
                    "qkv_prepare: rope table missing or misaligned");
     APEXMI_REQUIRE(split <= 0 || (wq2 && wk2) || (!wq && !wk), "qkv_prepare: split needs the second weight set");
     {
         ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D);
-        const int64_t nunit = (int64_t)S * 2 * H;
+        const int64_t nunit = (int64_t)S * (k ? 2 : 1) * H;
         hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
                            (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
                            (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
@@ -501,6 +509,16 @@ extern "C" int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const
     hipLaunchKernelGGL(rope_table_axes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, S, ax, D,
                        log((double)theta), out);
     return apexmi_check_launch("rope_table_axes");
+}
+
+extern "C" int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t rows, int64_t n,
+                                    apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && out && rows > 0 && n > 0, "add_bcast_f32: bad arguments");
+    ApexmiProfScope prof(5, stream, 0.0, 8.0 * rows * n);
+    hipLaunchKernelGGL(add_bcast_f32_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, stream, a, b,
+                       out, rows, n);
+    return apexmi_check_launch("add_bcast_f32");
 }
 
 extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {

@@ -48,6 +48,7 @@ SIGNATURES = {
     "apexmi_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                             vp]),
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
+    "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
     "apexmi_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_euler_step": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_int, vp]),

@@ -176,8 +176,9 @@ def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: 
     S = q.shape[0]
     D = q.shape[1] // H
     ld = q.stride(0)
-    assert k.stride(0) == ld and (v is None or v.stride(0) == ld)
-    assert qo.is_contiguous() and ko.is_contiguous() and qo.shape == ko.shape and qo.shape[0] == H
+    assert (k is None or k.stride(0) == ld) and (v is None or v.stride(0) == ld)
+    assert qo.is_contiguous() and qo.shape[0] == H
+    assert k is None or (ko.is_contiguous() and qo.shape == ko.shape)
     S_out = qo.shape[1]
     Skp = 0
     if vt is not None:
@@ -186,9 +187,9 @@ def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: 
     if rope is not None:
         _req(rope, torch.float32, "qkv_prepare.rope")
         assert rope.is_contiguous()
-    rc = _l.load().apexmi_qkv_prepare(q.data_ptr(), k.data_ptr(), _ptr(v), ld, S, H, D, split,
+    rc = _l.load().apexmi_qkv_prepare(q.data_ptr(), _ptr(k), _ptr(v), ld, S, H, D, split,
                                       _ptr(wq), _ptr(wk), _ptr(wq2), _ptr(wk2), float(eps),
-                                      _ptr(rope), rope_mode, qo.data_ptr(), ko.data_ptr(), _ptr(vt),
+                                      _ptr(rope), rope_mode, qo.data_ptr(), _ptr(ko), _ptr(vt),
                                       S_out, Skp, row0, _stream())
     _l.check(rc, "qkv_prepare")
 
@@ -286,6 +287,19 @@ def rope_table_axes(ids: torch.Tensor, axes_dim, theta: float = 10000.0) -> torc
     arr = (C.c_int * n)(*[int(a) for a in axes_dim])
     rc = _l.load().apexmi_rope_table_axes(ids.data_ptr(), S, n, arr, float(theta), out.data_ptr(), _stream())
     _l.check(rc, "rope_table_axes")
+    return out
+
+
+def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[l, :] = a[l, :] + b  (f32; a [L, n] contiguous, b [n])."""
+    _req(a, torch.float32, "add_bcast.a")
+    _req(b, torch.float32, "add_bcast.b")
+    assert a.is_contiguous() and b.is_contiguous() and a.shape[-1] == b.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    rows = a.numel() // b.numel()
+    _l.check(_l.load().apexmi_add_bcast_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, b.numel(),
+                                            _stream()), "add_bcast_f32")
     return out
 
 

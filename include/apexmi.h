@@ -146,7 +146,8 @@ int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int 
  * Replaces the unflatten / norm_q / norm_k / cat / apply_rotary_emb / permute chain of
  * FluxAttnProcessor.__call__ (transformer/flux/base/attention.py:62-94).
  *   q,k,v : bf16 [S, H*D] row pointers with row stride ld_in (elements) each (a fused
- *           [S, 3*H*D] projection output passes three offsets into one buffer)
+ *           [S, 3*H*D] projection output passes three offsets into one buffer); k and v may be
+ *           NULL (cross-attention prepares the query side and the text key/value side separately)
  *   wq,wk : bf16 [D] RMSNorm weights used for rows >= split;  wq2,wk2 for rows < split
  *           (the text stream's norm_added_q/k; pass split = 0 to use only wq,wk). NULL = no norm.
  *   rope  : f32 table, layout per rope_mode, indexed by row s
@@ -179,6 +180,11 @@ int apexmi_timestep_embedding(const float* t, float* out, int M, int dim, float 
  * Angles are computed in f64 like the reference. */
 int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const int* axes_dim, float theta,
                            float* out, apexmi_stream_t stream);
+
+/* out[l, i] = a[l, i] + b[i] in f32: `scale_shift_table + temb.float()` of every Wan block in one pass
+ * (wan model.py:1117-1128, :1849-1856). */
+int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t rows, int64_t n,
+                         apexmi_stream_t stream);
 
 /* f32 <-> bf16 helpers for the small conditioning vectors. */
 int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);

@@ -120,7 +120,7 @@ def install_stubs():
     m = _mod("diffusers.models")
     m.__path__ = []
     _mod("diffusers.models.attention", AttentionMixin=type("D", (), {}),
-         AttentionModuleMixin=AttentionModuleMixin, FeedForward=OL.FeedForward)
+         AttentionModuleMixin=AttentionModuleMixin, FeedForward=OL.FeedForward, Attention=type("Attention", (), {}))
     _mod("diffusers.models.cache_utils", CacheMixin=CacheMixin)
     _mod("diffusers.models.embeddings",
          CombinedTimestepGuidanceTextProjEmbeddings=OL.CombinedTimestepGuidanceTextProjEmbeddings,
@@ -235,12 +235,40 @@ def gen_flux_hybrid():
     print("flux_hybrid.pt", tuple(out.shape), float(out.abs().mean()), missing)
 
 
+TINY_WAN = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=16,
+                out_channels=16, text_dim=64, freq_dim=256, ffn_dim=512, num_layers=2, cross_attn_norm=True,
+                eps=1e-6)
+
+
+def gen_wan_hybrid():
+    """Reference WanTransformer3DModel run in float64: `x.float()` then copies, so the fp32 aliasing
+    defect of InplaceRMSNorm does not trigger and the result is the intended math."""
+    from src.transformer.wan.base.model import WanTransformer3DModel as RefWan
+    from oracle.wan import WanTransformer3DModel as OracleWan
+    ref = RefWan(**TINY_WAN, rope_max_seq_len=64).eval()
+    orc = OracleWan(**TINY_WAN).eval()
+    sd = synthetic_state_dict(orc, 9)
+    assert sorted(sd.keys()) == sorted(ref.state_dict().keys()), \
+        set(sd.keys()) ^ set(ref.state_dict().keys())
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.double()
+    inp = dict(hidden_states=seeded((1, 16, 3, 8, 12), 41), timestep=torch.tensor([500.0]),
+               encoder_hidden_states=seeded((1, 20, 64), 42))
+    with torch.no_grad():
+        out = ref(hidden_states=inp["hidden_states"].double(), timestep=inp["timestep"].double(),
+                  encoder_hidden_states=inp["encoder_hidden_states"].double(), return_dict=False)[0]
+    torch.save(dict(config=TINY_WAN, seed=9, inputs=inp, out=out.float(), keys=sorted(sd.keys())),
+               os.path.join(OUT, "wan_hybrid.pt"))
+    print("wan_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     gen_attention()
     gen_efficiency()
     gen_flux_hybrid()
+    gen_wan_hybrid()
 
 
 if __name__ == "__main__":

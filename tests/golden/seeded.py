@@ -14,6 +14,10 @@ def synthetic_state_dict(model, seed: int = 7):
     for name, p in sorted(model.state_dict().items()):
         if name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
             w = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+        elif name.endswith("scale_shift_table"):
+            w = torch.randn(p.shape, generator=g) / (p.shape[-1] ** 0.5)
+        elif name.endswith(("norm_q.weight", "norm_k.weight", "norm2.weight", "txt_norm.weight")) or ".norm_" in name:
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
         elif name.endswith(".bias"):
             w = 0.02 * torch.randn(p.shape, generator=g)
         else:

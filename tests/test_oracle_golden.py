@@ -82,3 +82,18 @@ def test_pack_unpack_roundtrip():
     assert p.shape == (2, 4 * 6, 64)
     assert torch.equal(OF.unpack_latents(p, 64, 96, 8), x)
     assert abs(OF.calculate_shift(4096) - 1.15) < 1e-9 and abs(OF.calculate_shift(256) - 0.5) < 1e-9
+
+
+def test_wan_wiring_matches_reference_blocks(golden_dir):
+    """oracle.wan vs the reference's own WanTransformer3DModel run in float64 (intended RMSNorm)."""
+    from oracle import wan as OW
+    g = _load(golden_dir, "wan_hybrid.pt")
+    model = OW.WanTransformer3DModel(**g["config"]).eval()
+    assert sorted(model.state_dict().keys()) == g["keys"]
+    model.load_state_dict(synthetic_state_dict(model, g["seed"]), strict=True)
+    inp = g["inputs"]
+    out = model(inp["hidden_states"], inp["timestep"], inp["encoder_hidden_states"])
+    rel = (out - g["out"]).norm() / g["out"].norm()
+    assert out.shape == g["out"].shape and rel < 2e-5, rel
+    b = model(inp["hidden_states"], inp["timestep"], inp["encoder_hidden_states"], policy=OL.BF16_STORAGE)
+    assert 0 < (out - b).norm() / out.norm() < 3e-2

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Run selected GPU tests: bash tools/gpu_test.sh <pytest args>
+set -u
+mkdir -p gpurun_out
+timeout 1500 python -m pytest "$@" -m gpu -q --no-header -rA -s -p no:cacheprovider > gpurun_out/pytest_sel.log 2>&1
+echo "pytest exit: $?"
+grep -E "^(FAILED|ERROR)|passed|failed|hip vs|rel |Error" gpurun_out/pytest_sel.log | tail -30
