@@ -50,7 +50,13 @@ def register(attention_register, set_default: bool = False, overwrite: bool = Tr
 
 
 def register_models(transformers_registry, vae_registry=None):
-    """Register the drop-in component classes (B-model): "flux.mi355" next to "flux.base"."""
+    """Register the drop-in component classes (B-model) next to "flux.base" / "wan.base" /
+    "qwenimage.base" (reference transformer/base.py:3; auto-scan transformer/__init__.py:21-84)."""
     from .flux import FluxTransformer2DModel
-    transformers_registry("flux.mi355", overwrite=True, available=available())(FluxTransformer2DModel)
+    from .qwenimage import QwenImageTransformer2DModel
+    from .wan import WanTransformer3DModel
+    ok = available()
+    transformers_registry("flux.mi355", overwrite=True, available=ok)(FluxTransformer2DModel)
+    transformers_registry("wan.mi355", overwrite=True, available=ok)(WanTransformer3DModel)
+    transformers_registry("qwenimage.mi355", overwrite=True, available=ok)(QwenImageTransformer2DModel)
     return transformers_registry

@@ -121,6 +121,7 @@ def install_stubs():
     m.__path__ = []
     _mod("diffusers.models.attention", AttentionMixin=type("D", (), {}),
          AttentionModuleMixin=AttentionModuleMixin, FeedForward=OL.FeedForward, Attention=type("Attention", (), {}))
+    _mod("diffusers.models.attention_processor", Attention=OL.DiffusersAttention)
     _mod("diffusers.models.cache_utils", CacheMixin=CacheMixin)
     _mod("diffusers.models.embeddings",
          CombinedTimestepGuidanceTextProjEmbeddings=OL.CombinedTimestepGuidanceTextProjEmbeddings,
@@ -262,6 +263,35 @@ def gen_wan_hybrid():
     print("wan_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
 
 
+TINY_QWEN = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=2, attention_head_dim=128,
+                 num_attention_heads=2, joint_attention_dim=64, guidance_embeds=False,
+                 axes_dims_rope=(16, 56, 56))
+
+
+def gen_qwen_hybrid():
+    """Reference QwenImageTransformer2DModel (edit layout: target image + one condition image)."""
+    # the reference does `from src.attention import attention_register`
+    import src.attention  # noqa: F401
+    from src.transformer.qwenimage.base.model import QwenImageTransformer2DModel as RefQwen
+    from oracle.qwenimage import QwenImageTransformer2DModel as OracleQwen
+    ref = RefQwen(**TINY_QWEN).eval()
+    orc = OracleQwen(**TINY_QWEN).eval()
+    sd = synthetic_state_dict(orc, 11)
+    assert sorted(sd.keys()) == sorted(ref.state_dict().keys()), set(sd) ^ set(ref.state_dict())
+    ref.load_state_dict(sd, strict=True)
+    shapes = [[(1, 6, 8), (1, 4, 6)]]
+    n_img = 6 * 8 + 4 * 6
+    inp = dict(hidden_states=seeded((1, n_img, 64), 51), encoder_hidden_states=seeded((1, 13, 64), 52),
+               timestep=torch.tensor([0.5]), img_shapes=shapes, txt_seq_lens=[13])
+    with torch.no_grad():
+        out = ref(hidden_states=inp["hidden_states"], encoder_hidden_states=inp["encoder_hidden_states"],
+                  encoder_hidden_states_mask=torch.ones(1, 13), timestep=inp["timestep"], img_shapes=shapes,
+                  txt_seq_lens=[13], return_dict=False)[0]
+    torch.save(dict(config=TINY_QWEN, seed=11, inputs=inp, out=out, keys=sorted(sd.keys())),
+               os.path.join(OUT, "qwen_hybrid.pt"))
+    print("qwen_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -269,6 +299,7 @@ def main():
     gen_efficiency()
     gen_flux_hybrid()
     gen_wan_hybrid()
+    gen_qwen_hybrid()
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ def test_backend_registration_and_argument_errors():
         with pytest.raises(ApexMIError):
             ab.hip_mfma(q, q, q, **kw)
     creg = ab.register_models(ClassRegister())
-    assert "flux.mi355" in creg.all()
+    assert {"flux.mi355", "wan.mi355", "qwenimage.mi355"} <= set(creg.all())
 
 
 def test_flux_class_contract_on_meta_device():
@@ -71,3 +71,32 @@ def test_flux_class_contract_on_meta_device():
     from apex_studio_amd.lib import ApexMIError
     with pytest.raises(ApexMIError):     # CPU weights: the product path refuses, it does not fall back
         m.pack()
+
+
+def test_wan_and_qwen_class_contracts_on_meta_device():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    w = WanTransformer3DModel.from_config(dict(num_attention_heads=2, ffn_dim=512, num_layers=1, text_dim=64),
+                                          device="meta")
+    keys = set(w.state_dict())
+    for k in ("patch_embedding.weight", "condition_embedder.time_embedder.linear_1.weight",
+              "condition_embedder.time_proj.bias", "condition_embedder.text_embedder.linear_2.weight",
+              "blocks.0.attn1.norm_q.weight", "blocks.0.attn2.to_k.bias", "blocks.0.norm2.bias",
+              "blocks.0.ffn.net.0.proj.weight", "blocks.0.scale_shift_table", "scale_shift_table", "proj_out.weight"):
+        assert k in keys, k
+    assert w.config.patch_size == (1, 2, 2) and w.config.get("in_channels") == 16
+    w.set_chunking_profile("balanced")          # reference memory knob: accepted, no-op
+    q = QwenImageTransformer2DModel.from_config(dict(num_attention_heads=2, num_layers=1, joint_attention_dim=64),
+                                                device="meta")
+    keys = set(q.state_dict())
+    for k in ("transformer_blocks.0.img_mod.1.weight", "transformer_blocks.0.txt_mod.1.bias",
+              "transformer_blocks.0.attn.add_q_proj.weight", "transformer_blocks.0.attn.norm_added_k.weight",
+              "transformer_blocks.0.img_mlp.net.0.proj.weight", "transformer_blocks.0.txt_mlp.net.2.bias",
+              "time_text_embed.timestep_embedder.linear_2.weight", "txt_norm.weight", "img_in.weight", "txt_in.bias",
+              "norm_out.linear.weight", "proj_out.bias"):
+        assert k in keys, k
+    with pytest.raises(NotImplementedError):
+        WanTransformer3DModel(image_dim=1280, device="meta")
+    with pytest.raises(NotImplementedError):
+        QwenImageTransformer2DModel(zero_cond_t=True, device="meta")

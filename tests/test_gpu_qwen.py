@@ -1,0 +1,74 @@
+"""HIP QwenImage MM-DiT ("qwenimage.mi355") vs the CPU oracle and the reference-wiring golden."""
+import os
+
+import pytest
+import torch
+
+from oracle import layers as OL
+from oracle import qwenimage as OQ
+from tests.golden.seeded import seeded, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONFIGS = {
+    "tiny": (dict(patch_size=2, in_channels=64, out_channels=16, num_layers=2, attention_head_dim=128,
+                  num_attention_heads=2, joint_attention_dim=64, axes_dims_rope=(16, 56, 56)),
+             [(1, 6, 8), (1, 4, 6)], 13),
+    "mid": (dict(patch_size=2, in_channels=64, out_channels=16, num_layers=3, attention_head_dim=128,
+                 num_attention_heads=4, joint_attention_dim=128, axes_dims_rope=(16, 56, 56)),
+            [(1, 16, 16), (1, 16, 12)], 77),
+}
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def _hip(cfg, sd, x, txt, t, shapes):
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    kw = dict(hidden_states=x.to(DEV).to(torch.bfloat16), encoder_hidden_states=txt.to(DEV).to(torch.bfloat16),
+              encoder_hidden_states_mask=torch.ones(1, txt.shape[1], device=DEV), timestep=t.to(DEV),
+              img_shapes=[shapes], txt_seq_lens=[txt.shape[1]], return_dict=False)
+    out = m(**kw)[0]
+    torch.cuda.synchronize()
+    out2 = m(**kw)[0]
+    assert torch.equal(out, out2), "the step must be deterministic"
+    return m, out.float().cpu()
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_qwen_forward_matches_oracle(name):
+    cfg, shapes, s_txt = CONFIGS[name]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    n_img = sum(f * h * w for f, h, w in shapes)
+    x = seeded((1, n_img, 64), 51).to(torch.bfloat16).float()
+    txt = seeded((1, s_txt, cfg["joint_attention_dim"]), 52).to(torch.bfloat16).float()
+    t = torch.tensor([0.5])
+    ref32 = orc(x, txt, t, shapes)
+    ref16 = orc(x, txt, t, shapes, policy=OL.BF16_STORAGE)
+    m, out = _hip(cfg, sd, x, txt, t, shapes)
+    assert out.shape == ref32.shape and torch.isfinite(out).all()
+    e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[qwen {name}] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3
+    after = m.state_dict()
+    for k in sd:
+        assert torch.equal(after[k].float().cpu(), sd[k]), k
+
+
+def test_qwen_matches_reference_wiring_golden(golden_dir):
+    g = torch.load(os.path.join(golden_dir, "qwen_hybrid.pt"), weights_only=False)
+    orc = OQ.QwenImageTransformer2DModel(**g["config"])
+    sd = synthetic_state_dict(orc, g["seed"])
+    inp = g["inputs"]
+    _, out = _hip(g["config"], sd, inp["hidden_states"], inp["encoder_hidden_states"], inp["timestep"],
+                  inp["img_shapes"][0])
+    rel = _rel(out, g["out"])
+    print(f"qwen hip bf16 vs reference-wiring fp32 golden: rel {rel:.3e}")
+    assert rel < 3e-2, rel

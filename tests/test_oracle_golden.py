@@ -97,3 +97,19 @@ def test_wan_wiring_matches_reference_blocks(golden_dir):
     assert out.shape == g["out"].shape and rel < 2e-5, rel
     b = model(inp["hidden_states"], inp["timestep"], inp["encoder_hidden_states"], policy=OL.BF16_STORAGE)
     assert 0 < (out - b).norm() / out.norm() < 3e-2
+
+
+def test_qwen_wiring_matches_reference_blocks(golden_dir):
+    """oracle.qwenimage vs the reference's own QwenImageTransformer2DModel (edit layout, two images)."""
+    from oracle import qwenimage as OQ
+    g = _load(golden_dir, "qwen_hybrid.pt")
+    model = OQ.QwenImageTransformer2DModel(**g["config"]).eval()
+    assert sorted(model.state_dict().keys()) == g["keys"]
+    model.load_state_dict(synthetic_state_dict(model, g["seed"]), strict=True)
+    inp = g["inputs"]
+    out = model(inp["hidden_states"], inp["encoder_hidden_states"], inp["timestep"], inp["img_shapes"])
+    rel = (out - g["out"]).norm() / g["out"].norm()
+    assert out.shape == g["out"].shape and rel < 2e-5, rel
+    pos = OQ.qwen_rope_positions([(1, 6, 8), (1, 4, 6)], 13)
+    assert pos.shape == (13 + 48 + 24, 3)
+    assert pos[0].tolist() == [4, 4, 4] and pos[13].tolist() == [0, -3, -4] and pos[13 + 48].tolist() == [1, -2, -3]
