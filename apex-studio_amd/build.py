@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libapex_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "elementwise.hip", "conv.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,367 @@
+// Causal 3-D convolution (and its 2-D / 1x1 special cases) of the Wan / QwenImage VAE decoder as an
+// implicit GEMM on MFMA, channels-last.
+//
+//   out[t, y, x, co] = bias[co] + sum_{tap, ci} W[co, tap, ci] * in[t + dt - (kT-1), y + dy - pH, x + dx - pW, ci]
+//   (+ residual[t, y, x, co])
+//
+// Replaces WanCausalConv3d.forward (reference vae/wan/model.py:178-185: time padding is all on the left,
+// 2*pad frames, i.e. causal; the per-frame feat_cache streaming of WanDecoder3d.forward :972-1021 is the
+// same arithmetic as one causal convolution over the whole tile sequence), nn.Conv2d 3x3 of WanResample
+// (:264-273) and the 1x1 convs (post_quant_conv, conv_shortcut, to_qkv, proj).  Zero padding at the
+// TILE borders is part of the reference's numerical contract (tiled_decode :1574-1596), so every tile is
+// convolved on its own.
+//
+// GEMM view: M = T*H*W output positions, N = Cout, K = ntaps * Cin (padded to 64).  Activations are
+// [T, H, W, Cin] bf16, so for one tap the Cin run of a position is contiguous and the A tile is staged
+// with the same 16-byte global_load_lds + XOR-swizzled LDS image as gemm.hip — only the per-lane source
+// address changes (tap shift + bounds test; out-of-range taps read a 16-byte zero line).
+// Weights are pre-packed [Cout, Kpad] (tap-major, ci-minor).  128x128x64 tile, 4 waves, 2 workgroups/CU.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int MAX_TAPS = 27;
+
+struct ConvArgs {
+    const bf16_t* in;     // [T, H, W, Cin]
+    const bf16_t* w;      // [Cout, Kpad]
+    const bf16_t* bias;   // [Cout] or null
+    const bf16_t* res;    // [T, H, W, Cout] or null
+    bf16_t* out;          // [T, H, W, Cout]
+    const bf16_t* zeros;  // >= 16 bytes of zeros
+    int T, H, W, Cin, Cout, Kpad;
+    int kT, kH, kW, ntaps;
+    int q64, r64;         // 64 / Cin, 64 % Cin
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int tap_off[MAX_TAPS];  // packed (dt, dy, dx) as signed offsets
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    if (tid < a.ntaps) {
+        const int dt = tid / (a.kH * a.kW), r = tid % (a.kH * a.kW);
+        const int dy = r / a.kW, dx = r % a.kW;
+        // causal in time (all padding on the left), symmetric "same" padding in space
+        tap_off[tid] = ((dt - (a.kT - 1)) & 0xff) | (((dy - (a.kH - 1) / 2) & 0xff) << 8) |
+                       (((dx - (a.kW - 1) / 2) & 0xff) << 16);
+    }
+    __syncthreads();
+
+    const int M = a.T * a.H * a.W;
+    const int nm = (M + BM - 1) / BM;
+    const int nn = (a.Cout + BN - 1) / BN;
+    const int s = xcd_remap(blockIdx.x, nm * nn);
+    const int pm = s / nn, pn = s % nn;  // consecutive workgroups share the activation rows
+    const int m0 = pm * BM, n0 = pn * BN;
+
+    // ---- per-lane A rows (output positions) and running (tap, ci) of the lane's 16-byte chunk ----
+    int pos_t[4], pos_y[4], pos_x[4], a_tap[4], a_ci[4];
+    const char* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (i * 4 + wave) * 64 + lane;
+        const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, M - 1);
+        pos_t[i] = m / (a.H * a.W);
+        const int r = m % (a.H * a.W);
+        pos_y[i] = r / a.W;
+        pos_x[i] = r % a.W;
+        const int k = c * 8;
+        a_tap[i] = k / a.Cin;
+        a_ci[i] = k % a.Cin;
+        w_src[i] = (const char*)(a.w + (int64_t)min(n0 + row, a.Cout - 1) * a.Kpad + c * 8);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nkt = a.Kpad / BK;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* src = a.zeros;
+            if (a_tap[i] < a.ntaps) {
+                const int o = tap_off[a_tap[i]];
+                const int ti = pos_t[i] + (int)(int8_t)(o & 0xff);
+                const int yi = pos_y[i] + (int)(int8_t)((o >> 8) & 0xff);
+                const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
+                if ((unsigned)ti < (unsigned)a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+                    src = a.in + ((int64_t)(ti * a.H + yi) * a.W + xi) * a.Cin + a_ci[i];
+            }
+            glds16(src, base + i * 4096);
+            // advance this lane's chunk by one K-tile (64 channels)
+            a_tap[i] += a.q64;
+            a_ci[i] += a.r64;
+            if (a_ci[i] >= a.Cin) {
+                a_ci[i] -= a.Cin;
+                a_tap[i] += 1;
+            }
+        }
+        const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(w_src[i] + koff, base + TILE_BYTES + i * 4096);
+    };
+
+    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 64 + t * 32 + l31;
+        const int rw = wn * 64 + t * 32 + l31;
+        a_off[t] = ra * 128;
+        a_sw[t] = (ra >> 1) & 7;
+        w_off[t] = rw * 128;
+        w_sw[t] = (rw >> 1) & 7;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA is not covered by __syncthreads()
+        __syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char* As = smem + (kt & 1) * STAGE_BYTES;
+        const char* Ws = As + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + hi;
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
+                wf[t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias (+ residual) -> bf16, lane holds out[m][n .. n+3] per group ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wm * 64 + mt * 32 + l31;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * hi;
+                if (m >= M || n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
+                if (a.bias != nullptr) {
+                    const u32x2 b = *(const u32x2*)(a.bias + n);
+                    v[0] += bf16_lo(b[0]);
+                    v[1] += bf16_hi(b[0]);
+                    v[2] += bf16_lo(b[1]);
+                    v[3] += bf16_hi(b[1]);
+                }
+                if (a.res != nullptr) {
+                    const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
+                    v[0] += bf16_lo(r[0]);
+                    v[1] += bf16_hi(r[0]);
+                    v[2] += bf16_lo(r[1]);
+                    v[3] += bf16_hi(r[1]);
+                }
+                u32x2 o;
+                o[0] = pack_bf16(v[0], v[1]);
+                o[1] = pack_bf16(v[2], v[3]);
+                *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = o;
+            }
+    }
+}
+
+// ---- channels-last elementwise companions --------------------------------------------------------
+
+// y = silu?( x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c] ) per position  (WanRMS_norm.forward, reference
+// vae/wan/model.py:216-222, followed by the SiLU of WanResidualBlock.forward :398-399).  G lanes per
+// position, 8 channels per lane.
+template <int G>
+__global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const bf16_t* __restrict__ x,
+                                                         bf16_t* __restrict__ y,
+                                                         const bf16_t* __restrict__ gamma, int64_t P, int C,
+                                                         int silu) {
+    const int64_t pos = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int l = threadIdx.x % G;
+    const bool live = pos < P && l * 8 < C;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    if (live) unpack8(*(const u32x4*)(x + pos * C + l * 8), v);
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sq += v[j] * v[j];
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float scale = sqrtf((float)C) / fmaxf(sqrtf(sq), 1e-12f);
+    if (live) {
+        float g[8];
+        unpack8(*(const u32x4*)(gamma + l * 8), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = v[j] * scale * g[j];
+            if (silu) r = silu_f(r);
+            v[j] = r;
+        }
+        *(u32x4*)(y + pos * C + l * 8) = pack8(v);
+    }
+}
+
+// nearest(-exact) 2x spatial upsample, [T, H, W, C] -> [T, 2H, 2W, C]  (WanUpsample, model.py:225-237)
+__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const bf16_t* __restrict__ x,
+                                                            bf16_t* __restrict__ y, int T, int H, int W,
+                                                            int C) {
+    const int cc = C >> 3;
+    const int64_t n = (int64_t)T * 2 * H * 2 * W * cc;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % cc);
+    int64_t r = idx / cc;
+    const int xo = (int)(r % (2 * W));
+    r /= 2 * W;
+    const int yo = (int)(r % (2 * H));
+    const int t = (int)(r / (2 * H));
+    *(u32x4*)(y + idx * 8) = *(const u32x4*)(x + (((int64_t)t * H + (yo >> 1)) * W + (xo >> 1)) * C + c * 8);
+}
+
+// time_conv output [T, H, W, 2C] -> frames interleaved [2T, H, W, C]: channel half h of frame t becomes
+// frame 2t + h  (WanResample.forward, model.py:332-336)
+__global__ __launch_bounds__(256) void time_interleave_cl_kernel(const bf16_t* __restrict__ x,
+                                                                 bf16_t* __restrict__ y, int T, int64_t HW,
+                                                                 int C) {
+    const int cc = C >> 3;
+    const int64_t n = (int64_t)2 * T * HW * cc;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % cc);
+    int64_t r = idx / cc;
+    const int64_t p = r % HW;
+    const int f = (int)(r / HW);
+    *(u32x4*)(y + idx * 8) = *(const u32x4*)(x + (((int64_t)(f >> 1) * HW + p) * 2 + (f & 1)) * C + c * 8);
+}
+
+// b[o, e, i] = a[o, e, i] * (1 - e/E) + b[o, e, i] * (e/E)   (blend_v / blend_h, model.py:1404-1422)
+__global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b,
+                                                        int64_t outer, int E, int64_t inner, int64_t a_so,
+                                                        int64_t a_se, int64_t b_so, int64_t b_se) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= outer * E * inner) return;
+    const int64_t i = idx % inner;
+    const int64_t r = idx / inner;
+    const int e = (int)(r % E);
+    const int64_t o = r / E;
+    const float w = (float)e / (float)E;
+    bf16_t* bp = b + o * b_so + e * b_se + i;
+    const float av = bf16_to_f32(a[o * a_so + e * a_se + i]);
+    *bp = f32_to_bf16(av * (1.0f - w) + bf16_to_f32(*bp) * w);
+}
+
+}  // namespace
+
+extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual,
+                                void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
+                                int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(in && w && out && zeros, "conv3d_cl: null operand");
+    APEXMI_REQUIRE(T > 0 && H > 0 && W > 0, "conv3d_cl: empty volume");
+    APEXMI_REQUIRE(Cin % 8 == 0 && Cout % 4 == 0, "conv3d_cl: Cin=%d must be a multiple of 8, Cout=%d of 4", Cin, Cout);
+    const int ntaps = kT * kH * kW;
+    APEXMI_REQUIRE(ntaps >= 1 && ntaps <= MAX_TAPS && (kH & 1) && (kW & 1), "conv3d_cl: kernel %dx%dx%d unsupported", kT, kH, kW);
+    APEXMI_REQUIRE(Kpad % BK == 0 && Kpad >= ntaps * Cin, "conv3d_cl: Kpad=%d must be >= taps*Cin rounded up to 64", Kpad);
+    APEXMI_REQUIRE(T < 128 && H < 128 * 8 && W < 128 * 8, "conv3d_cl: volume too large for one call");
+    APEXMI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
+                       ((uintptr_t)zeros % 16) == 0,
+                   "conv3d_cl: operands must be 16-byte aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    ConvArgs a;
+    a.in = (const bf16_t*)in;
+    a.w = (const bf16_t*)w;
+    a.bias = (const bf16_t*)bias;
+    a.res = (const bf16_t*)residual;
+    a.out = (bf16_t*)out;
+    a.zeros = (const bf16_t*)zeros;
+    a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Kpad = Kpad;
+    a.kT = kT; a.kH = kH; a.kW = kW; a.ntaps = ntaps;
+    a.q64 = 64 / Cin;
+    a.r64 = 64 % Cin;
+    const int64_t M = (int64_t)T * H * W;
+    const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
+    ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps * Cin,
+                         2.0 * ((double)M * Cin + (double)Cout * Kpad + (double)M * Cout));
+    hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
+    return apexmi_check_launch("conv3d_cl");
+}
+
+extern "C" int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
+                                 apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && gamma && P > 0, "rmsnorm_cl: bad arguments");
+    APEXMI_REQUIRE(C % 8 == 0 && C <= 512, "rmsnorm_cl: C=%d must be a multiple of 8 and <= 512", C);
+    ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)P * C);
+    const int lanes = C / 8;
+    if (lanes <= 16)
+        hipLaunchKernelGGL(rmsnorm_cl_kernel<16>, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, stream,
+                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+    else if (lanes <= 32)
+        hipLaunchKernelGGL(rmsnorm_cl_kernel<32>, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream,
+                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+    else
+        hipLaunchKernelGGL(rmsnorm_cl_kernel<64>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
+                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+    return apexmi_check_launch("rmsnorm_cl");
+}
+
+extern "C" int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W, int C,
+                                    apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && T > 0 && H > 0 && W > 0 && C % 8 == 0, "upsample2x_cl: bad arguments");
+    const int64_t n = (int64_t)T * 2 * H * 2 * W * (C / 8);
+    ApexmiProfScope prof(5, stream, 0.0, 2.5 * (double)n * 16);
+    hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)x, (bf16_t*)y, T, H, W, C);
+    return apexmi_check_launch("upsample2x_cl");
+}
+
+extern "C" int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t HW, int C,
+                                         apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && T > 0 && HW > 0 && C % 8 == 0, "time_interleave_cl: bad arguments");
+    const int64_t n = (int64_t)2 * T * HW * (C / 8);
+    ApexmiProfScope prof(5, stream, 0.0, 2.0 * (double)n * 16);
+    hipLaunchKernelGGL(time_interleave_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)x, (bf16_t*)y, T, HW, C);
+    return apexmi_check_launch("time_interleave_cl");
+}
+
+extern "C" int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,
+                                int64_t a_se, int64_t b_so, int64_t b_se, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && outer > 0 && E > 0 && inner > 0, "crossfade: bad arguments");
+    const int64_t n = outer * E * inner;
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * (double)n);
+    hipLaunchKernelGGL(crossfade_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)a, (bf16_t*)b, outer, E, inner, a_so, a_se, b_so, b_se);
+    return apexmi_check_launch("crossfade");
+}

@@ -45,6 +45,12 @@ SIGNATURES = {
                                      C.c_int, vp]),
     "apexmi_v_transpose": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                      C.c_int, vp]),
+    "apexmi_conv3d_cl": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "apexmi_rmsnorm_cl": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "apexmi_time_interleave_cl": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp]),
+    "apexmi_crossfade": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_int64, vp]),
     "apexmi_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                             vp]),
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),

@@ -332,3 +332,104 @@ def euler_step(sample: torch.Tensor, model_output: torch.Tensor, dt: float,
                                      sample.numel(), float(dt), _DT[sample.dtype], _stream())
     _l.check(rc, "euler_step")
     return out
+
+
+# ---- channels-last VAE ops ---------------------------------------------------------------------
+_zero_lines: dict = {}
+
+
+def _zeros16(device) -> torch.Tensor:
+    z = _zero_lines.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.bfloat16, device=device)
+        _zero_lines[device] = z
+    return z
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, (kT,) kH, kW] -> [Cout4, Kpad] with k = tap*Cin + ci, zero padded (K to 64, Cout to 4)."""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin = w.shape[:2]
+    k = w.shape[2] * w.shape[3] * w.shape[4] * cin
+    kpad = (k + 63) // 64 * 64
+    cout4 = (cout + 3) // 4 * 4
+    out = torch.zeros(cout4, kpad, dtype=w.dtype, device=w.device)
+    out[:cout, :k] = w.permute(0, 2, 3, 4, 1).reshape(cout, k)
+    return out
+
+
+def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" zero padding in space."""
+    _req(x, torch.bfloat16, "conv3d_cl.x")
+    _req(w_packed, torch.bfloat16, "conv3d_cl.w")
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, cin = x.shape
+    cout, kpad = w_packed.shape
+    if out is None:
+        out = torch.empty((T, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.shape == (T, H, W, cout)
+    if bias is not None:
+        assert bias.numel() == cout and bias.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual),
+                                    out.data_ptr(), _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad,
+                                    int(ksize[0]), int(ksize[1]), int(ksize[2]), _stream())
+    _l.check(rc, "conv3d_cl")
+    return out
+
+
+def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, torch.bfloat16, "rmsnorm_cl.x")
+    assert x.is_contiguous() and gamma.is_contiguous() and gamma.numel() == x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    P = x.numel() // x.shape[-1]
+    _l.check(_l.load().apexmi_rmsnorm_cl(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), P, x.shape[-1],
+                                         1 if silu else 0, _stream()), "rmsnorm_cl")
+    return out
+
+
+def upsample2x_cl(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.bfloat16, "upsample2x_cl.x")
+    assert x.dim() == 4 and x.is_contiguous()
+    T, H, W, Cc = x.shape
+    out = torch.empty((T, 2 * H, 2 * W, Cc), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().apexmi_upsample2x_cl(x.data_ptr(), out.data_ptr(), T, H, W, Cc, _stream()), "upsample2x_cl")
+    return out
+
+
+def time_interleave_cl(x: torch.Tensor) -> torch.Tensor:
+    """[T,H,W,2C] -> [2T,H,W,C]."""
+    _req(x, torch.bfloat16, "time_interleave_cl.x")
+    assert x.dim() == 4 and x.is_contiguous() and x.shape[3] % 16 == 0
+    T, H, W, C2 = x.shape
+    out = torch.empty((2 * T, H, W, C2 // 2), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().apexmi_time_interleave_cl(x.data_ptr(), out.data_ptr(), T, H * W, C2 // 2, _stream()),
+             "time_interleave_cl")
+    return out
+
+
+def crossfade_(a: torch.Tensor, b: torch.Tensor, dim: int) -> torch.Tensor:
+    """In place on b: b[.., e, ..] = a[.., e, ..] (1 - e/E) + b[.., e, ..] e/E along `dim` (E = size of dim).
+    a, b: same-shape bf16 views of [T, H, W, C] tensors (blend_v: dim=1, blend_h: dim=2)."""
+    _req(a, torch.bfloat16, "crossfade.a")
+    _req(b, torch.bfloat16, "crossfade.b")
+    assert a.shape == b.shape and a.dim() == 4 and a.stride(3) == 1 and b.stride(3) == 1
+    T, H, W, Cc = b.shape
+    E = b.shape[dim]
+    lib = _l.load()
+    if dim == 1:    # rows: outer = T, e = H rows, inner = W*C (needs contiguous rows in both)
+        assert a.stride(2) == Cc and b.stride(2) == Cc
+        rc = lib.apexmi_crossfade(a.data_ptr(), b.data_ptr(), T, E, W * Cc, a.stride(0), a.stride(1),
+                                  b.stride(0), b.stride(1), _stream())
+        _l.check(rc, "crossfade")
+    else:           # columns: one call per frame, outer = H, e = W columns, inner = C
+        for t in range(T):
+            rc = lib.apexmi_crossfade(a[t].data_ptr(), b[t].data_ptr(), H, E, Cc, a.stride(1), a.stride(2),
+                                      b.stride(1), b.stride(2), _stream())
+            _l.check(rc, "crossfade")
+    return b

@@ -1,0 +1,294 @@
+"""AutoencoderKLWan decode on the MI355X HIP ops — drop-in for VAE registry keys "wan" / "qwenimage"
+(decode half; the encoder is not on the denoise -> decode hot path).
+
+Mirrors what the engines use of the reference class (apps/api/src/vae/wan/model.py:1083-1672, identical
+architecture at vae/qwenimage/model.py:774): `from_config`, state-dict keys `decoder.*` /
+`post_quant_conv.*` (encoder / quant_conv keys in a checkpoint are ignored by `strict=False`),
+`.config` (z_dim, latents_mean, latents_std), `enable_tiling(...)`, `denormalize_latents`,
+`decode(z, return_dict=False)[0]`, `.dtype`.
+
+Decode runs channels-last and processes every spatial tile's WHOLE frame sequence in one causal pass
+(the reference streams frame by frame with `feat_cache`; oracle/vae_wan.py proves both give the same
+numbers, including the first-frame "Rep" rule).  Tiles and their in-place linear blends follow
+`tiled_decode` exactly (model.py:1516-1623): tiling is part of the numerical contract because each tile
+sees zero padding at its borders.  Per tile the kernels are: implicit-GEMM causal conv3d on MFMA with
+fused bias + residual, RMS-norm(channel)+SiLU, nearest 2x upsample, frame interleave, GEMMs for the
+1x1 convs, the attention operator for the 384-channel single-head mid block, and a crossfade for the blends.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as _l
+from . import ops
+from .flux import _Config
+
+WAN_LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715,
+                    0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+WAN_LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652,
+                   1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, ksize, **kw):
+        super().__init__()
+        self.ksize = tuple(ksize)
+        self.weight = nn.Parameter(torch.empty(cout, cin, *ksize, **kw), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(cout, **kw), requires_grad=False)
+
+
+class _Gamma(nn.Module):
+    def __init__(self, dim, images, **kw):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones((dim, 1, 1) if images else (dim, 1, 1, 1), **kw), requires_grad=False)
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.norm1 = _Gamma(cin, False, **kw)
+        self.conv1 = _Conv(cin, cout, (3, 3, 3), **kw)
+        self.norm2 = _Gamma(cout, False, **kw)
+        self.conv2 = _Conv(cout, cout, (3, 3, 3), **kw)
+        self.conv_shortcut = _Conv(cin, cout, (1, 1, 1), **kw) if cin != cout else nn.Identity()
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, **kw):
+        super().__init__()
+        self.norm = _Gamma(dim, True, **kw)
+        self.to_qkv = _Conv(dim, 3 * dim, (1, 1), **kw)
+        self.proj = _Conv(dim, dim, (1, 1), **kw)
+
+
+class _Resample(nn.Module):
+    def __init__(self, dim, mode, **kw):
+        super().__init__()
+        self.mode = mode
+        self.resample = nn.ModuleList([nn.Identity(), _Conv(dim, dim // 2, (3, 3), **kw)])
+        if mode == "upsample3d":
+            self.time_conv = _Conv(dim, 2 * dim, (3, 1, 1), **kw)
+
+
+class _Mid(nn.Module):
+    def __init__(self, dim, **kw):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(dim, dim, **kw), _Res(dim, dim, **kw)])
+        self.attentions = nn.ModuleList([_Attn(dim, **kw)])
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, n, mode, **kw):
+        super().__init__()
+        res, cur = [], cin
+        for _ in range(n + 1):
+            res.append(_Res(cur, cout, **kw))
+            cur = cout
+        self.resnets = nn.ModuleList(res)
+        self.upsamplers = nn.ModuleList([_Resample(cout, mode, **kw)]) if mode else None
+
+
+class _Decoder(nn.Module):
+    def __init__(self, dim, z_dim, dim_mult, num_res_blocks, temperal_upsample, out_channels, **kw):
+        super().__init__()
+        dims = [dim * u for u in [dim_mult[-1]] + dim_mult[::-1]]
+        self.conv_in = _Conv(z_dim, dims[0], (3, 3, 3), **kw)
+        self.mid_block = _Mid(dims[0], **kw)
+        ups = []
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            if i > 0:
+                cin = cin // 2
+            up = i != len(dim_mult) - 1
+            mode = ("upsample3d" if temperal_upsample[i] else "upsample2d") if up else None
+            ups.append(_Up(cin, cout, num_res_blocks, mode, **kw))
+        self.up_blocks = nn.ModuleList(ups)
+        self.norm_out = _Gamma(dims[-1], False, **kw)
+        self.conv_out = _Conv(dims[-1], out_channels, (3, 3, 3), **kw)
+
+
+class AutoencoderKLWan(nn.Module):
+    def __init__(self, base_dim: int = 96, decoder_base_dim: Optional[int] = None, z_dim: int = 16,
+                 dim_mult: List[int] = (1, 2, 4, 4), num_res_blocks: int = 2, attn_scales=(),
+                 temperal_downsample=(False, True, True), dropout: float = 0.0,
+                 latents_mean=WAN_LATENTS_MEAN, latents_std=WAN_LATENTS_STD, is_residual: bool = False,
+                 in_channels: int = 3, out_channels: int = 3, patch_size: Optional[int] = None,
+                 scale_factor_temporal: int = 4, scale_factor_spatial: int = 8, device=None,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if is_residual or patch_size is not None or list(attn_scales):
+            raise NotImplementedError("wan_mi355 VAE: residual (Wan 2.2 TI2V-5B) / patchified / attn_scales "
+                                      "variants are outside the configured hot path")
+        self.config = _Config(base_dim=base_dim, decoder_base_dim=decoder_base_dim, z_dim=z_dim,
+                              dim_mult=list(dim_mult), num_res_blocks=num_res_blocks,
+                              temperal_downsample=list(temperal_downsample), latents_mean=list(latents_mean),
+                              latents_std=list(latents_std), out_channels=out_channels, patch_size=patch_size,
+                              scale_factor_temporal=scale_factor_temporal,
+                              scale_factor_spatial=scale_factor_spatial)
+        kw = dict(device=device, dtype=dtype)
+        self.z_dim = z_dim
+        self.temperal_downsample = list(temperal_downsample)
+        self.post_quant_conv = _Conv(z_dim, z_dim, (1, 1, 1), **kw)
+        self.decoder = _Decoder(decoder_base_dim or base_dim, z_dim, list(dim_mult), num_res_blocks,
+                                list(temperal_downsample)[::-1], out_channels, **kw)
+        self.spatial_compression_ratio = scale_factor_spatial
+        self.use_tiling = False
+        self.tile_sample_min_height = self.tile_sample_min_width = 256
+        self.tile_sample_stride_height = self.tile_sample_stride_width = 192
+        self._packed: Dict[int, torch.Tensor] = {}
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = dict(config) if isinstance(config, dict) else dict(vars(config))
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    _from_config = from_config
+
+    @property
+    def dtype(self):
+        return self.post_quant_conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.post_quant_conv.weight.device
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = {}
+        return super().load_state_dict(*a, **k)
+
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None,
+                      tile_sample_stride_height=None, tile_sample_stride_width=None):
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_sample_stride_height = tile_sample_stride_height or self.tile_sample_stride_height
+        self.tile_sample_stride_width = tile_sample_stride_width or self.tile_sample_stride_width
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        return None
+
+    @torch.no_grad()
+    def denormalize_latents(self, latents):
+        mean = torch.tensor(self.config.latents_mean).view(1, self.z_dim, 1, 1, 1).to(latents.device, latents.dtype)
+        inv_std = 1.0 / torch.tensor(self.config.latents_std).view(1, self.z_dim, 1, 1, 1).to(latents.device,
+                                                                                               latents.dtype)
+        return latents / inv_std + mean
+
+    @torch.no_grad()
+    def normalize_latents(self, latents):
+        mean = torch.tensor(self.config.latents_mean).view(1, self.z_dim, 1, 1, 1).to(latents.device, latents.dtype)
+        inv_std = 1.0 / torch.tensor(self.config.latents_std).view(1, self.z_dim, 1, 1, 1).to(latents.device,
+                                                                                               latents.dtype)
+        return (latents - mean) * inv_std
+
+    # ---- kernels per layer ----------------------------------------------------------------------
+    def _w(self, conv: _Conv):
+        key = id(conv)
+        p = self._packed.get(key)
+        if p is None:
+            w = ops.pack_conv_weight(conv.weight.data)
+            b = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+            b[:conv.bias.numel()] = conv.bias.data
+            p = (w, b)
+            self._packed[key] = p
+        return p
+
+    def _conv(self, conv: _Conv, x, residual=None):
+        w, b = self._w(conv)
+        k = conv.ksize if len(conv.ksize) == 3 else (1,) + conv.ksize
+        return ops.conv3d_cl(x, w, b, k, residual=residual)
+
+    def _res(self, blk: _Res, x):
+        h = x if isinstance(blk.conv_shortcut, nn.Identity) else self._conv(blk.conv_shortcut, x)
+        y = self._conv(blk.conv1, ops.rmsnorm_cl(x, blk.norm1.gamma.data.reshape(-1).contiguous(), silu=True))
+        return self._conv(blk.conv2, ops.rmsnorm_cl(y, blk.norm2.gamma.data.reshape(-1).contiguous(), silu=True),
+                          residual=h)
+
+    def _attn(self, blk: _Attn, x):
+        T, H, W, Cc = x.shape
+        n = ops.rmsnorm_cl(x, blk.norm.gamma.data.reshape(-1).contiguous())
+        qkv = ops.gemm(n.view(T * H * W, Cc), blk.to_qkv.weight.data.reshape(3 * Cc, Cc), blk.to_qkv.bias.data)
+        qkv = qkv.view(T, 1, H * W, 3 * Cc)
+        o = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:])     # [T,1,HW,C] view
+        o = o.permute(0, 2, 1, 3).reshape(T * H * W, Cc)
+        ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
+        out = ops.gemm(o, blk.proj.weight.data.reshape(Cc, Cc), blk.proj.bias.data, epilogue="gate_res",
+                       gate=ones, residual=x.view(T * H * W, Cc))
+        return out.view(T, H, W, Cc)
+
+    def _resample(self, up: _Resample, x):
+        T = x.shape[0]
+        if up.mode == "upsample3d" and T > 1:
+            y = self._conv(up.time_conv, x[1:].contiguous())        # never sees frame 0 (the "Rep" rule)
+            x = torch.cat([x[:1], ops.time_interleave_cl(y)], dim=0)
+        return self._conv(up.resample[1], ops.upsample2x_cl(x))
+
+    def _decode_tile(self, z):
+        """z [T, h, w, z_dim] channels-last -> [T', 8h, 8w, 4] (3 channels + 1 pad)."""
+        d = self.decoder
+        x = self._conv(self.post_quant_conv, z)
+        x = self._conv(d.conv_in, x)
+        x = self._res(d.mid_block.resnets[0], x)
+        x = self._attn(d.mid_block.attentions[0], x)
+        x = self._res(d.mid_block.resnets[1], x)
+        for up in d.up_blocks:
+            for r in up.resnets:
+                x = self._res(r, x)
+            if up.upsamplers is not None:
+                x = self._resample(up.upsamplers[0], x)
+        x = ops.rmsnorm_cl(x, d.norm_out.gamma.data.reshape(-1).contiguous(), silu=True)
+        return self._conv(d.conv_out, x)
+
+    @torch.no_grad()
+    def _decode_one(self, z):
+        """z [C, T, H, W] -> [3, T', 8H, 8W] bf16."""
+        if z.device.type != "cuda" or self.dtype != torch.bfloat16:
+            raise _l.ApexMIError("wan_mi355 VAE needs bf16 weights and latents on a ROCm device (no CPU fallback)")
+        Cz, T, H, W = z.shape
+        ratio = self.spatial_compression_ratio
+        zc = z.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()           # [T, H, W, C]
+        lat_min_h, lat_min_w = self.tile_sample_min_height // ratio, self.tile_sample_min_width // ratio
+        if not (self.use_tiling and (W > lat_min_w or H > lat_min_h)):
+            out = self._decode_tile(zc)
+        else:
+            sh, sw = self.tile_sample_stride_height, self.tile_sample_stride_width
+            lsh, lsw = sh // ratio, sw // ratio
+            bh, bw = self.tile_sample_min_height - sh, self.tile_sample_min_width - sw
+            rows = [[self._decode_tile(zc[:, i:i + lat_min_h, j:j + lat_min_w].contiguous())
+                     for j in range(0, W, lsw)] for i in range(0, H, lsh)]
+            out_rows = []
+            for i, row in enumerate(rows):
+                parts = []
+                for j, tile in enumerate(row):
+                    if i > 0:      # blend_v: top rows of this tile with the bottom rows of the tile above
+                        a = rows[i - 1][j]
+                        e = min(a.shape[1], tile.shape[1], bh)
+                        ops.crossfade_(a[:, a.shape[1] - e:, :tile.shape[2]], tile[:, :e], dim=1)
+                    if j > 0:      # blend_h: left columns with the right columns of the (already blended) left tile
+                        a = row[j - 1]
+                        e = min(a.shape[2], tile.shape[2], bw)
+                        ops.crossfade_(a[:, :tile.shape[1], a.shape[2] - e:], tile[:, :, :e], dim=2)
+                    parts.append(tile[:, :sh, :sw])
+                out_rows.append(torch.cat(parts, dim=2))
+            out = torch.cat(out_rows, dim=1)[:, :H * ratio, :W * ratio]
+        out = out[..., :self.config.out_channels].clamp(-1.0, 1.0)
+        return out.permute(3, 0, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)
+        if not return_dict:
+            return (dec,)
+        return SimpleNamespace(sample=dec)

@@ -166,6 +166,30 @@ int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_i
 int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H, int D,
                        void* vt, int Skp, int row0, apexmi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3-D causal VAE decode (Wan 2.x / QwenImage), channels-last [T, H, W, C] bf16.
+ * apexmi_conv3d_cl: WanCausalConv3d.forward (vae/wan/model.py:178-185; time padding 2*(kT-1)/2... all on
+ *   the left), nn.Conv2d 3x3 of WanResample (:264-273) with kT = 1, and the 1x1 convolutions.
+ *   w is pre-packed [Cout, Kpad] bf16 with k = tap * Cin + ci, tap = (kt * kH + ky) * kW + kx, Kpad =
+ *   taps*Cin rounded up to 64 (zero filled); bias [Cout] or NULL; residual [T,H,W,Cout] or NULL (added
+ *   after the bias: the `x + h` of WanResidualBlock.forward :441); zeros = any 16 zero bytes on the device.
+ *   Cin % 8 == 0, Cout % 4 == 0.
+ * apexmi_rmsnorm_cl: WanRMS_norm.forward (:216-222) per position over C channels, optional SiLU.
+ * apexmi_upsample2x_cl: WanUpsample nearest-exact 2x (:225-237).
+ * apexmi_time_interleave_cl: [T,H,W,2C] -> [2T,H,W,C] (WanResample.forward :332-336).
+ * apexmi_crossfade: b[o,e,i] = a[o,e,i] (1 - e/E) + b[o,e,i] e/E (blend_v / blend_h :1404-1422),
+ *   element strides (outer, e) for a and b, inner contiguous.
+ * ------------------------------------------------------------------------------------------- */
+int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                     const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                     int kW, apexmi_stream_t stream);
+int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
+                      apexmi_stream_t stream);
+int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W, int C, apexmi_stream_t stream);
+int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t HW, int C, apexmi_stream_t stream);
+int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so, int64_t a_se,
+                     int64_t b_so, int64_t b_se, apexmi_stream_t stream);
+
 /* Sinusoidal timestep embedding (diffusers Timesteps(num_channels, flip_sin_to_cos=True,
  * downscale_freq_shift=0, scale); in-tree copy transformer/qwenimage/base/model.py:46-97).
  * t f32 [M] (device), out f32 [M, dim]. */

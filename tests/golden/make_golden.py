@@ -158,7 +158,7 @@ def load_by_path(name, rel):
     return mod
 
 
-from tests.golden.seeded import seeded, synthetic_state_dict  # noqa: E402
+from tests.golden.seeded import seeded, synthetic_state_dict, vae_synthetic_state_dict  # noqa: E402
 
 
 def gen_attention():
@@ -292,6 +292,50 @@ def gen_qwen_hybrid():
     print("qwen_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
 
 
+TINY_VAE = dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1,
+                temperal_downsample=[False, True, True])
+
+
+def install_vae_stubs():
+    class _Out:
+        def __init__(self, sample=None, latent_dist=None):
+            self.sample, self.latent_dist = sample, latent_dist
+
+    _mod("diffusers.models.activations", get_activation=lambda name: nn.SiLU())
+    sys.modules["diffusers.models.modeling_outputs"].AutoencoderKLOutput = _Out
+    ae = _mod("diffusers.models.autoencoders")
+    ae.__path__ = []
+    _mod("diffusers.models.autoencoders.vae", AutoencoderMixin=type("AutoencoderMixin", (), {}),
+         DecoderOutput=_Out, DiagonalGaussianDistribution=type("DGD", (), {}))
+
+
+def gen_vae_wan():
+    """The REFERENCE AutoencoderKLWan (streaming decoder with feat_cache) run here, untiled and tiled."""
+    install_vae_stubs()
+    ref_mod = load_by_path("ref_vae_wan", "src/vae/wan/model.py")
+    from oracle.vae_wan import AutoencoderKLWanDecoder
+    ref = ref_mod.AutoencoderKLWan(**TINY_VAE).eval()
+    orc = AutoencoderKLWanDecoder(**TINY_VAE)
+    sd = vae_synthetic_state_dict(orc, 13)
+    missing = ref.load_state_dict(sd, strict=False)      # encoder / quant_conv keep their init
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing.missing_keys)
+    z = seeded((1, 16, 3, 16, 20), 61)
+    with torch.no_grad():
+        untiled = ref.decode(z, return_dict=False)[0]
+        ref.enable_tiling(tile_sample_min_height=96, tile_sample_min_width=96,
+                          tile_sample_stride_height=64, tile_sample_stride_width=64)
+        tiled = ref.decode(z, return_dict=False)[0]
+        zn = ref.denormalize_latents(z)
+    assert float((tiled - untiled).abs().max()) > 1e-3    # tiling IS part of the numerical contract
+    torch.save(dict(config=TINY_VAE, seed=13, z_shape=(1, 16, 3, 16, 20), z_seed=61,
+                    tile=(96, 96, 64, 64), untiled=untiled.to(torch.bfloat16), tiled=tiled.to(torch.bfloat16),
+                    untiled_f32_sample=untiled[0, :, :, ::8, ::8].clone(), tiled_f32_sample=tiled[0, :, :, ::8, ::8].clone(),
+                    denorm_sample=zn[0, :, 0, 0, 0].clone(), keys=sorted(sd.keys())),
+               os.path.join(OUT, "vae_wan.pt"))
+    print("vae_wan.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -300,6 +344,7 @@ def main():
     gen_flux_hybrid()
     gen_wan_hybrid()
     gen_qwen_hybrid()
+    gen_vae_wan()
 
 
 if __name__ == "__main__":

@@ -24,3 +24,19 @@ def synthetic_state_dict(model, seed: int = 7):
             w = torch.randn(p.shape, generator=g) * (1.0 / (p.shape[-1] ** 0.5))
         sd[name] = w.to(torch.bfloat16).to(torch.float32)
     return sd
+
+
+def vae_synthetic_state_dict(model, seed=13):
+    """conv weights ~ N(0, 1/fan_in), gammas ~ 1 +- 0.1, small biases (deterministic, sorted keys)."""
+    sd = {}
+    g = torch.Generator().manual_seed(seed)
+    for name, p in sorted(model.state_dict().items()):
+        if name.endswith("gamma"):
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+        elif name.endswith(".bias"):
+            w = 0.02 * torch.randn(p.shape, generator=g)
+        else:
+            fan_in = p[0].numel()
+            w = torch.randn(p.shape, generator=g) / fan_in ** 0.5
+        sd[name] = w.to(torch.bfloat16).to(torch.float32)
+    return sd

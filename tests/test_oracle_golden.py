@@ -113,3 +113,25 @@ def test_qwen_wiring_matches_reference_blocks(golden_dir):
     pos = OQ.qwen_rope_positions([(1, 6, 8), (1, 4, 6)], 13)
     assert pos.shape == (13 + 48 + 24, 3)
     assert pos[0].tolist() == [4, 4, 4] and pos[13].tolist() == [0, -3, -4] and pos[13 + 48].tolist() == [1, -2, -3]
+
+
+def test_vae_full_sequence_restatement_matches_streaming_reference(golden_dir):
+    """oracle.vae_wan decodes a tile in ONE causal pass; the reference streams frame by frame with
+    feat_cache (tests/golden/vae_wan.pt is the reference's output).  They must agree: this pins the
+    reformulation the HIP path uses, including the "Rep" first-frame rule and the in-place tile blends."""
+    from oracle.vae_wan import AutoencoderKLWanDecoder
+    from tests.golden.seeded import vae_synthetic_state_dict
+    g = _load(golden_dir, "vae_wan.pt")
+    vae = AutoencoderKLWanDecoder(**g["config"]).eval()
+    assert sorted(vae.state_dict().keys()) == g["keys"]
+    vae.load_state_dict(vae_synthetic_state_dict(vae, g["seed"]), strict=True)
+    z = seeded(g["z_shape"], g["z_seed"])
+    untiled = vae.decode(z)
+    assert untiled.shape == g["untiled"].shape
+    assert torch.allclose(untiled[0, :, :, ::8, ::8], g["untiled_f32_sample"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(untiled, g["untiled"].float(), atol=8e-3, rtol=8e-3)     # golden stored in bf16
+    vae.enable_tiling(*g["tile"])
+    tiled = vae.decode(z)
+    assert torch.allclose(tiled[0, :, :, ::8, ::8], g["tiled_f32_sample"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(tiled, g["tiled"].float(), atol=8e-3, rtol=8e-3)
+    assert float((tiled - untiled).abs().max()) > 1e-3
