@@ -1,0 +1,135 @@
+"""Wan 2.2 A14B text-to-video engine surface on the HIP transformer + HIP VAE.
+
+Mirrors reference engine/wan/t2v.py:12-247 (`run`) and engine/wan/shared/__init__.py:478-608
+(`moe_denoise`), :464-476 (`_select_dual_noise_guidance_scale`), :309-462 (expert selection by
+`t >= boundary_timestep`): same argument names, the `(progress, message)` callback protocol and the
+`render_on_step_callback(frames)` preview hook.  Both 14B experts stay resident (57 GB of 288 GB), so
+the reference's load/offload choreography between experts has no counterpart.  Text encoding (UMT5) is
+outside the hot path: prompt embeddings are inputs.  The sampler loop stays in Python.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import torch
+
+from .schedulers import UniPCMultistepScheduler
+
+
+def _emit(cb, p, msg):
+    if cb is not None:
+        try:
+            cb(p, msg)
+        except Exception:
+            pass
+
+
+class WanT2VEngine:
+    def __init__(self, high_noise_transformer, low_noise_transformer=None, vae=None,
+                 scheduler: Optional[UniPCMultistepScheduler] = None, boundary_ratio: Optional[float] = 0.875,
+                 vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 8):
+        self.high_noise_transformer = high_noise_transformer
+        self.low_noise_transformer = low_noise_transformer or high_noise_transformer
+        self.vae = vae
+        self.scheduler = scheduler or UniPCMultistepScheduler(shift=3.0)
+        self.boundary_ratio = boundary_ratio
+        self.vae_scale_factor_temporal = vae_scale_factor_temporal
+        self.vae_scale_factor_spatial = vae_scale_factor_spatial
+        self.num_channels_latents = high_noise_transformer.config.in_channels
+
+    @property
+    def device(self):
+        return self.high_noise_transformer.device
+
+    @staticmethod
+    def _select_dual_noise_guidance_scale(t, boundary_timestep, guidance_scale) -> float:
+        high = boundary_timestep is not None and bool(t >= boundary_timestep)
+        if isinstance(guidance_scale, (list, tuple)):
+            return float(guidance_scale[0] if high else guidance_scale[1])
+        return float(guidance_scale)
+
+    def _select_dual_noise_transformer(self, t, boundary_timestep):
+        if boundary_timestep is None or bool(t >= boundary_timestep):
+            return self.high_noise_transformer
+        return self.low_noise_transformer
+
+    def vae_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """reference engine/base_engine.py:2030-2059: denormalize -> enable tiling -> decode."""
+        z = self.vae.denormalize_latents(latents.to(torch.float32)).to(self.vae.dtype)
+        self.vae.enable_tiling()
+        return self.vae.decode(z, return_dict=False)[0]
+
+    def moe_denoise(self, latents, timesteps, prompt_embeds, negative_prompt_embeds=None,
+                    guidance_scale: Union[float, List[float]] = 5.0, boundary_timestep=None,
+                    use_cfg_guidance: bool = True, transformer_dtype=torch.bfloat16, render_on_step: bool = False,
+                    render_on_step_callback=None, render_on_step_interval: int = 3,
+                    denoise_progress_callback=None):
+        _emit(denoise_progress_callback, 0.0, "Starting denoise")
+        n = len(timesteps)
+        for i, t in enumerate(timesteps):
+            x = latents.to(transformer_dtype)
+            timestep = t.expand(latents.shape[0])
+            transformer = self._select_dual_noise_transformer(t, boundary_timestep)
+            scale = self._select_dual_noise_guidance_scale(t, boundary_timestep, guidance_scale)
+            noise_pred = transformer(hidden_states=x, timestep=timestep, encoder_hidden_states=prompt_embeds,
+                                     return_dict=False)[0]
+            if use_cfg_guidance and negative_prompt_embeds is not None:
+                uncond = transformer(hidden_states=x, timestep=timestep,
+                                     encoder_hidden_states=negative_prompt_embeds, return_dict=False)[0]
+                noise_pred = uncond + scale * (noise_pred - uncond)
+            latents = self.scheduler.step(noise_pred.to(torch.float32), t, latents, return_dict=False)[0]
+            if (render_on_step and render_on_step_callback and self.vae is not None
+                    and ((i + 1) % render_on_step_interval == 0 or i == 0) and i != n - 1):
+                try:
+                    render_on_step_callback(self.vae_decode(latents))
+                except Exception:
+                    pass
+            _emit(denoise_progress_callback, float(i + 1) / n, f"Denoising step {i + 1}/{n}")
+        return latents
+
+    @torch.no_grad()
+    def run(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor] = None,
+            height: int = 720, width: int = 1280, duration: int = 81, num_inference_steps: int = 30,
+            guidance_scale: Union[float, List[float]] = (4.0, 3.0), seed: Optional[int] = None,
+            generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+            return_latents: bool = False, progress_callback=None, render_on_step: bool = False,
+            render_on_step_callback=None, render_on_step_interval: int = 3, **_ignored):
+        dev = self.device
+        B = prompt_embeds.shape[0]
+        num_latent_frames = (duration - 1) // self.vae_scale_factor_temporal + 1
+        shape = (B, self.num_channels_latents, num_latent_frames, height // self.vae_scale_factor_spatial,
+                 width // self.vae_scale_factor_spatial)
+        if latents is None:
+            if generator is None:
+                generator = torch.Generator(device=dev)
+                if seed is not None:
+                    generator.manual_seed(seed)
+            latents = torch.randn(shape, generator=generator, device=generator.device, dtype=torch.float32).to(dev)
+        else:
+            latents = latents.to(device=dev, dtype=torch.float32)
+        _emit(progress_callback, 0.2, "Prepared latents")
+        timesteps = self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        boundary = None
+        if self.boundary_ratio is not None:
+            boundary = self.boundary_ratio * self.scheduler.config["num_train_timesteps"]
+        cfg = negative_prompt_embeds is not None
+        pe = prompt_embeds.to(dev, torch.bfloat16)
+        ne = negative_prompt_embeds.to(dev, torch.bfloat16) if cfg else None
+
+        def mapped(p, msg):
+            _emit(progress_callback, 0.5 + 0.4 * p, msg)
+
+        latents = self.moe_denoise(latents=latents, timesteps=timesteps, prompt_embeds=pe,
+                                   negative_prompt_embeds=ne, guidance_scale=list(guidance_scale)
+                                   if isinstance(guidance_scale, (list, tuple)) else guidance_scale,
+                                   boundary_timestep=boundary, use_cfg_guidance=cfg,
+                                   render_on_step=render_on_step, render_on_step_callback=render_on_step_callback,
+                                   render_on_step_interval=render_on_step_interval,
+                                   denoise_progress_callback=mapped)
+        if return_latents or self.vae is None:
+            _emit(progress_callback, 1.0, "Returning latents")
+            return latents
+        _emit(progress_callback, 0.92, "Decoding video")
+        video = self.vae_decode(latents)
+        _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
+        return video

@@ -336,6 +336,30 @@ def gen_vae_wan():
     print("vae_wan.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
 
 
+def gen_unipc():
+    """In-tree UniPC (reference scheduler/unipc.py) trajectory: 6 steps, shift 3, fp32 latents."""
+    class SchedulerOutput:
+        def __init__(self, prev_sample):
+            self.prev_sample = prev_sample
+
+    sch = _mod("diffusers.schedulers")
+    sch.__path__ = []
+    _mod("diffusers.schedulers.scheduling_utils", KarrasDiffusionSchedulers=[], SchedulerMixin=type("SM", (), {}),
+         SchedulerOutput=SchedulerOutput)
+    mod = load_by_path("ref_unipc", "src/scheduler/unipc.py")
+    s = mod.UniPCMultistepScheduler(shift=3.0)
+    s.set_timesteps(6)
+    x = seeded((1, 4, 3, 5, 5), 71)
+    vs = [seeded((1, 4, 3, 5, 5), 72 + i) for i in range(6)]
+    traj = []
+    for i, t in enumerate(s.timesteps):
+        x = s.step(vs[i], t, x, return_dict=False)[0]
+        traj.append(x.clone())
+    torch.save(dict(steps=6, shift=3.0, shape=(1, 4, 3, 5, 5), seed=71, timesteps=s.timesteps.clone(),
+                    sigmas=s.sigmas.clone(), traj=traj), os.path.join(OUT, "unipc.pt"))
+    print("unipc.pt", s.timesteps.tolist(), float(traj[-1].abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -345,6 +369,7 @@ def main():
     gen_wan_hybrid()
     gen_qwen_hybrid()
     gen_vae_wan()
+    gen_unipc()
 
 
 if __name__ == "__main__":

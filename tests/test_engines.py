@@ -1,0 +1,96 @@
+"""Host-side sampler loops (stay in Python): expert switching, guidance selection, progress protocol,
+CFG renorm — exercised on CPU with stand-in transformers (the HIP models are tested in test_gpu_*)."""
+import contextlib
+from types import SimpleNamespace
+
+import torch
+
+
+class _FakeWan:
+    def __init__(self, tag):
+        self.tag, self.calls = tag, []
+        self.config = SimpleNamespace(in_channels=16)
+        self.device, self.dtype = torch.device("cpu"), torch.bfloat16
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, return_dict=False):
+        self.calls.append(float(timestep[0]))
+        return (hidden_states.float() * 0.1 + self.tag,)
+
+
+def test_wan_moe_denoise_switches_expert_at_boundary():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    hi, lo = _FakeWan(1.0), _FakeWan(2.0)
+    eng = WanT2VEngine(hi, lo, vae=None)
+    seen = []
+    out = eng.run(prompt_embeds=torch.zeros(1, 4, 8), height=64, width=64, duration=9, num_inference_steps=8,
+                  seed=0, generator=torch.Generator().manual_seed(0), return_latents=True,
+                  progress_callback=lambda p, m: seen.append((p, m)))
+    assert out.shape == (1, 16, 3, 8, 8) and out.dtype == torch.float32
+    assert hi.calls and lo.calls and min(hi.calls) >= 875 > max(lo.calls)
+    assert len(hi.calls) + len(lo.calls) == 8
+    ps = [p for p, _ in seen]
+    assert ps == sorted(ps) and ps[0] == 0.2 and ps[-1] == 1.0 and any("Denoising step 8/8" in m for _, m in seen)
+    assert eng._select_dual_noise_guidance_scale(torch.tensor(900), 875.0, [4.0, 3.0]) == 4.0
+    assert eng._select_dual_noise_guidance_scale(torch.tensor(100), 875.0, [4.0, 3.0]) == 3.0
+
+
+class _FakeQwen:
+    def __init__(self):
+        self.device, self.dtype = torch.device("cpu"), torch.float32
+        self.seen_shapes = []
+
+    @contextlib.contextmanager
+    def cache_context(self, name):
+        yield
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, img_shapes, txt_seq_lens,
+                 encoder_hidden_states_mask=None, return_dict=False):
+        self.seen_shapes.append((hidden_states.shape[1], img_shapes, txt_seq_lens))
+        return (hidden_states * (1.0 + encoder_hidden_states.mean()),)
+
+
+def test_qwen_edit_plus_loop_slices_target_tokens_and_renorms_cfg():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    m = _FakeQwen()
+    eng = QwenImageEditPlusEngine(m)
+    cond = torch.randn(1, 16, 64)
+    out = eng.run(prompt_embeds=torch.ones(1, 5, 8), image_latents=cond, image_shapes=[(64, 64)], height=64,
+                  width=64, num_inference_steps=3, negative_prompt_embeds=torch.zeros(1, 7, 8), true_cfg_scale=4.0,
+                  seed=1)
+    assert out.shape == (1, 16, 64)
+    n_tok, shapes, lens = m.seen_shapes[0]
+    assert n_tok == 32 and shapes == [[(1, 4, 4), (1, 4, 4)]] and lens == [5]
+    assert m.seen_shapes[1][2] == [7] and len(m.seen_shapes) == 6      # cond + uncond per step
+    ts = eng.scheduler.timesteps
+    assert float(ts[0]) <= 1000.0 and float(eng.scheduler.sigmas[-1]) == 0.0
+
+
+def test_flux_engine_progress_and_preview_protocol():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_flux import FluxT2IEngine, pack_latents, unpack_latents
+
+    class _FakeFlux:
+        config = SimpleNamespace(in_channels=64, guidance_embeds=True)
+        device, dtype = torch.device("cpu"), torch.float32
+
+        @contextlib.contextmanager
+        def cache_context(self, name):
+            yield
+
+        def __call__(self, hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids,
+                     img_ids, return_dict=False):
+            assert guidance.shape == (1,) and float(guidance[0]) == 3.5 and float(timestep[0]) <= 1.0
+            assert img_ids.shape == (hidden_states.shape[1], 3) and txt_ids.shape == (encoder_hidden_states.shape[1], 3)
+            return (hidden_states * 0.5,)
+
+    previews, prog = [], []
+    eng = FluxT2IEngine(_FakeFlux(), decode_fn=lambda z: z.mean())
+    img = eng.run(prompt_embeds=torch.zeros(1, 6, 32), pooled_prompt_embeds=torch.zeros(1, 16), height=64, width=64,
+                  num_inference_steps=4, seed=0, generator=torch.Generator().manual_seed(0),
+                  progress_callback=lambda p, m: prog.append(p), render_on_step=True,
+                  render_on_step_callback=previews.append, render_on_step_interval=2)
+    assert img.ndim == 0 and len(previews) == 2 and prog[-1] == 1.0 and prog == sorted(prog)
+    x = torch.randn(1, 16, 8, 8)
+    assert torch.equal(unpack_latents(pack_latents(x), 64, 64, 8), x)

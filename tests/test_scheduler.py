@@ -36,3 +36,20 @@ def test_static_shift_and_bf16_cast():
     x = torch.ones(4, dtype=torch.bfloat16)
     out = sch.step(torch.ones(4, dtype=torch.bfloat16), sch.timesteps[0], x, return_dict=False)[0]
     assert out.dtype == torch.bfloat16
+
+
+def test_unipc_matches_reference_trajectory(golden_dir):
+    """UniPC restatement vs the reference's in-tree scheduler (scheduler/unipc.py) run here."""
+    import os
+    from apex_studio_amd.schedulers import UniPCMultistepScheduler
+    from tests.golden.seeded import seeded
+    g = torch.load(os.path.join(golden_dir, "unipc.pt"), weights_only=False)
+    s = UniPCMultistepScheduler(shift=g["shift"])
+    ts = s.set_timesteps(g["steps"])
+    assert torch.equal(ts, g["timesteps"])
+    assert torch.allclose(s.sigmas, g["sigmas"], atol=1e-7)
+    x = seeded(g["shape"], g["seed"])
+    for i, t in enumerate(ts):
+        x = s.step(seeded(g["shape"], g["seed"] + 1 + i), t, x, return_dict=False)[0]
+        assert torch.allclose(x, g["traj"][i], atol=2e-5, rtol=2e-5), (i, float((x - g["traj"][i]).abs().max()))
+    assert x.dtype == torch.float32
