@@ -273,7 +273,123 @@ __global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict
     *bp = f32_to_bf16(av * (1.0f - w) + bf16_to_f32(*bp) * w);
 }
 
+// ---- GroupNorm (channels-last) for the Flux 2-D VAE: diffusers ResnetBlock2D / Decoder use
+// GroupNorm(32, C, eps=1e-6) (+ SiLU) (reference vae/auto/model.py:35-41 takes the
+// Decoder from diffusers).  Three deterministic passes: per-block per-channel partial sums, a f64
+// combine into per-group mean / rstd, and the apply (+ affine, + optional SiLU).
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                         int64_t P, int C, int rows_per_block) {
+    __shared__ float red[256][16];
+    const int ncol = C >> 3;                 // 16-byte chunks per position (<= 64)
+    const int col = threadIdx.x % ncol, r0 = threadIdx.x / ncol, rstep = 256 / ncol;
+    const int64_t p0 = (int64_t)blockIdx.x * rows_per_block;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0f;
+    if (r0 < rstep) {
+        for (int r = r0; r < rows_per_block; r += rstep) {
+            const int64_t p = p0 + r;
+            if (p >= P) break;
+            float v[8];
+            unpack8(*(const u32x4*)(x + p * C + col * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += v[j];
+                q[j] += v[j] * v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x][j] = s[j];
+        red[threadIdx.x][8 + j] = q[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < ncol) {                // fixed-order sum over the threads of this column
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        for (int t = threadIdx.x; t < rstep * ncol; t += ncol)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += red[t][j];
+        float* o = part + ((int64_t)blockIdx.x * C + threadIdx.x * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[2 * j] = acc[j];
+            o[2 * j + 1] = acc[8 + j];
+        }
+    }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk, int C,
+                                   int G, int64_t P, float eps) {
+    const int g = threadIdx.x;               // one thread per group
+    if (g >= G) return;
+    const int cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            s += part[((int64_t)b * C + c) * 2];
+            q += part[((int64_t)b * C + c) * 2 + 1];
+        }
+    const double n = (double)P * cpg;
+    const double mean = s / n;
+    const double var = fmax(q / n - mean * mean, 0.0);
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ stats,
+                                                       const bf16_t* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ beta, int64_t P, int C, int G,
+                                                       int silu) {
+    const int ncol = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * ncol) return;
+    const int col = (int)(idx % ncol);
+    const int cpg = C / G;
+    float v[8], gm[8], bt[8];
+    unpack8(*(const u32x4*)(x + idx * 8), v);
+    unpack8(*(const u32x4*)(gamma + col * 8), gm);
+    unpack8(*(const u32x4*)(beta + col * 8), bt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (col * 8 + j) / cpg;
+        float r = (v[j] - stats[2 * g]) * stats[2 * g + 1] * gm[j] + bt[j];
+        if (silu) r = silu_f(r);
+        v[j] = r;
+    }
+    *(u32x4*)(y + idx * 8) = pack8(v);
+}
+
 }  // namespace
+
+extern "C" size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C) {
+    const int nblk = (int)((P + 1023) / 1024);
+    return ((size_t)nblk * C * 2 + 2 * 64) * sizeof(float);
+}
+
+extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, const void* beta, int64_t P,
+                                   int C, int G, float eps, int silu, void* workspace, size_t workspace_bytes,
+                                   apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && gamma && beta && workspace && P > 0, "groupnorm_cl: bad arguments");
+    APEXMI_REQUIRE(C % 8 == 0 && C <= 512 && G > 0 && G <= 64 && C % G == 0 && 256 % (C / 8) == 0,
+                   "groupnorm_cl: C=%d G=%d unsupported", C, G);
+    APEXMI_REQUIRE(workspace_bytes >= apexmi_groupnorm_workspace_bytes(P, C), "groupnorm_cl: workspace too small");
+    const int rows = 1024;
+    const int nblk = (int)((P + rows - 1) / rows);
+    float* part = (float*)workspace;
+    float* stats = part + (size_t)nblk * C * 2;
+    ApexmiProfScope prof(3, stream, 0.0, 6.0 * (double)P * C);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, part, P, C, rows);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, stream, part, stats, nblk, C, G, P, eps);
+    const int64_t n = P * (C / 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)y, stats, (const bf16_t*)gamma, (const bf16_t*)beta, P, C, G, silu);
+    return apexmi_check_launch("groupnorm_cl");
+}
 
 extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual,
                                 void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,

@@ -49,6 +49,9 @@ SIGNATURES = {
     "apexmi_rmsnorm_cl": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_time_interleave_cl": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp]),
+    "apexmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "apexmi_groupnorm_cl": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, vp,
+                                      C.c_size_t, vp]),
     "apexmi_crossfade": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_int64, vp]),
     "apexmi_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,

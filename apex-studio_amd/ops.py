@@ -433,3 +433,29 @@ def crossfade_(a: torch.Tensor, b: torch.Tensor, dim: int) -> torch.Tensor:
                                       b.stride(1), b.stride(2), _stream())
             _l.check(rc, "crossfade")
     return b
+
+
+_gn_ws: dict = {}
+
+
+def groupnorm_cl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
+                 silu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm over a channels-last image [..., C] (all leading dims are positions)."""
+    _req(x, torch.bfloat16, "groupnorm_cl.x")
+    _req(gamma, torch.bfloat16, "groupnorm_cl.gamma")
+    assert x.is_contiguous() and gamma.is_contiguous() and beta.is_contiguous()
+    Cc = x.shape[-1]
+    P = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _l.load()
+    need = lib.apexmi_groupnorm_workspace_bytes(P, Cc)
+    key = (x.device, _stream())
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    rc = lib.apexmi_groupnorm_cl(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), P, Cc, groups,
+                                 float(eps), 1 if silu else 0, ws.data_ptr(), need, _stream())
+    _l.check(rc, "groupnorm_cl")
+    return out

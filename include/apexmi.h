@@ -187,6 +187,12 @@ int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int 
                       apexmi_stream_t stream);
 int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W, int C, apexmi_stream_t stream);
 int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t HW, int C, apexmi_stream_t stream);
+/* GroupNorm(G, C, eps) [+ SiLU] over a channels-last image x [P, C] (P = H*W positions) for the Flux 2-D
+ * VAE decoder (diffusers Decoder / ResnetBlock2D; reference vae/auto/model.py:35-41).
+ * gamma, beta bf16 [C]; workspace: apexmi_groupnorm_workspace_bytes(P, C) device bytes. */
+size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C);
+int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, const void* beta, int64_t P, int C, int G,
+                        float eps, int silu, void* workspace, size_t workspace_bytes, apexmi_stream_t stream);
 int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so, int64_t a_se,
                      int64_t b_so, int64_t b_se, apexmi_stream_t stream);
 
