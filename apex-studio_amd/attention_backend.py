@@ -59,4 +59,10 @@ def register_models(transformers_registry, vae_registry=None):
     transformers_registry("flux.mi355", overwrite=True, available=ok)(FluxTransformer2DModel)
     transformers_registry("wan.mi355", overwrite=True, available=ok)(WanTransformer3DModel)
     transformers_registry("qwenimage.mi355", overwrite=True, available=ok)(QwenImageTransformer2DModel)
+    if vae_registry is not None:   # reference vae/__init__.py:9-73 (keys "auto" | "wan" | "qwenimage")
+        from .vae_flux import AutoencoderKL
+        from .vae_wan import AutoencoderKLWan
+        vae_registry("auto_mi355", overwrite=True, available=ok)(AutoencoderKL)
+        vae_registry("wan_mi355", overwrite=True, available=ok)(AutoencoderKLWan)
+        vae_registry("qwenimage_mi355", overwrite=True, available=ok)(AutoencoderKLWan)
     return transformers_registry

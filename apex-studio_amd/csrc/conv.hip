@@ -401,7 +401,7 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
     const int ntaps = kT * kH * kW;
     APEXMI_REQUIRE(ntaps >= 1 && ntaps <= MAX_TAPS && (kH & 1) && (kW & 1), "conv3d_cl: kernel %dx%dx%d unsupported", kT, kH, kW);
     APEXMI_REQUIRE(Kpad % BK == 0 && Kpad >= ntaps * Cin, "conv3d_cl: Kpad=%d must be >= taps*Cin rounded up to 64", Kpad);
-    APEXMI_REQUIRE(T < 128 && H < 128 * 8 && W < 128 * 8, "conv3d_cl: volume too large for one call");
+    APEXMI_REQUIRE((int64_t)T * H * W < (int64_t)2147483647 - BM, "conv3d_cl: volume too large for one call");
     APEXMI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
                        ((uintptr_t)zeros % 16) == 0,
                    "conv3d_cl: operands must be 16-byte aligned");

@@ -1,26 +1,34 @@
 #!/usr/bin/env python
-"""Headline benchmark: Flux-Dev 1024x1024 denoise steps/s on MI355X (BASELINE.json configs[1]).
+"""Headline benchmark: denoise steps/s (+ s/clip) on MI355X — BASELINE.json metric.
 
-A "step" = one FluxTransformer2DModel forward (19 double + 38 single MM-DiT blocks, S_img 4096 +
-S_txt 512, 24x128 heads, bf16, B=1, no CFG) + one FlowMatch-Euler scheduler.step, on synthetic
-latents / prompt embeddings and random-init weights of the FLUX.1-dev architecture (no network for
-checkpoints).  Inputs are resident in HBM before the timed region.
+Default workload = BASELINE.json configs[1]: Flux-Dev 1024x1024.  A "step" = one
+FluxTransformer2DModel forward (19 double + 38 single MM-DiT blocks, S_img 4096 + S_txt 512, 24x128
+heads, bf16, B=1, no CFG) + one FlowMatch-Euler scheduler.step on synthetic latents / prompt embeddings
+and random-init weights of the FLUX.1-dev architecture (no network for checkpoints).  Inputs are resident
+in HBM before the timed region.  After the timed steps one whole clip (28 steps + 2-D VAE decode to
+1024x1024, bf16) is timed as `sec_per_clip`.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, each denoising its OWN clip (the reference's only multi-GPU mechanism:
-one engine-runner actor per GPU, apps/api/src/api/ray_tasks.py:181-306) -> weak scaling, no collective
-inside a step; RCCL is used once, before the timed region, to broadcast the shared prompt embeddings
-and a stand-in for the shared text-encoder/VAE weights (render_queue.broadcast_shared).
+Other single-GPU BASELINE configs (not the default bench line):
+  --workload qwen    QwenImage-Edit-2509 1024^2 + one 1024^2 condition image (config 3), steps/s
+  --workload wan     Wan-2.2 A14B 720p x 81 frames, one expert forward + UniPC step (config 4), steps/s;
+                     with --clip also 30 steps with the expert switch + tiled 3-D VAE decode (minutes)
+  --workload queue   config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips sharded one clip per GPU
+                     (--queue-wan-steps shortens the Wan clips; clips/hour, makespan)
+
+N > 1: one process per GPU, each denoising its OWN clip (the reference's only multi-GPU mechanism: one
+engine-runner actor per GPU, apps/api/src/api/ray_tasks.py:181-306) -> weak scaling, no collective inside
+a step; RCCL is used once, before the timed region, to broadcast the shared prompt embeddings and a
+stand-in for the shared text-encoder/VAE weights (render_queue.broadcast_shared).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     achieved TFLOP/s of the dominant kernel (gemm_bf16_kernel) = algorithmic 2MNK flops of
-               its launches / their summed HIP-event durations, measured live over extra profiled steps
-  cpu_baseline the CPU oracle (fp32 PyTorch restatement of the reference path) timed on this box's
-               host cores on a bounded sample (1 double + 1 single block at full width/sequence),
-               extrapolated to 19 + 38 blocks
+  roofline     achieved TFLOP/s of the dominant kernel (gemm_bf16_kernel) = algorithmic 2MNK flops of its
+               launches / their summed HIP-event durations, measured live over extra profiled steps
+  cpu_baseline the CPU oracle (fp32 PyTorch restatement of the reference path) timed on this box's host
+               cores on a bounded sample (1 double + 1 single block at full width/sequence), extrapolated
 """
 from __future__ import annotations
 
@@ -41,7 +49,7 @@ FLUX_DEV = dict(patch_size=1, in_channels=64, num_layers=19, num_single_layers=3
                 guidance_embeds=True, axes_dims_rope=(16, 56, 56))
 S_IMG, S_TXT = 4096, 512
 # algorithmic FLOPs of one step: 2MNK per GEMM + 4 H Sq Sk D per attention
-STEP_TFLOP = 74.36
+STEP_TFLOP = {"flux": 74.36, "qwen": 167.4, "wan": 6520.0}
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -50,9 +58,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["flux", "qwen", "wan", "queue"], default="flux")
     ap.add_argument("--layers", type=str, default="", help="debug: 'D,S' block counts (invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip (28 steps + decode) timing")
+    ap.add_argument("--clip", action="store_true", help="wan: also time a whole 30-step clip + decode")
+    ap.add_argument("--queue-wan-steps", type=int, default=30)
     ap.add_argument("--broadcast-mib", type=int, default=1024)
     return ap.parse_args()
 
@@ -87,6 +99,207 @@ def cpu_baseline():
     }
 
 
+def synth_vae_init(vae, seed):
+    g = torch.Generator(device=vae.device).manual_seed(seed)
+    for n, p in vae.named_parameters():
+        if n.endswith("gamma") or (n.endswith("weight") and p.dim() == 1):
+            p.data.fill_(1.0)
+        elif n.endswith("bias"):
+            p.data.zero_()
+        else:
+            p.data.copy_((torch.randn(p.shape, generator=g, device=p.device) / p[0].numel() ** 0.5).to(p.dtype))
+    return vae
+
+
+# ---- workloads: each returns (step_fn(i, state) -> state, state0, total_steps_setup_fn, extras) ----------------
+
+def build_flux(args, dev, rank, total):
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from apex_studio_amd.engine_flux import latent_image_ids, calculate_shift
+    cfg = dict(FLUX_DEV)
+    if args.layers:
+        d, s = (int(v) for v in args.layers.split(","))
+        cfg.update(num_layers=d, num_single_layers=s)
+    model = FluxTransformer2DModel(**cfg, device=dev, dtype=torch.bfloat16).init_synthetic(seed=1234 + rank)
+    model.pack()
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    latents = torch.randn(1, S_IMG, 64, generator=g, device=dev).to(torch.bfloat16)
+    gs = torch.Generator(device=dev).manual_seed(7)
+    enc = torch.randn(1, S_TXT, 4096, generator=gs, device=dev).to(torch.bfloat16)
+    pooled = torch.randn(1, 768, generator=gs, device=dev).to(torch.bfloat16)
+    img_ids = latent_image_ids(64, 64).to(dev)
+    txt_ids = torch.zeros(S_TXT, 3, device=dev)
+    guidance = torch.full([1], 3.5, device=dev, dtype=torch.float32)
+    sched = FlowMatchEulerDiscreteScheduler.flux_dev()
+
+    def reset(n):
+        sig = torch.linspace(1.0, 1.0 / n, n).tolist()
+        ts = sched.set_timesteps(sigmas=sig, mu=calculate_shift(S_IMG), device=dev)
+        sched.set_begin_index(0)
+        return ts
+
+    ts_box = {"ts": reset(total)}
+
+    def step(i, lat):
+        t = ts_box["ts"][i]
+        v = model(hidden_states=lat, timestep=t.expand(1).to(lat.dtype) / 1000, guidance=guidance,
+                  pooled_projections=pooled, encoder_hidden_states=enc, txt_ids=txt_ids, img_ids=img_ids,
+                  return_dict=False)[0]
+        return sched.step(v, t, lat, return_dict=False)[0]
+
+    def clip():
+        """One whole clip: 28 steps + unpack + 2-D VAE decode (engine/flux/t2i.py:251-255)."""
+        from apex_studio_amd.engine_flux import unpack_latents
+        from apex_studio_amd.vae_flux import AutoencoderKL
+        vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
+        lat = torch.randn(1, S_IMG, 64, generator=g, device=dev).to(torch.bfloat16)
+        for rep in range(2):        # first pass warms the VAE's packed weights
+            ts_box["ts"] = reset(28)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x = lat
+            for i in range(28):
+                x = step(i, x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            z = vae.denormalize_latents(unpack_latents(x, 1024, 1024, 8))
+            img = vae.decode(z, return_dict=False)[0]
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+        return {"sec_per_clip": t2 - t0, "denoise_s": t1 - t0, "decode_s": t2 - t1, "steps": 28,
+                "image": list(img.shape), "finite": bool(torch.isfinite(img.float()).all().item())}
+
+    label = ("flux-dev-1024x1024 denoise step (19 double + 38 single MM-DiT blocks, S_img 4096 + S_txt 512, "
+             "B=1, no CFG) + FlowMatch-Euler step") if not args.layers else \
+        f"DEBUG reduced depth {args.layers} (not a valid result)"
+    return step, latents, reset, [enc, pooled], clip, label
+
+
+def build_qwen(args, dev, rank, total):
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from apex_studio_amd.engine_flux import calculate_shift
+    model = QwenImageTransformer2DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=4321 + rank)
+    model.pack()
+    g = torch.Generator(device=dev).manual_seed(200 + rank)
+    latents = torch.randn(1, 4096, 64, generator=g, device=dev).to(torch.bfloat16)
+    cond = torch.randn(1, 4096, 64, generator=g, device=dev).to(torch.bfloat16)
+    enc = torch.randn(1, 256, 3584, generator=torch.Generator(device=dev).manual_seed(8), device=dev).to(torch.bfloat16)
+    shapes = [[(1, 64, 64), (1, 64, 64)]]
+    sched = FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9,
+                                            base_image_seq_len=256, max_image_seq_len=8192, shift_terminal=0.02)
+
+    def reset(n):
+        ts = sched.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / n, n).tolist(),
+                                 mu=calculate_shift(4096, 256, 8192, 0.5, 0.9), device=dev)
+        sched.set_begin_index(0)
+        return ts
+
+    ts_box = {"ts": reset(total)}
+
+    def step(i, lat):
+        t = ts_box["ts"][i]
+        x = torch.cat([lat, cond], dim=1)
+        v = model(hidden_states=x, encoder_hidden_states=enc, encoder_hidden_states_mask=None,
+                  timestep=t.expand(1).to(lat.dtype) / 1000, img_shapes=shapes, txt_seq_lens=[256],
+                  return_dict=False)[0][:, :4096]
+        return sched.step(v, t, lat, return_dict=False)[0]
+
+    label = ("qwenimage-edit-2509 1024x1024 + one 1024x1024 condition image, denoise step (60 MM-DiT blocks, "
+             "S_img 8192 + S_txt 256, B=1) + FlowMatch-Euler step")
+    return step, latents, reset, [enc], None, label
+
+
+def build_wan(args, dev, rank, total):
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from apex_studio_amd.schedulers import UniPCMultistepScheduler
+    model = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=999 + rank)
+    model.pack()
+    g = torch.Generator(device=dev).manual_seed(300 + rank)
+    latents = torch.randn(1, 16, 21, 90, 160, generator=g, device=dev)
+    enc = torch.randn(1, 512, 4096, generator=torch.Generator(device=dev).manual_seed(9), device=dev).to(torch.bfloat16)
+    sched = UniPCMultistepScheduler(shift=3.0)
+
+    def reset(n):
+        return sched.set_timesteps(n, device=dev)
+
+    ts_box = {"ts": reset(total)}
+
+    def step(i, lat):
+        t = ts_box["ts"][i]
+        v = model(hidden_states=lat.to(torch.bfloat16), timestep=t.expand(1), encoder_hidden_states=enc,
+                  return_dict=False)[0]
+        return sched.step(v.float(), t, lat, return_dict=False)[0]
+
+    def clip():
+        from apex_studio_amd.engine_wan import WanT2VEngine
+        from apex_studio_amd.vae_wan import AutoencoderKLWan
+        vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
+        low = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=555 + rank)
+        eng = WanT2VEngine(model, low, vae=vae)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        video = eng.run(prompt_embeds=enc, height=720, width=1280, duration=81, num_inference_steps=30,
+                        generator=torch.Generator(device=dev).manual_seed(1))
+        torch.cuda.synchronize()
+        return {"sec_per_clip": time.perf_counter() - t0, "steps": 30, "video": list(video.shape),
+                "finite": bool(torch.isfinite(video.float()).all().item())}
+
+    label = ("wan-2.2-a14b text-to-video 720p x 81 frames, one expert forward (40 blocks, S 75600 + 512 text, B=1, "
+             "no CFG) + UniPC step")
+    return step, latents, reset, [enc], (clip if args.clip else None), label
+
+
+def run_queue(args, dev, rank, world):
+    """config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips, one clip per GPU at a time (LPT assignment)."""
+    from apex_studio_amd import render_queue
+    from apex_studio_amd.engine_flux import FluxT2IEngine
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    flux = FluxT2IEngine(FluxTransformer2DModel(**FLUX_DEV, device=dev, dtype=torch.bfloat16).init_synthetic(1),
+                         decode_fn=None)
+    fvae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
+    flux.decode_fn = lambda z: fvae.decode(fvae.denormalize_latents(z), return_dict=False)[0]
+    hi = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(2)
+    lo = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(3)
+    wan = WanT2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6))
+    g = torch.Generator(device=dev).manual_seed(7)
+    f_enc = torch.randn(1, S_TXT, 4096, generator=g, device=dev).to(torch.bfloat16)
+    f_pool = torch.randn(1, 768, generator=g, device=dev).to(torch.bfloat16)
+    w_enc = torch.randn(1, 512, 4096, generator=g, device=dev).to(torch.bfloat16)
+    shared = torch.empty(args.broadcast_mib << 20, dtype=torch.uint8, device=dev)
+    bcast = render_queue.broadcast_shared([f_enc, f_pool, w_enc, shared], src=0)
+    del shared
+    clips = [{"kind": "flux", "seed": i, "cost": 2.5} for i in range(4)] + \
+            [{"kind": "wan", "seed": 10 + i, "cost": 6.0 * args.queue_wan_steps} for i in range(4)]
+
+    def runner(c):
+        if c["kind"] == "flux":
+            flux.run(prompt_embeds=f_enc, pooled_prompt_embeds=f_pool, height=1024, width=1024,
+                     num_inference_steps=28, seed=c["seed"])
+        else:
+            wan.run(prompt_embeds=w_enc, height=720, width=1280, duration=81,
+                    num_inference_steps=args.queue_wan_steps, seed=c["seed"])
+
+    runner(dict(clips[0], seed=99))      # warm (packing, workspaces)
+    res = render_queue.run_queue(clips, runner)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "queue_clips_per_hour", "value": res["clips_per_hour"], "unit": "clips/h", "n_gpus": world,
+            "steps": 1, "warmup": 1, "ms_per_step": 1e3 * res["makespan"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"8-clip render queue: 4x flux-dev 1024^2 (28 steps + decode) + 4x wan-2.2 "
+                                   f"720p x 81f ({args.queue_wan_steps} steps, expert switch, tiled 3D-VAE decode), "
+                                   f"one clip per GPU at a time", "parallelism": f"clip-per-gpu x{world}"},
+            "makespan_s": res["makespan"], "busy_s": res["busy"],
+            "clip_seconds": {str(k): round(v, 3) for k, v in sorted(res["clip_seconds"].items())},
+            "broadcast": bcast}), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -103,46 +316,24 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import apex_studio_amd  # noqa: F401
-    from apex_studio_amd import lib
-    from apex_studio_amd.flux import FluxTransformer2DModel
-    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
-    from apex_studio_amd import render_queue
-    from apex_studio_amd.engine_flux import latent_image_ids, calculate_shift
+    from apex_studio_amd import lib, render_queue
 
-    cfg = dict(FLUX_DEV)
-    if args.layers:
-        d, s = (int(v) for v in args.layers.split(","))
-        cfg.update(num_layers=d, num_single_layers=s)
-    model = FluxTransformer2DModel(**cfg, device=dev, dtype=torch.bfloat16).init_synthetic(seed=1234 + rank)
-    model.pack()
-
-    # this rank's clip: its own noise; the prompt embeddings are shared -> broadcast from rank 0
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
-    latents = torch.randn(1, S_IMG, 64, generator=g, device=dev).to(torch.bfloat16)
-    gs = torch.Generator(device=dev).manual_seed(7)
-    enc = torch.randn(1, S_TXT, 4096, generator=gs, device=dev).to(torch.bfloat16)
-    pooled = torch.randn(1, 768, generator=gs, device=dev).to(torch.bfloat16)
-    bcast = None
-    if distributed:
-        shared = torch.empty(args.broadcast_mib << 20, dtype=torch.uint8, device=dev)
-        bcast = render_queue.broadcast_shared([enc, pooled, shared], src=0)
-        del shared
-    img_ids = latent_image_ids(64, 64).to(dev)
-    txt_ids = torch.zeros(S_TXT, 3, device=dev)
-    guidance = torch.full([1], 3.5, device=dev, dtype=torch.float32)
+    if args.workload == "queue":
+        run_queue(args, dev, rank, world)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     total = args.warmup + args.steps
-    sched = FlowMatchEulerDiscreteScheduler.flux_dev()
-    sig = torch.linspace(1.0, 1.0 / total, total).tolist()
-    timesteps = sched.set_timesteps(sigmas=sig, mu=calculate_shift(S_IMG), device=dev)
-    sched.set_begin_index(0)
+    build = {"flux": build_flux, "qwen": build_qwen, "wan": build_wan}[args.workload]
+    step, latents, reset, shared_inputs, clip_fn, label = build(args, dev, rank, total)
 
-    def step(i, lat):
-        t = timesteps[i]
-        ts = t.expand(1).to(lat.dtype)
-        v = model(hidden_states=lat, timestep=ts / 1000, guidance=guidance, pooled_projections=pooled,
-                  encoder_hidden_states=enc, txt_ids=txt_ids, img_ids=img_ids, return_dict=False)[0]
-        return sched.step(v, t, lat, return_dict=False)[0]
+    bcast = None
+    if distributed:   # the prompt embeddings are shared -> broadcast from rank 0, with a stand-in weight buffer
+        shared = torch.empty(args.broadcast_mib << 20, dtype=torch.uint8, device=dev)
+        bcast = render_queue.broadcast_shared(list(shared_inputs) + [shared], src=0)
+        del shared
 
     for i in range(args.warmup):
         latents = step(i, latents)
@@ -167,8 +358,7 @@ def main():
     kernels = {}
     if rank == 0 and not args.no_roofline:
         nprof = min(3, args.steps)
-        sched.set_begin_index(0)
-        sched._step_index = None
+        reset(total)
         lib.prof_reset()
         lib.prof_enable(True)
         lat = latents
@@ -183,33 +373,41 @@ def main():
                                  "avg_launch_us": 1e3 * r["ms"] / r["launches"],
                                  "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12) if r["flops"] else None,
                                  "gbps": (r["bytes"] / (r["ms"] * 1e-3) / 1e9) if r["bytes"] else None}
-        gk = prof["gemm"]
+        # dominant kernel by time: the GEMM for flux / qwen, attention for wan
+        dom = max(("gemm", "attention"), key=lambda k: prof[k]["ms"])
+        gk = prof[dom]
         ach = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                    "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
+        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this command
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
+        if dom == "gemm" and args.workload == "flux" and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_kernel",
+                    "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "traffic": traffic, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
                     "launches_per_step": gk["launches"] / nprof,
                     "algorithmic_tflop_per_step": gk["flops"] / nprof / 1e12}
+
+    clip = None
+    if rank == 0 and clip_fn is not None and not args.no_clip and not args.layers:
+        clip = clip_fn()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         full = not args.layers
+        tf = STEP_TFLOP[args.workload]
         out = {
             "metric": "denoise_steps_per_sec", "value": args.gpus * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "flux-dev-1024x1024 denoise step (19 double + 38 single MM-DiT blocks, "
-                                   "S_img 4096 + S_txt 512, B=1, no CFG) + FlowMatch-Euler step"
-                       if full else f"DEBUG reduced depth {args.layers} (not a valid result)",
-                       "clips_in_flight": args.gpus, "parallelism": f"clip-per-gpu x{args.gpus}",
-                       "step_tflop": STEP_TFLOP if full else None},
-            "model_tflops_per_gpu": (STEP_TFLOP / (ms_per_step * 1e-3)) if full else None,
-            "mfma_utilisation_step": (STEP_TFLOP / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS) if full else None,
-            "finite": finite,
-            "roofline": roofline, "kernels": kernels, "broadcast": bcast,
+            "config": {"workload": label, "clips_in_flight": args.gpus, "parallelism": f"clip-per-gpu x{args.gpus}",
+                       "step_tflop": tf if full else None},
+            "model_tflops_per_gpu": (tf / (ms_per_step * 1e-3)) if full else None,
+            "mfma_utilisation_step": (tf / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS) if full else None,
+            "sec_per_clip": clip["sec_per_clip"] if clip else None, "clip": clip,
+            "finite": finite, "roofline": roofline, "kernels": kernels, "broadcast": bcast,
         }
-        if not args.no_cpu_baseline and args.gpus == 1:
+        if not args.no_cpu_baseline and args.gpus == 1 and args.workload == "flux":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:

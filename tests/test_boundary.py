@@ -42,8 +42,10 @@ def test_backend_registration_and_argument_errors():
     for kw in (dict(attn_mask=torch.ones(8, 8)), dict(dropout_p=0.1), dict(is_causal=True)):
         with pytest.raises(ApexMIError):
             ab.hip_mfma(q, q, q, **kw)
-    creg = ab.register_models(ClassRegister())
+    vreg = ClassRegister()
+    creg = ab.register_models(ClassRegister(), vreg)
     assert {"flux.mi355", "wan.mi355", "qwenimage.mi355"} <= set(creg.all())
+    assert {"auto_mi355", "wan_mi355", "qwenimage_mi355"} <= set(vreg.all())
 
 
 def test_flux_class_contract_on_meta_device():

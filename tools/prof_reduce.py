@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Reduce rocprofv3 CSV output (kernel_trace + counter_collection) to small per-kernel summaries that can
+be committed under profiles/: kernel_stats.csv (calls, total/avg/min/max ns, %) and pmc_summary.csv
+(per-kernel mean of every counter per dispatch)."""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(gemm_bf16_kernel<[^(]*?>\s*>?|attn_fwd_d128_kernel<\d+>|[A-Za-z_0-9]+_kernel(?:<[^>]*>)?)", name)
+    n = m.group(1) if m else name.split("(")[0]
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    return n[-110:]
+
+
+def main(root):
+    traces = glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    if traces:
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(traces[0])):
+            agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        tot = sum(sum(v) for v in agg.values()) or 1
+        with open(os.path.join(root, "kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([k, len(v), sum(v), f"{sum(v) / len(v):.1f}", min(v), max(v), f"{100.0 * sum(v) / tot:.2f}"])
+    pm = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            pm[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if pm:
+        counters = sorted({c for d in pm.values() for c in d})
+        with open(os.path.join(root, "pmc_summary.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Dispatches"] + counters)
+            for k, d in sorted(pm.items(), key=lambda kv: -len(next(iter(kv[1].values())))):
+                n = max(len(v) for v in d.values())
+                w.writerow([k, n] + [f"{sum(d[c]) / len(d[c]):.6g}" if c in d else "" for c in counters])
+    for name in ("kernel_stats.csv", "pmc_summary.csv"):
+        p = os.path.join(root, name)
+        if os.path.exists(p):
+            print("==", name)
+            print("".join(open(p).readlines()[:14]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
