@@ -30,7 +30,7 @@ def broadcast_shared(tensors: Sequence[torch.Tensor], src: int = 0, group=None,
                      big_bytes: int = 8 << 20) -> Dict[str, float]:
     """In-place broadcast of `tensors` from rank `src`.  Large contiguous tensors go
     scatter + all-gather, small ones a plain broadcast.  Returns bytes / seconds / GB/s."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return {"bytes": 0, "seconds": 0.0, "gbps": 0.0, "world": 1}
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -308,7 +308,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("APEX_FORCE_DIST") == "1"   # force: RCCL smoke test on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
