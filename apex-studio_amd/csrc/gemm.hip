@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -48,21 +49,29 @@ struct GemmGroup {
     int count, K, total;
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool PP_>
+template <int BM_, int BN_, int WM_, int WN_, int SCHED_, int VAR_ = 0>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-    static constexpr bool PP = PP_;
+    static constexpr int SCHED = SCHED_;  // 0 plain double buffer, 1 ping-pong phases, 2 rotated software pipeline
+    static constexpr bool PP = SCHED_ == 1;
+    static constexpr int VAR = VAR_;  // ABLATION ONLY
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
     static constexpr int STAGE = A_BYTES + W_BYTES;
     static constexpr int LDS = 2 * STAGE;
     static constexpr int A_LD = BM * 8 / NT, W_LD = BN * 8 / NT;  // glds per thread per K-tile
-    static constexpr int OCC = (LDS <= 80 * 1024 && NT == 256) ? 2 : (NT == 512 ? 2 : 1);
+    static constexpr int OCC = (LDS <= 80 * 1024 && NT == 256) ? 2 : (NT == 512 ? 2 : 1);  // waves per EU for launch_bounds
 };
-using CFG_128 = Cfg<128, 128, 2, 2, false>;
-using CFG_256 = Cfg<256, 256, 2, 4, false>;
-using CFG_256P = Cfg<256, 256, 2, 4, true>;
+using CFG_128 = Cfg<128, 128, 2, 2, 0>;
+using CFG_256 = Cfg<256, 256, 2, 4, 0>;
+using CFG_256P = Cfg<256, 256, 2, 4, 1>;
+using CFG_256R = Cfg<256, 256, 2, 4, 2>;
+using CFG_256S = Cfg<256, 256, 2, 4, 3>;
+using CFG_256W = Cfg<256, 256, 2, 2, 4>;
+using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
+template <int V> using CFG_WABL = Cfg<256, 256, 2, 2, 4, V>;
+template <int V> using CFG_ABL = Cfg<256, 256, 2, 4, 2, V>;
 
 // exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
 // columns: low half-wave gets [a_lo | a_hi] = cols 8g..8g+7, high half-wave [b_lo | b_hi] = cols
@@ -146,6 +155,80 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
         }
 }
 
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// v_permlane16_swap on a register pair: rows of 16 lanes, odd rows of `a` <-> even rows of `b`
+APEXMI_DEVICE void swap16(uint32_t& a, uint32_t& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+// Epilogue for one 32-column slab (two 16x16 n-tiles x, y) of a wave that accumulated with
+// v_mfma_f32_16x16x32_bf16 (operands swapped: D rows = output columns).  Accumulator layout: lane (g = lane >> 4,
+// c = lane & 15) holds C[m = mtile*16 + c][n = nbase + 16 t + 4 g + (0..3)] for t = 0 (x), 1 (y).  One
+// v_permlane16_swap per dword pair turns that into 8 consecutive columns per lane, starting at
+// nbase + 16 (g & 1) + 8 (g >> 1), so stores and residual loads are 16 bytes wide.
+template <int EPI, int MT>
+APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], const GemmProblem& P, int N,
+                                const int (&m)[MT], int nbase, int g) {
+    float bs[2][4];
+    f32x4 gt[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = min(nbase + 16 * t + 4 * g, N - 4);
+        u32x2 b = {0u, 0u};
+        if (P.bias != nullptr) b = *(const u32x2*)(P.bias + n);
+        bs[t][0] = bf16_lo(b[0]);
+        bs[t][1] = bf16_hi(b[0]);
+        bs[t][2] = bf16_lo(b[1]);
+        bs[t][3] = bf16_hi(b[1]);
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[t] = *(const f32x4*)(P.gate + n);
+    }
+    const int nst = nbase + 16 * (g & 1) + 8 * (g >> 1);  // first of the 8 columns this lane stores
+    u32x4 rr[MT];
+    if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            rr[mt] = *(const u32x4*)(P.R + (int64_t)max(m[mt], 0) * P.ldr + min(nst, N - 8));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float v[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[0][j] = x[mt][j] + bs[0][j];
+            v[1][j] = y[mt][j] + bs[1][j];
+            if (EPI == APEXMI_EPI_BIAS && P.gelu) {
+                v[0][j] = gelu_tanh_f(v[0][j]);
+                v[1][j] = gelu_tanh_f(v[1][j]);
+            }
+        }
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+            uint32_t r0 = rr[mt][0], r1 = rr[mt][1], r2 = rr[mt][2], r3 = rr[mt][3];
+            swap16(r0, r2);  // 16-byte row segment -> accumulator layout (the exchange is an involution)
+            swap16(r1, r3);
+            const uint32_t ra[2][2] = {{r0, r1}, {r2, r3}};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v[t][0] = bf16_lo(ra[t][0]) + gt[t][0] * v[t][0];
+                v[t][1] = bf16_hi(ra[t][0]) + gt[t][1] * v[t][1];
+                v[t][2] = bf16_lo(ra[t][1]) + gt[t][2] * v[t][2];
+                v[t][3] = bf16_hi(ra[t][1]) + gt[t][3] * v[t][3];
+            }
+        }
+        uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]);
+        uint32_t y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
+        swap16(x0, y0);
+        swap16(x1, y1);
+        if (m[mt] >= 0 && nst < N) {
+            const u32x4 o = {x0, x1, y0, y1};
+            *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;
+        }
+    }
+}
+
 template <typename CFG, int EPI>
 __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const GemmGroup G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,6 +280,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    f32x4_t acc16[4][8];  // SCHED 5 only: [16-column n-tile][16-row m-tile]
+    if constexpr (CFG::SCHED == 5) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     const int nkt = G.K / BK;
 
     auto stage = [&](int buf, int kt) {
@@ -224,7 +314,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         w_sw[t] = (r >> 1) & 7;
     }
 
-    if constexpr (!CFG::PP) {
+    if constexpr (CFG::SCHED == 0) {
         stage(0, 0);
         for (int kt = 0; kt < nkt; ++kt) {
             // tile kt's LDS-DMA landed (explicit: hipcc's __syncthreads() does not reliably wait for
@@ -249,6 +339,450 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
             }
         }
+    } else if constexpr (CFG::SCHED == 2) {
+        // ---- rotated software pipeline (TM = 4, TN = 2) ----
+        // One barrier per K-tile, placed between k-steps 2 and 3: by then every wave has ISSUED (and
+        // drained) all fragment reads of tile kt — k-step 3's fragments were prefetched during k-step
+        // 2's MFMAs — so the barrier both frees slot kt&1 for tile kt+2 and publishes tile kt+1 (each
+        // wave drains its own LDS-DMA pieces first).  The first MFMAs after the barrier already hold
+        // their operands, fragment reads run one k-step ahead of the MFMAs that consume them, and the
+        // 8 LDS-DMA pieces of the next-but-one tile go out 3/3/2 behind the first three k-steps of the
+        // period, leaving a k-step for the last piece to land before the next drain.
+        static_assert(CFG::SCHED != 2 || (TM == 4 && TN == 2 && CFG::A_LD == 4 && CFG::W_LD == 4),
+                      "rotated schedule is written for 128x64 wave tiles, 8 waves");
+        bf16x8 fa[2][4], fw[2][2];
+        u32x4 sink[8];
+        auto rd = [&](int slot, int ks, int b, bool force = false) {
+            const char* As = smem + slot * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
+            const int c = ks * 2 + hi;
+            if ((CFG::VAR & 2) && !force) return;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[b][t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fw[b][t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
+        };
+        auto mma = [&](int b) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][nt], fa[b][mt], acc[nt][mt], 0, 0, 0);
+        };
+        // pieces 0..3 = activation rows, 4..7 = weight rows of one tile image (same split as stage())
+        auto dma = [&](int slot, int kt, int first, int count) {
+            char* base = smem + slot * CFG::STAGE + wave * 1024;
+            const int64_t koff = (CFG::VAR & 4) ? 0 : (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int i = first; i < first + count; ++i) {
+                if (CFG::VAR & 1) continue;
+                if (CFG::VAR & 32) {  // plain register loads, never written to LDS
+                    const char* sp = i < 4 ? a_src[i] + koff : w_src[i - 4] + koff;
+                    sink[i] = *(const u32x4*)sp;
+                    continue;
+                }
+                if ((CFG::VAR & 16) && lane != 0) continue;
+                if (i < 4)
+                    glds16(a_src[i] + koff, base + i * (CFG::NW * 1024));
+                else
+                    glds16(w_src[i - 4] + koff, base + CFG::A_BYTES + (i - 4) * (CFG::NW * 1024));
+            }
+        };
+        // issue order hint for one k-step: MFMA / LDS read alternating, LDS-DMA after every 2nd MFMA
+        auto interleave = [&](int nread, int ndma) {
+            if (CFG::VAR & 64) return;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < nread) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if ((i & 1) && (i >> 1) < ndma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        };
+#define RS_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // one period = [k-step 3 of tile kt | k-steps 0..2 of tile kt+1]
+        auto period = [&](int kt, auto has_dma, auto has_next) {
+            constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
+            const int cur = kt & 1, nxt = cur ^ 1;
+            if (CFG::VAR & 32) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(sink[i]));
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            RS_FENCE();
+            if (!(CFG::VAR & 8)) __builtin_amdgcn_s_barrier();
+            if ((CFG::VAR & 128) && wm == 1) __builtin_amdgcn_s_sleep(2);
+            if ((CFG::VAR & 256) && wm == 1) __builtin_amdgcn_s_sleep(4);
+            RS_FENCE();
+            if (NEXT) rd(nxt, 0, 0);
+            if (DMA) dma(cur, kt + 2, 0, 3);
+            if (CFG::VAR & 64) RS_FENCE();
+            mma(1);
+            interleave(NEXT ? 6 : 0, DMA ? 3 : 0);
+            RS_FENCE();
+            if (NEXT) {
+                rd(nxt, 1, 1);
+                if (DMA) dma(cur, kt + 2, 3, 3);
+                if (CFG::VAR & 64) RS_FENCE();
+                mma(0);
+                interleave(6, DMA ? 3 : 0);
+                RS_FENCE();
+                rd(nxt, 2, 0);
+                if (DMA) dma(cur, kt + 2, 6, 2);
+                if (CFG::VAR & 64) RS_FENCE();
+                mma(1);
+                interleave(6, DMA ? 2 : 0);
+                RS_FENCE();
+                rd(nxt, 3, 1);
+                if (CFG::VAR & 64) RS_FENCE();
+                mma(0);
+                interleave(6, 0);
+                RS_FENCE();
+            }
+        };
+        if (CFG::VAR & 2) {
+            rd(0, 0, 0, true);
+            rd(0, 1, 1, true);
+        }
+        dma(0, 0, 0, 8);
+        if (nkt > 1) {
+            dma(1, 1, 0, 8);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        RS_FENCE();
+        __builtin_amdgcn_s_barrier();
+        RS_FENCE();
+        rd(0, 0, 0);
+        rd(0, 1, 1);
+        mma(0);
+        interleave(6, 0);
+        RS_FENCE();
+        rd(0, 2, 0);
+        mma(1);
+        interleave(6, 0);
+        RS_FENCE();
+        rd(0, 3, 1);
+        mma(0);
+        interleave(6, 0);
+        RS_FENCE();
+        int kt = 0;
+        for (; kt + 2 < nkt; ++kt) period(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nkt) {
+            period(kt, std::false_type{}, std::true_type{});
+            ++kt;
+        }
+        period(kt, std::false_type{}, std::false_type{});
+#undef RS_FENCE
+    } else if constexpr (CFG::SCHED == 3) {
+        // ---- slot schedule: the rotated pipeline of SCHED 2 with every instruction pinned to an MFMA slot ----
+        // A period (one barrier) is 32 MFMA slots = k-step 3 of tile kt, then k-steps 0..2 of tile kt+1.
+        // Slot s carries: MFMA s; for the first six slots of a k-step one ds_read_b128 of the NEXT k-step's
+        // fragments; and, on slots ROT, ROT+3, ..., ROT+21, one LDS-DMA piece of tile kt+2.  ROT = wave % 3,
+        // so the 8 waves of the CU hand the texture-address unit one 16-cycle piece at a time instead of 24
+        // at once (measured: simultaneous issue starves the matrix pipe for ~90 cycles per piece per wave).
+        static_assert(CFG::SCHED != 3 || (TM == 4 && TN == 2 && CFG::A_LD == 4 && CFG::W_LD == 4),
+                      "slot schedule is written for 128x64 wave tiles, 8 waves");
+        bf16x8 fa[2][4], fw[2][2];
+        auto rd1 = [&](int slot, int ks, int b, int j) {  // j-th of the six fragment reads of a k-step
+            const char* As = smem + slot * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
+            const int c = ks * 2 + hi;
+            if (j == 0) fw[b][0] = *(const bf16x8*)(Ws + w_off[0] + ((c ^ w_sw[0]) << 4));
+            else if (j == 5) fw[b][1] = *(const bf16x8*)(Ws + w_off[1] + ((c ^ w_sw[1]) << 4));
+            else fa[b][j - 1] = *(const bf16x8*)(As + a_off[j - 1] + ((c ^ a_sw[j - 1]) << 4));
+        };
+        auto mma1 = [&](int b, int i) {  // i-th MFMA of a k-step: (nt, mt) = (i / 4, i % 4)
+            acc[i >> 2][i & 3] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][i >> 2], fa[b][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+        };
+        auto dma1 = [&](int slot, int kt, int i) {
+            char* base = smem + slot * CFG::STAGE + wave * 1024;
+            const int64_t koff = (int64_t)kt * (BK * 2);
+            if (i < 4) glds16(a_src[i] + koff, base + i * (CFG::NW * 1024));
+            else glds16(w_src[i - 4] + koff, base + CFG::A_BYTES + (i - 4) * (CFG::NW * 1024));
+        };
+#define SL_FENCE() __builtin_amdgcn_sched_barrier(0)
+        auto period = [&](int kt, auto rot_, auto has_dma, auto has_next) {
+            constexpr int ROT = decltype(rot_)::value;
+            constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
+            const int cur = kt & 1, nxt = cur ^ 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            SL_FENCE();
+            __builtin_amdgcn_s_barrier();
+            SL_FENCE();
+#pragma unroll
+            for (int s = 0; s < (NEXT ? 32 : 8); ++s) {
+                const int q = s >> 3, i = s & 7;
+                mma1((q + 1) & 1, i);
+                if (NEXT && i < 6) rd1(nxt, q, q & 1, i);
+                if (DMA && s >= ROT && (s - ROT) % 3 == 0 && (s - ROT) / 3 < 8) dma1(cur, kt + 2, (s - ROT) / 3);
+                SL_FENCE();
+            }
+        };
+        auto run = [&](auto rot_) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma1(0, 0, i);
+            if (nkt > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dma1(1, 1, i);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            SL_FENCE();
+            __builtin_amdgcn_s_barrier();
+            SL_FENCE();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) rd1(0, 0, 0, j);
+            SL_FENCE();
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {  // k-steps 0..2 of tile 0
+                const int q = s >> 3, i = s & 7;
+                mma1(q & 1, i);
+                if (i < 6) rd1(0, q + 1, (q + 1) & 1, i);
+                SL_FENCE();
+            }
+            int kt = 0;
+            for (; kt + 2 < nkt; ++kt) period(kt, rot_, std::true_type{}, std::true_type{});
+            if (kt + 1 < nkt) {
+                period(kt, rot_, std::false_type{}, std::true_type{});
+                ++kt;
+            }
+            period(kt, rot_, std::false_type{}, std::false_type{});
+        };
+        const int rot = wave % 3;
+        if (rot == 0) run(std::integral_constant<int, 0>{});
+        else if (rot == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+#undef SL_FENCE
+    } else if constexpr (CFG::SCHED == 4) {
+        // ---- one wave per SIMD: 4 waves (2x2) of 128x128, accumulators in AGPRs ----
+        // Measured on gfx950 (tools/ubench/mfma_vmem.hip): at the GEMM's rate of one LDS-DMA piece per
+        // 4 MFMAs, two waves per SIMD lose 28-36 % of the matrix pipe to the piece issue, one wave per
+        // SIMD loses 1 % (buffer_load .. lds) to 5 % (global_load_lds).  So: 256 threads, every wave
+        // alone on its SIMD, the whole pipeline in one instruction stream.  Same rotated period as
+        // SCHED 2/3 (barrier between k-steps 2 and 3), 64 MFMA slots per period; slot s carries MFMA s,
+        // one of the 8 fragment reads of the next k-step on the first 8 slots of a k-step, and one of the
+        // 16 LDS-DMA pieces of tile kt+2 on every third slot from ROT.  Pieces go through buffer_load
+        // with the row/swizzle part in one VGPR per operand and the piece/K offset in an SGPR; rows past
+        // M fall outside the descriptor's range and read as zero, so there is no clamping.
+        static_assert(CFG::SCHED != 4 || (TM == 4 && TN == 4 && CFG::NW == 4), "SCHED 4 is written for 2x2 waves of 128x128");
+        bf16x8 fa[2][4], fw[2][4];
+        const int rows_a = min(M - m0, BM), rows_w = min(N - n0, BN);
+        auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (int64_t)m0 * P.lda), 0,
+                                                        (int)(((int64_t)(rows_a - 1) * P.lda + G.K) * 2), 0x00020000);
+        auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (int64_t)n0 * P.ldw), 0,
+                                                        (int)(((int64_t)(rows_w - 1) * P.ldw + G.K) * 2), 0x00020000);
+        // piece i of a wave = rows (i*4 + wave)*8 .. +7; (row >> 1) & 7 = 4 (wave & 1) + (lane >> 4) for every i
+        const int sw_src = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+        const int voff_a = (lane >> 3) * (int)P.lda * 2 + sw_src;
+        const int voff_w = (lane >> 3) * (int)P.ldw * 2 + sw_src;
+        const int sa = (int)P.lda * 2 * 8, sw = (int)P.ldw * 2 * 8;  // bytes per 8-row piece step
+        // When the row stride is a multiple of 8 KiB (K = 12288 or 8192) every row of every tile at one k
+        // offset falls into the same cache set / memory channel; CUs marching through K in lockstep then
+        // queue on it (945 vs 1220 TFLOP/s at 4096x3072x12288 against the same problem with the stride
+        // padded by 128 B).  Starting each XCD's tiles an eighth of K apart spreads them (+4 %) and keeps
+        // the operand sharing inside an XCD's L2; the fp32 sum is order-independent up to rounding.
+        const int krot = (G.K * 2) % 8192 == 0 ? (int)(blockIdx.x & 7) * (nkt >> 3) : 0;
+        auto dma1 = [&](int slot, int kt_, int i) {  // i in 0..15: 0..7 activation pieces, 8..15 weight pieces
+            int kt = kt_ + krot;
+            kt = kt >= nkt ? kt - nkt : kt;
+            char* base = smem + slot * CFG::STAGE + wave * 1024;
+            if (i < 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(base + i * 4096), 16, voff_a,
+                                                         (i * 4 + wave) * sa + kt * (BK * 2), 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(base + CFG::A_BYTES + (i - 8) * 4096), 16,
+                                                         voff_w, ((i - 8) * 4 + wave) * sw + kt * (BK * 2), 0, 0);
+        };
+        auto rd1 = [&](int slot, int ks, int b, int j) {  // j-th of the eight fragment reads of a k-step
+            const char* As = smem + slot * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
+            const int c = ks * 2 + hi;
+            // order W0 A0 A1 A2 A3 W1 W2 W3: the first MFMAs of the next k-step need the fewest reads
+            if (j == 0) fw[b][0] = *(const bf16x8*)(Ws + w_off[0] + ((c ^ w_sw[0]) << 4));
+            else if (j <= 4) fa[b][j - 1] = *(const bf16x8*)(As + a_off[j - 1] + ((c ^ a_sw[j - 1]) << 4));
+            else fw[b][j - 4] = *(const bf16x8*)(Ws + w_off[j - 4] + ((c ^ w_sw[j - 4]) << 4));
+        };
+        auto mma1 = [&](int b, int i) {  // i-th MFMA of a k-step: (nt, mt) = (i / 4, i % 4)
+            acc[i >> 2][i & 3] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][i >> 2], fa[b][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+        };
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+        constexpr int ROT = 0;
+        constexpr int STEP = (CFG::VAR & 16) ? 3 : (CFG::VAR & 32) ? 1 : 2;  // MFMA slots between LDS-DMA pieces
+        auto period = [&](int kt, auto has_dma, auto has_next) {
+            constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
+            const int cur = kt & 1, nxt = cur ^ 1;
+            if (CFG::VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            W4_FENCE();
+            if (!(CFG::VAR & 2)) __builtin_amdgcn_s_barrier();
+            W4_FENCE();
+#pragma unroll
+            for (int s = 0; s < (NEXT ? 64 : 16); ++s) {
+                const int q = s >> 4, i = s & 15;
+                mma1((q + 1) & 1, i);
+                if (NEXT && i < 8 && !(CFG::VAR & 8)) rd1(nxt, q, q & 1, i);
+                if (DMA && !(CFG::VAR & 4) && s >= ROT && (s - ROT) % STEP == 0 && (s - ROT) / STEP < 16) dma1(cur, kt + 2, (s - ROT) / STEP);
+                W4_FENCE();
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dma1(0, 0, i);
+        if (nkt > 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dma1(1, 1, i);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        W4_FENCE();
+        __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rd1(0, 0, 0, j);
+        W4_FENCE();
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {  // k-steps 0..2 of tile 0
+            const int q = s >> 4, i = s & 15;
+            mma1(q & 1, i);
+            if (i < 8) rd1(0, q + 1, (q + 1) & 1, i);
+            W4_FENCE();
+        }
+        int kt = 0;
+        for (; kt + 2 < nkt; ++kt) period(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nkt) {
+            period(kt, std::false_type{}, std::true_type{});
+            ++kt;
+        }
+        period(kt, std::false_type{}, std::false_type{});
+#undef W4_FENCE
+    } else if constexpr (CFG::SCHED == 5) {
+        // ---- ping-pong schedule on v_mfma_f32_16x16x32_bf16 ----
+        // Same phases, regions and waits as SCHED 1; the quadrant (64 rows x 32 columns x K 64) is 16 MFMAs
+        // of 16x16x32 instead of 8 of 32x32x16.  Measured at the chip's power limit (tools/ubench/
+        // mfma_power.hip, register-resident random operands, matrix pipe 95 % busy in both cases): the
+        // 16x16x32 form sustains 2.03 GHz against 1.79 GHz for 32x32x16 — the step is power-bound, so the
+        // cheaper instruction is the faster one.
+        const int l15 = lane & 15, g4 = lane >> 4;
+        const int sw16 = (l15 >> 1) & 7;
+        int a16[8], w16[4];  // byte offsets of this lane's row in each 16-row tile of the wave's sub-tiles
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a16[t] = (wm * 128 + t * 16 + l15) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w16[t] = (wn * 64 + t * 16 + l15) * 128;
+        const int ch16[2] = {((0 + g4) ^ sw16) << 4, ((4 + g4) ^ sw16) << 4};
+        bf16x8 af[4][2], wf[2][2];
+        auto rd_a = [&](const char* As, int half) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[t][ks] = *(const bf16x8*)(As + a16[half * 4 + t] + ch16[ks]);
+        };
+        auto rd_w = [&](const char* Ws, int nt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wf[u][ks] = *(const bf16x8*)(Ws + w16[nt * 2 + u] + ch16[ks]);
+        };
+        auto mma = [&](int half, int nt) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc16[nt * 2 + u][half * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf[u][ks], af[t][ks], acc16[nt * 2 + u][half * 4 + t], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+#define PP_SYNC()                                                                   \
+    do {                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        __builtin_amdgcn_s_barrier();                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#define PP_BAR()                               \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+        const char* ra_src[2][2];
+        const char* rw_src[2][2];
+        int ra_lds[2][2], rw_lds[2][2];
+#pragma unroll
+        for (int reg = 0; reg < 2; ++reg)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = j * 8 + wave;
+                const int ra0 = (q < 8 ? q * 8 : 128 + (q - 8) * 8) + reg * 64;
+                const int rw0 = (q >> 2) * 64 + reg * 32 + (q & 3) * 8;
+                const int ra = ra0 + (lane >> 3), rw = rw0 + (lane >> 3);
+                ra_src[reg][j] = (const char*)(P.A + (int64_t)min(m0 + ra, M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) * 8));
+                rw_src[reg][j] = (const char*)(P.W + (int64_t)min(n0 + rw, N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) * 8));
+                ra_lds[reg][j] = ra0 * 128;
+                rw_lds[reg][j] = CFG::A_BYTES + rw0 * 128;
+            }
+        auto stage_a = [&](int buf, int kt, int reg) {
+            char* base = smem + buf * CFG::STAGE;
+            const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(ra_src[reg][j] + koff, base + ra_lds[reg][j]);
+        };
+        auto stage_w = [&](int buf, int kt, int reg) {
+            char* base = smem + buf * CFG::STAGE;
+            const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(rw_src[reg][j] + koff, base + rw_lds[reg][j]);
+        };
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+        stage_a(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(0, 0, 1);
+        stage_a(0, 0, 1);
+        VMCNT(0);
+        PP_BAR();
+        if (wm == 1) PP_BAR();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* As = smem + (kt & 1) * CFG::STAGE;
+            const char* Ws = As + CFG::A_BYTES;
+            const bool more = kt + 1 < nkt;
+            const int nb = (kt + 1) & 1;
+            rd_a(As, 0);
+            rd_w(Ws, 0);
+            if (more) stage_a(nb, kt + 1, 0);
+            if (more) { VMCNT(4); } else { VMCNT(2); }
+            PP_SYNC();
+            mma(0, 0);
+            PP_BAR();
+            rd_w(Ws, 1);
+            if (more) stage_w(nb, kt + 1, 0);
+            if (more) { VMCNT(4); } else { VMCNT(0); }
+            PP_SYNC();
+            mma(0, 1);
+            PP_BAR();
+            rd_a(As, 1);
+            if (more) stage_w(nb, kt + 1, 1);
+            if (more) VMCNT(4);
+            PP_SYNC();
+            mma(1, 1);
+            PP_BAR();
+            rd_w(Ws, 0);
+            if (more) stage_a(nb, kt + 1, 1);
+            if (more) VMCNT(4);
+            PP_SYNC();
+            mma(1, 0);
+            PP_BAR();
+        }
+        if (wm == 0) PP_BAR();
+#undef VMCNT
+#undef PP_SYNC
+#undef PP_BAR
     } else {
         // ---- ping-pong schedule (TM = 4, TN = 2): 4 phases per K-tile ----
         static_assert(!CFG::PP || (TM == 4 && TN == 2), "ping-pong schedule is written for 128x64 wave tiles");
@@ -380,6 +914,18 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     }
 
     // ---- epilogue ----
+    if constexpr (CFG::SCHED == 5) {
+        int mrow16[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            mrow16[mt] = m0 + wm * 128 + mt * 16 + (lane & 15);
+            if (mrow16[mt] >= M) mrow16[mt] = -1;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            store_slab16<EPI, 8>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, lane >> 4);
+        return;
+    }
     int mrow[TM];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -391,7 +937,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
 }
 
-int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P
+int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
+int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P, 4 CFG_256R
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -425,11 +972,40 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
             nmax = G.p[i].N > nmax ? G.p[i].N : nmax;
         }
         // large problems: 256x256 tiles, one per CU per round; otherwise the 128x128 tiling
-        cfg = (mtot >= 1024 && nmax >= 1024 && G.K >= 256) ? 3 : 1;
+        cfg = (mtot >= 1024 && nmax >= 1024 && G.K >= 256) ? g_large_cfg : 1;
+        // measured in the Flux step (profiles/r01_gemm_w4_ab.md): with a 24 KiB row stride (K = 12288, the
+        // MLP down-projection) the one-wave-per-SIMD kernel loses 17-23 % to channel aliasing that the
+        // slower ping-pong schedule does not see; everywhere else it wins 3-16 %
+        if (cfg == 6 && G.K % 12288 == 0) cfg = 3;
     }
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
         case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
+        case 4: return launch_cfg<CFG_256R, EPI>(G, Ms, stream);
+        case 5: return launch_cfg<CFG_256S, EPI>(G, Ms, stream);
+        case 6: return launch_cfg<CFG_256W, EPI>(G, Ms, stream);
+        case 7: return launch_cfg<CFG_256P16, EPI>(G, Ms, stream);
+        case 61: return launch_cfg<CFG_WABL<1>, EPI>(G, Ms, stream);
+        case 62: return launch_cfg<CFG_WABL<2>, EPI>(G, Ms, stream);
+        case 63: return launch_cfg<CFG_WABL<3>, EPI>(G, Ms, stream);
+        case 64: return launch_cfg<CFG_WABL<4>, EPI>(G, Ms, stream);
+        case 68: return launch_cfg<CFG_WABL<8>, EPI>(G, Ms, stream);
+        case 72: return launch_cfg<CFG_WABL<12>, EPI>(G, Ms, stream);
+        case 76: return launch_cfg<CFG_WABL<16>, EPI>(G, Ms, stream);
+        case 92: return launch_cfg<CFG_WABL<32>, EPI>(G, Ms, stream);
+        case 124: return launch_cfg<CFG_WABL<64>, EPI>(G, Ms, stream);
+        case 188: return launch_cfg<CFG_WABL<128>, EPI>(G, Ms, stream);
+        case 11: return launch_cfg<CFG_ABL<1>, EPI>(G, Ms, stream);
+        case 12: return launch_cfg<CFG_ABL<2>, EPI>(G, Ms, stream);
+        case 13: return launch_cfg<CFG_ABL<3>, EPI>(G, Ms, stream);
+        case 14: return launch_cfg<CFG_ABL<4>, EPI>(G, Ms, stream);
+        case 18: return launch_cfg<CFG_ABL<8>, EPI>(G, Ms, stream);
+        case 26: return launch_cfg<CFG_ABL<16>, EPI>(G, Ms, stream);
+        case 42: return launch_cfg<CFG_ABL<32>, EPI>(G, Ms, stream);
+        case 74: return launch_cfg<CFG_ABL<64>, EPI>(G, Ms, stream);
+        case 202: return launch_cfg<CFG_ABL<192>, EPI>(G, Ms, stream);
+        case 330: return launch_cfg<CFG_ABL<320>, EPI>(G, Ms, stream);
+        case 138: return launch_cfg<CFG_ABL<128>, EPI>(G, Ms, stream);
         default:
             return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
     }
@@ -514,6 +1090,10 @@ void apexmi_set_attn_waves(int v);
 extern "C" int apexmi_tune_set(const char* key, int value) {
     if (key && !strcmp(key, "attn.waves")) {
         apexmi_set_attn_waves(value);
+        return 0;
+    }
+    if (key && !strcmp(key, "gemm.large")) {
+        g_large_cfg = value;
         return 0;
     }
     if (key && !strcmp(key, "gemm.config")) {

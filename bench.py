@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--clip", action="store_true", help="wan: also time a whole 30-step clip + decode")
     ap.add_argument("--queue-wan-steps", type=int, default=30)
     ap.add_argument("--broadcast-mib", type=int, default=1024)
+    ap.add_argument("--tune", type=str, default="", help="debug A/B: comma list of key=value for apexmi_tune_set")
     return ap.parse_args()
 
 
@@ -311,6 +312,10 @@ def main():
     distributed = world > 1 or os.environ.get("APEX_FORCE_DIST") == "1"   # force: RCCL smoke test on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    for kv in filter(None, args.tune.split(",")):
+        from apex_studio_amd import lib as _lib
+        key, val = kv.split("=")
+        _lib.tune_set(key, int(val))
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)

@@ -13,10 +13,10 @@ DEV = "cuda"
 g = torch.Generator(device=DEV).manual_seed(0)
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 if what in ("all", "gemm"):
-    for (M, N, K) in [(8192, 8192, 8192), (4608, 9216, 3072)]:
+    for (M, N, K) in ([(8192, 8192, 8192)] if os.environ.get('GEMM_CFGS') else [(8192, 8192, 8192), (4608, 9216, 3072)]):
         a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
-        for cfg, var in ((2, 1), (3, 1)):
+        for cfg, var in [(int(c), 1) for c in os.environ.get('GEMM_CFGS', '2,3').split(',')]:
             lib.tune_set("gemm.config", cfg)
             for _ in range(3):
                 ops.gemm(a, w)
