@@ -230,6 +230,219 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
     }
 }
 
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16 -----------------------------------------------
+// The denoise step runs at the chip's power limit; at equal matrix-pipe occupancy the 16x16x32 form
+// sustains ~13 % higher clocks than 32x32x16 (tools/ubench/mfma_power.hip), so it is the faster one.
+// Layout: a wave owns 2 query tiles of 16; S^T tiles are 16 keys x 16 queries, lane (g = lane >> 4,
+// c = lane & 15) holds S^T[key row 4 g + r][query c].  K rows are READ permuted — row 4 g + r of key
+// tile 2 kk + t is key 32 kk + 8 g + 4 t + r — so the 8 scores a lane holds for PV step kk are the
+// consecutive keys 32 kk + 8 g .. + 7: P feeds the PV MFMA unshuffled and a V^T fragment is one
+// ds_read_b128.  K is staged in natural row order with chunk ^= ((row >> 3) & 3) << 2 | (row & 3)
+// (bank-conflict-free for that read); V^T as before.  Row max / sum cross 4 lanes (c, c+16, c+32,
+// c+48): one v_permlane16_swap + one v_permlane32_swap.
+APEXMI_DEVICE float max_xor16(float x) {
+    uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+APEXMI_DEVICE float sum_xor16(float x) {
+    uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+APEXMI_DEVICE int kswz(int row) { return (((row >> 3) & 3) << 2) | (row & 3); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((ext_vector_type(4))) float f4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    const int s = xcd_remap(blockIdx.x, total);
+    const int hb = s / nqb, qb = s % nqb;
+    const int b = hb / H, h = hb % H;
+
+    const bf16_t* Qp = Q + (int64_t)hb * Sq * HD;
+    const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
+    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
+
+    constexpr int QB = NW * 32;
+    constexpr int LD = 1024 / (NW * 64);
+    int qrow[2];
+    bf16x8 qf[2][4];  // B operand of S^T: lane supplies Q[query][32 ks + 8 g .. +7]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        qrow[qt] = qb * QB + wave * 32 + qt * 16 + l15;
+        const int qc = min(qrow[qt], Sq - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const bf16x8*)(Qp + (int64_t)qc * HD + ks * 32 + g4 * 8);
+    }
+
+    int k_key[LD], k_c[LD];
+    const char* v_src[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        const int p = (wave * LD + i) * 64 + lane;
+        {
+            const int row = p >> 4, pc = p & 15;
+            k_c[i] = (pc ^ kswz(row)) * 8;
+            k_key[i] = row;
+        }
+        {
+            const int row = p >> 3, pc = p & 7;
+            const int c = pc ^ ((row >> 1) & 7);
+            v_src[i] = (const char*)(Vp + (int64_t)row * Skp + c * 8);
+        }
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * ATT_STAGE + wave * (LD * 1024);
+        const int kv0 = t * KV;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int key = min(kv0 + k_key[i], Sk - 1);
+            glds16(Kp + (int64_t)key * HD + k_c[i], base + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i)
+            glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * 1024);
+    };
+
+    // LDS read offsets.  K tile kt = 2 kk + t, lane row = 32 kk + 8 (c >> 2) + 4 t + (c & 3); its swizzle is c.
+    int k_off[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) k_off[kt] = (32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3)) * 256;
+    int k_ch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_ch[ks] = ((4 * ks + g4) ^ l15) << 4;
+    const int v_row = l15 * 128;
+    int v_ch[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) v_ch[kk] = ((4 * kk + g4) ^ ((l15 >> 1) & 7)) << 4;
+
+    f4 oacc[8][2];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-1.0e30f, -1.0e30f};
+    float l_run[2] = {0.0f, 0.0f};
+
+    const int nt = (Sk + KV - 1) / KV;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of tile t (see the 32x32 kernel)
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* Ks = smem + (t & 1) * ATT_STAGE;
+        const char* Vs = Ks + K_TILE_BYTES;
+
+        f4 sacc[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) sacc[kt][qt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + k_off[kt] + k_ch[ks]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], sacc[kt][qt], 0, 0, 0);
+            }
+
+        if (t == nt - 1 && (Sk & (KV - 1)) != 0) {  // mask keys past Sk (wave-uniform branch)
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + 32 * (kt >> 1) + 8 * g4 + 4 * (kt & 1) + r;
+                    if (key >= Sk) {
+                        sacc[kt][0][r] = -1.0e30f;
+                        sacc[kt][1][r] = -1.0e30f;
+                    }
+                }
+        }
+
+        float mx[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float m = sacc[0][qt][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sacc[kt][qt][r]);
+            mx[qt] = max_xor32(max_xor16(m)) * scale_log2e;
+        }
+        if (__any(mx[0] > m_run[0] + DEFER || mx[1] > m_run[1] + DEFER)) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float m_new = fmaxf(m_run[qt], mx[qt]);
+                const float alpha = fast_exp2(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[dt][qt][r] *= alpha;
+            }
+        }
+        bf16x8 pf[2][2];  // [query tile][PV step]: keys 32 kk + 8 g .. +7
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float psum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = fast_exp2(fmaf(sacc[kt][qt][r], scale_log2e, -m_run[qt]));
+                    psum += pv;
+                    pf[qt][kt >> 1][4 * (kt & 1) + r] = (__bf16)pv;
+                }
+            l_run[qt] += psum;
+        }
+
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(Vs + dt * 2048 + v_row + v_ch[kk]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], oacc[dt][qt], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: lane holds O[query c][d = 16 dt + 4 g + (0..3)]; pairs of d-tiles are exchanged with
+    // v_permlane16_swap into 8 consecutive d starting at 32 p + 16 (g & 1) + 8 (g >> 1) -> 16-byte stores
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float inv = 1.0f / sum_xor32(sum_xor16(l_run[qt]));
+        bf16_t* op = O + (int64_t)b * o_sb + (int64_t)min(qrow[qt], Sq - 1) * o_ss + (int64_t)h * o_sh;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t x0 = pack_bf16(oacc[2 * p][qt][0] * inv, oacc[2 * p][qt][1] * inv);
+            uint32_t x1 = pack_bf16(oacc[2 * p][qt][2] * inv, oacc[2 * p][qt][3] * inv);
+            uint32_t y0 = pack_bf16(oacc[2 * p + 1][qt][0] * inv, oacc[2 * p + 1][qt][1] * inv);
+            uint32_t y1 = pack_bf16(oacc[2 * p + 1][qt][2] * inv, oacc[2 * p + 1][qt][3] * inv);
+            auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+            auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+            if (qrow[qt] < Sq) {
+                const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                *(u32x4*)(op + 32 * p + 16 * (g4 & 1) + 8 * (g4 >> 1)) = o;
+            }
+        }
+    }
+}
+
 // ---- generic fallback: any D <= 256, bf16 / f16 / f32, strided views; one workgroup per query row.
 // Exists so the operator survives the reference's backend verification probe
 // (B,H,S,D = 1,2,8,64 fp16; attention/functions.py:1999-2251) and odd head sizes (VAE C = 384 is
@@ -321,6 +534,7 @@ int launch_generic(const void* q, const void* k, const void* v, void* out, int B
 }
 
 int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
+int g_attn_mfma = 32;  // 32: 32x32x16 kernel (shipped: 3 % faster in the Flux step), 16: 16x16x32 kernel (apexmi_tune_set "attn.mfma")
 
 // contiguity test for the MFMA path's packed [B,H,S,128] operands
 bool packed_bhsd(const int64_t* st, int H, int S, int D) {
@@ -338,15 +552,19 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
     APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attn_fwd_prepared: empty problem");
     APEXMI_REQUIRE(Skp % KV == 0 && Skp >= Sk, "attn_fwd_prepared: Skp=%d must be Sk=%d rounded up to 64", Skp, Sk);
     APEXMI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 &&
-                       ((uintptr_t)out % 8) == 0,
+                       ((uintptr_t)out % 16) == 0,
                    "attn_fwd_prepared: operands must be 16-byte aligned");
-    APEXMI_REQUIRE(o_strides[0] % 4 == 0 && o_strides[1] % 4 == 0 && o_strides[2] % 4 == 0,
-                   "attn_fwd_prepared: output strides must be multiples of 4 elements");
+    APEXMI_REQUIRE(o_strides[0] % 8 == 0 && o_strides[1] % 8 == 0 && o_strides[2] % 8 == 0,
+                   "attn_fwd_prepared: output strides must be multiples of 8 elements");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<4>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<8>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_mi16_kernel<4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_mi16_kernel<8>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         attr_set = true;
     }
@@ -355,23 +573,19 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
                          2.0 * B * H * HD * (2.0 * Sq + 2.0 * Sk));
     // 8-wave workgroups (256 query rows) once there are enough of them to fill the chip
     const bool big = g_attn_waves == 8 || (g_attn_waves == 0 && (int64_t)((Sq + 255) / 256) * H * B >= 256);
-    if (big) {
-        const int nqb = (Sq + 255) / 256;
-        const int total = nqb * H * B;
-        hipLaunchKernelGGL(attn_fwd_d128_kernel<8>, dim3(total), dim3(512), 2 * ATT_STAGE, stream,
-                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
-                           Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
-    } else {
-        const int nqb = (Sq + 127) / 128;
-        const int total = nqb * H * B;
-        hipLaunchKernelGGL(attn_fwd_d128_kernel<4>, dim3(total), dim3(256), 2 * ATT_STAGE, stream,
-                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq,
-                           Sk, Skp, nqb, total, o_strides[0], o_strides[1], o_strides[2], c);
-    }
+    const int qbr = big ? 256 : 128;
+    const int nqb = (Sq + qbr - 1) / qbr;
+    const int total = nqb * H * B;
+    auto kern = g_attn_mfma == 32 ? (big ? attn_fwd_d128_kernel<8> : attn_fwd_d128_kernel<4>)
+                                  : (big ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_mi16_kernel<4>);
+    hipLaunchKernelGGL(kern, dim3(total), dim3(big ? 512 : 256), 2 * ATT_STAGE, stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,
+                       o_strides[0], o_strides[1], o_strides[2], c);
     return apexmi_check_launch("attn_fwd_d128");
 }
 
 void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
+void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype != APEXMI_BF16 || D != HD) return 0;

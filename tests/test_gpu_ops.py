@@ -373,19 +373,23 @@ def test_attention_mfma_vs_oracle(B, H, Sq, Sk):
     _check(out, ref, 1e-2, f"attention {B}x{H}x{Sq}x{Sk}", ulp=3.0)
 
 
+@pytest.mark.parametrize("mfma", [16, 32])
 @pytest.mark.parametrize("waves", [4, 8])
-def test_attention_workgroup_sizes(waves):
+def test_attention_workgroup_sizes(waves, mfma):
+    """Both workgroup sizes of both MFMA kernels (32x32x16 shipped, 16x16x32 kept for A/B), ragged Sq / Sk."""
     from apex_studio_amd import lib
     ops = _ops()
     q = seeded((1, 2, 700, 128), 85, torch.bfloat16)
     k = seeded((1, 2, 333, 128), 86, torch.bfloat16)
     v = seeded((1, 2, 333, 128), 87, torch.bfloat16)
     lib.tune_set("attn.waves", waves)
+    lib.tune_set("attn.mfma", mfma)
     try:
         out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     finally:
         lib.tune_set("attn.waves", 0)
-    _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention {waves} waves", ulp=3.0)
+        lib.tune_set("attn.mfma", 32)
+    _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention {waves} waves mfma{mfma}", ulp=3.0)
 
 
 def test_attention_online_softmax_rescale_spike():

@@ -70,20 +70,20 @@ def main():
         print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "epi": epi,
                           "tflops": {f"cfg{c}": [round(x, 1) for x in v] for c, v in res.items()},
                           "torch_matmul_tflops": round(2.0 * M * N * K / (ref_ms * 1e-3) / 1e12, 1)}), flush=True)
-    for (H, S) in ([] if os.environ.get('GEMM_SHAPES') else [(24, 4608), (24, 1536), (40, 8192)]):
+    for (H, S) in ([] if os.environ.get('GEMM_SHAPES', '') not in ('', 'attn') else [(24, 4608), (24, 1536), (40, 8192)]):
         q = torch.randn(1, H, S, 128, generator=g, device=DEV).to(torch.bfloat16)
         k = torch.randn(1, H, S, 128, generator=g, device=DEV).to(torch.bfloat16)
         vt = torch.randn(1, H, 128, S, generator=g, device=DEV).to(torch.bfloat16)
         o = torch.empty(1, S, H, 128, device=DEV, dtype=torch.bfloat16)
         res = {}
-        for w in (4, 8):
-            lib.tune_set("attn.waves", w)
+        for w in (16, 32):
+            lib.tune_set("attn.mfma", w)
             res[w] = round(4.0 * H * S * S * 128 / (timeit(lambda: ops.attention_prepared(q, k, vt, o, S)) * 1e-3) / 1e12, 1)
-        lib.tune_set("attn.waves", 0)
+        lib.tune_set("attn.mfma", 32)
         ms = timeit(lambda: ops.attention_prepared(q, k, vt, o, S))
         v = vt.transpose(2, 3).contiguous()
         ref_ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v), iters=5)
-        print(json.dumps({"attention": [H, S], "tflops": round(4.0 * H * S * S * 128 / (ms * 1e-3) / 1e12, 1), "by_waves": res,
+        print(json.dumps({"attention": [H, S], "tflops": round(4.0 * H * S * S * 128 / (ms * 1e-3) / 1e12, 1), "by_mfma": res,
                           "torch_sdpa_tflops": round(4.0 * H * S * S * 128 / (ref_ms * 1e-3) / 1e12, 1)}), flush=True)
 
 
