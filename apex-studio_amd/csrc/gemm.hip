@@ -7,14 +7,23 @@
 // proj_mlp / proj_out of the single block (:180-182), x_embedder / context_embedder (:439-440),
 // and the gate * y + residual tails of FluxTransformerBlock.forward (:296-297, :305-307).
 //
-// One kernel template, three tilings (gfx950, v_mfma_f32_32x32x16_bf16, BK = 64):
-//   CFG_128  : 128x128 block, 4 waves (2x2), wave tile 64x64,  2 blocks/CU — small / ragged problems
-//   CFG_256  : 256x256 block, 8 waves (2x4), wave tile 128x64, 1 block/CU  — the large Flux GEMMs
-//   CFG_256P : CFG_256 with a ping-pong schedule: the K-tile is cut into 4 quadrant phases of
-//              {ds_read sub-tile | barrier | 8 MFMA | barrier}; the M-halves of the block (waves w and
-//              w+4 share a SIMD) run one barrier apart, so on every SIMD one wave is in its MFMA segment
-//              while its partner is in its LDS/DMA segment, and the next K-tile's LDS-DMA stays in
-//              flight for three phases behind a counted wait.
+// One kernel template, five tilings (gfx950, BK = 64); `apexmi_tune_set("gemm.config", n)` forces one:
+//   1 CFG_128    : 128x128 block, 4 waves (2x2) of 64x64, 2 blocks/CU — small / ragged problems
+//   2 CFG_256    : 256x256 block, 8 waves (2x4) of 128x64, plain double buffer (baseline for A/B)
+//   3 CFG_256P   : ping-pong schedule on v_mfma_f32_32x32x16_bf16: the K-tile is cut into 4 quadrant
+//                  phases of {ds_read sub-tile | barrier | 8 MFMA | barrier}; the M-halves of the block
+//                  (waves w and w+4 share a SIMD) run one barrier apart, so on every SIMD one wave is in
+//                  its MFMA segment while its partner is in its LDS/DMA segment, and the next K-tile's
+//                  LDS-DMA stays in flight for three phases behind a counted wait.
+//   7 CFG_256P16 : the same schedule on v_mfma_f32_16x16x32_bf16 — SHIPPED for the large GEMMs.  The
+//                  denoise step runs at the chip's power limit, and at equal matrix-pipe occupancy the
+//                  16x16x32 form sustains 2.03 GHz against 1.79 GHz for 32x32x16 (tools/ubench/
+//                  mfma_power.hip); in the Flux step it is 8 % faster per GEMM, 6.5 % per step.
+//   6 CFG_256W   : 4 waves (2x2) of 128x128, one wave per SIMD, accumulators in AGPRs, LDS-DMA through
+//                  buffer_load with scalar piece offsets.  17 % fewer cycles than CFG_256P and faster in
+//                  an isolated loop, but not in the step: the chip answers the denser instruction
+//                  stream with a lower clock (1.30 vs 1.57 GHz under the profiler).  Kept for the record
+//                  and for shapes that are not power-bound.
 // Both operands are K-contiguous, so A and W tiles are staged identically with 16-byte
 // global_load_lds into a double-buffered LDS image; the XOR swizzle (chunk ^= (row >> 1) & 7: two 128-byte rows share a 256-byte bank
 // row, and a 32-row MFMA fragment read must spread each 16-lane group over all 16 slots) is applied on
@@ -49,12 +58,12 @@ struct GemmGroup {
     int count, K, total;
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int SCHED_, int VAR_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-    static constexpr int SCHED = SCHED_;  // 0 plain double buffer, 1 ping-pong phases, 2 rotated software pipeline
+    // 0 plain double buffer | 1 ping-pong phases, 32x32x16 | 4 one wave per SIMD, rotated pipeline | 5 ping-pong, 16x16x32
+    static constexpr int SCHED = SCHED_;
     static constexpr bool PP = SCHED_ == 1;
-    static constexpr int VAR = VAR_;  // ABLATION ONLY
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
@@ -66,12 +75,8 @@ struct Cfg {
 using CFG_128 = Cfg<128, 128, 2, 2, 0>;
 using CFG_256 = Cfg<256, 256, 2, 4, 0>;
 using CFG_256P = Cfg<256, 256, 2, 4, 1>;
-using CFG_256R = Cfg<256, 256, 2, 4, 2>;
-using CFG_256S = Cfg<256, 256, 2, 4, 3>;
 using CFG_256W = Cfg<256, 256, 2, 2, 4>;
 using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
-template <int V> using CFG_WABL = Cfg<256, 256, 2, 2, 4, V>;
-template <int V> using CFG_ABL = Cfg<256, 256, 2, 4, 2, V>;
 
 // exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
 // columns: low half-wave gets [a_lo | a_hi] = cols 8g..8g+7, high half-wave [b_lo | b_hi] = cols
@@ -339,223 +344,6 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
             }
         }
-    } else if constexpr (CFG::SCHED == 2) {
-        // ---- rotated software pipeline (TM = 4, TN = 2) ----
-        // One barrier per K-tile, placed between k-steps 2 and 3: by then every wave has ISSUED (and
-        // drained) all fragment reads of tile kt — k-step 3's fragments were prefetched during k-step
-        // 2's MFMAs — so the barrier both frees slot kt&1 for tile kt+2 and publishes tile kt+1 (each
-        // wave drains its own LDS-DMA pieces first).  The first MFMAs after the barrier already hold
-        // their operands, fragment reads run one k-step ahead of the MFMAs that consume them, and the
-        // 8 LDS-DMA pieces of the next-but-one tile go out 3/3/2 behind the first three k-steps of the
-        // period, leaving a k-step for the last piece to land before the next drain.
-        static_assert(CFG::SCHED != 2 || (TM == 4 && TN == 2 && CFG::A_LD == 4 && CFG::W_LD == 4),
-                      "rotated schedule is written for 128x64 wave tiles, 8 waves");
-        bf16x8 fa[2][4], fw[2][2];
-        u32x4 sink[8];
-        auto rd = [&](int slot, int ks, int b, bool force = false) {
-            const char* As = smem + slot * CFG::STAGE;
-            const char* Ws = As + CFG::A_BYTES;
-            const int c = ks * 2 + hi;
-            if ((CFG::VAR & 2) && !force) return;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fa[b][t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
-#pragma unroll
-            for (int t = 0; t < 2; ++t) fw[b][t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
-        };
-        auto mma = [&](int b) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][nt], fa[b][mt], acc[nt][mt], 0, 0, 0);
-        };
-        // pieces 0..3 = activation rows, 4..7 = weight rows of one tile image (same split as stage())
-        auto dma = [&](int slot, int kt, int first, int count) {
-            char* base = smem + slot * CFG::STAGE + wave * 1024;
-            const int64_t koff = (CFG::VAR & 4) ? 0 : (int64_t)kt * (BK * 2);
-#pragma unroll
-            for (int i = first; i < first + count; ++i) {
-                if (CFG::VAR & 1) continue;
-                if (CFG::VAR & 32) {  // plain register loads, never written to LDS
-                    const char* sp = i < 4 ? a_src[i] + koff : w_src[i - 4] + koff;
-                    sink[i] = *(const u32x4*)sp;
-                    continue;
-                }
-                if ((CFG::VAR & 16) && lane != 0) continue;
-                if (i < 4)
-                    glds16(a_src[i] + koff, base + i * (CFG::NW * 1024));
-                else
-                    glds16(w_src[i - 4] + koff, base + CFG::A_BYTES + (i - 4) * (CFG::NW * 1024));
-            }
-        };
-        // issue order hint for one k-step: MFMA / LDS read alternating, LDS-DMA after every 2nd MFMA
-        auto interleave = [&](int nread, int ndma) {
-            if (CFG::VAR & 64) return;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < nread) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if ((i & 1) && (i >> 1) < ndma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        };
-#define RS_FENCE() __builtin_amdgcn_sched_barrier(0)
-        // one period = [k-step 3 of tile kt | k-steps 0..2 of tile kt+1]
-        auto period = [&](int kt, auto has_dma, auto has_next) {
-            constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
-            const int cur = kt & 1, nxt = cur ^ 1;
-            if (CFG::VAR & 32) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(sink[i]));
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            RS_FENCE();
-            if (!(CFG::VAR & 8)) __builtin_amdgcn_s_barrier();
-            if ((CFG::VAR & 128) && wm == 1) __builtin_amdgcn_s_sleep(2);
-            if ((CFG::VAR & 256) && wm == 1) __builtin_amdgcn_s_sleep(4);
-            RS_FENCE();
-            if (NEXT) rd(nxt, 0, 0);
-            if (DMA) dma(cur, kt + 2, 0, 3);
-            if (CFG::VAR & 64) RS_FENCE();
-            mma(1);
-            interleave(NEXT ? 6 : 0, DMA ? 3 : 0);
-            RS_FENCE();
-            if (NEXT) {
-                rd(nxt, 1, 1);
-                if (DMA) dma(cur, kt + 2, 3, 3);
-                if (CFG::VAR & 64) RS_FENCE();
-                mma(0);
-                interleave(6, DMA ? 3 : 0);
-                RS_FENCE();
-                rd(nxt, 2, 0);
-                if (DMA) dma(cur, kt + 2, 6, 2);
-                if (CFG::VAR & 64) RS_FENCE();
-                mma(1);
-                interleave(6, DMA ? 2 : 0);
-                RS_FENCE();
-                rd(nxt, 3, 1);
-                if (CFG::VAR & 64) RS_FENCE();
-                mma(0);
-                interleave(6, 0);
-                RS_FENCE();
-            }
-        };
-        if (CFG::VAR & 2) {
-            rd(0, 0, 0, true);
-            rd(0, 1, 1, true);
-        }
-        dma(0, 0, 0, 8);
-        if (nkt > 1) {
-            dma(1, 1, 0, 8);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        RS_FENCE();
-        __builtin_amdgcn_s_barrier();
-        RS_FENCE();
-        rd(0, 0, 0);
-        rd(0, 1, 1);
-        mma(0);
-        interleave(6, 0);
-        RS_FENCE();
-        rd(0, 2, 0);
-        mma(1);
-        interleave(6, 0);
-        RS_FENCE();
-        rd(0, 3, 1);
-        mma(0);
-        interleave(6, 0);
-        RS_FENCE();
-        int kt = 0;
-        for (; kt + 2 < nkt; ++kt) period(kt, std::true_type{}, std::true_type{});
-        if (kt + 1 < nkt) {
-            period(kt, std::false_type{}, std::true_type{});
-            ++kt;
-        }
-        period(kt, std::false_type{}, std::false_type{});
-#undef RS_FENCE
-    } else if constexpr (CFG::SCHED == 3) {
-        // ---- slot schedule: the rotated pipeline of SCHED 2 with every instruction pinned to an MFMA slot ----
-        // A period (one barrier) is 32 MFMA slots = k-step 3 of tile kt, then k-steps 0..2 of tile kt+1.
-        // Slot s carries: MFMA s; for the first six slots of a k-step one ds_read_b128 of the NEXT k-step's
-        // fragments; and, on slots ROT, ROT+3, ..., ROT+21, one LDS-DMA piece of tile kt+2.  ROT = wave % 3,
-        // so the 8 waves of the CU hand the texture-address unit one 16-cycle piece at a time instead of 24
-        // at once (measured: simultaneous issue starves the matrix pipe for ~90 cycles per piece per wave).
-        static_assert(CFG::SCHED != 3 || (TM == 4 && TN == 2 && CFG::A_LD == 4 && CFG::W_LD == 4),
-                      "slot schedule is written for 128x64 wave tiles, 8 waves");
-        bf16x8 fa[2][4], fw[2][2];
-        auto rd1 = [&](int slot, int ks, int b, int j) {  // j-th of the six fragment reads of a k-step
-            const char* As = smem + slot * CFG::STAGE;
-            const char* Ws = As + CFG::A_BYTES;
-            const int c = ks * 2 + hi;
-            if (j == 0) fw[b][0] = *(const bf16x8*)(Ws + w_off[0] + ((c ^ w_sw[0]) << 4));
-            else if (j == 5) fw[b][1] = *(const bf16x8*)(Ws + w_off[1] + ((c ^ w_sw[1]) << 4));
-            else fa[b][j - 1] = *(const bf16x8*)(As + a_off[j - 1] + ((c ^ a_sw[j - 1]) << 4));
-        };
-        auto mma1 = [&](int b, int i) {  // i-th MFMA of a k-step: (nt, mt) = (i / 4, i % 4)
-            acc[i >> 2][i & 3] =
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][i >> 2], fa[b][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
-        };
-        auto dma1 = [&](int slot, int kt, int i) {
-            char* base = smem + slot * CFG::STAGE + wave * 1024;
-            const int64_t koff = (int64_t)kt * (BK * 2);
-            if (i < 4) glds16(a_src[i] + koff, base + i * (CFG::NW * 1024));
-            else glds16(w_src[i - 4] + koff, base + CFG::A_BYTES + (i - 4) * (CFG::NW * 1024));
-        };
-#define SL_FENCE() __builtin_amdgcn_sched_barrier(0)
-        auto period = [&](int kt, auto rot_, auto has_dma, auto has_next) {
-            constexpr int ROT = decltype(rot_)::value;
-            constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
-            const int cur = kt & 1, nxt = cur ^ 1;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            SL_FENCE();
-            __builtin_amdgcn_s_barrier();
-            SL_FENCE();
-#pragma unroll
-            for (int s = 0; s < (NEXT ? 32 : 8); ++s) {
-                const int q = s >> 3, i = s & 7;
-                mma1((q + 1) & 1, i);
-                if (NEXT && i < 6) rd1(nxt, q, q & 1, i);
-                if (DMA && s >= ROT && (s - ROT) % 3 == 0 && (s - ROT) / 3 < 8) dma1(cur, kt + 2, (s - ROT) / 3);
-                SL_FENCE();
-            }
-        };
-        auto run = [&](auto rot_) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma1(0, 0, i);
-            if (nkt > 1) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dma1(1, 1, i);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            SL_FENCE();
-            __builtin_amdgcn_s_barrier();
-            SL_FENCE();
-#pragma unroll
-            for (int j = 0; j < 6; ++j) rd1(0, 0, 0, j);
-            SL_FENCE();
-#pragma unroll
-            for (int s = 0; s < 24; ++s) {  // k-steps 0..2 of tile 0
-                const int q = s >> 3, i = s & 7;
-                mma1(q & 1, i);
-                if (i < 6) rd1(0, q + 1, (q + 1) & 1, i);
-                SL_FENCE();
-            }
-            int kt = 0;
-            for (; kt + 2 < nkt; ++kt) period(kt, rot_, std::true_type{}, std::true_type{});
-            if (kt + 1 < nkt) {
-                period(kt, rot_, std::false_type{}, std::true_type{});
-                ++kt;
-            }
-            period(kt, rot_, std::false_type{}, std::false_type{});
-        };
-        const int rot = wave % 3;
-        if (rot == 0) run(std::integral_constant<int, 0>{});
-        else if (rot == 1) run(std::integral_constant<int, 1>{});
-        else run(std::integral_constant<int, 2>{});
-#undef SL_FENCE
     } else if constexpr (CFG::SCHED == 4) {
         // ---- one wave per SIMD: 4 waves (2x2) of 128x128, accumulators in AGPRs ----
         // Measured on gfx950 (tools/ubench/mfma_vmem.hip): at the GEMM's rate of one LDS-DMA piece per
@@ -611,21 +399,20 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         };
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
         constexpr int ROT = 0;
-        constexpr int STEP = (CFG::VAR & 16) ? 3 : (CFG::VAR & 32) ? 1 : 2;  // MFMA slots between LDS-DMA pieces
+        constexpr int STEP = 2;  // MFMA slots between LDS-DMA pieces (3: -3 %, 1: -4 % on the Flux shapes)
         auto period = [&](int kt, auto has_dma, auto has_next) {
             constexpr bool DMA = decltype(has_dma)::value, NEXT = decltype(has_next)::value;
             const int cur = kt & 1, nxt = cur ^ 1;
-            if (CFG::VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             W4_FENCE();
-            if (!(CFG::VAR & 2)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             W4_FENCE();
 #pragma unroll
             for (int s = 0; s < (NEXT ? 64 : 16); ++s) {
                 const int q = s >> 4, i = s & 15;
                 mma1((q + 1) & 1, i);
-                if (NEXT && i < 8 && !(CFG::VAR & 8)) rd1(nxt, q, q & 1, i);
-                if (DMA && !(CFG::VAR & 4) && s >= ROT && (s - ROT) % STEP == 0 && (s - ROT) / STEP < 16) dma1(cur, kt + 2, (s - ROT) / STEP);
+                if (NEXT && i < 8) rd1(nxt, q, q & 1, i);
+                if (DMA && s >= ROT && (s - ROT) % STEP == 0 && (s - ROT) / STEP < 16) dma1(cur, kt + 2, (s - ROT) / STEP);
                 W4_FENCE();
             }
         };
@@ -938,7 +725,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 }
 
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
-int g_force_cfg = 0;  // 0 auto, 1 CFG_128, 2 CFG_256, 3 CFG_256P, 4 CFG_256R
+int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -973,39 +760,15 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         }
         // large problems: 256x256 tiles, one per CU per round; otherwise the 128x128 tiling
         cfg = (mtot >= 1024 && nmax >= 1024 && G.K >= 256) ? g_large_cfg : 1;
-        // measured in the Flux step (profiles/r01_gemm_w4_ab.md): with a 24 KiB row stride (K = 12288, the
-        // MLP down-projection) the one-wave-per-SIMD kernel loses 17-23 % to channel aliasing that the
-        // slower ping-pong schedule does not see; everywhere else it wins 3-16 %
-        if (cfg == 6 && G.K % 12288 == 0) cfg = 3;
+        // with a 24 KiB row stride (K = 12288, the MLP down-projection) the one-wave-per-SIMD kernel loses
+        // 17-23 % to channel aliasing that the ping-pong schedules do not see
+        if (cfg == 6 && G.K % 12288 == 0) cfg = 7;
     }
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
         case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
-        case 4: return launch_cfg<CFG_256R, EPI>(G, Ms, stream);
-        case 5: return launch_cfg<CFG_256S, EPI>(G, Ms, stream);
         case 6: return launch_cfg<CFG_256W, EPI>(G, Ms, stream);
         case 7: return launch_cfg<CFG_256P16, EPI>(G, Ms, stream);
-        case 61: return launch_cfg<CFG_WABL<1>, EPI>(G, Ms, stream);
-        case 62: return launch_cfg<CFG_WABL<2>, EPI>(G, Ms, stream);
-        case 63: return launch_cfg<CFG_WABL<3>, EPI>(G, Ms, stream);
-        case 64: return launch_cfg<CFG_WABL<4>, EPI>(G, Ms, stream);
-        case 68: return launch_cfg<CFG_WABL<8>, EPI>(G, Ms, stream);
-        case 72: return launch_cfg<CFG_WABL<12>, EPI>(G, Ms, stream);
-        case 76: return launch_cfg<CFG_WABL<16>, EPI>(G, Ms, stream);
-        case 92: return launch_cfg<CFG_WABL<32>, EPI>(G, Ms, stream);
-        case 124: return launch_cfg<CFG_WABL<64>, EPI>(G, Ms, stream);
-        case 188: return launch_cfg<CFG_WABL<128>, EPI>(G, Ms, stream);
-        case 11: return launch_cfg<CFG_ABL<1>, EPI>(G, Ms, stream);
-        case 12: return launch_cfg<CFG_ABL<2>, EPI>(G, Ms, stream);
-        case 13: return launch_cfg<CFG_ABL<3>, EPI>(G, Ms, stream);
-        case 14: return launch_cfg<CFG_ABL<4>, EPI>(G, Ms, stream);
-        case 18: return launch_cfg<CFG_ABL<8>, EPI>(G, Ms, stream);
-        case 26: return launch_cfg<CFG_ABL<16>, EPI>(G, Ms, stream);
-        case 42: return launch_cfg<CFG_ABL<32>, EPI>(G, Ms, stream);
-        case 74: return launch_cfg<CFG_ABL<64>, EPI>(G, Ms, stream);
-        case 202: return launch_cfg<CFG_ABL<192>, EPI>(G, Ms, stream);
-        case 330: return launch_cfg<CFG_ABL<320>, EPI>(G, Ms, stream);
-        case 138: return launch_cfg<CFG_ABL<128>, EPI>(G, Ms, stream);
         default:
             return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
     }

@@ -95,7 +95,7 @@ def gemm_config():
     lib.tune_set("gemm.config", 0)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 192), (1024, 1024, 1024), (77, 3072, 256)])
 def test_gemm_every_tiling(cfg, M, N, K, gemm_config):
     """128x128, 256x256 and the 256x256 ping-pong schedule must agree with the fp32 reference."""
@@ -112,7 +112,7 @@ def test_gemm_every_tiling(cfg, M, N, K, gemm_config):
     _check(x, r.float() + gate * ref, 3e-3, f"cfg{cfg} gate_res")
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
 def test_gemm_pingpong_race_screen(cfg, gemm_config):
     """Repeat a deep-K problem: a staging/barrier race shows up as run-to-run differences."""
     ops = _ops()
@@ -127,7 +127,7 @@ def test_gemm_pingpong_race_screen(cfg, gemm_config):
         assert torch.equal(ops.gemm(a, w), first), "non-deterministic result: LDS staging race"
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7])
 def test_gemm_grouped(cfg, gemm_config):
     """img + txt streams in one launch, writing row ranges of one joint buffer."""
     ops = _ops()
@@ -150,7 +150,7 @@ def test_gemm_grouped(cfg, gemm_config):
     _check(x[:Mt], x0[:Mt] + gt.cpu() * (at.float() @ wt.float().T + bt.float()), 3e-3, "grouped txt gate")
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7])
 def test_gemm_grouped_mixed_n_and_epilogue(cfg, gemm_config):
     """QKV (bias) + MLP-up (gelu) of a single block: same input, different N, one launch."""
     ops = _ops()

@@ -12,7 +12,7 @@ import apex_studio_amd  # noqa: E402,F401
 from apex_studio_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
-CFGS = tuple(int(c) for c in os.environ.get("GEMM_CFGS", "3,4").split(","))
+CFGS = tuple(int(c) for c in os.environ.get("GEMM_CFGS", "3,6,7").split(","))
 SHAPES_ALL = [  # (name, M, N, K, epilogue)
     ("qkv_joint", 4608, 9216, 3072, "bias"), ("mlp_up_single", 4608, 12288, 3072, "gelu"),
     ("proj_out_single", 4608, 3072, 15360, "gate_res"), ("attn_out_img", 4096, 3072, 3072, "gate_res"),
