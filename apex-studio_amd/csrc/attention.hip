@@ -18,6 +18,8 @@
 // its L2 copy of K / V^T.
 #include "common.h"
 
+#include <cstdint>
+
 namespace {
 
 constexpr int KV = 64;    // keys per tile
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
     const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
 
     constexpr int QB = NW * 32;
-    constexpr int LD = 1024 / (NW * 64);  // 16-byte chunks per thread per tile image (1024 chunks)
+    constexpr int LD = (16 + NW - 1) / NW;  // 1 KiB LDS-DMA pieces per wave per tile image (16 pieces each for K and V^T)
     const int qrow = qb * QB + wave * 32 + l31;
     const int qrow_c = min(qrow, Sq - 1);
 
@@ -68,36 +70,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
     for (int ks = 0; ks < 8; ++ks)
         qf[ks] = *(const bf16x8*)(Qp + (int64_t)qrow_c * HD + ks * 16 + hi * 8);
 
-    // staging sources. K image: [64 rows][16 chunks], chunk ^= row & 15, row i <- key perm(i).
-    // V^T image: [128 rows (d)][8 chunks], chunk ^= (row >> 1) & 7.
+    // staging sources.  Piece p = i NW + wave (p < 16).  K image: [64 rows][16 chunks], chunk ^= row & 15,
+    // row i <- key perm(i).  V^T image: [128 rows (d)][8 chunks], chunk ^= (row >> 1) & 7.
     int k_key[LD], k_c[LD];
     const char* v_src[LD];
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-        const int p = (wave * LD + i) * 64 + lane;
+        const int p = (i * NW + wave) * 64 + lane;
         {
-            const int row = p >> 4, pc = p & 15;
+            const int row = (p >> 4) & 63, pc = p & 15;
             k_c[i] = (pc ^ (row & 15)) * 8;
             k_key[i] = (row & 32) + perm32(row & 31);
         }
         {
-            const int row = p >> 3, pc = p & 7;
+            const int row = (p >> 3) & 127, pc = p & 7;
             const int c = pc ^ ((row >> 1) & 7);
             v_src[i] = (const char*)(Vp + (int64_t)row * Skp + c * 8);
         }
     }
 
     auto stage = [&](int buf, int t) {
-        char* base = smem + buf * ATT_STAGE + wave * (LD * 1024);
+        char* base = smem + buf * ATT_STAGE + wave * 1024;
         const int kv0 = t * KV;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int key = min(kv0 + k_key[i], Sk - 1);
-            glds16(Kp + (int64_t)key * HD + k_c[i], base + i * 1024);
-        }
+        for (int i = 0; i < LD; ++i)
+            if (i * NW + wave < 16) {  // wave-uniform
+                const int key = min(kv0 + k_key[i], Sk - 1);
+                glds16(Kp + (int64_t)key * HD + k_c[i], base + i * (NW * 1024));
+            }
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * 1024);
+            if (i * NW + wave < 16) glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * (NW * 1024));
     };
 
     // LDS read offsets
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
     const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
 
     constexpr int QB = NW * 32;
-    constexpr int LD = 1024 / (NW * 64);
+    constexpr int LD = (16 + NW - 1) / NW;  // 1 KiB LDS-DMA pieces per wave per tile image
     int qrow[2];
     bf16x8 qf[2][4];  // B operand of S^T: lane supplies Q[query][32 ks + 8 g .. +7]
 #pragma unroll
@@ -289,29 +292,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
     const char* v_src[LD];
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-        const int p = (wave * LD + i) * 64 + lane;
+        const int p = (i * NW + wave) * 64 + lane;
         {
-            const int row = p >> 4, pc = p & 15;
+            const int row = (p >> 4) & 63, pc = p & 15;
             k_c[i] = (pc ^ kswz(row)) * 8;
             k_key[i] = row;
         }
         {
-            const int row = p >> 3, pc = p & 7;
+            const int row = (p >> 3) & 127, pc = p & 7;
             const int c = pc ^ ((row >> 1) & 7);
             v_src[i] = (const char*)(Vp + (int64_t)row * Skp + c * 8);
         }
     }
     auto stage = [&](int buf, int t) {
-        char* base = smem + buf * ATT_STAGE + wave * (LD * 1024);
+        char* base = smem + buf * ATT_STAGE + wave * 1024;
         const int kv0 = t * KV;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int key = min(kv0 + k_key[i], Sk - 1);
-            glds16(Kp + (int64_t)key * HD + k_c[i], base + i * 1024);
-        }
+        for (int i = 0; i < LD; ++i)
+            if (i * NW + wave < 16) {  // wave-uniform
+                const int key = min(kv0 + k_key[i], Sk - 1);
+                glds16(Kp + (int64_t)key * HD + k_c[i], base + i * (NW * 1024));
+            }
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * 1024);
+            if (i * NW + wave < 16) glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * (NW * 1024));
     };
 
     // LDS read offsets.  K tile kt = 2 kk + t, lane row = 32 kk + 8 (c >> 2) + 4 t + (c & 3); its swizzle is c.
@@ -556,29 +560,36 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
                    "attn_fwd_prepared: operands must be 16-byte aligned");
     APEXMI_REQUIRE(o_strides[0] % 8 == 0 && o_strides[1] % 8 == 0 && o_strides[2] % 8 == 0,
                    "attn_fwd_prepared: output strides must be multiples of 8 elements");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<4>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_kernel<8>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_mi16_kernel<4>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_d128_mi16_kernel<8>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        attr_set = true;
-    }
     const float c = softmax_scale * 1.4426950408889634f;
     ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * HD,
                          2.0 * B * H * HD * (2.0 * Sq + 2.0 * Sk));
-    // 8-wave workgroups (256 query rows) once there are enough of them to fill the chip
-    const bool big = g_attn_waves == 8 || (g_attn_waves == 0 && (int64_t)((Sq + 255) / 256) * H * B >= 256);
-    const int qbr = big ? 256 : 128;
+    // Workgroup height: NW waves x 32 query rows, two workgroups resident per CU (64 KiB LDS each).
+    // 8-wave workgroups once there are enough of them to fill the chip, else 4.  (Measured and rejected:
+    // the height in {4..8} that minimises rounds of 512 resident workgroups — Flux fits one round of 504
+    // seven-wave workgroups — is 7 % SLOWER than 432 eight-wave ones: 14 waves per CU split 4/4/3/3 over
+    // the SIMDs.  `attn.waves` still accepts 4..8.)
+    int nw = g_attn_waves;
+    if (nw == 0) nw = (int64_t)((Sq + 255) / 256) * H * B >= 256 ? 8 : 4;
+    const int qbr = nw * 32;
     const int nqb = (Sq + qbr - 1) / qbr;
     const int total = nqb * H * B;
-    auto kern = g_attn_mfma == 32 ? (big ? attn_fwd_d128_kernel<8> : attn_fwd_d128_kernel<4>)
-                                  : (big ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_mi16_kernel<4>);
-    hipLaunchKernelGGL(kern, dim3(total), dim3(big ? 512 : 256), 2 * ATT_STAGE, stream, (const bf16_t*)q,
+    void (*kern)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, int64_t, int64_t,
+                 int64_t, float) = nullptr;
+    const bool m16 = g_attn_mfma == 16;
+    switch (nw) {
+        case 4: kern = m16 ? attn_fwd_d128_mi16_kernel<4> : attn_fwd_d128_kernel<4>; break;
+        case 5: kern = m16 ? attn_fwd_d128_mi16_kernel<5> : attn_fwd_d128_kernel<5>; break;
+        case 6: kern = m16 ? attn_fwd_d128_mi16_kernel<6> : attn_fwd_d128_kernel<6>; break;
+        case 7: kern = m16 ? attn_fwd_d128_mi16_kernel<7> : attn_fwd_d128_kernel<7>; break;
+        case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_kernel<8>; break;
+        default: apexmi_set_error("attn_fwd_prepared: attn.waves=%d not in [4,8]", nw); return 1;
+    }
+    static bool attr_done[2][9] = {};
+    if (!attr_done[m16][nw]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        attr_done[m16][nw] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(total), dim3(nw * 64), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,
                        o_strides[0], o_strides[1], o_strides[2], c);
     return apexmi_check_launch("attn_fwd_d128");

@@ -374,7 +374,7 @@ def test_attention_mfma_vs_oracle(B, H, Sq, Sk):
 
 
 @pytest.mark.parametrize("mfma", [16, 32])
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [4, 5, 6, 7, 8])
 def test_attention_workgroup_sizes(waves, mfma):
     """Both workgroup sizes of both MFMA kernels (32x32x16 shipped, 16x16x32 kept for A/B), ragged Sq / Sk."""
     from apex_studio_amd import lib
