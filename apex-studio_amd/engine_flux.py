@@ -13,6 +13,8 @@ from typing import Callable, Optional
 
 import torch
 
+from .lora import EngineLoraMixin
+
 from .schedulers import FlowMatchEulerDiscreteScheduler
 
 
@@ -51,7 +53,7 @@ def _emit(cb, p, msg):
             pass
 
 
-class FluxT2IEngine:
+class FluxT2IEngine(EngineLoraMixin):
     """engine.run(...) for Flux text-to-image with pre-computed prompt embeddings."""
 
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,

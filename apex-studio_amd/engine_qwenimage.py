@@ -9,6 +9,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
+from .lora import EngineLoraMixin
+
 from .engine_flux import calculate_shift
 from .schedulers import FlowMatchEulerDiscreteScheduler
 
@@ -21,7 +23,7 @@ def _emit(cb, p, msg):
             pass
 
 
-class QwenImageEditPlusEngine:
+class QwenImageEditPlusEngine(EngineLoraMixin):
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, decode_fn=None):
         self.transformer = transformer
         # Qwen-Image scheduler_config.json: dynamic exponential shifting, base/max shift 0.5/0.9,

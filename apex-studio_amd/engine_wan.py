@@ -13,6 +13,8 @@ from typing import List, Optional, Union
 
 import torch
 
+from .lora import EngineLoraMixin
+
 from .schedulers import UniPCMultistepScheduler
 
 
@@ -24,7 +26,7 @@ def _emit(cb, p, msg):
             pass
 
 
-class WanT2VEngine:
+class WanT2VEngine(EngineLoraMixin):
     def __init__(self, high_noise_transformer, low_noise_transformer=None, vae=None,
                  scheduler: Optional[UniPCMultistepScheduler] = None, boundary_ratio: Optional[float] = 0.875,
                  vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 8):

@@ -30,6 +30,8 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
+
+from .lora import LoraAdapterMixin  # noqa: E402
 from . import lib as _l
 from . import ops
 
@@ -141,7 +143,7 @@ def _repoint(params, packed_rows):
     assert r == packed_rows.shape[0]
 
 
-class FluxTransformer2DModel(nn.Module):
+class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
     _supports_gradient_checkpointing = False
     _no_split_modules = ["_DoubleBlock", "_SingleBlock"]
 

@@ -24,6 +24,8 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+
+from .lora import LoraAdapterMixin  # noqa: E402
 from . import lib as _l
 from . import ops
 from .flux import _Config, _Linear, _Norm, _FF, _AdaNorm, _TimestepEmbedding, _repoint
@@ -63,7 +65,7 @@ class _TimeTextEmbed(nn.Module):
         self.timestep_embedder = _TimestepEmbedding(256, dim, **kw)
 
 
-class QwenImageTransformer2DModel(nn.Module):
+class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
     _no_split_modules = ["_QwenBlock"]
 
     def __init__(self, patch_size: int = 2, in_channels: int = 64, out_channels: Optional[int] = 16,

@@ -24,6 +24,8 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
+
+from .lora import LoraAdapterMixin  # noqa: E402
 from . import lib as _l
 from . import ops
 from .flux import _Config, _Linear, _Norm, _FF, _repoint
@@ -76,7 +78,7 @@ class _Conv3dParams(nn.Module):
         self.bias = nn.Parameter(torch.empty(cout, **kw), requires_grad=False)
 
 
-class WanTransformer3DModel(nn.Module):
+class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
     _no_split_modules = ["_WanBlock"]
 
     def __init__(self, patch_size: Tuple[int, int, int] = (1, 2, 2), num_attention_heads: int = 40,

@@ -16,6 +16,9 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
                         oracle"): pins block wiring, chunk orders, RoPE layout, concat
                         order and reshapes of oracle.flux — not the diffusers leaf arithmetic.
   flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
+  lora_convert.pt       reference LoraConverter().convert (lora/lora_converter.py:80-183) on seeded PEFT-with-alpha
+                        and lora_down/lora_up state dicts — pins key normalisation and alpha folding of
+                        apex_studio_amd.lora / oracle.lora (the PEFT runtime arithmetic itself is absent).
 
 The diffusers stubs below carry NO arithmetic except the leaves re-exported from oracle.layers.
 """
@@ -360,6 +363,53 @@ def gen_unipc():
     print("unipc.pt", s.timesteps.tolist(), float(traj[-1].abs().mean()))
 
 
+def gen_lora():
+    """Reference LoraConverter on seeded state dicts.  Stubs: the two rename tables imported from diffusers (only
+    used for the legacy diffusers formats, not exercised) and src.quantize.ggml_ops (imported by converters/utils,
+    unused on this path)."""
+    _mod("diffusers.utils.state_dict_utils", DIFFUSERS_TO_PEFT={}, DIFFUSERS_OLD_TO_PEFT={})
+    q = _mod("src.quantize")
+    q.__path__ = []
+    _mod("src.quantize.ggml_ops", ggml_cat=None, ggml_chunk=None)
+    import diffusers
+    if not hasattr(diffusers, "ModelMixin"):
+        diffusers.ModelMixin = type("ModelMixin", (), {})
+    cp = _mod("src.converters")
+    cp.__path__ = [os.path.join(REF, "src/converters")]
+    mod = load_by_path("ref_lora_converter", "src/lora/lora_converter.py")
+    conv = mod.LoraConverter()
+    cases = {}
+    # PEFT keys with alpha, "transformer." prefix, two modules of different rank
+    peft = {
+        "transformer.blocks.0.attn1.to_q.lora_A.weight": seeded((8, 32), 901),
+        "transformer.blocks.0.attn1.to_q.lora_B.weight": seeded((64, 8), 902),
+        "transformer.blocks.0.attn1.to_q.alpha": torch.tensor(4.0),
+        "transformer.blocks.1.ffn.net.2.lora_A.weight": seeded((4, 128), 903),
+        "transformer.blocks.1.ffn.net.2.lora_B.weight": seeded((32, 4), 904),
+        "transformer.blocks.1.ffn.net.2.alpha": torch.tensor(0.25),
+        "transformer.blocks.1.attn1.to_k.lora_A.weight": seeded((16, 32), 905),   # no alpha
+        "transformer.blocks.1.attn1.to_k.lora_B.weight": seeded((64, 16), 906),
+    }
+    base = {
+        "diffusion_model.blocks.0.ffn.net.0.proj.lora_down.weight": seeded((4, 32), 911),
+        "diffusion_model.blocks.0.ffn.net.0.proj.lora_up.weight": seeded((128, 4), 912),
+        "diffusion_model.blocks.0.ffn.net.0.proj.alpha": torch.tensor(8.0),
+        "diffusion_model.blocks.0.attn2.to_out.0.lora_down.weight": seeded((16, 32), 913),
+        "diffusion_model.blocks.0.attn2.to_out.0.lora_up.weight": seeded((32, 16), 914),
+        "diffusion_model.blocks.0.attn2.to_out.0.alpha": torch.tensor(1.0),
+    }
+    model_keys = ["blocks.0.attn1.to_q.weight", "blocks.1.ffn.net.2.weight", "blocks.1.attn1.to_k.weight",
+                  "blocks.0.ffn.net.0.proj.weight", "blocks.0.attn2.to_out.0.weight"]
+    for name, sd in (("peft", peft), ("base", base)):
+        out = conv.convert({k: v.clone() for k, v in sd.items()}, model_keys=list(model_keys))
+        cases[name] = dict(inp=sd, out={k: v.clone() for k, v in out.items()})
+        print("lora", name, sorted(out.keys())[:3], "...")
+    torch.save(dict(cases=cases, model_keys=model_keys,
+                    alpha_scales={(r, a): conv.get_alpha_scales(torch.zeros(r, 1), a)
+                                  for r in (4, 8, 16, 64) for a in (0.25, 1.0, 4.0, 8.0, 128.0)}),
+               os.path.join(OUT, "lora_convert.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -370,6 +420,7 @@ def main():
     gen_qwen_hybrid()
     gen_vae_wan()
     gen_unipc()
+    gen_lora()
 
 
 if __name__ == "__main__":
