@@ -368,6 +368,47 @@ __global__ void euler_step_kernel(const void* __restrict__ sample, const bf16_t*
     }
 }
 
+// float8_e4m3fn (OCP: bias 7, no infinity, S.1111.111 = NaN) and float8_e5m2 (IEEE-like, bias 15) -> f32, by bits,
+// so the result is the one torch's .to(float32) gives on every value including subnormals.
+APEXMI_DEVICE float fp8_e4m3fn_to_f32(uint32_t b) {
+    const uint32_t sign = (b & 0x80u) << 24, e = (b >> 3) & 0xFu, m = b & 7u;
+    if (e == 0xFu && m == 7u) return __uint_as_float(sign | 0x7FC00000u);
+    if (e == 0u) return __uint_as_float(sign | __float_as_uint((float)m * 0.001953125f));  // m * 2^-9
+    return __uint_as_float(sign | ((e + 120u) << 23) | (m << 20));
+}
+APEXMI_DEVICE float fp8_e5m2_to_f32(uint32_t b) {
+    const _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)(b << 8));  // e5m2 is the top byte of an fp16
+    return (float)h;
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_scaled_kernel(const uint8_t* __restrict__ w, int format,
+                                                                 const bf16_t* __restrict__ scale, int per_row,
+                                                                 int64_t rows, int64_t cols, bf16_t* __restrict__ out,
+                                                                 int64_t ldo) {
+    const int64_t r = blockIdx.y;
+    const float s = bf16_to_f32(scale[per_row ? r : 0]);
+    const uint8_t* wr = w + r * cols;
+    bf16_t* orow = out + r * ldo;
+    for (int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; c < cols; c += (int64_t)gridDim.x * 256 * 8) {
+        if (c + 8 <= cols && ((cols | ldo) & 7) == 0) {
+            const u32x2 q = *(const u32x2*)(wr + c);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t byte = (q[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                // the reference multiplies two bf16 tensors: fp8 -> bf16 is exact, the product rounds once
+                f[j] = (format == 0 ? fp8_e4m3fn_to_f32(byte) : bf16_to_f32(f32_to_bf16(fp8_e5m2_to_f32(byte)))) * s;
+            }
+            *(u32x4*)(orow + c) = pack8(f);
+        } else {
+            for (int64_t j = c; j < min(c + 8, cols); ++j) {
+                const float v = format == 0 ? fp8_e4m3fn_to_f32(wr[j]) : bf16_to_f32(f32_to_bf16(fp8_e5m2_to_f32(wr[j])));
+                orow[j] = f32_to_bf16(v * s);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
@@ -519,6 +560,29 @@ extern "C" int apexmi_add_bcast_f32(const float* a, const float* b, float* out, 
     hipLaunchKernelGGL(add_bcast_f32_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, stream, a, b,
                        out, rows, n);
     return apexmi_check_launch("add_bcast_f32");
+}
+
+extern "C" int apexmi_dequant_fp8_scaled(const void* w, int format, const void* scale, int64_t scale_count,
+                                         int64_t rows, int64_t cols, void* out, int64_t ldo, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(w && scale && out && rows > 0 && cols > 0 && ldo >= cols, "dequant_fp8_scaled: bad arguments");
+    APEXMI_REQUIRE(format == 0 || format == 1, "dequant_fp8_scaled: format %d is neither e4m3fn (0) nor e5m2 (1)", format);
+    APEXMI_REQUIRE(scale_count == 1 || scale_count == rows,
+                   "dequant_fp8_scaled: scale_weight has %lld values for %lld output rows", (long long)scale_count,
+                   (long long)rows);
+    APEXMI_REQUIRE(rows < 65536 * 32767LL, "dequant_fp8_scaled: too many rows");
+    ApexmiProfScope prof(5, stream, 0.0, 3.0 * rows * cols);
+    const int64_t gx64 = (cols + 2047) / 2048;
+    const unsigned gx = (unsigned)(gx64 < 64 ? gx64 : 64);
+    // blockIdx.y is limited to 65535: fold longer matrices into several launches
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(dequant_fp8_scaled_kernel, dim3(gx, (unsigned)nr), dim3(256), 0, stream,
+                           (const uint8_t*)w + r0 * cols, format,
+                           (const bf16_t*)scale + (scale_count == 1 ? 0 : r0), (int)(scale_count != 1), nr, cols,
+                           (bf16_t*)out + r0 * ldo, ldo);
+    }
+    return apexmi_check_launch("dequant_fp8_scaled");
 }
 
 extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {

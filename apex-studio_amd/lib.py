@@ -60,6 +60,7 @@ SIGNATURES = {
     "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
     "apexmi_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "apexmi_dequant_fp8_scaled": (C.c_int, [vp, C.c_int, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64, vp]),
     "apexmi_euler_step": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_int, vp]),
     "apexmi_prof_enable": (C.c_int, [C.c_int]),
     "apexmi_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

@@ -311,6 +311,27 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def dequant_fp8_scaled(w: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[rows, cols] (bf16) = w (float8_e4m3fn | float8_e5m2, [rows, cols]).to(bf16) * scale.to(bf16); `scale` is
+    a scalar or one value per row.  `out` may be a row-range view of a packed weight matrix."""
+    fmt = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}.get(w.dtype)
+    if fmt is None:
+        raise TypeError(f"dequant_fp8_scaled: weight dtype {w.dtype} is not an fp8 format")
+    if not w.is_cuda:
+        raise RuntimeError("dequant_fp8_scaled: tensors must be on the GPU (there is no CPU path)")
+    w2 = w.reshape(w.shape[0], -1).contiguous()
+    rows, cols = w2.shape
+    s = scale.to(w.device).to(torch.bfloat16).reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.bfloat16, device=w.device)
+    else:
+        _req(out, torch.bfloat16, "dequant_fp8_scaled.out")
+        assert out.shape == (rows, cols) and out.stride(1) == 1
+    _l.check(_l.load().apexmi_dequant_fp8_scaled(w2.data_ptr(), fmt, s.data_ptr(), s.numel(), rows, cols,
+                                                 out.data_ptr(), out.stride(0), _stream()), "dequant_fp8_scaled")
+    return out
+
+
 def to_f32(x: torch.Tensor) -> torch.Tensor:
     _req(x, torch.bfloat16, "to_f32.x")
     x = x.contiguous()

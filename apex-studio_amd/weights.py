@@ -1,0 +1,91 @@
+"""Checkpoint shards -> the packed device layout, without a host-side state dict.
+
+The reference loads every weight file into a full state dict, runs the key converter, optionally patches the
+model with FP-scaled layers that dequantise `weight * scale_weight` on EVERY forward, and calls
+`model.load_state_dict(sd, strict=False, assign=True)` per file (`R/src/mixins/loader_mixin.py:439-531`;
+`R/src/quantize/scaled_layer.py:496-549`, `fp8_activation_dequant` :154-167).
+
+Here tensors are streamed one at a time out of the safetensors shards (`safe_open`, lazy) straight into the model's
+parameters on the GPU — which, once `model.pack()` has run, are views of the fused QKV / modulation matrices, so
+the "fused/tiled device layout" is written exactly once.  FP8-scaled pairs (`<m>.weight` in float8_e4m3fn / e5m2
+plus `<m>.scale_weight`) are dequantised once at load by `apexmi_dequant_fp8_scaled` into the same bf16 values the
+reference recomputes per forward, so the denoise kernels are unchanged.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import torch
+
+FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
+
+
+def iter_checkpoint(files: Sequence[str]) -> Iterator[Tuple[str, Callable[[], torch.Tensor]]]:
+    """(key, loader) for every tensor of every shard; `loader()` reads that one tensor to the host."""
+    for path in files:
+        if path.endswith(".safetensors"):
+            from safetensors import safe_open
+            f = safe_open(path, framework="pt", device="cpu")
+            for k in f.keys():
+                yield k, (lambda f=f, k=k: f.get_tensor(k))
+        else:
+            sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+            for k, v in sd.items():
+                yield k, (lambda v=v: v)
+
+
+def remap_key(key: str, key_map: Optional[Dict[str, str]]) -> str:
+    """`key_map` semantics of the reference loader (loader_mixin.py:462-471): replace a substring."""
+    if key_map:
+        for src, dst in key_map.items():
+            if src in key:
+                key = key.replace(src, dst)
+    return key
+
+
+@torch.no_grad()
+def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: Optional[Dict[str, str]] = None,
+                         strict: bool = False) -> Tuple[List[str], List[str]]:
+    """Stream `files` into `model` (already on the GPU, bf16).  Returns (missing_keys, unexpected_keys) like
+    `load_state_dict(strict=False)`; `strict=True` raises on either.  Shapes must match exactly, except that a
+    0-d / 1-element `scale_weight` may pair with any weight (scaled_layer.py:444-493)."""
+    from . import ops
+    targets: Dict[str, torch.Tensor] = dict(model.named_parameters())
+    targets.update({k: v for k, v in model.named_buffers() if k not in targets})
+    if any(not t.is_cuda for t in targets.values()):
+        raise RuntimeError("load_checkpoint_into: move the model to the GPU first (there is no CPU path)")
+    entries = [(remap_key(k, key_map), ld) for k, ld in iter_checkpoint(files)]
+    scales = {k[:-len("scale_weight")]: ld for k, ld in entries if k.endswith("scale_weight")}
+    seen, unexpected = set(), []
+    for key, ld in entries:
+        if key.endswith("scale_weight"):
+            if key[:-len("scale_weight")] + "weight" not in targets:
+                unexpected.append(key)
+            continue
+        if key not in targets:
+            unexpected.append(key)
+            continue
+        dst = targets[key]
+        src = ld()
+        if tuple(src.shape) != tuple(dst.shape):
+            raise ValueError(f"{key}: checkpoint shape {tuple(src.shape)} != parameter shape {tuple(dst.shape)}")
+        prefix = key[:-len("weight")] if key.endswith("weight") else None
+        if src.dtype in FP8_DTYPES:
+            if prefix is None or prefix not in scales:
+                raise ValueError(f"{key}: fp8 tensor without a '{(prefix or key)}scale_weight' partner")
+            if dst.dtype != torch.bfloat16:
+                raise TypeError(f"{key}: fp8-scaled weights load into bf16 parameters, not {dst.dtype}")
+            q = src.view(torch.uint8).to(dst.device, non_blocking=True).view(src.dtype)
+            out2d = dst.data.view(dst.shape[0], -1) if dst.dim() != 2 else dst.data
+            ops.dequant_fp8_scaled(q, scales[prefix](), out=out2d)
+        else:
+            if prefix is not None and prefix in scales:
+                # the reference raises here too (`physical_dtype in (torch.uint8)`, scaled_layer.py:525)
+                raise TypeError(f"{key}: '{prefix}scale_weight' is present but the weight is {src.dtype}, not fp8")
+            dst.data.copy_(src.to(dst.device, non_blocking=True))
+        seen.add(key)
+    missing = [k for k in targets if k not in seen]
+    if strict and (missing or unexpected):
+        raise RuntimeError(f"load_checkpoint_into: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "
+                           f"unexpected {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+    return missing, unexpected

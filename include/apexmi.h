@@ -220,6 +220,14 @@ int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t row
 int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);
 int apexmi_cast_bf16_to_f32(const void* x, float* out, int64_t n, apexmi_stream_t stream);
 
+/* FP-scaled checkpoint weights (`*_fp8_e4m3fn_scaled` files with `scale_weight` keys): the reference
+ * dequantises on every forward, `weight.to(dtype) * scale_weight.to(dtype)` (quantize/scaled_layer.py:154-167,
+ * :496-549; scale is a scalar or one value per output row).  Here it runs once at load:
+ * out[r, c] (bf16, row stride ldo) = bf16( float(fp8 w[r, c]) * float(bf16 scale[r or 0]) ), i.e. exactly the
+ * bf16 x bf16 product torch computes.  format: 0 = float8_e4m3fn, 1 = float8_e5m2; scale_count = 1 or rows. */
+int apexmi_dequant_fp8_scaled(const void* w, int format, const void* scale, int64_t scale_count, int64_t rows,
+                              int64_t cols, void* out, int64_t ldo, apexmi_stream_t stream);
+
 /* Scheduler step on device (the loop stays in Python; this is the per-step axpy of
  * FlowMatchEulerDiscreteScheduler.step: prev = sample + dt * model_output in f32,
  * cast back).  sample/out: bf16 or f32 per sample_dtype; v bf16. */

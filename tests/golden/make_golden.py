@@ -16,6 +16,10 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
                         oracle"): pins block wiring, chunk orders, RoPE layout, concat
                         order and reshapes of oracle.flux — not the diffusers leaf arithmetic.
   flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
+  fp_scaled.pt          reference fp8_activation_dequant / FPScaledLinear._scale_and_cast_weight
+                        (quantize/scaled_layer.py:154-167, :496-549) on seeded float8_e4m3fn / e5m2 weights with
+                        scalar and per-row scales, every fp8 code point included — pins oracle.weights and the
+                        HIP dequant kernel.
   lora_convert.pt       reference LoraConverter().convert (lora/lora_converter.py:80-183) on seeded PEFT-with-alpha
                         and lora_down/lora_up state dicts — pins key normalisation and alpha folding of
                         apex_studio_amd.lora / oracle.lora (the PEFT runtime arithmetic itself is absent).
@@ -410,6 +414,29 @@ def gen_lora():
                os.path.join(OUT, "lora_convert.pt"))
 
 
+def gen_fp_scaled():
+    """Reference FP-scaled dequantisation.  `FPScaledLinear` is instantiated only to reach the bound method
+    `_scale_and_cast_weight`; transformer_engine is optional in the reference and absent here."""
+    mod = load_by_path("ref_scaled_layer", "src/quantize/scaled_layer.py")
+    lin = mod.FPScaledLinear(16, 8, bias=False, compute_dtype=torch.bfloat16)
+    cases = {}
+    for name, dt in (("e4m3fn", torch.float8_e4m3fn), ("e5m2", torch.float8_e5m2)):
+        allcodes = torch.arange(256, dtype=torch.uint8).view(dt).reshape(8, 32)          # every code point once
+        w = (seeded((24, 40), 951) * 3.0).to(dt)
+        s_scalar = torch.tensor(0.0173)
+        s_row = (seeded((24, 1), 952).abs() * 0.02 + 0.001)
+        s_all = (seeded((8, 1), 953).abs() * 0.5 + 0.01)
+        cases[name] = dict(
+            w=w.view(torch.uint8), w_all=allcodes.view(torch.uint8), s_scalar=s_scalar, s_row=s_row, s_all=s_all,
+            out_scalar=mod.fp8_activation_dequant(w, s_scalar, torch.bfloat16),
+            out_row=mod.fp8_activation_dequant(w, s_row, torch.bfloat16),
+            out_all=mod.fp8_activation_dequant(allcodes, s_all, torch.bfloat16),
+            out_method=lin._scale_and_cast_weight(w, s_scalar, target_dtype=torch.bfloat16))
+        print("fp_scaled", name, float(cases[name]["out_row"].float().abs().mean()))
+    # (a non-fp8 weight WITH a scale_weight raises TypeError in the reference, scaled_layer.py:525 — no fixture)
+    torch.save(cases, os.path.join(OUT, "fp_scaled.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -421,6 +448,7 @@ def main():
     gen_vae_wan()
     gen_unipc()
     gen_lora()
+    gen_fp_scaled()
 
 
 if __name__ == "__main__":

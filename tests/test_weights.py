@@ -1,0 +1,126 @@
+"""Weight formats: FP-scaled dequantisation against the reference's own outputs
+(tests/golden/fp_scaled.pt) and the streaming safetensors loader into the packed device layout."""
+import os
+
+import pytest
+import torch
+
+from oracle import weights as OW
+from tests.golden.seeded import seeded
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fp_scaled.pt")
+DT = {"e4m3fn": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+
+
+def _same(a, b):
+    """bit-equal, NaNs in the same places"""
+    a, b = a.float(), b.float()
+    return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+
+@pytest.mark.parametrize("fmt", ["e4m3fn", "e5m2"])
+def test_oracle_dequant_matches_reference(fmt):
+    c = torch.load(GOLD, weights_only=False)[fmt]
+    w, wall = c["w"].view(DT[fmt]), c["w_all"].view(DT[fmt])
+    assert _same(OW.dequant(w, c["s_scalar"]), c["out_scalar"])
+    assert _same(OW.dequant(w, c["s_scalar"]), c["out_method"])
+    assert _same(OW.dequant(w, c["s_row"]), c["out_row"])
+    assert _same(OW.dequant(wall, c["s_all"]), c["out_all"])
+    with pytest.raises(TypeError):
+        OW.dequant(w.to(torch.bfloat16), c["s_scalar"])           # the reference raises for this combination too
+
+
+def test_key_map_and_iter(tmp_path):
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import weights
+    from safetensors.torch import save_file
+    save_file({"model.a.weight": torch.ones(2, 2), "model.b": torch.zeros(3)}, str(tmp_path / "s1.safetensors"))
+    torch.save({"c": torch.ones(1)}, str(tmp_path / "s2.pt"))
+    got = {weights.remap_key(k, {"model.": ""}): ld() for k, ld in
+           weights.iter_checkpoint([str(tmp_path / "s1.safetensors"), str(tmp_path / "s2.pt")])}
+    assert set(got) == {"a.weight", "b", "c"} and got["a.weight"].shape == (2, 2)
+    lin = torch.nn.Linear(2, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            weights.load_checkpoint_into(lin, [str(tmp_path / "s1.safetensors")])
+
+
+# ---------------------------------------------------------------- GPU
+DEV = "cuda"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["e4m3fn", "e5m2"])
+def test_hip_dequant_bit_exact_vs_reference(fmt):
+    """Every fp8 code point (subnormals, max, NaN, -0) and seeded matrices, scalar and per-row scales, ragged
+    width, strided output view: bit-exact against the reference fixture (integer/bit-level work: no tolerance)."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import ops
+    c = torch.load(GOLD, weights_only=False)[fmt]
+    w, wall = c["w"].view(DT[fmt]).to(DEV), c["w_all"].view(DT[fmt]).to(DEV)
+    assert _same(ops.dequant_fp8_scaled(w, c["s_scalar"]).cpu(), c["out_scalar"])
+    assert _same(ops.dequant_fp8_scaled(w, c["s_row"]).cpu(), c["out_row"])
+    assert _same(ops.dequant_fp8_scaled(wall, c["s_all"]).cpu(), c["out_all"])
+    wr = (seeded((7, 37), 961) * 2).to(DT[fmt])                                      # ragged: scalar tail path
+    sr = seeded((7, 1), 962).abs() + 0.1
+    assert _same(ops.dequant_fp8_scaled(wr.to(DEV), sr).cpu(), OW.dequant(wr, sr))
+    packed = torch.zeros(3 * 24, 40, dtype=torch.bfloat16, device=DEV)                # into a packed-matrix view
+    ops.dequant_fp8_scaled(w, c["s_row"], out=packed[24:48])
+    assert _same(packed[24:48].cpu(), c["out_row"]) and float(packed[:24].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="scale_weight has"):
+        ops.dequant_fp8_scaled(w, torch.ones(5))
+
+
+@pytest.mark.gpu
+def test_streaming_loader_into_packed_flux(tmp_path):
+    """Two shards (one bf16, one fp8-scaled) streamed into a packed tiny Flux: state_dict equals the expected
+    tensors bit-exactly, missing/unexpected keys are reported, and the forward equals a plain load_state_dict."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import weights
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from oracle import flux as OF
+    from safetensors.torch import save_file
+    from tests.golden.seeded import synthetic_state_dict
+    cfg = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128,
+               num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True,
+               axes_dims_rope=(16, 56, 56))
+    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(OF.FluxTransformer2DModel(**cfg), 7).items()}
+    keys = sorted(sd)
+    q_keys = [k for k in keys if k.endswith(".weight") and sd[k].dim() == 2 and "transformer_blocks" in k][:6]
+    shard_a = {k: sd[k] for k in keys[: len(keys) // 2] if k not in q_keys}
+    shard_b = {k: sd[k] for k in keys[len(keys) // 2:] if k not in q_keys}
+    expect = dict(sd)
+    for i, k in enumerate(q_keys):                       # quantise: per-tensor scalar scale or per-row [out, 1]
+        w = sd[k].float()
+        s = (w.abs().amax(dim=1, keepdim=True) / 448.0) if i % 2 else (w.abs().max() / 448.0).reshape(())
+        q = (w / s).to(torch.float8_e4m3fn)
+        shard_b["model." + k] = q
+        shard_b["model." + k[:-len("weight")] + "scale_weight"] = s.to(torch.float32)
+        expect[k] = OW.dequant(q, s)
+    shard_b["model.not_a_parameter.weight"] = torch.zeros(2, 2)
+    missing_key = keys[0] if keys[0] not in q_keys else keys[1]
+    shard_a.pop(missing_key, None)
+    shard_b.pop(missing_key, None)
+    save_file({("model." + k if not k.startswith("model.") else k): v.contiguous() for k, v in shard_a.items()},
+              str(tmp_path / "a.safetensors"))
+    save_file({("model." + k if not k.startswith("model.") else k): v.contiguous() for k, v in shard_b.items()},
+              str(tmp_path / "b.safetensors"))
+
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    missing, unexpected = weights.load_checkpoint_into(
+        m, [str(tmp_path / "a.safetensors"), str(tmp_path / "b.safetensors")], key_map={"model.": ""})
+    assert missing == [missing_key] and unexpected == ["not_a_parameter.weight"]
+    got = m.state_dict()
+    for k, v in expect.items():
+        if k != missing_key:
+            assert torch.equal(got[k].cpu(), v), k
+    with pytest.raises(RuntimeError, match="missing"):
+        weights.load_checkpoint_into(m, [str(tmp_path / "a.safetensors")], key_map={"model.": ""}, strict=True)
+    # an fp8 weight without its scale, and a scaled non-fp8 weight, are errors
+    save_file({q_keys[0]: shard_b["model." + q_keys[0]]}, str(tmp_path / "c.safetensors"))
+    with pytest.raises(ValueError, match="scale_weight"):
+        weights.load_checkpoint_into(m, [str(tmp_path / "c.safetensors")])
+    save_file({q_keys[0]: sd[q_keys[0]], q_keys[0][:-len("weight")] + "scale_weight": torch.ones(())},
+              str(tmp_path / "d.safetensors"))
+    with pytest.raises(TypeError, match="not fp8"):
+        weights.load_checkpoint_into(m, [str(tmp_path / "d.safetensors")])
