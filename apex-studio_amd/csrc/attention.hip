@@ -447,6 +447,84 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
     }
 }
 
+// ---- materialised attention for head dims the flash kernel does not cover (VAE mid blocks: one head of
+// C = 384 / 512 over 1k-16k tokens).  scores (f32) = q k^T by the GEMM kernel's f32 epilogue, one row-softmax
+// pass (f32 in, bf16 probabilities out, zero-padded to a multiple of 64 keys), out = P V by the GEMM kernel with
+// V^T as its weight operand.  Same rounding points as the flash kernels: f32 scores, bf16 P, f32 accumulation.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int cols,
+                                                           float scale_log2e, bf16_t* __restrict__ out, int64_t ldo,
+                                                           int cols_pad) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (int64_t)blockIdx.x * ldx;
+    bf16_t* orow = out + (int64_t)blockIdx.x * ldo;
+    constexpr int MAXCH = 16;  // register-resident up to 16 x 1024 columns; longer rows stream from L2
+    f32x4 v[MAXCH];
+    const bool fits = cols <= MAXCH * 1024;
+    float mx = -1.0e30f;
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = (i * 256 + tid) * 4;
+            v[i] = c < cols ? *(const f32x4*)(xr + c) : f32x4{-1.0e30f, -1.0e30f, -1.0e30f, -1.0e30f};
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+        }
+    } else {
+        for (int c = tid * 4; c < cols; c += 1024) {
+            const f32x4 t = *(const f32x4*)(xr + c);
+            mx = fmaxf(mx, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+    float sum = 0.0f;
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[i][j] = fast_exp2(fmaf(v[i][j], scale_log2e, -mx));
+                sum += v[i][j];
+            }
+        }
+    } else {
+        for (int c = tid * 4; c < cols; c += 1024) {
+            const f32x4 t = *(const f32x4*)(xr + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += fast_exp2(fmaf(t[j], scale_log2e, -mx));
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = (i * 256 + tid) * 4;
+            if (c < cols_pad) {
+                u32x2 o = {0u, 0u};
+                if (c < cols) o = u32x2{pack_bf16(v[i][0] * inv, v[i][1] * inv), pack_bf16(v[i][2] * inv, v[i][3] * inv)};
+                *(u32x2*)(orow + c) = o;
+            }
+        }
+    } else {
+        for (int c = tid * 4; c < cols_pad; c += 1024) {
+            u32x2 o = {0u, 0u};
+            if (c < cols) {
+                const f32x4 t = *(const f32x4*)(xr + c);
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = fast_exp2(fmaf(t[j], scale_log2e, -mx)) * inv;
+                o = u32x2{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3])};
+            }
+            *(u32x2*)(orow + c) = o;
+        }
+    }
+}
+
 // ---- generic fallback: any D <= 256, bf16 / f16 / f32, strided views; one workgroup per query row.
 // Exists so the operator survives the reference's backend verification probe
 // (B,H,S,D = 1,2,8,64 fp16; attention/functions.py:1999-2251) and odd head sizes (VAE C = 384 is
@@ -545,6 +623,18 @@ bool packed_bhsd(const int64_t* st, int H, int S, int D) {
     return st[2] == D && st[1] == (int64_t)S * D && st[0] == (int64_t)H * S * D;
 }
 
+
+// workspace layout of the materialised path: [scores f32 Sq x Sk][P bf16 Sq x Skp][V^T bf16 D x Skp]
+bool use_materialised(int Sq, int Sk, int D, int dtype, const int64_t* qs, const int64_t* ks, const int64_t* vs,
+                      const int64_t* os) {
+    return dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && Sk % 8 == 0 &&
+           (int64_t)Sq * Sk >= 256 * 256 && qs[2] % 8 == 0 && ks[2] % 8 == 0 && vs[2] % 8 == 0 && os[1] % 8 == 0;
+}
+size_t materialised_bytes(int Sq, int Sk, int D) {
+    const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
+    return (size_t)Sq * Sk * 4 + (size_t)Sq * skp * 2 + (size_t)D * skp * 2;
+}
+
 }  // namespace
 
 extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void* out,
@@ -599,6 +689,8 @@ void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
 void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
+    if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && Sk % 8 == 0 && (int64_t)Sq * Sk >= 256 * 256)
+        return materialised_bytes(Sq, Sk, D);   // one (batch, head) at a time on the stream
     if (dtype != APEXMI_BF16 || D != HD) return 0;
     const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
     // V^T plus packed copies of q and k (used only when the caller's views are not packed)
@@ -643,6 +735,36 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
         }
         return apexmi_attn_fwd_prepared(qp, kp, vt, out, B, H, Sq, Sk, skp, o_strides, softmax_scale,
                                         stream);
+    }
+    if (use_materialised(Sq, Sk, D, dtype, q_strides, k_strides, v_strides, o_strides) && workspace &&
+        workspace_bytes >= materialised_bytes(Sq, Sk, D)) {
+        const int skp = ((Sk + KV - 1) / KV) * KV;
+        float* sc = (float*)workspace;
+        bf16_t* pb = (bf16_t*)((char*)workspace + (size_t)Sq * Sk * 4);
+        bf16_t* vt = pb + (size_t)Sq * skp;
+        const float c = softmax_scale * 1.4426950408889634f;
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                const bf16_t* qp = (const bf16_t*)q + b * q_strides[0] + h * q_strides[1];
+                const bf16_t* kp = (const bf16_t*)k + b * k_strides[0] + h * k_strides[1];
+                const bf16_t* vp = (const bf16_t*)v + b * v_strides[0] + h * v_strides[1];
+                bf16_t* op = (bf16_t*)out + b * o_strides[0] + h * o_strides[2];
+                if (int rc = apexmi_gemm_bf16(qp, q_strides[2], kp, k_strides[2], nullptr, sc, Sk, Sq, Sk, D,
+                                              APEXMI_EPI_BIAS_F32, nullptr, nullptr, 0, stream_))
+                    return rc;
+                {
+                    ApexmiProfScope prof(1, stream, 0.0, (double)Sq * Sk * 6.0);
+                    hipLaunchKernelGGL(softmax_rows_kernel, dim3(Sq), dim3(256), 0, stream, sc, (int64_t)Sk, Sk, c, pb,
+                                       (int64_t)skp, skp);
+                    if (int rc = apexmi_check_launch("softmax_rows")) return rc;
+                }
+                // V^T [D, skp]: the 128-wide transpose kernel over D / 128 column slices
+                if (int rc = apexmi_v_transpose(vp, 128, v_strides[2], Sk, D / 128, 128, vt, skp, 0, stream_)) return rc;
+                if (int rc = apexmi_gemm_bf16(pb, skp, vt, skp, nullptr, op, o_strides[1], Sq, D, skp, APEXMI_EPI_BIAS,
+                                              nullptr, nullptr, 0, stream_))
+                    return rc;
+            }
+        return 0;
     }
     APEXMI_REQUIRE(D <= GEN_THREADS, "attn_fwd: head dim %d > %d unsupported", D, GEN_THREADS);
     ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * D, 0.0);

@@ -114,6 +114,21 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
         bs[g][3] = bf16_hi(b[1]);
         if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[g] = *(const f32x4*)(P.gate + n);
     }
+    if (EPI == APEXMI_EPI_BIAS_F32) {  // C is float[M][ldc]: the lane's 4 consecutive columns of each group, no exchange
+        float* Cf = (float*)P.C;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + 8 * g + 4 * hi;
+                if (m[mt] >= 0 && n < N) {
+                    const f32x4 o = {acc[mt][4 * g + 0] + bs[g][0], acc[mt][4 * g + 1] + bs[g][1],
+                                     acc[mt][4 * g + 2] + bs[g][2], acc[mt][4 * g + 3] + bs[g][3]};
+                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = o;
+                }
+            }
+        return;
+    }
     u32x4 rr[TM][2];
     if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
 #pragma unroll
@@ -190,6 +205,21 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         bs[t][2] = bf16_lo(b[1]);
         bs[t][3] = bf16_hi(b[1]);
         if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[t] = *(const f32x4*)(P.gate + n);
+    }
+    if (EPI == APEXMI_EPI_BIAS_F32) {  // C is float[M][ldc]: 4 consecutive columns per tile, no exchange
+        float* Cf = (float*)P.C;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = nbase + 16 * t + 4 * g;
+                const f32x4_t& a = t ? y[mt] : x[mt];
+                if (m[mt] >= 0 && n < N) {
+                    const f32x4 o = {a[0] + bs[t][0], a[1] + bs[t][1], a[2] + bs[t][2], a[3] + bs[t][3]};
+                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = o;
+                }
+            }
+        return;
     }
     const int nst = nbase + 16 * (g & 1) + 8 * (g >> 1);  // first of the 8 columns this lane stores
     u32x4 rr[MT];
@@ -692,8 +722,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
             mma(1, 1);
             PP_BAR();
             // phase 4: (m-half 1, n-tile 0)
-            // phase 4 needs no fragment read: n-tile 0's weight fragments of phase 1 are still in registers
-            // (-0.8 % per step against re-reading them)
+            rd_w(Ws, 0);
             if (more) stage_a(nb, kt + 1, 1);
             if (more) VMCNT(4);
             PP_SYNC();
@@ -780,10 +809,15 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     }
 }
 
-int launch_group(GemmGroup& G, const int* Ms, bool gate_res, hipStream_t stream) {
-    return gate_res ? launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream)
-                    : launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
+int launch_group(GemmGroup& G, const int* Ms, int kind, hipStream_t stream) {
+    switch (kind) {  // epilogue class: bias (+gelu flag) | gate/residual | f32 output
+        case APEXMI_EPI_BIAS_GATE_RES: return launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream);
+        case APEXMI_EPI_BIAS_F32: return launch_epi<APEXMI_EPI_BIAS_F32>(G, Ms, stream);
+        default: return launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
+    }
 }
+
+int epi_kind(int epilogue) { return epilogue == APEXMI_EPI_BIAS_GELU ? APEXMI_EPI_BIAS : epilogue; }
 
 int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
                   int N, int K, int epilogue, const float* gate, const void* R, int64_t ldr) {
@@ -811,7 +845,8 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                                 apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
-    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 2, "gemm_bf16: unknown epilogue %d", epilogue);
+    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm_bf16: unknown epilogue %d", epilogue);
+    APEXMI_REQUIRE(epilogue != APEXMI_EPI_BIAS_F32 || ((uintptr_t)C % 16) == 0, "gemm_bf16: f32 output must be 16-byte aligned");
     GemmGroup G;
     G.count = 1;
     G.K = K;
@@ -820,7 +855,7 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                          epilogue == APEXMI_EPI_BIAS_GELU};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch_group(G, &M, epilogue == APEXMI_EPI_BIAS_GATE_RES, stream);
+    return launch_group(G, &M, epi_kind(epilogue), stream);
 }
 
 extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda,
@@ -835,9 +870,9 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     G.count = count;
     G.K = K;
     double flops = 0, bytes = 0;
-    const bool gate_res = epilogue[0] == APEXMI_EPI_BIAS_GATE_RES;
+    const int kind = epi_kind(epilogue[0]);
     for (int i = 0; i < count; ++i) {
-        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 2 && (epilogue[i] == APEXMI_EPI_BIAS_GATE_RES) == gate_res,
+        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 3 && epi_kind(epilogue[i]) == kind,
                        "gemm_bf16_grouped: gate/residual problems cannot be mixed with bias/gelu ones");
         const float* g = gate ? gate[i] : nullptr;
         const void* r = R ? R[i] : nullptr;
@@ -851,7 +886,7 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
         bytes += 2.0 * ((double)M[i] * K + (double)N[i] * K + (double)M[i] * N[i]);
     }
     ApexmiProfScope prof(0, stream, flops, bytes);
-    return launch_group(G, M, gate_res, stream);
+    return launch_group(G, M, kind, stream);
 }
 
 void apexmi_set_attn_waves(int v);

@@ -34,6 +34,7 @@ typedef void* apexmi_stream_t; /* a hipStream_t; NULL = the null stream */
 #define APEXMI_EPI_BIAS 0          /* C = A W^T + b                                   */
 #define APEXMI_EPI_BIAS_GELU 1     /* C = gelu_tanh(A W^T + b)                        */
 #define APEXMI_EPI_BIAS_GATE_RES 2 /* C = R + gate[n] * (A W^T + b)   (R may alias C) */
+#define APEXMI_EPI_BIAS_F32 3      /* C = A W^T + b stored as float (C is float*, ldc in floats): attention scores */
 
 /* GEMV flags */
 #define APEXMI_GEMV_PRE_SILU 1   /* x <- silu(x) before the dot product           */

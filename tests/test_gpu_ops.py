@@ -448,3 +448,36 @@ def test_euler_step_and_casts():
     assert torch.allclose(out.float().cpu(), sb.float() + (-0.0357) * v.float(), atol=1e-6, rtol=2.0 ** -7)
     assert torch.equal(ops.to_bf16(s.to(DEV)).cpu(), sb)
     assert torch.equal(ops.to_f32(sb.to(DEV)).cpu(), sb.float())
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1024, 1024, 512), (2, 1, 1024, 1000, 384), (1, 2, 300, 2048, 256)])
+def test_attention_materialised_wide_heads(shape):
+    """Head dims the flash kernel does not cover (VAE mid blocks, C = 384 / 512): scores by the GEMM's f32
+    epilogue, row softmax, P V by the GEMM.  Same bar as the flash kernel (P is rounded to bf16 before P V)."""
+    ops = _ops()
+    B, H, Sq, Sk, D = shape
+    q = seeded((B, H, Sq, D), 181, torch.bfloat16)
+    k = seeded((B, H, Sk, D), 182, torch.bfloat16)
+    v = seeded((B, H, Sk, D), 183, torch.bfloat16)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    ref = OL.sdpa(q.float().to(DEV), k.float().to(DEV), v.float().to(DEV)).cpu()
+    _check(out, ref, 1e-2, f"attention materialised {shape}", ulp=3.0)
+    out2 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert torch.equal(out.cpu(), out2.cpu())
+
+
+def test_gemm_f32_epilogue():
+    """APEXMI_EPI_BIAS_F32: float output of both tilings (scores of the materialised attention)."""
+    from apex_studio_amd import lib
+    import ctypes  # noqa: F401
+    ops = _ops()
+    for (M, N, K) in [(300, 264, 128), (1280, 1032, 512)]:
+        a = seeded((M, K), 191, torch.bfloat16).to(DEV)
+        w = seeded((N, K), 192, torch.bfloat16).to(DEV)
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        rc = lib.load().apexmi_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, out.data_ptr(),
+                                         out.stride(0), M, N, K, 3, None, None, 0, torch.cuda.current_stream().cuda_stream)
+        lib.check(rc, "gemm f32")
+        ref = a.float() @ w.float().t()
+        assert torch.isfinite(out).all()
+        assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), (M, N, K)

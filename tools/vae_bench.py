@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Time the VAE decodes alone (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
+usage: vae_bench.py flux|wan [reps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import apex_studio_amd  # noqa: E402,F401
+from bench import synth_vae_init  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "flux"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+if which == "flux":
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
+    z = torch.randn(1, 16, 128, 128, device=dev).to(torch.bfloat16)
+else:
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
+    z = torch.randn(1, 16, 21, 90, 160, device=dev).to(torch.bfloat16)
+vae.decode(z, return_dict=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    out = vae.decode(z, return_dict=False)[0]
+torch.cuda.synchronize()
+print(f"{which} vae decode: {(time.perf_counter() - t0) / reps * 1e3:.1f} ms  out {tuple(out.shape)}")
