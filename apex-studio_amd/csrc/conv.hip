@@ -321,22 +321,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk, int C,
-                                   int G, int64_t P, float eps) {
-    const int g = threadIdx.x;               // one thread per group
-    if (g >= G) return;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                          int nblk, int C, int G, int64_t P, float eps) {
+    // one workgroup per group; thread t sums items t, t + 256, ... of the group's nblk x cpg partials in f64, then a
+    // fixed-shape tree in LDS: the result does not depend on scheduling (run-to-run bit-identical)
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, t = threadIdx.x;
     const int cpg = C / G;
+    const int64_t items = (int64_t)nblk * cpg;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            s += part[((int64_t)b * C + c) * 2];
-            q += part[((int64_t)b * C + c) * 2 + 1];
+    for (int64_t i = t; i < items; i += 256) {
+        const int64_t b = i / cpg;
+        const int c = g * cpg + (int)(i % cpg);
+        s += part[(b * C + c) * 2];
+        q += part[(b * C + c) * 2 + 1];
+    }
+    rs[t] = s;
+    rq[t] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            rs[t] += rs[t + w];
+            rq[t] += rq[t + w];
         }
-    const double n = (double)P * cpg;
-    const double mean = s / n;
-    const double var = fmax(q / n - mean * mean, 0.0);
-    stats[2 * g] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double n = (double)P * cpg;
+        const double mean = rs[0] / n;
+        const double var = fmax(rq[0] / n - mean * mean, 0.0);
+        stats[2 * g] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
@@ -384,7 +400,7 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
     float* stats = part + (size_t)nblk * C * 2;
     ApexmiProfScope prof(3, stream, 0.0, 6.0 * (double)P * C);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, part, P, C, rows);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, stream, part, stats, nblk, C, G, P, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, stream, part, stats, nblk, C, G, P, eps);
     const int64_t n = P * (C / 8);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        (bf16_t*)y, stats, (const bf16_t*)gamma, (const bf16_t*)beta, P, C, G, silu);
