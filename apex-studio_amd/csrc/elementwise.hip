@@ -112,6 +112,82 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     }
 }
 
+// Wave-per-row variant for C = 64 * 8 * NCH (3072, 3584, 5120): a lane owns NCH 16-byte chunks, the two
+// statistics are wave reductions (no LDS, no barrier), four rows per workgroup.  Same arithmetic order per lane
+// as the block kernel's per-thread part; the cross-lane sums differ in shape, both are f32.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms, int split,
+    const float* __restrict__ scale2, const float* __restrict__ shift2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    if (row < split) {
+        scale = scale2;
+        shift = shift2;
+    }
+    const bf16_t* xp = x + (int64_t)row * ldx;
+    float v[NCH][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        unpack8(*(const u32x4*)(xp + (it * 64 + lane) * 8), v[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[it][j];
+    }
+    const float mean = rms ? 0.0f : wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[it][j] - mean;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    bf16_t* op = out + (int64_t)row * ldo;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int c = it * 64 + lane;
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (v[it][j] - mean) * rstd;
+        if (gamma != nullptr) {
+            float g[8];
+            unpack8(*(const u32x4*)(gamma + c * 8), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] *= g[j];
+        }
+        if (beta != nullptr) {
+            float bt[8];
+            unpack8(*(const u32x4*)(beta + c * 8), bt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] += bt[j];
+        }
+        if (scale != nullptr) {
+            const f32x4 s0 = *(const f32x4*)(scale + c * 8);
+            const f32x4 s1 = *(const f32x4*)(scale + c * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] *= 1.0f + s0[j];
+                y[j + 4] *= 1.0f + s1[j];
+            }
+        }
+        if (shift != nullptr) {
+            const f32x4 s0 = *(const f32x4*)(shift + c * 8);
+            const f32x4 s1 = *(const f32x4*)(shift + c * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] += s0[j];
+                y[j + 4] += s1[j];
+            }
+        }
+        *(u32x4*)(op + c * 8) = pack8(y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // q/k: per-head RMSNorm (f32) * weight, rotary embedding, write [H, S_out, 128].
 // 16 lanes per (row, which, head) unit, 8 elements (4 rotary pairs) per lane.
@@ -418,6 +494,9 @@ extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t
                                nullptr, stream_);
 }
 
+int g_ln_wave = 1;  // apexmi_tune_set("ln.wave", 0/1): wave-per-row kernel for C in {3072, 3584, 5120}
+void apexmi_set_ln_wave(int v) { g_ln_wave = v; }
+
 extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
                                    const float* scale, const float* shift, const void* gamma,
                                    const void* beta, float eps, int rms, int split,
@@ -435,6 +514,21 @@ extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_
     APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
                    "ln_modulate: scale/shift must be 16-byte aligned");
     ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)M * C);
+#define LNW_LAUNCH(N)                                                                                          \
+    hipLaunchKernelGGL(ln_modulate_wave_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, ldx, \
+                       (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms, \
+                       split, scale2, shift2)
+    if (g_ln_wave && C % 512 == 0) {
+        bool done = true;
+        switch (C / 512) {
+            case 6: LNW_LAUNCH(6); break;
+            case 7: LNW_LAUNCH(7); break;
+            case 10: LNW_LAUNCH(10); break;
+            default: done = false;
+        }
+        if (done) return apexmi_check_launch("ln_modulate");
+    }
+#undef LNW_LAUNCH
     const int nit = (C / 8 + 255) / 256;
 #define LN_LAUNCH(N)                                                                                  \
     hipLaunchKernelGGL(ln_modulate_kernel<N>, dim3(M), dim3(256), 0, stream, (const bf16_t*)x, ldx,   \
