@@ -51,14 +51,16 @@ def register(attention_register, set_default: bool = False, overwrite: bool = Tr
 
 def register_models(transformers_registry, vae_registry=None):
     """Register the drop-in component classes (B-model) next to "flux.base" / "wan.base" /
-    "qwenimage.base" (reference transformer/base.py:3; auto-scan transformer/__init__.py:21-84)."""
+    "qwenimage.base" / "hunyuanvideo15.base" (reference transformer/base.py:3; auto-scan transformer/__init__.py:21-84)."""
     from .flux import FluxTransformer2DModel
+    from .hunyuan15 import HunyuanVideo15Transformer3DModel
     from .qwenimage import QwenImageTransformer2DModel
     from .wan import WanTransformer3DModel
     ok = available()
     transformers_registry("flux.mi355", overwrite=True, available=ok)(FluxTransformer2DModel)
     transformers_registry("wan.mi355", overwrite=True, available=ok)(WanTransformer3DModel)
     transformers_registry("qwenimage.mi355", overwrite=True, available=ok)(QwenImageTransformer2DModel)
+    transformers_registry("hunyuanvideo15.mi355", overwrite=True, available=ok)(HunyuanVideo15Transformer3DModel)
     if vae_registry is not None:   # reference vae/__init__.py:9-73 (keys "auto" | "wan" | "qwenimage")
         from .vae_flux import AutoencoderKL
         from .vae_wan import AutoencoderKLWan

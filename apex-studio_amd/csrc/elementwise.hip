@@ -485,6 +485,24 @@ __global__ __launch_bounds__(256) void dequant_fp8_scaled_kernel(const uint8_t* 
     }
 }
 
+// out[r, c] = x[r, c] + v[c] (bf16 in / out, f32 add): `tokens + cond_type_embed(type)` of the HunyuanVideo-1.5
+// conditioning streams (transformer/hunyuanvideo15/base/model.py:1013-1056)
+__global__ __launch_bounds__(256) void add_rowvec_bf16_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                                              int64_t ldo, int64_t rows, int cols) {
+    const int nch = cols >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nch) return;
+    const int64_t r = idx / nch;
+    const int c = (int)(idx % nch) * 8;
+    float a[8], b[8];
+    unpack8(*(const u32x4*)(x + r * ldx + c), a);
+    unpack8(*(const u32x4*)(v + c), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    *(u32x4*)(out + r * ldo + c) = pack8(a);
+}
+
 }  // namespace
 
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
@@ -677,6 +695,20 @@ extern "C" int apexmi_dequant_fp8_scaled(const void* w, int format, const void* 
                            (bf16_t*)out + r0 * ldo, ldo);
     }
     return apexmi_check_launch("dequant_fp8_scaled");
+}
+
+extern "C" int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
+                                      int cols, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && v && out && rows > 0 && cols > 0, "add_rowvec_bf16: bad arguments");
+    APEXMI_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                       ((uintptr_t)out % 16) == 0,
+                   "add_rowvec_bf16: rows must be 16-byte aligned and cols a multiple of 8");
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * rows * cols);
+    const int64_t n = rows * (cols / 8);
+    hipLaunchKernelGGL(add_rowvec_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       ldx, (const bf16_t*)v, (bf16_t*)out, ldo, rows, cols);
+    return apexmi_check_launch("add_rowvec_bf16");
 }
 
 extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {

@@ -78,6 +78,16 @@ using CFG_256P = Cfg<256, 256, 2, 4, 1>;
 using CFG_256W = Cfg<256, 256, 2, 2, 4>;
 using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
 
+// activation of the bias epilogue: 1 gelu(tanh), 2 gelu(erf, torch nn.GELU() default), 3 silu
+APEXMI_DEVICE float act_f(float x, int mode) {
+    if (mode == 1) return gelu_tanh_f(x);
+    if (mode == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    return silu_f(x);
+}
+inline int act_mode(int epilogue) {
+    return epilogue == APEXMI_EPI_BIAS_GELU ? 1 : epilogue == APEXMI_EPI_BIAS_GELU_ERF ? 2 : epilogue == APEXMI_EPI_BIAS_SILU ? 3 : 0;
+}
+
 // exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
 // columns: low half-wave gets [a_lo | a_hi] = cols 8g..8g+7, high half-wave [b_lo | b_hi] = cols
 // 8(g+1)..8(g+1)+7.  The exchange is an involution, so it also maps a 16-byte residual load back to
@@ -151,7 +161,7 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[q][j] = acc[mt][4 * (g0 + q) + j] + bs[g0 + q][j];
-                    if (EPI == APEXMI_EPI_BIAS && P.gelu) v[q][j] = gelu_tanh_f(v[q][j]);  // block-uniform
+                    if (EPI == APEXMI_EPI_BIAS && P.gelu) v[q][j] = act_f(v[q][j], P.gelu);  // block-uniform
                 }
             if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
                 u32x2 ra = {rr[mt][pr][0], rr[mt][pr][1]}, rb = {rr[mt][pr][2], rr[mt][pr][3]};
@@ -236,8 +246,8 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
             v[0][j] = x[mt][j] + bs[0][j];
             v[1][j] = y[mt][j] + bs[1][j];
             if (EPI == APEXMI_EPI_BIAS && P.gelu) {
-                v[0][j] = gelu_tanh_f(v[0][j]);
-                v[1][j] = gelu_tanh_f(v[1][j]);
+                v[0][j] = act_f(v[0][j], P.gelu);
+                v[1][j] = act_f(v[1][j], P.gelu);
             }
         }
         if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
@@ -818,7 +828,7 @@ int launch_group(GemmGroup& G, const int* Ms, int kind, hipStream_t stream) {
     }
 }
 
-int epi_kind(int epilogue) { return epilogue == APEXMI_EPI_BIAS_GELU ? APEXMI_EPI_BIAS : epilogue; }
+int epi_kind(int epilogue) { return act_mode(epilogue) ? APEXMI_EPI_BIAS : epilogue; }
 
 int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
                   int N, int K, int epilogue, const float* gate, const void* R, int64_t ldr) {
@@ -846,14 +856,14 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                                 apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
-    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm_bf16: unknown epilogue %d", epilogue);
+    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 5, "gemm_bf16: unknown epilogue %d", epilogue);
     APEXMI_REQUIRE(epilogue != APEXMI_EPI_BIAS_F32 || ((uintptr_t)C % 16) == 0, "gemm_bf16: f32 output must be 16-byte aligned");
     GemmGroup G;
     G.count = 1;
     G.K = K;
     G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, gate,
                          (const bf16_t*)R, lda, ldw, ldc, ldr, M, N, 0, 0, 0,
-                         epilogue == APEXMI_EPI_BIAS_GELU};
+                         act_mode(epilogue)};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch_group(G, &M, epi_kind(epilogue), stream);
@@ -873,7 +883,7 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     double flops = 0, bytes = 0;
     const int kind = epi_kind(epilogue[0]);
     for (int i = 0; i < count; ++i) {
-        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 3 && epi_kind(epilogue[i]) == kind,
+        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 5 && epi_kind(epilogue[i]) == kind,
                        "gemm_bf16_grouped: gate/residual problems cannot be mixed with bias/gelu ones");
         const float* g = gate ? gate[i] : nullptr;
         const void* r = R ? R[i] : nullptr;
@@ -882,7 +892,7 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
             return rc;
         G.p[i] = GemmProblem{(const bf16_t*)A[i], (const bf16_t*)W[i], (const bf16_t*)(bias ? bias[i] : nullptr),
                              (bf16_t*)C[i], g, (const bf16_t*)r, lda[i], ldw[i], ldc[i], lr, M[i], N[i], 0, 0, 0,
-                             epilogue[i] == APEXMI_EPI_BIAS_GELU};
+                             act_mode(epilogue[i])};
         flops += 2.0 * M[i] * N[i] * (double)K;
         bytes += 2.0 * ((double)M[i] * K + (double)N[i] * K + (double)M[i] * N[i]);
     }

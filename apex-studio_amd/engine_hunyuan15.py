@@ -1,0 +1,127 @@
+"""HunyuanVideo-1.5 text-to-video sampler loop (stays in Python) — mirrors the reference engine
+(`apps/api/src/engine/hunyuanvideo15/t2v.py:107-361`): latents [B, 32, F, H/16, W/16], the transformer input is
+`cat([latents, cond_latents (zeros), mask (zeros)], dim=1)` (65 channels, :20-42, :238-241), the timestep goes in as
+`t.expand(B).to(latents.dtype)` on the 0-1000 scale (:243-245), manual CFG with optional std rescale (:248-306),
+FlowMatch-Euler step, progress protocol 0.45 -> [0.50, 0.90] -> decode.  Prompt embeddings (MLLM + ByT5, with their
+masks) are inputs: the text encoders are outside this backend's scope.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .lora import EngineLoraMixin
+from .schedulers import FlowMatchEulerDiscreteScheduler
+
+
+def _emit(cb, p, msg):
+    if cb is not None:
+        try:
+            cb(p, msg)
+        except TypeError:
+            cb(p, msg, None)
+
+
+class HunyuanVideo15T2VEngine(EngineLoraMixin):
+    def __init__(self, transformer, vae=None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
+                 vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 16,
+                 vision_num_semantic_tokens: int = 729, vision_states_dim: int = 1152, decode_fn=None):
+        self.transformer = transformer
+        self.vae = vae
+        self.decode_fn = decode_fn
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(shift=7.0)
+        self.vae_scale_factor_temporal = vae_scale_factor_temporal
+        self.vae_scale_factor_spatial = vae_scale_factor_spatial
+        self.vision_num_semantic_tokens = vision_num_semantic_tokens
+        self.vision_states_dim = vision_states_dim
+        self.num_channels_latents = (transformer.config.in_channels - 1) // 2       # 65 = 32 + 32 + 1
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    @staticmethod
+    def prepare_cond_latents_and_mask(latents, dtype, device):
+        b, c, f, h, w = latents.shape
+        return (torch.zeros(b, c, f, h, w, dtype=dtype, device=device), torch.zeros(b, 1, f, h, w, dtype=dtype, device=device))
+
+    def denoise(self, latents, timesteps, cond, uncond=None, guidance_scale: float = 6.0, guidance_rescale: float = 0.0,
+                image_embeds=None, denoise_progress_callback=None):
+        dt = self.transformer.dtype
+        cond_latents, mask = self.prepare_cond_latents_and_mask(latents, dt, latents.device)
+        n = len(timesteps)
+        for i, t in enumerate(timesteps):
+            x = torch.cat([latents.to(dt), cond_latents, mask], dim=1)
+            timestep = t.expand(x.shape[0]).to(dt)
+            pred = None
+            if uncond is not None:
+                with self.transformer.cache_context("pred_uncond"):
+                    pred_u = self.transformer(hidden_states=x, image_embeds=image_embeds, timestep=timestep,
+                                              return_dict=False, **uncond)[0]
+            with self.transformer.cache_context("pred_cond"):
+                pred_c = self.transformer(hidden_states=x, image_embeds=image_embeds, timestep=timestep,
+                                          return_dict=False, **cond)[0]
+            if uncond is not None:
+                pred = pred_u + guidance_scale * (pred_c - pred_u)
+                if guidance_rescale > 0.0:    # arXiv 2305.08891 §3.4, t2v.py:291-303
+                    dims = list(range(1, pred_c.ndim))
+                    rescaled = pred * (pred_c.std(dim=dims, keepdim=True) / pred.std(dim=dims, keepdim=True))
+                    pred = guidance_rescale * rescaled + (1 - guidance_rescale) * pred
+            else:
+                pred = pred_c
+            latents = self.scheduler.step(pred, t, latents, return_dict=False)[0]
+            _emit(denoise_progress_callback, float(i + 1) / float(max(n, 1)), f"Denoising step {i + 1}/{n}")
+        return latents
+
+    @torch.no_grad()
+    def run(self, prompt_embeds, prompt_embeds_mask, prompt_embeds_2, prompt_embeds_mask_2,
+            negative_prompt_embeds=None, negative_prompt_embeds_mask=None, negative_prompt_embeds_2=None,
+            negative_prompt_embeds_mask_2=None, height: int = 480, width: int = 832, num_frames: int = 121,
+            num_inference_steps: int = 50, guidance_scale: float = 6.0, guidance_rescale: float = 0.0, sigmas=None,
+            seed: Optional[int] = None, generator: Optional[torch.Generator] = None, latents=None,
+            return_latents: bool = False, progress_callback=None, **_ignored):
+        dev, dt = self.device, self.transformer.dtype
+        B = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
+        if guidance_scale > 1.0 and negative_prompt_embeds is None and _ignored.get("negative_prompt") is not None:
+            raise ValueError("CFG requested (guidance_scale > 1.0) but no negative prompt embeds were provided.")
+        _emit(progress_callback, 0.15, "Preparing timesteps")
+        if sigmas is None:
+            sigmas = torch.linspace(1.0, 0.0, num_inference_steps + 1, dtype=torch.float64)[:-1]
+        timesteps = self.scheduler.set_timesteps(num_inference_steps, device=dev, sigmas=sigmas)
+        _emit(progress_callback, 0.20, "Preparing latents")
+        shape = (B, self.num_channels_latents, (num_frames - 1) // self.vae_scale_factor_temporal + 1,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if latents is None:
+            if generator is None:
+                generator = torch.Generator(device=dev)
+                if seed is not None:
+                    generator.manual_seed(seed)
+            latents = torch.randn(shape, generator=generator, device=generator.device, dtype=torch.float32).to(dev, dt)
+        else:
+            latents = latents.to(dev, dt)
+        image_embeds = torch.zeros(B, self.vision_num_semantic_tokens, self.vision_states_dim, dtype=dt, device=dev)
+        cond = dict(encoder_hidden_states=prompt_embeds.to(dev, dt), encoder_attention_mask=prompt_embeds_mask.to(dev),
+                    encoder_hidden_states_2=prompt_embeds_2.to(dev, dt), encoder_attention_mask_2=prompt_embeds_mask_2.to(dev))
+        uncond = None
+        if do_cfg:
+            uncond = dict(encoder_hidden_states=negative_prompt_embeds.to(dev, dt),
+                          encoder_attention_mask=negative_prompt_embeds_mask.to(dev),
+                          encoder_hidden_states_2=negative_prompt_embeds_2.to(dev, dt),
+                          encoder_attention_mask_2=negative_prompt_embeds_mask_2.to(dev))
+        _emit(progress_callback, 0.45, f"Starting denoise (CFG: {'on' if do_cfg else 'off'})")
+
+        def mapped(p, msg):
+            _emit(progress_callback, 0.50 + 0.40 * p, msg)
+
+        latents = self.denoise(latents, timesteps, cond, uncond, guidance_scale, guidance_rescale, image_embeds, mapped)
+        if return_latents:
+            _emit(progress_callback, 1.0, "Returning latents")
+            return latents
+        if self.decode_fn is None:
+            raise RuntimeError("hunyuanvideo15: no decode_fn / VAE attached; pass return_latents=True")
+        _emit(progress_callback, 0.94, "Decoding latents")
+        video = self.decode_fn(latents)
+        _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
+        return video

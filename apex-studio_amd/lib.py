@@ -58,6 +58,7 @@ SIGNATURES = {
                                             vp]),
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
     "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
+    "apexmi_add_rowvec_bf16": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]),
     "apexmi_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_dequant_fp8_scaled": (C.c_int, [vp, C.c_int, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64, vp]),
@@ -72,7 +73,7 @@ NCLASS = 6
 PROF_CLASSES = ("gemm", "attention", "gemv", "ln_modulate", "qkv_prepare", "other")
 
 BF16, F16, F32 = 0, 1, 2
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_F32, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU = 0, 1, 2, 3, 4, 5
 GEMV_PRE_SILU, GEMV_POST_SILU, GEMV_POST_GELU, GEMV_ACCUM = 1, 2, 4, 8
 ROPE_INTERLEAVED, ROPE_COMPLEX, ROPE_NONE = 0, 1, 2
 

@@ -28,7 +28,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-_EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES}
+_EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES,
+        "gelu_erf": _l.EPI_BIAS_GELU_ERF, "silu": _l.EPI_BIAS_SILU}
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -300,6 +301,21 @@ def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = No
     rows = a.numel() // b.numel()
     _l.check(_l.load().apexmi_add_bcast_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, b.numel(),
                                             _stream()), "add_bcast_f32")
+    return out
+
+
+def add_rowvec(x: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r, :] = x[r, :] + v  (bf16 [rows, cols] + bf16 [cols], f32 add)."""
+    _req(x, torch.bfloat16, "add_rowvec.x")
+    _req(v, torch.bfloat16, "add_rowvec.v")
+    assert x.dim() == 2 and x.stride(1) == 1 and v.is_contiguous() and v.numel() == x.shape[1]
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    else:
+        _req(out, torch.bfloat16, "add_rowvec.out")
+        assert out.shape == x.shape and out.stride(1) == 1
+    _l.check(_l.load().apexmi_add_rowvec_bf16(x.data_ptr(), x.stride(0), v.data_ptr(), out.data_ptr(), out.stride(0),
+                                              x.shape[0], x.shape[1], _stream()), "add_rowvec_bf16")
     return out
 
 

@@ -49,7 +49,7 @@ FLUX_DEV = dict(patch_size=1, in_channels=64, num_layers=19, num_single_layers=3
                 guidance_embeds=True, axes_dims_rope=(16, 56, 56))
 S_IMG, S_TXT = 4096, 512
 # algorithmic FLOPs of one step: 2MNK per GEMM + 4 H Sq Sk D per attention
-STEP_TFLOP = {"flux": 74.36, "qwen": 167.4, "wan": 6520.0}
+STEP_TFLOP = {"flux": 74.36, "qwen": 167.4, "wan": 6520.0, "hunyuan": 1394.9}
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["flux", "qwen", "wan", "queue"], default="flux")
+    ap.add_argument("--workload", choices=["flux", "qwen", "wan", "hunyuan", "queue"], default="flux")
     ap.add_argument("--layers", type=str, default="", help="debug: 'D,S' block counts (invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -252,6 +252,45 @@ def build_wan(args, dev, rank, total):
     return step, latents, reset, [enc], (clip if args.clip else None), label
 
 
+def build_hunyuan(args, dev, rank, total):
+    """HunyuanVideo-1.5 480p x 121 frames T2V (not a BASELINE.json config): 54 MM-DiT blocks,
+    d 2048 = 16 x 128, S_img 31*30*52 = 48360, condition tokens 1000 MLLM (300 valid) + 256 ByT5 (64 valid) + 729
+    vision slots (masked for t2v).  273.7 TFLOP GEMM + 1121 TFLOP attention per forward."""
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    model = HunyuanVideo15Transformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=777 + rank)
+    model.pack()
+    g = torch.Generator(device=dev).manual_seed(400 + rank)
+    latents = torch.randn(1, 32, 31, 30, 52, generator=g, device=dev)
+    ge = torch.Generator(device=dev).manual_seed(9)
+    enc = torch.randn(1, 1000, 3584, generator=ge, device=dev).to(torch.bfloat16)
+    enc2 = torch.randn(1, 256, 1472, generator=ge, device=dev).to(torch.bfloat16)
+    m1 = torch.zeros(1, 1000, device=dev)
+    m1[:, :300] = 1
+    m2 = torch.zeros(1, 256, device=dev)
+    m2[:, :64] = 1
+    img = torch.zeros(1, 729, 1152, device=dev, dtype=torch.bfloat16)
+    zeros = torch.zeros(1, 33, 31, 30, 52, device=dev, dtype=torch.bfloat16)
+    sched = FlowMatchEulerDiscreteScheduler(shift=7.0)
+
+    def reset(n):
+        return sched.set_timesteps(n, device=dev, sigmas=torch.linspace(1.0, 0.0, n + 1, dtype=torch.float64)[:-1])
+
+    ts_box = {"ts": reset(total)}
+
+    def step(i, lat):
+        t = ts_box["ts"][i]
+        x = torch.cat([lat.to(torch.bfloat16), zeros], dim=1)
+        v = model(hidden_states=x, timestep=t.expand(1).to(torch.bfloat16), encoder_hidden_states=enc,
+                  encoder_attention_mask=m1, encoder_hidden_states_2=enc2, encoder_attention_mask_2=m2, image_embeds=img,
+                  return_dict=False)[0]
+        return sched.step(v, t, lat, return_dict=False)[0]
+
+    label = ("hunyuanvideo-1.5 text-to-video 480p x 121 frames, one forward (54 MM-DiT blocks, S 48360 latent + 1985 "
+             "condition tokens, B=1, no CFG) + FlowMatch-Euler step")
+    return step, latents, reset, [enc, enc2], None, label
+
+
 def run_queue(args, dev, rank, world):
     """config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips, one clip per GPU at a time (LPT assignment)."""
     from apex_studio_amd import render_queue
@@ -331,7 +370,7 @@ def main():
         return
 
     total = args.warmup + args.steps
-    build = {"flux": build_flux, "qwen": build_qwen, "wan": build_wan}[args.workload]
+    build = {"flux": build_flux, "qwen": build_qwen, "wan": build_wan, "hunyuan": build_hunyuan}[args.workload]
     step, latents, reset, shared_inputs, clip_fn, label = build(args, dev, rank, total)
 
     bcast = None

@@ -34,6 +34,8 @@ typedef void* apexmi_stream_t; /* a hipStream_t; NULL = the null stream */
 #define APEXMI_EPI_BIAS 0          /* C = A W^T + b                                   */
 #define APEXMI_EPI_BIAS_GELU 1     /* C = gelu_tanh(A W^T + b)                        */
 #define APEXMI_EPI_BIAS_GATE_RES 2 /* C = R + gate[n] * (A W^T + b)   (R may alias C) */
+#define APEXMI_EPI_BIAS_GELU_ERF 4 /* C = gelu_erf(A W^T + b): nn.GELU() of the HunyuanVideo-1.5 text/image projections */
+#define APEXMI_EPI_BIAS_SILU 5     /* C = silu(A W^T + b): the "linear-silu" FeedForward of its token refiner        */
 #define APEXMI_EPI_BIAS_F32 3      /* C = A W^T + b stored as float (C is float*, ldc in floats): attention scores */
 
 /* GEMV flags */
@@ -216,6 +218,11 @@ int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const int* axes_
  * (wan model.py:1117-1128, :1849-1856). */
 int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t rows, int64_t n,
                          apexmi_stream_t stream);
+
+/* out[r, :] = x[r, :] + v (bf16, f32 add): token stream + type embedding
+ * (hunyuanvideo15 model.py:1013-1056 `encoder_hidden_states + cond_type_embed(...)`). */
+int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
+                           int cols, apexmi_stream_t stream);
 
 /* f32 <-> bf16 helpers for the small conditioning vectors. */
 int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);

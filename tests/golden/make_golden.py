@@ -15,6 +15,9 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
                         the un-vendored diffusers leaf layers supplied by oracle.layers ("hybrid
                         oracle"): pins block wiring, chunk orders, RoPE layout, concat
                         order and reshapes of oracle.flux — not the diffusers leaf arithmetic.
+  hunyuan15_hybrid.pt   the reference's OWN HunyuanVideo15Transformer3DModel / block / attention processor / token refiner
+                        (transformer/hunyuanvideo15/base/model.py) on a tiny config, t2v and i2v token orders, leaves
+                        from oracle.layers: pins the wiring of oracle.hunyuan15.
   flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
   fp_scaled.pt          reference fp8_activation_dequant / FPScaledLinear._scale_and_cast_weight
                         (quantize/scaled_layer.py:154-167, :496-549) on seeded float8_e4m3fn / e5m2 weights with
@@ -367,6 +370,49 @@ def gen_unipc():
     print("unipc.pt", s.timesteps.tolist(), float(traj[-1].abs().mean()))
 
 
+TINY_HY15 = dict(in_channels=9, out_channels=8, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+                 num_refiner_layers=2, mlp_ratio=4.0, patch_size=1, patch_size_t=1, qk_norm="rms_norm",
+                 text_embed_dim=64, text_embed_2_dim=128, image_embed_dim=64, rope_theta=256.0,
+                 rope_axes_dim=(16, 56, 56))
+
+
+def hy15_inputs():
+    m1 = torch.ones(1, 12)
+    m1[0, 9:] = 0                                   # mllm prompt: 9 valid tokens, right padded
+    m2 = torch.ones(1, 8)
+    m2[0, 5:] = 0                                   # byt5 glyph tokens: 5 valid
+    return dict(hidden_states=seeded((1, 9, 2, 4, 6), 61), timestep=torch.tensor([500.0]),
+                encoder_hidden_states=seeded((1, 12, 64), 62), encoder_attention_mask=m1,
+                encoder_hidden_states_2=seeded((1, 8, 128), 63), encoder_attention_mask_2=m2)
+
+
+def gen_hunyuan15_hybrid():
+    """Reference HunyuanVideo15Transformer3DModel (transformer/hunyuanvideo15/base/model.py) in float64 (InplaceRMSNorm,
+    see gen_wan_hybrid), two cases: t2v (image_embeds all zero -> image tokens masked to the back) and i2v."""
+    import src.attention  # noqa: F401
+    from src.transformer.hunyuanvideo15.base.model import HunyuanVideo15Transformer3DModel as Ref
+    from oracle.hunyuan15 import HunyuanVideo15Transformer3DModel as Orc
+    ref = Ref(**TINY_HY15).eval()
+    orc = Orc(**TINY_HY15).eval()
+    sd = synthetic_state_dict(orc, 15)
+    assert sorted(sd.keys()) == sorted(ref.state_dict().keys()), set(sd) ^ set(ref.state_dict())
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.double()
+    inp = hy15_inputs()
+    outs = {}
+    for name, img in (("t2v", torch.zeros(1, 3, 64)), ("i2v", seeded((1, 3, 64), 64))):
+        with torch.no_grad():
+            outs[name] = ref(hidden_states=inp["hidden_states"].double(), timestep=inp["timestep"].double(),
+                             encoder_hidden_states=inp["encoder_hidden_states"].double(),
+                             encoder_attention_mask=inp["encoder_attention_mask"],
+                             encoder_hidden_states_2=inp["encoder_hidden_states_2"].double(),
+                             encoder_attention_mask_2=inp["encoder_attention_mask_2"],
+                             image_embeds=img.double(), return_dict=False)[0].float()
+        print("hunyuan15_hybrid", name, tuple(outs[name].shape), float(outs[name].abs().mean()))
+    torch.save(dict(config=TINY_HY15, seed=15, inputs=inp, image_embeds_i2v=seeded((1, 3, 64), 64), out=outs,
+                    keys=sorted(sd.keys())), os.path.join(OUT, "hunyuan15_hybrid.pt"))
+
+
 def gen_lora():
     """Reference LoraConverter on seeded state dicts.  Stubs: the two rename tables imported from diffusers (only
     used for the legacy diffusers formats, not exercised) and src.quantize.ggml_ops (imported by converters/utils,
@@ -445,6 +491,7 @@ def main():
     gen_flux_hybrid()
     gen_wan_hybrid()
     gen_qwen_hybrid()
+    gen_hunyuan15_hybrid()
     gen_vae_wan()
     gen_unipc()
     gen_lora()

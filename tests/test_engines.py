@@ -94,3 +94,44 @@ def test_flux_engine_progress_and_preview_protocol():
     assert img.ndim == 0 and len(previews) == 2 and prog[-1] == 1.0 and prog == sorted(prog)
     x = torch.randn(1, 16, 8, 8)
     assert torch.equal(unpack_latents(pack_latents(x), 64, 64, 8), x)
+
+
+class _FakeHunyuan:
+    def __init__(self):
+        self.config = SimpleNamespace(in_channels=65)
+        self.device, self.dtype = torch.device("cpu"), torch.float32
+        self.calls = []
+
+    @contextlib.contextmanager
+    def cache_context(self, name):
+        self.calls.append(name)
+        yield
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, encoder_hidden_states_2,
+                 encoder_attention_mask_2, image_embeds, return_dict=False):
+        assert hidden_states.shape[1] == 65 and float(hidden_states[:, 32:].abs().sum()) == 0.0   # zero cond + mask
+        assert image_embeds.shape[1:] == (729, 1152) and float(image_embeds.abs().sum()) == 0.0      # t2v marker
+        assert 0.0 < float(timestep[0]) <= 1000.0
+        return (hidden_states[:, :32] * 0.1 + encoder_hidden_states.mean(),)
+
+
+def test_hunyuan15_t2v_loop_cfg_rescale_and_progress():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15T2VEngine
+    m = _FakeHunyuan()
+    eng = HunyuanVideo15T2VEngine(m)
+    seen = []
+    kw = dict(prompt_embeds=torch.ones(1, 6, 8), prompt_embeds_mask=torch.ones(1, 6), prompt_embeds_2=torch.ones(1, 4, 8),
+              prompt_embeds_mask_2=torch.ones(1, 4), height=64, width=96, num_frames=9, num_inference_steps=4,
+              generator=torch.Generator().manual_seed(0), return_latents=True)
+    out = eng.run(progress_callback=lambda p, m_: seen.append(p), guidance_scale=1.0, **kw)
+    assert out.shape == (1, 32, 3, 4, 6) and m.calls == ["pred_cond"] * 4
+    assert seen == sorted(seen) and seen[0] == 0.15 and seen[-1] == 1.0
+    m.calls.clear()
+    neg = dict(negative_prompt_embeds=torch.zeros(1, 6, 8), negative_prompt_embeds_mask=torch.ones(1, 6),
+               negative_prompt_embeds_2=torch.zeros(1, 4, 8), negative_prompt_embeds_mask_2=torch.ones(1, 4))
+    a = eng.run(guidance_scale=6.0, guidance_rescale=0.0, **kw, **neg)
+    assert m.calls == ["pred_uncond", "pred_cond"] * 4
+    kw["generator"] = torch.Generator().manual_seed(0)
+    b = eng.run(guidance_scale=6.0, guidance_rescale=0.7, **kw, **neg)
+    assert not torch.equal(a, b) and torch.isfinite(b).all()

@@ -1,0 +1,106 @@
+"""HunyuanVideo-1.5 transformer ("hunyuanvideo15.mi355") against the CPU oracle on the same seeded weights/inputs
+and against the reference-wiring golden.  Same two bars as the Flux/Wan/Qwen model tests:
+  * vs the oracle with the bf16 STORAGE policy: rel L2 < 1e-2;
+  * vs the fp32 oracle: no further from fp32 truth than 2x the oracle's own bf16 emulation (+2e-3)."""
+import os
+
+import pytest
+import torch
+
+from oracle import hunyuan15 as OH
+from oracle import layers as OL
+from tests.golden.seeded import seeded, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONFIGS = {
+    "tiny": (dict(in_channels=9, out_channels=8, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+                  num_refiner_layers=2, text_embed_dim=64, text_embed_2_dim=128, image_embed_dim=64),
+             (2, 4, 6), 12, 9, 8, 5),
+    # patch 2 spatially, ragged sequence lengths, 3 refiner-visible heads
+    "mid": (dict(in_channels=16, out_channels=8, num_attention_heads=3, attention_head_dim=128, num_layers=3,
+                 num_refiner_layers=2, patch_size=2, text_embed_dim=128, text_embed_2_dim=64, image_embed_dim=128),
+            (3, 8, 12), 70, 41, 20, 20),
+}
+
+
+def _inputs(cfg, fhw, t1, v1, t2, v2, i2v, seed=61):
+    m1 = torch.ones(1, t1)
+    m1[0, v1:] = 0
+    m2 = torch.ones(1, t2)
+    m2[0, v2:] = 0
+    img = seeded((1, 3, cfg["image_embed_dim"]), seed + 3) if i2v else torch.zeros(1, 3, cfg["image_embed_dim"])
+    return dict(hidden_states=seeded((1, cfg["in_channels"]) + fhw, seed), timestep=torch.tensor([500.0]),
+                encoder_hidden_states=seeded((1, t1, cfg["text_embed_dim"]), seed + 1), encoder_attention_mask=m1,
+                encoder_hidden_states_2=seeded((1, t2, cfg["text_embed_2_dim"]), seed + 2),
+                encoder_attention_mask_2=m2, image_embeds=img)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def _run_hip(cfg, sd, inp):
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    g = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k != "timestep" and "mask" not in k
+             else v.to(DEV)) for k, v in inp.items()}
+    out = m(return_dict=False, **g)[0]
+    torch.cuda.synchronize()
+    return m, out.float().cpu()
+
+
+def _oracle(orc, inp, policy=OL.FP32):
+    r = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 and k != "timestep" and "mask" not in k else v)
+         for k, v in inp.items()}
+    return orc(r["hidden_states"], r["timestep"], r["encoder_hidden_states"], r["encoder_attention_mask"],
+               r["encoder_hidden_states_2"], r["encoder_attention_mask_2"], r["image_embeds"], policy=policy)
+
+
+@pytest.mark.parametrize("i2v", [False, True])
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_hunyuan15_forward_matches_oracle(name, i2v):
+    cfg, fhw, t1, v1, t2, v2 = CONFIGS[name]
+    orc = OH.HunyuanVideo15Transformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 15)
+    orc.load_state_dict(sd, strict=True)
+    inp = _inputs(cfg, fhw, t1, v1, t2, v2, i2v)
+    ref32, ref16 = _oracle(orc, inp), _oracle(orc, inp, OL.BF16_STORAGE)
+    _, out = _run_hip(cfg, sd, inp)
+    assert out.shape == ref32.shape and torch.isfinite(out).all()
+    e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[hunyuan15 {name} {'i2v' if i2v else 't2v'}] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; "
+          f"emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
+
+
+def test_hunyuan15_matches_reference_wiring_golden(golden_dir):
+    g = torch.load(os.path.join(golden_dir, "hunyuan15_hybrid.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = OH.HunyuanVideo15Transformer3DModel(**cfg)
+    sd = synthetic_state_dict(orc, g["seed"])
+    for name, img in (("t2v", torch.zeros_like(g["image_embeds_i2v"])), ("i2v", g["image_embeds_i2v"])):
+        inp = dict(g["inputs"], image_embeds=img)
+        _, out = _run_hip({k: v for k, v in cfg.items() if k not in ("qk_norm", "mlp_ratio", "rope_theta", "rope_axes_dim",
+                                                                       "patch_size", "patch_size_t")}, sd, inp)
+        rel = _rel(out, g["out"][name])
+        print(f"hunyuan15 hip bf16 vs reference-wiring f64 golden ({name}): rel {rel:.3e}")
+        assert rel < 3e-2, rel
+
+
+def test_hunyuan15_all_tokens_valid_and_determinism():
+    """No padding at all (the refiner's fast path, model.py:375-379) and bit-identical repeats."""
+    cfg, fhw, t1, _, t2, _ = CONFIGS["tiny"]
+    orc = OH.HunyuanVideo15Transformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 15)
+    orc.load_state_dict(sd, strict=True)
+    inp = _inputs(cfg, fhw, t1, t1, t2, t2, False)
+    m, out = _run_hip(cfg, sd, inp)
+    assert _rel(out, _oracle(orc, inp, OL.BF16_STORAGE)) < 1e-2
+    g = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k != "timestep" and "mask" not in k
+             else v.to(DEV)) for k, v in inp.items()}
+    again = m(return_dict=False, **g)[0].float().cpu()
+    assert torch.equal(out, again)

@@ -135,3 +135,21 @@ def test_vae_full_sequence_restatement_matches_streaming_reference(golden_dir):
     assert torch.allclose(tiled[0, :, :, ::8, ::8], g["tiled_f32_sample"], atol=2e-5, rtol=1e-4)
     assert torch.allclose(tiled, g["tiled"].float(), atol=8e-3, rtol=8e-3)
     assert float((tiled - untiled).abs().max()) > 1e-3
+
+
+def test_hunyuan15_wiring_matches_reference_blocks(golden_dir):
+    """oracle.hunyuan15 against the reference's own HunyuanVideo-1.5 classes (hybrid oracle, float64 run): token
+    refiner with a key-padding mask, t2v and i2v token orders, RoPE on latent tokens only, un-patchify."""
+    from oracle.hunyuan15 import HunyuanVideo15Transformer3DModel
+    g = torch.load(os.path.join(golden_dir, "hunyuan15_hybrid.pt"), weights_only=False)
+    m = HunyuanVideo15Transformer3DModel(**g["config"]).eval()
+    sd = synthetic_state_dict(m, g["seed"])
+    assert sorted(sd.keys()) == g["keys"]
+    m.load_state_dict(sd)
+    i = g["inputs"]
+    for name, img in (("t2v", torch.zeros_like(g["image_embeds_i2v"])), ("i2v", g["image_embeds_i2v"])):
+        out = m(i["hidden_states"], i["timestep"], i["encoder_hidden_states"], i["encoder_attention_mask"],
+                i["encoder_hidden_states_2"], i["encoder_attention_mask_2"], img)
+        ref = g["out"][name]
+        rel = float((out - ref).norm() / ref.norm())
+        assert rel < 1e-5, (name, rel)
