@@ -233,6 +233,234 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
     }
 }
 
+// ---- 4-cluster ping-pong variant (8 waves) ---------------------------------------------------------------
+template <int NW, int PRIO>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int s = xcd_remap(blockIdx.x, total);
+    const int hb = s / nqb, qb = s % nqb;
+    const int b = hb / H, h = hb % H;
+
+    const bf16_t* Qp = Q + (int64_t)hb * Sq * HD;
+    const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
+    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
+
+    constexpr int QB = NW * 32;
+    constexpr int LD = (16 + NW - 1) / NW;  // 1 KiB LDS-DMA pieces per wave per tile image (16 pieces each for K and V^T)
+    const int qrow = qb * QB + wave * 32 + l31;
+    const int qrow_c = min(qrow, Sq - 1);
+
+    // Q fragments: B operand of S^T, lane supplies Q[qrow][16 ks + 8 hi .. +7]
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        qf[ks] = *(const bf16x8*)(Qp + (int64_t)qrow_c * HD + ks * 16 + hi * 8);
+
+    // staging sources.  Piece p = i NW + wave (p < 16).  K image: [64 rows][16 chunks], chunk ^= row & 15,
+    // row i <- key perm(i).  V^T image: [128 rows (d)][8 chunks], chunk ^= (row >> 1) & 7.
+    int k_key[LD], k_c[LD];
+    const char* v_src[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        const int p = (i * NW + wave) * 64 + lane;
+        {
+            const int row = (p >> 4) & 63, pc = p & 15;
+            k_c[i] = (pc ^ (row & 15)) * 8;
+            k_key[i] = (row & 32) + perm32(row & 31);
+        }
+        {
+            const int row = (p >> 3) & 127, pc = p & 7;
+            const int c = pc ^ ((row >> 1) & 7);
+            v_src[i] = (const char*)(Vp + (int64_t)row * Skp + c * 8);
+        }
+    }
+
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * ATT_STAGE + wave * 1024;
+        const int kv0 = t * KV;
+#pragma unroll
+        for (int i = 0; i < LD; ++i)
+            if (i * NW + wave < 16) {  // wave-uniform
+                const int key = min(kv0 + k_key[i], Sk - 1);
+                glds16(Kp + (int64_t)key * HD + k_c[i], base + i * (NW * 1024));
+            }
+#pragma unroll
+        for (int i = 0; i < LD; ++i)
+            if (i * NW + wave < 16) glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * (NW * 1024));
+    };
+
+    // LDS read offsets
+    int k_off[2], k_sw[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int row = kt * 32 + l31;
+        k_off[kt] = row * 256;
+        k_sw[kt] = row & 15;
+    }
+    int v_off[4], v_sw[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int row = dt * 32 + l31;
+        v_off[dt] = row * 128;
+        v_sw[dt] = (row >> 1) & 7;
+    }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+    float m_run = -1.0e30f;  // running max, already in the scaled (log2) domain
+    float l_run = 0.0f;      // this lane's partial row sum (its 32 keys of every tile)
+
+    // ---- 4-cluster ping-pong (8 waves; wave w and w + 4 share a SIMD) -------------------------------------------
+    // A tile is four clusters per wave, each closed by an s_barrier:
+    //   C1 load K : 16 ds_read_b128 of the tile's K fragments into a 64-VGPR block; the LDS-DMA of tile t+1
+    //   C2 K Q^T  : 16 MFMAs out of registers
+    //   C3 load V : 16 ds_read_b128 of the V^T fragments into the SAME block, the softmax VALU beside them
+    //   C4 P V    : 16 MFMAs out of registers
+    // Waves 4..7 run one cluster behind waves 0..3, so on every SIMD one wave is in a matrix cluster while its partner
+    // is in a load cluster: the fragment reads (-15 % when interleaved with the MFMAs they feed, profiles/
+    // r01_attention_notes.md) and the softmax run in the partner's matrix time.
+    const int nt = (Sk + KV - 1) / KV;
+    const bool late = wave >= NW / 2;
+    bf16x8 kv[16];
+    f32x16 sacc[2];
+    bf16x8 pf[4];
+#define C4_BAR()                               \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#define C4_LGKM_BAR()                                            \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        C4_BAR();                                                \
+    } while (0)
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C4_BAR();                  // tile 0 visible
+    if (late) C4_BAR();        // second half runs one cluster behind
+    for (int t = 0; t < nt; ++t) {
+        const char* Ks = smem + (t & 1) * ATT_STAGE;
+        const char* Vs = Ks + K_TILE_BYTES;
+        // ---- C1: K fragments -> registers; LDS-DMA of the next tile (its stage was last read two clusters ago) ----
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                kv[ks * 2 + kt] = *(const bf16x8*)(Ks + k_off[kt] + (((ks * 2 + hi) ^ k_sw[kt]) << 4));
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        C4_LGKM_BAR();
+        // ---- C2: S^T = K Q^T ----
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.0f;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[ks * 2 + kt], qf[ks], sacc[kt], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        C4_BAR();
+        // ---- C3: V^T fragments -> the same registers, softmax beside the reads ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                kv[kk * 4 + dt] = *(const bf16x8*)(Vs + v_off[dt] + (((kk * 2 + hi) ^ v_sw[dt]) << 4));
+        if (t == nt - 1 && (Sk & (KV - 1)) != 0) {   // mask keys past Sk (wave-uniform branch)
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int a = r >> 2, bb = r & 3;
+                    const int key = kv0 + kt * 32 + 16 * (a >> 1) + 8 * hi + 4 * (a & 1) + bb;
+                    if (key >= Sk) sacc[kt][r] = -1.0e30f;
+                }
+        }
+        {
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+            mx = max_xor32(mx) * scale_log2e;
+            if (__any(mx > m_run + DEFER)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = fast_exp2(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_run));
+                    sacc[kt][r] = pv;
+                    psum += pv;
+                }
+            l_run += psum;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[kk][j] = (__bf16)sacc[kk >> 1][8 * (kk & 1) + j];
+        }
+        // this wave's LDS-DMA pieces of tile t+1 must have landed before the barrier that opens the first cluster
+        // reading them: the early half's C1(t+1) follows ITS C4(t) and the late half's C3(t) in the same slot
+        if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C4_LGKM_BAR();
+        // ---- C4: O^T += V^T P^T ----
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[kk * 4 + dt], pf[kk], oacc[dt], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C4_BAR();
+    }
+    if (!late) C4_BAR();       // balance the barrier count of the two halves
+#undef C4_BAR
+#undef C4_LGKM_BAR
+
+    // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
+    const float l_tot = sum_xor32(l_run);
+    const float inv = 1.0f / l_tot;
+    if (qrow < Sq) {
+        bf16_t* op = O + (int64_t)b * o_sb + (int64_t)qrow * o_ss + (int64_t)h * o_sh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+                *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
+            }
+    }
+}
+
+
 // ---- the same kernel on v_mfma_f32_16x16x32_bf16 -----------------------------------------------
 // The denoise step runs at the chip's power limit; at equal matrix-pipe occupancy the 16x16x32 form
 // sustains ~13 % higher clocks than 32x32x16 (tools/ubench/mfma_power.hip), so it is the faster one.
@@ -616,6 +844,8 @@ int launch_generic(const void* q, const void* k, const void* v, void* out, int B
 }
 
 int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
+int g_attn_c4 = 1;  // apexmi_tune_set("attn.c4", 0|1|2): 8-wave launches use the 4-cluster ping-pong kernel (shipped: -3.4 % per
+                    // attention launch in the Flux and HunyuanVideo steps); 0 = plain loop, 2 = with s_setprio in the matrix clusters
 int g_attn_mfma = 32;  // 32: 32x32x16 kernel (shipped: 3 % faster in the Flux step), 16: 16x16x32 kernel (apexmi_tune_set "attn.mfma")
 
 // contiguity test for the MFMA path's packed [B,H,S,128] operands
@@ -671,13 +901,13 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
         case 5: kern = m16 ? attn_fwd_d128_mi16_kernel<5> : attn_fwd_d128_kernel<5>; break;
         case 6: kern = m16 ? attn_fwd_d128_mi16_kernel<6> : attn_fwd_d128_kernel<6>; break;
         case 7: kern = m16 ? attn_fwd_d128_mi16_kernel<7> : attn_fwd_d128_kernel<7>; break;
-        case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_kernel<8>; break;
+        case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : g_attn_c4 == 1 ? attn_fwd_d128_c4_kernel<8, 0> : g_attn_c4 == 2 ? attn_fwd_d128_c4_kernel<8, 1> : attn_fwd_d128_kernel<8>; break;
         default: apexmi_set_error("attn_fwd_prepared: attn.waves=%d not in [4,8]", nw); return 1;
     }
-    static bool attr_done[2][9] = {};
-    if (!attr_done[m16][nw]) {
+    static bool attr_done[3][2][9] = {};
+    if (!attr_done[g_attn_c4 % 3][m16][nw]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        attr_done[m16][nw] = true;
+        attr_done[g_attn_c4 % 3][m16][nw] = true;
     }
     hipLaunchKernelGGL(kern, dim3(total), dim3(nw * 64), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,
@@ -687,6 +917,7 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
 
 void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
 void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
+void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && Sk % 8 == 0 && (int64_t)Sq * Sk >= 256 * 256)

@@ -903,10 +903,15 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
 void apexmi_set_attn_waves(int v);
 void apexmi_set_attn_mfma(int v);
 void apexmi_set_ln_wave(int v);
+void apexmi_set_attn_c4(int v);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
     if (key && !strcmp(key, "attn.waves")) {
         apexmi_set_attn_waves(value);
+        return 0;
+    }
+    if (key && !strcmp(key, "attn.c4")) {
+        apexmi_set_attn_c4(value);
         return 0;
     }
     if (key && !strcmp(key, "ln.wave")) {

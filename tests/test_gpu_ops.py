@@ -481,3 +481,26 @@ def test_gemm_f32_epilogue():
         ref = a.float() @ w.float().t()
         assert torch.isfinite(out).all()
         assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), (M, N, K)
+
+
+@pytest.mark.parametrize("c4", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(1, 2, 700, 333), (1, 4, 1536, 1536), (2, 3, 260, 1000), (1, 2, 256, 64)])
+def test_attention_four_cluster_variant(shape, c4):
+    """`attn.c4`: 4-cluster ping-pong kernel (K / V fragments burst-read into registers, halves one cluster apart).
+    Same bar as the shipped kernel; bit-identical repeats screen the staggered LDS-DMA / barrier choreography."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    B, H, Sq, Sk = shape
+    q = seeded((B, H, Sq, 128), 385, torch.bfloat16)
+    k = seeded((B, H, Sk, 128), 386, torch.bfloat16)
+    v = seeded((B, H, Sk, 128), 387, torch.bfloat16)
+    lib.tune_set("attn.waves", 8)
+    lib.tune_set("attn.c4", c4)
+    try:
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+        out2 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    finally:
+        lib.tune_set("attn.waves", 0)
+        lib.tune_set("attn.c4", 1)
+    _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention c4 {shape}", ulp=3.0)
+    assert torch.equal(out.cpu(), out2.cpu())
