@@ -141,3 +141,33 @@ def test_denoise_loop_matches_oracle_loop():
     rel = _rel(lat.float().cpu(), lat_ref)
     print(f"4-step latent rel error vs oracle loop: {rel:.3e}")
     assert rel < 1e-2, rel
+
+
+def test_flux_full_width_one_plus_one_blocks_match_oracle():
+    """BASELINE.json configs[1] geometry (d 3072 = 24 x 128, mlp 12288, S_img 4096 + S_txt 512, FLUX.1-dev axes) with the
+    depth cut to 1 double + 1 single block so the fp32 CPU oracle finishes in about a minute on the box's host cores: the
+    full-size tilings (256x256 GEMM tiles, 8-wave attention workgroups, grouped launches, XCD remap, side-stream
+    modulation GEMV) are compared with the oracle instead of only the tiny configs.  Same two bars as above."""
+    cfg = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128,
+               num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
+               axes_dims_rope=(16, 56, 56))
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    inp = _inputs(cfg, (64, 64), 512)
+    rin = {k: (v.to(torch.bfloat16).float() if k in ("hidden_states", "encoder_hidden_states", "pooled_projections")
+               else v) for k, v in inp.items()}
+    args = (rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"],
+            rin["img_ids"], rin["txt_ids"], rin["guidance"])
+    ref32 = orc(*args)
+    ref16 = orc(*args, policy=OL.BF16_STORAGE)
+    m, out = _run_hip(cfg, sd, inp)
+    assert out.shape == ref32.shape == (1, 4096, 64) and torch.isfinite(out).all()
+    e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[flux full width 1+1] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
+    g = {k: (v.to(DEV).to(torch.bfloat16) if k in ("hidden_states", "encoder_hidden_states", "pooled_projections")
+             else v.to(DEV)) for k, v in inp.items()}
+    assert torch.equal(m(return_dict=False, **g)[0].float().cpu(), out), "full-size step must be deterministic"

@@ -72,3 +72,26 @@ def test_qwen_matches_reference_wiring_golden(golden_dir):
     rel = _rel(out, g["out"])
     print(f"qwen hip bf16 vs reference-wiring fp32 golden: rel {rel:.3e}")
     assert rel < 3e-2, rel
+
+
+def test_qwen_full_width_one_block_matches_oracle():
+    """QwenImage-Edit-2509 geometry (d 3072 = 24 x 128, text 3584, target 64x64 + one 64x64 condition image, 256 text
+    tokens: S 8448) with ONE block against the fp32 CPU oracle (about a minute on the host cores)."""
+    cfg = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=1, attention_head_dim=128,
+               num_attention_heads=24, joint_attention_dim=3584, axes_dims_rope=(16, 56, 56))
+    torch.set_num_threads(os.cpu_count() or 1)
+    shapes = [(1, 64, 64), (1, 64, 64)]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    x = seeded((1, 8192, 64), 51).to(torch.bfloat16).float()
+    txt = seeded((1, 256, 3584), 52).to(torch.bfloat16).float()
+    t = torch.tensor([0.5])
+    ref32 = orc(x, txt, t, shapes)
+    ref16 = orc(x, txt, t, shapes, policy=OL.BF16_STORAGE)
+    _, out = _hip(cfg, sd, x, txt, t, shapes)
+    assert out.shape == ref32.shape and torch.isfinite(out).all()
+    e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[qwen full width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3

@@ -71,3 +71,26 @@ def test_wan_matches_reference_wiring_golden(golden_dir):
     rel = _rel(out, g["out"])
     print(f"wan hip bf16 vs reference-wiring f64 golden: rel {rel:.3e}")
     assert rel < 3e-2, rel
+
+
+def test_wan_full_width_one_block_matches_oracle():
+    """Wan-2.2-A14B geometry (d 5120 = 40 x 128, ffn 13824, text 4096 x 512 tokens, patch (1,2,2)) with ONE block and a
+    latent of 16 x 5 x 60 x 104 (S 7800: edge tiles in every GEMM, 31 attention query blocks) so the fp32 CPU oracle
+    finishes in about a minute; the full-size tilings are what is being compared.  Same bars as the small configs."""
+    cfg = dict(patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16,
+               text_dim=4096, freq_dim=256, ffn_dim=13824, num_layers=1, cross_attn_norm=True, eps=1e-6)
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = OW.WanTransformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 9)
+    orc.load_state_dict(sd, strict=True)
+    x = seeded((1, 16, 5, 60, 104), 41).to(torch.bfloat16).float()
+    txt = seeded((1, 512, 4096), 42).to(torch.bfloat16).float()
+    t = torch.tensor([500.0])
+    ref32 = orc(x, t, txt)
+    ref16 = orc(x, t, txt, policy=OL.BF16_STORAGE)
+    _, out = _hip(cfg, sd, x, t, txt)
+    assert out.shape == ref32.shape and torch.isfinite(out).all()
+    e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[wan full width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 1e-2, e_like
+    assert e_true < 2 * e_emul + 2e-3
