@@ -3,7 +3,9 @@
 // default "sdpa" :338-377) at the call sites flux/base/attention.py:89-94,
 // wan/base/attention.py:397-399 and qwenimage/base/model.py:555-562.
 //
-// MFMA kernel (bf16, D = 128), per workgroup 4 waves x 32 query rows, KV tile = 64 keys:
+// MFMA kernels (bf16, D = 128), per workgroup NW = 4..8 waves x 32 query rows, KV tile = 64 keys (169-238 VGPRs: two
+// waves per SIMD, ONE workgroup per CU).  Launches that fill the chip use the 8-wave 4-cluster ping-pong kernel
+// (attn_fwd_d128_c4_kernel, below); the plain loop (attn_fwd_d128_kernel) serves small launches and A/B:
 //   S^T = K Q^T      (MFMA "A" = K rows from LDS, "B" = Q rows held in registers)
 //   O^T = V^T P^T    (MFMA "A" = V^T rows from LDS, "B" = P, straight out of the S^T accumulators)
 // Both products are "swapped" so lane l owns query row (l & 31): the row max / row sum of the

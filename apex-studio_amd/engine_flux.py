@@ -4,8 +4,9 @@ calculate_shift :57-68, latent ids :197-215, base_denoise :504-619) and engine/f
 (`run`): same argument names, same progress-callback protocol `(progress: float, message: str)`,
 same `render_on_step_callback(frame)` preview hook, `return_latents=True` to stop before decode.
 
-Out of this round's scope: text encoders (prompt embeddings are inputs) and
-the 2D VAE decode (pass `decode_fn`).  The sampler loop stays in Python by design.
+Text encoders are outside this backend (prompt embeddings are inputs).  The 2-D VAE decode is
+`vae_flux.AutoencoderKL` on the same HIP ops; the engine takes it as `decode_fn` (latents -> image) so the preview
+hook and the final decode share one callable.  The sampler loop stays in Python by design.
 """
 from __future__ import annotations
 

@@ -16,6 +16,7 @@ Other single-GPU BASELINE configs (not the default bench line):
   --workload qwen    QwenImage-Edit-2509 1024^2 + one 1024^2 condition image (config 3), steps/s
   --workload wan     Wan-2.2 A14B 720p x 81 frames, one expert forward + UniPC step (config 4), steps/s;
                      with --clip also 30 steps with the expert switch + tiled 3-D VAE decode (minutes)
+  --workload hunyuan HunyuanVideo-1.5 480p x 121 frames, one forward + FlowMatch-Euler step (not a BASELINE config)
   --workload queue   config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips sharded one clip per GPU
                      (--queue-wan-steps shortens the Wan clips; clips/hour, makespan)
 
