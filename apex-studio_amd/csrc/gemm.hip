@@ -55,7 +55,7 @@ struct GemmProblem {
 };
 struct GemmGroup {
     GemmProblem p[MAX_GROUPS];
-    int count, K, total;
+    int count, K, total, group_m;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -294,9 +294,10 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     const GemmProblem& P = G.p[gi];
     s -= P.tile0;
     const int nn = P.nn, N = P.N, M = P.M;
-    const int width = GROUP_M * nn;
-    const int first_m = (s / width) * GROUP_M;
-    const int gsz = min(P.nm - first_m, GROUP_M);
+    const int GM = G.group_m;
+    const int width = GM * nn;
+    const int first_m = (s / width) * GM;
+    const int gsz = min(P.nm - first_m, GM);
     const int pm = first_m + (s % width) % gsz;
     const int pn = (s % width) / gsz;
     const int m0 = pm * BM, n0 = pn * BN;
@@ -770,6 +771,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
 }
 
+int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
 
@@ -790,6 +792,7 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
         t += G.p[i].nm * G.p[i].nn;
     }
     G.total = t;
+    G.group_m = g_group_m;
     hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }
@@ -920,6 +923,10 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
     }
     if (key && !strcmp(key, "attn.mfma")) {
         apexmi_set_attn_mfma(value);
+        return 0;
+    }
+    if (key && !strcmp(key, "gemm.group_m")) {
+        g_group_m = value > 0 ? value : GROUP_M;
         return 0;
     }
     if (key && !strcmp(key, "gemm.large")) {

@@ -58,11 +58,17 @@ def blaslt():
 
 
 res = {}
-for name, cfg in (("cfg7", 7), ("cfg3", 3), ("cfg6", 6)):
+for name, cfg in (("cfg7", 7), ("cfg3", 3), ("cfg6", 6)) if not os.environ.get("SEQ_TUNE") else ():
     lib.tune_set("gemm.large", cfg)
     ms = run(ours)
     res[name] = {"ms_per_step": round(ms, 2), "tflops": round(flops / ms / 1e9, 1)}
 lib.tune_set("gemm.large", 7)
+for kv in filter(None, os.environ.get("SEQ_TUNE", "").split(";")):     # e.g. SEQ_TUNE="gemm.group_m=4;gemm.group_m=16"
+    key, val = kv.split("=")
+    lib.tune_set(key, int(val))
+    ms = run(ours)
+    res[kv] = {"ms_per_step": round(ms, 2), "tflops": round(flops / ms / 1e9, 1)}
+lib.tune_set("gemm.group_m", 0)
 ms = run(blaslt)
 res["torch_matmul"] = {"ms_per_step": round(ms, 2), "tflops": round(flops / ms / 1e9, 1)}
 ms = run(ours)
