@@ -61,10 +61,12 @@ def register_models(transformers_registry, vae_registry=None):
     transformers_registry("wan.mi355", overwrite=True, available=ok)(WanTransformer3DModel)
     transformers_registry("qwenimage.mi355", overwrite=True, available=ok)(QwenImageTransformer2DModel)
     transformers_registry("hunyuanvideo15.mi355", overwrite=True, available=ok)(HunyuanVideo15Transformer3DModel)
-    if vae_registry is not None:   # reference vae/__init__.py:9-73 (keys "auto" | "wan" | "qwenimage")
+    if vae_registry is not None:   # reference vae/__init__.py:9-73 (keys "auto" | "wan" | "qwenimage" | "hunyuanvideo15")
         from .vae_flux import AutoencoderKL
+        from .vae_hunyuan15 import AutoencoderKLHunyuanVideo15
         from .vae_wan import AutoencoderKLWan
         vae_registry("auto_mi355", overwrite=True, available=ok)(AutoencoderKL)
         vae_registry("wan_mi355", overwrite=True, available=ok)(AutoencoderKLWan)
         vae_registry("qwenimage_mi355", overwrite=True, available=ok)(AutoencoderKLWan)
+        vae_registry("hunyuanvideo15_mi355", overwrite=True, available=ok)(AutoencoderKLHunyuanVideo15)
     return transformers_registry

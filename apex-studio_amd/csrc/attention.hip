@@ -681,13 +681,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
 // C = 384 / 512 over 1k-16k tokens).  scores (f32) = q k^T by the GEMM kernel's f32 epilogue, one row-softmax
 // pass (f32 in, bf16 probabilities out, zero-padded to a multiple of 64 keys), out = P V by the GEMM kernel with
 // V^T as its weight operand.  Same rounding points as the flash kernels: f32 scores, bf16 P, f32 accumulation.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int cols,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int cols_all,
                                                            float scale_log2e, bf16_t* __restrict__ out, int64_t ldo,
-                                                           int cols_pad) {
+                                                           int cols_pad, int causal_block) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xr = x + (int64_t)blockIdx.x * ldx;
     bf16_t* orow = out + (int64_t)blockIdx.x * ldo;
+    // frame-causal mask (HunyuanVideo15AttnBlock.prepare_causal_attention_mask): row r sees the keys of frames <= its own,
+    // i.e. columns < (r / block + 1) * block; masked probabilities are exact zeros, as exp(-inf) is
+    const int cols = causal_block > 0 ? min(cols_all, ((int)blockIdx.x / causal_block + 1) * causal_block) : cols_all;
     constexpr int MAXCH = 16;  // register-resident up to 16 x 1024 columns; longer rows stream from L2
     f32x4 v[MAXCH];
     const bool fits = cols <= MAXCH * 1024;
@@ -697,11 +700,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         for (int i = 0; i < MAXCH; ++i) {
             const int c = (i * 256 + tid) * 4;
             v[i] = c < cols ? *(const f32x4*)(xr + c) : f32x4{-1.0e30f, -1.0e30f, -1.0e30f, -1.0e30f};
+#pragma unroll
+            for (int j = 1; j < 4; ++j) v[i][j] = c + j < cols ? v[i][j] : -1.0e30f;   // cols need not be a multiple of 4
             mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
         }
     } else {
         for (int c = tid * 4; c < cols; c += 1024) {
-            const f32x4 t = *(const f32x4*)(xr + c);
+            f32x4 t = *(const f32x4*)(xr + c);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) t[j] = c + j < cols ? t[j] : -1.0e30f;
             mx = fmaxf(mx, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
         }
     }
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         for (int c = tid * 4; c < cols; c += 1024) {
             const f32x4 t = *(const f32x4*)(xr + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum += fast_exp2(fmaf(t[j], scale_log2e, -mx));
+            for (int j = 0; j < 4; ++j) sum += c + j < cols ? fast_exp2(fmaf(t[j], scale_log2e, -mx)) : 0.0f;
         }
     }
     sum = wave_sum(sum);
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                 const f32x4 t = *(const f32x4*)(xr + c);
                 float e[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = fast_exp2(fmaf(t[j], scale_log2e, -mx)) * inv;
+                for (int j = 0; j < 4; ++j) e[j] = c + j < cols ? fast_exp2(fmaf(t[j], scale_log2e, -mx)) * inv : 0.0f;
                 o = u32x2{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3])};
             }
             *(u32x2*)(orow + c) = o;
@@ -848,6 +855,9 @@ int launch_generic(const void* q, const void* k, const void* v, void* out, int B
 int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
 int g_attn_c4 = 1;  // apexmi_tune_set("attn.c4", 0|1|2): 8-wave launches use the 4-cluster ping-pong kernel (shipped: -3.4 % per
                     // attention launch in the Flux and HunyuanVideo steps); 0 = plain loop, 2 = with s_setprio in the matrix clusters
+}  // namespace
+namespace { int g_causal_block = 0; }  // set only inside apexmi_attn_fwd_framecausal
+namespace {
 int g_attn_mfma = 32;  // 32: 32x32x16 kernel (shipped: 3 % faster in the Flux step), 16: 16x16x32 kernel (apexmi_tune_set "attn.mfma")
 
 // contiguity test for the MFMA path's packed [B,H,S,128] operands
@@ -856,15 +866,20 @@ bool packed_bhsd(const int64_t* st, int H, int S, int D) {
 }
 
 
-// workspace layout of the materialised path: [scores f32 Sq x Sk][P bf16 Sq x Skp][V^T bf16 D x Skp]
+extern int g_causal_block;
+
+// workspace layout of the materialised path: [scores f32 Sq x Sk8][P bf16 Sq x Skp][V^T bf16 D x Skp][K bf16 Sk8 x D]
+// (Sk8 = Sk rounded up to 8: the GEMM writes whole 8-column groups; the zero-padded K copy exists only when Sk8 != Sk)
 bool use_materialised(int Sq, int Sk, int D, int dtype, const int64_t* qs, const int64_t* ks, const int64_t* vs,
                       const int64_t* os) {
-    return dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && Sk % 8 == 0 &&
-           (int64_t)Sq * Sk >= 256 * 256 && qs[2] % 8 == 0 && ks[2] % 8 == 0 && vs[2] % 8 == 0 && os[1] % 8 == 0;
+    // D = 128 belongs to the flash kernels, except under the frame-causal mask (they carry no mask)
+    return dtype == APEXMI_BF16 && (D != HD || g_causal_block > 0) && D % 128 == 0 && D <= 1024 &&
+           ((int64_t)Sq * Sk >= 256 * 256 || g_causal_block > 0) && qs[2] % 8 == 0 && ks[2] % 8 == 0 && vs[2] % 8 == 0 &&
+           os[1] % 8 == 0;
 }
 size_t materialised_bytes(int Sq, int Sk, int D) {
-    const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
-    return (size_t)Sq * Sk * 4 + (size_t)Sq * skp * 2 + (size_t)D * skp * 2;
+    const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV, sk8 = (size_t)((Sk + 7) / 8) * 8;
+    return (size_t)Sq * sk8 * 4 + (size_t)Sq * skp * 2 + (size_t)D * skp * 2 + (sk8 != (size_t)Sk ? sk8 * D * 2 : 0);
 }
 
 }  // namespace
@@ -922,7 +937,7 @@ void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
-    if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && Sk % 8 == 0 && (int64_t)Sq * Sk >= 256 * 256)
+    if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && (int64_t)Sq * Sk >= 256 * 256)
         return materialised_bytes(Sq, Sk, D);   // one (batch, head) at a time on the stream
     if (dtype != APEXMI_BF16 || D != HD) return 0;
     const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
@@ -941,7 +956,7 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(q && k && v && out, "attn_fwd: null operand");
     APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0 && D > 0, "attn_fwd: empty problem");
-    if (dtype == APEXMI_BF16 && D == HD) {
+    if (dtype == APEXMI_BF16 && D == HD && g_causal_block == 0) {
         const size_t need = apexmi_attn_workspace_bytes(B, H, Sq, Sk, D, dtype);
         APEXMI_REQUIRE(workspace && workspace_bytes >= need,
                        "attn_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -971,10 +986,11 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
     }
     if (use_materialised(Sq, Sk, D, dtype, q_strides, k_strides, v_strides, o_strides) && workspace &&
         workspace_bytes >= materialised_bytes(Sq, Sk, D)) {
-        const int skp = ((Sk + KV - 1) / KV) * KV;
+        const int skp = ((Sk + KV - 1) / KV) * KV, sk8 = (Sk + 7) / 8 * 8;
         float* sc = (float*)workspace;
-        bf16_t* pb = (bf16_t*)((char*)workspace + (size_t)Sq * Sk * 4);
+        bf16_t* pb = (bf16_t*)((char*)workspace + (size_t)Sq * sk8 * 4);
         bf16_t* vt = pb + (size_t)Sq * skp;
+        bf16_t* kpad = vt + (size_t)D * skp;
         const float c = softmax_scale * 1.4426950408889634f;
         for (int b = 0; b < B; ++b)
             for (int h = 0; h < H; ++h) {
@@ -982,13 +998,24 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
                 const bf16_t* kp = (const bf16_t*)k + b * k_strides[0] + h * k_strides[1];
                 const bf16_t* vp = (const bf16_t*)v + b * v_strides[0] + h * v_strides[1];
                 bf16_t* op = (bf16_t*)out + b * o_strides[0] + h * o_strides[2];
-                if (int rc = apexmi_gemm_bf16(qp, q_strides[2], kp, k_strides[2], nullptr, sc, Sk, Sq, Sk, D,
+                int64_t ldk = k_strides[2];
+                if (sk8 != Sk) {   // the GEMM's weight operand needs whole groups of 8 rows: zero-padded copy of K
+                    if (hipMemcpy2DAsync(kpad, (size_t)D * 2, kp, (size_t)ldk * 2, (size_t)D * 2, Sk, hipMemcpyDeviceToDevice,
+                                         stream) != hipSuccess ||
+                        hipMemsetAsync(kpad + (size_t)Sk * D, 0, (size_t)(sk8 - Sk) * D * 2, stream) != hipSuccess) {
+                        apexmi_set_error("attn_fwd: padding K failed");
+                        return 1;
+                    }
+                    kp = kpad;
+                    ldk = D;
+                }
+                if (int rc = apexmi_gemm_bf16(qp, q_strides[2], kp, ldk, nullptr, sc, sk8, Sq, sk8, D,
                                               APEXMI_EPI_BIAS_F32, nullptr, nullptr, 0, stream_))
                     return rc;
                 {
                     ApexmiProfScope prof(1, stream, 0.0, (double)Sq * Sk * 6.0);
-                    hipLaunchKernelGGL(softmax_rows_kernel, dim3(Sq), dim3(256), 0, stream, sc, (int64_t)Sk, Sk, c, pb,
-                                       (int64_t)skp, skp);
+                    hipLaunchKernelGGL(softmax_rows_kernel, dim3(Sq), dim3(256), 0, stream, sc, (int64_t)sk8, Sk, c, pb,
+                                       (int64_t)skp, skp, g_causal_block);
                     if (int rc = apexmi_check_launch("softmax_rows")) return rc;
                 }
                 // V^T [D, skp]: the 128-wide transpose kernel over D / 128 column slices
@@ -1015,4 +1042,21 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
             apexmi_set_error("attn_fwd: unknown dtype %d", dtype);
             return 1;
     }
+}
+
+extern "C" size_t apexmi_attn_framecausal_workspace_bytes(int S, int D) { return materialised_bytes(S, S, D); }
+
+extern "C" int apexmi_attn_fwd_framecausal(const void* q, const void* k, const void* v, void* out, int B, int H,
+                                           int S, int D, int block, const int64_t q_strides[3],
+                                           const int64_t k_strides[3], const int64_t v_strides[3],
+                                           const int64_t o_strides[3], float softmax_scale, void* workspace,
+                                           size_t workspace_bytes, apexmi_stream_t stream_) {
+    APEXMI_REQUIRE(block > 0 && S % block == 0, "attn_fwd_framecausal: S=%d is not a whole number of frames of %d tokens", S, block);
+    APEXMI_REQUIRE(D % 128 == 0 && D <= 1024, "attn_fwd_framecausal: D=%d must be a multiple of 128 (<= 1024)", D);
+    APEXMI_REQUIRE(workspace && workspace_bytes >= materialised_bytes(S, S, D), "attn_fwd_framecausal: workspace too small");
+    g_causal_block = block;
+    const int rc = apexmi_attn_fwd(q, k, v, out, B, H, S, S, D, q_strides, k_strides, v_strides, o_strides, softmax_scale,
+                                   APEXMI_BF16, workspace, workspace_bytes, stream_);
+    g_causal_block = 0;
+    return rc;
 }

@@ -35,6 +35,7 @@ struct ConvArgs {
     int T, H, W, Cin, Cout, Kpad;
     int kT, kH, kW, ntaps;
     int q64, r64;         // 64 / Cin, 64 % Cin
+    int replicate;        // 0: out-of-range taps read zeros; 1: coordinates are clamped (replicate padding)
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
                 const int ti = pos_t[i] + (int)(int8_t)(o & 0xff);
                 const int yi = pos_y[i] + (int)(int8_t)((o >> 8) & 0xff);
                 const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
-                if ((unsigned)ti < (unsigned)a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+                if (a.replicate) {   // HunyuanVideo15CausalConv3d: F.pad(..., mode="replicate") == clamped coordinates
+                    const int tc = max(ti, 0), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
+                    src = a.in + ((int64_t)(tc * a.H + yc) * a.W + xc) * a.Cin + a_ci[i];
+                } else if ((unsigned)ti < (unsigned)a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
                     src = a.in + ((int64_t)(ti * a.H + yi) * a.W + xi) * a.Cin + a_ci[i];
+                }
             }
             glds16(src, base + i * 4096);
             // advance this lane's chunk by one K-tile (64 channels)
@@ -222,6 +227,42 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const bf16_t* __restric
         }
         *(u32x4*)(y + pos * C + l * 8) = pack8(v);
     }
+}
+
+// C in (512, 1024] (HunyuanVideo-1.5 VAE, 1024 channels): one wave per position, two 8-channel chunks per lane.
+__global__ __launch_bounds__(256) void rmsnorm_cl_wide_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const bf16_t* __restrict__ gamma, int64_t P, int C,
+                                                              int silu) {
+    const int64_t pos = (int64_t)blockIdx.x * 4 + threadIdx.x / 64;
+    const int l = threadIdx.x % 64;
+    float v[2][8];
+    bool live[2];
+    float sq = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        live[h] = pos < P && (h * 64 + l) * 8 < C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[h][j] = 0.0f;
+        if (live[h]) unpack8(*(const u32x4*)(x + pos * C + (h * 64 + l) * 8), v[h]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq += v[h][j] * v[h][j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float scale = sqrtf((float)C) / fmaxf(sqrtf(sq), 1e-12f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (live[h]) {
+            float g[8];
+            unpack8(*(const u32x4*)(gamma + (h * 64 + l) * 8), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float r = v[h][j] * scale * g[j];
+                if (silu) r = silu_f(r);
+                v[h][j] = r;
+            }
+            *(u32x4*)(y + pos * C + (h * 64 + l) * 8) = pack8(v[h]);
+        }
 }
 
 // nearest(-exact) 2x spatial upsample, [T, H, W, C] -> [T, 2H, 2W, C]  (WanUpsample, model.py:225-237)
@@ -407,9 +448,9 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
     return apexmi_check_launch("groupnorm_cl");
 }
 
-extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual,
-                                void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
-                                int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
+static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                          const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                          int replicate, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(in && w && out && zeros, "conv3d_cl: null operand");
     APEXMI_REQUIRE(T > 0 && H > 0 && W > 0, "conv3d_cl: empty volume");
@@ -438,6 +479,7 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
     a.kT = kT; a.kH = kH; a.kW = kW; a.ntaps = ntaps;
     a.q64 = 64 / Cin;
     a.r64 = 64 % Cin;
+    a.replicate = replicate;
     const int64_t M = (int64_t)T * H * W;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps * Cin,
@@ -446,14 +488,29 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
     return apexmi_check_launch("conv3d_cl");
 }
 
+extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual,
+                                void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
+                                int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_);
+}
+
+extern "C" int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual,
+                                          void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
+                                          int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 1, stream_);
+}
+
 extern "C" int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
                                  apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(x && y && gamma && P > 0, "rmsnorm_cl: bad arguments");
-    APEXMI_REQUIRE(C % 8 == 0 && C <= 512, "rmsnorm_cl: C=%d must be a multiple of 8 and <= 512", C);
+    APEXMI_REQUIRE(C % 8 == 0 && C <= 1024, "rmsnorm_cl: C=%d must be a multiple of 8 and <= 1024", C);
     ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)P * C);
     const int lanes = C / 8;
-    if (lanes <= 16)
+    if (lanes > 64)
+        hipLaunchKernelGGL(rmsnorm_cl_wide_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
+                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+    else if (lanes <= 16)
         hipLaunchKernelGGL(rmsnorm_cl_kernel<16>, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, stream,
                            (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
     else if (lanes <= 32)

@@ -503,6 +503,20 @@ __global__ __launch_bounds__(256) void add_rowvec_bf16_kernel(const bf16_t* __re
     *(u32x4*)(out + r * ldo + c) = pack8(a);
 }
 
+// out = a + b (bf16, f32 add): `h + shortcut` of HunyuanVideo15Upsample.forward / Decoder3D.forward after the DCAE
+// rearranges (vae/hunyuanvideo15/model.py:274, :709-711), where the two addends come out of different layouts
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ out, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float x[8], y[8];
+    unpack8(*(const u32x4*)(a + i * 8), x);
+    unpack8(*(const u32x4*)(b + i * 8), y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    *(u32x4*)(out + i * 8) = pack8(x);
+}
+
 }  // namespace
 
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
@@ -709,6 +723,17 @@ extern "C" int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v,
     hipLaunchKernelGGL(add_rowvec_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        ldx, (const bf16_t*)v, (bf16_t*)out, ldo, rows, cols);
     return apexmi_check_launch("add_rowvec_bf16");
+}
+
+extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "add_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    APEXMI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                   "add_bf16: operands must be 16-byte aligned");
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)out, n / 8);
+    return apexmi_check_launch("add_bf16");
 }
 
 extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {

@@ -41,6 +41,13 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
     def device(self):
         return self.transformer.device
 
+    def vae_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """BaseEngine.vae_decode (engine/base_engine.py:2030-2059) after t2v.py:350 `vae.enable_tiling()`: denormalise,
+        tiled decode, [B, 3, F, H, W]."""
+        z = self.vae.denormalize_latents(latents.to(torch.float32)).to(self.vae.dtype)
+        self.vae.enable_tiling()
+        return self.vae.decode(z, return_dict=False)[0]
+
     @staticmethod
     def prepare_cond_latents_and_mask(latents, dtype, device):
         b, c, f, h, w = latents.shape
@@ -119,9 +126,9 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         if return_latents:
             _emit(progress_callback, 1.0, "Returning latents")
             return latents
-        if self.decode_fn is None:
+        if self.decode_fn is None and self.vae is None:
             raise RuntimeError("hunyuanvideo15: no decode_fn / VAE attached; pass return_latents=True")
         _emit(progress_callback, 0.94, "Decoding latents")
-        video = self.decode_fn(latents)
+        video = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents)
         _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
         return video

@@ -27,6 +27,9 @@ SIGNATURES = {
                                   C.c_size_t, vp]),
     "apexmi_attn_fwd_prepared": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, c_i64p, C.c_float, vp]),
+    "apexmi_attn_framecausal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "apexmi_attn_fwd_framecausal": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              c_i64p, c_i64p, c_i64p, c_i64p, C.c_float, vp, C.c_size_t, vp]),
     "apexmi_gemm_bf16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, vp, C.c_int64, vp]),
     "apexmi_gemm_bf16_grouped": (C.c_int, [C.c_int, C.POINTER(vp), c_i64p, C.POINTER(vp), c_i64p,
@@ -46,6 +49,8 @@ SIGNATURES = {
     "apexmi_v_transpose": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                      C.c_int, vp]),
     "apexmi_conv3d_cl": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "apexmi_conv3d_cl_replicate": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "apexmi_add_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "apexmi_rmsnorm_cl": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_time_interleave_cl": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp]),

@@ -264,6 +264,45 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     return out.permute(0, 2, 1, 3)
 
 
+def attention_framecausal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tokens_per_frame: int,
+                          softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """Frame-causal attention of the HunyuanVideo-1.5 VAE mid block: q, k, v [B,H,S,D] bf16 (D a multiple of 128 up to
+    1024, any S), token i attends the keys of frames <= its own.  Same return convention as `attention`."""
+    _req(q, torch.bfloat16, "attention_framecausal.q")
+    B, H, S, D = q.shape
+    q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(D)
+    out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+    lib = _l.load()
+    need = lib.apexmi_attn_framecausal_workspace_bytes(S, D)
+    key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < max(need, 1):
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
+        _ws_cache[key] = ws
+    rc = lib.apexmi_attn_fwd_framecausal(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, S, D,
+                                         int(tokens_per_frame),
+                                         _l.i64x3((q.stride(0), q.stride(1), q.stride(2))),
+                                         _l.i64x3((k.stride(0), k.stride(1), k.stride(2))),
+                                         _l.i64x3((v.stride(0), v.stride(1), v.stride(2))),
+                                         _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
+                                         float(softmax_scale), ws.data_ptr(), need, _stream())
+    _l.check(rc, "attn_fwd_framecausal")
+    return out.permute(0, 2, 1, 3)
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a + b for contiguous bf16 tensors of equal shape (numel a multiple of 8)."""
+    _req(a, torch.bfloat16, "add.a")
+    _req(b, torch.bfloat16, "add.b")
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    _l.check(_l.load().apexmi_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add_bf16")
+    return out
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, scale: float = 1.0, flip_sin_to_cos: bool = True,
                        downscale_freq_shift: float = 0.0) -> torch.Tensor:
     _req(t, torch.float32, "timestep_embedding.t")
@@ -397,8 +436,10 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
-              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" zero padding in space."""
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              replicate: bool = False) -> torch.Tensor:
+    """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" padding in space: zeros, or (replicate)
+    clamped coordinates as HunyuanVideo15CausalConv3d pads."""
     _req(x, torch.bfloat16, "conv3d_cl.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
@@ -411,9 +452,10 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
         assert bias.numel() == cout and bias.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
-    rc = _l.load().apexmi_conv3d_cl(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual),
-                                    out.data_ptr(), _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad,
-                                    int(ksize[0]), int(ksize[1]), int(ksize[2]), _stream())
+    fn = _l.load().apexmi_conv3d_cl_replicate if replicate else _l.load().apexmi_conv3d_cl
+    rc = fn(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+            _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]), int(ksize[1]), int(ksize[2]),
+            _stream())
     _l.check(rc, "conv3d_cl")
     return out
 

@@ -1,0 +1,297 @@
+"""AutoencoderKLHunyuanVideo15 decode on the MI355X HIP ops — drop-in for VAE registry key "hunyuanvideo15"
+(decode half).
+
+Mirrors what the engines use of the reference class (apps/api/src/vae/hunyuanvideo15/model.py:735-1158):
+`from_config`, state-dict keys `decoder.*` (encoder keys in a checkpoint are ignored by `strict=False`), `.config`
+(scaling_factor, spatial / temporal compression), `enable_tiling(...)`, `denormalize_latents`,
+`decode(z, return_dict=False)[0]`, `.dtype`.
+
+Decode runs channels-last [T, H, W, C].  Per tile (the reference decodes 8x8-latent tiles with stride 6 over the WHOLE
+frame sequence and blends 32-pixel overlaps, `tiled_decode` :1060-1119 — tiling is part of the numerical contract):
+implicit-GEMM causal conv3d on MFMA with REPLICATE padding (clamped tap coordinates) and fused bias + residual,
+RMS-norm(channel)+SiLU, GEMMs for the 1x1x1 convs, the frame-causal single-head attention of the mid block
+(materialised through the GEMM kernel with the mask applied in the row softmax), DCAE pixel-shuffle upsampling as
+pure data movement plus one add, crossfades for the blends.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import lib as _l
+from . import ops
+from .flux import _Config
+
+
+class _CConv(nn.Module):
+    """HunyuanVideo15CausalConv3d: parameters live under `.conv` (model.py:82-84)."""
+
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv = nn.Module()
+        self.conv.weight = nn.Parameter(torch.empty(cout, cin, 3, 3, 3, **kw), requires_grad=False)
+        self.conv.bias = nn.Parameter(torch.empty(cout, **kw), requires_grad=False)
+
+
+class _Conv1(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1, 1, **kw), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(cout, **kw), requires_grad=False)
+
+
+class _Gamma(nn.Module):
+    def __init__(self, dim, **kw):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim, 1, 1, 1, **kw), requires_grad=False)
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.norm1, self.conv1 = _Gamma(cin, **kw), _CConv(cin, cout, **kw)
+        self.norm2, self.conv2 = _Gamma(cout, **kw), _CConv(cout, cout, **kw)
+        self.conv_shortcut = _Conv1(cin, cout, **kw) if cin != cout else None
+
+
+class _Attn(nn.Module):
+    def __init__(self, c, **kw):
+        super().__init__()
+        self.norm = _Gamma(c, **kw)
+        self.to_q, self.to_k, self.to_v, self.proj_out = (_Conv1(c, c, **kw) for _ in range(4))
+
+
+class _Upsample(nn.Module):
+    def __init__(self, cin, cout, temporal, **kw):
+        super().__init__()
+        self.factor = 8 if temporal else 4
+        self.conv = _CConv(cin, cout * self.factor, **kw)
+        self.temporal = temporal
+        self.repeats = self.factor * cout // cin
+
+
+class _Mid(nn.Module):
+    def __init__(self, c, **kw):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(c, c, **kw), _Res(c, c, **kw)])
+        self.attentions = nn.ModuleList([_Attn(c, **kw)])
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, n, up_out, temporal, **kw):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(cin if i == 0 else cout, cout, **kw) for i in range(n)])
+        self.upsamplers = None if up_out is None else nn.ModuleList([_Upsample(cout, up_out, temporal, **kw)])
+
+
+class _Decoder(nn.Module):
+    def __init__(self, in_channels, out_channels, ch, layers_per_block, spatial_ratio, temporal_ratio, **kw):
+        super().__init__()
+        self.repeat = ch[0] // in_channels
+        self.conv_in = _CConv(in_channels, ch[0], **kw)
+        self.mid_block = _Mid(ch[0], **kw)
+        ups, cin = [], ch[0]
+        for i, cout in enumerate(ch):
+            sp, tp = i < math.log2(spatial_ratio), i < math.log2(temporal_ratio)
+            if sp or tp:
+                ups.append(_Up(cin, cout, layers_per_block + 1, ch[i + 1], tp, **kw))
+                cin = ch[i + 1]
+            else:
+                ups.append(_Up(cin, cout, layers_per_block + 1, None, False, **kw))
+                cin = cout
+        self.up_blocks = nn.ModuleList(ups)
+        self.norm_out = _Gamma(ch[-1], **kw)
+        self.conv_out = _CConv(ch[-1], out_channels, **kw)
+
+
+def _rearrange_cl(x: torch.Tensor, r1: int, r2: int, r3: int) -> torch.Tensor:
+    """channels-last form of `_dcae_upsample_rearrange` (model.py:231-247): [T, H, W, r1*r2*r3*c] -> [r1 T, r2 H, r3 W, c]."""
+    T, H, W, pc = x.shape
+    c = pc // (r1 * r2 * r3)
+    return x.view(T, H, W, r1, r2, r3, c).permute(0, 3, 1, 4, 2, 5, 6).reshape(T * r1, H * r2, W * r3, c)
+
+
+class AutoencoderKLHunyuanVideo15(nn.Module):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 32,
+                 block_out_channels: Tuple[int, ...] = (128, 256, 512, 1024, 1024), layers_per_block: int = 2,
+                 spatial_compression_ratio: int = 16, temporal_compression_ratio: int = 4,
+                 downsample_match_channel: bool = True, upsample_match_channel: bool = True,
+                 scaling_factor: float = 1.03682, light_vae_path: Optional[str] = None, device=None,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if not upsample_match_channel:
+            raise NotImplementedError("hunyuanvideo15_mi355 VAE: upsample_match_channel=False is not a shipped configuration")
+        self.config = _Config(in_channels=in_channels, out_channels=out_channels, latent_channels=latent_channels,
+                              block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                              spatial_compression_ratio=spatial_compression_ratio,
+                              temporal_compression_ratio=temporal_compression_ratio, scaling_factor=scaling_factor,
+                              shift_factor=None)
+        kw = dict(device=device, dtype=dtype)
+        self.decoder = _Decoder(latent_channels, out_channels, list(reversed(block_out_channels)), layers_per_block,
+                                spatial_compression_ratio, temporal_compression_ratio, **kw)
+        self.spatial_compression_ratio = spatial_compression_ratio
+        self.temporal_compression_ratio = temporal_compression_ratio
+        self.use_tiling = False
+        self.tile_sample_min_height = self.tile_sample_min_width = 128
+        self.tile_latent_min_height = self.tile_latent_min_width = 128 // spatial_compression_ratio
+        self.tile_overlap_factor = 0.25
+        self._packed: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = dict(config) if isinstance(config, dict) else dict(vars(config))
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_") and k != "shift_factor"}
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    _from_config = from_config
+
+    @property
+    def dtype(self):
+        return self.decoder.conv_in.conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.decoder.conv_in.conv.weight.device
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = {}
+        return super().load_state_dict(*a, **k)
+
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_latent_min_height=None,
+                      tile_latent_min_width=None, tile_overlap_factor=None, use_light_vae: bool = False):
+        if use_light_vae:
+            raise NotImplementedError("hunyuanvideo15_mi355 VAE: the TAEHV light decoder is not implemented")
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_latent_min_height = tile_latent_min_height or self.tile_latent_min_height
+        self.tile_latent_min_width = tile_latent_min_width or self.tile_latent_min_width
+        self.tile_overlap_factor = tile_overlap_factor or self.tile_overlap_factor
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        return None
+
+    def denormalize_latents(self, latents):
+        return latents / self.config.scaling_factor
+
+    def normalize_latents(self, latents):
+        return latents * self.config.scaling_factor
+
+    # ---- kernels per layer ----------------------------------------------------------------------
+    def _w(self, mod, weight, bias):
+        key = id(mod)
+        p = self._packed.get(key)
+        if p is None:
+            w = ops.pack_conv_weight(weight.data)
+            b = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+            b[:bias.numel()] = bias.data
+            p = (w, b)
+            self._packed[key] = p
+        return p
+
+    def _cconv(self, c: _CConv, x, residual=None):
+        w, b = self._w(c, c.conv.weight, c.conv.bias)
+        return ops.conv3d_cl(x, w, b, (3, 3, 3), residual=residual, replicate=True)
+
+    def _conv1(self, c: _Conv1, x2d, **kw):
+        return ops.gemm(x2d, c.weight.data.reshape(c.weight.shape[0], c.weight.shape[1]), c.bias.data, **kw)
+
+    @staticmethod
+    def _g(n: _Gamma):
+        return n.gamma.data.reshape(-1).contiguous()
+
+    def _res(self, blk: _Res, x):
+        T, H, W, Cc = x.shape
+        h = self._cconv(blk.conv1, ops.rmsnorm_cl(x, self._g(blk.norm1), silu=True))
+        sc = x if blk.conv_shortcut is None else self._conv1(blk.conv_shortcut, x.view(T * H * W, Cc)).view(T, H, W, -1)
+        return self._cconv(blk.conv2, ops.rmsnorm_cl(h, self._g(blk.norm2), silu=True), residual=sc)
+
+    def _attn(self, blk: _Attn, x):
+        T, H, W, Cc = x.shape
+        S = T * H * W
+        n = ops.rmsnorm_cl(x, self._g(blk.norm)).view(S, Cc)
+        q, k, v = (self._conv1(m, n).view(1, 1, S, Cc) for m in (blk.to_q, blk.to_k, blk.to_v))
+        o = ops.attention_framecausal(q, k, v, H * W).permute(0, 2, 1, 3).reshape(S, Cc)
+        ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
+        return self._conv1(blk.proj_out, o, epilogue="gate_res", gate=ones, residual=x.view(S, Cc)).view(T, H, W, Cc)
+
+    def _upsample(self, up: _Upsample, x):
+        h = self._cconv(up.conv, x)
+        if up.temporal:
+            hf = _rearrange_cl(h[:1], 1, 2, 2)
+            hf = hf[..., : hf.shape[-1] // 2]
+            h = torch.cat([hf, _rearrange_cl(h[1:], 2, 2, 2)], dim=0)
+            xf = _rearrange_cl(x[:1], 1, 2, 2).repeat_interleave(up.repeats // 2, dim=-1)
+            xn = _rearrange_cl(x[1:], 2, 2, 2).repeat_interleave(up.repeats, dim=-1)
+            sc = torch.cat([xf, xn], dim=0)
+        else:
+            h = _rearrange_cl(h, 1, 2, 2)
+            sc = _rearrange_cl(x.repeat_interleave(up.repeats, dim=-1), 1, 2, 2)
+        return ops.add(h.contiguous(), sc.contiguous())
+
+    def _decode_tile(self, z):
+        """z [T, h, w, latent_channels] channels-last -> [4 (T - 1) + 1, 16 h, 16 w, 4] (3 channels + 1 pad)."""
+        d = self.decoder
+        x = self._cconv(d.conv_in, z, residual=z.repeat_interleave(d.repeat, dim=-1).contiguous())
+        x = self._res(d.mid_block.resnets[0], x)
+        x = self._attn(d.mid_block.attentions[0], x)
+        x = self._res(d.mid_block.resnets[1], x)
+        for ub in d.up_blocks:
+            for r in ub.resnets:
+                x = self._res(r, x)
+            if ub.upsamplers is not None:
+                x = self._upsample(ub.upsamplers[0], x)
+        return self._cconv(d.conv_out, ops.rmsnorm_cl(x, self._g(d.norm_out), silu=True))
+
+    @torch.no_grad()
+    def _decode_one(self, z):
+        """z [C, T, H, W] -> [3, T', 16 H, 16 W] bf16."""
+        if z.device.type != "cuda" or self.dtype != torch.bfloat16:
+            raise _l.ApexMIError("hunyuanvideo15_mi355 VAE needs bf16 weights and latents on a ROCm device (no CPU fallback)")
+        _, T, H, W = z.shape
+        zc = z.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+        tlh, tlw = self.tile_latent_min_height, self.tile_latent_min_width
+        if not (self.use_tiling and (W > tlw or H > tlh)):
+            out = self._decode_tile(zc)
+        else:
+            ovh, ovw = int(tlh * (1 - self.tile_overlap_factor)), int(tlw * (1 - self.tile_overlap_factor))
+            bh = int(self.tile_sample_min_height * self.tile_overlap_factor)
+            bw = int(self.tile_sample_min_width * self.tile_overlap_factor)
+            lh, lw = self.tile_sample_min_height - bh, self.tile_sample_min_width - bw
+            rows = [[self._decode_tile(zc[:, i:i + tlh, j:j + tlw].contiguous()) for j in range(0, W, ovw)]
+                    for i in range(0, H, ovh)]
+            out_rows = []
+            for i, row in enumerate(rows):
+                parts = []
+                for j, tile in enumerate(row):
+                    if i > 0:
+                        a = rows[i - 1][j]
+                        e = min(a.shape[1], tile.shape[1], bh)
+                        ops.crossfade_(a[:, a.shape[1] - e:, :tile.shape[2]], tile[:, :e], dim=1)
+                    if j > 0:
+                        a = row[j - 1]
+                        e = min(a.shape[2], tile.shape[2], bw)
+                        ops.crossfade_(a[:, :tile.shape[1], a.shape[2] - e:], tile[:, :, :e], dim=2)
+                    parts.append(tile[:, :lh, :lw])
+                out_rows.append(torch.cat(parts, dim=2))
+            out = torch.cat(out_rows, dim=1)
+        return out[..., :self.config.out_channels].permute(3, 0, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)
+        if not return_dict:
+            return (dec,)
+        return SimpleNamespace(sample=dec)

@@ -86,6 +86,16 @@ int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void*
                              const int64_t o_strides[3], float softmax_scale,
                              apexmi_stream_t stream);
 
+/* HunyuanVideo15AttnBlock.forward (vae/hunyuanvideo15/model.py:130-214): one head of C channels over frames x (H W)
+ * tokens with the frame-causal mask of prepare_causal_attention_mask (:143-165): token i attends the keys of frames
+ * <= its own, `block` = tokens per frame.  bf16, D = C a multiple of 128 up to 1024, any S; materialised through the GEMM
+ * kernel; workspace >= apexmi_attn_framecausal_workspace_bytes(S, D), reused for every (batch, head). */
+size_t apexmi_attn_framecausal_workspace_bytes(int S, int D);
+int apexmi_attn_fwd_framecausal(const void* q, const void* k, const void* v, void* out, int B, int H, int S, int D,
+                                int block, const int64_t q_strides[3], const int64_t k_strides[3],
+                                const int64_t v_strides[3], const int64_t o_strides[3], float softmax_scale,
+                                void* workspace, size_t workspace_bytes, apexmi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Linear layers.  Replace torch.nn.Linear on the denoise path
  * (to_q/to_k/to_v/to_out, ff.net.0.proj/net.2, proj_mlp/proj_out:
@@ -186,6 +196,11 @@ int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, in
 int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
                      int kW, apexmi_stream_t stream);
+/* HunyuanVideo15CausalConv3d.forward (vae/hunyuanvideo15/model.py:52-90): the same implicit GEMM with REPLICATE padding
+ * (coordinates clamped: two frames in front, one pixel around) instead of zeros. */
+int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                               const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                               int kW, apexmi_stream_t stream);
 int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
                       apexmi_stream_t stream);
 int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W, int C, apexmi_stream_t stream);
@@ -223,6 +238,10 @@ int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t row
  * (hunyuanvideo15 model.py:1013-1056 `encoder_hidden_states + cond_type_embed(...)`). */
 int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
                            int cols, apexmi_stream_t stream);
+
+/* out = a + b, n bf16 elements (n % 8 == 0): `h + shortcut` after the DCAE rearranges of the HunyuanVideo-1.5 VAE
+ * (vae/hunyuanvideo15/model.py:274, :709-711). */
+int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
 
 /* f32 <-> bf16 helpers for the small conditioning vectors. */
 int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);

@@ -23,6 +23,8 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
                         (quantize/scaled_layer.py:154-167, :496-549) on seeded float8_e4m3fn / e5m2 weights with
                         scalar and per-row scales, every fp8 code point included — pins oracle.weights and the
                         HIP dequant kernel.
+  vae_hunyuan15.pt      the reference's AutoencoderKLHunyuanVideo15 decode (replicate-padded causal convs, frame-causal
+                        mid-block attention, DCAE pixel-shuffle upsampling, 8x8-latent tiling) — pins oracle.vae_hunyuan15.
   lora_convert.pt       reference LoraConverter().convert (lora/lora_converter.py:80-183) on seeded PEFT-with-alpha
                         and lora_down/lora_up state dicts — pins key normalisation and alpha folding of
                         apex_studio_amd.lora / oracle.lora (the PEFT runtime arithmetic itself is absent).
@@ -346,6 +348,42 @@ def gen_vae_wan():
     print("vae_wan.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
 
 
+TINY_VAE_HY15 = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
+                     layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
+
+
+def gen_vae_hunyuan15():
+    """The REFERENCE AutoencoderKLHunyuanVideo15 (vae/hunyuanvideo15/model.py) decode, untiled and tiled (8x8-latent tiles,
+    stride 6, 32-px blends), on a small channel plan.  Stubs carry no arithmetic: the light-VAE class, the download mixin
+    and the components-path helper are never used on the decode path."""
+    install_vae_stubs()
+    import src.attention  # noqa: F401
+    d = _mod("src.utils.defaults", get_components_path=lambda *a, **k: "/tmp")
+    t = _mod("src.vae.tae")
+    t.__path__ = []
+    _mod("src.vae.tae.model", TAEHV=type("TAEHV", (), {}))
+    _mod("src.mixins.download_mixin", DownloadMixin=type("DownloadMixin", (), {}))
+    ref_mod = load_by_path("ref_vae_hy15", "src/vae/hunyuanvideo15/model.py")
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    ref = ref_mod.AutoencoderKLHunyuanVideo15(**TINY_VAE_HY15).eval()
+    orc = Orc(**TINY_VAE_HY15)
+    sd = vae_synthetic_state_dict(orc, 17)
+    missing = ref.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all(k.startswith("encoder.") for k in missing.missing_keys), missing.missing_keys[:5]
+    z = seeded((1, 32, 3, 10, 14), 71)
+    with torch.no_grad():
+        untiled = ref.decode(z, return_dict=False)[0]
+        ref.enable_tiling()
+        tiled = ref.decode(z, return_dict=False)[0]
+    assert float((tiled - untiled).abs().max()) > 1e-3
+    torch.save(dict(config=TINY_VAE_HY15, seed=17, z_shape=(1, 32, 3, 10, 14), z_seed=71,
+                    untiled=untiled.to(torch.bfloat16), tiled=tiled.to(torch.bfloat16),
+                    untiled_f32_sample=untiled[0, :, :, ::8, ::8].clone(), tiled_f32_sample=tiled[0, :, :, ::8, ::8].clone(),
+                    keys=sorted(sd.keys())), os.path.join(OUT, "vae_hunyuan15.pt"))
+    print("vae_hunyuan15.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
+
+
 def gen_unipc():
     """In-tree UniPC (reference scheduler/unipc.py) trajectory: 6 steps, shift 3, fp32 latents."""
     class SchedulerOutput:
@@ -493,6 +531,7 @@ def main():
     gen_qwen_hybrid()
     gen_hunyuan15_hybrid()
     gen_vae_wan()
+    gen_vae_hunyuan15()
     gen_unipc()
     gen_lora()
     gen_fp_scaled()

@@ -45,7 +45,7 @@ def test_backend_registration_and_argument_errors():
     vreg = ClassRegister()
     creg = ab.register_models(ClassRegister(), vreg)
     assert {"flux.mi355", "wan.mi355", "qwenimage.mi355"} <= set(creg.all())
-    assert {"auto_mi355", "wan_mi355", "qwenimage_mi355"} <= set(vreg.all())
+    assert {"auto_mi355", "wan_mi355", "qwenimage_mi355", "hunyuanvideo15_mi355"} <= set(vreg.all())
 
 
 def test_flux_class_contract_on_meta_device():

@@ -143,7 +143,7 @@ def test_denoise_loop_matches_oracle_loop():
     assert rel < 1e-2, rel
 
 
-def test_flux_full_width_one_plus_one_blocks_match_oracle():
+def test_flux_full_width_one_plus_one_blocks_match_oracle(host_threads):
     """BASELINE.json configs[1] geometry (d 3072 = 24 x 128, mlp 12288, S_img 4096 + S_txt 512, FLUX.1-dev axes) with the
     depth cut to 1 double + 1 single block so the fp32 CPU oracle finishes in about a minute on the box's host cores: the
     full-size tilings (256x256 GEMM tiles, 8-wave attention workgroups, grouped launches, XCD remap, side-stream
@@ -151,7 +151,6 @@ def test_flux_full_width_one_plus_one_blocks_match_oracle():
     cfg = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128,
                num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
                axes_dims_rope=(16, 56, 56))
-    torch.set_num_threads(os.cpu_count() or 1)
     orc = OF.FluxTransformer2DModel(**cfg).eval()
     sd = synthetic_state_dict(orc, 7)
     orc.load_state_dict(sd, strict=True)

@@ -450,7 +450,8 @@ def test_euler_step_and_casts():
     assert torch.equal(ops.to_f32(sb.to(DEV)).cpu(), sb.float())
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1024, 1024, 512), (2, 1, 1024, 1000, 384), (1, 2, 300, 2048, 256)])
+@pytest.mark.parametrize("shape", [(1, 1, 1024, 1024, 512), (2, 1, 1024, 1000, 384), (1, 2, 300, 2048, 256),
+                                   (1, 1, 700, 1021, 384)])
 def test_attention_materialised_wide_heads(shape):
     """Head dims the flash kernel does not cover (VAE mid blocks, C = 384 / 512): scores by the GEMM's f32
     epilogue, row softmax, P V by the GEMM.  Same bar as the flash kernel (P is rounded to bf16 before P V)."""

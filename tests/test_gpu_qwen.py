@@ -74,12 +74,11 @@ def test_qwen_matches_reference_wiring_golden(golden_dir):
     assert rel < 3e-2, rel
 
 
-def test_qwen_full_width_one_block_matches_oracle():
+def test_qwen_full_width_one_block_matches_oracle(host_threads):
     """QwenImage-Edit-2509 geometry (d 3072 = 24 x 128, text 3584, target 64x64 + one 64x64 condition image, 256 text
     tokens: S 8448) with ONE block against the fp32 CPU oracle (about a minute on the host cores)."""
     cfg = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=1, attention_head_dim=128,
                num_attention_heads=24, joint_attention_dim=3584, axes_dims_rope=(16, 56, 56))
-    torch.set_num_threads(os.cpu_count() or 1)
     shapes = [(1, 64, 64), (1, 64, 64)]
     orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
     sd = synthetic_state_dict(orc, 11)

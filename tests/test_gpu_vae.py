@@ -45,7 +45,7 @@ def test_conv3d_cl(cin, cout, k, T, H, W):
 
 def test_vae_elementwise_ops():
     from apex_studio_amd import ops
-    for C in (96, 192, 384, 128):
+    for C in (96, 192, 384, 128, 1024, 640):
         x = _bf(seeded((2, 5, 7, C), 11) * 2)
         g = _bf(1 + 0.1 * seeded((C,), 12))
         for silu in (False, True):
@@ -162,3 +162,79 @@ def test_flux_vae_decode_matches_oracle():
     print(f"[flux vae] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
     assert e_like < 2e-2 and e_true < 2 * e_emul + 1e-2
     assert abs(float(vae.denormalize_latents(torch.tensor(0.3611))) - 1.1159) < 1e-4
+
+
+# ---- HunyuanVideo-1.5 VAE ---------------------------------------------------------
+
+@pytest.mark.parametrize("cin,cout,T,H,W", [(32, 128, 3, 10, 14), (64, 3, 2, 33, 17), (128, 128, 1, 8, 8)])
+def test_conv3d_cl_replicate(cin, cout, T, H, W):
+    """HunyuanVideo15CausalConv3d: F.pad(mode="replicate") by (1, 1, 1, 1, 2, 0) then a valid 3x3x3 conv."""
+    from apex_studio_amd import ops
+    x = _bf(seeded((T, H, W, cin), 1))
+    w = _bf(seeded((cout, cin, 3, 3, 3), 2, scale=(cin * 27) ** -0.5))
+    b = _bf(seeded((cout,), 3) * 0.1)
+    res = _bf(seeded((T, H, W, (cout + 3) // 4 * 4), 4))
+    wp = ops.pack_conv_weight(w.to(DEV))
+    bp = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    bp[:cout] = b.to(DEV)
+    out = ops.conv3d_cl(x.to(DEV), wp, bp, (3, 3, 3), replicate=True)
+    xin = F.pad(x.float().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0), mode="replicate")
+    ref = F.conv3d(xin, w.float(), b.float())[0].permute(1, 2, 3, 0)
+    assert _rel(out[..., :cout].cpu(), ref) < 4e-3
+    zero = F.conv3d(F.pad(x.float().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    assert _rel(out[..., :cout].cpu(), zero) > 5e-2                  # the padding mode is observable
+    out2 = ops.conv3d_cl(x.to(DEV), wp, bp, (3, 3, 3), residual=res.to(DEV), replicate=True)
+    assert _rel(out2[..., :cout].cpu(), ref + res.float()[..., :cout]) < 4e-3
+
+
+@pytest.mark.parametrize("D,frames,per", [(128, 3, 80), (256, 4, 35), (1024, 5, 48), (128, 1, 64)])
+def test_attention_framecausal(D, frames, per):
+    """Mid-block attention of the HunyuanVideo-1.5 VAE (model.py:137-176): one head of the full channel width, token i
+    sees the keys of frames <= its own."""
+    from apex_studio_amd import ops
+    S = frames * per
+    q, k, v = (_bf(seeded((1, 1, S, D), 30 + i)) for i in range(3))
+    out = ops.attention_framecausal(q.to(DEV), k.to(DEV), v.to(DEV), per).cpu()
+    fr = torch.arange(S) // per
+    mask = fr[:, None] >= fr[None, :]
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float(), attn_mask=mask)
+    assert out.shape == ref.shape and _rel(out, ref) < 1e-2
+    if frames > 1:
+        assert _rel(out, F.scaled_dot_product_attention(q.float(), k.float(), v.float())) > 5e-2
+
+
+def test_add_bf16():
+    from apex_studio_amd import ops
+    a, b = _bf(seeded((3, 5, 7, 64), 40)), _bf(seeded((3, 5, 7, 64), 41))
+    assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), _bf(a.float() + b.float()))
+
+
+def test_hunyuan15_vae_decode_matches_reference_and_oracle(golden_dir):
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    g = torch.load(os.path.join(golden_dir, "vae_hunyuan15.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = Orc(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    z = seeded(g["z_shape"], g["z_seed"]).to(torch.bfloat16)
+    vae = AutoencoderKLHunyuanVideo15(**cfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    assert sorted(vae.state_dict().keys()) == g["keys"]
+    for tiled in (False, True):
+        if tiled:
+            vae.enable_tiling()
+            orc.enable_tiling()
+        out = vae.decode(z.to(DEV), return_dict=False)[0].float().cpu()
+        ref = g["tiled" if tiled else "untiled"].float()                     # the reference class, fp32 -> bf16
+        ref16 = orc.decode(z.float(), policy=OL.BF16_STORAGE)
+        ref32 = orc.decode(z.float())
+        assert out.shape == ref.shape and torch.isfinite(out).all()
+        e_like, e_ref, e_emul = _rel(out, ref16), _rel(out, ref), _rel(ref16, ref32)
+        print(f"[hy15 vae tiled={tiled}] hip vs bf16-storage oracle {e_like:.3e}; vs reference {e_ref:.3e}; "
+              f"emulation vs fp32 {e_emul:.3e}")
+        assert e_like < 2e-2, e_like
+        assert e_ref < 2 * e_emul + 1e-2, (e_ref, e_emul)
+    assert torch.equal(vae.decode(z.to(DEV), return_dict=False)[0], vae.decode(z.to(DEV), return_dict=False)[0])
+    zn = vae.denormalize_latents(z.to(DEV).float())
+    assert torch.allclose(zn.cpu(), z.float() / cfg.get("scaling_factor", 1.03682), atol=1e-6)

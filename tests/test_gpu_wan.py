@@ -73,13 +73,12 @@ def test_wan_matches_reference_wiring_golden(golden_dir):
     assert rel < 3e-2, rel
 
 
-def test_wan_full_width_one_block_matches_oracle():
+def test_wan_full_width_one_block_matches_oracle(host_threads):
     """Wan-2.2-A14B geometry (d 5120 = 40 x 128, ffn 13824, text 4096 x 512 tokens, patch (1,2,2)) with ONE block and a
     latent of 16 x 5 x 60 x 104 (S 7800: edge tiles in every GEMM, 31 attention query blocks) so the fp32 CPU oracle
     finishes in about a minute; the full-size tilings are what is being compared.  Same bars as the small configs."""
     cfg = dict(patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16,
                text_dim=4096, freq_dim=256, ffn_dim=13824, num_layers=1, cross_attn_norm=True, eps=1e-6)
-    torch.set_num_threads(os.cpu_count() or 1)
     orc = OW.WanTransformer3DModel(**cfg).eval()
     sd = synthetic_state_dict(orc, 9)
     orc.load_state_dict(sd, strict=True)

@@ -137,6 +137,28 @@ def test_vae_full_sequence_restatement_matches_streaming_reference(golden_dir):
     assert float((tiled - untiled).abs().max()) > 1e-3
 
 
+def test_hunyuan15_vae_restatement_matches_reference(golden_dir):
+    """oracle.vae_hunyuan15 against the reference AutoencoderKLHunyuanVideo15.decode (tests/golden/vae_hunyuan15.pt):
+    replicate-padded causal convs, frame-causal mid-block attention, DCAE pixel-shuffle upsampling with the first-frame
+    half-channel rule, and the 8x8-latent tiled decode with 32-px blends."""
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    from tests.golden.seeded import vae_synthetic_state_dict
+    g = _load(golden_dir, "vae_hunyuan15.pt")
+    vae = AutoencoderKLHunyuanVideo15(**g["config"]).eval()
+    assert sorted(vae.state_dict().keys()) == g["keys"]
+    vae.load_state_dict(vae_synthetic_state_dict(vae, g["seed"]), strict=True)
+    z = seeded(g["z_shape"], g["z_seed"])
+    untiled = vae.decode(z)
+    assert untiled.shape == g["untiled"].shape
+    assert torch.allclose(untiled[0, :, :, ::8, ::8], g["untiled_f32_sample"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(untiled, g["untiled"].float(), atol=8e-3, rtol=8e-3)     # golden stored in bf16
+    vae.enable_tiling()
+    tiled = vae.decode(z)
+    assert torch.allclose(tiled[0, :, :, ::8, ::8], g["tiled_f32_sample"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(tiled, g["tiled"].float(), atol=8e-3, rtol=8e-3)
+    assert float((tiled - untiled).abs().max()) > 1e-3
+
+
 def test_hunyuan15_wiring_matches_reference_blocks(golden_dir):
     """oracle.hunyuan15 against the reference's own HunyuanVideo-1.5 classes (hybrid oracle, float64 run): token
     refiner with a key-padding mask, t2v and i2v token orders, RoPE on latent tokens only, un-patchify."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the VAE decodes alone (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
-usage: vae_bench.py flux|wan [reps]"""
+usage: vae_bench.py flux|wan|hunyuan [reps]"""
 import os
 import sys
 import time
@@ -18,6 +18,11 @@ if which == "flux":
     from apex_studio_amd.vae_flux import AutoencoderKL
     vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
     z = torch.randn(1, 16, 128, 128, device=dev).to(torch.bfloat16)
+elif which == "hunyuan":      # HunyuanVideo-1.5 480p x 121 frames: latent [32, 31, 30, 52], 8x8-latent tiles
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    vae = synth_vae_init(AutoencoderKLHunyuanVideo15(device=dev, dtype=torch.bfloat16), 7)
+    vae.enable_tiling()
+    z = torch.randn(1, 32, 31, 30, 52, device=dev).to(torch.bfloat16)
 else:
     from apex_studio_amd.vae_wan import AutoencoderKLWan
     vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
