@@ -762,6 +762,49 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+// ---- row softmax with an additive bias and a key mask (text encoders: T5 / UMT5 relative-position bias shared by
+// the batch, CLIP's causal mask).  Grid (Sq, heads); f32 scores [heads, Sq, ldx] in, bf16 probabilities
+// [heads, Sq, ldo] out, zero beyond the kept keys.  p = softmax(x * scale + bias[head, row, :]) over the kept
+// columns; masked keys get exact zeros, which is what the reference's finfo.min additive mask yields in f32.
+__global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __restrict__ x, int64_t ldx, int Sq, int cols,
+                                                                float scale_log2e, const float* __restrict__ bias,
+                                                                int64_t bias_ld, const uint8_t* __restrict__ keep,
+                                                                int causal, bf16_t* __restrict__ out, int64_t ldo,
+                                                                int cols_pad) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = (int64_t)blockIdx.y * Sq + blockIdx.x;
+    const float* xr = x + row * ldx;
+    const float* br = bias ? bias + row * bias_ld : nullptr;
+    bf16_t* orow = out + row * ldo;
+    const int lim = causal ? min(cols, (int)blockIdx.x + 1) : cols;
+    constexpr float LOG2E = 1.4426950408889634f;
+    auto score = [&](int c) -> float {
+        if (c >= lim || (keep && !keep[c])) return -1.0e30f;
+        return fmaf(xr[c], scale_log2e, br ? br[c] * LOG2E : 0.0f);
+    };
+    float mx = -1.0e30f;
+    for (int c = tid; c < lim; c += 256) mx = fmaxf(mx, score(c));
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int c = tid; c < lim; c += 256) {
+        const float sc = score(c);
+        sum += sc > -1.0e29f ? fast_exp2(sc - mx) : 0.0f;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float tot = red[4] + red[5] + red[6] + red[7];
+    const float inv = tot > 0.0f ? 1.0f / tot : 0.0f;   // a row with no kept key (never produced by the encoders) -> zeros
+    for (int c = tid; c < cols_pad; c += 256) {
+        const float sc = score(c);
+        orow[c] = f32_to_bf16(sc > -1.0e29f ? fast_exp2(sc - mx) * inv : 0.0f);
+    }
+}
+
 // ---- generic fallback: any D <= 256, bf16 / f16 / f32, strided views; one workgroup per query row.
 // Exists so the operator survives the reference's backend verification probe
 // (B,H,S,D = 1,2,8,64 fp16; attention/functions.py:1999-2251) and odd head sizes (VAE C = 384 is
@@ -1059,4 +1102,62 @@ extern "C" int apexmi_attn_fwd_framecausal(const void* q, const void* k, const v
                                    APEXMI_BF16, workspace, workspace_bytes, stream_);
     g_causal_block = 0;
     return rc;
+}
+
+// ---- attention with an additive bias / key mask / causal mask over packed projections (text encoders) ----------
+namespace {
+size_t attn_bias_bytes(int H, int Sq, int Sk, int D) {
+    const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV, sk8 = (size_t)((Sk + 7) / 8) * 8;
+    return (size_t)H * Sq * sk8 * 4 + (size_t)H * Sq * skp * 2 + (size_t)H * D * skp * 2 +
+           (sk8 != (size_t)Sk ? sk8 * (size_t)H * D * 2 : 0);
+}
+}  // namespace
+
+extern "C" int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldw,
+                                        int64_t stride_w, void* C, int64_t ldc, int64_t stride_c, int batch, int M,
+                                        int N, int K, int epilogue, apexmi_stream_t stream);
+
+extern "C" size_t apexmi_attn_bias_workspace_bytes(int H, int Sq, int Sk, int D) { return attn_bias_bytes(H, Sq, Sk, D); }
+
+extern "C" int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                    void* out, int64_t ldo, int H, int Sq, int Sk, int D, float softmax_scale,
+                                    const float* bias, const uint8_t* keep, int causal, void* workspace,
+                                    size_t workspace_bytes, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && v && out && workspace, "attn_fwd_bias: null operand");
+    APEXMI_REQUIRE(H > 0 && Sq > 0 && Sk > 0, "attn_fwd_bias: empty problem");
+    APEXMI_REQUIRE(D % 64 == 0 && (H * D) % 128 == 0, "attn_fwd_bias: head dim %d must be a multiple of 64 and H*D=%d of 128", D, H * D);
+    APEXMI_REQUIRE(!causal || Sq == Sk, "attn_fwd_bias: the causal mask needs Sq == Sk");
+    APEXMI_REQUIRE(workspace_bytes >= attn_bias_bytes(H, Sq, Sk, D), "attn_fwd_bias: workspace too small (%zu < %zu)",
+                   workspace_bytes, attn_bias_bytes(H, Sq, Sk, D));
+    const int skp = ((Sk + KV - 1) / KV) * KV, sk8 = (Sk + 7) / 8 * 8;
+    float* sc = (float*)workspace;
+    bf16_t* pb = (bf16_t*)((char*)workspace + (size_t)H * Sq * sk8 * 4);
+    bf16_t* vt = pb + (size_t)H * Sq * skp;
+    bf16_t* kpad = vt + (size_t)H * D * skp;
+    const bf16_t* kp = (const bf16_t*)k;
+    if (sk8 != Sk) {   // the GEMM's weight operand comes in whole groups of 8 rows
+        if (hipMemcpy2DAsync(kpad, (size_t)H * D * 2, k, (size_t)ldk * 2, (size_t)H * D * 2, Sk, hipMemcpyDeviceToDevice,
+                             stream) != hipSuccess ||
+            hipMemsetAsync(kpad + (size_t)Sk * H * D, 0, (size_t)(sk8 - Sk) * H * D * 2, stream) != hipSuccess) {
+            apexmi_set_error("attn_fwd_bias: padding K failed");
+            return 1;
+        }
+        kp = kpad;
+        ldk = (int64_t)H * D;
+    }
+    // scores[h] = q_h k_h^T: one batched launch over the heads
+    if (int rc = apexmi_gemm_bf16_batched(q, ldq, D, kp, ldk, D, sc, sk8, (int64_t)Sq * sk8, H, Sq, sk8, D,
+                                          APEXMI_EPI_BIAS_F32, stream_))
+        return rc;
+    {
+        ApexmiProfScope prof(1, stream, 0.0, (double)H * Sq * Sk * 10.0);
+        hipLaunchKernelGGL(softmax_bias_rows_kernel, dim3(Sq, H), dim3(256), 0, stream, sc, (int64_t)sk8, Sq, Sk,
+                           softmax_scale * 1.4426950408889634f, bias, (int64_t)Sk, keep, causal, pb, (int64_t)skp, skp);
+        if (int rc = apexmi_check_launch("softmax_bias_rows")) return rc;
+    }
+    // V^T [H*D, skp] by 128-column slices of V (independent of the head size), zero-padded key columns
+    if (int rc = apexmi_v_transpose(v, 128, ldv, Sk, H * D / 128, 128, vt, skp, 0, stream_)) return rc;
+    return apexmi_gemm_bf16_batched(pb, skp, (int64_t)Sq * skp, vt, skp, (int64_t)D * skp, out, ldo, D, H, Sq, D, skp,
+                                    APEXMI_EPI_BIAS, stream_);
 }

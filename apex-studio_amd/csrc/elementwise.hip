@@ -517,6 +517,59 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict_
     *(u32x4*)(out + i * 8) = pack8(x);
 }
 
+// out = a * b (bf16, f32 product): `hidden_gelu * hidden_linear` of T5DenseGatedActDense (transformers
+// models/t5/modeling_t5.py, gated-gelu feed-forward of T5 v1.1 / UMT5)
+__global__ __launch_bounds__(256) void mul_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ out, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float x[8], y[8];
+    unpack8(*(const u32x4*)(a + i * 8), x);
+    unpack8(*(const u32x4*)(b + i * 8), y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] *= y[j];
+    *(u32x4*)(out + i * 8) = pack8(x);
+}
+
+// out[r, :] = table[ids[r], :] (+ pos[r % period, :]): nn.Embedding lookups of the text encoders (token embedding;
+// CLIPTextEmbeddings adds the learned position embedding of the row's position)
+__global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const bf16_t* __restrict__ table, int64_t ldt,
+                                                               const int64_t* __restrict__ ids, int64_t vocab,
+                                                               const bf16_t* __restrict__ pos, int64_t ldp, int period,
+                                                               bf16_t* __restrict__ out, int64_t ldo, int64_t rows,
+                                                               int c8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c8) return;
+    const int64_t r = i / c8;
+    const int c = (int)(i % c8) * 8;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-range ids are rejected on the host; never fault here
+    u32x4 val = *(const u32x4*)(table + id * ldt + c);
+    if (pos) {
+        float x[8], y[8];
+        unpack8(val, x);
+        unpack8(*(const u32x4*)(pos + (r % period) * ldp + c), y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        val = pack8(x);
+    }
+    *(u32x4*)(out + r * ldo + c) = val;
+}
+
+// bias[h, i, j] = weight[bucket[j - i + Sq - 1], h]: T5Attention.compute_bias (modeling_t5.py) with the bucket of every
+// relative distance j - i in [-(Sq-1), Sk-1] computed once on the host (integer / log arithmetic, 2S-1 values)
+__global__ __launch_bounds__(256) void relpos_bias_kernel(const bf16_t* __restrict__ weight, int H,
+                                                          const int* __restrict__ bucket, int Sq, int Sk,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)H * Sq * Sk;
+    if (i >= n) return;
+    const int j = (int)(i % Sk);
+    const int q = (int)((i / Sk) % Sq);
+    const int h = (int)(i / ((int64_t)Sk * Sq));
+    out[i] = bf16_to_f32(weight[(int64_t)bucket[j - q + Sq - 1] * H + h]);
+}
+
 }  // namespace
 
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
@@ -734,6 +787,45 @@ extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t 
     hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)out, n / 8);
     return apexmi_check_launch("add_bf16");
+}
+
+extern "C" int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "mul_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    APEXMI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                   "mul_bf16: operands must be 16-byte aligned");
+    ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(mul_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)out, n / 8);
+    return apexmi_check_launch("mul_bf16");
+}
+
+extern "C" int apexmi_gather_rows_bf16(const void* table, int64_t ldt, int64_t vocab, const int64_t* ids, const void* pos,
+                                       int64_t ldp, int period, void* out, int64_t ldo, int64_t rows, int C,
+                                       apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(table && ids && out && rows > 0 && vocab > 0, "gather_rows_bf16: bad arguments");
+    APEXMI_REQUIRE(C > 0 && C % 8 == 0 && ldt % 8 == 0 && ldo % 8 == 0 && (!pos || (ldp % 8 == 0 && period > 0)),
+                   "gather_rows_bf16: C=%d and the row strides must be multiples of 8", C);
+    APEXMI_REQUIRE(((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)pos % 16) == 0,
+                   "gather_rows_bf16: operands must be 16-byte aligned");
+    const int64_t n = rows * (C / 8);
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * (double)rows * C);
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)table, ldt, ids, vocab, (const bf16_t*)pos, ldp, pos ? period : 1, (bf16_t*)out, ldo,
+                       rows, C / 8);
+    return apexmi_check_launch("gather_rows_bf16");
+}
+
+extern "C" int apexmi_relpos_bias(const void* weight, int num_buckets, int H, const int* bucket, int Sq, int Sk,
+                                  float* out, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(weight && bucket && out && H > 0 && Sq > 0 && Sk > 0 && num_buckets > 0, "relpos_bias: bad arguments");
+    const int64_t n = (int64_t)H * Sq * Sk;
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * (double)n);
+    hipLaunchKernelGGL(relpos_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)weight, H,
+                       bucket, Sq, Sk, out);
+    return apexmi_check_launch("relpos_bias");
 }
 
 extern "C" int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream_) {

@@ -56,6 +56,9 @@ struct GemmProblem {
 struct GemmGroup {
     GemmProblem p[MAX_GROUPS];
     int count, K, total, group_m;
+    // batched mode (count == 1): blockIdx.y selects the batch element; strides in elements of A / W, bytes of C
+    int batch;
+    int64_t bsA, bsW, bsC_bytes;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -82,10 +85,11 @@ using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
 APEXMI_DEVICE float act_f(float x, int mode) {
     if (mode == 1) return gelu_tanh_f(x);
     if (mode == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (mode == 4) return x / (1.0f + __expf(-1.702f * x));   // quick_gelu (CLIP text MLP)
     return silu_f(x);
 }
 inline int act_mode(int epilogue) {
-    return epilogue == APEXMI_EPI_BIAS_GELU ? 1 : epilogue == APEXMI_EPI_BIAS_GELU_ERF ? 2 : epilogue == APEXMI_EPI_BIAS_SILU ? 3 : 0;
+    return epilogue == APEXMI_EPI_BIAS_GELU ? 1 : epilogue == APEXMI_EPI_BIAS_GELU_ERF ? 2 : epilogue == APEXMI_EPI_BIAS_SILU ? 3 : epilogue == APEXMI_EPI_BIAS_QUICK_GELU ? 4 : 0;
 }
 
 // exchange so that (a, b) = this lane's two 4-column groups (8g.., 8(g+1)..) become 8 CONSECUTIVE
@@ -291,7 +295,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
     for (int i = 1; i < MAX_GROUPS; ++i)
         if (i < G.count && s >= G.p[i].tile0) gi = i;
-    const GemmProblem& P = G.p[gi];
+    GemmProblem P = G.p[gi];
+    if (G.batch > 1) {   // uniform: one batch element per blockIdx.y (per-head attention GEMMs of the text encoders)
+        const int64_t z = blockIdx.y;
+        P.A += z * G.bsA;
+        P.W += z * G.bsW;
+        P.C = (bf16_t*)((char*)P.C + z * G.bsC_bytes);
+    }
     s -= P.tile0;
     const int nn = P.nn, N = P.N, M = P.M;
     const int GM = G.group_m;
@@ -793,7 +803,7 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     }
     G.total = t;
     G.group_m = g_group_m;
-    hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t), dim3(CFG::NT), CFG::LDS, stream, G);
+    hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t, G.batch), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }
 
@@ -859,16 +869,44 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                                 apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
-    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 5, "gemm_bf16: unknown epilogue %d", epilogue);
+    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 6, "gemm_bf16: unknown epilogue %d", epilogue);
     APEXMI_REQUIRE(epilogue != APEXMI_EPI_BIAS_F32 || ((uintptr_t)C % 16) == 0, "gemm_bf16: f32 output must be 16-byte aligned");
     GemmGroup G;
     G.count = 1;
     G.K = K;
+    G.batch = 1;
+    G.bsA = G.bsW = G.bsC_bytes = 0;
     G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, gate,
                          (const bf16_t*)R, lda, ldw, ldc, ldr, M, N, 0, 0, 0,
                          act_mode(epilogue)};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_group(G, &M, epi_kind(epilogue), stream);
+}
+
+extern "C" int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldw,
+                                        int64_t stride_w, void* C, int64_t ldc, int64_t stride_c, int batch, int M,
+                                        int N, int K, int epilogue, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, nullptr, nullptr, 0)) return rc;
+    APEXMI_REQUIRE(epilogue == APEXMI_EPI_BIAS || epilogue == APEXMI_EPI_BIAS_F32,
+                   "gemm_bf16_batched: epilogue %d unsupported (plain bf16 or f32 output only)", epilogue);
+    APEXMI_REQUIRE(batch >= 1 && batch <= 65535, "gemm_bf16_batched: batch=%d not in [1, 65535]", batch);
+    const int esz = epilogue == APEXMI_EPI_BIAS_F32 ? 4 : 2;
+    APEXMI_REQUIRE(stride_a % 8 == 0 && stride_w % 8 == 0 && (stride_c * esz) % 16 == 0,
+                   "gemm_bf16_batched: batch strides must keep every element 16-byte aligned");
+    APEXMI_REQUIRE(epilogue != APEXMI_EPI_BIAS_F32 || ((uintptr_t)C % 16) == 0, "gemm_bf16_batched: f32 output must be 16-byte aligned");
+    GemmGroup G;
+    G.count = 1;
+    G.K = K;
+    G.batch = batch;
+    G.bsA = stride_a;
+    G.bsW = stride_w;
+    G.bsC_bytes = stride_c * esz;
+    G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, nullptr, (bf16_t*)C, nullptr, nullptr, lda, ldw, ldc, 0,
+                         M, N, 0, 0, 0, 0};
+    ApexmiProfScope prof(0, stream, 2.0 * batch * M * N * (double)K,
+                         2.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
     return launch_group(G, &M, epi_kind(epilogue), stream);
 }
 
@@ -883,10 +921,12 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     GemmGroup G;
     G.count = count;
     G.K = K;
+    G.batch = 1;
+    G.bsA = G.bsW = G.bsC_bytes = 0;
     double flops = 0, bytes = 0;
     const int kind = epi_kind(epilogue[0]);
     for (int i = 0; i < count; ++i) {
-        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 5 && epi_kind(epilogue[i]) == kind,
+        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 6 && epi_kind(epilogue[i]) == kind,
                        "gemm_bf16_grouped: gate/residual problems cannot be mixed with bias/gelu ones");
         const float* g = gate ? gate[i] : nullptr;
         const void* r = R ? R[i] : nullptr;

@@ -36,6 +36,11 @@ SIGNATURES = {
                                            C.POINTER(vp), C.POINTER(vp), c_i64p, C.POINTER(C.c_int),
                                            C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(vp),
                                            C.POINTER(vp), c_i64p, vp]),
+    "apexmi_gemm_bf16_batched": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "apexmi_attn_bias_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "apexmi_attn_fwd_bias": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, vp, C.c_size_t, vp]),
     "apexmi_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                               C.c_int, C.c_int, vp]),
@@ -64,6 +69,10 @@ SIGNATURES = {
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
     "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
     "apexmi_add_rowvec_bf16": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]),
+    "apexmi_mul_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "apexmi_gather_rows_bf16": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int, vp, C.c_int64,
+                                          C.c_int64, C.c_int, vp]),
+    "apexmi_relpos_bias": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
     "apexmi_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_int64, vp]),
     "apexmi_dequant_fp8_scaled": (C.c_int, [vp, C.c_int, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64, vp]),
@@ -78,7 +87,7 @@ NCLASS = 6
 PROF_CLASSES = ("gemm", "attention", "gemv", "ln_modulate", "qkv_prepare", "other")
 
 BF16, F16, F32 = 0, 1, 2
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_F32, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU = 0, 1, 2, 3, 4, 5
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_F32, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU, EPI_BIAS_QUICK_GELU = 0, 1, 2, 3, 4, 5, 6
 GEMV_PRE_SILU, GEMV_POST_SILU, GEMV_POST_GELU, GEMV_ACCUM = 1, 2, 4, 8
 ROPE_INTERLEAVED, ROPE_COMPLEX, ROPE_NONE = 0, 1, 2
 

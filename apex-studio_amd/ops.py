@@ -29,7 +29,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES,
-        "gelu_erf": _l.EPI_BIAS_GELU_ERF, "silu": _l.EPI_BIAS_SILU}
+        "gelu_erf": _l.EPI_BIAS_GELU_ERF, "silu": _l.EPI_BIAS_SILU, "quick_gelu": _l.EPI_BIAS_QUICK_GELU}
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -290,6 +290,83 @@ def attention_framecausal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tok
                                          float(softmax_scale), ws.data_ptr(), need, _stream())
     _l.check(rc, "attn_fwd_framecausal")
     return out.permute(0, 2, 1, 3)
+
+
+def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, softmax_scale: float,
+                   bias: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None,
+                   causal: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Text-encoder self-attention over packed projections: q [Sq, H*D], k, v [Sk, H*D] bf16 (row-strided views of a
+    fused QKV buffer welcome), bias f32 [H, Sq, Sk] (T5 relative-position bias), keep uint8 [Sk] (0 = padded key).
+    Returns [Sq, H*D]."""
+    _req(q, torch.bfloat16, "attention_bias.q")
+    _req(k, torch.bfloat16, "attention_bias.k")
+    _req(v, torch.bfloat16, "attention_bias.v")
+    assert q.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    Sq, inner = q.shape
+    Sk = k.shape[0]
+    D = inner // heads
+    if out is None:
+        out = torch.empty((Sq, inner), dtype=torch.bfloat16, device=q.device)
+    if bias is not None:
+        _req(bias, torch.float32, "attention_bias.bias")
+        assert bias.is_contiguous() and bias.shape == (heads, Sq, Sk)
+    if keep is not None:
+        _req(keep, torch.uint8, "attention_bias.keep")
+        assert keep.is_contiguous() and keep.numel() == Sk
+    lib = _l.load()
+    need = lib.apexmi_attn_bias_workspace_bytes(heads, Sq, Sk, D)
+    key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _ws_cache[key] = ws
+    rc = lib.apexmi_attn_fwd_bias(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                  out.data_ptr(), out.stride(0), heads, Sq, Sk, D, float(softmax_scale), _ptr(bias),
+                                  _ptr(keep), 1 if causal else 0, ws.data_ptr(), need, _stream())
+    _l.check(rc, "attn_fwd_bias")
+    return out
+
+
+def relpos_bias(weight: torch.Tensor, bucket: torch.Tensor, Sq: int, Sk: int) -> torch.Tensor:
+    """weight bf16 [num_buckets, H], bucket int32 [Sq + Sk - 1] (device) -> f32 [H, Sq, Sk]."""
+    _req(weight, torch.bfloat16, "relpos_bias.weight")
+    _req(bucket, torch.int32, "relpos_bias.bucket")
+    assert weight.is_contiguous() and bucket.is_contiguous() and bucket.numel() == Sq + Sk - 1
+    nb, H = weight.shape
+    out = torch.empty((H, Sq, Sk), dtype=torch.float32, device=weight.device)
+    _l.check(_l.load().apexmi_relpos_bias(weight.data_ptr(), nb, H, bucket.data_ptr(), Sq, Sk, out.data_ptr(), _stream()),
+             "relpos_bias")
+    return out
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """table[ids] (+ pos[row % len(pos)]): bf16 [vocab, C], ids int64 [rows] on the device -> [rows, C]."""
+    _req(table, torch.bfloat16, "gather_rows.table")
+    _req(ids, torch.int64, "gather_rows.ids")
+    assert table.dim() == 2 and table.stride(1) == 1 and ids.dim() == 1 and ids.is_contiguous()
+    rows, Cc = ids.numel(), table.shape[1]
+    out = torch.empty((rows, Cc), dtype=torch.bfloat16, device=table.device)
+    period = 1
+    if pos is not None:
+        _req(pos, torch.bfloat16, "gather_rows.pos")
+        assert pos.dim() == 2 and pos.stride(1) == 1 and pos.shape[1] == Cc
+        period = pos.shape[0]
+    rc = _l.load().apexmi_gather_rows_bf16(table.data_ptr(), table.stride(0), table.shape[0], ids.data_ptr(), _ptr(pos),
+                                           pos.stride(0) if pos is not None else 0, period, out.data_ptr(), out.stride(0),
+                                           rows, Cc, _stream())
+    _l.check(rc, "gather_rows_bf16")
+    return out
+
+
+def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a * b for contiguous bf16 tensors of equal shape (numel a multiple of 8)."""
+    _req(a, torch.bfloat16, "mul.a")
+    _req(b, torch.bfloat16, "mul.b")
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    _l.check(_l.load().apexmi_mul_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mul_bf16")
+    return out
 
 
 def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -35,6 +35,7 @@ typedef void* apexmi_stream_t; /* a hipStream_t; NULL = the null stream */
 #define APEXMI_EPI_BIAS_GELU 1     /* C = gelu_tanh(A W^T + b)                        */
 #define APEXMI_EPI_BIAS_GATE_RES 2 /* C = R + gate[n] * (A W^T + b)   (R may alias C) */
 #define APEXMI_EPI_BIAS_GELU_ERF 4 /* C = gelu_erf(A W^T + b): nn.GELU() of the HunyuanVideo-1.5 text/image projections */
+#define APEXMI_EPI_BIAS_QUICK_GELU 6 /* C = x sigmoid(1.702 x), x = A W^T + b: CLIPMLP (transformers "quick_gelu")         */
 #define APEXMI_EPI_BIAS_SILU 5     /* C = silu(A W^T + b): the "linear-silu" FeedForward of its token refiner        */
 #define APEXMI_EPI_BIAS_F32 3      /* C = A W^T + b stored as float (C is float*, ldc in floats): attention scores */
 
@@ -122,6 +123,27 @@ int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda
                              void* const* C, const int64_t* ldc, const int* M, const int* N, int K,
                              const int* epilogue, const float* const* gate, const void* const* R,
                              const int64_t* ldr, apexmi_stream_t stream);
+
+/* Batched C[z] = A[z] W[z]^T over blockIdx.y (z < batch <= 65535): per-head GEMMs of one attention layer in one launch.
+ * Strides in elements; epilogue APEXMI_EPI_BIAS (bf16 C, no bias) or APEXMI_EPI_BIAS_F32 (float C).  Same kernels and
+ * argument rules as apexmi_gemm_bf16. */
+int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldw, int64_t stride_w,
+                             void* C, int64_t ldc, int64_t stride_c, int batch, int M, int N, int K, int epilogue,
+                             apexmi_stream_t stream);
+
+/* Self-attention of the text encoders the reference loads by class name from `transformers` (pinned 4.57.1,
+ * R/requirements/requirements.txt:79; call site R/src/text_encoder/text_encoder.py:335-342):
+ *   T5Attention / UMT5Attention.forward: softmax(q k^T + position_bias + mask) v, NO 1/sqrt(d) scaling (scale = 1);
+ *   CLIPAttention.forward: softmax(q k^T / sqrt(d) + causal mask) v.
+ * q, k, v, out: bf16 [S, H*D] projections (row strides ldq/ldk/ldv/ldo), head h in columns [h D, (h+1) D).
+ * bias: f32 [H, Sq, Sk] or NULL; keep: uint8 [Sk], 0 = padded key (NULL = all kept); causal != 0 adds the causal mask.
+ * Masked keys get probability exactly 0 (what the additive finfo.min mask gives in f32).  D a multiple of 64, H*D of
+ * 128.  Materialised: batched scores GEMM (f32), row softmax, batched P V GEMM; workspace from the _bytes query. */
+size_t apexmi_attn_bias_workspace_bytes(int H, int Sq, int Sk, int D);
+int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out,
+                         int64_t ldo, int H, int Sq, int Sk, int D, float softmax_scale, const float* bias,
+                         const uint8_t* keep, int causal, void* workspace, size_t workspace_bytes,
+                         apexmi_stream_t stream);
 
 /* Tuning knobs for A/B measurements (bench.py, tests): "gemm.config" = 0 auto | 1 128x128 |
  * 2 256x256 | 3 256x256 ping-pong; "attn.waves" = 0 auto | 4 | 8 waves per attention workgroup.
@@ -242,6 +264,21 @@ int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out,
 /* out = a + b, n bf16 elements (n % 8 == 0): `h + shortcut` after the DCAE rearranges of the HunyuanVideo-1.5 VAE
  * (vae/hunyuanvideo15/model.py:274, :709-711). */
 int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
+
+/* out = a * b, contiguous bf16, n a multiple of 8 (T5DenseGatedActDense: hidden_gelu * hidden_linear). */
+int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
+
+/* out[r, :] = table[ids[r], :] (+ pos[r % period, :] when pos != NULL): the nn.Embedding lookups of T5Stack
+ * (`shared`) and CLIPTextEmbeddings (token + position).  ids int64 on the device, clamped to [0, vocab). */
+int apexmi_gather_rows_bf16(const void* table, int64_t ldt, int64_t vocab, const int64_t* ids, const void* pos,
+                            int64_t ldp, int period, void* out, int64_t ldo, int64_t rows, int C,
+                            apexmi_stream_t stream);
+
+/* T5Attention.compute_bias: out[h, i, j] = weight[bucket[j - i + Sq - 1], h]; weight bf16 [num_buckets, H]
+ * (relative_attention_bias.weight), bucket int32 [Sq + Sk - 1] on the device = _relative_position_bucket of every
+ * distance, computed by the caller. */
+int apexmi_relpos_bias(const void* weight, int num_buckets, int H, const int* bucket, int Sq, int Sk, float* out,
+                       apexmi_stream_t stream);
 
 /* f32 <-> bf16 helpers for the small conditioning vectors. */
 int apexmi_cast_f32_to_bf16(const float* x, void* out, int64_t n, apexmi_stream_t stream);

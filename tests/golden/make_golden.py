@@ -170,7 +170,7 @@ def load_by_path(name, rel):
     return mod
 
 
-from tests.golden.seeded import seeded, synthetic_state_dict, vae_synthetic_state_dict  # noqa: E402
+from tests.golden.seeded import seeded, synthetic_state_dict, text_encoder_state_dict, vae_synthetic_state_dict  # noqa: E402
 
 
 def gen_attention():
@@ -521,6 +521,70 @@ def gen_fp_scaled():
     torch.save(cases, os.path.join(OUT, "fp_scaled.pt"))
 
 
+TINY_T5 = dict(vocab_size=100, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2,
+               relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6,
+               feed_forward_proj="gated-gelu")
+TINY_CLIP = dict(vocab_size=100, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                 max_position_embeddings=24, layer_norm_eps=1e-5, hidden_act="quick_gelu", eos_token_id=2)
+
+
+def gen_text_encoders():
+    """The text encoders the reference resolves by class name from `transformers` (text_encoder/text_encoder.py:24-82,
+    :335-342): T5EncoderModel, UMT5EncoderModel, CLIPTextModel of the transformers build installed HERE, small configs,
+    fp32, with and without a padding mask.  The third-party package itself is the reference for this row."""
+    import transformers
+    from oracle import text_encoders as OT
+    out = dict(transformers_version=transformers.__version__, t5_config=TINY_T5, clip_config=TINY_CLIP)
+    S = 21
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 100, (2, S), generator=g)
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, 13:] = 0
+    ids[1, 13:] = 0                                            # pad id
+    out["t5_ids"], out["t5_mask"] = ids, mask
+    for name, hf_cls, cfg_cls, extra in (("t5", transformers.T5EncoderModel, transformers.T5Config, {}),
+                                         ("t5_relu", transformers.T5EncoderModel, transformers.T5Config,
+                                          dict(feed_forward_proj="relu")),
+                                         ("umt5", transformers.UMT5EncoderModel, transformers.UMT5Config, {})):
+        kw = {**TINY_T5, **extra}
+        orc = OT.T5EncoderModel(**kw, per_layer_bias=(name == "umt5")).eval()
+        sd = text_encoder_state_dict(orc, 23, 24, "layer_norm.weight")
+        sd.pop("encoder.embed_tokens.weight", None)              # tied to `shared.weight`
+        hf = hf_cls(cfg_cls(**kw, is_decoder=False, use_cache=False, dropout_rate=0.0)).eval().float()
+        res = hf.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
+        assert all(k in ("encoder.embed_tokens.weight",) for k in res.missing_keys), res.missing_keys
+        with torch.no_grad():
+            a = hf(input_ids=ids, output_hidden_states=True)
+            b = hf(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+        out[name] = dict(keys=sorted(sd.keys()), seed=23, last=a.last_hidden_state, hidden1=a.hidden_states[1],
+                         n_hidden=len(a.hidden_states), last_masked=b.last_hidden_state)
+        print("text", name, float(a.last_hidden_state.abs().mean()), float((a.last_hidden_state - b.last_hidden_state).abs().max()))
+    S = 19
+    ids = torch.randint(3, 99, (2, S), generator=g)
+    ids[0, 11], ids[1, 16] = 99, 99                              # EOS = highest id (legacy argmax pooling, eos_token_id == 2)
+    ids[0, 12:], ids[1, 17:] = 0, 0
+    mask = (ids != 0).long()
+    orc = OT.CLIPTextModel(**TINY_CLIP).eval()
+    sd = text_encoder_state_dict(orc, 29, 30, "layer_norm")
+    hf = transformers.CLIPTextModel(transformers.CLIPTextConfig(**TINY_CLIP, attention_dropout=0.0, bos_token_id=1,
+                                                                pad_token_id=0)).eval().float()
+    # checkpoints (and transformers 4.57, the reference's pin) carry a `text_model.` prefix; 5.x modules dropped it
+    flat = not any(k.startswith("text_model.") for k in hf.state_dict())
+    res = hf.load_state_dict({(k[len("text_model."):] if flat else k): v for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all("position_ids" in k for k in res.missing_keys), res.missing_keys
+    with torch.no_grad():
+        a = hf(input_ids=ids, output_hidden_states=True)
+        b = hf(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+    out["clip_ids"], out["clip_mask"] = ids, mask
+    out["clip"] = dict(keys=sorted(sd.keys()), seed=29, last=a.last_hidden_state, pooled=a.pooler_output,
+                       hidden_m2=a.hidden_states[-2], n_hidden=len(a.hidden_states), last_masked=b.last_hidden_state,
+                       pooled_masked=b.pooler_output)
+    print("text clip", float(a.pooler_output.abs().mean()), float((a.pooler_output - b.pooler_output).abs().max()))
+    torch.save(out, os.path.join(OUT, "text_encoders.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -535,7 +599,14 @@ def main():
     gen_unipc()
     gen_lora()
     gen_fp_scaled()
+    gen_text_encoders()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py text_encoders vae_hunyuan15 ...
+        os.makedirs(OUT, exist_ok=True)
+        install_stubs()
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+    else:
+        main()

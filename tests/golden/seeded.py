@@ -40,3 +40,15 @@ def vae_synthetic_state_dict(model, seed=13):
             w = torch.randn(p.shape, generator=g) / fan_in ** 0.5
         sd[name] = w.to(torch.bfloat16).to(torch.float32)
     return sd
+
+
+def text_encoder_state_dict(model, seed: int, norm_seed: int, norm_tag: str):
+    """synthetic_state_dict with the (RMS / Layer) norm weights drawn around 1 — what make_golden.gen_text_encoders used."""
+    sd = synthetic_state_dict(model, seed)
+    for k in [k for k in sd if norm_tag in k and k.endswith("weight")]:
+        sd[k] = 1.0 + 0.1 * seeded(sd[k].shape, norm_seed + len(k)).to(torch.bfloat16).float()
+    # T5 attention has no 1/sqrt(d_kv): trained checkpoints carry that factor in q.  Without it random weights give
+    # near one-hot softmaxes whose argmax flips under any rounding, and the comparison measures chaos, not kernels.
+    for k in [k for k in sd if k.endswith("SelfAttention.q.weight")]:
+        sd[k] = sd[k] * 0.125
+    return sd

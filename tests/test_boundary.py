@@ -102,3 +102,32 @@ def test_wan_and_qwen_class_contracts_on_meta_device():
         WanTransformer3DModel(image_dim=1280, device="meta")
     with pytest.raises(NotImplementedError):
         QwenImageTransformer2DModel(zero_cond_t=True, device="meta")
+
+
+def test_text_encoder_class_contracts_match_transformers():
+    """The text-encoder drop-ins are resolved by class name from a module (text_encoder/text_encoder.py:24-82) and built
+    through `_from_config(config_dict)` (loader_mixin.py:249-257): same class names, same parameter names and shapes as
+    the `transformers` classes (keys of the 4.57 layout the checkpoints use), and no CPU fallback."""
+    import transformers
+    from apex_studio_amd import text_encoders as TE
+    from apex_studio_amd.lib import ApexMIError
+    t5 = dict(vocab_size=64, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2, feed_forward_proj="gated-gelu")
+    for name, cfg_cls in (("T5EncoderModel", transformers.T5Config), ("UMT5EncoderModel", transformers.UMT5Config)):
+        mine = getattr(TE, name)._from_config(t5, device="meta")
+        hf = getattr(transformers, name)(cfg_cls(**t5))
+        ref = {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+        got = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+        assert got == ref, (name, set(got) ^ set(ref))
+    clip = dict(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                max_position_embeddings=16)
+    mine = TE.CLIPTextModel.from_config(clip, device="meta")
+    hf = transformers.CLIPTextModel(transformers.CLIPTextConfig(**clip, bos_token_id=1, pad_token_id=0, eos_token_id=2))
+    ref = {k if k.startswith("text_model.") else "text_model." + k: tuple(v.shape) for k, v in hf.state_dict().items()
+           if "position_ids" not in k}
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == ref
+    assert mine.config.hidden_act == "quick_gelu" and mine.config.get("eos_token_id") == 2
+    cpu = TE.T5EncoderModel(t5, dtype=torch.bfloat16)
+    with pytest.raises(ApexMIError):
+        cpu(input_ids=torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        TE.T5EncoderModel(dict(t5, feed_forward_proj="relu"), device="meta")

@@ -175,3 +175,45 @@ def test_hunyuan15_wiring_matches_reference_blocks(golden_dir):
         ref = g["out"][name]
         rel = float((out - ref).norm() / ref.norm())
         assert rel < 1e-5, (name, rel)
+
+
+def _text_sd(model, seed, norm_seed, tag):
+    from tests.golden.seeded import text_encoder_state_dict
+    sd = text_encoder_state_dict(model, seed, norm_seed, tag)
+    sd.pop("encoder.embed_tokens.weight", None)
+    return sd
+
+
+def test_text_encoders_restatement_matches_transformers(golden_dir):
+    """oracle.text_encoders against the `transformers` classes the reference loads by name (text_encoder.py:24-82):
+    T5 (gated-gelu and relu feed-forward), UMT5 (per-layer position bias), CLIP text (causal, quick-gelu, EOS pooling),
+    with and without a padding mask (tests/golden/text_encoders.pt, generated from the package installed here)."""
+    from oracle import text_encoders as OT
+    g = torch.load(os.path.join(golden_dir, "text_encoders.pt"), weights_only=False)
+    ids, mask = g["t5_ids"], g["t5_mask"]
+    for name, extra in (("t5", {}), ("t5_relu", dict(feed_forward_proj="relu")), ("umt5", dict(per_layer_bias=True))):
+        c = g[name]
+        m = OT.T5EncoderModel(**{**g["t5_config"], **extra}).eval()
+        assert sorted(m.state_dict().keys()) == sorted(c["keys"] + ["encoder.embed_tokens.weight"]), name
+        sd = _text_sd(m, c["seed"], 24, "layer_norm.weight")
+        m.load_state_dict(sd, strict=False)
+        out = m(ids)
+        assert len(out.hidden_states) == c["n_hidden"]
+        assert torch.allclose(out.last_hidden_state, c["last"], atol=2e-5, rtol=1e-4), name
+        assert torch.allclose(out.hidden_states[1], c["hidden1"], atol=2e-5, rtol=1e-4), name
+        outm = m(ids, attention_mask=mask)
+        real = mask.bool()
+        assert torch.allclose(outm.last_hidden_state[real], c["last_masked"][real], atol=2e-5, rtol=1e-4), name
+    c = g["clip"]
+    m = OT.CLIPTextModel(**g["clip_config"]).eval()
+    assert sorted(m.state_dict().keys()) == c["keys"]
+    m.load_state_dict(_text_sd(m, c["seed"], 30, "layer_norm"), strict=True)
+    out = m(g["clip_ids"])
+    assert len(out.hidden_states) == c["n_hidden"]
+    assert torch.allclose(out.last_hidden_state, c["last"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(out.pooler_output, c["pooled"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(out.hidden_states[-2], c["hidden_m2"], atol=2e-5, rtol=1e-4)
+    outm = m(g["clip_ids"], attention_mask=g["clip_mask"])
+    real = g["clip_mask"].bool()
+    assert torch.allclose(outm.last_hidden_state[real], c["last_masked"][real], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(outm.pooler_output, c["pooled_masked"], atol=2e-5, rtol=1e-4)
