@@ -899,7 +899,6 @@ int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
 int g_attn_c4 = 1;  // apexmi_tune_set("attn.c4", 0|1|2): 8-wave launches use the 4-cluster ping-pong kernel (shipped: -3.4 % per
                     // attention launch in the Flux and HunyuanVideo steps); 0 = plain loop, 2 = with s_setprio in the matrix clusters
 }  // namespace
-namespace { int g_causal_block = 0; }  // set only inside apexmi_attn_fwd_framecausal
 namespace {
 int g_attn_mfma = 32;  // 32: 32x32x16 kernel (shipped: 3 % faster in the Flux step), 16: 16x16x32 kernel (apexmi_tune_set "attn.mfma")
 
@@ -909,15 +908,14 @@ bool packed_bhsd(const int64_t* st, int H, int S, int D) {
 }
 
 
-extern int g_causal_block;
 
 // workspace layout of the materialised path: [scores f32 Sq x Sk8][P bf16 Sq x Skp][V^T bf16 D x Skp][K bf16 Sk8 x D]
 // (Sk8 = Sk rounded up to 8: the GEMM writes whole 8-column groups; the zero-padded K copy exists only when Sk8 != Sk)
 bool use_materialised(int Sq, int Sk, int D, int dtype, const int64_t* qs, const int64_t* ks, const int64_t* vs,
-                      const int64_t* os) {
+                      const int64_t* os, int causal_block) {
     // D = 128 belongs to the flash kernels, except under the frame-causal mask (they carry no mask)
-    return dtype == APEXMI_BF16 && (D != HD || g_causal_block > 0) && D % 128 == 0 && D <= 1024 &&
-           ((int64_t)Sq * Sk >= 256 * 256 || g_causal_block > 0) && qs[2] % 8 == 0 && ks[2] % 8 == 0 && vs[2] % 8 == 0 &&
+    return dtype == APEXMI_BF16 && (D != HD || causal_block > 0) && D % 128 == 0 && D <= 1024 &&
+           ((int64_t)Sq * Sk >= 256 * 256 || causal_block > 0) && qs[2] % 8 == 0 && ks[2] % 8 == 0 && vs[2] % 8 == 0 &&
            os[1] % 8 == 0;
 }
 size_t materialised_bytes(int Sq, int Sk, int D) {
@@ -991,15 +989,15 @@ extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int 
 int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int D, void* out,
                      hipStream_t stream);
 
-extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void* out, int B, int H,
-                               int Sq, int Sk, int D, const int64_t q_strides[3],
-                               const int64_t k_strides[3], const int64_t v_strides[3],
-                               const int64_t o_strides[3], float softmax_scale, int dtype,
-                               void* workspace, size_t workspace_bytes, apexmi_stream_t stream_) {
+// causal_block > 0: frame-causal mask with that many tokens per frame (materialised path only)
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
+                         const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+                         const int64_t o_strides[3], float softmax_scale, int dtype, void* workspace,
+                         size_t workspace_bytes, int causal_block, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(q && k && v && out, "attn_fwd: null operand");
     APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0 && D > 0, "attn_fwd: empty problem");
-    if (dtype == APEXMI_BF16 && D == HD && g_causal_block == 0) {
+    if (dtype == APEXMI_BF16 && D == HD && causal_block == 0) {
         const size_t need = apexmi_attn_workspace_bytes(B, H, Sq, Sk, D, dtype);
         APEXMI_REQUIRE(workspace && workspace_bytes >= need,
                        "attn_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -1027,7 +1025,7 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
         return apexmi_attn_fwd_prepared(qp, kp, vt, out, B, H, Sq, Sk, skp, o_strides, softmax_scale,
                                         stream);
     }
-    if (use_materialised(Sq, Sk, D, dtype, q_strides, k_strides, v_strides, o_strides) && workspace &&
+    if (use_materialised(Sq, Sk, D, dtype, q_strides, k_strides, v_strides, o_strides, causal_block) && workspace &&
         workspace_bytes >= materialised_bytes(Sq, Sk, D)) {
         const int skp = ((Sk + KV - 1) / KV) * KV, sk8 = (Sk + 7) / 8 * 8;
         float* sc = (float*)workspace;
@@ -1058,7 +1056,7 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
                 {
                     ApexmiProfScope prof(1, stream, 0.0, (double)Sq * Sk * 6.0);
                     hipLaunchKernelGGL(softmax_rows_kernel, dim3(Sq), dim3(256), 0, stream, sc, (int64_t)sk8, Sk, c, pb,
-                                       (int64_t)skp, skp, g_causal_block);
+                                       (int64_t)skp, skp, causal_block);
                     if (int rc = apexmi_check_launch("softmax_rows")) return rc;
                 }
                 // V^T [D, skp]: the 128-wide transpose kernel over D / 128 column slices
@@ -1069,6 +1067,7 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
             }
         return 0;
     }
+    APEXMI_REQUIRE(causal_block == 0, "attn_fwd_framecausal: operand strides must be multiples of 8 elements");
     APEXMI_REQUIRE(D <= GEN_THREADS, "attn_fwd: head dim %d > %d unsupported", D, GEN_THREADS);
     ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * D, 0.0);
     switch (dtype) {
@@ -1087,6 +1086,15 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
     }
 }
 
+extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void* out, int B, int H,
+                               int Sq, int Sk, int D, const int64_t q_strides[3],
+                               const int64_t k_strides[3], const int64_t v_strides[3],
+                               const int64_t o_strides[3], float softmax_scale, int dtype,
+                               void* workspace, size_t workspace_bytes, apexmi_stream_t stream_) {
+    return attn_fwd_impl(q, k, v, out, B, H, Sq, Sk, D, q_strides, k_strides, v_strides, o_strides, softmax_scale, dtype,
+                         workspace, workspace_bytes, 0, stream_);
+}
+
 extern "C" size_t apexmi_attn_framecausal_workspace_bytes(int S, int D) { return materialised_bytes(S, S, D); }
 
 extern "C" int apexmi_attn_fwd_framecausal(const void* q, const void* k, const void* v, void* out, int B, int H,
@@ -1097,11 +1105,8 @@ extern "C" int apexmi_attn_fwd_framecausal(const void* q, const void* k, const v
     APEXMI_REQUIRE(block > 0 && S % block == 0, "attn_fwd_framecausal: S=%d is not a whole number of frames of %d tokens", S, block);
     APEXMI_REQUIRE(D % 128 == 0 && D <= 1024, "attn_fwd_framecausal: D=%d must be a multiple of 128 (<= 1024)", D);
     APEXMI_REQUIRE(workspace && workspace_bytes >= materialised_bytes(S, S, D), "attn_fwd_framecausal: workspace too small");
-    g_causal_block = block;
-    const int rc = apexmi_attn_fwd(q, k, v, out, B, H, S, S, D, q_strides, k_strides, v_strides, o_strides, softmax_scale,
-                                   APEXMI_BF16, workspace, workspace_bytes, stream_);
-    g_causal_block = 0;
-    return rc;
+    return attn_fwd_impl(q, k, v, out, B, H, S, S, D, q_strides, k_strides, v_strides, o_strides, softmax_scale,
+                         APEXMI_BF16, workspace, workspace_bytes, block, stream_);
 }
 
 // ---- attention with an additive bias / key mask / causal mask over packed projections (text encoders) ----------

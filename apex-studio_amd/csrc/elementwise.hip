@@ -570,6 +570,28 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const bf16_t* __restri
     out[i] = bf16_to_f32(weight[(int64_t)bucket[j - q + Sq - 1] * H + h]);
 }
 
+// frames[t, y, x, c] = uint8(round(clamp(v * 0.5 + 0.5, 0, 1) * 255)) for v = video[c, t, y, x] (any strides): the
+// denormalize -> permute -> (x 255).round().astype(uint8) chain of diffusers VideoProcessor.postprocess_video that
+// BaseEngine._tensor_to_frames calls (engine/base_engine.py:2945-2949).  The reference runs denormalize in the decode
+// dtype, so for bf16 input the sum v/2 + 1/2 is rounded to bf16 before the scaling — reproduced here, bit for bit.
+__global__ __launch_bounds__(256) void frames_to_u8_kernel(const bf16_t* __restrict__ x, int64_t sc, int64_t st, int64_t sy,
+                                                           int64_t sx, int C, int T, int H, int W,
+                                                           uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)T * H * W;
+    if (i >= n) return;
+    const int xw = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int t = (int)(i / ((int64_t)W * H));
+    const bf16_t* p = x + t * st + y * sy + xw * sx;
+    for (int c = 0; c < C; ++c) {
+        const float half = bf16_to_f32(f32_to_bf16(bf16_to_f32(p[c * sc]) * 0.5f));
+        float u = bf16_to_f32(f32_to_bf16(half + 0.5f));
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        out[i * C + c] = (uint8_t)rintf(u * 255.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
@@ -787,6 +809,17 @@ extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t 
     hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)out, n / 8);
     return apexmi_check_launch("add_bf16");
+}
+
+extern "C" int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h,
+                                   int64_t stride_w, int C, int T, int H, int W, void* out, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(video && out && C > 0 && C <= 4 && T > 0 && H > 0 && W > 0, "frames_to_u8: bad arguments (C=%d)", C);
+    const int64_t n = (int64_t)T * H * W;
+    ApexmiProfScope prof(5, stream, 0.0, 3.0 * (double)n * C);
+    hipLaunchKernelGGL(frames_to_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)video,
+                       stride_c, stride_t, stride_h, stride_w, C, T, H, W, (uint8_t*)out);
+    return apexmi_check_launch("frames_to_u8");
 }
 
 extern "C" int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {

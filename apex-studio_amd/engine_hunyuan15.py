@@ -87,7 +87,7 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             negative_prompt_embeds_mask_2=None, height: int = 480, width: int = 832, num_frames: int = 121,
             num_inference_steps: int = 50, guidance_scale: float = 6.0, guidance_rescale: float = 0.0, sigmas=None,
             seed: Optional[int] = None, generator: Optional[torch.Generator] = None, latents=None,
-            return_latents: bool = False, progress_callback=None, **_ignored):
+            return_latents: bool = False, progress_callback=None, output_type: Optional[str] = None, **_ignored):
         dev, dt = self.device, self.transformer.dtype
         B = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
@@ -131,4 +131,7 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         _emit(progress_callback, 0.94, "Decoding latents")
         video = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents)
         _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
+        if output_type is not None:      # t2v.py: `self._tensor_to_frames(video)` — uint8 frames made on the GPU
+            from .postprocess import tensor_to_frames
+            return tensor_to_frames(video, output_type)
         return video

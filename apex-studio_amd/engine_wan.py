@@ -95,7 +95,7 @@ class WanT2VEngine(EngineLoraMixin):
             guidance_scale: Union[float, List[float]] = (4.0, 3.0), seed: Optional[int] = None,
             generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
             return_latents: bool = False, progress_callback=None, render_on_step: bool = False,
-            render_on_step_callback=None, render_on_step_interval: int = 3, **_ignored):
+            render_on_step_callback=None, render_on_step_interval: int = 3, output_type: Optional[str] = None, **_ignored):
         dev = self.device
         B = prompt_embeds.shape[0]
         num_latent_frames = (duration - 1) // self.vae_scale_factor_temporal + 1
@@ -134,4 +134,7 @@ class WanT2VEngine(EngineLoraMixin):
         _emit(progress_callback, 0.92, "Decoding video")
         video = self.vae_decode(latents)
         _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
+        if output_type is not None:      # t2v.py: `self._tensor_to_frames(video)` — uint8 frames made on the GPU
+            from .postprocess import tensor_to_frames
+            return tensor_to_frames(video, output_type)
         return video

@@ -358,6 +358,18 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, pos: Optional[torch.Tens
     return out
 
 
+def frames_to_u8(video: torch.Tensor) -> torch.Tensor:
+    """bf16 video [C, T, H, W] (any strides) in [-1, 1] -> uint8 frames [T, H, W, C]."""
+    _req(video, torch.bfloat16, "frames_to_u8.video")
+    assert video.dim() == 4
+    Cc, T, H, W = video.shape
+    out = torch.empty((T, H, W, Cc), dtype=torch.uint8, device=video.device)
+    rc = _l.load().apexmi_frames_to_u8(video.data_ptr(), video.stride(0), video.stride(1), video.stride(2), video.stride(3),
+                                       Cc, T, H, W, out.data_ptr(), _stream())
+    _l.check(rc, "frames_to_u8")
+    return out
+
+
 def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a * b for contiguous bf16 tensors of equal shape (numel a multiple of 8)."""
     _req(a, torch.bfloat16, "mul.a")

@@ -265,6 +265,13 @@ int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out,
  * (vae/hunyuanvideo15/model.py:274, :709-711). */
 int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
 
+/* BaseEngine._tensor_to_frames (engine/base_engine.py:2945-2949 -> diffusers VideoProcessor.postprocess_video):
+ * frames uint8 [T, H, W, C] = round(clamp(video / 2 + 1/2, 0, 1) * 255) from a bf16 video [C, T, H, W] given by element
+ * strides (a planar decode output or a channels-last tile alike); the intermediate is rounded to bf16 as the reference's
+ * bf16 denormalize does, so the bytes are identical.  C <= 4. */
+int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
+                        int C, int T, int H, int W, void* out, apexmi_stream_t stream);
+
 /* out = a * b, contiguous bf16, n a multiple of 8 (T5DenseGatedActDense: hidden_gelu * hidden_linear). */
 int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
 
