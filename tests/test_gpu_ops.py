@@ -505,3 +505,59 @@ def test_attention_four_cluster_variant(shape, c4):
         lib.tune_set("attn.c4", 1)
     _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention c4 {shape}", ulp=3.0)
     assert torch.equal(out.cpu(), out2.cpu())
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
+def test_gemm_random_shape_sweep(cfg, gemm_config):
+    """Seeded sweep over ragged problems for every tiling: M from 1 row up, N any multiple of 8, K any multiple of 64,
+    padded leading dimensions, every epilogue, guard columns/rows around the output checked for stray writes."""
+    ops = _ops()
+    gemm_config(cfg)
+    rng = torch.Generator().manual_seed(1000 + cfg)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    epis = ["bias", "gelu", "gelu_erf", "silu", "quick_gelu", "gate_res"]
+    for case in range(14):
+        M = [1, 7, 31, 129, 255, 257, 511, 513][case % 8] if case < 8 else ri(1, 1500)
+        N = 8 * ri(1, 200)
+        K = 64 * ri(1, 20)
+        pa, pw, pc = 8 * ri(0, 3), 8 * ri(0, 3), 8 * ri(0, 3)
+        epi = epis[case % len(epis)]
+        abuf = _bf(seeded((M, K + pa), 7 * case + 1)).to(DEV)
+        wbuf = _bf(seeded((N, K + pw), 7 * case + 2, scale=K ** -0.5)).to(DEV)
+        a, w = abuf[:, :K], wbuf[:, :K]
+        b = _bf(seeded((N,), 7 * case + 3)).to(DEV)
+        cbuf = torch.full((M + 2, N + pc + 8), 7.0, dtype=torch.bfloat16, device=DEV)
+        out = cbuf[1:M + 1, 8:8 + N]
+        ref = a.float() @ w.float().T + b.float()
+        if epi == "gate_res":
+            gate, r = seeded((N,), 7 * case + 4).to(DEV), _bf(seeded((M, N), 7 * case + 5)).to(DEV)
+            ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate, residual=r)
+            ref = r.float() + gate * ref
+        else:
+            ops.gemm(a, w, b, out=out, epilogue=epi)
+            ref = {"bias": lambda x: x, "gelu": lambda x: torch.nn.functional.gelu(x, approximate="tanh"),
+                   "gelu_erf": torch.nn.functional.gelu, "silu": torch.nn.functional.silu,
+                   "quick_gelu": lambda x: x * torch.sigmoid(1.702 * x)}[epi](ref)
+        _check(out, ref.cpu(), 3e-3, f"cfg{cfg} sweep {case}: M{M} N{N} K{K} {epi}")
+        guard = cbuf.clone()
+        guard[1:M + 1, 8:8 + N] = 7.0
+        assert bool((guard == 7.0).all()), f"cfg{cfg} sweep {case}: write outside the output view (M{M} N{N} K{K})"
+
+
+def test_attention_random_length_sweep():
+    """Flash path (D = 128) over ragged query / key lengths and strided (fused-QKV) operands."""
+    ops = _ops()
+    rng = torch.Generator().manual_seed(77)
+    for case in range(10):
+        B, H = int(torch.randint(1, 3, (1,), generator=rng)), int(torch.randint(1, 5, (1,), generator=rng))
+        Sq = int(torch.randint(1, 700, (1,), generator=rng))
+        Sk = Sq if case % 2 == 0 else int(torch.randint(1, 900, (1,), generator=rng))
+        q = seeded((B, Sq, H, 128), 300 + case, torch.bfloat16).to(DEV).permute(0, 2, 1, 3)       # [B,H,S,D] views
+        kv = seeded((B, Sk, 2, H, 128), 400 + case, torch.bfloat16).to(DEV)
+        k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+        out = ops.attention(q, k, v)
+        ref = OL.sdpa(q.float(), k.float(), v.float())
+        _check(out, ref.cpu(), 1e-2, f"attention sweep {case}: B{B} H{H} Sq{Sq} Sk{Sk}", ulp=3.0)
