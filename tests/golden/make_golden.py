@@ -585,6 +585,61 @@ def gen_text_encoders():
     torch.save(out, os.path.join(OUT, "text_encoders.pt"))
 
 
+TINY_QWEN_VL_TEXT = dict(vocab_size=200, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, rms_norm_eps=1e-6, rope_theta=1000000.0)
+TINY_QWEN_VL_VISION = dict(depth=2, hidden_size=320, intermediate_size=172, num_heads=4, in_channels=3, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])
+
+
+def gen_qwen2_5_vl():
+    """transformers.Qwen2_5_VLForConditionalGeneration (the class the QwenImage manifests name) on a small config: a
+    right-padded text-only batch, and one prompt with two images (vision tower with windowed + full attention blocks,
+    head dim 80 and intermediate size 172 chosen to have the production model's divisibility quirks, image-embedding
+    scatter, 3-D RoPE positions).  fp32."""
+    import transformers
+    from oracle.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration as Orc
+    IMG = 151
+    orc = Orc(**TINY_QWEN_VL_TEXT, mrope_section=(16, 24, 24), image_token_id=IMG, vision_config=TINY_QWEN_VL_VISION).eval()
+    sd = text_encoder_state_dict(orc, 51, 52, "norm")
+    for k in [k for k in sd if k.endswith("ln_q.weight")]:
+        sd[k] = 1.0 + 0.1 * seeded(sd[k].shape, 53).to(torch.bfloat16).float()
+    cfg = transformers.Qwen2_5_VLConfig(
+        text_config={**TINY_QWEN_VL_TEXT, "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]},
+                     "max_position_embeddings": 512, "tie_word_embeddings": False, "pad_token_id": 0, "bos_token_id": 1,
+                     "eos_token_id": 2},
+        vision_config={**TINY_QWEN_VL_VISION, "out_hidden_size": 256, "hidden_act": "silu"},
+        image_token_id=IMG, video_token_id=152, vision_start_token_id=149, vision_end_token_id=150)
+    hf = transformers.Qwen2_5_VLForConditionalGeneration(cfg).eval().float()
+    res = hf.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(8)
+    # text only, right padded
+    ids = torch.randint(3, 140, (2, 17), generator=g)
+    mask = torch.ones(2, 17, dtype=torch.long)
+    mask[1, 11:] = 0
+    ids[1, 11:] = 0
+    with torch.no_grad():
+        a = hf(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+    out = dict(transformers_version=transformers.__version__, text_config=TINY_QWEN_VL_TEXT, vision_config=TINY_QWEN_VL_VISION,
+               image_token_id=IMG, keys=sorted(sd.keys()), seed=51,
+               text=dict(ids=ids, mask=mask, last=a.hidden_states[-1], hidden1=a.hidden_states[1], n_hidden=len(a.hidden_states)))
+    # text + two images: grids (t, h, w) in patches; merged tokens 15 + 8
+    grid = torch.tensor([[1, 6, 10], [1, 8, 4]])
+    n1, n2 = 15, 8
+    seq = [5, 6, 149] + [IMG] * n1 + [150, 7, 8, 149] + [IMG] * n2 + [150] + [9, 10, 11, 12, 13]
+    ids = torch.tensor([seq])
+    mask = torch.ones_like(ids)
+    pix = seeded((60 + 32, 3 * 2 * 14 * 14), 61)
+    with torch.no_grad():
+        b = hf(input_ids=ids, attention_mask=mask, pixel_values=pix, image_grid_thw=grid, output_hidden_states=True,
+               mm_token_type_ids=(ids == IMG).int())
+        vis = hf.model.visual(pix, grid_thw=grid).pooler_output
+        pos, _ = hf.model.get_rope_index(ids, (ids == IMG).int(), image_grid_thw=grid, attention_mask=mask)
+    out["image"] = dict(ids=ids, mask=mask, pixel_values=pix, grid=grid, last=b.hidden_states[-1], vision=vis,
+                        position_ids=pos, n_hidden=len(b.hidden_states))
+    torch.save(out, os.path.join(OUT, "qwen2_5_vl.pt"))
+    print("qwen2_5_vl", float(a.hidden_states[-1].abs().mean()), float(b.hidden_states[-1].abs().mean()), float(vis.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -600,6 +655,7 @@ def main():
     gen_lora()
     gen_fp_scaled()
     gen_text_encoders()
+    gen_qwen2_5_vl()
 
 
 if __name__ == "__main__":

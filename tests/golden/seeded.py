@@ -51,4 +51,6 @@ def text_encoder_state_dict(model, seed: int, norm_seed: int, norm_tag: str):
     # near one-hot softmaxes whose argmax flips under any rounding, and the comparison measures chaos, not kernels.
     for k in [k for k in sd if k.endswith("SelfAttention.q.weight")]:
         sd[k] = sd[k] * 0.125
+    for k in [k for k in sd if k.endswith("embed_tokens.weight") or k.endswith("patch_embed.proj.weight")]:
+        sd[k] = sd[k] * 16.0           # O(1) embeddings, as trained ones are (the synthetic draw is 1/sqrt(fan_in))
     return sd

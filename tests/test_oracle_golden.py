@@ -217,3 +217,38 @@ def test_text_encoders_restatement_matches_transformers(golden_dir):
     real = g["clip_mask"].bool()
     assert torch.allclose(outm.last_hidden_state[real], c["last_masked"][real], atol=2e-5, rtol=1e-4)
     assert torch.allclose(outm.pooler_output, c["pooled_masked"], atol=2e-5, rtol=1e-4)
+
+
+def _qwen_vl_oracle(g):
+    from oracle.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from tests.golden.seeded import text_encoder_state_dict
+    m = Qwen2_5_VLForConditionalGeneration(**g["text_config"], mrope_section=(16, 24, 24), image_token_id=g["image_token_id"],
+                                           vision_config=g["vision_config"]).eval()
+    sd = text_encoder_state_dict(m, g["seed"], 52, "norm")
+    for k in [k for k in sd if k.endswith("ln_q.weight")]:
+        sd[k] = 1.0 + 0.1 * seeded(sd[k].shape, 53).to(torch.bfloat16).float()
+    assert sorted(sd.keys()) == g["keys"]
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+def test_qwen2_5_vl_restatement_matches_transformers(golden_dir):
+    """oracle.qwen2_5_vl against transformers.Qwen2_5_VLForConditionalGeneration (tests/golden/qwen2_5_vl.pt): the causal
+    GQA decoder with a right-padded batch, and a two-image prompt through the vision tower (window index, 2-D rotary,
+    windowed / full blocks, merger), the embedding scatter and the 3-D RoPE position ids."""
+    from oracle import qwen2_5_vl as OQV
+    g = torch.load(os.path.join(golden_dir, "qwen2_5_vl.pt"), weights_only=False)
+    m, _ = _qwen_vl_oracle(g)
+    t = g["text"]
+    out = m(t["ids"], attention_mask=t["mask"])
+    real = t["mask"].bool()
+    assert len(out.hidden_states) == t["n_hidden"]
+    assert torch.allclose(out.hidden_states[-1][real], t["last"][real], atol=3e-5, rtol=1e-4)
+    assert torch.allclose(out.hidden_states[1][real], t["hidden1"][real], atol=3e-5, rtol=1e-4)
+    im = g["image"]
+    pos = OQV.rope_index(im["ids"], im["mask"], im["grid"], g["image_token_id"], g["vision_config"]["spatial_merge_size"])
+    assert torch.equal(pos, im["position_ids"])
+    vis = m.model.visual(im["pixel_values"], im["grid"])
+    assert torch.allclose(vis, im["vision"], atol=3e-5, rtol=1e-4)
+    out = m(im["ids"], attention_mask=im["mask"], pixel_values=im["pixel_values"], image_grid_thw=im["grid"])
+    assert torch.allclose(out.hidden_states[-1], im["last"], atol=3e-5, rtol=1e-4)
