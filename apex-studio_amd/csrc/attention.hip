@@ -769,8 +769,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 __global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __restrict__ x, int64_t ldx, int Sq, int cols,
                                                                 float scale_log2e, const float* __restrict__ bias,
                                                                 int64_t bias_ld, const uint8_t* __restrict__ keep,
-                                                                int causal, bf16_t* __restrict__ out, int64_t ldo,
-                                                                int cols_pad) {
+                                                                const int* __restrict__ seg, int causal,
+                                                                bf16_t* __restrict__ out, int64_t ldo, int cols_pad) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = (int64_t)blockIdx.y * Sq + blockIdx.x;
@@ -778,9 +778,10 @@ __global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __r
     const float* br = bias ? bias + row * bias_ld : nullptr;
     bf16_t* orow = out + row * ldo;
     const int lim = causal ? min(cols, (int)blockIdx.x + 1) : cols;
+    const int myseg = seg ? seg[blockIdx.x] : 0;   // block-diagonal attention: a query sees the keys of its own segment
     constexpr float LOG2E = 1.4426950408889634f;
     auto score = [&](int c) -> float {
-        if (c >= lim || (keep && !keep[c])) return -1.0e30f;
+        if (c >= lim || (keep && !keep[c]) || (seg && seg[c] != myseg)) return -1.0e30f;
         return fmaf(xr[c], scale_log2e, br ? br[c] * LOG2E : 0.0f);
     };
     float mx = -1.0e30f;
@@ -1125,44 +1126,54 @@ extern "C" int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stri
 extern "C" size_t apexmi_attn_bias_workspace_bytes(int H, int Sq, int Sk, int D) { return attn_bias_bytes(H, Sq, Sk, D); }
 
 extern "C" int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                                    void* out, int64_t ldo, int H, int Sq, int Sk, int D, float softmax_scale,
-                                    const float* bias, const uint8_t* keep, int causal, void* workspace,
+                                    void* out, int64_t ldo, int H, int Hkv, int Sq, int Sk, int D, float softmax_scale,
+                                    const float* bias, const uint8_t* keep, const int* seg, int causal, void* workspace,
                                     size_t workspace_bytes, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(q && k && v && out && workspace, "attn_fwd_bias: null operand");
     APEXMI_REQUIRE(H > 0 && Sq > 0 && Sk > 0, "attn_fwd_bias: empty problem");
-    APEXMI_REQUIRE(D % 64 == 0 && (H * D) % 128 == 0, "attn_fwd_bias: head dim %d must be a multiple of 64 and H*D=%d of 128", D, H * D);
-    APEXMI_REQUIRE(!causal || Sq == Sk, "attn_fwd_bias: the causal mask needs Sq == Sk");
+    APEXMI_REQUIRE(Hkv > 0 && H % Hkv == 0, "attn_fwd_bias: %d query heads are not a multiple of %d key/value heads", H, Hkv);
+    APEXMI_REQUIRE(D % 64 == 0 && (Hkv * D) % 128 == 0, "attn_fwd_bias: head dim %d must be a multiple of 64 and Hkv*D=%d of 128", D, Hkv * D);
+    APEXMI_REQUIRE((!causal && !seg) || Sq == Sk, "attn_fwd_bias: the causal / segment masks need Sq == Sk");
     APEXMI_REQUIRE(workspace_bytes >= attn_bias_bytes(H, Sq, Sk, D), "attn_fwd_bias: workspace too small (%zu < %zu)",
                    workspace_bytes, attn_bias_bytes(H, Sq, Sk, D));
-    const int skp = ((Sk + KV - 1) / KV) * KV, sk8 = (Sk + 7) / 8 * 8;
+    const int skp = ((Sk + KV - 1) / KV) * KV, sk8 = (Sk + 7) / 8 * 8, rep = H / Hkv;
     float* sc = (float*)workspace;
     bf16_t* pb = (bf16_t*)((char*)workspace + (size_t)H * Sq * sk8 * 4);
     bf16_t* vt = pb + (size_t)H * Sq * skp;
     bf16_t* kpad = vt + (size_t)H * D * skp;
     const bf16_t* kp = (const bf16_t*)k;
     if (sk8 != Sk) {   // the GEMM's weight operand comes in whole groups of 8 rows
-        if (hipMemcpy2DAsync(kpad, (size_t)H * D * 2, k, (size_t)ldk * 2, (size_t)H * D * 2, Sk, hipMemcpyDeviceToDevice,
-                             stream) != hipSuccess ||
-            hipMemsetAsync(kpad + (size_t)Sk * H * D, 0, (size_t)(sk8 - Sk) * H * D * 2, stream) != hipSuccess) {
+        if (hipMemcpy2DAsync(kpad, (size_t)Hkv * D * 2, k, (size_t)ldk * 2, (size_t)Hkv * D * 2, Sk,
+                             hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            hipMemsetAsync(kpad + (size_t)Sk * Hkv * D, 0, (size_t)(sk8 - Sk) * Hkv * D * 2, stream) != hipSuccess) {
             apexmi_set_error("attn_fwd_bias: padding K failed");
             return 1;
         }
         kp = kpad;
-        ldk = (int64_t)H * D;
+        ldk = (int64_t)Hkv * D;
     }
-    // scores[h] = q_h k_h^T: one batched launch over the heads
-    if (int rc = apexmi_gemm_bf16_batched(q, ldq, D, kp, ldk, D, sc, sk8, (int64_t)Sq * sk8, H, Sq, sk8, D,
-                                          APEXMI_EPI_BIAS_F32, stream_))
-        return rc;
+    // scores[h] = q_h k_{h / rep}^T.  One batched launch over the heads that share a key head (stride 0 on K: grouped-
+    // query attention without materialising the repeated keys); plain multi-head attention is a single launch.
+    const int launches = rep == 1 ? 1 : Hkv, per = rep == 1 ? H : rep;
+    for (int g = 0; g < launches; ++g)
+        if (int rc = apexmi_gemm_bf16_batched((const bf16_t*)q + (int64_t)g * per * D, ldq, D, kp + (int64_t)g * D, ldk,
+                                              rep == 1 ? D : 0, sc + (size_t)g * per * Sq * sk8, sk8, (int64_t)Sq * sk8, per,
+                                              Sq, sk8, D, APEXMI_EPI_BIAS_F32, stream_))
+            return rc;
     {
         ApexmiProfScope prof(1, stream, 0.0, (double)H * Sq * Sk * 10.0);
         hipLaunchKernelGGL(softmax_bias_rows_kernel, dim3(Sq, H), dim3(256), 0, stream, sc, (int64_t)sk8, Sq, Sk,
-                           softmax_scale * 1.4426950408889634f, bias, (int64_t)Sk, keep, causal, pb, (int64_t)skp, skp);
+                           softmax_scale * 1.4426950408889634f, bias, (int64_t)Sk, keep, seg, causal, pb, (int64_t)skp, skp);
         if (int rc = apexmi_check_launch("softmax_bias_rows")) return rc;
     }
-    // V^T [H*D, skp] by 128-column slices of V (independent of the head size), zero-padded key columns
-    if (int rc = apexmi_v_transpose(v, 128, ldv, Sk, H * D / 128, 128, vt, skp, 0, stream_)) return rc;
-    return apexmi_gemm_bf16_batched(pb, skp, (int64_t)Sq * skp, vt, skp, (int64_t)D * skp, out, ldo, D, H, Sq, D, skp,
-                                    APEXMI_EPI_BIAS, stream_);
+    // V^T [Hkv*D, skp] by 128-column slices of V (independent of the head size), zero-padded key columns
+    if (int rc = apexmi_v_transpose(v, 128, ldv, Sk, Hkv * D / 128, 128, vt, skp, 0, stream_)) return rc;
+    for (int g = 0; g < launches; ++g)
+        if (int rc = apexmi_gemm_bf16_batched(pb + (size_t)g * per * Sq * skp, skp, (int64_t)Sq * skp,
+                                              vt + (size_t)g * D * skp, skp, rep == 1 ? (int64_t)D * skp : 0,
+                                              (bf16_t*)out + (int64_t)g * per * D, ldo, D, per, Sq, D, skp, APEXMI_EPI_BIAS,
+                                              stream_))
+            return rc;
+    return 0;
 }

@@ -570,6 +570,28 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const bf16_t* __restri
     out[i] = bf16_to_f32(weight[(int64_t)bucket[j - q + Sq - 1] * H + h]);
 }
 
+// x[r, h, i] <- x[r, h, i] cos[r, i] - x[r, h, i + D/2] sin[r, i];  x[r, h, i + D/2] <- x[r, h, i + D/2] cos[r, i + D/2]
+// + x[r, h, i] sin[r, i + D/2]  — `q * cos + rotate_half(q) * sin` of transformers' Qwen2.5-VL
+// (apply_rotary_pos_emb_vision / apply_multimodal_rotary_pos_emb, modeling_qwen2_5_vl.py), in place on a packed
+// projection [rows, heads * head_stride] whose heads rotate their first D columns (the vision tower's 80-wide heads
+// live in 128-wide slots).  f32 arithmetic, one rounding to bf16.
+__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int heads,
+                                                        int head_stride, int D, const float* __restrict__ cs,
+                                                        const float* __restrict__ sn) {
+    const int half = D >> 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * heads * half) return;
+    const int c = (int)(i % half);
+    const int h = (int)((i / half) % heads);
+    const int64_t r = i / ((int64_t)half * heads);
+    bf16_t* p = x + r * ldx + (int64_t)h * head_stride;
+    const float a = bf16_to_f32(p[c]), b = bf16_to_f32(p[c + half]);
+    const float* cr = cs + r * D;
+    const float* sr = sn + r * D;
+    p[c] = f32_to_bf16(a * cr[c] - b * sr[c]);
+    p[c + half] = f32_to_bf16(b * cr[c + half] + a * sr[c + half]);
+}
+
 // frames[t, y, x, c] = uint8(round(clamp(v * 0.5 + 0.5, 0, 1) * 255)) for v = video[c, t, y, x] (any strides): the
 // denormalize -> permute -> (x 255).round().astype(uint8) chain of diffusers VideoProcessor.postprocess_video that
 // BaseEngine._tensor_to_frames calls (engine/base_engine.py:2945-2949).  The reference runs denormalize in the decode
@@ -809,6 +831,18 @@ extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t 
     hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)out, n / 8);
     return apexmi_check_launch("add_bf16");
+}
+
+extern "C" int apexmi_rope_half(void* x, int64_t ldx, int64_t rows, int heads, int head_stride, int D, const float* cos_,
+                                const float* sin_, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && cos_ && sin_ && rows > 0 && heads > 0, "rope_half: bad arguments");
+    APEXMI_REQUIRE(D > 0 && D % 2 == 0 && D <= head_stride, "rope_half: D=%d must be even and <= head_stride=%d", D, head_stride);
+    const int64_t n = rows * heads * (D / 2);
+    ApexmiProfScope prof(4, stream, 0.0, 4.0 * (double)rows * heads * D);
+    hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ldx, rows, heads,
+                       head_stride, D, cos_, sin_);
+    return apexmi_check_launch("rope_half");
 }
 
 extern "C" int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h,

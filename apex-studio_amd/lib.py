@@ -40,7 +40,8 @@ SIGNATURES = {
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_attn_bias_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "apexmi_attn_fwd_bias": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
-                                       C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, vp, C.c_size_t, vp]),
+                                       C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp, C.c_size_t, vp]),
+    "apexmi_rope_half": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "apexmi_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                               C.c_int, C.c_int, vp]),

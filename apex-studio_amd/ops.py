@@ -294,10 +294,11 @@ def attention_framecausal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tok
 
 def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, softmax_scale: float,
                    bias: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None,
-                   causal: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Text-encoder self-attention over packed projections: q [Sq, H*D], k, v [Sk, H*D] bf16 (row-strided views of a
-    fused QKV buffer welcome), bias f32 [H, Sq, Sk] (T5 relative-position bias), keep uint8 [Sk] (0 = padded key).
-    Returns [Sq, H*D]."""
+                   causal: bool = False, out: Optional[torch.Tensor] = None, kv_heads: Optional[int] = None,
+                   seg: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Text-encoder self-attention over packed projections: q [Sq, H*D], k, v [Sk, Hkv*D] bf16 (row-strided views of a
+    fused QKV buffer welcome), bias f32 [H, Sq, Sk] (T5 relative-position bias), keep uint8 [Sk] (0 = padded key), seg
+    int32 [S] (block-diagonal attention: segment id per token).  Returns [Sq, H*D]."""
     _req(q, torch.bfloat16, "attention_bias.q")
     _req(k, torch.bfloat16, "attention_bias.k")
     _req(v, torch.bfloat16, "attention_bias.v")
@@ -313,6 +314,11 @@ def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     if keep is not None:
         _req(keep, torch.uint8, "attention_bias.keep")
         assert keep.is_contiguous() and keep.numel() == Sk
+    if seg is not None:
+        _req(seg, torch.int32, "attention_bias.seg")
+        assert seg.is_contiguous() and seg.numel() == Sq == Sk
+    hkv = heads if kv_heads is None else int(kv_heads)
+    assert k.shape[1] == hkv * D and v.shape[1] == hkv * D
     lib = _l.load()
     need = lib.apexmi_attn_bias_workspace_bytes(heads, Sq, Sk, D)
     key = (q.device.index, torch.cuda.current_stream().cuda_stream)
@@ -321,10 +327,23 @@ def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
         ws = torch.empty(need, dtype=torch.uint8, device=q.device)
         _ws_cache[key] = ws
     rc = lib.apexmi_attn_fwd_bias(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                  out.data_ptr(), out.stride(0), heads, Sq, Sk, D, float(softmax_scale), _ptr(bias),
-                                  _ptr(keep), 1 if causal else 0, ws.data_ptr(), need, _stream())
+                                  out.data_ptr(), out.stride(0), heads, hkv, Sq, Sk, D, float(softmax_scale), _ptr(bias),
+                                  _ptr(keep), _ptr(seg), 1 if causal else 0, ws.data_ptr(), need, _stream())
     _l.check(rc, "attn_fwd_bias")
     return out
+
+
+def rope_half_(x: torch.Tensor, heads: int, head_stride: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """In place: every head of x [rows, >= heads * head_stride] (bf16, row-strided view welcome) rotates its first D =
+    cos.shape[1] columns, x <- x cos + rotate_half(x) sin with f32 tables [rows, D]."""
+    _req(x, torch.bfloat16, "rope_half.x")
+    _req(cos, torch.float32, "rope_half.cos")
+    _req(sin, torch.float32, "rope_half.sin")
+    assert x.dim() == 2 and x.stride(1) == 1 and cos.shape == sin.shape == (x.shape[0], cos.shape[1])
+    assert cos.is_contiguous() and sin.is_contiguous() and x.shape[1] >= heads * head_stride
+    _l.check(_l.load().apexmi_rope_half(x.data_ptr(), x.stride(0), x.shape[0], heads, head_stride, cos.shape[1],
+                                        cos.data_ptr(), sin.data_ptr(), _stream()), "rope_half")
+    return x
 
 
 def relpos_bias(weight: torch.Tensor, bucket: torch.Tensor, Sq: int, Sk: int) -> torch.Tensor:

@@ -135,14 +135,18 @@ int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, const
  * R/requirements/requirements.txt:79; call site R/src/text_encoder/text_encoder.py:335-342):
  *   T5Attention / UMT5Attention.forward: softmax(q k^T + position_bias + mask) v, NO 1/sqrt(d) scaling (scale = 1);
  *   CLIPAttention.forward: softmax(q k^T / sqrt(d) + causal mask) v.
- * q, k, v, out: bf16 [S, H*D] projections (row strides ldq/ldk/ldv/ldo), head h in columns [h D, (h+1) D).
- * bias: f32 [H, Sq, Sk] or NULL; keep: uint8 [Sk], 0 = padded key (NULL = all kept); causal != 0 adds the causal mask.
- * Masked keys get probability exactly 0 (what the additive finfo.min mask gives in f32).  D a multiple of 64, H*D of
- * 128.  Materialised: batched scores GEMM (f32), row softmax, batched P V GEMM; workspace from the _bytes query. */
+ *   Qwen2_5_VLAttention / Qwen2_5_VLVisionAttention.forward: grouped-query causal attention with a padding mask /
+ *   block-diagonal (window or per-image) attention.
+ * q, out: bf16 [Sq, H*D]; k, v: bf16 [Sk, Hkv*D] (row strides ldq/ldk/ldv/ldo), head h in columns [h D, (h+1) D) and
+ * query head h reading key/value head h / (H / Hkv).  bias: f32 [H, Sq, Sk] or NULL; keep: uint8 [Sk], 0 = padded key
+ * (NULL = all kept); seg: int32 [S] segment id per token, a query sees only keys of its own segment (NULL = one
+ * segment); causal != 0 adds the causal mask.  Masked keys get probability exactly 0 (what the additive finfo.min mask
+ * gives in f32).  D a multiple of 64, Hkv*D of 128.  Materialised: batched scores GEMM (f32; stride 0 on the shared
+ * key head for GQA), row softmax, batched P V GEMM; workspace from the _bytes query. */
 size_t apexmi_attn_bias_workspace_bytes(int H, int Sq, int Sk, int D);
 int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out,
-                         int64_t ldo, int H, int Sq, int Sk, int D, float softmax_scale, const float* bias,
-                         const uint8_t* keep, int causal, void* workspace, size_t workspace_bytes,
+                         int64_t ldo, int H, int Hkv, int Sq, int Sk, int D, float softmax_scale, const float* bias,
+                         const uint8_t* keep, const int* seg, int causal, void* workspace, size_t workspace_bytes,
                          apexmi_stream_t stream);
 
 /* Tuning knobs for A/B measurements (bench.py, tests): "gemm.config" = 0 auto | 1 128x128 |
@@ -271,6 +275,13 @@ int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_s
  * bf16 denormalize does, so the bytes are identical.  C <= 4. */
 int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
                         int C, int T, int H, int W, void* out, apexmi_stream_t stream);
+
+/* In-place rotary embedding of the "rotate_half" form, x <- x cos + rotate_half(x) sin, on a packed projection
+ * x bf16 [rows, heads * head_stride] (row stride ldx): each head rotates its first D columns with the row's
+ * cos / sin f32 [rows, D] (transformers apply_rotary_pos_emb_vision / apply_multimodal_rotary_pos_emb of Qwen2.5-VL;
+ * the caller builds the tables — 2-D patch positions or the 3-D mrope sections). */
+int apexmi_rope_half(void* x, int64_t ldx, int64_t rows, int heads, int head_stride, int D, const float* cos_table,
+                     const float* sin_table, apexmi_stream_t stream);
 
 /* out = a * b, contiguous bf16, n a multiple of 8 (T5DenseGatedActDense: hidden_gelu * hidden_linear). */
 int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);

@@ -131,3 +131,26 @@ def test_text_encoder_class_contracts_match_transformers():
         cpu(input_ids=torch.zeros(1, 4, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         TE.T5EncoderModel(dict(t5, feed_forward_proj="relu"), device="meta")
+
+
+def test_qwen2_5_vl_class_contract_matches_transformers():
+    """Same parameter names and shapes as transformers.Qwen2_5_VLForConditionalGeneration (the 4.57 module layout the
+    reference's converter targets, converters/text_encoder_converters.py:30-45), both config spellings accepted."""
+    import transformers
+    from apex_studio_amd.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration as Mine
+    text = dict(vocab_size=160, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=1, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]})
+    vis = dict(depth=2, hidden_size=320, intermediate_size=172, num_heads=4, in_channels=3, patch_size=14,
+               spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1], out_hidden_size=256)
+    hf = transformers.Qwen2_5_VLForConditionalGeneration(transformers.Qwen2_5_VLConfig(
+        text_config={**text, "tie_word_embeddings": False, "pad_token_id": 0, "bos_token_id": 1, "eos_token_id": 2},
+        vision_config=vis, image_token_id=151, video_token_id=152, vision_start_token_id=149, vision_end_token_id=150))
+    ref = {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+    nested = Mine._from_config(dict(text_config=text, vision_config=vis, image_token_id=151), device="meta")
+    assert {k: tuple(v.shape) for k, v in nested.state_dict().items()} == ref
+    flat = Mine.from_config({**text, "vision_config": vis, "image_token_id": 151}, device="meta")      # 4.x config.json
+    assert {k: tuple(v.shape) for k, v in flat.state_dict().items()} == ref
+    assert flat.config.mrope_section == (16, 24, 24) and flat.config.vision_config.fullatt_block_indexes == [1]
+    with pytest.raises(NotImplementedError):
+        Mine(dict(text_config={**text, "num_attention_heads": 4}), device="meta")          # head dim 64: sections do not fit
