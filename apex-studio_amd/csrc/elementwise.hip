@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            y[2 * i] = x[2 * i] * cs[2 * i] - x[2 * i + 1] * sn[2 * i];
-            y[2 * i + 1] = x[2 * i + 1] * cs[2 * i + 1] + x[2 * i] * sn[2 * i + 1];
+            y[2 * i] = fmaf(x[2 * i], cs[2 * i], -(x[2 * i + 1] * sn[2 * i]));
+            y[2 * i + 1] = fmaf(x[2 * i + 1], cs[2 * i + 1], x[2 * i] * sn[2 * i + 1]);
         }
     } else if (rope_mode == APEXMI_ROPE_COMPLEX) {
         const float* tp = rope + ((int64_t)srow * (D / 2) + l16 * 4) * 2;
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
         const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            y[2 * i] = x[2 * i] * cs[i] - x[2 * i + 1] * sn[i];
-            y[2 * i + 1] = x[2 * i] * sn[i] + x[2 * i + 1] * cs[i];
+            y[2 * i] = fmaf(x[2 * i], cs[i], -(x[2 * i + 1] * sn[i]));
+            y[2 * i + 1] = fmaf(x[2 * i], sn[i], x[2 * i + 1] * cs[i]);
         }
     } else {
 #pragma unroll
@@ -265,18 +265,98 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
     }
 }
 
+// Same arithmetic, four heads per 16-lane group: the four 16-byte loads are issued together (4x the bytes in flight per
+// wave: the one-head kernel is latency-bound at ~3.9 TB/s) and the rope table row and norm weights are fetched once for
+// the four heads.  H % 4 == 0.
+APEXMI_DEVICE void qk_norm_rope4_body(
+    int bx, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+    const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
+    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
+    bf16_t* __restrict__ ko, int S_out, int row0) {
+    constexpr int D = 128, G = 4;
+    const int64_t grp = (int64_t)bx * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const int nk = (k != nullptr) ? 2 : 1;
+    const int gpr = nk * H / G;                       // groups per row
+    const int64_t ngrp = (int64_t)S * gpr;
+    const bool live = grp < ngrp;
+    const int64_t u = live ? grp : ngrp - 1;
+    const int s = (int)(u / gpr);
+    const int rem = (int)(u % gpr);
+    const int which = rem / (H / G), h0 = (rem % (H / G)) * G;
+    const int d = l16 * 8;
+    const bf16_t* src = (which ? k : q) + (int64_t)s * ld_in + h0 * D + d;
+    u32x4 raw[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) raw[i] = *(const u32x4*)(src + i * D);
+    const bf16_t* w = which ? (s < split ? wk2 : wk) : (s < split ? wq2 : wq);
+    float wv[8];
+    if (w != nullptr) unpack8(*(const u32x4*)(w + d), wv);
+    const int srow = row0 + s;
+    float cs[8], sn[8];
+    if (rope_mode == APEXMI_ROPE_INTERLEAVED) {
+        const float* cp = rope + (int64_t)srow * D + d;
+        const float* sp = rope + (int64_t)S_out * D + (int64_t)srow * D + d;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs[j] = c0[j];
+            cs[j + 4] = c1[j];
+            sn[j] = s0[j];
+            sn[j + 4] = s1[j];
+        }
+    } else if (rope_mode == APEXMI_ROPE_COMPLEX) {
+        const float* tp = rope + ((int64_t)srow * (D / 2) + l16 * 4) * 2;
+        const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
+        cs[0] = t0[0]; cs[1] = t0[2]; cs[2] = t1[0]; cs[3] = t1[2];
+        sn[0] = t0[1]; sn[1] = t0[3]; sn[2] = t1[1]; sn[3] = t1[3];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        float x[8], y[8];
+        unpack8(raw[i], x);
+        if (w != nullptr) {
+            float sq = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += x[j] * x[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float r = rsqrtf(sq * (1.0f / D) + eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[j] * r * wv[j];
+        }
+        if (rope_mode == APEXMI_ROPE_INTERLEAVED) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                y[2 * p] = fmaf(x[2 * p], cs[2 * p], -(x[2 * p + 1] * sn[2 * p]));
+                y[2 * p + 1] = fmaf(x[2 * p + 1], cs[2 * p + 1], x[2 * p] * sn[2 * p + 1]);
+            }
+        } else if (rope_mode == APEXMI_ROPE_COMPLEX) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                y[2 * p] = fmaf(x[2 * p], cs[p], -(x[2 * p + 1] * sn[p]));
+                y[2 * p + 1] = fmaf(x[2 * p], sn[p], x[2 * p + 1] * cs[p]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = x[j];
+        }
+        if (live) *(u32x4*)((which ? ko : qo) + ((int64_t)(h0 + i) * S_out + srow) * D + d) = pack8(y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // vt[h][d][col0 + s] = v[s][h][d]; columns in [S, round_up(S, 64)) are zero-filled (the attention
 // kernel multiplies them by p = 0, so they must be finite).  64 x 128 tile through LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v,
-                                                          int64_t v_sh, int64_t v_ss, int S, int D,
-                                                          bf16_t* __restrict__ vt, int Skp,
-                                                          int col0) {
+APEXMI_DEVICE void v_transpose_body(int bx, int by, const bf16_t* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
+                                    int D, bf16_t* __restrict__ vt, int Skp, int col0) {
     constexpr int LDW = 136;  // padded LDS row (elements)
     __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDW];
     const int tid = threadIdx.x;
-    const int s0 = blockIdx.x * 64, h = blockIdx.y;
+    const int s0 = bx * 64, h = by;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * 256 + tid;
@@ -298,6 +378,36 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restri
         for (int j = 0; j < 4; ++j) o[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
         *(u32x4*)(vt + ((int64_t)h * D + d) * Skp + col0 + s0 + sc * 8) = o;
     }
+}
+
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
+                                                          int D, bf16_t* __restrict__ vt, int Skp, int col0) {
+    v_transpose_body(blockIdx.x, blockIdx.y, v, v_sh, v_ss, S, D, vt, Skp, col0);
+}
+
+__global__ __launch_bounds__(256) void qk_norm_rope4_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+    const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
+    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
+    bf16_t* __restrict__ ko, int S_out, int row0) {
+    qk_norm_rope4_body(blockIdx.x, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, S_out, row0);
+}
+
+// q/k norm + RoPE and the V transpose of one attention layer in ONE launch: both are short, latency-bound passes
+// over disjoint data (29 + 16 us at the Flux shape when launched back to back), so their workgroups share the chip.
+// Blocks [0, nb_v) transpose V (64-key tiles x heads), the rest run the q/k groups.
+__global__ __launch_bounds__(256) void qkv_prepare_fused_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld_in, int S, int H,
+    int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+    const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
+    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
+    bf16_t* __restrict__ ko, bf16_t* __restrict__ vt, int S_out, int Skp, int row0, int nb_v, int nst) {
+    if ((int)blockIdx.x < nb_v)
+        v_transpose_body(blockIdx.x % nst, blockIdx.x / nst, v, 128, ld_in, S, 128, vt, Skp, row0);
+    else
+        qk_norm_rope4_body(blockIdx.x - nb_v, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko,
+                           S_out, row0);
 }
 
 // strided [B,H,S,D] view -> packed copy
@@ -699,6 +809,9 @@ int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int 
     return apexmi_check_launch("pack_bhsd");
 }
 
+int g_qk_group = 1;  // apexmi_tune_set("qk.group", n): 0 one head per lane group | 2 four heads | 1 four heads + V transpose in the same launch
+void apexmi_set_qk_group(int v) { g_qk_group = v; }
+
 extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_in, int S,
                                   int H, int D, int split, const void* wq, const void* wk,
                                   const void* wq2, const void* wk2, float eps, const float* rope,
@@ -713,13 +826,30 @@ extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, i
     APEXMI_REQUIRE(rope_mode == APEXMI_ROPE_NONE || (rope && ((uintptr_t)rope % 16) == 0),
                    "qkv_prepare: rope table missing or misaligned");
     APEXMI_REQUIRE(split <= 0 || (wq2 && wk2) || (!wq && !wk), "qkv_prepare: split needs the second weight set");
+    if (g_qk_group == 1 && H % 4 == 0 && v != nullptr && vt != nullptr && row0 % 64 == 0 && Skp % 64 == 0 &&
+        row0 + ((S + 63) / 64) * 64 <= Skp && ((uintptr_t)v % 16) == 0 && ((uintptr_t)vt % 16) == 0) {
+        ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D + 4.0 * (double)S * H * D);
+        const int64_t ngrp = (int64_t)S * (k ? 2 : 1) * H / 4;
+        const int nst = (S + 63) / 64, nb_v = nst * H;
+        hipLaunchKernelGGL(qkv_prepare_fused_kernel, dim3((unsigned)(nb_v + (ngrp + 15) / 16)), dim3(256), 0, stream,
+                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld_in, S, H, split, (const bf16_t*)wq,
+                           (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope, rope_mode, (bf16_t*)qo,
+                           (bf16_t*)ko, (bf16_t*)vt, S_out, Skp, row0, nb_v, nst);
+        return apexmi_check_launch("qkv_prepare_fused");
+    }
     {
         ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D);
         const int64_t nunit = (int64_t)S * (k ? 2 : 1) * H;
-        hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
-                           (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
-                           (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
-                           rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
+        if (g_qk_group && H % 4 == 0)
+            hipLaunchKernelGGL(qk_norm_rope4_kernel, dim3((unsigned)((nunit / 4 + 15) / 16)), dim3(256), 0, stream,
+                               (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
+                               (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
+                               rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
+        else
+            hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
+                               (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
+                               (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
+                               rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
         if (int rc = apexmi_check_launch("qk_norm_rope")) return rc;
     }
     if (v != nullptr && vt != nullptr)

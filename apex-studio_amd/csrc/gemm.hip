@@ -947,8 +947,13 @@ void apexmi_set_attn_waves(int v);
 void apexmi_set_attn_mfma(int v);
 void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
+void apexmi_set_qk_group(int v);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (key && !strcmp(key, "qk.group")) {
+        apexmi_set_qk_group(value);
+        return 0;
+    }
     if (key && !strcmp(key, "attn.waves")) {
         apexmi_set_attn_waves(value);
         return 0;

@@ -271,7 +271,7 @@ def _qkv_ref(qkv, H, wq, wk, wq2, wk2, split, cos, sin):
     return q[0].permute(1, 0, 2), k[0].permute(1, 0, 2), v[0].permute(1, 2, 0)  # [H,S,D],[H,S,D],[H,D,S]
 
 
-@pytest.mark.parametrize("S,H,split", [(80, 2, 16), (200, 3, 0), (64, 24, 7)])
+@pytest.mark.parametrize("S,H,split", [(80, 2, 16), (200, 3, 0), (64, 24, 7), (131, 4, 0), (100, 8, 20)])
 def test_qkv_prepare(S, H, split):
     ops = _ops()
     from apex_studio_amd import lib
@@ -300,10 +300,41 @@ def test_qkv_prepare(S, H, split):
     assert torch.equal(vt[:, :, S:].float().cpu(), torch.zeros(H, 128, skp - S)), "V^T pad must be zero"
 
 
+def test_qk_norm_rope_grouped_kernel_is_bit_identical():
+    """The shipped launch (`qk.group=1`: four heads per lane group, V transpose in the same launch) against the four-head
+    kernel alone (2) and the original one-head kernel + separate transpose (0): same arithmetic, identical bits."""
+    ops = _ops()
+    from apex_studio_amd import lib
+    S, H = 333, 24
+    dim = H * 128
+    skp = (S + 63) // 64 * 64
+    qkv = _bf(seeded((S, 3 * dim), 71)).to(DEV)
+    ws = [_bf(1 + 0.1 * seeded((128,), 72 + i)).to(DEV) for i in range(4)]
+    ang = seeded((S, 64), 76) * 3
+    tables = {lib.ROPE_COMPLEX: torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().to(DEV),
+              lib.ROPE_INTERLEAVED: torch.stack([ang.cos().repeat_interleave(2, 1), ang.sin().repeat_interleave(2, 1)]).contiguous().to(DEV)}
+    try:
+        for mode, table in tables.items():
+            outs = []
+            for grp in (0, 2, 1):
+                lib.tune_set("qk.group", grp)
+                qo = torch.empty(H, S, 128, dtype=torch.bfloat16, device=DEV)
+                ko = torch.empty_like(qo)
+                vt = torch.full((H, 128, skp), float("nan"), dtype=torch.bfloat16, device=DEV)
+                ops.qkv_prepare(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], H, qo, ko, vt, wq=ws[0], wk=ws[1],
+                                wq2=ws[2], wk2=ws[3], split=40, eps=1e-6, rope=table, rope_mode=mode)
+                outs.append((qo, ko, vt))
+            for o in outs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), mode
+            assert torch.equal(outs[0][2][:, :, :S].cpu(), qkv[:, 2 * dim:].cpu().view(S, H, 128).permute(1, 2, 0))
+    finally:
+        lib.tune_set("qk.group", 1)
+
+
 def test_rope_complex_mode_equals_interleaved():
     ops = _ops()
     from apex_studio_amd import lib
-    S, H = 96, 2
+    S, H = 96, 4
     dim = H * 128
     qkv = _bf(seeded((S, 3 * dim), 61)).to(DEV)
     ang = seeded((S, 64), 62) * 3
