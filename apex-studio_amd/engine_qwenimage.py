@@ -5,7 +5,7 @@ is cut back to the target tokens, :405-406; `img_shapes` :287-303).  Prompt embe
 the VAE-encoded condition image latents are inputs; the sampler loop stays in Python."""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 

@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import lib as _l
 from . import ops
-from .flux import _AdaNorm, _Config, _FF, _Linear, _Norm, _TimestepEmbedding, _repoint
+from .flux import _AdaNorm, _Config, _FF, _Linear, _TimestepEmbedding, _repoint
 from .lora import LoraAdapterMixin
 from .qwenimage import _QwenAttn
 

@@ -25,7 +25,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import lib as _l
 from . import ops
 from .flux import _Config
 from .text_encoders import _Base, _Emb, _N, _W, _cfg_dict

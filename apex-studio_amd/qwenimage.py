@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import contextlib
 from types import SimpleNamespace
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn

@@ -8,7 +8,7 @@ When this backend is dropped into the reference tree the reference's own registr
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, Optional
+from typing import Any, Dict, Optional
 
 
 class _Registry:

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import math
 from types import SimpleNamespace
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn

@@ -13,7 +13,7 @@ reference recomputes per forward, so the denoise kernels are unchanged.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
 
 import torch
 

@@ -17,7 +17,7 @@ which runs the reference's own classes with those leaves.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn

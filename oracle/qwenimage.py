@@ -13,11 +13,10 @@ come from oracle.layers.  zero_cond_t / additional_t_cond / layer3d rope variant
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import layers as L
 from .layers import Policy, FP32

@@ -15,7 +15,7 @@ test requires this restatement to match them.  Parameter names equal the referen
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn

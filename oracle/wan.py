@@ -16,7 +16,7 @@ fp32 aliasing defect) on top of oracle.layers leaves.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn
