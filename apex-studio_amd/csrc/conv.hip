@@ -36,6 +36,9 @@ struct ConvArgs {
     int kT, kH, kW, ntaps;
     int q64, r64;         // 64 / Cin, 64 % Cin
     int replicate;        // 0: out-of-range taps read zeros; 1: coordinates are clamped (replicate padding)
+    int Ho, Wo, sy, sx;   // output height / width and spatial stride (Ho = H, Wo = W, 1, 1 for the "same" convolutions)
+    int py, px;           // zero rows / columns assumed above / left of the input ((k-1)/2 for "same"; 0 for the
+                          // ZeroPad2d((0,1,0,1)) + stride-2 downsampling convolution of the VAE encoders)
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
@@ -52,12 +55,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
         const int dt = tid / (a.kH * a.kW), r = tid % (a.kH * a.kW);
         const int dy = r / a.kW, dx = r % a.kW;
         // causal in time (all padding on the left), symmetric "same" padding in space
-        tap_off[tid] = ((dt - (a.kT - 1)) & 0xff) | (((dy - (a.kH - 1) / 2) & 0xff) << 8) |
-                       (((dx - (a.kW - 1) / 2) & 0xff) << 16);
+        tap_off[tid] = ((dt - (a.kT - 1)) & 0xff) | (((dy - a.py) & 0xff) << 8) | (((dx - a.px) & 0xff) << 16);
     }
     __syncthreads();
 
-    const int M = a.T * a.H * a.W;
+    const int M = a.T * a.Ho * a.Wo;
     const int nm = (M + BM - 1) / BM;
     const int nn = (a.Cout + BN - 1) / BN;
     const int s = xcd_remap(blockIdx.x, nm * nn);
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
         const int p = (i * 4 + wave) * 64 + lane;
         const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, M - 1);
-        pos_t[i] = m / (a.H * a.W);
-        const int r = m % (a.H * a.W);
-        pos_y[i] = r / a.W;
-        pos_x[i] = r % a.W;
+        pos_t[i] = m / (a.Ho * a.Wo);
+        const int r = m % (a.Ho * a.Wo);
+        pos_y[i] = (r / a.Wo) * a.sy;   // input row / column of tap (0, 0) before the pad offset
+        pos_x[i] = (r % a.Wo) * a.sx;
         const int k = c * 8;
         a_tap[i] = k / a.Cin;
         a_ci[i] = k % a.Cin;
@@ -450,13 +452,21 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
 
 static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
-                          int replicate, apexmi_stream_t stream_) {
+                          int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
+                          int Ho = 0, int Wo = 0) {
+    if (py < 0) py = (kH - 1) / 2;   // "same" convolution
+    if (px < 0) px = (kW - 1) / 2;
+    if (Ho <= 0) Ho = H;
+    if (Wo <= 0) Wo = W;
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(in && w && out && zeros, "conv3d_cl: null operand");
     APEXMI_REQUIRE(T > 0 && H > 0 && W > 0, "conv3d_cl: empty volume");
     APEXMI_REQUIRE(Cin % 8 == 0 && Cout % 4 == 0, "conv3d_cl: Cin=%d must be a multiple of 8, Cout=%d of 4", Cin, Cout);
     const int ntaps = kT * kH * kW;
     APEXMI_REQUIRE(ntaps >= 1 && ntaps <= MAX_TAPS && (kH & 1) && (kW & 1), "conv3d_cl: kernel %dx%dx%d unsupported", kT, kH, kW);
+    APEXMI_REQUIRE(sy >= 1 && sx >= 1 && py >= 0 && px >= 0 && py < kH && px < kW && (Ho - 1) * sy - py < H &&
+                       (Wo - 1) * sx - px < W,
+                   "conv3d_cl: stride %dx%d / pad %d,%d / output %dx%d do not fit the %dx%d input", sy, sx, py, px, Ho, Wo, H, W);
     APEXMI_REQUIRE(Kpad % BK == 0 && Kpad >= ntaps * Cin, "conv3d_cl: Kpad=%d must be >= taps*Cin rounded up to 64", Kpad);
     APEXMI_REQUIRE((int64_t)T * H * W < (int64_t)2147483647 - BM, "conv3d_cl: volume too large for one call");
     APEXMI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
@@ -480,7 +490,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.q64 = 64 / Cin;
     a.r64 = 64 % Cin;
     a.replicate = replicate;
-    const int64_t M = (int64_t)T * H * W;
+    a.Ho = Ho; a.Wo = Wo; a.sy = sy; a.sx = sx; a.py = py; a.px = px;
+    const int64_t M = (int64_t)T * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps * Cin,
                          2.0 * ((double)M * Cin + (double)Cout * Kpad + (double)M * Cout));
@@ -492,6 +503,15 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
                                 void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
                                 int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_);
+}
+
+extern "C" int apexmi_conv3d_cl_strided(const void* in, const void* w, const void* bias, const void* residual,
+                                        void* out, const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad,
+                                        int kT, int kH, int kW, int stride_h, int stride_w, int pad_top, int pad_left,
+                                        int Ho, int Wo, apexmi_stream_t stream_) {
+    APEXMI_REQUIRE(Ho > 0 && Wo > 0, "conv3d_cl_strided: empty output %dx%d", Ho, Wo);
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, stride_h,
+                          stride_w, pad_top, pad_left, Ho, Wo);
 }
 
 extern "C" int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual,

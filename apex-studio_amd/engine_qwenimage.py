@@ -24,8 +24,10 @@ def _emit(cb, p, msg):
 
 
 class QwenImageEditPlusEngine(EngineLoraMixin):
-    def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, decode_fn=None):
+    def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, decode_fn=None,
+                 vae=None):
         self.transformer = transformer
+        self.vae = vae
         # Qwen-Image scheduler_config.json: dynamic exponential shifting, base/max shift 0.5/0.9,
         # base/max seq 256/8192, shift_terminal 0.02
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(
@@ -36,6 +38,59 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
     @property
     def device(self):
         return self.transformer.device
+
+    @staticmethod
+    def _pack_latents(latents):
+        """[B, C, 1, H, W] -> [B, (H/2)(W/2), 4 C] (QwenImage `_pack_latents`, engine/qwenimage/shared.py)."""
+        B, Cc, _, H, W = latents.shape
+        x = latents.view(B, Cc, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5)
+        return x.reshape(B, (H // 2) * (W // 2), Cc * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width):
+        B, _, ch = latents.shape
+        h, w = 2 * (height // 16), 2 * (width // 16)
+        x = latents.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+        return x.reshape(B, ch // 4, 1, h, w)
+
+    @torch.no_grad()
+    def vae_encode(self, image: torch.Tensor, sample_mode: str = "mode", generator=None) -> torch.Tensor:
+        """BaseEngine.vae_encode (engine/base_engine.py:2061-2165): tiled encode, posterior mode / sample, normalise."""
+        x = image.to(self.device, self.vae.dtype)
+        if x.dim() == 4:
+            x = x.unsqueeze(2)
+        self.vae.enable_tiling()
+        post = self.vae.encode(x, return_dict=False)[0]
+        if sample_mode not in ("mode", "sample"):
+            raise ValueError(f"Invalid sample mode: {sample_mode}")
+        lat = post.mode() if sample_mode == "mode" else post.sample(generator=generator)
+        return self.vae.normalize_latents(lat.to(self.vae.dtype))
+
+    def prepare_image_latents(self, images, batch_size: int = 1):
+        """`_prepare_image_latents` (engine/qwenimage/edit_plus.py:26-110) for condition images given as pixels in [-1, 1]
+        ([B, 3, H, W]) or as latents: encode (posterior mode), repeat to the batch, pack, concatenate along the sequence.
+        Returns (image_latents [B, S, 64], image_shapes [(H, W) in pixels, ...])."""
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        packed, shapes = [], []
+        for image in images:
+            lat = self.vae_encode(image) if image.shape[1] != 16 else image.to(self.device)
+            if lat.dim() == 4:
+                lat = lat.unsqueeze(2)
+            if batch_size > lat.shape[0]:
+                if batch_size % lat.shape[0]:
+                    raise ValueError(f"Cannot duplicate `image` of batch size {lat.shape[0]} to {batch_size} text prompts.")
+                lat = torch.cat([lat] * (batch_size // lat.shape[0]), dim=0)
+            shapes.append((lat.shape[3] * 8, lat.shape[4] * 8))
+            packed.append(self._pack_latents(lat))
+        return torch.cat(packed, dim=1), shapes
+
+    @torch.no_grad()
+    def vae_decode(self, latents: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        z = self._unpack_latents(latents, height, width)
+        z = self.vae.denormalize_latents(z.to(torch.float32)).to(self.vae.dtype)
+        self.vae.enable_tiling()
+        return self.vae.decode(z, return_dict=False)[0][:, :, 0]
 
     def base_denoise(self, latents, timesteps, prompt_embeds, img_shapes, image_latents=None,
                      negative_prompt_embeds=None, true_cfg_scale: float = 1.0, use_cfg_guidance: bool = False,
@@ -68,8 +123,10 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             image_shapes: Sequence[Tuple[int, int]] = (), height: int = 1024, width: int = 1024,
             num_inference_steps: int = 8, negative_prompt_embeds: Optional[torch.Tensor] = None,
             true_cfg_scale: float = 1.0, latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
-            return_latents: bool = True, progress_callback=None, **_ignored):
+            return_latents: bool = True, progress_callback=None, images=None, **_ignored):
         dev, dt = self.device, self.transformer.dtype
+        if images is not None:       # condition images as pixels (or latents): encode + pack here
+            image_latents, image_shapes = self.prepare_image_latents(images, prompt_embeds.shape[0])
         h2, w2 = height // 16, width // 16
         B = prompt_embeds.shape[0]
         if latents is None:
@@ -96,6 +153,8 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
                                     negative_prompt_embeds=None if not cfg else negative_prompt_embeds.to(dev, dt),
                                     true_cfg_scale=true_cfg_scale, use_cfg_guidance=cfg,
                                     denoise_progress_callback=mapped)
-        if return_latents or self.decode_fn is None:
+        if return_latents or (self.decode_fn is None and self.vae is None):
             return latents
-        return self.decode_fn(latents)
+        if self.decode_fn is not None:
+            return self.decode_fn(latents)
+        return self.vae_decode(latents, height, width)

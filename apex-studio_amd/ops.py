@@ -568,6 +568,25 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """ZeroPad2d((0, 1, 0, 1)) + Conv2d(3x3, stride 2) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4] with
+    Ho = (H - 2) // 2 + 1 (= H / 2 for even H); w_packed from pack_conv_weight of the [Cout, Cin, 3, 3] weight."""
+    _req(x, torch.bfloat16, "conv2d_cl_down2.x")
+    _req(w_packed, torch.bfloat16, "conv2d_cl_down2.w")
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, cin = x.shape
+    cout, kpad = w_packed.shape
+    Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        assert bias.numel() == cout and bias.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl_strided(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), None, out.data_ptr(),
+                                            _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, 1, 3, 3, 2, 2, 0, 0,
+                                            Ho, Wo, _stream())
+    _l.check(rc, "conv3d_cl_strided")
+    return out
+
+
 def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(x, torch.bfloat16, "rmsnorm_cl.x")

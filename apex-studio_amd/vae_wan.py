@@ -1,11 +1,17 @@
-"""AutoencoderKLWan decode on the MI355X HIP ops — drop-in for VAE registry keys "wan" / "qwenimage"
-(decode half; the encoder is not on the denoise -> decode hot path).
+"""AutoencoderKLWan on the MI355X HIP ops — drop-in for VAE registry keys "wan" / "qwenimage".
 
 Mirrors what the engines use of the reference class (apps/api/src/vae/wan/model.py:1083-1672, identical
-architecture at vae/qwenimage/model.py:774): `from_config`, state-dict keys `decoder.*` /
-`post_quant_conv.*` (encoder / quant_conv keys in a checkpoint are ignored by `strict=False`),
-`.config` (z_dim, latents_mean, latents_std), `enable_tiling(...)`, `denormalize_latents`,
-`decode(z, return_dict=False)[0]`, `.dtype`.
+architecture at vae/qwenimage/model.py:774): `from_config`, the reference's state-dict keys (`encoder.*`, `quant_conv.*`,
+`decoder.*`, `post_quant_conv.*`), `.config` (z_dim, latents_mean, latents_std), `enable_tiling(...)`,
+`denormalize_latents` / `normalize_latents`, `decode(z, return_dict=False)[0]`,
+`encode(x, return_dict=False)[0].mode() / .sample(generator)` (BaseEngine.vae_encode, engine/base_engine.py:2061-2165:
+the condition image of QwenImage-Edit, first frames of image-to-video), `.dtype`.
+
+Encode mirrors decode: every spatial tile's whole 1 + 4k frame sequence in one causal pass (the reference streams the
+first frame and then chunks of four with `feat_cache`, model.py:1273-1304; oracle/vae_wan.py proves both give the same
+numbers), the stride-2 spatial downsampling as a strided implicit-GEMM convolution with the zero pad on the right / bottom
+only, the temporal downsampling as "frame 0 passes through, output j is the 3-tap convolution ending at frame 2j", tiles
+of 256 px with stride 192 blended in latent space (`tiled_encode`, :1424-1514).
 
 Decode runs channels-last and processes every spatial tile's WHOLE frame sequence in one causal pass
 (the reference streams frame by frame with `feat_cache`; oracle/vae_wan.py proves both give the same
@@ -74,6 +80,15 @@ class _Resample(nn.Module):
             self.time_conv = _Conv(dim, 2 * dim, (3, 1, 1), **kw)
 
 
+class _Down(nn.Module):
+    def __init__(self, dim, mode, **kw):
+        super().__init__()
+        self.mode = mode
+        self.resample = nn.ModuleList([nn.Identity(), _Conv(dim, dim, (3, 3), **kw)])
+        if mode == "downsample3d":
+            self.time_conv = _Conv(dim, dim, (3, 1, 1), **kw)
+
+
 class _Mid(nn.Module):
     def __init__(self, dim, **kw):
         super().__init__()
@@ -110,6 +125,43 @@ class _Decoder(nn.Module):
         self.conv_out = _Conv(dims[-1], out_channels, (3, 3, 3), **kw)
 
 
+class _Encoder(nn.Module):
+    def __init__(self, in_channels, dim, z_dim, dim_mult, num_res_blocks, temperal_downsample, **kw):
+        super().__init__()
+        dims = [dim * u for u in [1] + dim_mult]
+        self.conv_in = _Conv(in_channels, dims[0], (3, 3, 3), **kw)
+        blocks = []
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                blocks.append(_Res(cin, cout, **kw))
+                cin = cout
+            if i != len(dim_mult) - 1:
+                blocks.append(_Down(cout, "downsample3d" if temperal_downsample[i] else "downsample2d", **kw))
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _Mid(dims[-1], **kw)
+        self.norm_out = _Gamma(dims[-1], False, **kw)
+        self.conv_out = _Conv(dims[-1], z_dim, (3, 3, 3), **kw)
+
+
+class DiagonalGaussianDistribution:
+    """The posterior object `encode(...)[0]` returns (diffusers DiagonalGaussianDistribution as the reference uses it,
+    model.py:1327): parameters [B, 2 z, T, H, W] = mean | logvar, logvar clamped to [-30, 20]."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        dev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=dev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+
 class AutoencoderKLWan(nn.Module):
     def __init__(self, base_dim: int = 96, decoder_base_dim: Optional[int] = None, z_dim: int = 16,
                  dim_mult: List[int] = (1, 2, 4, 4), num_res_blocks: int = 2, attn_scales=(),
@@ -125,12 +177,16 @@ class AutoencoderKLWan(nn.Module):
         self.config = _Config(base_dim=base_dim, decoder_base_dim=decoder_base_dim, z_dim=z_dim,
                               dim_mult=list(dim_mult), num_res_blocks=num_res_blocks,
                               temperal_downsample=list(temperal_downsample), latents_mean=list(latents_mean),
-                              latents_std=list(latents_std), out_channels=out_channels, patch_size=patch_size,
+                              latents_std=list(latents_std), in_channels=in_channels, out_channels=out_channels,
+                              patch_size=patch_size,
                               scale_factor_temporal=scale_factor_temporal,
                               scale_factor_spatial=scale_factor_spatial)
         kw = dict(device=device, dtype=dtype)
         self.z_dim = z_dim
         self.temperal_downsample = list(temperal_downsample)
+        self.encoder = _Encoder(in_channels, base_dim, z_dim * 2, list(dim_mult), num_res_blocks,
+                                list(temperal_downsample), **kw)
+        self.quant_conv = _Conv(z_dim * 2, z_dim * 2, (1, 1, 1), **kw)
         self.post_quant_conv = _Conv(z_dim, z_dim, (1, 1, 1), **kw)
         self.decoder = _Decoder(decoder_base_dim or base_dim, z_dim, list(dim_mult), num_res_blocks,
                                 list(temperal_downsample)[::-1], out_channels, **kw)
@@ -198,7 +254,11 @@ class AutoencoderKLWan(nn.Module):
         key = id(conv)
         p = self._packed.get(key)
         if p is None:
-            w = ops.pack_conv_weight(conv.weight.data)
+            wt = conv.weight.data
+            if wt.shape[1] % 8:      # the RGB input convolution: channels zero-padded to 8, as the activations are
+                pad = torch.zeros(wt.shape[0], 8 - wt.shape[1] % 8, *wt.shape[2:], dtype=wt.dtype, device=wt.device)
+                wt = torch.cat([wt, pad], dim=1)
+            w = ops.pack_conv_weight(wt)
             b = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
             b[:conv.bias.numel()] = conv.bias.data
             p = (w, b)
@@ -285,6 +345,74 @@ class AutoencoderKLWan(nn.Module):
             out = torch.cat(out_rows, dim=1)[:, :H * ratio, :W * ratio]
         out = out[..., :self.config.out_channels].clamp(-1.0, 1.0)
         return out.permute(3, 0, 1, 2).contiguous()
+
+    # ---- encode ----------------------------------------------------------------------------------
+    def _down(self, dn: _Down, x):
+        w, b = self._w(dn.resample[1])
+        x = ops.conv2d_cl_down2(x, w, b)
+        if dn.mode == "downsample3d" and x.shape[0] > 1:
+            y = self._conv(dn.time_conv, x)          # causal 3-tap convolution ending at every frame ...
+            x = torch.cat([x[:1], y[2::2]], dim=0)   # ... kept at frames 2, 4, ...; frame 0 passes through
+        return x
+
+    def _encode_tile(self, x):
+        """x [T, H, W, 8] channels-last (RGB + zero pad) -> posterior parameters [T', H/8, W/8, 2 z]."""
+        e = self.encoder
+        x = self._conv(e.conv_in, x)
+        for blk in e.down_blocks:
+            x = self._down(blk, x) if isinstance(blk, _Down) else self._res(blk, x)
+        x = self._res(e.mid_block.resnets[0], x)
+        x = self._attn(e.mid_block.attentions[0], x)
+        x = self._res(e.mid_block.resnets[1], x)
+        x = self._conv(e.conv_out, ops.rmsnorm_cl(x, e.norm_out.gamma.data.reshape(-1).contiguous(), silu=True))
+        return self._conv(self.quant_conv, x)
+
+    @torch.no_grad()
+    def _encode_one(self, x):
+        """x [3, T, H, W] in [-1, 1] -> [2 z, T', H/8, W/8] bf16."""
+        if x.device.type != "cuda" or self.dtype != torch.bfloat16:
+            raise _l.ApexMIError("wan_mi355 VAE needs bf16 weights and inputs on a ROCm device (no CPU fallback)")
+        Cin, T, H, W = x.shape
+        if (T - 1) % 4:
+            raise ValueError(f"encode expects 1 + 4k frames (the reference's chunking), got {T}")
+        ratio = self.spatial_compression_ratio
+        if H % ratio or W % ratio:
+            raise ValueError(f"encode expects height and width divisible by {ratio}, got {H}x{W}")
+        xc = torch.zeros((T, H, W, 8), dtype=torch.bfloat16, device=x.device)
+        xc[..., :Cin] = x.to(torch.bfloat16).permute(1, 2, 3, 0)
+        mh, mw = self.tile_sample_min_height, self.tile_sample_min_width
+        if not (self.use_tiling and (W > mw or H > mh)):
+            out = self._encode_tile(xc)
+        else:
+            sh, sw = self.tile_sample_stride_height, self.tile_sample_stride_width
+            lsh, lsw = sh // ratio, sw // ratio
+            bh, bw = mh // ratio - lsh, mw // ratio - lsw
+            rows = [[self._encode_tile(xc[:, i:i + mh, j:j + mw].contiguous()) for j in range(0, W, sw)]
+                    for i in range(0, H, sh)]
+            out_rows = []
+            for i, row in enumerate(rows):
+                parts = []
+                for j, tile in enumerate(row):
+                    if i > 0:
+                        a = rows[i - 1][j]
+                        e = min(a.shape[1], tile.shape[1], bh)
+                        ops.crossfade_(a[:, a.shape[1] - e:, :tile.shape[2]], tile[:, :e], dim=1)
+                    if j > 0:
+                        a = row[j - 1]
+                        e = min(a.shape[2], tile.shape[2], bw)
+                        ops.crossfade_(a[:, :tile.shape[1], a.shape[2] - e:], tile[:, :, :e], dim=2)
+                    parts.append(tile[:, :lsh, :lsw])
+                out_rows.append(torch.cat(parts, dim=2))
+            out = torch.cat(out_rows, dim=1)[:, :H // ratio, :W // ratio]
+        return out[..., :2 * self.z_dim].permute(3, 0, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        h = torch.stack([self._encode_one(x[b]) for b in range(x.shape[0])], dim=0).to(x.dtype)
+        posterior = DiagonalGaussianDistribution(h)
+        if not return_dict:
+            return (posterior,)
+        return SimpleNamespace(latent_dist=posterior)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

@@ -222,6 +222,15 @@ int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, in
 int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
                      int kW, apexmi_stream_t stream);
+/* Strided variant: out[t, y, x] reads in[t + dt - (kT-1), y stride_h + dy - pad_top, x stride_w + dx - pad_left], taps
+ * outside the input read zeros; out is [T, Ho, Wo, Cout].  `nn.ZeroPad2d((0, 1, 0, 1)) + nn.Conv2d(dim, dim, 3, stride=2)`
+ * of WanResample "downsample2d/3d" (R/src/vae/wan/model.py:276-283) is kT=1, kH=kW=3, stride 2, pad_top=pad_left=0,
+ * Ho = H / 2, Wo = W / 2: the VAE encoders' spatial downsampling without a padded copy. */
+int apexmi_conv3d_cl_strided(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                             const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                             int stride_h, int stride_w, int pad_top, int pad_left, int Ho, int Wo,
+                             apexmi_stream_t stream);
+
 /* HunyuanVideo15CausalConv3d.forward (vae/hunyuanvideo15/model.py:52-90): the same implicit GEMM with REPLICATE padding
  * (coordinates clamped: two frames in front, one pixel around) instead of zeros. */
 int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual, void* out,

@@ -11,6 +11,10 @@ fp32 CPU restatement of the Wan / QwenImage 3-D causal VAE DECODE path:
   blend_v / blend_h                           :1404-1422
   denormalize_latents                         :1649-1660
 
+and of the ENCODE path the engines call for condition images / first frames (`vae_encode`,
+engine/base_engine.py:2061-2165): AutoencoderKLWan._encode / tiled_encode (:1273-1304, :1424-1514),
+WanEncoder3d.forward (:665-713), WanResample "downsample2d/3d" (:276-286, :336-365) — class AutoencoderKLWanEncoder.
+
 Restated as ONE causal pass over a tile's whole frame sequence instead of the reference's per-frame
 streaming with `feat_cache`: a kernel-3 causal convolution fed the last two cached input frames is the
 same sum as the convolution over the full zero-left-padded sequence, and the temporal upsampler's
@@ -227,3 +231,102 @@ class AutoencoderKLWanDecoder(nn.Module):
             out_rows.append(torch.cat(out, dim=-1))
         dec = torch.cat(out_rows, dim=3)[:, :, :, :H * self.ratio, :W * self.ratio]
         return torch.clamp(dec, -1.0, 1.0)
+
+
+# ---- encode half ------------------------------------------------------------------------------------------------
+
+class Downsample(nn.Module):
+    """WanResample "downsample2d" / "downsample3d".  Full-sequence form of the streaming temporal downsample: the first
+    frame passes through and output j >= 1 is the kernel-3 convolution of frames (2j-2, 2j-1, 2j) — what the
+    reference computes chunk by chunk from the cached last frame (model.py:340-365) for 1 + 4k input frames."""
+
+    def __init__(self, dim: int, mode: str):
+        super().__init__()
+        self.mode = mode
+        self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+        if mode == "downsample3d":
+            self.time_conv = nn.Conv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1))
+
+    def forward(self, x, pol: Policy):
+        b, c, t, h, w = x.shape
+        y = pol.r(self.resample(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)))
+        x = y.view(b, t, c, y.size(2), y.size(3)).permute(0, 2, 1, 3, 4)
+        if self.mode == "downsample3d" and t > 1:
+            x = torch.cat([x[:, :, :1], pol.r(self.time_conv(x))], dim=2)
+        return x
+
+
+class Encoder3d(nn.Module):
+    def __init__(self, in_channels: int, dim: int, z_dim: int, dim_mult: List[int], num_res_blocks: int,
+                 temperal_downsample: List[bool]):
+        super().__init__()
+        dims = [dim * u for u in [1] + list(dim_mult)]
+        self.conv_in = CausalConv3d(in_channels, dims[0], 3, padding=1)
+        blocks = []
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                blocks.append(ResidualBlock(cin, cout))
+                cin = cout
+            if i != len(dim_mult) - 1:
+                blocks.append(Downsample(cout, "downsample3d" if temperal_downsample[i] else "downsample2d"))
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = MidBlock(dims[-1])
+        self.norm_out = RMSNorm(dims[-1], images=False)
+        self.conv_out = CausalConv3d(dims[-1], z_dim, 3, padding=1)
+
+    def forward(self, x, pol: Policy):
+        x = pol.r(self.conv_in(x))
+        for blk in self.down_blocks:
+            x = blk(x, pol)
+        x = self.mid_block(x, pol)
+        return pol.r(self.conv_out(pol.r(F.silu(self.norm_out(x)))))
+
+
+class AutoencoderKLWanEncoder(nn.Module):
+    """encode half of AutoencoderKLWan: `encode(x)` returns the posterior parameters [B, 2 z, T', H/8, W/8] (mean | logvar);
+    `.mode()` of the reference's DiagonalGaussianDistribution is the first z channels."""
+
+    def __init__(self, base_dim: int = 96, z_dim: int = 16, dim_mult=(1, 2, 4, 4), num_res_blocks: int = 2,
+                 temperal_downsample=(False, True, True), in_channels: int = 3, latents_mean=None, latents_std=None,
+                 scale_factor_spatial: int = 8):
+        super().__init__()
+        self.z_dim = z_dim
+        self.encoder = Encoder3d(in_channels, base_dim, z_dim * 2, list(dim_mult), num_res_blocks, list(temperal_downsample))
+        self.quant_conv = CausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.ratio = scale_factor_spatial
+        self.latents_mean, self.latents_std = latents_mean, latents_std
+        self.tile_min, self.tile_stride, self.use_tiling = (256, 256), (192, 192), False
+
+    enable_tiling = AutoencoderKLWanDecoder.enable_tiling
+    _blend = staticmethod(AutoencoderKLWanDecoder._blend)
+
+    def normalize_latents(self, z):
+        mean = torch.tensor(self.latents_mean).view(1, self.z_dim, 1, 1, 1).to(z)
+        inv_std = 1.0 / torch.tensor(self.latents_std).view(1, self.z_dim, 1, 1, 1).to(z)
+        return (z - mean) * inv_std
+
+    def _tile(self, x, pol):
+        return pol.r(self.quant_conv(self.encoder(x, pol)))
+
+    @torch.no_grad()
+    def encode(self, x, policy: Policy = FP32):
+        pol = policy
+        _, _, T, H, W = x.shape
+        assert (T - 1) % 4 == 0, "the reference encodes 1 + 4k frames"
+        if not (self.use_tiling and (W > self.tile_min[1] or H > self.tile_min[0])):
+            return self._tile(x, pol)
+        lat_stride = (self.tile_stride[0] // self.ratio, self.tile_stride[1] // self.ratio)
+        blend = (self.tile_min[0] // self.ratio - lat_stride[0], self.tile_min[1] // self.ratio - lat_stride[1])
+        rows = [[self._tile(x[:, :, :, i:i + self.tile_min[0], j:j + self.tile_min[1]], pol)
+                 for j in range(0, W, self.tile_stride[1])] for i in range(0, H, self.tile_stride[0])]
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, blend[0], 3)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, blend[1], 4)
+                out.append(tile[:, :, :, :lat_stride[0], :lat_stride[1]])
+            out_rows.append(torch.cat(out, dim=-1))
+        return torch.cat(out_rows, dim=3)[:, :, :, :H // self.ratio, :W // self.ratio]

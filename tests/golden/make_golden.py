@@ -348,6 +348,36 @@ def gen_vae_wan():
     print("vae_wan.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
 
 
+def gen_vae_wan_encode():
+    """The REFERENCE AutoencoderKLWan._encode (streaming encoder with feat_cache: first frame, then chunks of 4) on a 9-frame
+    clip and on a single image, untiled and tiled; outputs are the posterior parameters (mean | logvar)."""
+    install_vae_stubs()
+    ref_mod = load_by_path("ref_vae_wan_enc", "src/vae/wan/model.py")
+    from oracle.vae_wan import AutoencoderKLWanEncoder
+    ref = ref_mod.AutoencoderKLWan(**TINY_VAE).eval()
+    orc = AutoencoderKLWanEncoder(**TINY_VAE)
+    sd = vae_synthetic_state_dict(orc, 15)
+    missing = ref.load_state_dict(sd, strict=False)      # decoder / post_quant_conv keep their init
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all(k.startswith(("decoder.", "post_quant_conv.")) for k in missing.missing_keys)
+    x = seeded((1, 3, 9, 64, 80), 63)
+    tile = dict(tile_sample_min_height=48, tile_sample_min_width=48, tile_sample_stride_height=32,
+                tile_sample_stride_width=32)
+    with torch.no_grad():
+        video = ref._encode(x)
+        image = ref._encode(x[:, :, :1])
+        ref.enable_tiling(**tile)
+        video_tiled = ref._encode(x)
+        image_tiled = ref._encode(x[:, :, :1])
+        zn = ref.normalize_latents(video[:, :16])
+    assert float((video_tiled - video).abs().max()) > 1e-3
+    torch.save(dict(config=TINY_VAE, seed=15, x_shape=(1, 3, 9, 64, 80), x_seed=63, tile=(48, 48, 32, 32), video=video,
+                    image=image, video_tiled=video_tiled, image_tiled=image_tiled, norm_sample=zn[0, :, 0, 0, 0].clone(),
+                    keys=sorted(sd.keys())), os.path.join(OUT, "vae_wan_encode.pt"))
+    print("vae_wan_encode.pt", tuple(video.shape), tuple(image.shape), float(video.abs().mean()),
+          float((video_tiled - video).abs().max()))
+
+
 TINY_VAE_HY15 = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
                      layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
 
@@ -650,6 +680,7 @@ def main():
     gen_qwen_hybrid()
     gen_hunyuan15_hybrid()
     gen_vae_wan()
+    gen_vae_wan_encode()
     gen_vae_hunyuan15()
     gen_unipc()
     gen_lora()

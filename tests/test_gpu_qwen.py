@@ -94,3 +94,33 @@ def test_qwen_full_width_one_block_matches_oracle(host_threads):
     print(f"[qwen full width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
     assert e_like < 1e-2, e_like
     assert e_true < 2 * e_emul + 2e-3
+
+
+def test_qwen_edit_pixels_in_pixels_out():
+    """QwenImage-Edit from pixels: condition image -> tiled VAE encode (posterior mode) -> normalise -> pack -> denoise
+    loop -> unpack -> denormalise -> tiled VAE decode, all on the HIP classes; the `images=` entry must give exactly what
+    precomputed `image_latents=` give, and the packed latents must equal pack(normalise(encode))."""
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from tests.golden.seeded import vae_synthetic_state_dict
+    cfg = CONFIGS["tiny"][0]
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(OQ.QwenImageTransformer2DModel(**cfg), 3).items()})
+    vcfg = dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True])
+    vae = AutoencoderKLWan(**vcfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vae_synthetic_state_dict(vae, 31).items()}, strict=True)
+    eng = QwenImageEditPlusEngine(m, vae=vae)
+    img = seeded((1, 3, 96, 64), 71).clamp(-1, 1)
+    lat, shapes = eng.prepare_image_latents(img.to(DEV))
+    assert lat.shape == (1, (96 // 16) * (64 // 16), 64) and shapes == [(96, 64)]
+    post = vae.encode(img.to(DEV, torch.bfloat16).unsqueeze(2), return_dict=False)[0]
+    assert torch.equal(lat, eng._pack_latents(vae.normalize_latents(post.mode())))
+    assert torch.equal(eng._unpack_latents(lat, 96, 64), vae.normalize_latents(post.mode()))
+    txt = seeded((1, 13, 64), 72).to(torch.bfloat16)
+    kw = dict(prompt_embeds=txt.to(DEV), height=128, width=96, num_inference_steps=2, seed=5)
+    a = eng.run(images=img.to(DEV), return_latents=True, **kw)
+    b = eng.run(image_latents=lat, image_shapes=shapes, return_latents=True, **kw)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    out = eng.run(images=img.to(DEV), return_latents=False, **kw)
+    assert out.shape == (1, 3, 128, 96) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0

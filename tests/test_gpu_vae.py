@@ -78,7 +78,10 @@ def test_vae_elementwise_ops():
 def _hip_vae(cfg, sd):
     from apex_studio_amd.vae_wan import AutoencoderKLWan
     vae = AutoencoderKLWan(**cfg, device=DEV, dtype=torch.bfloat16)
-    missing = vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    res = vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=False)   # one half at a time
+    assert not res.unexpected_keys
+    halves = (("encoder.", "quant_conv."), ("decoder.", "post_quant_conv."))
+    assert any(all(k.startswith(h) for k in res.missing_keys) for h in halves), res.missing_keys[:4]
     return vae
 
 
@@ -91,7 +94,7 @@ def test_vae_decode_matches_streaming_reference_and_oracle(golden_dir):
     orc.load_state_dict(sd, strict=True)
     z = seeded(g["z_shape"], g["z_seed"]).to(torch.bfloat16)
     vae = _hip_vae(cfg, sd)
-    assert sorted(vae.state_dict().keys()) == g["keys"]
+    assert sorted(k for k in vae.state_dict() if k.startswith(("decoder.", "post_quant_conv."))) == g["keys"]
     for tiled in (False, True):
         if tiled:
             vae.enable_tiling(*g["tile"])
@@ -238,3 +241,52 @@ def test_hunyuan15_vae_decode_matches_reference_and_oracle(golden_dir):
     assert torch.equal(vae.decode(z.to(DEV), return_dict=False)[0], vae.decode(z.to(DEV), return_dict=False)[0])
     zn = vae.denormalize_latents(z.to(DEV).float())
     assert torch.allclose(zn.cpu(), z.float() / cfg.get("scaling_factor", 1.03682), atol=1e-6)
+
+
+# ---- Wan / QwenImage VAE encode (the B-model `.encode` contract) ------------------------------------
+
+@pytest.mark.parametrize("cin,cout,T,H,W", [(32, 32, 3, 16, 20), (64, 64, 1, 33, 18), (96, 96, 2, 64, 48)])
+def test_conv2d_cl_down2(cin, cout, T, H, W):
+    """WanResample "downsample2d": ZeroPad2d((0, 1, 0, 1)) + Conv2d(dim, dim, 3, stride=2), per frame."""
+    from apex_studio_amd import ops
+    x = _bf(seeded((T, H, W, cin), 1))
+    w = _bf(seeded((cout, cin, 3, 3), 2, scale=(cin * 9) ** -0.5))
+    b = _bf(seeded((cout,), 3) * 0.1)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    out = ops.conv2d_cl_down2(x.to(DEV), wp, b.to(DEV))
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.float(), b.float(), stride=2).permute(0, 2, 3, 1)
+    assert out.shape == ref.shape and _rel(out.cpu(), ref) < 4e-3
+
+
+def test_wan_vae_encode_matches_streaming_reference_and_oracle(golden_dir):
+    from oracle.vae_wan import AutoencoderKLWanEncoder
+    g = torch.load(os.path.join(golden_dir, "vae_wan_encode.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = AutoencoderKLWanEncoder(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    vae = _hip_vae(cfg, sd)
+    assert sorted(k for k in vae.state_dict() if k.startswith(("encoder.", "quant_conv."))) == g["keys"]
+    x = seeded(g["x_shape"], g["x_seed"]).to(torch.bfloat16)
+    for tiled in (False, True):
+        if tiled:
+            vae.enable_tiling(*g["tile"])
+            orc.enable_tiling(*g["tile"])
+        for name, xin in (("video", x), ("image", x[:, :, :1])):
+            post = vae.encode(xin.to(DEV), return_dict=False)[0]
+            got = post.parameters.float().cpu()
+            ref = g[name + ("_tiled" if tiled else "")]                       # the reference class, streaming, fp32
+            ref16, ref32 = orc.encode(xin.float(), policy=OL.BF16_STORAGE), orc.encode(xin.float())
+            assert got.shape == ref.shape and torch.isfinite(got).all()
+            e_like, e_ref, e_emul = _rel(got, ref16), _rel(got, ref), _rel(ref16, ref32)
+            print(f"[vae encode {name} tiled={tiled}] hip vs bf16-storage oracle {e_like:.3e}; vs reference streaming {e_ref:.3e}; "
+                  f"emulation vs fp32 {e_emul:.3e}")
+            assert e_like < 2e-2 and e_ref < 2 * e_emul + 1e-2
+            assert torch.equal(post.mode(), post.parameters[:, :cfg["z_dim"]])
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    smp = post.sample(gen)
+    assert smp.shape == post.mode().shape and not torch.equal(smp, post.mode())
+    lat = post.mode().float()
+    assert torch.allclose(vae.denormalize_latents(vae.normalize_latents(lat)), lat, atol=1e-4)
+    with pytest.raises(ValueError):
+        vae.encode(x[:, :, :3].to(DEV))

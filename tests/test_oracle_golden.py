@@ -252,3 +252,21 @@ def test_qwen2_5_vl_restatement_matches_transformers(golden_dir):
     assert torch.allclose(vis, im["vision"], atol=3e-5, rtol=1e-4)
     out = m(im["ids"], attention_mask=im["mask"], pixel_values=im["pixel_values"], image_grid_thw=im["grid"])
     assert torch.allclose(out.hidden_states[-1], im["last"], atol=3e-5, rtol=1e-4)
+
+
+def test_vae_encode_full_sequence_restatement_matches_streaming_reference(golden_dir):
+    """oracle.vae_wan.AutoencoderKLWanEncoder encodes a clip in ONE pass (strided temporal downsampling over the whole
+    sequence, frame 0 passing through); the reference streams 1 + 4 + 4 frames with feat_cache
+    (tests/golden/vae_wan_encode.pt is its `_encode` output: clip and single image, untiled and tiled)."""
+    from oracle.vae_wan import AutoencoderKLWanEncoder
+    from tests.golden.seeded import vae_synthetic_state_dict
+    g = _load(golden_dir, "vae_wan_encode.pt")
+    vae = AutoencoderKLWanEncoder(**g["config"]).eval()
+    assert sorted(vae.state_dict().keys()) == g["keys"]
+    vae.load_state_dict(vae_synthetic_state_dict(vae, g["seed"]), strict=True)
+    x = seeded(g["x_shape"], g["x_seed"])
+    assert torch.allclose(vae.encode(x), g["video"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(vae.encode(x[:, :, :1]), g["image"], atol=2e-5, rtol=1e-4)
+    vae.enable_tiling(*g["tile"])
+    assert torch.allclose(vae.encode(x), g["video_tiled"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(vae.encode(x[:, :, :1]), g["image_tiled"], atol=2e-5, rtol=1e-4)
