@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""End-to-end clips on one MI355X, every stage on the HIP classes, random weights (there is no network for
+checkpoints): token ids / pixels in, uint8 frames out, with the time of each stage.
+
+  flux : T5-XXL (512 tokens) + CLIP-L (77) -> 28 denoise steps -> 2-D VAE decode -> frames          (BASELINE config 1)
+  qwen : Qwen2.5-VL-7B (prompt + 1 condition image) + VAE encode of the condition image -> 8 steps -> decode -> frames
+         (BASELINE config 2, QwenImage-Edit-2509 with the 8-step lightning schedule)
+
+usage: pipeline_demo.py flux|qwen [steps]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import apex_studio_amd  # noqa: E402,F401
+from apex_studio_amd import postprocess  # noqa: E402
+from apex_studio_amd import text_encoders as TE  # noqa: E402
+from bench import FLUX_DEV, synth_vae_init  # noqa: E402
+
+dev = torch.device("cuda", 0)
+which = sys.argv[1] if len(sys.argv) > 1 else "flux"
+
+
+def init(m, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for n, p in m.named_parameters():
+        if "norm" in n or n.endswith("ln_q.weight"):
+            p.data.fill_(1.0)
+        elif n.endswith("bias"):
+            p.data.zero_()
+        else:
+            p.data.copy_((torch.randn(p.shape, generator=g, device=dev) * (0.125 if n.endswith(".q.weight") else 1.0)
+                          / p.shape[-1] ** 0.5).to(p.dtype))
+    return m
+
+
+class Timer:
+    def __init__(self):
+        self.t = {}
+
+    def __call__(self, name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        self.t[name] = round((time.perf_counter() - t0) * 1e3, 2)
+        return out
+
+
+def flux(steps):
+    from apex_studio_amd.engine_flux import FluxT2IEngine
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    t5 = init(TE.T5EncoderModel({}, device=dev), 1)
+    clip = init(TE.CLIPTextModel({}, device=dev), 2)
+    model = FluxTransformer2DModel(**FLUX_DEV, device=dev, dtype=torch.bfloat16).init_synthetic(seed=3)
+    model.pack()
+    vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
+    eng = FluxT2IEngine(model, decode_fn=lambda z: vae.decode(vae.denormalize_latents(z.float()).to(vae.dtype),
+                                                               return_dict=False)[0])
+    ids5 = torch.randint(3, 30000, (1, 512), device=dev)
+    idsc = torch.randint(3, 49000, (1, 77), device=dev)
+    idsc[0, 40] = 49407
+    result = {}
+    for rep in range(2):            # the first pass packs weights and sizes workspaces
+        tm = Timer()
+        emb = tm("t5_xxl_encode", lambda: t5(input_ids=ids5).last_hidden_state)
+        pooled = tm("clip_l_encode", lambda: clip(input_ids=idsc).pooler_output)
+        img = tm(f"denoise_{steps}_steps+vae_decode", lambda: eng.run(emb, pooled, num_inference_steps=steps, seed=1))
+        frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frame(img, "uint8"))
+        result = dict(tm.t, total_ms=round(sum(tm.t.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
+    return result
+
+
+def qwen(steps):
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vl = init(Qwen2_5_VLForConditionalGeneration({}, device=dev), 1)
+    model = QwenImageTransformer2DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=2)
+    model.pack()
+    vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
+    eng = QwenImageEditPlusEngine(model, vae=vae)
+    IMG = vl.config.image_token_id
+    seq = list(range(100, 164)) + [IMG] * 196 + list(range(300, 420))          # template + one 392x392 view + prompt
+    ids = torch.tensor([seq], device=dev)
+    grid = torch.tensor([[1, 28, 28]])
+    pix = torch.randn(784, 1176, device=dev).to(torch.bfloat16)
+    image = (torch.rand(1, 3, 1024, 1024, device=dev) * 2 - 1).to(torch.bfloat16)
+    result = {}
+    for rep in range(2):
+        tm = Timer()
+        hs = tm("qwen2_5_vl_7b_encode", lambda: vl(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=pix,
+                                                    image_grid_thw=grid, output_hidden_states=True).hidden_states[-1])
+        emb = hs[:, 64:]                                                        # drop the template tokens
+        lat = tm("vae_encode_1024", lambda: eng.prepare_image_latents(image))
+        img = tm(f"denoise_{steps}_steps+vae_decode",
+                 lambda: eng.run(prompt_embeds=emb, image_latents=lat[0], image_shapes=lat[1], height=1024, width=1024,
+                                 num_inference_steps=steps, seed=1, return_latents=False))
+        frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frame(img, "uint8"))
+        result = dict(tm.t, total_ms=round(sum(tm.t.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
+    return result
+
+
+if __name__ == "__main__":
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (28 if which == "flux" else 8)
+    out = flux(steps) if which == "flux" else qwen(steps)
+    print(json.dumps({"pipeline": which, "steps": steps, **out}))
