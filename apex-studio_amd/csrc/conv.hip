@@ -32,7 +32,8 @@ struct ConvArgs {
     const bf16_t* res;    // [T, H, W, Cout] or null
     bf16_t* out;          // [T, H, W, Cout]
     const bf16_t* zeros;  // >= 16 bytes of zeros
-    int T, H, W, Cin, Cout, Kpad;
+    int T, H, W, Cin, Cout, Kpad;   // Kpad: row stride of w (elements)
+    int Kext;                       // K extent actually iterated (a multiple of 64, <= Kpad)
     int kT, kH, kW, ntaps;
     int q64, r64;         // 64 / Cin, 64 % Cin
     int replicate;        // 0: out-of-range taps read zeros; 1: coordinates are clamped (replicate padding)
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nkt = a.Kpad / BK;
+    const int nkt = a.Kext / BK;
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES + wave * 1024;
@@ -453,7 +454,7 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
 static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
-                          int Ho = 0, int Wo = 0) {
+                          int Ho = 0, int Wo = 0, int independent = 0) {
     if (py < 0) py = (kH - 1) / 2;   // "same" convolution
     if (px < 0) px = (kW - 1) / 2;
     if (Ho <= 0) Ho = H;
@@ -485,16 +486,31 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.res = (const bf16_t*)residual;
     a.out = (bf16_t*)out;
     a.zeros = (const bf16_t*)zeros;
-    a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Kpad = Kpad;
-    a.kT = kT; a.kH = kH; a.kW = kW; a.ntaps = ntaps;
+    // A single frame sees only the LAST temporal tap: the kT - 1 earlier ones fall in the causal zero padding
+    // (QwenImage's image VAE and every T = 1 tile run 3x3x3 kernels on one frame).  Skip them: start at the last
+    // temporal slice of the packed weight (k = tap * Cin + ci, taps time-major) and iterate kH*kW taps — a third of the
+    // work, the same sum (the skipped products are exact zeros).
+    int Kext = Kpad, kT_eff = kT, ntaps_eff = ntaps;
+    const int skip = (kT - 1) * kH * kW * Cin, kspatial = ((kH * kW * Cin + BK - 1) / BK) * BK;
+    APEXMI_REQUIRE(!independent || kT == 1 || (!replicate && skip % 8 == 0 && skip + kspatial <= Kpad),
+                   "conv3d_cl_frames: Kpad=%d leaves no room to address the last temporal slice (need >= %d; pack the "
+                   "weight with apexmi's packing rule)", Kpad, skip + kspatial);
+    if ((T == 1 || independent) && kT > 1 && !replicate && skip % 8 == 0 && skip + kspatial <= Kpad) {
+        a.w += skip;
+        Kext = kspatial;
+        kT_eff = 1;
+        ntaps_eff = kH * kW;
+    }
+    a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Kpad = Kpad; a.Kext = Kext;
+    a.kT = kT_eff; a.kH = kH; a.kW = kW; a.ntaps = ntaps_eff;
     a.q64 = 64 / Cin;
     a.r64 = 64 % Cin;
     a.replicate = replicate;
     a.Ho = Ho; a.Wo = Wo; a.sy = sy; a.sx = sx; a.py = py; a.px = px;
     const int64_t M = (int64_t)T * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
-    ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps * Cin,
-                         2.0 * ((double)M * Cin + (double)Cout * Kpad + (double)M * Cout));
+    ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
+                         2.0 * ((double)M * Cin + (double)Cout * Kext + (double)M * Cout));
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
     return apexmi_check_launch("conv3d_cl");
 }
@@ -503,6 +519,13 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
                                 void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
                                 int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_);
+}
+
+extern "C" int apexmi_conv3d_cl_frames(const void* in, const void* w, const void* bias, const void* residual,
+                                       void* out, const void* zeros, int N, int H, int W, int Cin, int Cout, int Kpad,
+                                       int kT, int kH, int kW, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, N, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
+                          0, 0, 1);
 }
 
 extern "C" int apexmi_conv3d_cl_strided(const void* in, const void* w, const void* bias, const void* residual,

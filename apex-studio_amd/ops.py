@@ -537,6 +537,9 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     cout, cin = w.shape[:2]
     k = w.shape[2] * w.shape[3] * w.shape[4] * cin
     kpad = (k + 63) // 64 * 64
+    if w.shape[2] > 1:     # room to address the last temporal slice on its own (single-frame / independent-frame launches)
+        spatial = w.shape[3] * w.shape[4] * cin
+        kpad = (max(kpad, (w.shape[2] - 1) * spatial + (spatial + 63) // 64 * 64) + 63) // 64 * 64
     cout4 = (cout + 3) // 4 * 4
     out = torch.zeros(cout4, kpad, dtype=w.dtype, device=w.device)
     out[:cout, :k] = w.permute(0, 2, 3, 4, 1).reshape(cout, k)
@@ -545,7 +548,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              replicate: bool = False) -> torch.Tensor:
+              replicate: bool = False, independent_frames: bool = False) -> torch.Tensor:
     """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" padding in space: zeros, or (replicate)
     clamped coordinates as HunyuanVideo15CausalConv3d pads."""
     _req(x, torch.bfloat16, "conv3d_cl.x")
@@ -560,7 +563,9 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
         assert bias.numel() == cout and bias.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
-    fn = _l.load().apexmi_conv3d_cl_replicate if replicate else _l.load().apexmi_conv3d_cl
+    assert not (replicate and independent_frames)
+    fn = (_l.load().apexmi_conv3d_cl_replicate if replicate else
+          _l.load().apexmi_conv3d_cl_frames if independent_frames else _l.load().apexmi_conv3d_cl)
     rc = fn(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
             _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]), int(ksize[1]), int(ksize[2]),
             _stream())

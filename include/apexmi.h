@@ -222,6 +222,16 @@ int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, in
 int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
                      int kW, apexmi_stream_t stream);
+/* N INDEPENDENT single-frame clips in one launch: in / out are [N, H, W, C] and every frame is convolved as if it were
+ * a one-frame clip — of a causal kT-tap kernel only the last temporal tap touches data, the others fall in the zero
+ * padding, so the launch iterates kH*kW taps from the last temporal slice of the packed weight.  (A single-frame call
+ * of apexmi_conv3d_cl does the same by itself.)  This is how the 36 spatial tiles of a 1024x1024 QwenImage VAE
+ * decode / encode run as 4 shape groups instead of 36 tile passes; results equal the per-tile calls bit for bit.
+ * Kpad must leave room for that slice: Kpad >= (kT-1) kH kW Cin + round_up(kH kW Cin, 64). */
+int apexmi_conv3d_cl_frames(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                            const void* zeros, int N, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                            apexmi_stream_t stream);
+
 /* Strided variant: out[t, y, x] reads in[t + dt - (kT-1), y stride_h + dy - pad_top, x stride_w + dx - pad_left], taps
  * outside the input read zeros; out is [T, Ho, Wo, Cout].  `nn.ZeroPad2d((0, 1, 0, 1)) + nn.Conv2d(dim, dim, 3, stride=2)`
  * of WanResample "downsample2d/3d" (R/src/vae/wan/model.py:276-283) is kT=1, kH=kW=3, stride 2, pad_top=pad_left=0,

@@ -23,7 +23,9 @@ def _bf(x):
 
 @pytest.mark.parametrize("cin,cout,k,T,H,W", [(16, 16, (1, 1, 1), 3, 9, 11), (16, 128, (3, 3, 3), 3, 12, 10),
                                                (96, 96, (3, 3, 3), 5, 20, 24), (192, 384, (3, 1, 1), 4, 8, 8),
-                                               (128, 64, (1, 3, 3), 3, 16, 16), (96, 3, (3, 3, 3), 2, 33, 17)])
+                                               (128, 64, (1, 3, 3), 3, 16, 16), (96, 3, (3, 3, 3), 2, 33, 17),
+                                               (96, 96, (3, 3, 3), 1, 20, 24), (16, 128, (3, 3, 3), 1, 12, 10),
+                                               (384, 384, (3, 3, 3), 1, 16, 16), (192, 96, (3, 1, 1), 1, 8, 8)])
 def test_conv3d_cl(cin, cout, k, T, H, W):
     from apex_studio_amd import ops
     x = _bf(seeded((T, H, W, cin), 1))
@@ -290,3 +292,36 @@ def test_wan_vae_encode_matches_streaming_reference_and_oracle(golden_dir):
     assert torch.allclose(vae.denormalize_latents(vae.normalize_latents(lat)), lat, atol=1e-4)
     with pytest.raises(ValueError):
         vae.encode(x[:, :, :3].to(DEV))
+
+
+def test_single_frame_tiles_batched_pass_is_bit_identical():
+    """An image (T = 1) decodes / encodes its spatial tiles in shape groups, every frame of a stacked tensor treated as
+    an independent one-frame clip (`apexmi_conv3d_cl_frames`): same bits as one pass per tile, and the independent-frame
+    convolution equals per-frame calls."""
+    from apex_studio_amd import ops
+    from oracle.vae_wan import AutoencoderKLWanDecoder
+    cfg = dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True])
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vae = AutoencoderKLWan(**cfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vae_synthetic_state_dict(vae, 23).items()}, strict=True)
+    vae.enable_tiling(48, 48, 32, 32)
+    z = seeded((1, 16, 1, 14, 10), 81).to(torch.bfloat16).to(DEV)
+    x = seeded((1, 3, 1, 112, 80), 82).clamp(-1, 1).to(torch.bfloat16).to(DEV)
+    outs = []
+    for batched in (True, False):
+        vae.batch_single_frame_tiles = batched
+        outs.append((vae.decode(z, return_dict=False)[0], vae.encode(x, return_dict=False)[0].parameters))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].shape == (1, 3, 1, 112, 80) and outs[0][1].shape == (1, 32, 1, 14, 10)
+    orc = AutoencoderKLWanDecoder(**cfg).eval()
+    orc.load_state_dict({k: v for k, v in vae_synthetic_state_dict(vae, 23).items() if k in orc.state_dict()}, strict=True)
+    orc.enable_tiling(48, 48, 32, 32)
+    assert _rel(outs[0][0].float().cpu(), orc.decode(z.float().cpu(), policy=OL.BF16_STORAGE)) < 2e-2
+    # the op itself: N frames in one launch == N single-frame launches
+    for cin, cout in ((16, 96), (96, 96)):
+        xs = _bf(seeded((5, 12, 10, cin), 83)).to(DEV)
+        w = ops.pack_conv_weight(_bf(seeded((cout, cin, 3, 3, 3), 84, scale=(27 * cin) ** -0.5)).to(DEV))
+        b = _bf(seeded((cout,), 85) * 0.1).to(DEV)
+        one = torch.cat([ops.conv3d_cl(xs[i:i + 1].contiguous(), w, b, (3, 3, 3)) for i in range(5)], dim=0)
+        assert torch.equal(ops.conv3d_cl(xs, w, b, (3, 3, 3), independent_frames=True), one)
+        assert not torch.equal(ops.conv3d_cl(xs, w, b, (3, 3, 3)), one)            # as one clip the frames DO mix
