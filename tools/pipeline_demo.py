@@ -6,7 +6,10 @@ checkpoints): token ids / pixels in, uint8 frames out, with the time of each sta
   qwen : Qwen2.5-VL-7B (prompt + 1 condition image) + VAE encode of the condition image -> 8 steps -> decode -> frames
          (BASELINE config 2, QwenImage-Edit-2509 with the 8-step lightning schedule)
 
-usage: pipeline_demo.py flux|qwen [steps]"""
+  wan  : UMT5-XXL (512 tokens) -> N UniPC steps over the two Wan-2.2-A14B experts -> tiled 3-D VAE decode -> 81 frames
+         (BASELINE config 3; default 4 steps here — a full clip is 30 steps, 175 s)
+
+usage: pipeline_demo.py flux|qwen|wan [steps]"""
 import json
 import os
 import sys
@@ -106,7 +109,27 @@ def qwen(steps):
     return result
 
 
+def wan(steps):
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from apex_studio_amd.wan import WanTransformer3DModel
+    umt5 = init(TE.UMT5EncoderModel({}, device=dev), 1)
+    hi = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(2)
+    lo = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(3)
+    eng = WanT2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6))
+    ids = torch.randint(3, 30000, (1, 512), device=dev)
+    mask = torch.ones_like(ids)
+    mask[0, 300:] = 0
+    tm = Timer()
+    emb = tm("umt5_xxl_encode", lambda: umt5(input_ids=ids, attention_mask=mask).last_hidden_state)
+    emb = tm("umt5_xxl_encode", lambda: umt5(input_ids=ids, attention_mask=mask).last_hidden_state)     # second pass
+    video = tm(f"denoise_{steps}_steps+vae_decode", lambda: eng.run(prompt_embeds=emb, height=720, width=1280, duration=81,
+                                                                    num_inference_steps=steps, seed=1))
+    frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frames(video, "uint8"))
+    return dict(tm.t, total_ms=round(sum(tm.t.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
+
+
 if __name__ == "__main__":
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (28 if which == "flux" else 8)
-    out = flux(steps) if which == "flux" else qwen(steps)
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else {"flux": 28, "qwen": 8, "wan": 4}[which]
+    out = {"flux": flux, "qwen": qwen, "wan": wan}[which](steps)
     print(json.dumps({"pipeline": which, "steps": steps, **out}))
