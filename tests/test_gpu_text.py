@@ -191,3 +191,25 @@ def test_t5_xxl_width_one_block_matches_oracle(host_threads):
     e_like, e_true, e_emul = _rel(got[real], ref16[real]), _rel(got[real], ref32[real]), _rel(ref16[real], ref32[real])
     print(f"[t5 xxl width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
     assert e_like < 2e-2 and e_true < 2 * e_emul + 2e-3
+
+
+def test_t5_byt5_like_geometry_matches_oracle():
+    """ByT5-style proportions (HunyuanVideo-1.5's glyph encoder is a T5 v1.1 encoder: d_model 1472, 6 heads x 64, d_ff 3584):
+    inner width != d_model, head count not a power of two, a 73-token padded prompt."""
+    from apex_studio_amd import text_encoders as TE
+    cfg = dict(vocab_size=384, d_model=192, d_kv=64, d_ff=448, num_layers=3, num_heads=6)
+    orc = OT.T5EncoderModel(**cfg).eval()
+    sd = text_encoder_state_dict(orc, 61, 62, "layer_norm.weight")
+    sd.pop("encoder.embed_tokens.weight")
+    orc.load_state_dict(sd, strict=False)
+    hip = _load_hip(TE.T5EncoderModel, cfg, sd)
+    ids = torch.randint(1, 384, (2, 73), generator=torch.Generator().manual_seed(4))
+    mask = torch.ones(2, 73, dtype=torch.long)
+    mask[0, 50:] = 0
+    got = hip(input_ids=ids.to(DEV), attention_mask=mask.to(DEV)).last_hidden_state.float().cpu()
+    ref16 = orc(ids, attention_mask=mask, policy=OL.BF16_STORAGE).last_hidden_state
+    ref32 = orc(ids, attention_mask=mask).last_hidden_state
+    real = mask.bool()
+    e_like, e_true, e_emul = _rel(got[real], ref16[real]), _rel(got[real], ref32[real]), _rel(ref16[real], ref32[real])
+    print(f"[t5 byt5-like] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+    assert e_like < 2e-2 and e_true < 2 * e_emul + 2e-3
