@@ -426,6 +426,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
         if dom == "gemm" and args.workload == "flux" and os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+        pmc_wan = os.path.join(ROOT, "profiles", "r01_pmc_attn_wan.json")
+        if dom == "attention" and args.workload == "wan" and os.path.exists(pmc_wan):
+            traffic = json.load(open(pmc_wan)).get("traffic_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_c4_kernel",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
