@@ -236,11 +236,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
 }
 
 // ---- 4-cluster ping-pong variant (8 waves) ---------------------------------------------------------------
+// Tail mode (nsplit > 1): the launch covers the workgroups s_base .. of the (head, q-block) order that would otherwise
+// form a nearly empty last round, each cut into nsplit key ranges; a workgroup writes its normalised partial output
+// (bf16) and the log2-sum-exp of its rows, attn_combine_kernel merges them.
 template <int NW, int PRIO>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
-    bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
-    int64_t o_ss, int64_t o_sh, float scale_log2e) {
+    bf16_t* __restrict__ O, int H, int Sq, int Sk_all, int Skp, int nqb, int total, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale_log2e, int s_base, int nsplit, bf16_t* __restrict__ opart,
+    float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -248,13 +252,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int s = xcd_remap(blockIdx.x, total);
+    int s, kv_begin = 0, Sk = Sk_all, part = 0;
+    if (nsplit > 1) {   // block-uniform
+        part = blockIdx.x;
+        s = s_base + part / nsplit;
+        const int per = (((Sk_all + KV - 1) / KV + nsplit - 1) / nsplit) * KV;   // keys per split, whole tiles
+        kv_begin = (part % nsplit) * per;
+        Sk = min(Sk_all - kv_begin, per);                                        // host guarantees kv_begin < Sk_all
+    } else {
+        s = xcd_remap(blockIdx.x, total);
+    }
     const int hb = s / nqb, qb = s % nqb;
     const int b = hb / H, h = hb % H;
 
     const bf16_t* Qp = Q + (int64_t)hb * Sq * HD;
-    const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
-    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
+    const bf16_t* Kp = K + (int64_t)hb * Sk_all * HD + (int64_t)kv_begin * HD;
+    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp + kv_begin;
 
     constexpr int QB = NW * 32;
     constexpr int LD = (16 + NW - 1) / NW;  // 1 KiB LDS-DMA pieces per wave per tile image (16 pieces each for K and V^T)
@@ -448,6 +461,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
     const float l_tot = sum_xor32(l_run);
     const float inv = 1.0f / l_tot;
+    if (nsplit > 1) {
+        constexpr int QBR = NW * 32;
+        const int rloc = wave * 32 + l31;
+        bf16_t* op = opart + ((int64_t)part * QBR + rloc) * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+                o[1] = pack_bf16(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+                *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
+            }
+        if (hi == 0) lse[(int64_t)part * QBR + rloc] = m_run + __log2f(l_tot);
+        return;
+    }
     if (qrow < Sq) {
         bf16_t* op = O + (int64_t)b * o_sb + (int64_t)qrow * o_ss + (int64_t)h * o_sh;
 #pragma unroll
@@ -926,10 +955,74 @@ size_t materialised_bytes(int Sq, int Sk, int D) {
 
 }  // namespace
 
+// out[row] = sum_i w_i o_i, w_i = 2^(lse_i - max) / sum_j 2^(lse_j - max): merge of the tail launch's partial outputs.
+// One wave per query row, 2 channels per lane.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restrict__ opart, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ O, int nsplit, int qbr, int nqb, int H,
+                                                           int Sq, int s_base, int ntail, int64_t o_sb, int64_t o_ss,
+                                                           int64_t o_sh) {
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)ntail * qbr) return;
+    const int j = (int)(gw / qbr), r = (int)(gw % qbr), lane = threadIdx.x & 63;
+    const int s = s_base + j, hb = s / nqb, qb = s % nqb;
+    const int qrow = qb * qbr + r;
+    if (qrow >= Sq) return;
+    float mx = -1.0e30f;
+    for (int i = 0; i < nsplit; ++i) mx = fmaxf(mx, lse[((int64_t)j * nsplit + i) * qbr + r]);
+    float den = 0.0f, a0 = 0.0f, a1 = 0.0f;
+    for (int i = 0; i < nsplit; ++i) {
+        const int64_t p = ((int64_t)j * nsplit + i) * qbr + r;
+        const float w = fast_exp2(lse[p] - mx);
+        const uint32_t v = *(const uint32_t*)(opart + p * HD + lane * 2);
+        den += w;
+        a0 = fmaf(w, bf16_lo(v), a0);
+        a1 = fmaf(w, bf16_hi(v), a1);
+    }
+    const float inv = 1.0f / den;
+    *(uint32_t*)(O + (int64_t)(hb / H) * o_sb + (int64_t)qrow * o_ss + (int64_t)(hb % H) * o_sh + lane * 2) =
+        pack_bf16(a0 * inv, a1 * inv);
+}
+
+namespace {
+int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
+constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
+// the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
+int attn_tail(int total, int Sk) {
+    const int tail = total % ATT_NCU, rounds = total / ATT_NCU;
+    return (g_attn_split && tail > 0 && tail * 4 <= ATT_NCU && rounds >= 1 && rounds <= 8 && Sk >= ATT_NSPLIT * 8 * KV) ? tail : 0;
+}
+}  // namespace
+void apexmi_set_attn_split(int v) { g_attn_split = v; }
+
+extern "C" size_t apexmi_attn_prepared_workspace_bytes(int B, int H, int Sq, int Sk) {
+    const int nqb = (Sq + 255) / 256;
+    const int64_t total = (int64_t)nqb * H * B;
+    if (total < 256 || g_attn_waves == 4 || (g_attn_waves != 0 && g_attn_waves != 8)) return 0;
+    const int tail = attn_tail((int)total, Sk);
+    return (size_t)tail * ATT_NSPLIT * 256 * (HD * 2 + 4);
+}
+
+static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
+                                  int Skp, const int64_t o_strides[3], float softmax_scale, void* workspace,
+                                  size_t workspace_bytes, apexmi_stream_t stream_);
+
 extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void* out,
                                         int B, int H, int Sq, int Sk, int Skp,
                                         const int64_t o_strides[3], float softmax_scale,
                                         apexmi_stream_t stream_) {
+    return attn_fwd_prepared_impl(q, k, vt, out, B, H, Sq, Sk, Skp, o_strides, softmax_scale, nullptr, 0, stream_);
+}
+
+extern "C" int apexmi_attn_fwd_prepared_ws(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq,
+                                           int Sk, int Skp, const int64_t o_strides[3], float softmax_scale,
+                                           void* workspace, size_t workspace_bytes, apexmi_stream_t stream_) {
+    return attn_fwd_prepared_impl(q, k, vt, out, B, H, Sq, Sk, Skp, o_strides, softmax_scale, workspace, workspace_bytes,
+                                  stream_);
+}
+
+static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
+                                  int Skp, const int64_t o_strides[3], float softmax_scale, void* workspace,
+                                  size_t workspace_bytes, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(q && k && vt && out, "attn_fwd_prepared: null operand");
     APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attn_fwd_prepared: empty problem");
@@ -952,21 +1045,51 @@ extern "C" int apexmi_attn_fwd_prepared(const void* q, const void* k, const void
     const int qbr = nw * 32;
     const int nqb = (Sq + qbr - 1) / qbr;
     const int total = nqb * H * B;
+    const bool m16 = g_attn_mfma == 16;
+    if (nw == 8 && !m16 && g_attn_c4) {
+        // ---- shipped path: 4-cluster kernel; a nearly empty last round is cut into ATT_NSPLIT key ranges ----
+        auto c4 = g_attn_c4 == 2 ? attn_fwd_d128_c4_kernel<8, 1> : attn_fwd_d128_c4_kernel<8, 0>;
+        static bool c4_attr[2] = {};
+        if (!c4_attr[g_attn_c4 == 2]) {
+            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+            c4_attr[g_attn_c4 == 2] = true;
+        }
+        int tail = attn_tail(total, Sk);
+        const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 2 + 4);
+        if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
+        const int main_wgs = total - tail;
+        hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
+                           o_strides[2], c, 0, 1, (bf16_t*)nullptr, (float*)nullptr);
+        if (int rc = apexmi_check_launch("attn_fwd_d128")) return rc;
+        if (tail) {
+            bf16_t* opart = (bf16_t*)workspace;
+            float* lse = (float*)((char*)workspace + (size_t)tail * ATT_NSPLIT * 256 * HD * 2);
+            hipLaunchKernelGGL(c4, dim3(tail * ATT_NSPLIT), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total, o_strides[0],
+                               o_strides[1], o_strides[2], c, main_wgs, ATT_NSPLIT, opart, lse);
+            if (int rc = apexmi_check_launch("attn_fwd_d128 (tail)")) return rc;
+            hipLaunchKernelGGL(attn_combine_kernel, dim3((tail * 256 + 3) / 4), dim3(256), 0, stream, opart, lse,
+                               (bf16_t*)out, ATT_NSPLIT, 256, nqb, H, Sq, main_wgs, tail, o_strides[0], o_strides[1],
+                               o_strides[2]);
+            return apexmi_check_launch("attn_combine");
+        }
+        return 0;
+    }
     void (*kern)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, int64_t, int64_t,
                  int64_t, float) = nullptr;
-    const bool m16 = g_attn_mfma == 16;
     switch (nw) {
         case 4: kern = m16 ? attn_fwd_d128_mi16_kernel<4> : attn_fwd_d128_kernel<4>; break;
         case 5: kern = m16 ? attn_fwd_d128_mi16_kernel<5> : attn_fwd_d128_kernel<5>; break;
         case 6: kern = m16 ? attn_fwd_d128_mi16_kernel<6> : attn_fwd_d128_kernel<6>; break;
         case 7: kern = m16 ? attn_fwd_d128_mi16_kernel<7> : attn_fwd_d128_kernel<7>; break;
-        case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : g_attn_c4 == 1 ? attn_fwd_d128_c4_kernel<8, 0> : g_attn_c4 == 2 ? attn_fwd_d128_c4_kernel<8, 1> : attn_fwd_d128_kernel<8>; break;
+        case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_kernel<8>; break;
         default: apexmi_set_error("attn_fwd_prepared: attn.waves=%d not in [4,8]", nw); return 1;
     }
-    static bool attr_done[3][2][9] = {};
-    if (!attr_done[g_attn_c4 % 3][m16][nw]) {
+    static bool attr_done[2][9] = {};
+    if (!attr_done[m16][nw]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        attr_done[g_attn_c4 % 3][m16][nw] = true;
+        attr_done[m16][nw] = true;
     }
     hipLaunchKernelGGL(kern, dim3(total), dim3(nw * 64), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,

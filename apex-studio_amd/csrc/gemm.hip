@@ -948,8 +948,13 @@ void apexmi_set_attn_mfma(int v);
 void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
 void apexmi_set_qk_group(int v);
+void apexmi_set_attn_split(int v);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (key && !strcmp(key, "attn.split")) {
+        apexmi_set_attn_split(value);
+        return 0;
+    }
     if (key && !strcmp(key, "qk.group")) {
         apexmi_set_qk_group(value);
         return 0;

@@ -27,6 +27,9 @@ SIGNATURES = {
                                   C.c_size_t, vp]),
     "apexmi_attn_fwd_prepared": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, c_i64p, C.c_float, vp]),
+    "apexmi_attn_prepared_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "apexmi_attn_fwd_prepared_ws": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, c_i64p, C.c_float, vp, C.c_size_t, vp]),
     "apexmi_attn_framecausal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "apexmi_attn_fwd_framecausal": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               c_i64p, c_i64p, c_i64p, c_i64p, C.c_float, vp, C.c_size_t, vp]),

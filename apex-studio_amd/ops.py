@@ -214,10 +214,18 @@ def attention_prepared(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: 
     assert out.shape == (B, Sq, H, D) and out.stride(3) == 1
     if scale is None:
         scale = 1.0 / math.sqrt(D)
-    rc = _l.load().apexmi_attn_fwd_prepared(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(),
-                                            B, H, Sq, Sk, vt.shape[3],
-                                            _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
-                                            float(scale), _stream())
+    lib = _l.load()
+    need = lib.apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk)     # scratch of the tail split, usually 0
+    ws = None
+    if need:
+        key = ("prep", q.device.index, torch.cuda.current_stream().cuda_stream)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            _ws_cache[key] = ws
+    rc = lib.apexmi_attn_fwd_prepared_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Sq, Sk,
+                                         vt.shape[3], _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
+                                         float(scale), _ptr(ws), need, _stream())
     _l.check(rc, "attn_fwd_prepared")
     return out
 

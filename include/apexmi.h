@@ -87,6 +87,16 @@ int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void*
                              const int64_t o_strides[3], float softmax_scale,
                              apexmi_stream_t stream);
 
+/* Same, with scratch for the TAIL SPLIT: when the 8-wave launch would end in a round that keeps at most a quarter of the
+ * CUs busy (QwenImage-Edit: 792 workgroups = 3 rounds + 24), those last workgroups run as a second launch cut into 4 key
+ * ranges each and a merge of the partial results (log-sum-exp weights), instead of a nearly empty round of full-length
+ * workgroups.  workspace >= apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk) (0 when no split applies; NULL / too
+ * small simply disables the split). */
+size_t apexmi_attn_prepared_workspace_bytes(int B, int H, int Sq, int Sk);
+int apexmi_attn_fwd_prepared_ws(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
+                                int Skp, const int64_t o_strides[3], float softmax_scale, void* workspace,
+                                size_t workspace_bytes, apexmi_stream_t stream);
+
 /* HunyuanVideo15AttnBlock.forward (vae/hunyuanvideo15/model.py:130-214): one head of C channels over frames x (H W)
  * tokens with the frame-causal mask of prepare_causal_attention_mask (:143-165): token i attends the keys of frames
  * <= its own, `block` = tokens per frame.  bf16, D = C a multiple of 128 up to 1024, any S; materialised through the GEMM

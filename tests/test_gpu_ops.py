@@ -592,3 +592,42 @@ def test_attention_random_length_sweep():
         out = ops.attention(q, k, v)
         ref = OL.sdpa(q.float(), k.float(), v.float())
         _check(out, ref.cpu(), 1e-2, f"attention sweep {case}: B{B} H{H} Sq{Sq} Sk{Sk}", ulp=3.0)
+
+
+@pytest.mark.parametrize("H,S", [(24, 8448), (8, 8448 + 100), (33, 2304)])
+def test_attention_tail_split_matches_unsplit_and_reference(H, S):
+    """Launches whose last round would keep <= 1/4 of the CUs busy run it as 4 key ranges + a merge (`attn.split`):
+    same result as the single launch up to the extra bf16 rounding of the partial outputs, and within the attention bar
+    of the fp32 reference.  (24, 8448) is the QwenImage-Edit shape: 792 workgroups = 3 rounds + 24."""
+    ops = _ops()
+    from apex_studio_amd import lib
+    q = seeded((1, H, S, 128), 501, torch.bfloat16).to(DEV)
+    k = seeded((1, H, S, 128), 502, torch.bfloat16).to(DEV)
+    v = seeded((1, H, S, 128), 503, torch.bfloat16).to(DEV)
+    skp = (S + 63) // 64 * 64
+    vt = torch.zeros(1, H, 128, skp, dtype=torch.bfloat16, device=DEV)
+    vt[..., :S] = v.transpose(2, 3)
+    nqb = (S + 255) // 256
+    tail = (nqb * H) % 256
+    assert 0 < tail <= 64, "shape must exercise the split"
+    assert lib.load().apexmi_attn_prepared_workspace_bytes(1, H, S, S) == tail * 4 * 256 * (256 + 4)
+    outs = {}
+    try:
+        for split in (1, 0):
+            lib.tune_set("attn.split", split)
+            o = torch.full((1, S, H, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.attention_prepared(q, k, vt, o, S)
+            outs[split] = o.clone()
+            o2 = torch.empty_like(o)
+            ops.attention_prepared(q, k, vt, o2, S)
+            assert torch.equal(o, o2)
+    finally:
+        lib.tune_set("attn.split", 1)
+    assert torch.isfinite(outs[1]).all()
+    d = (outs[1].float() - outs[0].float()).abs().max() / outs[0].float().abs().max()
+    assert float(d) < 2.0 ** -7, float(d)
+    changed = (outs[1] != outs[0]).any(dim=(0, 3))                       # [S, H]: only the tail q-blocks may differ
+    assert int(changed.sum()) <= tail * 256
+    rows = slice(S - 300, S)
+    ref = OL.sdpa(q[:, :, rows].float(), k.float(), v.float()).permute(0, 2, 1, 3)
+    _check(outs[1][:, rows], ref.cpu(), 1e-2, f"attention tail split H{H} S{S}", ulp=3.0)
