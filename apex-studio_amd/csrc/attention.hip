@@ -1106,8 +1106,9 @@ extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int 
         return materialised_bytes(Sq, Sk, D);   // one (batch, head) at a time on the stream
     if (dtype != APEXMI_BF16 || D != HD) return 0;
     const size_t skp = (size_t)((Sk + KV - 1) / KV) * KV;
-    // V^T plus packed copies of q and k (used only when the caller's views are not packed)
-    return (size_t)B * H * HD * skp * 2 + (size_t)B * H * ((size_t)Sq + Sk) * HD * 2;
+    // V^T plus packed copies of q and k (used only when the caller's views are not packed) plus the tail-split scratch
+    return (size_t)B * H * HD * skp * 2 + (size_t)B * H * ((size_t)Sq + Sk) * HD * 2 +
+           apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk);
 }
 
 int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int D, void* out,
@@ -1146,8 +1147,9 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
             if (int rc = apexmi_v_transpose(vb, v_strides[1], v_strides[2], Sk, H, D, vtb, skp, 0, stream))
                 return rc;
         }
-        return apexmi_attn_fwd_prepared(qp, kp, vt, out, B, H, Sq, Sk, skp, o_strides, softmax_scale,
-                                        stream);
+        ws += (size_t)B * H * Sk * HD * 2;
+        return apexmi_attn_fwd_prepared_ws(qp, kp, vt, out, B, H, Sq, Sk, skp, o_strides, softmax_scale, ws,
+                                           apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk), stream);
     }
     if (use_materialised(Sq, Sk, D, dtype, q_strides, k_strides, v_strides, o_strides, causal_block) && workspace &&
         workspace_bytes >= materialised_bytes(Sq, Sk, D)) {

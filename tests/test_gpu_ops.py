@@ -631,3 +631,23 @@ def test_attention_tail_split_matches_unsplit_and_reference(H, S):
     rows = slice(S - 300, S)
     ref = OL.sdpa(q[:, :, rows].float(), k.float(), v.float()).permute(0, 2, 1, 3)
     _check(outs[1][:, rows], ref.cpu(), 1e-2, f"attention tail split H{H} S{S}", ulp=3.0)
+
+
+def test_attention_operator_uses_the_tail_split():
+    """The registered operator (`apexmi_attn_fwd`, strided [B,H,S,D] views) takes the same tail split as the fused path."""
+    ops = _ops()
+    from apex_studio_amd import lib
+    H, S = 24, 8448
+    qkv = seeded((1, S, 3, H, 128), 601, torch.bfloat16).to(DEV)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    try:
+        lib.tune_set("attn.split", 0)
+        a = ops.attention(q, k, v).clone()
+        lib.tune_set("attn.split", 1)
+        b = ops.attention(q, k, v).clone()
+    finally:
+        lib.tune_set("attn.split", 1)
+    assert not torch.equal(a, b), "the split path was not taken"
+    assert float((a.float() - b.float()).abs().max() / a.float().abs().max()) < 2.0 ** -7
+    ref = OL.sdpa(q[:, :, -200:].float(), k.float(), v.float())
+    _check(b[:, :, -200:], ref.cpu(), 1e-2, "operator tail split", ulp=3.0)
