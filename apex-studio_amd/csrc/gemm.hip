@@ -784,6 +784,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
+int g_tail_split = 1; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -822,6 +823,26 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         // with a 24 KiB row stride (K = 12288, the MLP down-projection) the one-wave-per-SIMD kernel loses
         // 17-23 % to channel aliasing that the ping-pong schedules do not see
         if (cfg == 6 && G.K % 12288 == 0) cfg = 7;
+        // A grouped launch whose leading problems fill whole rounds of 256 tiles and whose LAST problem is a small tail
+        // (QwenImage's feed-forward up-projection: image stream 32 x 48 = 1536 tiles = 6 rounds, text stream 48 tiles):
+        // a partial round costs about half a full one however few tiles it holds (tools/gemm_rounds.py: +66 us for 48
+        // tiles on a 577 us launch), so the tail problem goes out as its own 128x128-tiled launch (192 quarter-size
+        // tiles, under one round of the two-workgroups-per-CU kernel).
+        if (cfg == 7 && g_tail_split && G.count >= 2 && G.batch == 1) {
+            int64_t lead = 0;
+            for (int i = 0; i + 1 < G.count; ++i)
+                lead += (int64_t)((Ms[i] + 255) / 256) * ((G.p[i].N + 255) / 256);
+            const int li = G.count - 1;
+            const int64_t last = (int64_t)((Ms[li] + 255) / 256) * ((G.p[li].N + 255) / 256);
+            if (lead >= 256 && lead % 256 == 0 && last <= 64) {
+                GemmGroup T = G;
+                T.count = 1;
+                T.p[0] = G.p[li];
+                G.count = li;
+                if (int rc = launch_cfg<CFG_256P16, EPI>(G, Ms, stream)) return rc;
+                return launch_cfg<CFG_128, EPI>(T, Ms + li, stream);
+            }
+        }
     }
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
@@ -951,6 +972,10 @@ void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (key && !strcmp(key, "gemm.tail")) {
+        g_tail_split = value;
+        return 0;
+    }
     if (key && !strcmp(key, "attn.split")) {
         apexmi_set_attn_split(value);
         return 0;

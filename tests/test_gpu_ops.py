@@ -651,3 +651,28 @@ def test_attention_operator_uses_the_tail_split():
     assert float((a.float() - b.float()).abs().max() / a.float().abs().max()) < 2.0 ** -7
     ref = OL.sdpa(q[:, :, -200:].float(), k.float(), v.float())
     _check(b[:, :, -200:], ref.cpu(), 1e-2, "operator tail split", ulp=3.0)
+
+
+def test_gemm_grouped_tail_problem_on_small_tiling():
+    """Grouped launch = image stream filling whole rounds (8 x 32 tiles = 256) + a small text stream: the text problem
+    goes out on the 128x128 tiling (`gemm.tail`); both ways agree with the reference."""
+    ops = _ops()
+    from apex_studio_amd import lib
+    K, N, Mi, Mt = 512, 8192, 2048, 256
+    ai, at = _bf(seeded((Mi, K), 1)).to(DEV), _bf(seeded((Mt, K), 2)).to(DEV)
+    wi, wt = _bf(seeded((N, K), 3, scale=K ** -0.5)).to(DEV), _bf(seeded((N, K), 4, scale=K ** -0.5)).to(DEV)
+    bi, bt = _bf(seeded((N,), 5)).to(DEV), _bf(seeded((N,), 6)).to(DEV)
+    outs = {}
+    try:
+        for tail in (1, 0):
+            lib.tune_set("gemm.tail", tail)
+            out = torch.full((Mt + Mi, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm_grouped([ai, at], [wi, wt], [bi, bt], [out[Mt:], out[:Mt]], epilogue="gelu")
+            outs[tail] = out.clone()
+    finally:
+        lib.tune_set("gemm.tail", 1)
+    ref = torch.cat([torch.nn.functional.gelu(at.float() @ wt.float().T + bt.float(), approximate="tanh"),
+                     torch.nn.functional.gelu(ai.float() @ wi.float().T + bi.float(), approximate="tanh")])
+    for tail in (1, 0):
+        _check(outs[tail], ref.cpu(), 3e-3, f"grouped tail={tail}")
+    assert torch.equal(outs[1][Mt:], outs[0][Mt:])          # the image rows come from the same kernel either way
