@@ -159,8 +159,15 @@ int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk,
                          const uint8_t* keep, const int* seg, int causal, void* workspace, size_t workspace_bytes,
                          apexmi_stream_t stream);
 
-/* Tuning knobs for A/B measurements (bench.py, tests): "gemm.config" = 0 auto | 1 128x128 |
- * 2 256x256 | 3 256x256 ping-pong; "attn.waves" = 0 auto | 4 | 8 waves per attention workgroup.
+/* Tuning knobs for A/B measurements (bench.py --tune, tests); defaults are the shipped choices:
+ *   "gemm.config"  0 auto | 1 128x128 | 2 256x256 | 3 256x256 ping-pong 32x32x16 | 6 one wave per SIMD | 7 ping-pong 16x16x32
+ *   "gemm.large"   tiling the auto rule picks for large problems (7)      "gemm.group_m"  rows of a tile-order group (8)
+ *   "gemm.tail"    1: a small last problem of a grouped launch after whole rounds of tiles goes out on the 128x128 tiling
+ *   "attn.waves"   0 auto | 4..8 waves per attention workgroup            "attn.mfma"     32 | 16
+ *   "attn.c4"      1: 4-cluster ping-pong kernel | 2: same + s_setprio | 0: plain loop
+ *   "attn.split"   1: a nearly empty last round runs as 4 key ranges + merge (needs the _ws entry point's scratch)
+ *   "qk.group"     1: q/k norm + RoPE four heads per lane group with the V transpose in the same launch | 2: without | 0: one head
+ *   "ln.wave"      1: wave-per-row LayerNorm kernel for C in {3072, 3584, 5120}
  * Returns non-zero for an unknown key. */
 int apexmi_tune_set(const char* key, int value);
 
