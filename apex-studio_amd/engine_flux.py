@@ -111,7 +111,7 @@ class FluxT2IEngine(EngineLoraMixin):
             latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
             generator: Optional[torch.Generator] = None, return_latents: bool = False,
             progress_callback=None, render_on_step: bool = False, render_on_step_callback=None,
-            render_on_step_interval: int = 3, sigmas=None, **_ignored):
+            render_on_step_interval: int = 3, sigmas=None, output_type: Optional[str] = None, **_ignored):
         dev, dt = self.device, self.transformer.dtype
         B = prompt_embeds.shape[0]
         h = 2 * (int(height) // (self.vae_scale_factor * 2))
@@ -152,5 +152,8 @@ class FluxT2IEngine(EngineLoraMixin):
             return latents
         _emit(progress_callback, 0.92, "Decoding")
         out = self.decode_fn(unpack_latents(latents, height, width, self.vae_scale_factor))
+        if output_type is not None and torch.is_tensor(out):   # t2i.py:254 `self._tensor_to_frame(image)`: uint8 frames on the GPU
+            from .postprocess import tensor_to_frame
+            out = tensor_to_frame(out, output_type)
         _emit(progress_callback, 1.0, "Completed text-to-image pipeline")
         return out

@@ -123,7 +123,8 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             image_shapes: Sequence[Tuple[int, int]] = (), height: int = 1024, width: int = 1024,
             num_inference_steps: int = 8, negative_prompt_embeds: Optional[torch.Tensor] = None,
             true_cfg_scale: float = 1.0, latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
-            return_latents: bool = True, progress_callback=None, images=None, **_ignored):
+            return_latents: bool = True, progress_callback=None, images=None, output_type: Optional[str] = None,
+            **_ignored):
         dev, dt = self.device, self.transformer.dtype
         if images is not None:       # condition images as pixels (or latents): encode + pack here
             image_latents, image_shapes = self.prepare_image_latents(images, prompt_embeds.shape[0])
@@ -155,6 +156,8 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
                                     denoise_progress_callback=mapped)
         if return_latents or (self.decode_fn is None and self.vae is None):
             return latents
-        if self.decode_fn is not None:
-            return self.decode_fn(latents)
-        return self.vae_decode(latents, height, width)
+        out = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents, height, width)
+        if output_type is not None and torch.is_tensor(out):
+            from .postprocess import tensor_to_frame
+            out = tensor_to_frame(out, output_type)
+        return out

@@ -124,3 +124,6 @@ def test_qwen_edit_pixels_in_pixels_out():
     assert torch.equal(a, b) and torch.isfinite(a).all()
     out = eng.run(images=img.to(DEV), return_latents=False, **kw)
     assert out.shape == (1, 3, 128, 96) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
+    frames = eng.run(images=img.to(DEV), return_latents=False, output_type="np", **kw)
+    from oracle.postprocess import video_to_uint8_frames
+    assert frames.shape == (1, 128, 96, 3) and (frames == video_to_uint8_frames(out.cpu().unsqueeze(2))[:, 0]).all()
