@@ -5,6 +5,7 @@ The shared library travels to the GPU box with the repo snapshot; nothing is JIT
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -25,11 +26,30 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def _stale(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _digest(paths: list[str], extra: str = "") -> str:
+    """sha256 over the CONTENT of the inputs (+ compiler flags): mtimes do not survive a repo snapshot / checkout."""
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
+def _stale(target: str, digest: str) -> bool:
+    """True unless `target` exists and `target.sha256` records exactly this input digest."""
+    stamp = target + ".sha256"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
+
+
+def _stamp(target: str, digest: str) -> None:
+    with open(target + ".sha256", "w") as f:
+        f.write(digest + "\n")
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -37,21 +57,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, "common.h"),
                os.path.join(PKG_DIR, "..", "include", "apexmi.h")]
     objs = []
+    jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + headers):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op,
-                   "-Wno-unused-result"]
+        dg = _digest([sp] + headers, " ".join(FLAGS + [ARCH]))
+        if force or _stale(op, dg):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", sp, "-o", op]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-    if force or _stale(LIB_PATH, objs):
+            jobs.append((subprocess.Popen(cmd), cmd, op, dg))   # the translation units compile side by side
+    for proc, cmd, op, dg in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        _stamp(op, dg)
+    dg = _digest(objs, ARCH)
+    if force or _stale(LIB_PATH, dg):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        _stamp(LIB_PATH, dg)
     return LIB_PATH
 
 
