@@ -39,6 +39,11 @@ APEXMI_DEVICE int perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) 
 // some row's tile max exceeds it by more than DEFER (log2 units), so p = 2^(s c - m) stays <= 2^DEFER;
 // in steady state the 64-register O rescale is skipped.  Every P of a tile is exponentiated after the
 // decision that covers it (no pending P V is split by a rescale).
+// The running max is kept an INTEGER (ceil, base-2 domain): every rescale factor 2^(m_old - m_new) is then an exact
+// power of two and bf16(2^k p) = 2^k bf16(p), so the bf16 rounding of P — and with it the result — does not depend
+// on the key-tile order, the deferral threshold or a key-range split: O = sum_j bf16(2^(s_j c - M)) v_j / sum_j
+// 2^(s_j c - M) for ANY integer M, up to f32 summation order.  That is what lets the CPU oracle reproduce the
+// kernel's rounding points (oracle.layers.sdpa, bf16 policy) without replaying its schedule.
 constexpr float DEFER = 6.0f;
 
 template <int NW>
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
         mx = max_xor32(mx) * scale_log2e;
         if (__any(mx > m_run + DEFER)) {  // wave-uniform; always taken on the first tile
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = ceilf(fmaxf(m_run, mx));   // integer: see the note above DEFER
             const float alpha = fast_exp2(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
@@ -243,7 +248,7 @@ template <int NW, int PRIO>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int H, int Sq, int Sk_all, int Skp, int nqb, int total, int64_t o_sb,
-    int64_t o_ss, int64_t o_sh, float scale_log2e, int s_base, int nsplit, bf16_t* __restrict__ opart,
+    int64_t o_ss, int64_t o_sh, float scale_log2e, int s_base, int nsplit, float* __restrict__ opart,
     float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
             mx = max_xor32(mx) * scale_log2e;
             if (__any(mx > m_run + DEFER)) {
-                const float m_new = fmaxf(m_run, mx);
+                const float m_new = ceilf(fmaxf(m_run, mx));   // integer: see the note above DEFER
                 const float alpha = fast_exp2(m_run - m_new);
                 m_run = m_new;
                 l_run *= alpha;
@@ -464,17 +469,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     if (nsplit > 1) {
         constexpr int QBR = NW * 32;
         const int rloc = wave * 32 + l31;
-        bf16_t* op = opart + ((int64_t)part * QBR + rloc) * HD;
+        // un-normalised f32 partial numerator + (integer max, partial sum): the merge applies exact power-of-two
+        // weights, so a split launch rounds to bf16 once, exactly where the single launch does
+        float* op = opart + ((int64_t)part * QBR + rloc) * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                u32x2 o;
-                o[0] = pack_bf16(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
-                o[1] = pack_bf16(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
-                *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
+                f32x4 o = {oacc[dt][4 * g + 0], oacc[dt][4 * g + 1], oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]};
+                *(f32x4*)(op + dt * 32 + g * 8 + hi * 4) = o;
             }
-        if (hi == 0) lse[(int64_t)part * QBR + rloc] = m_run + __log2f(l_tot);
+        if (hi == 0) {
+            lse[((int64_t)part * QBR + rloc) * 2] = m_run;
+            lse[((int64_t)part * QBR + rloc) * 2 + 1] = l_tot;
+        }
         return;
     }
     if (qrow < Sq) {
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_mi16_kernel(
         if (__any(mx[0] > m_run[0] + DEFER || mx[1] > m_run[1] + DEFER)) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                const float m_new = fmaxf(m_run[qt], mx[qt]);
+                const float m_new = ceilf(fmaxf(m_run[qt], mx[qt]));   // integer: see the note above DEFER
                 const float alpha = fast_exp2(m_run[qt] - m_new);
                 m_run[qt] = m_new;
                 l_run[qt] *= alpha;
@@ -955,9 +963,9 @@ size_t materialised_bytes(int Sq, int Sk, int D) {
 
 }  // namespace
 
-// out[row] = sum_i w_i o_i, w_i = 2^(lse_i - max) / sum_j 2^(lse_j - max): merge of the tail launch's partial outputs.
-// One wave per query row, 2 channels per lane.
-__global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restrict__ opart, const float* __restrict__ lse,
+// out[row] = sum_i 2^(m_i - M) o_i / sum_i 2^(m_i - M) l_i, M = max_i m_i: merge of the tail launch's partial numerators
+// o_i (f32), integer maxima m_i and partial sums l_i.  One wave per query row, 2 channels per lane.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ opart, const float* __restrict__ ml,
                                                            bf16_t* __restrict__ O, int nsplit, int qbr, int nqb, int H,
                                                            int Sq, int s_base, int ntail, int64_t o_sb, int64_t o_ss,
                                                            int64_t o_sh) {
@@ -968,15 +976,15 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restr
     const int qrow = qb * qbr + r;
     if (qrow >= Sq) return;
     float mx = -1.0e30f;
-    for (int i = 0; i < nsplit; ++i) mx = fmaxf(mx, lse[((int64_t)j * nsplit + i) * qbr + r]);
+    for (int i = 0; i < nsplit; ++i) mx = fmaxf(mx, ml[(((int64_t)j * nsplit + i) * qbr + r) * 2]);
     float den = 0.0f, a0 = 0.0f, a1 = 0.0f;
     for (int i = 0; i < nsplit; ++i) {
         const int64_t p = ((int64_t)j * nsplit + i) * qbr + r;
-        const float w = fast_exp2(lse[p] - mx);
-        const uint32_t v = *(const uint32_t*)(opart + p * HD + lane * 2);
-        den += w;
-        a0 = fmaf(w, bf16_lo(v), a0);
-        a1 = fmaf(w, bf16_hi(v), a1);
+        const float w = fast_exp2(ml[p * 2] - mx);          // exact power of two (integer maxima)
+        const float2 v = *(const float2*)(opart + p * HD + lane * 2);
+        den = fmaf(w, ml[p * 2 + 1], den);
+        a0 = fmaf(w, v.x, a0);
+        a1 = fmaf(w, v.y, a1);
     }
     const float inv = 1.0f / den;
     *(uint32_t*)(O + (int64_t)(hb / H) * o_sb + (int64_t)qrow * o_ss + (int64_t)(hb % H) * o_sh + lane * 2) =
@@ -999,7 +1007,7 @@ extern "C" size_t apexmi_attn_prepared_workspace_bytes(int B, int H, int Sq, int
     const int64_t total = (int64_t)nqb * H * B;
     if (total < 256 || g_attn_waves == 4 || (g_attn_waves != 0 && g_attn_waves != 8)) return 0;
     const int tail = attn_tail((int)total, Sk);
-    return (size_t)tail * ATT_NSPLIT * 256 * (HD * 2 + 4);
+    return (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
 }
 
 static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
@@ -1049,22 +1057,20 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
     if (nw == 8 && !m16 && g_attn_c4) {
         // ---- shipped path: 4-cluster kernel; a nearly empty last round is cut into ATT_NSPLIT key ranges ----
         auto c4 = g_attn_c4 == 2 ? attn_fwd_d128_c4_kernel<8, 1> : attn_fwd_d128_c4_kernel<8, 0>;
-        static bool c4_attr[2] = {};
-        if (!c4_attr[g_attn_c4 == 2]) {
+        static uint64_t c4_attr[2] = {};
+        if (apexmi_once_per_device(c4_attr[g_attn_c4 == 2]))
             (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-            c4_attr[g_attn_c4 == 2] = true;
-        }
         int tail = attn_tail(total, Sk);
-        const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 2 + 4);
+        const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
         if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
         const int main_wgs = total - tail;
         hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
-                           o_strides[2], c, 0, 1, (bf16_t*)nullptr, (float*)nullptr);
+                           o_strides[2], c, 0, 1, (float*)nullptr, (float*)nullptr);
         if (int rc = apexmi_check_launch("attn_fwd_d128")) return rc;
         if (tail) {
-            bf16_t* opart = (bf16_t*)workspace;
-            float* lse = (float*)((char*)workspace + (size_t)tail * ATT_NSPLIT * 256 * HD * 2);
+            float* opart = (float*)workspace;
+            float* lse = (float*)((char*)workspace + (size_t)tail * ATT_NSPLIT * 256 * HD * 4);
             hipLaunchKernelGGL(c4, dim3(tail * ATT_NSPLIT), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                                (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total, o_strides[0],
                                o_strides[1], o_strides[2], c, main_wgs, ATT_NSPLIT, opart, lse);
@@ -1086,11 +1092,9 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
         case 8: kern = m16 ? attn_fwd_d128_mi16_kernel<8> : attn_fwd_d128_kernel<8>; break;
         default: apexmi_set_error("attn_fwd_prepared: attn.waves=%d not in [4,8]", nw); return 1;
     }
-    static bool attr_done[2][9] = {};
-    if (!attr_done[m16][nw]) {
+    static uint64_t attr_done[2][9] = {};
+    if (apexmi_once_per_device(attr_done[m16][nw]))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        attr_done[m16][nw] = true;
-    }
     hipLaunchKernelGGL(kern, dim3(total), dim3(nw * 64), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,
                        o_strides[0], o_strides[1], o_strides[2], c);

@@ -107,6 +107,15 @@ APEXMI_DEVICE int xcd_remap(int bid, int total) {
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// Function attributes (dynamic LDS size) are per DEVICE: `mask` holds one bit per device ordinal; true the first time
+// the calling thread's current device asks.  The launch wrappers run with the operand tensors' device current.
+static inline bool apexmi_once_per_device(uint64_t& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    const bool first = !(__atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED) & bit);
+    return first;
+}
 void apexmi_set_error(const char* fmt, ...);
 int apexmi_check_launch(const char* what);
 

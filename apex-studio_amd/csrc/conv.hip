@@ -473,12 +473,10 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     APEXMI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
                        ((uintptr_t)zeros % 16) == 0,
                    "conv3d_cl: operands must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static uint64_t attr_set = 0;
+    if (apexmi_once_per_device(attr_set))
         (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * STAGE_BYTES);
-        attr_set = true;
-    }
     ConvArgs a;
     a.in = (const bf16_t*)in;
     a.w = (const bf16_t*)w;

@@ -476,14 +476,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
 }
 
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out,
-                                          int M, int dim, float scale, int flip, float shift) {
+                                          int M, int dim, float scale, int flip, float shift,
+                                          const float* __restrict__ freqs) {
     const int half = dim / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * half) return;
     const int m = idx / half, i = idx % half;
     // exponent = -ln(10000) * i / (half - shift)
-    const float e = expf(-9.210340371976184f * (float)i / ((float)half - shift));
-    const float a = t[m] * e * scale;
+    const float e = freqs ? freqs[i] : expf(-9.210340371976184f * (float)i / ((float)half - shift));
+    const float a = __fmul_rn(__fmul_rn(t[m], e), scale);   // (t * freq) * scale, two f32 roundings as in the reference
     const float sn = sinf(a), cs = cosf(a);
     float* o = out + (int64_t)m * dim;
     if (flip) {
@@ -874,14 +875,14 @@ extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const f
 }
 
 extern "C" int apexmi_timestep_embedding(const float* t, float* out, int M, int dim, float scale,
-                                         int flip_sin_to_cos, float downscale_freq_shift,
+                                         int flip_sin_to_cos, float downscale_freq_shift, const float* freqs,
                                          apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(t && out && M > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments");
     const int n = M * (dim / 2);
     ApexmiProfScope prof(5, stream, 0.0, 4.0 * M * dim);
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, out,
-                       M, dim, scale, flip_sin_to_cos, downscale_freq_shift);
+                       M, dim, scale, flip_sin_to_cos, downscale_freq_shift, freqs);
     return apexmi_check_launch("timestep_embedding");
 }
 

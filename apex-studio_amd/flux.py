@@ -427,6 +427,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias, out=out)
         return out
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                 pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None,

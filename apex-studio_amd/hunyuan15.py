@@ -242,12 +242,21 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
             rb._bqkv = torch.empty(3 * dim, device=dev, dtype=dt)
             _repoint([a.to_q.weight, a.to_k.weight, a.to_v.weight], rb._wqkv)
             _repoint([a.to_q.bias, a.to_k.bias, a.to_v.bias], rb._bqkv)
-        # patch embedding as a GEMM over [S, C*pt*p*p] rows, K padded to a multiple of 64 (zeros)
+        self._packed = True
+        self._weights_changed()
+
+    @torch.no_grad()
+    def _weights_changed(self):
+        """Rebuild what is DERIVED from parameter values: the patch embedding as a GEMM operand over
+        [S, C*pt*p*p] rows, K padded to a multiple of 64 (zeros).  `weights.load_checkpoint_into` writes parameters in
+        place after `pack()` and calls this."""
+        if not self._packed:
+            return
+        dim = self.inner_dim
         w = self.x_embedder.proj.weight.data.reshape(dim, -1)
         kp = (w.shape[1] + 63) // 64 * 64
-        self._w_patch = torch.zeros(dim, kp, device=dev, dtype=dt)
+        self._w_patch = torch.zeros(dim, kp, device=w.device, dtype=w.dtype)
         self._w_patch[:, :w.shape[1]] = w
-        self._packed = True
 
     def _workspace(self, s_txt: int, s_img: int):
         key = (s_txt, s_img)
@@ -422,6 +431,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         y = y.reshape(grid[0], grid[1], grid[2], -1, pt, p, p).permute(3, 0, 4, 1, 5, 2, 6)
         return y.reshape(-1, grid[0] * pt, grid[1] * p, grid[2] * p)
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 encoder_attention_mask: torch.Tensor, timestep_r: Optional[torch.Tensor] = None,

@@ -71,7 +71,7 @@ SIGNATURES = {
     "apexmi_crossfade": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_int64, vp]),
     "apexmi_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
-                                            vp]),
+                                            vp, vp]),
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
     "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
     "apexmi_add_rowvec_bf16": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]),

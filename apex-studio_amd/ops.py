@@ -419,15 +419,33 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+_freq_tables: dict = {}
+
+
+def _timestep_freqs(dim: int, shift: float, device) -> torch.Tensor:
+    """The layer constant exp(-ln(10000) * i / (dim/2 - shift)), i < dim/2, built ONCE per (dim, shift, device) on the
+    host with the f32 operation sequence of diffusers' `get_timestep_embedding` (in-tree copy: reference
+    transformer/qwenimage/base/model.py:46-97), so the kernel's sin / cos arguments equal the reference's bit for bit."""
+    key = (dim, float(shift), str(device))
+    f = _freq_tables.get(key)
+    if f is None:
+        half = dim // 2
+        exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32)
+        f = torch.exp(exponent / (half - shift)).to(device)
+        _freq_tables[key] = f
+    return f
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, scale: float = 1.0, flip_sin_to_cos: bool = True,
                        downscale_freq_shift: float = 0.0) -> torch.Tensor:
     _req(t, torch.float32, "timestep_embedding.t")
     t = t.contiguous()
     M = t.numel()
     out = torch.empty((M, dim), dtype=torch.float32, device=t.device)
+    freqs = _timestep_freqs(dim, downscale_freq_shift, t.device)
     rc = _l.load().apexmi_timestep_embedding(t.data_ptr(), out.data_ptr(), M, dim, float(scale),
                                              1 if flip_sin_to_cos else 0, float(downscale_freq_shift),
-                                             _stream())
+                                             freqs.data_ptr(), _stream())
     _l.check(rc, "timestep_embedding")
     return out
 
@@ -678,3 +696,57 @@ def groupnorm_cl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group
                                  float(eps), 1 if silu else 0, ws.data_ptr(), need, _stream())
     _l.check(rc, "groupnorm_cl")
     return out
+
+
+# ---- device guard ------------------------------------------------------------------------------------------------
+# Every wrapper above enqueues on `torch.cuda.current_stream()` of the CURRENT device.  A model living on cuda:1
+# while the caller's current device is cuda:0 would otherwise launch on device 0's stream with device-1 pointers.
+# Each public op therefore runs with its first device operand's device current; model entry points (forward /
+# decode / encode) do the same with `on_model_device`, which also covers their own stream / event objects.
+def _first_device(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda:
+            return a[0].device
+    return None
+
+
+def _guarded(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = _first_device(args, kwargs)
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def on_model_device(method):
+    """Decorator for model entry points: run with `self.device` as the current device."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        dev = self.device
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
+def _install_guards():
+    import types
+    g = globals()
+    for name, obj in list(g.items()):
+        if isinstance(obj, types.FunctionType) and not name.startswith("_") and obj.__module__ == __name__ \
+                and name not in ("on_model_device",):
+            g[name] = _guarded(obj)
+
+
+_install_guards()

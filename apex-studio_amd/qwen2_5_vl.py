@@ -229,6 +229,7 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
         return f
 
     # ---- vision tower ----------------------------------------------------------------------------------------------
+    @ops.on_model_device
     def get_image_features(self, pixel_values: torch.Tensor, image_grid_thw) -> torch.Tensor:
         """pixel_values [patches, C * T_p * P * P] (the processor's flattened patches) -> merged image tokens
         [patches / merge^2, hidden_size], in input order."""
@@ -282,6 +283,7 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
         sin = torch.cat([m[i % 3] for i, m in enumerate(emb.sin().split(sec, dim=-1))], dim=-1)
         return cos.to(self.device).contiguous(), sin.to(self.device).contiguous()
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
                 output_hidden_states=False, return_dict=True, **_):

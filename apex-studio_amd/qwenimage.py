@@ -291,6 +291,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.ln_modulate(Xi, ws.MOD[0, o:o + dim], ws.MOD[0, o + dim:o + 2 * dim], out=XNi)
         return ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias)
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                 encoder_hidden_states_mask: torch.Tensor = None, timestep: torch.Tensor = None,

@@ -92,6 +92,10 @@ class _Base(nn.Module):
         self._fused = {}
         return super().load_state_dict(*a, **k)
 
+    def _weights_changed(self):
+        """Parameters were written in place (`weights.load_checkpoint_into`): drop the fused / padded copies."""
+        self._fused = {}
+
     def _check(self, input_ids):
         if self.device.type != "cuda" or self.dtype != torch.bfloat16:
             raise _l.ApexMIError(f"{type(self).__name__} (mi355) needs bf16 weights on a ROCm device (no CPU fallback)")
@@ -184,6 +188,7 @@ class T5EncoderModel(_Base):
         bucket = _t5_buckets(S, c.relative_attention_num_buckets, c.relative_attention_max_distance).to(self.device)
         return ops.relpos_bias(att.relative_attention_bias.weight.data.contiguous(), bucket, S, S)
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, output_hidden_states=False, return_dict=True, **_):
         self._check(input_ids)
@@ -274,6 +279,7 @@ class CLIPTextModel(_Base):
         tm.final_layer_norm = _N(c.hidden_size, True, **kw)
         self._fused = {}
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, output_hidden_states=False, return_dict=True, **_):
         self._check(input_ids)

@@ -128,6 +128,10 @@ class AutoencoderKL(nn.Module):
         self._packed = {}
         return super().load_state_dict(*a, **k)
 
+    def _weights_changed(self):
+        """Parameters were written in place (`weights.load_checkpoint_into`): drop the packed conv-weight cache."""
+        self._packed = {}
+
     def enable_tiling(self, *a, **k):   # 1024^2 latents equal tile_latent_min_size: untiled (model.py:229-236)
         return None
 
@@ -191,6 +195,7 @@ class AutoencoderKL(nn.Module):
         x = self._conv(d.conv_out, x)
         return x[0, :, :, :self.config.out_channels].permute(2, 0, 1).contiguous()
 
+    @ops.on_model_device
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
         dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)

@@ -166,6 +166,10 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         self._packed = {}
         return super().load_state_dict(*a, **k)
 
+    def _weights_changed(self):
+        """Parameters were written in place (`weights.load_checkpoint_into`): drop the packed conv-weight cache."""
+        self._packed = {}
+
     def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_latent_min_height=None,
                       tile_latent_min_width=None, tile_overlap_factor=None, use_light_vae: bool = False):
         if use_light_vae:
@@ -289,6 +293,7 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
             out = torch.cat(out_rows, dim=1)
         return out[..., :self.config.out_channels].permute(3, 0, 1, 2).contiguous()
 
+    @ops.on_model_device
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)

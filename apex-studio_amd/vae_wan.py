@@ -223,6 +223,10 @@ class AutoencoderKLWan(nn.Module):
         self._packed = {}
         return super().load_state_dict(*a, **k)
 
+    def _weights_changed(self):
+        """Parameters were written in place (`weights.load_checkpoint_into`): drop the packed conv-weight cache."""
+        self._packed = {}
+
     def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None,
                       tile_sample_stride_height=None, tile_sample_stride_width=None):
         self.use_tiling = True
@@ -433,6 +437,7 @@ class AutoencoderKLWan(nn.Module):
             out = torch.cat(out_rows, dim=1)[:, :H // ratio, :W // ratio]
         return out[..., :2 * self.z_dim].permute(3, 0, 1, 2).contiguous()
 
+    @ops.on_model_device
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         h = torch.stack([self._encode_one(x[b]) for b in range(x.shape[0])], dim=0).to(x.dtype)
@@ -441,6 +446,7 @@ class AutoencoderKLWan(nn.Module):
             return (posterior,)
         return SimpleNamespace(latent_dist=posterior)
 
+    @ops.on_model_device
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)

@@ -196,12 +196,20 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
             blk._bkv2 = torch.empty(2 * dim, device=dev, dtype=dt)
             _repoint([a2.to_k.weight, a2.to_v.weight], blk._wkv2)
             _repoint([a2.to_k.bias, a2.to_v.bias], blk._bkv2)
-        # f32 copies of the modulation tables: [L, 6*dim] and [2*dim]
-        self._sst = torch.stack([b.scale_shift_table.data.float().reshape(-1) for b in self.blocks]) \
-            if L else torch.empty(0, 6 * dim, device=dev)
-        self._sst_out = self.scale_shift_table.data.float().reshape(-1).contiguous()
         self._ones = torch.ones(dim, device=dev, dtype=torch.float32)
         self._packed = True
+        self._weights_changed()
+
+    @torch.no_grad()
+    def _weights_changed(self):
+        """Rebuild what is DERIVED from parameter values (f32 copies of the modulation tables, [L, 6*dim] and
+        [2*dim]).  `weights.load_checkpoint_into` writes parameters in place after `pack()` and calls this."""
+        if not self._packed:
+            return
+        dim, dev = self.inner_dim, self.device
+        self._sst = torch.stack([b.scale_shift_table.data.float().reshape(-1) for b in self.blocks]) \
+            if len(self.blocks) else torch.empty(0, 6 * dim, device=dev)
+        self._sst_out = self.scale_shift_table.data.float().reshape(-1).contiguous()
 
     def _workspace(self, S: int, s_txt: int):
         key = (S, s_txt)
@@ -314,6 +322,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         out = out.reshape(grid[0], grid[1], grid[2], pt, ph, pw, -1).permute(6, 0, 3, 1, 4, 2, 5)
         return out.reshape(-1, T, Hh, Ww)
 
+    @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor = None,
                 encoder_hidden_states: torch.Tensor = None, encoder_hidden_states_image=None,

@@ -84,6 +84,11 @@ def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: 
                 raise TypeError(f"{key}: '{prefix}scale_weight' is present but the weight is {src.dtype}, not fp8")
             dst.data.copy_(src.to(dst.device, non_blocking=True))
         seen.add(key)
+    # derived state (f32 modulation tables, padded patch-embed operand, packed conv weights) follows the new values
+    for m in model.modules():
+        hook = getattr(m, "_weights_changed", None)
+        if callable(hook):
+            hook()
     missing = [k for k in targets if k not in seen]
     if strict and (missing or unexpected):
         raise RuntimeError(f"load_checkpoint_into: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "

@@ -278,9 +278,12 @@ int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner
 
 /* Sinusoidal timestep embedding (diffusers Timesteps(num_channels, flip_sin_to_cos=True,
  * downscale_freq_shift=0, scale); in-tree copy transformer/qwenimage/base/model.py:46-97).
- * t f32 [M] (device), out f32 [M, dim]. */
+ * t f32 [M] (device), out f32 [M, dim].  `freqs` (device f32 [dim/2], may be NULL) is the layer's frequency table
+ * exp(-ln(10000) i / (dim/2 - shift)); when given it is used verbatim — the host computes it once with the very f32
+ * operation sequence of the reference, so the sin / cos ARGUMENTS t*freq*scale are bit-identical to the reference's
+ * (a 1-ulp difference in a frequency is a 5e-5 phase error at t = 1000). */
 int apexmi_timestep_embedding(const float* t, float* out, int M, int dim, float scale,
-                              int flip_sin_to_cos, float downscale_freq_shift,
+                              int flip_sin_to_cos, float downscale_freq_shift, const float* freqs,
                               apexmi_stream_t stream);
 
 /* Rotary table for multi-axis positions (FluxPosEmbed.forward, flux model.py:338-359, i.e.

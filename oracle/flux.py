@@ -61,7 +61,7 @@ class FluxAttention(nn.Module):
             q = L.apply_rotary_emb(q, rope, sequence_dim=1)
             k = L.apply_rotary_emb(k, rope, sequence_dim=1)
         q, k = pol.r(q), pol.r(k)
-        o = L.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3))
+        o = L.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), policy=pol)
         o = pol.r(o.permute(0, 2, 1, 3).flatten(2, 3))
         if ctx is not None:
             n_txt = ctx.shape[1]

@@ -142,7 +142,7 @@ class TransformerBlock(nn.Module):
         ck = a.norm_added_k(pol.r(a.add_k_proj(c)).view(B, T, h, -1))
         cv = pol.r(a.add_v_proj(c)).view(B, T, h, -1)
         q, k, v = (pol.r(torch.cat(p, dim=1)) for p in ((q, cq), (k, ck), (v, cv)))
-        o = pol.r(L.sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).flatten(2, 3))
+        o = pol.r(L.sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), policy=pol).transpose(1, 2).flatten(2, 3))
         return a.to_out[0](o[:, :S]), a.to_add_out(o[:, S:])
 
     def forward(self, x, c, temb, rope, pol: Policy):

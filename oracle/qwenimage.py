@@ -82,7 +82,7 @@ class QwenImageTransformerBlock(nn.Module):
         v = torch.cat([pol.r(a.add_v_proj(txt)).unflatten(-1, (H, -1)),
                        pol.r(a.to_v(img)).unflatten(-1, (H, -1))], dim=1)
         q, k = pol.r(apply_rope_complex(q, *rope)), pol.r(apply_rope_complex(k, *rope))
-        o = L.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3))
+        o = L.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), policy=pol)
         o = pol.r(o.permute(0, 2, 1, 3).flatten(2, 3))
         return a.to_out[0](o[:, n_txt:]), a.to_add_out(o[:, :n_txt])
 

@@ -62,8 +62,10 @@ class WanAttention(nn.Module):
 
     def forward(self, x, ctx, rope, pol: Policy):
         src = x if ctx is None else ctx
-        q = self.norm_q(pol.r(self.to_q(x)))
-        k = self.norm_k(pol.r(self.to_k(src)))
+        # the across-heads RMSNorm is its own pass writing bf16 in place, in the reference (InplaceRMSNorm on bf16 tensors,
+        # transformer/efficiency/mod.py:24-35) as in the HIP path: a storage point under the bf16 policy
+        q = pol.r(self.norm_q(pol.r(self.to_q(x))))
+        k = pol.r(self.norm_k(pol.r(self.to_k(src))))
         v = pol.r(self.to_v(src))
         q = q.unflatten(2, (self.heads, -1)).transpose(1, 2)
         k = k.unflatten(2, (self.heads, -1)).transpose(1, 2)
@@ -71,7 +73,7 @@ class WanAttention(nn.Module):
         if rope is not None:
             q, k = apply_wan_rope(q, *rope), apply_wan_rope(k, *rope)
         q, k = pol.r(q), pol.r(k)
-        o = pol.r(L.sdpa(q, k, v).transpose(1, 2).flatten(2, 3))
+        o = pol.r(L.sdpa(q, k, v, policy=pol).transpose(1, 2).flatten(2, 3))
         return self.to_out[0](o)
 
 

@@ -1,0 +1,130 @@
+"""Every storage point of the Flux / Wan / QwenImage forward, HIP vs the bf16-storage oracle, like for like.
+
+tests/stage_parity.py explains the method (teacher forcing: after each op the buffers it wrote are compared with the
+oracle's value for that storage point and then replaced by it).  Bars, stated here as BASELINE.json's north_star
+demands: every one of the 60-120 storage points of a forward within 5e-4 relative L2 of the oracle (measured: 1e-6 to
+1.5e-4), the model output — one kernel after the last forced point — within the same 5e-4, and the f32 conditioning
+path (timestep embedding -> MLP -> AdaLN projections) within 2e-6.  The free-running forward (no forcing) is reported
+next to it: it sits at the bf16 noise floor (2e-3 .. 4e-3), as far from the oracle as the oracle's own bf16 emulation
+is from fp32.
+"""
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import layers as OL
+from oracle import qwenimage as OQ
+from oracle import wan as OW
+from tests import stage_parity as SP
+from tests.golden.seeded import seeded, synthetic_state_dict
+from tests.test_gpu_flux import CONFIGS as FLUX_CONFIGS, _inputs as flux_inputs
+from tests.test_gpu_qwen import CONFIGS as QWEN_CONFIGS
+from tests.test_gpu_wan import CONFIGS as WAN_CONFIGS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+STAGE_TOL = 5e-4
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm())
+
+
+def _finish(tag, report, out, po, free, ref16):
+    worst, _ = SP.print_report(tag, report)
+    e_out = _rel(out, po)
+    e_free = _rel(free, ref16)
+    print(f"[stage {tag}] model output after the last forced point: rel {e_out:.2e}; free-running forward vs the same "
+          f"oracle: {e_free:.2e}")
+    bad = [r for r in report if r[3] > STAGE_TOL]
+    assert not bad, f"storage points beyond {STAGE_TOL}: {[(r[2], r[3]) for r in bad]}"
+    assert e_out <= STAGE_TOL, e_out
+    assert e_free < 6e-3, e_free       # the bf16 noise floor of a free-running chain (see tests/stage_parity.py)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_flux_every_storage_point(name):
+    from apex_studio_amd import ops
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = FLUX_CONFIGS[name]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    inp = flux_inputs(cfg, hw, s_txt)
+    act = ("hidden_states", "encoder_hidden_states", "pooled_projections")
+    rin = {k: (v.to(torch.bfloat16).float() if k in act else v) for k, v in inp.items()}
+    pol = SP.TracePolicy()
+    ref16 = orc(rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"],
+                rin["img_ids"], rin["txt_ids"], rin["guidance"], policy=pol)
+    plan, po = SP.flux_plan(pol.points, cfg, s_txt)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    g = {k: (v.to(DEV).to(torch.bfloat16) if k in act else v.to(DEV)) for k, v in inp.items()}
+    free = m(return_dict=False, **g)[0]
+    out, report = SP.run_forced(ops, m, plan, lambda: m(return_dict=False, **g)[0])
+    # f32 conditioning path
+    temb = orc.time_text_embed((rin["timestep"].to(torch.bfloat16) * 1000).float(),
+                               (rin["guidance"].to(torch.bfloat16) * 1000).float(), rin["pooled_projections"])
+    ws = next(iter(m._ws.values()))
+    e_t = _rel(ws.TEMB[0], temb[0])
+    blk = orc.transformer_blocks[0]
+    off = m._mod_off[("d", 0, "txt")]
+    mod = blk.norm1_context.linear(torch.nn.functional.silu(temb))[0]
+    e_m = _rel(ws.MOD[0, off:off + mod.numel()], mod)
+    print(f"[stage flux {name}] f32 conditioning: temb rel {e_t:.2e}, AdaLN projection rel {e_m:.2e}")
+    assert e_t < 2e-6 and e_m < 2e-6
+    _finish(f"flux {name}", report, out, po, free, ref16)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_wan_every_storage_point(name):
+    from apex_studio_amd import ops
+    from apex_studio_amd.wan import WanTransformer3DModel
+    cfg, shape, s_txt = WAN_CONFIGS[name]
+    orc = OW.WanTransformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 9)
+    orc.load_state_dict(sd, strict=True)
+    x = seeded(shape, 41).to(torch.bfloat16).float()
+    txt = seeded((1, s_txt, cfg["text_dim"]), 42).to(torch.bfloat16).float()
+    t = torch.tensor([500.0])
+    pol = SP.TracePolicy()
+    ref16 = orc(x, t, txt, policy=pol)
+    plan, po = SP.wan_plan(pol.points, cfg)
+    m = WanTransformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    kw = dict(hidden_states=x.to(DEV), timestep=t.to(DEV), encoder_hidden_states=txt.to(DEV).to(torch.bfloat16),
+              return_dict=False)
+    free = m(**kw)[0]
+    out, report = SP.run_forced(ops, m, plan, lambda: m(**kw)[0])
+    # the oracle's proj_out point is [1, S, C*p*p] before the un-patchify; compare after the same reshuffle
+    B, C, T, H, W = shape
+    pt, ph, pw = cfg["patch_size"]
+    gd = (T // pt, H // ph, W // pw)
+    po_img = po.reshape(B, gd[0], gd[1], gd[2], pt, ph, pw, -1).permute(0, 7, 1, 4, 2, 5, 3, 6) \
+        .flatten(6, 7).flatten(4, 5).flatten(2, 3)
+    _finish(f"wan {name}", report, out, po_img, free, ref16)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_qwen_every_storage_point(name):
+    from apex_studio_amd import ops
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    cfg, shapes, s_txt = QWEN_CONFIGS[name]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    n_img = sum(f * h * w for f, h, w in shapes)
+    x = seeded((1, n_img, 64), 51).to(torch.bfloat16).float()
+    txt = seeded((1, s_txt, cfg["joint_attention_dim"]), 52).to(torch.bfloat16).float()
+    t = torch.tensor([0.5])
+    pol = SP.TracePolicy()
+    ref16 = orc(x, txt, t, shapes, policy=pol)
+    plan, po = SP.qwen_plan(pol.points, cfg, s_txt)
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    kw = dict(hidden_states=x.to(DEV).to(torch.bfloat16), encoder_hidden_states=txt.to(DEV).to(torch.bfloat16),
+              encoder_hidden_states_mask=torch.ones(1, txt.shape[1], device=DEV), timestep=t.to(DEV),
+              img_shapes=[shapes], txt_seq_lens=[txt.shape[1]], return_dict=False)
+    free = m(**kw)[0]
+    out, report = SP.run_forced(ops, m, plan, lambda: m(**kw)[0])
+    _finish(f"qwen {name}", report, out, po, free, ref16)
