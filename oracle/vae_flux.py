@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import layers as L
 from .layers import Policy, FP32
 
 
@@ -52,7 +53,7 @@ class AttnBlock(nn.Module):
         b, c, h, w = x.shape
         y = pol.r(self.group_norm(x)).view(b, c, h * w).transpose(1, 2)
         q, k, v = pol.r(self.to_q(y)), pol.r(self.to_k(y)), pol.r(self.to_v(y))
-        o = pol.r(F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0])
+        o = pol.r(L.sdpa_dispatch(q, k, v, policy=pol))
         o = self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
         return pol.r(o + x)
 

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import layers as L
 from .layers import Policy, FP32
 
 
@@ -77,8 +78,8 @@ class AttnBlock(nn.Module):
         n = pol.r(self.norm(x))
         q, k, v = (pol.r(m(n)).reshape(b, c, f * h * w).permute(0, 2, 1).unsqueeze(1) for m in (self.to_q, self.to_k, self.to_v))
         frame = torch.arange(f * h * w) // (h * w)
-        mask = torch.zeros(f * h * w, f * h * w).masked_fill(frame[None, :] > frame[:, None], float("-inf"))
-        o = pol.r(F.scaled_dot_product_attention(q, k, v, attn_mask=mask))
+        keep = frame[None, :] <= frame[:, None]        # token i sees the keys of frames <= its own
+        o = pol.r(L.sdpa_dispatch(q, k, v, policy=pol, mask=keep))
         o = o.squeeze(1).reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
         return pol.r(self.proj_out(o) + x)
 

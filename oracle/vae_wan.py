@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import layers as L
 from .layers import Policy, FP32
 
 
@@ -86,7 +87,7 @@ class AttentionBlock(nn.Module):
         qkv = pol.r(self.to_qkv(pol.r(self.norm(y))))
         qkv = qkv.reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2)
         q, k, v = qkv.chunk(3, dim=-1)
-        o = pol.r(F.scaled_dot_product_attention(q, k, v))
+        o = pol.r(L.sdpa_dispatch(q, k, v, policy=pol))
         o = o.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, w)
         o = self.proj(o).view(b, t, c, h, w).permute(0, 2, 1, 3, 4)
         return pol.r(o + x)
@@ -199,13 +200,15 @@ class AutoencoderKLWanDecoder(nn.Module):
         return self.decoder(pol.r(self.post_quant_conv(z)), pol)
 
     @staticmethod
-    def _blend(a, b, extent, dim):
+    def _blend(a, b, extent, dim, pol: Policy = FP32):
+        """Linear cross-fade of an overlap, written into `b` in place like the reference (model.py:1404-1422); the blended
+        values are a storage point (the HIP crossfade kernel writes bf16 tiles)."""
         extent = min(a.shape[dim], b.shape[dim], extent)
         w = (torch.arange(extent, dtype=a.dtype) / extent).view([-1 if d == dim % 5 else 1 for d in range(5)])
         sa = [slice(None)] * 5
         sb = [slice(None)] * 5
         sa[dim], sb[dim] = slice(a.shape[dim] - extent, None), slice(0, extent)
-        b[tuple(sb)] = a[tuple(sa)] * (1 - w) + b[tuple(sb)] * w
+        b[tuple(sb)] = pol.r(a[tuple(sa)] * (1 - w) + b[tuple(sb)] * w)
         return b
 
     @torch.no_grad()
@@ -224,9 +227,9 @@ class AutoencoderKLWanDecoder(nn.Module):
             out = []
             for j, tile in enumerate(row):
                 if i > 0:
-                    tile = self._blend(rows[i - 1][j], tile, blend[0], 3)   # in place, like the reference
+                    tile = self._blend(rows[i - 1][j], tile, blend[0], 3, pol)   # in place, like the reference
                 if j > 0:
-                    tile = self._blend(row[j - 1], tile, blend[1], 4)
+                    tile = self._blend(row[j - 1], tile, blend[1], 4, pol)
                 out.append(tile[:, :, :, :self.tile_stride[0], :self.tile_stride[1]])
             out_rows.append(torch.cat(out, dim=-1))
         dec = torch.cat(out_rows, dim=3)[:, :, :, :H * self.ratio, :W * self.ratio]
@@ -324,9 +327,9 @@ class AutoencoderKLWanEncoder(nn.Module):
             out = []
             for j, tile in enumerate(row):
                 if i > 0:
-                    tile = self._blend(rows[i - 1][j], tile, blend[0], 3)
+                    tile = self._blend(rows[i - 1][j], tile, blend[0], 3, pol)
                 if j > 0:
-                    tile = self._blend(row[j - 1], tile, blend[1], 4)
+                    tile = self._blend(row[j - 1], tile, blend[1], 4, pol)
                 out.append(tile[:, :, :, :lat_stride[0], :lat_stride[1]])
             out_rows.append(torch.cat(out, dim=-1))
         return torch.cat(out_rows, dim=3)[:, :, :, :H // self.ratio, :W // self.ratio]

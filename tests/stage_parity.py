@@ -107,6 +107,21 @@ def print_report(tag: str, report) -> Tuple[float, float]:
     return worst, mean
 
 
+STAGE_TOL = 5e-4
+
+
+def assert_stages(tag: str, report, out, po) -> None:
+    """The bar of north_star, per storage point: every kernel output within STAGE_TOL (relative L2) of the oracle's
+    value given bit-identical inputs, and the model output (one kernel after the last forced point) as well."""
+    print_report(tag, report)
+    o, p = out.float().cpu(), po.float().cpu()
+    e_out = float((o - p).norm() / p.norm())
+    print(f"[stage {tag}] model output after the last forced point: rel {e_out:.2e}")
+    bad = [r for r in report if r[3] > STAGE_TOL]
+    assert not bad, f"storage points beyond {STAGE_TOL}: {[(r[2], r[3]) for r in bad]}"
+    assert e_out <= STAGE_TOL, e_out
+
+
 # ---- plans ------------------------------------------------------------------------------------------------------------
 def _heads_from_bshd(v):     # oracle [1, S, H, 128] -> [H, S, 128]
     return v[0].permute(1, 0, 2).contiguous()

@@ -14,6 +14,7 @@ import torch
 
 from oracle import flux as OF
 from oracle import layers as OL
+from tests import stage_parity as SP
 from tests.golden.seeded import seeded, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +76,7 @@ def test_flux_forward_matches_oracle(name):
     e_emul = _rel(ref16, ref32)
     print(f"[{name}] hip vs bf16-storage oracle {e_like:.3e}; hip vs fp32 {e_true:.3e}; "
           f"emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
 
 
@@ -160,13 +161,19 @@ def test_flux_full_width_one_plus_one_blocks_match_oracle(host_threads):
     args = (rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"],
             rin["img_ids"], rin["txt_ids"], rin["guidance"])
     ref32 = orc(*args)
-    ref16 = orc(*args, policy=OL.BF16_STORAGE)
+    pol = SP.TracePolicy()
+    ref16 = orc(*args, policy=pol)
     m, out = _run_hip(cfg, sd, inp)
     assert out.shape == ref32.shape == (1, 4096, 64) and torch.isfinite(out).all()
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[flux full width 1+1] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
     g = {k: (v.to(DEV).to(torch.bfloat16) if k in ("hidden_states", "encoder_hidden_states", "pooled_projections")
              else v.to(DEV)) for k, v in inp.items()}
     assert torch.equal(m(return_dict=False, **g)[0].float().cpu(), out), "full-size step must be deterministic"
+    # every storage point of the full-width forward, like for like (tests/stage_parity.py)
+    from apex_studio_amd import ops
+    plan, po = SP.flux_plan(pol.points, cfg, 512)
+    forced, report = SP.run_forced(ops, m, plan, lambda: m(return_dict=False, **g)[0])
+    SP.assert_stages("flux full width 1+1", report, forced, po)

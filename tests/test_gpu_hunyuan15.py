@@ -73,7 +73,7 @@ def test_hunyuan15_forward_matches_oracle(name, i2v):
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[hunyuan15 {name} {'i2v' if i2v else 't2v'}] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; "
           f"emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3, (e_true, e_emul)
 
 

@@ -6,6 +6,7 @@ import torch
 
 from oracle import layers as OL
 from oracle import qwenimage as OQ
+from tests import stage_parity as SP
 from tests.golden.seeded import seeded, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -55,7 +56,7 @@ def test_qwen_forward_matches_oracle(name):
     assert out.shape == ref32.shape and torch.isfinite(out).all()
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[qwen {name}] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3
     after = m.state_dict()
     for k in sd:
@@ -87,12 +88,20 @@ def test_qwen_full_width_one_block_matches_oracle(host_threads):
     txt = seeded((1, 256, 3584), 52).to(torch.bfloat16).float()
     t = torch.tensor([0.5])
     ref32 = orc(x, txt, t, shapes)
-    ref16 = orc(x, txt, t, shapes, policy=OL.BF16_STORAGE)
-    _, out = _hip(cfg, sd, x, txt, t, shapes)
+    pol = SP.TracePolicy()
+    ref16 = orc(x, txt, t, shapes, policy=pol)
+    m, out = _hip(cfg, sd, x, txt, t, shapes)
     assert out.shape == ref32.shape and torch.isfinite(out).all()
+    from apex_studio_amd import ops
+    plan, po = SP.qwen_plan(pol.points, cfg, 256)
+    forced, report = SP.run_forced(ops, m, plan, lambda: m(
+        hidden_states=x.to(DEV).to(torch.bfloat16), encoder_hidden_states=txt.to(DEV).to(torch.bfloat16),
+        encoder_hidden_states_mask=torch.ones(1, 256, device=DEV), timestep=t.to(DEV), img_shapes=[shapes],
+        txt_seq_lens=[256], return_dict=False)[0])
+    SP.assert_stages("qwen full width 1 block", report, forced, po)
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[qwen full width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3
 
 

@@ -23,7 +23,6 @@ from tests.test_gpu_wan import CONFIGS as WAN_CONFIGS
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-STAGE_TOL = 5e-4
 
 
 def _rel(a, b):
@@ -31,14 +30,9 @@ def _rel(a, b):
 
 
 def _finish(tag, report, out, po, free, ref16):
-    worst, _ = SP.print_report(tag, report)
-    e_out = _rel(out, po)
+    SP.assert_stages(tag, report, out, po)
     e_free = _rel(free, ref16)
-    print(f"[stage {tag}] model output after the last forced point: rel {e_out:.2e}; free-running forward vs the same "
-          f"oracle: {e_free:.2e}")
-    bad = [r for r in report if r[3] > STAGE_TOL]
-    assert not bad, f"storage points beyond {STAGE_TOL}: {[(r[2], r[3]) for r in bad]}"
-    assert e_out <= STAGE_TOL, e_out
+    print(f"[stage {tag}] free-running forward vs the same oracle: {e_free:.2e}")
     assert e_free < 6e-3, e_free       # the bf16 noise floor of a free-running chain (see tests/stage_parity.py)
 
 

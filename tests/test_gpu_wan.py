@@ -7,6 +7,7 @@ import torch
 
 from oracle import layers as OL
 from oracle import wan as OW
+from tests import stage_parity as SP
 from tests.golden.seeded import seeded, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -51,7 +52,7 @@ def test_wan_forward_matches_oracle(name):
     assert out.shape == ref32.shape and torch.isfinite(out).all()
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[wan {name}] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3
     # state dict round trip + determinism
     after = m.state_dict()
@@ -86,10 +87,18 @@ def test_wan_full_width_one_block_matches_oracle(host_threads):
     txt = seeded((1, 512, 4096), 42).to(torch.bfloat16).float()
     t = torch.tensor([500.0])
     ref32 = orc(x, t, txt)
-    ref16 = orc(x, t, txt, policy=OL.BF16_STORAGE)
-    _, out = _hip(cfg, sd, x, t, txt)
+    pol = SP.TracePolicy()
+    ref16 = orc(x, t, txt, policy=pol)
+    m, out = _hip(cfg, sd, x, t, txt)
     assert out.shape == ref32.shape and torch.isfinite(out).all()
+    from apex_studio_amd import ops
+    plan, po = SP.wan_plan(pol.points, cfg)
+    forced, report = SP.run_forced(ops, m, plan, lambda: m(
+        hidden_states=x.to(DEV), timestep=t.to(DEV), encoder_hidden_states=txt.to(DEV).to(torch.bfloat16),
+        return_dict=False)[0])
+    po = po.reshape(1, 5, 30, 52, 1, 2, 2, -1).permute(0, 7, 1, 4, 2, 5, 3, 6).flatten(6, 7).flatten(4, 5).flatten(2, 3)
+    SP.assert_stages("wan full width 1 block", report, forced, po)
     e_like, e_true, e_emul = _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
     print(f"[wan full width 1 block] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
-    assert e_like < 1e-2, e_like
+    assert e_like < 6e-3, e_like   # free-running bf16 chain: the noise floor (tests/stage_parity.py); per-stage bar 5e-4 there
     assert e_true < 2 * e_emul + 2e-3
