@@ -59,6 +59,71 @@ def broadcast_shared(tensors: Sequence[torch.Tensor], src: int = 0, group=None,
     return {"bytes": nbytes, "seconds": dt, "gbps": (nbytes / dt / 1e9) if dt > 0 else 0.0, "world": world}
 
 
+def shared_tensors(modules) -> List[torch.Tensor]:
+    """Every parameter and buffer of `modules` once (tied weights — T5's `shared` / `encoder.embed_tokens` — are one
+    storage), as the flat list `broadcast_parameters` moves."""
+    seen, out = set(), []
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            key = (t.data_ptr(), t.numel(), t.dtype)
+            if t.numel() and key not in seen:
+                seen.add(key)
+                out.append(t.data)
+    return out
+
+
+def broadcast_parameters(modules, src: int = 0, group=None, bucket_bytes: int = 1 << 30) -> Dict[str, float]:
+    """The one exchange step of the render queue (north_star: "RCCL over xGMI only for the broadcast of shared
+    text-encoder/VAE weights"): rank `src` holds the loaded text encoders / VAE, every other rank has constructed the
+    same classes on its device with uninitialised storage; the parameters travel in ~1 GiB buckets (one staging
+    buffer, scatter + all-gather per bucket, see `broadcast_shared`) and are written in place on the receivers, whose
+    derived state (fused / padded / packed copies) is then dropped through the `_weights_changed` hooks.
+    Sizes to expect: Flux T5-XXL 9.5 GB + CLIP-L 0.25 GB + VAE 0.17 GB; Wan UMT5-XXL 11.4 GB + VAE 0.5 GB."""
+    tensors = shared_tensors(modules)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
+        return {"bytes": sum(t.numel() * t.element_size() for t in tensors), "seconds": 0.0, "gbps": 0.0,
+                "world": 1, "tensors": len(tensors), "buckets": 0}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = tensors[0].device
+    pad = 16 * world                                          # every bucket a multiple of the world size and 16 B
+    buckets, cur, cur_n = [], [], 0
+    for t in tensors:
+        assert t.is_contiguous() and t.device == dev, "broadcast_parameters: contiguous tensors on one device"
+        n = (t.numel() * t.element_size() + 15) // 16 * 16
+        if cur and cur_n + n > bucket_bytes:
+            buckets.append((cur, cur_n))
+            cur, cur_n = [], 0
+        cur.append((t, cur_n, t.numel() * t.element_size()))
+        cur_n += n
+    if cur:
+        buckets.append((cur, cur_n))
+    cap = (max(n for _, n in buckets) + pad - 1) // pad * pad
+    stage = torch.empty(cap, dtype=torch.uint8, device=dev)
+    _sync(stage)
+    t0 = time.perf_counter()
+    total = 0
+    for items, n in buckets:
+        npad = (n + pad - 1) // pad * pad
+        if rank == src:
+            for t, off, nb in items:
+                stage[off:off + nb].copy_(t.view(-1).view(torch.uint8))
+        broadcast_shared([stage[:npad]], src=src, group=group)
+        if rank != src:
+            for t, off, nb in items:
+                t.view(-1).view(torch.uint8).copy_(stage[off:off + nb])
+        total += n
+    _sync(stage)
+    dt = time.perf_counter() - t0
+    if rank != src:
+        for m in modules:
+            for sub in m.modules():
+                hook = getattr(sub, "_weights_changed", None)
+                if callable(hook):
+                    hook()
+    return {"bytes": total, "seconds": dt, "gbps": total / dt / 1e9 if dt > 0 else 0.0, "world": world,
+            "tensors": len(tensors), "buckets": len(buckets)}
+
+
 def assign_clips(costs: Sequence[float], world: int) -> List[List[int]]:
     """Longest-processing-time-first assignment of clip indices to ranks; deterministic, identical on
     every rank (ties broken by index).  Puts the long (video) clips on distinct GPUs first, which is

@@ -22,8 +22,12 @@ Other single-GPU BASELINE configs (not the default bench line):
 
 N > 1: one process per GPU, each denoising its OWN clip (the reference's only multi-GPU mechanism: one
 engine-runner actor per GPU, apps/api/src/api/ray_tasks.py:181-306) -> weak scaling, no collective inside
-a step; RCCL is used once, before the timed region, to broadcast the shared prompt embeddings and a
-stand-in for the shared text-encoder/VAE weights (render_queue.broadcast_shared).
+a step; RCCL is used once, before the timed region, to broadcast the weights every clip shares — the text encoders
+and the VAE of the workload (Flux: T5-XXL + CLIP-L + 2-D VAE; Wan: UMT5-XXL + 3-D VAE), initialised on rank 0 only —
+and the shared prompt embeddings (render_queue.broadcast_parameters / broadcast_shared); every rank then encodes the
+same token ids and the outputs are compared bit for bit ("verified" in the JSON).
+Started WITHOUT torchrun, `bench.py --gpus N` (N > 1) re-executes itself under torch.distributed.run with N ranks and
+refuses to run when fewer than N GPUs are visible: an N-GPU number only ever comes from N processes.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     achieved TFLOP/s of the dominant kernel (gemm_bf16_kernel) = algorithmic 2MNK flops of its
@@ -66,7 +70,9 @@ def parse():
     ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip (28 steps + decode) timing")
     ap.add_argument("--clip", action="store_true", help="wan: also time a whole 30-step clip + decode")
     ap.add_argument("--queue-wan-steps", type=int, default=30)
-    ap.add_argument("--broadcast-mib", type=int, default=1024)
+    ap.add_argument("--no-shared-weights", action="store_true",
+                    help="N>1: broadcast only the prompt embeddings, not the text-encoder/VAE weights")
+    ap.add_argument("--no-wan", action="store_true", help="N=1 flux: skip the Wan-2.2 720p half of the headline metric")
     ap.add_argument("--tune", type=str, default="", help="debug A/B: comma list of key=value for apexmi_tune_set")
     return ap.parse_args()
 
@@ -99,6 +105,113 @@ def cpu_baseline():
                    f"({t1 - t0:.2f} s) + 1 single block ({t2 - t1:.2f} s) at full width 3072 / S=4608, "
                    f"extrapolated x19 / x38; embedders and final layer (<0.1% of FLOPs) excluded"),
     }
+
+
+def _cpu_rate(flops, seconds, step_tflop, cores, sample):
+    rate = flops / seconds                                    # algorithmic FLOP/s the host cores sustain on the sample
+    return {"value": rate / (step_tflop * 1e12), "unit": "steps/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def cpu_baseline_qwen():
+    """Oracle QwenImage block (fp32) at full width on a shortened sequence, scaled to the step by algorithmic FLOPs."""
+    from oracle import qwenimage as OQ
+    from oracle import layers as OL
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    dim, H, s_img, s_txt = 3072, 24, 4096, 256
+    g = torch.Generator().manual_seed(0)
+    blk = OQ.QwenImageTransformerBlock(dim, H, 128).eval()
+    img, txt, temb = torch.randn(1, s_img, dim, generator=g), torch.randn(1, s_txt, dim, generator=g), torch.randn(1, dim, generator=g)
+    rope = OQ.qwen_rope_table(OQ.qwen_rope_positions([(1, 64, 64)], s_txt), (16, 56, 56))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        blk(img, txt, temb, rope, OL.FP32)
+        dt = time.perf_counter() - t0
+    S = s_img + s_txt
+    flops = 2.0 * S * 12 * dim * dim + 4.0 * S * S * dim
+    return _cpu_rate(flops, dt, STEP_TFLOP["qwen"], ncores,
+                     f"oracle fp32 QwenImage block at full width 3072, S = {s_img} + {s_txt} tokens ({dt:.2f} s, "
+                     f"{flops / 1e12:.2f} TFLOP); steps/s = sustained FLOP/s / {STEP_TFLOP['qwen']} TFLOP per step")
+
+
+def cpu_baseline_wan():
+    """Oracle Wan block (fp32) at full width on a shortened clip, scaled to the step by algorithmic FLOPs."""
+    from oracle import wan as OW
+    from oracle import layers as OL
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    dim, H, ffn, s_txt, grid = 5120, 40, 13824, 512, (3, 30, 52)
+    S = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(0)
+    blk = OW.WanTransformerBlock(dim, ffn, H).eval()
+    x, ctx = torch.randn(1, S, dim, generator=g), torch.randn(1, s_txt, dim, generator=g)
+    temb6 = torch.randn(1, 6, dim, generator=g)
+    rope = OW.wan_rope_table(grid, 128)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        blk(x, ctx, temb6, rope, OL.FP32)
+        dt = time.perf_counter() - t0
+    flops = 2.0 * S * (6 * dim * dim + 2 * dim * ffn) + 2.0 * s_txt * 2 * dim * dim + 4.0 * S * S * dim + 4.0 * S * s_txt * dim
+    return _cpu_rate(flops, dt, STEP_TFLOP["wan"], ncores,
+                     f"oracle fp32 Wan block at full width 5120 / ffn 13824 on a {grid} latent grid (S = {S}) + {s_txt} "
+                     f"text tokens ({dt:.2f} s, {flops / 1e12:.2f} TFLOP); steps/s = sustained FLOP/s / "
+                     f"{STEP_TFLOP['wan']} TFLOP per expert forward")
+
+
+def wan_half(dev):
+    """The other half of BASELINE.json's metric on the default line: Wan-2.2 A14B 720p x 81 frames (config 4), one
+    expert, 1 warm-up + 2 timed [forward + UniPC step], then the tiled 3-D VAE decode (1 warm-up + 1 timed)."""
+    from apex_studio_amd import lib
+    from apex_studio_amd.schedulers import UniPCMultistepScheduler
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from apex_studio_amd.wan import WanTransformer3DModel
+    model = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=999)
+    model.pack()
+    g = torch.Generator(device=dev).manual_seed(300)
+    lat = torch.randn(1, 16, 21, 90, 160, generator=g, device=dev)
+    enc = torch.randn(1, 512, 4096, generator=torch.Generator(device=dev).manual_seed(9), device=dev).to(torch.bfloat16)
+    sched = UniPCMultistepScheduler(shift=3.0)
+    ts = sched.set_timesteps(30, device=dev)
+
+    def step(i, x):
+        v = model(hidden_states=x.to(torch.bfloat16), timestep=ts[i].expand(1), encoder_hidden_states=enc,
+                  return_dict=False)[0]
+        return sched.step(v.float(), ts[i], x, return_dict=False)[0]
+
+    lat = step(0, lat)
+    torch.cuda.synchronize()
+    lib.prof_reset()
+    lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in (1, 2):
+        lat = step(i, lat)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    prof = lib.prof_read()
+    lib.prof_enable(False)
+    lib.prof_reset()
+    finite = bool(torch.isfinite(lat).all().item())
+    att = prof["attention"]
+    del model
+    torch.cuda.empty_cache()
+    vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
+    vae.enable_tiling()
+    z = vae.denormalize_latents(lat).to(torch.bfloat16)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        video = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        dec = time.perf_counter() - t0
+    tf = STEP_TFLOP["wan"]
+    return {"workload": "wan-2.2-a14b text-to-video 720p x 81 frames: one expert forward (40 blocks, S 75600 + 512 text "
+                        "tokens, B=1, no CFG) + UniPC step; tiled 3-D VAE decode to [1,3,81,720,1280]",
+            "steps_timed": 2, "ms_per_step": 1e3 * dt, "steps_per_sec": 1.0 / dt, "step_tflop": tf,
+            "model_tflops": tf / dt, "mfma_utilisation_step": tf / dt / PEAK_BF16_TFLOPS,
+            "attention": {"tflops": att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] else None,
+                          "ms_per_step": att["ms"] / 2, "launches_per_step": att["launches"] / 2},
+            "decode_s": dec, "sec_per_clip_30_steps": 30 * dt + dec, "video": list(video.shape),
+            "finite": finite and bool(torch.isfinite(video.float()).all().item())}
 
 
 def synth_vae_init(vae, seed):
@@ -312,11 +425,19 @@ def run_queue(args, dev, rank, world):
     f_enc = torch.randn(1, S_TXT, 4096, generator=g, device=dev).to(torch.bfloat16)
     f_pool = torch.randn(1, 768, generator=g, device=dev).to(torch.bfloat16)
     w_enc = torch.randn(1, 512, 4096, generator=g, device=dev).to(torch.bfloat16)
-    shared = torch.empty(args.broadcast_mib << 20, dtype=torch.uint8, device=dev)
-    bcast = render_queue.broadcast_shared([f_enc, f_pool, w_enc, shared], src=0)
-    del shared
-    clips = [{"kind": "flux", "seed": i, "cost": 2.5} for i in range(4)] + \
-            [{"kind": "wan", "seed": 10 + i, "cost": 6.0 * args.queue_wan_steps} for i in range(4)]
+    bcast = {"embeddings": render_queue.broadcast_shared([f_enc, f_pool, w_enc], src=0)}
+    if world > 1 and not args.no_shared_weights:     # the queue's shared components: both families' encoders; the VAEs above
+        from apex_studio_amd import text_encoders as TE
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        enc_mods = [TE.T5EncoderModel({}, **bf), TE.CLIPTextModel({}, **bf), TE.UMT5EncoderModel({}, **bf)]
+        if rank == 0:
+            for i, m in enumerate(enc_mods):
+                _synth_text_init(m, 40 + i)
+        bcast["weights"] = dict(render_queue.broadcast_parameters(enc_mods + [fvae, wan.vae], src=0),
+                                what="T5-XXL + CLIP-L + UMT5-XXL text encoders + Flux 2-D VAE + Wan 3-D VAE")
+        del enc_mods
+        torch.cuda.empty_cache()
+    wan_cost = 6.0 * args.queue_wan_steps
 
     def runner(c):
         if c["kind"] == "flux":
@@ -326,8 +447,16 @@ def run_queue(args, dev, rank, world):
             wan.run(prompt_embeds=w_enc, height=720, width=1280, duration=81,
                     num_inference_steps=args.queue_wan_steps, seed=c["seed"])
 
-    runner(dict(clips[0], seed=99))      # warm (packing, workspaces)
+    runner({"kind": "flux", "seed": 99})      # warm (packing, workspaces)
+    # (1) the literal config 5: 8 clips, STRONG scaling — bounded by its longest clip once every GPU holds one
+    clips = [{"kind": "flux", "seed": i, "cost": 2.5} for i in range(4)] + \
+            [{"kind": "wan", "seed": 10 + i, "cost": wan_cost} for i in range(4)]
     res = render_queue.run_queue(clips, runner)
+    # (2) the same queue DEEPENED with the node (WEAK scaling: one Flux + one Wan clip per GPU) — the regime in which
+    # clip-per-GPU sharding can show its N-fold throughput (north_star's >= 7.5x at 8 GPUs)
+    weak_clips = [{"kind": "flux", "seed": 100 + i, "cost": 2.5} for i in range(world)] + \
+                 [{"kind": "wan", "seed": 200 + i, "cost": wan_cost} for i in range(world)]
+    weak = render_queue.run_queue(weak_clips, runner)
     if rank == 0:
         print(json.dumps({
             "metric": "queue_clips_per_hour", "value": res["clips_per_hour"], "unit": "clips/h", "n_gpus": world,
@@ -336,18 +465,90 @@ def run_queue(args, dev, rank, world):
             "config": {"workload": f"8-clip render queue: 4x flux-dev 1024^2 (28 steps + decode) + 4x wan-2.2 "
                                    f"720p x 81f ({args.queue_wan_steps} steps, expert switch, tiled 3D-VAE decode), "
                                    f"one clip per GPU at a time", "parallelism": f"clip-per-gpu x{world}"},
-            "makespan_s": res["makespan"], "busy_s": res["busy"],
+            "world": world, "makespan_s": res["makespan"], "busy_s": res["busy"],
             "clip_seconds": {str(k): round(v, 3) for k, v in sorted(res["clip_seconds"].items())},
+            "weak_scaling": {"clips": len(weak_clips), "what": "one flux-dev 1024^2 clip + one wan-2.2 720p clip PER GPU",
+                             "clips_per_hour": weak["clips_per_hour"], "makespan_s": weak["makespan"],
+                             "busy_s": weak["busy"]},
             "broadcast": bcast}), flush=True)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RCCL) and exit with their
+    status.  Refuses when the node shows fewer than N GPUs — a single process never reports an N-GPU number."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node; an {args.gpus}-GPU "
+                         f"result needs {args.gpus} ranks, one per GPU — refusing to run")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _synth_text_init(m, seed):
+    g = torch.Generator(device=m.device).manual_seed(seed)
+    for n, p in m.named_parameters():
+        if "norm" in n or n.endswith("ln_q.weight"):
+            p.data.fill_(1.0)
+        elif n.endswith("bias"):
+            p.data.zero_()
+        else:
+            sc = (0.125 if n.endswith(".q.weight") else 1.0) / p.shape[-1] ** 0.5
+            flat = p.data.view(-1)
+            for i in range(0, flat.numel(), 1 << 26):
+                k = min(1 << 26, flat.numel() - i)
+                flat[i:i + k] = (torch.randn(k, generator=g, device=p.device) * sc).to(p.dtype)
+    return m
+
+
+def shared_weights(workload, dev, rank):
+    """The components every clip of a queue shares (reference manifests: Flux yml:55,66,83; Wan yml:84,71): built on
+    every rank, initialised (stand-in for loaded) on rank 0 only.  Returns (modules, label, probe) where probe(mods)
+    encodes fixed token ids and returns a checksum tensor."""
+    from apex_studio_amd import text_encoders as TE
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    if workload in ("flux", "queue"):
+        from apex_studio_amd.vae_flux import AutoencoderKL
+        mods = [TE.T5EncoderModel({}, **bf), TE.CLIPTextModel({}, **bf), AutoencoderKL(**bf)]
+        label = "T5-XXL + CLIP-L text encoders + Flux 2-D VAE"
+    elif workload == "wan":
+        from apex_studio_amd.vae_wan import AutoencoderKLWan
+        mods = [TE.UMT5EncoderModel({}, **bf), AutoencoderKLWan(**bf)]
+        label = "UMT5-XXL text encoder + Wan 3-D VAE"
+    else:
+        return None, None, None
+    if rank == 0:
+        for i, m in enumerate(mods[:-1]):
+            _synth_text_init(m, 40 + i)
+        synth_vae_init(mods[-1], 5)
+
+    def probe(ms):
+        out = []
+        for m in ms[:-1]:
+            S = 77 if isinstance(m, TE.CLIPTextModel) else 512
+            ids = (torch.arange(S, device=dev) * 37 % 30000 + 3).reshape(1, S)
+            out.append(m(input_ids=ids, attention_mask=torch.ones_like(ids)).last_hidden_state.double().sum())
+        return torch.stack(out)
+    return mods, label, probe
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: every GPU counted in the result must be "
+                         f"one rank of this job")
     import torch.distributed as dist
     distributed = world > 1 or os.environ.get("APEX_FORCE_DIST") == "1"   # force: RCCL smoke test on one GPU
     torch.cuda.set_device(local_rank)
@@ -375,10 +576,19 @@ def main():
     step, latents, reset, shared_inputs, clip_fn, label = build(args, dev, rank, total)
 
     bcast = None
-    if distributed:   # the prompt embeddings are shared -> broadcast from rank 0, with a stand-in weight buffer
-        shared = torch.empty(args.broadcast_mib << 20, dtype=torch.uint8, device=dev)
-        bcast = render_queue.broadcast_shared(list(shared_inputs) + [shared], src=0)
-        del shared
+    if distributed:   # the ONE exchange step: shared text-encoder / VAE weights + shared prompt embeddings from rank 0
+        bcast = {"embeddings": render_queue.broadcast_shared(list(shared_inputs), src=0),
+                 "rccl_ranks": dist.get_world_size()}
+        mods, what, probe = (None, None, None) if args.no_shared_weights else shared_weights(args.workload, dev, rank)
+        if mods is not None:
+            bcast["weights"] = dict(render_queue.broadcast_parameters(mods, src=0), what=what)
+            sums = probe(mods)                                  # every rank encodes the same ids with ITS copy
+            gathered = [torch.empty_like(sums) for _ in range(dist.get_world_size())]
+            dist.all_gather(gathered, sums)
+            bcast["weights"]["verified"] = bool(all(torch.equal(g, gathered[0]) for g in gathered)
+                                                and torch.isfinite(gathered[0]).all())
+            del mods
+            torch.cuda.empty_cache()
 
     for i in range(args.warmup):
         latents = step(i, latents)
@@ -422,16 +632,21 @@ def main():
         dom = max(("gemm", "attention"), key=lambda k: prof[k]["ms"])
         gk = prof[dom]
         ach = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this command
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
-        if dom == "gemm" and args.workload == "flux" and os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        pmc_wan = os.path.join(ROOT, "profiles", "r01_pmc_attn_wan.json")
-        if dom == "attention" and args.workload == "wan" and os.path.exists(pmc_wan):
-            traffic = json.load(open(pmc_wan)).get("traffic_bytes_per_launch")
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pmc*.sh), which cannot run
+        # inside this process: the committed summary is used ONLY if it was taken from the kernel source this binary
+        # was built from (sha256 recorded next to it); otherwise null — never a stale constant.
+        traffic, traffic_src = None, None
+        src_file, pmc_file = (("gemm.hip", "r02_pmc_gemm.json") if dom == "gemm" else ("attention.hip", "r02_pmc_attn_wan.json"))
+        pmc = os.path.join(ROOT, "profiles", pmc_file)
+        if os.path.exists(pmc) and ((dom == "gemm" and args.workload == "flux") or (dom == "attention" and args.workload == "wan")):
+            import hashlib
+            rec = json.load(open(pmc))
+            with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
+                if rec.get("source_sha256") == hashlib.sha256(f.read()).hexdigest():
+                    traffic, traffic_src = rec.get("traffic_bytes_per_launch"), f"profiles/{pmc_file}"
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_c4_kernel",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                    "traffic": traffic, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
                     "launches_per_step": gk["launches"] / nprof,
                     "algorithmic_tflop_per_step": gk["flops"] / nprof / 1e12}
 
@@ -444,19 +659,24 @@ def main():
         full = not args.layers
         tf = STEP_TFLOP[args.workload]
         out = {
-            "metric": "denoise_steps_per_sec", "value": args.gpus * args.steps / elapsed, "unit": "steps/s",
+            "metric": "denoise_steps_per_sec", "value": world * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": label, "clips_in_flight": args.gpus, "parallelism": f"clip-per-gpu x{args.gpus}",
                        "step_tflop": tf if full else None},
+            "world": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
             "model_tflops_per_gpu": (tf / (ms_per_step * 1e-3)) if full else None,
             "mfma_utilisation_step": (tf / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS) if full else None,
             "sec_per_clip": clip["sec_per_clip"] if clip else None, "clip": clip,
             "finite": finite, "roofline": roofline, "kernels": kernels, "broadcast": bcast,
         }
-        if not args.no_cpu_baseline and args.gpus == 1 and args.workload == "flux":
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and args.gpus == 1 and args.workload in ("flux", "qwen", "wan"):
+            out["cpu_baseline"] = {"flux": cpu_baseline, "qwen": cpu_baseline_qwen, "wan": cpu_baseline_wan}[args.workload]()
+        if args.workload == "flux" and args.gpus == 1 and full and not args.no_wan:
+            del step, latents, clip_fn
+            torch.cuda.empty_cache()
+            out["wan"] = wan_half(dev)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

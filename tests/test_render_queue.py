@@ -66,3 +66,67 @@ def test_assign_clips_lpt():
     a = assign_clips([2, 2, 2, 2, 100, 100, 100, 100], 4)
     assert all(len(x) == 2 and sum(1 for i in x if i >= 4) == 1 for x in a)
     assert assign_clips([], 2) == [[], []]
+
+
+def _param_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    from apex_studio_amd import text_encoders as TE
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    # the shared components of a Flux queue at toy sizes: T5 (tied embedding), CLIP, 2-D VAE; constructed on every rank,
+    # filled on rank 0 only — the receivers start from garbage
+    t5 = TE.T5EncoderModel(dict(vocab_size=64, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2), dtype=torch.bfloat16)
+    clip = TE.CLIPTextModel(dict(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                 num_attention_heads=2, max_position_embeddings=16), dtype=torch.bfloat16)
+    vae = AutoencoderKL(latent_channels=16, block_out_channels=(32, 32, 64, 64), layers_per_block=1, dtype=torch.bfloat16)
+    mods = [t5, clip, vae]
+    g = torch.Generator().manual_seed(123)
+    for m in mods:
+        for p in m.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g).to(p.dtype) if rank == 0 else torch.full(p.shape, float("nan")).to(p.dtype))
+    vae._packed = {"stale": 1}                          # derived state on a receiver must be dropped
+    stats = rq.broadcast_parameters(mods, src=0, bucket_bytes=1 << 18)   # several buckets
+    g = torch.Generator().manual_seed(123)
+    ok = True
+    for m in mods:
+        for p in m.parameters():
+            ok = ok and torch.equal(p.data, torch.randn(p.shape, generator=g).to(p.dtype))
+    n_unique = len(rq.shared_tensors(mods))
+    q.put((rank, bool(ok), stats["bytes"], stats["buckets"], n_unique, dict(vae._packed)))
+    dist.destroy_process_group()
+
+
+def test_broadcast_parameters_world2():
+    """The queue's one exchange step with REAL module parameters (text encoders + VAE), world 2 over gloo."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_param_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, ok0, n0, b0, u0, packed0), (_, ok1, n1, b1, u1, packed1) = out
+    assert ok0 and ok1, "every parameter on every rank must equal rank 0's"
+    assert n0 == n1 > 0 and b0 == b1 > 1 and u0 == u1
+    assert packed0 == {"stale": 1} and packed1 == {}, "the receiver's packed-weight cache must be invalidated, the sender's kept"
+
+
+def test_bench_refuses_to_fake_multi_gpu():
+    """`python bench.py --gpus 2` must start 2 ranks or fail loudly — never one process reporting n_gpus 2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to run" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
