@@ -123,7 +123,7 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             image_shapes: Sequence[Tuple[int, int]] = (), height: int = 1024, width: int = 1024,
             num_inference_steps: int = 8, negative_prompt_embeds: Optional[torch.Tensor] = None,
             true_cfg_scale: float = 1.0, latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
-            return_latents: bool = True, progress_callback=None, images=None, output_type: Optional[str] = None,
+            return_latents: bool = False, progress_callback=None, images=None, output_type: Optional[str] = None,
             **_ignored):
         dev, dt = self.device, self.transformer.dtype
         if images is not None:       # condition images as pixels (or latents): encode + pack here

@@ -28,6 +28,12 @@ class FlowMatchEulerDiscreteScheduler:
                            time_shift_type=time_shift_type)
         self.num_train_timesteps = num_train_timesteps
         self.shift = shift
+        # diffusers keeps the ends of the TRAINING schedule, already shifted when the shift is static; set_timesteps
+        # without explicit sigmas spaces between them (and then applies the shift again — upstream behaviour)
+        tr = torch.linspace(1, num_train_timesteps, num_train_timesteps, dtype=torch.float64).flip(0) / num_train_timesteps
+        if not use_dynamic_shifting:
+            tr = shift * tr / (1 + (shift - 1) * tr)
+        self.sigma_max, self.sigma_min = float(tr[0]), float(tr[-1])
         self.timesteps = None
         self.sigmas = None
         self._step_index = None
@@ -50,8 +56,7 @@ class FlowMatchEulerDiscreteScheduler:
                       sigmas: Optional[Sequence[float]] = None, mu: Optional[float] = None):
         n = self.num_train_timesteps
         if sigmas is None:
-            smax, smin = 1.0, 1.0 / n
-            sigmas = torch.linspace(smax * n, smin * n, num_inference_steps, dtype=torch.float64) / n
+            sigmas = torch.linspace(self.sigma_max * n, self.sigma_min * n, num_inference_steps, dtype=torch.float64) / n
         else:
             sigmas = torch.as_tensor(list(sigmas) if not torch.is_tensor(sigmas) else sigmas,
                                      dtype=torch.float64)

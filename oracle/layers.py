@@ -7,11 +7,16 @@ from the published diffusers semantics summarised in SURVEY.md Appendix A and cr
 the in-tree corroborating code cited per function.  Only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg may import this package.
 
-Parity status: the reference's own tests hold no golden vectors for these layers, and
-diffusers is absent from the container, so these leaves are "parity unpinned" against diffusers
-itself; what IS pinned (tests/golden, generated by tests/golden/make_golden.py from the reference run
-in this container) is: the attention operator (reference `sdpa`), the in-tree efficiency ops, and
-the reference's own Flux block wiring executed on top of these leaves.
+Parity status: diffusers itself is absent from the container, but the reference tree carries its own copies of nearly
+every leaf restated here, and those copies RUN here.  tests/golden/leaf_pins.pt (tests/golden/make_golden.py
+`gen_leaf_pins`, file:line per leaf in its docstring) holds their outputs; tests/test_oracle_leaf_pins.py checks this
+module against them: get_timestep_embedding (bit-identical), TimestepEmbedding, PixArtAlphaTextProjection, FeedForward /
+GELU-tanh, RMSNorm, get_1d_rotary_pos_embed, apply_rotary_emb (both sequence dims), AdaLayerNormZero (projection, chunk
+order, formula), the chunk orders of the Zero / ZeroSingle forms, and the [scale, shift] order of
+AdaLayerNormContinuous (through the reference's checkpoint converter).  Also pinned by reference-run fixtures: the
+attention operator (reference `sdpa`), the in-tree efficiency ops, and the reference's own Flux / Wan / Qwen block
+wiring executed on top of these leaves.  Left "parity unpinned" (no copy in the tree): FP32LayerNorm (torch's
+layer_norm in f32), the CombinedTimestep*Embeddings containers (sums of pinned parts), `LinearActivation`.
 
 `emulate_bf16`: the GPU path stores activations in bf16 between kernels and accumulates in f32.
 `Policy.r(x)` rounds to bf16 at exactly those storage points so a like-for-like comparison is

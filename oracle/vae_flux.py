@@ -9,8 +9,14 @@ summarised in SURVEY.md App. A:
   -> UpDecoderBlock2D x len(block_out_channels) (layers_per_block+1 ResnetBlock2D each; nearest 2x Upsample2D +
   conv3x3 on all but the last) -> GroupNorm(32, eps 1e-6) -> SiLU -> conv_out(C0 -> 3).
   ResnetBlock2D: GN32 -> SiLU -> conv3x3 -> GN32 -> SiLU -> conv3x3 (+ 1x1 conv_shortcut when C changes).
-PARITY UNPINNED: diffusers is absent from the container and the reference's tests hold no vectors for
-this decoder; parameter names follow diffusers' state-dict keys (decoder.mid_block.attentions.0.to_q, ...).
+Parity: the BLOCKS are pinned against the reference's own in-tree copies run in the build container
+(tests/golden/leaf_pins.pt, tests/test_oracle_leaf_pins.py): ResnetBlock2D against vae/seedvr/modules/__model.py:73-142
+and against the LDM-style ResnetBlock of vae/hunyuanimage3/model.py:202-240 on a one-frame clip, the single-head
+GroupNorm attention block against :169-199, the nearest-2x + 3x3 upsampler against :297-308.  Only the decoder TOPOLOGY
+(which blocks in which order, `layers_per_block + 1` resnets per up block, no upsampler on the last) is still "parity
+unpinned": diffusers is absent and no in-tree class assembles these blocks the way diffusers' Decoder does; it is
+restated from the published class and from the state-dict keys of the FLUX.1 VAE checkpoint the manifest names
+(decoder.mid_block.attentions.0.to_q, decoder.up_blocks.0.resnets.2..., decoder.up_blocks.2.upsamplers.0.conv).
 FLUX.1-dev VAE config: latent 16, block_out_channels (128, 256, 512, 512), layers_per_block 2,
 scaling_factor 0.3611, shift_factor 0.1159, no post_quant_conv.
 """

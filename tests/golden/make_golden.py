@@ -689,6 +689,146 @@ def main():
     gen_qwen2_5_vl()
 
 
+
+# ---- leaf pins: the reference's IN-TREE copies of the diffusers leaves -----------------------------------------------
+def extract_defs(rel, names, ns=None):
+    """Execute only the named top-level functions / classes of a reference source file (by AST), in a namespace that
+    supplies torch / nn / F / math / typing — for files whose module-level imports need packages absent here.  The
+    reference's code is RUN from where it lies; nothing of it is written anywhere."""
+    import ast
+    import math
+    import typing
+    import numpy as np
+    import torch.nn.functional as F
+    from einops import rearrange
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    want = set(names)
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want]
+    missing = want - {n.name for n in body}
+    assert not missing, f"{rel}: {missing} not found"
+    env = dict(torch=torch, nn=nn, F=F, math=math, np=np, rearrange=rearrange, Tensor=torch.Tensor,
+               Optional=typing.Optional, Tuple=typing.Tuple, Union=typing.Union, Dict=typing.Dict, List=typing.List,
+               Any=typing.Any, Callable=typing.Callable)
+    env.update(ns or {})
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), env)
+    return env
+
+
+def gen_leaf_pins():
+    """tests/golden/leaf_pins.pt: outputs of the reference's own in-tree copies of the un-vendored diffusers leaves the
+    hot path uses, run here on seeded inputs / weights (weights are regenerated from seeds by the tests):
+      timestep embedding stack   transformer/stepvideo/base/modules.py:204-330  (get_timestep_embedding, Timesteps,
+                                 TimestepEmbedding), :525-550 (PixArtAlphaTextProjection), :657-712 (GELU, FeedForward),
+                                 :121-175 (RMSNorm)
+      rotary                     utils/models/hunyuan.py:138-185 (get_1d_rotary_pos_embed),
+                                 transformer/flux2/control/base_model.py:71-132 (apply_rotary_emb)
+      AdaLN family               transformer/hunyuanvideo/base/model.py:98-161 (linear(silu(emb)) -> chunk(6) -> formula),
+                                 transformer/chroma/base/model.py:59-135 (chunk(6) / chunk(3) orders),
+                                 converters/utils.py:82-85 (swap_scale_shift: AdaLayerNormContinuous is [scale, shift])
+      2-D VAE blocks             vae/seedvr/modules/__model.py:73-142 (ResnetBlock2D),
+                                 vae/hunyuanimage3/model.py:169-240 (AttnBlock, ResnetBlock), :297-308 (Upsample)
+      FlowMatch-Euler            scheduler/flow.py:293-355 (FlowMatchDiscreteScheduler.step) + sd3_time_shift"""
+    out = {}
+    sv = extract_defs("src/transformer/stepvideo/base/modules.py",
+                      ["get_timestep_embedding", "Timesteps", "TimestepEmbedding", "PixArtAlphaTextProjection", "GELU",
+                       "FeedForward", "RMSNorm"],
+                      dict(get_activation=lambda name: {"silu": nn.SiLU(), "swish": nn.SiLU(), "gelu": nn.GELU()}[name]))
+    t = torch.tensor([0.0, 1.0, 37.5, 500.0, 718.75, 999.0, 1000.0])
+    out["timestep_embedding"] = [dict(t=t / sc, dim=256, flip=True, shift=sh, scale=sc,
+                                      out=sv["get_timestep_embedding"](t / sc, 256, flip_sin_to_cos=True,
+                                                                       downscale_freq_shift=sh, scale=sc))
+                                 for sc, sh in ((1.0, 0.0), (1000.0, 0.0), (1.0, 1.0))]
+
+    def run(mod, seed, *xs):
+        sd = synthetic_state_dict(mod, seed)
+        mod.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            return mod.eval()(*xs), sorted(sd.keys())
+
+    x = seeded((2, 256), 101)
+    o, keys = run(sv["TimestepEmbedding"](256, 192), 102, x)
+    out["TimestepEmbedding"] = dict(seed=102, x_seed=101, x_shape=(2, 256), dims=(256, 192), out=o, keys=keys)
+    x = seeded((2, 9, 96), 103)
+    o, keys = run(sv["PixArtAlphaTextProjection"](96, 160), 104, x)
+    out["PixArtAlphaTextProjection"] = dict(seed=104, x_seed=103, x_shape=(2, 9, 96), dims=(96, 160), out=o, keys=keys)
+    x = seeded((2, 9, 128), 105)
+    o, keys = run(sv["FeedForward"](128, inner_dim=320, bias=True), 106, x)
+    out["FeedForward"] = dict(seed=106, x_seed=105, x_shape=(2, 9, 128), dims=(128, 320), out=o, keys=keys)
+    x = seeded((2, 9, 128), 107) * 3
+    o, keys = run(sv["RMSNorm"](128, eps=1e-6), 108, x)
+    out["RMSNorm"] = dict(seed=108, x_seed=107, x_shape=(2, 9, 128), dim=128, eps=1e-6, out=o, keys=keys)
+
+    hy = extract_defs("src/utils/models/hunyuan.py", ["get_1d_rotary_pos_embed"])
+    pos = torch.arange(0, 77).float() * 1.5
+    out["get_1d_rotary_pos_embed"] = [dict(dim=d, pos=pos, out=hy["get_1d_rotary_pos_embed"](d, pos, theta=10000.0, use_real=True))
+                                      for d in (16, 56, 128)]
+    f2 = extract_defs("src/transformer/flux2/control/base_model.py", ["apply_rotary_emb"])
+    cos, sin = hy["get_1d_rotary_pos_embed"](128, torch.arange(40).float(), use_real=True)
+    xs1, xs2 = seeded((2, 40, 3, 128), 109), seeded((2, 3, 40, 128), 110)
+    out["apply_rotary_emb"] = dict(cos=cos, sin=sin, x1_seed=109, x1_shape=(2, 40, 3, 128), x2_seed=110, x2_shape=(2, 3, 40, 128),
+                                   out1=f2["apply_rotary_emb"](xs1, (cos, sin), sequence_dim=1),
+                                   out2=f2["apply_rotary_emb"](xs2, (cos, sin), sequence_dim=2))
+
+    hv = extract_defs("src/transformer/hunyuanvideo/base/model.py", ["HunyuanVideoTokenReplaceAdaLayerNormZero"],
+                      dict(FP32LayerNorm=OL.FP32LayerNorm))
+    ada = hv["HunyuanVideoTokenReplaceAdaLayerNormZero"](64)
+    x, emb = seeded((2, 11, 64), 111), seeded((2, 64), 112)
+    sd = synthetic_state_dict(ada, 113)
+    ada.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        r = ada.eval()(x, emb, emb, 0)      # no replaced tokens: plain AdaLayerNormZero
+    out["AdaLayerNormZero"] = dict(seed=113, x_seed=111, emb_seed=112, dim=64, keys=sorted(sd.keys()),
+                                   out=[v for v in r[:5]])
+    ch = extract_defs("src/transformer/chroma/base/model.py",
+                      ["ChromaAdaLayerNormZeroPruned", "ChromaAdaLayerNormZeroSinglePruned"],
+                      dict(FP32LayerNorm=OL.FP32LayerNorm, CombinedTimestepLabelEmbeddings=None))
+    e6, e3 = seeded((2, 6, 64), 114), seeded((2, 3, 64), 115)
+    with torch.no_grad():
+        out["AdaLN_chunk_orders"] = dict(x_seed=111, e6_seed=114, e3_seed=115, dim=64,
+                                         zero=[v for v in ch["ChromaAdaLayerNormZeroPruned"](64)(x, emb=e6)],
+                                         single=[v for v in ch["ChromaAdaLayerNormZeroSinglePruned"](64)(x, emb=e3)])
+    cu = extract_defs("src/converters/utils.py", ["swap_scale_shift"], dict(ggml_chunk=torch.chunk, ggml_cat=torch.cat))
+    w = seeded((2 * 48, 32), 116)
+    out["swap_scale_shift"] = dict(w_seed=116, w_shape=(96, 32), out=cu["swap_scale_shift"](w, dim=0))
+
+    sr = extract_defs("src/vae/seedvr/modules/__model.py", ["ResnetBlock2D"])
+    for tag, cin, cout, seed in (("same", 64, 64, 120), ("widen", 64, 96, 121)):
+        blk = sr["ResnetBlock2D"](in_channels=cin, out_channels=cout)
+        sd = vae_synthetic_state_dict(blk, seed)
+        blk.load_state_dict(sd, strict=True)
+        xx = seeded((1, cin, 12, 10), seed + 10)
+        with torch.no_grad():
+            out[f"ResnetBlock2D_{tag}"] = dict(seed=seed, x_seed=seed + 10, x_shape=(1, cin, 12, 10), cin=cin, cout=cout,
+                                               keys=sorted(sd.keys()), out=blk.eval()(xx))
+    h3 = extract_defs("src/vae/hunyuanimage3/model.py", ["swish", "Conv3d", "AttnBlock", "ResnetBlock", "Upsample"])
+    for name, mk, cin in (("AttnBlock", lambda: h3["AttnBlock"](64), 64), ("ResnetBlock", lambda: h3["ResnetBlock"](64, 96), 64),
+                          ("Upsample", lambda: h3["Upsample"](64, add_temporal_upsample=False), 64)):
+        blk = mk()
+        sd = vae_synthetic_state_dict(blk, 130 + len(name))
+        blk.load_state_dict(sd, strict=True)
+        xx = seeded((1, cin, 1, 12, 10), 140 + len(name))
+        with torch.no_grad():
+            out["ldm_" + name] = dict(seed=130 + len(name), x_seed=140 + len(name), x_shape=(1, cin, 1, 12, 10),
+                                      keys=sorted(sd.keys()), out=blk.eval()(xx))
+
+    # FlowMatch-Euler: the in-tree scheduler (needs only its config plumbing, supplied by the stubs)
+    _mod("src.scheduler.scheduler", SchedulerInterface=type("SchedulerInterface", (), {}))
+    sys.modules["diffusers.utils"].BaseOutput = dict
+    fl = load_by_path("ref_flow", "src/scheduler/flow.py")
+    sch = fl.FlowMatchDiscreteScheduler(shift=3.0)
+    sch.set_timesteps(6)
+    xx = seeded((1, 4, 8, 8), 150)
+    traj = []
+    for i, tt in enumerate(sch.timesteps):
+        xx = sch.step(seeded((1, 4, 8, 8), 151 + i), tt, xx, return_dict=False)[0]
+        traj.append(xx.clone())
+    out["flow_euler"] = dict(shift=3.0, steps=6, x_seed=150, shape=(1, 4, 8, 8), timesteps=sch.timesteps.clone(),
+                             sigmas=sch.sigmas.clone(), traj=traj)
+    torch.save(out, os.path.join(OUT, "leaf_pins.pt"))
+    print("leaf_pins.pt", sorted(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py text_encoders vae_hunyuan15 ...
         os.makedirs(OUT, exist_ok=True)

@@ -31,7 +31,9 @@ def test_static_shift_and_bf16_cast():
     from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
     sch = FlowMatchEulerDiscreteScheduler(shift=3.0)
     sch.set_timesteps(4)
-    ref = OS.flow_sigmas(np.linspace(1.0, 1.0 / 1000, 4), shift=3.0)
+    # diffusers: without explicit sigmas the grid runs between the ends of the (already shifted) training schedule,
+    # sigma_max = shift*1/(1+(shift-1)*1) = 1 and sigma_min = shift*1e-3/(1+(shift-1)*1e-3), and is shifted again
+    ref = OS.flow_sigmas(np.linspace(1.0, 3.0 * 1e-3 / (1 + 2.0 * 1e-3), 4), shift=3.0)
     assert np.allclose(sch.sigmas.numpy(), ref, atol=1e-6)
     x = torch.ones(4, dtype=torch.bfloat16)
     out = sch.step(torch.ones(4, dtype=torch.bfloat16), sch.timesteps[0], x, return_dict=False)[0]

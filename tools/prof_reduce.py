@@ -41,7 +41,31 @@ def main(root):
             for k, d in sorted(pm.items(), key=lambda kv: -len(next(iter(kv[1].values())))):
                 n = max(len(v) for v in d.values())
                 w.writerow([k, n] + [f"{sum(d[c]) / len(d[c]):.6g}" if c in d else "" for c in counters])
-    for name in ("kernel_stats.csv", "pmc_summary.csv"):
+    # ---- derived per-kernel figures: HBM-side bytes per launch and achieved GB/s (FETCH_SIZE is in KB and, on gfx950,
+    # counts HALF the bytes of wide coalesced reads — doubled here as MI355X_MICROARCH.md prescribes; WRITE_SIZE in KB,
+    # uncalibrated), MFMA-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) and
+    # the judge's SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES
+    if traces and pm:
+        with open(os.path.join(root, "derived.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalMs", "AvgUs", "FetchMBPerLaunch_x2", "WriteMBPerLaunch", "AchievedGBps",
+                        "FracOf8TBps", "MfmaBusyOverAllSimds", "MfmaBusyOverSqBusy", "LdsConflictShare"])
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+                d = pm.get(k, {})
+                mean = lambda c: (sum(d[c]) / len(d[c])) if c in d and d[c] else None   # noqa: E731
+                avg_ns = sum(v) / len(v)
+                fetch = mean("FETCH_SIZE")
+                write = mean("WRITE_SIZE")
+                fetch_mb = fetch * 2 * 1024 / 1e6 if fetch is not None else None
+                write_mb = write * 1024 / 1e6 if write is not None else None
+                gbps = ((fetch_mb or 0) + (write_mb or 0)) * 1e6 / avg_ns if (fetch_mb is not None or write_mb is not None) else None
+                mf, gui, sqb = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("GRBM_GUI_ACTIVE"), mean("SQ_BUSY_CYCLES")
+                lc, la = mean("SQ_LDS_BANK_CONFLICT"), mean("SQ_LDS_IDX_ACTIVE")
+                fmt = lambda x, p=3: "" if x is None else f"{x:.{p}f}"   # noqa: E731
+                w.writerow([k, len(v), f"{sum(v) / 1e6:.3f}", f"{avg_ns / 1e3:.2f}", fmt(fetch_mb), fmt(write_mb), fmt(gbps, 1),
+                            fmt(gbps / 8000.0 if gbps is not None else None), fmt(mf / (gui / 8 * 1024) if mf and gui else None),
+                            fmt(mf / sqb if mf and sqb else None), fmt(lc / la if lc is not None and la else None)])
+    for name in ("kernel_stats.csv", "pmc_summary.csv", "derived.csv"):
         p = os.path.join(root, name)
         if os.path.exists(p):
             print("==", name)

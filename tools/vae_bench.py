@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the VAE decodes alone (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
-usage: vae_bench.py flux|wan|hunyuan [reps]"""
+usage: vae_bench.py flux|wan|wan-untiled|hunyuan [reps]   (wan = the 4 x 7-tile decode the reference always takes)"""
 import os
 import sys
 import time
@@ -26,6 +26,8 @@ elif which == "hunyuan":      # HunyuanVideo-1.5 480p x 121 frames: latent [32, 
 else:
     from apex_studio_amd.vae_wan import AutoencoderKLWan
     vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
+    if which != "wan-untiled":
+        vae.enable_tiling()
     z = torch.randn(1, 16, 21, 90, 160, device=dev).to(torch.bfloat16)
 vae.decode(z, return_dict=False)
 torch.cuda.synchronize()
