@@ -1,0 +1,189 @@
+"""Full-size evidence for BASELINE.json configs 1, 4 and 5 on the HIP path (the other GPU tests use reduced sequences).
+
+  config 4  Wan-2.2 720p x 81 frames: self-attention at [1, 40, 75600, 128] and cross-attention over 512 text keys
+            (reference transformer/wan/base/attention.py:397-399) — row-stochasticity, determinism, and 64 sampled query
+            rows of every head against the oracle evaluated with the kernel's rounding points; the tiled 3-D VAE decode of
+            [1, 16, 21, 90, 160] -> [1, 3, 81, 720, 1280] (reference vae/wan/model.py:1516-1623: 4 x 7 tiles of 32 x 32
+            latents, stride 24) — shape, range, determinism, and an interior tile region equal to a stand-alone decode
+            of that latent tile (tiles see zero padding at their own borders, so this is the tiling contract).
+  config 1  Flux-Dev 512 x 512, 4 steps: the geometry of the reference's CPU-runnable case (S_img 1024 + S_txt 512) on
+            the HIP engine — full depth for shape / finiteness / determinism, depth 1 + 1 at full width against the
+            oracle's 4-step loop.
+  config 5  the render queue on ONE GPU (`render_queue.run_queue`, world 1) with both families at their full geometry
+            and shortened clips: every clip rendered once, per-clip seconds and makespan reported.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import layers as OL
+from tests.golden.seeded import seeded, synthetic_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _randn(shape, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(shape, generator=g, device=DEV).to(BF)
+
+
+@pytest.mark.parametrize("Sk", [75600, 512])
+def test_wan_attention_full_size(Sk):
+    from apex_studio_amd import ops
+    H, Sq = 40, 75600
+    q, k, v = _randn((1, H, Sq, 128), 1), _randn((1, H, Sk, 128), 2), _randn((1, H, Sk, 128), 3)
+    ones = torch.ones_like(v)
+    out1 = ops.attention(q, k, ones)
+    assert float((out1.float() - 1).abs().max()) <= 8e-3, "softmax rows must sum to one (V = 1 -> out = 1)"
+    del out1, ones
+    out = ops.attention(q, k, v)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(ops.attention(q, k, v), out), "attention must be deterministic"
+    rows = torch.arange(64, device=DEV) * 1181 + 7                    # 64 query rows spread over the 296 query blocks
+    assert int(rows.max()) < Sq
+    ref = OL.sdpa(q[:, :, rows].cpu().float(), k.cpu().float(), v.cpu().float(), policy=OL.BF16_STORAGE)
+    got = out[:, :, rows].float().cpu()
+    ref = ref.to(BF).float()
+    rel = _rel(got, ref)
+    nd = int((got != ref).sum())
+    print(f"[full size] attention [1,40,75600,128] x {Sk} keys: 64 sampled rows x 40 heads vs the oracle (kernel rounding "
+          f"points): rel L2 {rel:.2e}, {nd}/{ref.numel()} elements differ")
+    assert rel <= 5e-4, rel
+
+
+def test_wan_vae_decode_720p_81_frames():
+    sys.path.insert(0, ROOT)
+    from bench import synth_vae_init
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vae = synth_vae_init(AutoencoderKLWan(device=DEV, dtype=BF), 6)
+    vae.enable_tiling()                                               # what the reference engine always does
+    z = _randn((1, 16, 21, 90, 160), 11)
+    out = vae.decode(z, return_dict=False)[0]
+    assert out.shape == (1, 3, 81, 720, 1280) and out.dtype == BF
+    assert torch.isfinite(out.float()).all() and float(out.float().abs().max()) <= 1.0
+    assert float(out.float().std()) > 1e-3, "degenerate decode"
+    assert torch.equal(vae.decode(z, return_dict=False)[0], out), "the decode must be deterministic"
+    # tile (1, 2) of the 4 x 7 grid: latent rows 24..56, columns 48..80.  Of its 256 x 256 output pixels the first 64
+    # rows / columns are cross-faded with the previous tiles and only the first 192 are kept, so rows / columns
+    # 64..192 of the tile are exactly the stand-alone decode of that latent tile.
+    i, j = 1, 2
+    tile = vae.decode(z[:, :, :, 24 * i:24 * i + 32, 24 * j:24 * j + 32].contiguous(), return_dict=False)[0]
+    assert tile.shape == (1, 3, 81, 256, 256)
+    a = out[:, :, :, 192 * i + 64:192 * i + 192, 192 * j + 64:192 * j + 192]
+    b = tile[:, :, :, 64:192, 64:192]
+    nd = int((a != b).sum())
+    print(f"[full size] wan 720p x 81f tiled decode: interior of tile ({i},{j}) vs the stand-alone decode of its latent tile: "
+          f"{nd}/{a.numel()} samples differ, max |diff| {float((a.float() - b.float()).abs().max()):.3e}")
+    assert torch.equal(a, b), "tiling contract: a tile's interior is the stand-alone decode of its latents"
+    from apex_studio_amd.postprocess import tensor_to_frames
+    frames = tensor_to_frames(out, "uint8")
+    assert frames.shape == (1, 81, 720, 1280, 3) and frames.dtype == torch.uint8
+
+
+FLUX_FULL = dict(patch_size=1, in_channels=64, attention_head_dim=128, num_attention_heads=24, joint_attention_dim=4096,
+                 pooled_projection_dim=768, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+
+
+def test_flux_512_four_steps_full_depth():
+    """BASELINE configs[0] geometry on the HIP engine at full depth (19 + 38 blocks): shape, range, determinism."""
+    sys.path.insert(0, ROOT)
+    from bench import synth_vae_init
+    from apex_studio_amd.engine_flux import FluxT2IEngine
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    m = FluxTransformer2DModel(**FLUX_FULL, num_layers=19, num_single_layers=38, device=DEV, dtype=BF).init_synthetic(3)
+    vae = synth_vae_init(AutoencoderKL(device=DEV, dtype=BF), 5)
+    eng = FluxT2IEngine(m, decode_fn=lambda z: vae.decode(vae.denormalize_latents(z.float()).to(BF), return_dict=False)[0])
+    enc, pooled = _randn((1, 512, 4096), 21), _randn((1, 768), 22)
+    kw = dict(prompt_embeds=enc, pooled_prompt_embeds=pooled, height=512, width=512, num_inference_steps=4, seed=5)
+    lat = eng.run(return_latents=True, **kw)
+    assert lat.shape == (1, 1024, 64) and torch.isfinite(lat.float()).all()
+    img = eng.run(**kw)
+    assert img.shape == (1, 3, 512, 512) and torch.isfinite(img.float()).all()
+    assert torch.equal(eng.run(return_latents=True, **kw), lat), "the 4-step loop must be deterministic"
+    frames = eng.run(output_type="np", **kw)
+    assert frames.shape == (1, 512, 512, 3) and frames.dtype.name == "uint8"
+
+
+def test_flux_512_four_steps_vs_oracle_loop(host_threads):
+    """The same geometry (S_img 1024 + S_txt 512, d 3072) at depth 1 + 1 against the oracle's 4-step Euler loop."""
+    from apex_studio_amd.engine_flux import FluxT2IEngine, pack_latents
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    cfg = dict(FLUX_FULL, num_layers=1, num_single_layers=1)
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=BF)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    lat0 = pack_latents(seeded((1, 16, 64, 64), 31).to(BF))
+    enc, pooled = seeded((1, 512, 4096), 32).to(BF), seeded((1, 768), 33).to(BF)
+    eng = FluxT2IEngine(m)
+    lat_hip = eng.run(enc.to(DEV), pooled.to(DEV), height=512, width=512, num_inference_steps=4, guidance_scale=4.0,
+                      latents=lat0.to(DEV), return_latents=True)
+    sch = FlowMatchEulerDiscreteScheduler.flux_dev()
+    ts = sch.set_timesteps(sigmas=torch.linspace(1.0, 0.25, 4).tolist(), mu=OF.calculate_shift(1024))
+    assert abs(OF.calculate_shift(1024) - 0.63) < 0.01            # mu = 0.63 at 512^2
+    sch.set_begin_index(0)
+    lat = lat0.clone()
+    img_ids, txt_ids, g = OF.latent_image_ids(32, 32), torch.zeros(512, 3), torch.full([1], 4.0)
+    for t in ts:
+        tt = (t.expand(1).to(BF) / 1000).float()
+        v = orc(lat.float(), enc.float(), pooled.float(), tt, img_ids, txt_ids, g, policy=OL.BF16_STORAGE)
+        lat = sch.step(v.to(BF), t, lat, return_dict=False)[0]
+    rel = _rel(lat_hip, lat)
+    print(f"[full size] flux 512^2, 4 Euler steps, depth 1+1 at full width: latents vs the oracle loop rel L2 {rel:.2e}")
+    assert rel < 6e-3, rel       # free-running bf16 chain: the noise floor (tests/stage_parity.py)
+
+
+def test_render_queue_on_one_gpu():
+    """config 5's machinery at world 1: both engines at full geometry (Flux 1024^2, Wan 720p x 81 f) with the depth and the
+    step counts cut so the test stays short; LPT order, every clip once, timings reported."""
+    sys.path.insert(0, ROOT)
+    from bench import synth_vae_init
+    from apex_studio_amd import render_queue
+    from apex_studio_amd.engine_flux import FluxT2IEngine
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.vae_flux import AutoencoderKL
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from apex_studio_amd.wan import WanTransformer3DModel
+    fm = FluxTransformer2DModel(**FLUX_FULL, num_layers=2, num_single_layers=2, device=DEV, dtype=BF).init_synthetic(1)
+    fvae = synth_vae_init(AutoencoderKL(device=DEV, dtype=BF), 5)
+    flux = FluxT2IEngine(fm, decode_fn=lambda z: fvae.decode(fvae.denormalize_latents(z.float()).to(BF), return_dict=False)[0])
+    hi = WanTransformer3DModel(num_layers=1, device=DEV, dtype=BF).init_synthetic(2)
+    lo = WanTransformer3DModel(num_layers=1, device=DEV, dtype=BF).init_synthetic(3)
+    wan = WanT2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=DEV, dtype=BF), 6))
+    f_enc, f_pool, w_enc = _randn((1, 512, 4096), 41), _randn((1, 768), 42), _randn((1, 512, 4096), 43)
+    done = []
+
+    def runner(c):
+        if c["kind"] == "flux":
+            out = flux.run(prompt_embeds=f_enc, pooled_prompt_embeds=f_pool, height=1024, width=1024,
+                           num_inference_steps=2, seed=c["seed"], output_type="uint8")
+            assert out.shape == (1, 1024, 1024, 3)
+        else:
+            out = wan.run(prompt_embeds=w_enc, height=720, width=1280, duration=81, num_inference_steps=2,
+                          seed=c["seed"], output_type="uint8")
+            assert out.shape == (1, 81, 720, 1280, 3)
+        done.append(c["id"])
+
+    clips = [{"id": i, "kind": "flux", "seed": i, "cost": 1.0} for i in range(2)] + \
+            [{"id": 2 + i, "kind": "wan", "seed": 10 + i, "cost": 10.0} for i in range(2)]
+    res = render_queue.run_queue(clips, runner)
+    assert sorted(done) == [0, 1, 2, 3] and done[:2] == [2, 3], "longest clips first, every clip exactly once"
+    assert sorted(res["clip_seconds"]) == [0, 1, 2, 3] and res["makespan"] >= max(res["clip_seconds"].values())
+    print(f"[full size] 1-GPU queue (2 flux 1024^2 + 2 wan 720p x 81f clips, reduced depth, 2 steps): per-clip s "
+          f"{ {k: round(v, 2) for k, v in res['clip_seconds'].items()} }, makespan {res['makespan']:.2f} s, "
+          f"{res['clips_per_hour']:.0f} clips/h")
