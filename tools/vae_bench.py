@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Time the VAE decodes alone (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
-usage: vae_bench.py flux|wan|wan-untiled|hunyuan [reps]   (wan = the 4 x 7-tile decode the reference always takes)"""
+usage: vae_bench.py flux|wan|wan-untiled|wan-tile|hunyuan [reps]   (wan = the 4 x 7-tile decode the reference always
+takes; wan-tile = ONE of its 28 tiles, [1,16,21,32,32] -> [1,3,81,256,256]: same launches, short enough for --pmc passes)"""
 import os
 import sys
 import time
@@ -29,6 +30,8 @@ else:
     if which != "wan-untiled":
         vae.enable_tiling()
     z = torch.randn(1, 16, 21, 90, 160, device=dev).to(torch.bfloat16)
+    if which == "wan-tile":
+        z = z[:, :, :, :32, :32].contiguous()
 vae.decode(z, return_dict=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
