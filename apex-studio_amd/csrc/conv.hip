@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict
 // combine into per-group mean / rstd, and the apply (+ affine, + optional SiLU).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
                                                          int64_t P, int C, int rows_per_block) {
-    __shared__ float red[256][16];
+    __shared__ float red[16][256];           // [statistic][thread]: lane-contiguous, no bank conflicts either way
     const int ncol = C >> 3;                 // 16-byte chunks per position (<= 64)
     const int col = threadIdx.x % ncol, r0 = threadIdx.x / ncol, rstep = 256 / ncol;
     const int64_t p0 = (int64_t)blockIdx.x * rows_per_block;
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        red[threadIdx.x][j] = s[j];
-        red[threadIdx.x][8 + j] = q[j];
+        red[j][threadIdx.x] = s[j];
+        red[8 + j][threadIdx.x] = q[j];
     }
     __syncthreads();
     if (threadIdx.x < ncol) {                // fixed-order sum over the threads of this column
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
         for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
         for (int t = threadIdx.x; t < rstep * ncol; t += ncol)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += red[t][j];
+            for (int j = 0; j < 16; ++j) acc[j] += red[j][t];
         float* o = part + ((int64_t)blockIdx.x * C + threadIdx.x * 8) * 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

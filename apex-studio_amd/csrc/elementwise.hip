@@ -353,7 +353,10 @@ APEXMI_DEVICE void qk_norm_rope4_body(
 // ------------------------------------------------------------------------------------------------
 APEXMI_DEVICE void v_transpose_body(int bx, int by, const bf16_t* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
                                     int D, bf16_t* __restrict__ vt, int Skp, int col0) {
-    constexpr int LDW = 136;  // padded LDS row (elements)
+    // Row r = 8 sc + j of the tile is stored ROTATED by 8 sc elements (16 bytes x sc): in the transposed read the 8
+    // lanes of one 128-byte output segment (sc = 0..7, same j, same d) then hit 8 different bank groups instead of
+    // one (row stride 64 dwords = 0 mod 32 banks; PMC: SQ_LDS_BANK_CONFLICT was 80 % of SQ_LDS_IDX_ACTIVE before).
+    constexpr int LDW = 128;
     __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDW];
     const int tid = threadIdx.x;
     const int s0 = bx * 64, h = by;
@@ -363,7 +366,7 @@ APEXMI_DEVICE void v_transpose_body(int bx, int by, const bf16_t* __restrict__ v
         const int r = idx >> 4, dc = idx & 15;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (s0 + r < S) val = *(const u32x4*)(v + (int64_t)h * v_sh + (int64_t)(s0 + r) * v_ss + dc * 8);
-        *(u32x4*)(tile + r * LDW + dc * 8) = val;
+        *(u32x4*)(tile + r * LDW + (((dc + (r >> 3)) & 15) << 3)) = val;
     }
     __syncthreads();
 #pragma unroll
@@ -372,7 +375,7 @@ APEXMI_DEVICE void v_transpose_body(int bx, int by, const bf16_t* __restrict__ v
         const int d = idx >> 3, sc = idx & 7;
         bf16_t e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = tile[(sc * 8 + j) * LDW + d];
+        for (int j = 0; j < 8; ++j) e[j] = tile[(sc * 8 + j) * LDW + ((d + 8 * sc) & 127)];
         u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
@@ -951,6 +954,26 @@ extern "C" int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v,
     hipLaunchKernelGGL(add_rowvec_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        ldx, (const bf16_t*)v, (bf16_t*)out, ldo, rows, cols);
     return apexmi_check_launch("add_rowvec_bf16");
+}
+
+__global__ __launch_bounds__(256) void group_mean_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                              int64_t n, int gs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one output element: position * C + channel
+    if (i >= n) return;
+    const bf16_t* p = x + i * gs;
+    float s = 0.0f;
+    for (int g = 0; g < gs; ++g) s += bf16_to_f32(p[g]);
+    out[i] = f32_to_bf16(s / (float)gs);
+}
+
+extern "C" int apexmi_group_mean_bf16(const void* x, void* out, int64_t P, int C, int gs, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out && P > 0 && C > 0 && gs >= 1 && gs <= 64, "group_mean_bf16: bad arguments (gs=%d)", gs);
+    const int64_t n = P * C;
+    ApexmiProfScope prof(5, stream, 0.0, 2.0 * n * (gs + 1));
+    hipLaunchKernelGGL(group_mean_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)out, n, gs);
+    return apexmi_check_launch("group_mean_bf16");
 }
 
 extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {

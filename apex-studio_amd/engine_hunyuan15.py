@@ -1,9 +1,14 @@
-"""HunyuanVideo-1.5 text-to-video sampler loop (stays in Python) — mirrors the reference engine
+"""HunyuanVideo-1.5 text-to-video and image-to-video sampler loops (stay in Python) — mirrors the reference engine
 (`apps/api/src/engine/hunyuanvideo15/t2v.py:107-361`): latents [B, 32, F, H/16, W/16], the transformer input is
 `cat([latents, cond_latents (zeros), mask (zeros)], dim=1)` (65 channels, :20-42, :238-241), the timestep goes in as
 `t.expand(B).to(latents.dtype)` on the 0-1000 scale (:243-245), manual CFG with optional std rescale (:248-306),
 FlowMatch-Euler step, progress protocol 0.45 -> [0.50, 0.90] -> decode.  Prompt embeddings (MLLM + ByT5, with their
 masks) are inputs: the text encoders are outside this backend's scope.
+
+`HunyuanVideo15I2VEngine` mirrors `engine/hunyuanvideo15/i2v.py:14-407`: the first frame is VAE-encoded (posterior mode,
+normalised; `_get_image_latents`, shared/__init__.py:285-299 -> BaseEngine.vae_encode, base_engine.py:2061-2165), the
+condition latents are that frame followed by zeros and the mask is one on the first latent frame (i2v.py:20-58); the
+SigLIP image embeddings (`encode_image`, shared :325-341) are an input like the prompt embeddings.
 """
 from __future__ import annotations
 
@@ -48,15 +53,14 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         self.vae.enable_tiling()
         return self.vae.decode(z, return_dict=False)[0]
 
-    @staticmethod
-    def prepare_cond_latents_and_mask(latents, dtype, device):
+    def prepare_cond_latents_and_mask(self, latents, dtype, device, image=None):
         b, c, f, h, w = latents.shape
         return (torch.zeros(b, c, f, h, w, dtype=dtype, device=device), torch.zeros(b, 1, f, h, w, dtype=dtype, device=device))
 
     def denoise(self, latents, timesteps, cond, uncond=None, guidance_scale: float = 6.0, guidance_rescale: float = 0.0,
-                image_embeds=None, denoise_progress_callback=None):
+                image_embeds=None, denoise_progress_callback=None, image=None):
         dt = self.transformer.dtype
-        cond_latents, mask = self.prepare_cond_latents_and_mask(latents, dt, latents.device)
+        cond_latents, mask = self.prepare_cond_latents_and_mask(latents, dt, latents.device, image=image)
         n = len(timesteps)
         for i, t in enumerate(timesteps):
             x = torch.cat([latents.to(dt), cond_latents, mask], dim=1)
@@ -87,7 +91,8 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             negative_prompt_embeds_mask_2=None, height: int = 480, width: int = 832, num_frames: int = 121,
             num_inference_steps: int = 50, guidance_scale: float = 6.0, guidance_rescale: float = 0.0, sigmas=None,
             seed: Optional[int] = None, generator: Optional[torch.Generator] = None, latents=None,
-            return_latents: bool = False, progress_callback=None, output_type: Optional[str] = None, **_ignored):
+            return_latents: bool = False, progress_callback=None, output_type: Optional[str] = None, image=None,
+            image_embeds=None, **_ignored):
         dev, dt = self.device, self.transformer.dtype
         B = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
@@ -108,7 +113,12 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             latents = torch.randn(shape, generator=generator, device=generator.device, dtype=torch.float32).to(dev, dt)
         else:
             latents = latents.to(dev, dt)
-        image_embeds = torch.zeros(B, self.vision_num_semantic_tokens, self.vision_states_dim, dtype=dt, device=dev)
+        if image_embeds is None:      # t2v.py:181-187: zero vision states when there is no reference image
+            image_embeds = torch.zeros(B, self.vision_num_semantic_tokens, self.vision_states_dim, dtype=dt, device=dev)
+        else:
+            image_embeds = image_embeds.to(dev, dt)
+            if image_embeds.shape[0] != B:
+                image_embeds = image_embeds.repeat(B // image_embeds.shape[0], 1, 1)
         cond = dict(encoder_hidden_states=prompt_embeds.to(dev, dt), encoder_attention_mask=prompt_embeds_mask.to(dev),
                     encoder_hidden_states_2=prompt_embeds_2.to(dev, dt), encoder_attention_mask_2=prompt_embeds_mask_2.to(dev))
         uncond = None
@@ -122,7 +132,8 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         def mapped(p, msg):
             _emit(progress_callback, 0.50 + 0.40 * p, msg)
 
-        latents = self.denoise(latents, timesteps, cond, uncond, guidance_scale, guidance_rescale, image_embeds, mapped)
+        latents = self.denoise(latents, timesteps, cond, uncond, guidance_scale, guidance_rescale, image_embeds, mapped,
+                               image=image)
         if return_latents:
             _emit(progress_callback, 1.0, "Returning latents")
             return latents
@@ -135,3 +146,47 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             from .postprocess import tensor_to_frames
             return tensor_to_frames(video, output_type)
         return video
+
+
+
+class HunyuanVideo15I2VEngine(HunyuanVideo15T2VEngine):
+    """Image-to-video: `run(image=pixels [B|1, 3, H, W] in [-1, 1] (or first-frame latents [B|1, 32, 1, h, w]),
+    image_embeds=SigLIP states [B|1, 729, 1152], ...)`; everything else as the text-to-video engine."""
+
+    def vae_encode(self, image: torch.Tensor, sample_mode: str = "mode", generator=None) -> torch.Tensor:
+        """BaseEngine.vae_encode: tiling on, encode, posterior mode / sample, normalise in the VAE dtype."""
+        if self.vae is None:
+            raise RuntimeError("hunyuanvideo15 i2v: a VAE is needed to encode the first frame (or pass its latents)")
+        x = image.to(self.device, self.vae.dtype)
+        if x.dim() == 4:
+            x = x.unsqueeze(2)
+        self.vae.enable_tiling()
+        post = self.vae.encode(x, return_dict=False)[0]
+        if sample_mode not in ("mode", "sample"):
+            raise ValueError(f"Invalid sample mode: {sample_mode}")
+        lat = post.mode() if sample_mode == "mode" else post.sample(generator=generator)
+        return self.vae.normalize_latents(lat.to(self.vae.dtype))
+
+    def prepare_cond_latents_and_mask(self, latents, dtype, device, image=None):
+        """i2v.py:20-58: condition = the image latents on latent frame 0 and zeros after it; mask = 1 on frame 0."""
+        if image is None:
+            raise ValueError("hunyuanvideo15 i2v: `image` (pixels or first-frame latents) is required")
+        b, c, f, h, w = latents.shape
+        lat = image if image.shape[1] == c else self.vae_encode(image)
+        if lat.dim() == 4:
+            lat = lat.unsqueeze(2)
+        if lat.shape[-2:] != (h, w):
+            raise ValueError(f"image latents {tuple(lat.shape[-2:])} do not match the video latents {(h, w)}")
+        cond = torch.zeros(b, c, f, h, w, dtype=dtype, device=device)
+        cond[:, :, 0] = lat[:, :, 0].to(device=device, dtype=dtype).expand(b, -1, -1, -1) if lat.shape[0] != b \
+            else lat[:, :, 0].to(device=device, dtype=dtype)
+        mask = torch.zeros(b, 1, f, h, w, dtype=dtype, device=device)
+        mask[:, :, 0] = 1.0
+        return cond, mask
+
+    @torch.no_grad()
+    def run(self, image=None, image_embeds=None, *args, **kwargs):
+        if image is None:
+            raise ValueError("hunyuanvideo15 i2v: `image` is required")
+        kwargs.setdefault("guidance_scale", 1.0)          # i2v.py:103: CFG off unless asked for
+        return super().run(*args, image=image, image_embeds=image_embeds, **kwargs)

@@ -24,6 +24,7 @@ keep working and memory is not doubled.
 from __future__ import annotations
 
 import contextlib
+import os
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple
 
@@ -369,6 +370,9 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         att_v = att.unflatten(-1, (H, 128)).unsqueeze(0)  # [1, S, H, 128] strided view
 
         nblk = 0
+        overlap = os.environ.get("APEX_FLUX_OVERLAP") == "1"
+        if overlap and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
 
         def join_mod():
             nonlocal mod_ready
@@ -410,13 +414,28 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             a = blk.attn
             ms = lambda j: self._mod(ws, ("s", i), j)  # noqa: E731  (shift, scale, gate)
             ops.ln_modulate(X, ms(1), ms(0), out=XN)
-            # QKV and MLP-up read the same XN: one launch, 1512 tiles = 5.9 rounds of the 256 CUs
-            ops.gemm_grouped([XN, XN], [blk._wqkv, blk.proj_mlp.weight], [blk._bqkv, blk.proj_mlp.bias],
-                             [QKV, CAT[:, dim:]], epilogue=["bias", "gelu"])
+            if overlap:
+                # experiment (APEX_FLUX_OVERLAP=1): the MLP-up GEMM on the side stream underneath q/k prepare +
+                # attention, whose 1.69-round launch leaves 80 CUs idle in its second round
+                main = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    ops.gemm(XN, blk.proj_mlp.weight, blk.proj_mlp.bias, out=CAT[:, dim:], epilogue="gelu")
+                    mlp_done = torch.cuda.Event()
+                    mlp_done.record(self._side)
+                ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
+            else:
+                # QKV and MLP-up read the same XN: one launch, 1512 tiles = 5.9 rounds of the 256 CUs
+                ops.gemm_grouped([XN, XN], [blk._wqkv, blk.proj_mlp.weight], [blk._bqkv, blk.proj_mlp.bias],
+                                 [QKV, CAT[:, dim:]], epilogue=["bias", "gelu"])
             ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
                             wk=a.norm_k.weight, split=0, eps=1e-6, rope=rope,
                             rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(Qp, Kp, VT, att_v, S)
+            if overlap:
+                torch.cuda.current_stream().wait_event(mlp_done)
             ops.gemm(CAT, blk.proj_out.weight, blk.proj_out.bias, out=X, epilogue="gate_res", gate=ms(2),
                      residual=X)
 

@@ -419,6 +419,17 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+def group_mean(x: torch.Tensor, out_channels: int) -> torch.Tensor:
+    """Mean over consecutive channel groups of a channels-last tensor: [..., C * gs] -> [..., C] (bf16, f32 sum)."""
+    _req(x, torch.bfloat16, "group_mean.x")
+    assert x.is_contiguous() and x.shape[-1] % out_channels == 0
+    gs = x.shape[-1] // out_channels
+    out = torch.empty(*x.shape[:-1], out_channels, dtype=x.dtype, device=x.device)
+    P = x.numel() // x.shape[-1]
+    _l.check(_l.load().apexmi_group_mean_bf16(x.data_ptr(), out.data_ptr(), P, out_channels, gs, _stream()), "group_mean_bf16")
+    return out
+
+
 _freq_tables: dict = {}
 
 

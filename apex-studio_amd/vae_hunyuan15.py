@@ -88,6 +88,62 @@ class _Up(nn.Module):
         self.upsamplers = None if up_out is None else nn.ModuleList([_Upsample(cout, up_out, temporal, **kw)])
 
 
+class _Downsample(nn.Module):
+    def __init__(self, cin, cout, temporal, **kw):
+        super().__init__()
+        self.factor = 8 if temporal else 4
+        self.conv = _CConv(cin, cout // self.factor, **kw)
+        self.temporal = temporal
+        self.cout = cout
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, n, down_out, temporal, **kw):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res(cin if i == 0 else cout, cout, **kw) for i in range(n)])
+        self.downsamplers = None if down_out is None else nn.ModuleList([_Downsample(cout, down_out, temporal, **kw)])
+
+
+class _Encoder(nn.Module):
+    """HunyuanVideo15Encoder3D (model.py:535-636): same parameter names (`encoder.*`)."""
+
+    def __init__(self, in_channels, out_channels, ch, layers_per_block, spatial_ratio, temporal_ratio, **kw):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv_in = _CConv(in_channels, ch[0], **kw)
+        downs, cin = [], ch[0]
+        for i, cout in enumerate(ch):
+            if i < math.log2(spatial_ratio):
+                tp = i >= math.log2(spatial_ratio // temporal_ratio)
+                downs.append(_Down(cin, cout, layers_per_block, ch[i + 1], tp, **kw))
+                cin = ch[i + 1]
+            else:
+                downs.append(_Down(cin, cout, layers_per_block, None, False, **kw))
+                cin = cout
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = _Mid(ch[-1], **kw)
+        self.norm_out = _Gamma(ch[-1], **kw)
+        self.conv_out = _CConv(ch[-1], out_channels, **kw)
+
+
+class _Posterior:
+    """DiagonalGaussianDistribution as the engines use it (`.mode()`, `.sample(generator)`; engine/base_engine.py:2144-2149):
+    parameters [B, 2 C, T, H, W] = mean | logvar, logvar clamped to [-30, 20]."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
+        return self.mean + self.std * noise.to(self.mean.dtype)
+
+
 class _Decoder(nn.Module):
     def __init__(self, in_channels, out_channels, ch, layers_per_block, spatial_ratio, temporal_ratio, **kw):
         super().__init__()
@@ -106,6 +162,13 @@ class _Decoder(nn.Module):
         self.up_blocks = nn.ModuleList(ups)
         self.norm_out = _Gamma(ch[-1], **kw)
         self.conv_out = _CConv(ch[-1], out_channels, **kw)
+
+
+def _pack_cl(x: torch.Tensor, r1: int, r2: int, r3: int) -> torch.Tensor:
+    """channels-last form of `_dcae_downsample_rearrange` (model.py:289-302): [r1 T, r2 H, r3 W, c] -> [T, H, W, r1*r2*r3*c]."""
+    PT, PH, PW, c = x.shape
+    T, H, W = PT // r1, PH // r2, PW // r3
+    return x.view(T, r1, H, r2, W, r3, c).permute(0, 2, 4, 1, 3, 5, 6).reshape(T, H, W, r1 * r2 * r3 * c).contiguous()
 
 
 def _rearrange_cl(x: torch.Tensor, r1: int, r2: int, r3: int) -> torch.Tensor:
@@ -131,11 +194,15 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
                               temporal_compression_ratio=temporal_compression_ratio, scaling_factor=scaling_factor,
                               shift_factor=None)
         kw = dict(device=device, dtype=dtype)
+        self.encoder = _Encoder(in_channels, 2 * latent_channels, list(block_out_channels), layers_per_block,
+                                spatial_compression_ratio, temporal_compression_ratio, **kw)
         self.decoder = _Decoder(latent_channels, out_channels, list(reversed(block_out_channels)), layers_per_block,
                                 spatial_compression_ratio, temporal_compression_ratio, **kw)
         self.spatial_compression_ratio = spatial_compression_ratio
         self.temporal_compression_ratio = temporal_compression_ratio
         self.use_tiling = False
+        # the reference class keeps ONE pair of tile sizes for both directions (model.py:866-888): the decode reads the
+        # latent pair, the encode the sample pair
         self.tile_sample_min_height = self.tile_sample_min_width = 128
         self.tile_latent_min_height = self.tile_latent_min_width = 128 // spatial_compression_ratio
         self.tile_overlap_factor = 0.25
@@ -198,7 +265,11 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         key = id(mod)
         p = self._packed.get(key)
         if p is None:
-            w = ops.pack_conv_weight(weight.data)
+            wt = weight.data
+            if wt.shape[1] % 8:      # the RGB input convolution: channels zero-padded to 8, as the activations are
+                pad = torch.zeros(wt.shape[0], 8 - wt.shape[1] % 8, *wt.shape[2:], dtype=wt.dtype, device=wt.device)
+                wt = torch.cat([wt, pad], dim=1)
+            w = ops.pack_conv_weight(wt)
             b = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
             b[:bias.numel()] = bias.data
             p = (w, b)
@@ -244,6 +315,87 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
             h = _rearrange_cl(h, 1, 2, 2)
             sc = _rearrange_cl(x.repeat_interleave(up.repeats, dim=-1), 1, 2, 2)
         return ops.add(h.contiguous(), sc.contiguous())
+
+    def _downsample(self, dn: _Downsample, x):
+        """HunyuanVideo15Downsample.forward (model.py:304-333) on a channels-last tile: conv -> pixel un-shuffle into the
+        channels; the shortcut is the grouped channel mean of the un-shuffled input.  With temporal downsampling the
+        first frame is un-shuffled in space only and its channels duplicated."""
+        h = self._cconv(dn.conv, x)[..., :dn.conv.conv.weight.shape[0]]
+        if dn.temporal:
+            hf = _pack_cl(h[:1], 1, 2, 2)
+            hf = torch.cat([hf, hf], dim=-1)
+            h = torch.cat([hf, _pack_cl(h[1:], 2, 2, 2)], dim=0) if h.shape[0] > 1 else hf
+            sc = ops.group_mean(_pack_cl(x[:1], 1, 2, 2), dn.cout)
+            if x.shape[0] > 1:
+                sc = torch.cat([sc, ops.group_mean(_pack_cl(x[1:], 2, 2, 2), dn.cout)], dim=0)
+        else:
+            h = _pack_cl(h, 1, 2, 2)
+            sc = ops.group_mean(_pack_cl(x, 1, 2, 2), dn.cout)
+        return ops.add(h.contiguous(), sc.contiguous())
+
+    def _encode_tile(self, x):
+        """x [T, H, W, 8] channels-last pixels (3 channels + zero pad) -> moments [T', H/16, W/16, 2 * latent_channels]."""
+        e = self.encoder
+        x = self._cconv(e.conv_in, x)
+        for db in e.down_blocks:
+            for r in db.resnets:
+                x = self._res(r, x)
+            if db.downsamplers is not None:
+                x = self._downsample(db.downsamplers[0], x)
+        x = self._res(e.mid_block.resnets[0], x)
+        x = self._attn(e.mid_block.attentions[0], x)
+        x = self._res(e.mid_block.resnets[1], x)
+        sc = ops.group_mean(x, e.out_channels)
+        return self._cconv(e.conv_out, ops.rmsnorm_cl(x, self._g(e.norm_out), silu=True), residual=sc)
+
+    @torch.no_grad()
+    def _encode_one(self, x):
+        """x [3, T, H, W] in [-1, 1] -> moments [2 C, T', H/16, W/16] bf16 (`_encode` / `tiled_encode`, model.py:890-897,
+        :994-1058: 256-px tiles at stride 192, blended over 25 % of a latent tile)."""
+        if x.device.type != "cuda" or self.dtype != torch.bfloat16:
+            raise _l.ApexMIError("hunyuanvideo15_mi355 VAE needs bf16 weights and pixels on a ROCm device (no CPU fallback)")
+        Cc, T, H, W = x.shape
+        if (T - 1) % self.temporal_compression_ratio:
+            raise ValueError(f"hunyuanvideo15 VAE encodes 1 + {self.temporal_compression_ratio} k frames, got {T}")
+        xc = torch.zeros(T, H, W, 8, dtype=torch.bfloat16, device=x.device)
+        xc[..., :Cc] = x.to(torch.bfloat16).permute(1, 2, 3, 0)
+        tsh, tsw = self.tile_sample_min_height, self.tile_sample_min_width
+        if not (self.use_tiling and (W > tsw or H > tsh)):
+            out = self._encode_tile(xc)
+        else:
+            ovh, ovw = int(tsh * (1 - self.tile_overlap_factor)), int(tsw * (1 - self.tile_overlap_factor))
+            bh = int(self.tile_latent_min_height * self.tile_overlap_factor)
+            bw = int(self.tile_latent_min_width * self.tile_overlap_factor)
+            lh, lw = self.tile_latent_min_height - bh, self.tile_latent_min_width - bw
+            rows = [[self._encode_tile(xc[:, i:i + tsh, j:j + tsw].contiguous()) for j in range(0, W, ovw)]
+                    for i in range(0, H, ovh)]
+            out_rows = []
+            for i, row in enumerate(rows):
+                parts = []
+                for j, tile in enumerate(row):
+                    if i > 0 and bh > 0:
+                        a = rows[i - 1][j]
+                        e = min(a.shape[1], tile.shape[1], bh)
+                        ops.crossfade_(a[:, a.shape[1] - e:, :tile.shape[2]], tile[:, :e], dim=1)
+                    if j > 0 and bw > 0:
+                        a = row[j - 1]
+                        e = min(a.shape[2], tile.shape[2], bw)
+                        ops.crossfade_(a[:, :tile.shape[1], a.shape[2] - e:], tile[:, :, :e], dim=2)
+                    parts.append(tile[:, :lh, :lw])
+                out_rows.append(torch.cat(parts, dim=2))
+            out = torch.cat(out_rows, dim=1)
+        return out[..., :self.encoder.out_channels].permute(3, 0, 1, 2).contiguous()
+
+    @ops.on_model_device
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """`vae.encode(x, return_dict=False)[0].mode()` (engine/base_engine.py:2061-2165): x [B, 3, T, H, W]."""
+        if x.dim() == 4:
+            x = x.unsqueeze(2)
+        post = _Posterior(torch.stack([self._encode_one(x[b]) for b in range(x.shape[0])], dim=0))
+        if not return_dict:
+            return (post,)
+        return SimpleNamespace(latent_dist=post)
 
     def _decode_tile(self, z):
         """z [T, h, w, latent_channels] channels-last -> [4 (T - 1) + 1, 16 h, 16 w, 4] (3 channels + 1 pad)."""

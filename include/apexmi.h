@@ -89,8 +89,9 @@ int apexmi_attn_fwd_prepared(const void* q, const void* k, const void* vt, void*
 
 /* Same, with scratch for the TAIL SPLIT: when the 8-wave launch would end in a round that keeps at most a quarter of the
  * CUs busy (QwenImage-Edit: 792 workgroups = 3 rounds + 24), those last workgroups run as a second launch cut into 4 key
- * ranges each and a merge of the partial results (log-sum-exp weights), instead of a nearly empty round of full-length
- * workgroups.  workspace >= apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk) (0 when no split applies; NULL / too
+ * ranges each and a merge of the partial results, instead of a nearly empty round of full-length workgroups.  The
+ * partials are un-normalised f32 numerators with their (integer, base-2) row maxima and partial sums, merged with exact
+ * power-of-two weights: a split launch rounds to bf16 exactly where the single launch does.  workspace >= apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk) (0 when no split applies; NULL / too
  * small simply disables the split). */
 size_t apexmi_attn_prepared_workspace_bytes(int B, int H, int Sq, int Sk);
 int apexmi_attn_fwd_prepared_ws(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
@@ -307,6 +308,12 @@ int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out,
 /* out = a + b, n bf16 elements (n % 8 == 0): `h + shortcut` after the DCAE rearranges of the HunyuanVideo-1.5 VAE
  * (vae/hunyuanvideo15/model.py:274, :709-711). */
 int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
+
+/* out[p, c] = mean_{g < gs} x[p, c * gs + g] (f32 sum, one bf16 rounding), x bf16 [P, C * gs], out bf16 [P, C]: the
+ * grouped channel mean of the DCAE shortcuts of the HunyuanVideo-1.5 VAE ENCODER (vae/hunyuanvideo15/model.py:318-331
+ * `x.view(B, C, group_size, T, H, W).mean(dim=2)` of HunyuanVideo15Downsample, :622-625 of Encoder3D.forward), in
+ * channels-last form.  gs in [1, 64]. */
+int apexmi_group_mean_bf16(const void* x, void* out, int64_t P, int C, int gs, apexmi_stream_t stream);
 
 /* BaseEngine._tensor_to_frames (engine/base_engine.py:2945-2949 -> diffusers VideoProcessor.postprocess_video):
  * frames uint8 [T, H, W, C] = round(clamp(video / 2 + 1/2, 0, 1) * 255) from a bf16 video [C, T, H, W] given by element

@@ -10,8 +10,14 @@ fp32 CPU restatement of the HunyuanVideo-1.5 3-D causal VAE DECODE path (SURVEY.
   HunyuanVideo15CausalConv3d.forward                   :52-90     (REPLICATE padding, 2 frames in front)
   HunyuanVideo15RMS_norm.forward                       :93-127
   blend_v / blend_h, denormalize_latents               :974-992, :1145-1150
-tests/golden/vae_hunyuan15.pt holds outputs of the REFERENCE class run in this container (untiled and tiled); the CPU
-test requires this restatement to match them.  Parameter names equal the reference's `decoder.*` state-dict keys.
+and of its ENCODE path (image-to-video conditioning, engine/hunyuanvideo15/shared `_get_image_latents`):
+  AutoencoderKLHunyuanVideo15._encode / tiled_encode   :890-897, :994-1058   (256-px tiles, stride 192, 2-latent blends)
+  HunyuanVideo15Encoder3D.forward                      :535-636   (grouped-mean shortcut around norm_out/conv_out)
+  HunyuanVideo15DownBlock3D / Downsample.forward       :440-478, :277-333  (DCAE pixel un-shuffle; first frame: spatial
+                                                        only, its channels duplicated; shortcut = grouped channel mean)
+tests/golden/vae_hunyuan15.pt and vae_hunyuan15_encode.pt hold outputs of the REFERENCE class run in this container (untiled
+and tiled); the CPU tests require this restatement to match them.  Parameter names equal the reference's `decoder.*` /
+`encoder.*` state-dict keys.
 """
 from __future__ import annotations
 
@@ -108,6 +114,56 @@ class Upsample(nn.Module):
         return pol.r(h + sc)
 
 
+def dcae_downsample_rearrange(t: torch.Tensor, r1: int = 1, r2: int = 2, r3: int = 2) -> torch.Tensor:
+    """(b, c, r1*f, r2*h, r3*w) -> (b, r1*r2*r3*c, f, h, w), model.py:289-302."""
+    b, c, pf, ph, pw = t.shape
+    f, h, w = pf // r1, ph // r2, pw // r3
+    return t.view(b, c, f, r1, h, r2, w, r3).permute(0, 3, 5, 7, 1, 2, 4, 6).reshape(b, r1 * r2 * r3 * c, f, h, w)
+
+
+def group_mean(t: torch.Tensor, out_channels: int) -> torch.Tensor:
+    """Channel groups averaged: (b, C, ...) -> (b, out_channels, ...), group g = channels g*gs .. (g+1)*gs - 1."""
+    b, c = t.shape[:2]
+    return t.view(b, out_channels, c // out_channels, *t.shape[2:]).mean(dim=2)
+
+
+class Downsample(nn.Module):
+    def __init__(self, cin: int, cout: int, temporal: bool):
+        super().__init__()
+        factor = 8 if temporal else 4
+        self.conv = CausalConv3d(cin, cout // factor)
+        self.temporal = temporal
+        self.cout = cout
+
+    def forward(self, x, pol: Policy):
+        h = pol.r(self.conv(x))
+        if self.temporal:
+            hf = dcae_downsample_rearrange(h[:, :, :1], 1, 2, 2)
+            hf = torch.cat([hf, hf], dim=1)
+            h = torch.cat([hf, dcae_downsample_rearrange(h[:, :, 1:], 2, 2, 2)], dim=2)
+            xf = group_mean(dcae_downsample_rearrange(x[:, :, :1], 1, 2, 2), self.cout)
+            xn = group_mean(dcae_downsample_rearrange(x[:, :, 1:], 2, 2, 2), self.cout)
+            sc = pol.r(torch.cat([xf, xn], dim=2))
+        else:
+            h = dcae_downsample_rearrange(h, 1, 2, 2)
+            sc = pol.r(group_mean(dcae_downsample_rearrange(x, 1, 2, 2), self.cout))
+        return pol.r(h + sc)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, n: int, down_out, temporal: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock(cin if i == 0 else cout, cout) for i in range(n)])
+        self.downsamplers = None if down_out is None else nn.ModuleList([Downsample(cout, down_out, temporal)])
+
+    def forward(self, x, pol: Policy):
+        for r in self.resnets:
+            x = r(x, pol)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x, pol)
+        return x
+
+
 class MidBlock(nn.Module):
     def __init__(self, c: int):
         super().__init__()
@@ -162,12 +218,45 @@ class Decoder3D(nn.Module):
         return pol.r(self.conv_out(pol.r(F.silu(self.norm_out(x)))))
 
 
+class Encoder3D(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, block_out_channels: Tuple[int, ...], layers_per_block: int,
+                 spatial_compression_ratio: int, temporal_compression_ratio: int):
+        super().__init__()
+        import math
+        ch = list(block_out_channels)
+        self.out_channels = out_channels
+        self.conv_in = CausalConv3d(in_channels, ch[0])
+        self.down_blocks = nn.ModuleList()
+        cin = ch[0]
+        for i, cout in enumerate(ch):
+            if i < math.log2(spatial_compression_ratio):
+                tp = i >= math.log2(spatial_compression_ratio // temporal_compression_ratio)
+                self.down_blocks.append(DownBlock(cin, cout, layers_per_block, ch[i + 1], tp))
+                cin = ch[i + 1]
+            else:
+                self.down_blocks.append(DownBlock(cin, cout, layers_per_block, None, False))
+                cin = cout
+        self.mid_block = MidBlock(ch[-1])
+        self.norm_out = RMSNorm(ch[-1])
+        self.conv_out = CausalConv3d(ch[-1], out_channels)
+
+    def forward(self, x, pol: Policy = FP32):
+        x = pol.r(self.conv_in(x))
+        for db in self.down_blocks:
+            x = db(x, pol)
+        x = self.mid_block(x, pol)
+        sc = pol.r(group_mean(x, self.out_channels))
+        return pol.r(self.conv_out(pol.r(F.silu(self.norm_out(x)))) + sc)
+
+
 class AutoencoderKLHunyuanVideo15(nn.Module):
     def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 32,
                  block_out_channels=(128, 256, 512, 1024, 1024), layers_per_block: int = 2,
                  spatial_compression_ratio: int = 16, temporal_compression_ratio: int = 4, scaling_factor: float = 1.03682,
                  **_unused):
         super().__init__()
+        self.encoder = Encoder3D(in_channels, latent_channels * 2, tuple(block_out_channels), layers_per_block,
+                                 spatial_compression_ratio, temporal_compression_ratio)
         self.decoder = Decoder3D(latent_channels, out_channels, tuple(reversed(block_out_channels)), layers_per_block,
                                  spatial_compression_ratio, temporal_compression_ratio)
         self.scaling_factor = scaling_factor
@@ -182,6 +271,33 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
 
     def denormalize_latents(self, latents):
         return latents / self.scaling_factor
+
+    def normalize_latents(self, latents):
+        return latents * self.scaling_factor
+
+    @torch.no_grad()
+    def encode(self, x, policy: Policy = FP32, tile_sample_min: int = 128):
+        """Posterior parameters [B, 2 * latent_channels, T', H/16, W/16] (mean | logvar); `.mode()` = the first half."""
+        _, _, _, H, W = x.shape
+        ts = tile_sample_min
+        if not (self.use_tiling and (W > ts or H > ts)):
+            return self.encoder(x, policy)
+        tl = ts // self.spatial_compression_ratio
+        ov = int(ts * (1 - self.tile_overlap_factor))
+        blend = int(tl * self.tile_overlap_factor)
+        limit = tl - blend
+        rows = [[self.encoder(x[:, :, :, i:i + ts, j:j + ts], policy) for j in range(0, W, ov)] for i in range(0, H, ov)]
+        out_rows = []
+        for i, row in enumerate(rows):
+            res = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = policy.r(self._blend(rows[i - 1][j], tile, blend, 3))
+                if j > 0:
+                    tile = policy.r(self._blend(row[j - 1], tile, blend, 4))
+                res.append(tile[:, :, :, :limit, :limit])
+            out_rows.append(torch.cat(res, dim=-1))
+        return torch.cat(out_rows, dim=-2)
 
     @staticmethod
     def _blend(a, b, extent: int, dim: int):

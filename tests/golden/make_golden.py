@@ -414,6 +414,37 @@ def gen_vae_hunyuan15():
     print("vae_hunyuan15.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
 
 
+def gen_vae_hunyuan15_encode():
+    """The REFERENCE AutoencoderKLHunyuanVideo15 ENCODE path (image-to-video conditioning): one frame and a 5-frame clip,
+    untiled, and a tiled encode (tile 64 px, stride 48, 1-latent blends via the constructor-free attributes)."""
+    install_vae_stubs()
+    import src.attention  # noqa: F401
+    _mod("src.utils.defaults", get_components_path=lambda *a, **k: "/tmp")
+    t = _mod("src.vae.tae")
+    t.__path__ = []
+    _mod("src.vae.tae.model", TAEHV=type("TAEHV", (), {}))
+    _mod("src.mixins.download_mixin", DownloadMixin=type("DownloadMixin", (), {}))
+    ref_mod = load_by_path("ref_vae_hy15e", "src/vae/hunyuanvideo15/model.py")
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    ref = ref_mod.AutoencoderKLHunyuanVideo15(**TINY_VAE_HY15).eval()
+    orc = Orc(**TINY_VAE_HY15)
+    sd = vae_synthetic_state_dict(orc, 19)
+    res = ref.load_state_dict(sd, strict=True)
+    out = dict(config=TINY_VAE_HY15, seed=19, keys=sorted(sd.keys()))
+    with torch.no_grad():
+        for name, shape, seed in (("image", (1, 3, 1, 64, 96), 81), ("clip", (1, 3, 5, 64, 64), 82)):
+            x = seeded(shape, seed).clamp(-1, 1)
+            h = ref._encode(x)
+            out[name] = dict(shape=shape, seed=seed, moments=h)
+        # tiled: 128 x 160 px with 64-px tiles (4 latents), stride 48 px, blend 1 latent
+        ref.enable_tiling(tile_sample_min_height=64, tile_sample_min_width=64, tile_latent_min_height=4,
+                          tile_latent_min_width=4)
+        x = seeded((1, 3, 1, 128, 160), 83).clamp(-1, 1)
+        out["tiled"] = dict(shape=(1, 3, 1, 128, 160), seed=83, tile=64, moments=ref._encode(x))
+    torch.save(out, os.path.join(OUT, "vae_hunyuan15_encode.pt"))
+    print("vae_hunyuan15_encode.pt", {k: tuple(v["moments"].shape) for k, v in out.items() if isinstance(v, dict) and "moments" in v}, res)
+
+
 def gen_unipc():
     """In-tree UniPC (reference scheduler/unipc.py) trajectory: 6 steps, shift 3, fp32 latents."""
     class SchedulerOutput:

@@ -135,3 +135,52 @@ def test_hunyuan15_t2v_loop_cfg_rescale_and_progress():
     kw["generator"] = torch.Generator().manual_seed(0)
     b = eng.run(guidance_scale=6.0, guidance_rescale=0.7, **kw, **neg)
     assert not torch.equal(a, b) and torch.isfinite(b).all()
+
+
+def test_hunyuan15_i2v_condition_latents_mask_and_image_embeds():
+    """reference engine/hunyuanvideo15/i2v.py:20-58, :262-264: cond = image latents on latent frame 0 / zeros after it,
+    mask = 1 on frame 0, SigLIP embeddings forwarded; the first frame comes from vae.encode(...).mode() normalised."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15I2VEngine
+    seen = {}
+
+    class _Fake(_FakeHunyuan):
+        def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, encoder_hidden_states_2,
+                     encoder_attention_mask_2, image_embeds, return_dict=False):
+            seen["cond"], seen["mask"] = hidden_states[:, 32:64].clone(), hidden_states[:, 64:].clone()
+            seen["img"] = image_embeds.clone()
+            return (hidden_states[:, :32] * 0.1,)
+
+    class _FakeVAE:
+        dtype = torch.float32
+        tiling = 0
+
+        def enable_tiling(self):
+            self.tiling += 1
+
+        def encode(self, x, return_dict=False):
+            assert x.shape == (1, 3, 1, 64, 96)
+            mean = torch.full((1, 32, 1, 4, 6), 0.5)
+            return (SimpleNamespace(mode=lambda: mean, sample=lambda generator=None: mean + 1),)
+
+        def normalize_latents(self, z):
+            return z * 2.0
+
+    vae = _FakeVAE()
+    eng = HunyuanVideo15I2VEngine(_Fake(), vae=vae)
+    kw = dict(prompt_embeds=torch.ones(1, 6, 8), prompt_embeds_mask=torch.ones(1, 6), prompt_embeds_2=torch.ones(1, 4, 8),
+              prompt_embeds_mask_2=torch.ones(1, 4), height=64, width=96, num_frames=9, num_inference_steps=2,
+              generator=torch.Generator().manual_seed(0), return_latents=True)
+    emb = torch.full((1, 729, 1152), 0.25)
+    out = eng.run(image=torch.zeros(1, 3, 64, 96), image_embeds=emb, **kw)
+    assert out.shape == (1, 32, 3, 4, 6) and vae.tiling >= 1
+    assert torch.equal(seen["cond"][:, :, 0], torch.full((1, 32, 4, 6), 1.0)) and float(seen["cond"][:, :, 1:].abs().sum()) == 0
+    assert torch.equal(seen["mask"][:, :, 0], torch.ones(1, 1, 4, 6)) and float(seen["mask"][:, :, 1:].abs().sum()) == 0
+    assert torch.equal(seen["img"], emb)
+    # first-frame latents given directly (no VAE call), and the image is mandatory
+    eng2 = HunyuanVideo15I2VEngine(_Fake(), vae=None)
+    eng2.run(image=torch.full((1, 32, 1, 4, 6), 3.0), **dict(kw, generator=torch.Generator().manual_seed(0)))
+    assert torch.equal(seen["cond"][:, :, 0], torch.full((1, 32, 4, 6), 3.0))
+    import pytest
+    with pytest.raises(ValueError):
+        eng2.run(**kw)

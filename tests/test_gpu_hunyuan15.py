@@ -104,3 +104,38 @@ def test_hunyuan15_all_tokens_valid_and_determinism():
              else v.to(DEV)) for k, v in inp.items()}
     again = m(return_dict=False, **g)[0].float().cpu()
     assert torch.equal(out, again)
+
+
+def test_hunyuan15_i2v_engine_pixels_to_frames():
+    """Image-to-video on the HIP classes (reference engine/hunyuanvideo15/i2v.py): first frame pixels -> tiled VAE encode
+    (posterior mode, normalised) -> condition latents + mask -> 2 CFG steps -> tiled VAE decode -> uint8 frames.  The
+    `image=pixels` entry must equal the run fed the pre-encoded first-frame latents, and the condition must matter."""
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15I2VEngine
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    from tests.golden.seeded import vae_synthetic_state_dict
+    cfg = dict(in_channels=65, out_channels=32, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+               num_refiner_layers=1, text_embed_dim=64, text_embed_2_dim=128, image_embed_dim=64)
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(OH.HunyuanVideo15Transformer3DModel(**cfg), 21).items()})
+    vcfg = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
+                layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
+    vae = AutoencoderKLHunyuanVideo15(**vcfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vae_synthetic_state_dict(vae, 23).items()}, strict=True)
+    eng = HunyuanVideo15I2VEngine(m, vae=vae, vision_num_semantic_tokens=3, vision_states_dim=64)
+    H, W, F_ = 160, 192, 9
+    img = seeded((1, 3, H, W), 91).clamp(-1, 1)
+    pe, pe2 = seeded((1, 12, 64), 92).to(torch.bfloat16), seeded((1, 8, 128), 93).to(torch.bfloat16)
+    kw = dict(prompt_embeds=pe, prompt_embeds_mask=torch.ones(1, 12), prompt_embeds_2=pe2, prompt_embeds_mask_2=torch.ones(1, 8),
+              negative_prompt_embeds=pe * 0, negative_prompt_embeds_mask=torch.ones(1, 12), negative_prompt_embeds_2=pe2 * 0,
+              negative_prompt_embeds_mask_2=torch.ones(1, 8), guidance_scale=4.0, height=H, width=W, num_frames=F_,
+              num_inference_steps=2, seed=3, image_embeds=seeded((1, 3, 64), 94).to(torch.bfloat16))
+    lat = eng.run(image=img.to(DEV), return_latents=True, **kw)
+    assert lat.shape == (1, 32, 3, H // 16, W // 16) and torch.isfinite(lat.float()).all()
+    first = eng.vae_encode(img.to(DEV))                       # 160 x 192 px > the 128-px tile: the tiled encode path
+    assert first.shape == (1, 32, 1, H // 16, W // 16)
+    assert torch.equal(eng.run(image=first, return_latents=True, **kw), lat)
+    other = eng.run(image=(img * 0.5).to(DEV), return_latents=True, **kw)
+    assert _rel(other, lat) > 1e-3, "the first-frame condition must reach the transformer"
+    frames = eng.run(image=img.to(DEV), output_type="np", **kw)
+    assert frames.shape == (1, F_, H, W, 3) and frames.dtype.name == "uint8"

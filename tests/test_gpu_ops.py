@@ -597,8 +597,8 @@ def test_attention_random_length_sweep():
 @pytest.mark.parametrize("H,S", [(24, 8448), (8, 8448 + 100), (33, 2304)])
 def test_attention_tail_split_matches_unsplit_and_reference(H, S):
     """Launches whose last round would keep <= 1/4 of the CUs busy run it as 4 key ranges + a merge (`attn.split`):
-    same result as the single launch up to the extra bf16 rounding of the partial outputs, and within the attention bar
-    of the fp32 reference.  (24, 8448) is the QwenImage-Edit shape: 792 workgroups = 3 rounds + 24."""
+    same result as the single launch up to f32 summation order (partials are f32 numerators + integer maxima, merged with
+    exact power-of-two weights), and within the attention bar of the fp32 reference.  (24, 8448) is the QwenImage-Edit shape: 792 workgroups = 3 rounds + 24."""
     ops = _ops()
     from apex_studio_amd import lib
     q = seeded((1, H, S, 128), 501, torch.bfloat16).to(DEV)
@@ -610,7 +610,7 @@ def test_attention_tail_split_matches_unsplit_and_reference(H, S):
     nqb = (S + 255) // 256
     tail = (nqb * H) % 256
     assert 0 < tail <= 64, "shape must exercise the split"
-    assert lib.load().apexmi_attn_prepared_workspace_bytes(1, H, S, S) == tail * 4 * 256 * (256 + 4)
+    assert lib.load().apexmi_attn_prepared_workspace_bytes(1, H, S, S) == tail * 4 * 256 * (128 * 4 + 8)
     outs = {}
     try:
         for split in (1, 0):
