@@ -40,6 +40,8 @@ struct ConvArgs {
     int Ho, Wo, sy, sx;   // output height / width and spatial stride (Ho = H, Wo = W, 1, 1 for the "same" convolutions)
     int py, px;           // zero rows / columns assumed above / left of the input ((k-1)/2 for "same"; 0 for the
                           // ZeroPad2d((0,1,0,1)) + stride-2 downsampling convolution of the VAE encoders)
+    int up;               // 1: the input is read through a nearest 2x spatial upsample (H, W are the UPSAMPLED extents,
+    int Hin, Win;         //    the stored image is Hin x Win = H/2 x W/2 and tap (y, x) reads pixel (y >> 1, x >> 1))
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
                 const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
                 if (a.replicate) {   // HunyuanVideo15CausalConv3d: F.pad(..., mode="replicate") == clamped coordinates
                     const int tc = max(ti, 0), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
-                    src = a.in + ((int64_t)(tc * a.H + yc) * a.W + xc) * a.Cin + a_ci[i];
+                    src = a.in + ((int64_t)(tc * a.Hin + (yc >> a.up)) * a.Win + (xc >> a.up)) * a.Cin + a_ci[i];
                 } else if ((unsigned)ti < (unsigned)a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
-                    src = a.in + ((int64_t)(ti * a.H + yi) * a.W + xi) * a.Cin + a_ci[i];
+                    src = a.in + ((int64_t)(ti * a.Hin + (yi >> a.up)) * a.Win + (xi >> a.up)) * a.Cin + a_ci[i];
                 }
             }
             glds16(src, base + i * 4096);
@@ -454,7 +456,12 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
 static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
-                          int Ho = 0, int Wo = 0, int independent = 0) {
+                          int Ho = 0, int Wo = 0, int independent = 0, int up = 0) {
+    const int Hin = H, Win = W;
+    if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
+        H *= 2;
+        W *= 2;
+    }
     if (py < 0) py = (kH - 1) / 2;   // "same" convolution
     if (px < 0) px = (kW - 1) / 2;
     if (Ho <= 0) Ho = H;
@@ -505,6 +512,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.r64 = 64 % Cin;
     a.replicate = replicate;
     a.Ho = Ho; a.Wo = Wo; a.sy = sy; a.sx = sx; a.py = py; a.px = px;
+    a.up = up ? 1 : 0; a.Hin = Hin; a.Win = Win;
     const int64_t M = (int64_t)T * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
@@ -517,6 +525,13 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
                                 void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
                                 int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_);
+}
+
+extern "C" int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                    const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                                    int kW, int independent, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
+                          0, 0, independent, 1);
 }
 
 extern "C" int apexmi_conv3d_cl_frames(const void* in, const void* w, const void* bias, const void* residual,

@@ -585,22 +585,30 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              replicate: bool = False, independent_frames: bool = False) -> torch.Tensor:
+              replicate: bool = False, independent_frames: bool = False, upsample2x: bool = False) -> torch.Tensor:
     """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" padding in space: zeros, or (replicate)
-    clamped coordinates as HunyuanVideo15CausalConv3d pads."""
+    clamped coordinates as HunyuanVideo15CausalConv3d pads.  upsample2x: the convolution reads x through a nearest 2x
+    spatial upsample (output [T,2H,2W,Cout4]) without materialising it."""
     _req(x, torch.bfloat16, "conv3d_cl.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
+    Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
     if out is None:
-        out = torch.empty((T, H, W, cout), dtype=torch.bfloat16, device=x.device)
-    assert out.is_contiguous() and out.shape == (T, H, W, cout)
+        out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.shape == (T, Ho, Wo, cout)
     if bias is not None:
         assert bias.numel() == cout and bias.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
-    assert not (replicate and independent_frames)
+    assert not (replicate and independent_frames) and not (replicate and upsample2x)
+    if upsample2x:
+        rc = _l.load().apexmi_conv3d_cl_up2(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                            _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]),
+                                            int(ksize[1]), int(ksize[2]), 1 if independent_frames else 0, _stream())
+        _l.check(rc, "conv3d_cl_up2")
+        return out
     fn = (_l.load().apexmi_conv3d_cl_replicate if replicate else
           _l.load().apexmi_conv3d_cl_frames if independent_frames else _l.load().apexmi_conv3d_cl)
     rc = fn(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),

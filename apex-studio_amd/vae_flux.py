@@ -146,7 +146,7 @@ class AutoencoderKL(nn.Module):
     def normalize_latents(self, latents):
         return (latents - self.config.shift_factor) * self.config.scaling_factor
 
-    def _conv(self, conv: _Conv, x, residual=None):
+    def _conv(self, conv: _Conv, x, residual=None, upsample2x=False):
         key = id(conv)
         p = self._packed.get(key)
         if p is None:
@@ -155,7 +155,7 @@ class AutoencoderKL(nn.Module):
             b[:conv.bias.numel()] = conv.bias.data
             p = (w, b)
             self._packed[key] = p
-        return ops.conv3d_cl(x, p[0], p[1], (1,) + conv.ksize, residual=residual)
+        return ops.conv3d_cl(x, p[0], p[1], (1,) + conv.ksize, residual=residual, upsample2x=upsample2x)
 
     def _res(self, blk: _Res2D, x):
         s = x if blk.conv_shortcut is None else self._conv(blk.conv_shortcut, x)
@@ -190,7 +190,8 @@ class AutoencoderKL(nn.Module):
             for r in up.resnets:
                 x = self._res(r, x)
             if up.upsamplers is not None:
-                x = self._conv(up.upsamplers[0].conv, ops.upsample2x_cl(x))
+                # diffusers Upsample2D (nearest 2x + conv) with the upsample folded into the convolution's gather
+                x = self._conv(up.upsamplers[0].conv, x, upsample2x=True)
         x = ops.groupnorm_cl(x, d.conv_norm_out.weight.data, d.conv_norm_out.bias.data, silu=True)
         x = self._conv(d.conv_out, x)
         return x[0, :, :, :self.config.out_channels].permute(2, 0, 1).contiguous()

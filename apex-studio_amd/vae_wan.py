@@ -271,10 +271,11 @@ class AutoencoderKLWan(nn.Module):
             self._packed[key] = p
         return p
 
-    def _conv(self, conv: _Conv, x, residual=None):
+    def _conv(self, conv: _Conv, x, residual=None, upsample2x=False):
         w, b = self._w(conv)
         k = conv.ksize if len(conv.ksize) == 3 else (1,) + conv.ksize
-        return ops.conv3d_cl(x, w, b, k, residual=residual, independent_frames=self._indep and k[0] > 1)
+        return ops.conv3d_cl(x, w, b, k, residual=residual, independent_frames=self._indep and k[0] > 1,
+                             upsample2x=upsample2x)
 
     def _run_tiles(self, fn, tiles):
         """fn over every tile.  Single-frame tiles (QwenImage's image VAE, first-frame encodes) of equal shape run as ONE
@@ -320,7 +321,8 @@ class AutoencoderKLWan(nn.Module):
         if up.mode == "upsample3d" and T > 1 and not self._indep:
             y = self._conv(up.time_conv, x[1:].contiguous())        # never sees frame 0 (the "Rep" rule)
             x = torch.cat([x[:1], ops.time_interleave_cl(y)], dim=0)
-        return self._conv(up.resample[1], ops.upsample2x_cl(x))
+        # WanUpsample (nearest-exact 2x) is folded into the convolution's gather: no 4x larger intermediate
+        return self._conv(up.resample[1], x, upsample2x=True)
 
     def _decode_tile(self, z):
         """z [T, h, w, z_dim] channels-last -> [T', 8h, 8w, 4] (3 channels + 1 pad)."""

@@ -240,6 +240,15 @@ int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, in
 int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
                      int kW, apexmi_stream_t stream);
+/* The same convolution read THROUGH a nearest 2x spatial upsample: in is [T, H, W, Cin], out [T, 2H, 2W, Cout], tap
+ * (y, x) of the upsampled image reads stored pixel (y >> 1, x >> 1).  Replaces WanUpsample (nearest-exact 2x,
+ * vae/wan/model.py:225-237) + the Conv2d of WanResample "upsample2d/3d" (:264-273) and diffusers' Upsample2D of the Flux
+ * VAE without materialising the 4x larger image.  independent != 0: frames are independent
+ * images (see apexmi_conv3d_cl_frames). */
+int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                         const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                         int independent, apexmi_stream_t stream);
+
 /* N INDEPENDENT single-frame clips in one launch: in / out are [N, H, W, C] and every frame is convolved as if it were
  * a one-frame clip — of a causal kT-tap kernel only the last temporal tap touches data, the others fall in the zero
  * padding, so the launch iterates kH*kW taps from the last temporal slice of the packed weight.  (A single-frame call

@@ -220,3 +220,39 @@ def test_materialised_attention_rounds_like_the_oracle():
     out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     ref = OL.sdpa_materialized(q.float(), k.float(), v.float(), policy=POL)
     _like(out, ref, "materialised attention C=384")
+
+
+# ------------------------------------------------------------------------------------------------ VAE ops
+@pytest.mark.parametrize("cin,cout,T,H,W,k", [(96, 96, 3, 20, 24, (3, 3, 3)), (192, 96, 2, 16, 16, (3, 3, 3)),
+                                              (384, 384, 2, 10, 12, (3, 3, 3)), (128, 128, 1, 32, 24, (1, 3, 3))])
+def test_conv3d_bias_residual_round_once(cin, cout, T, H, W, k):
+    """Implicit-GEMM convolution: f32 accumulation over all taps, bias and residual added in f32, ONE bf16 rounding."""
+    import torch.nn.functional as F
+    ops = _ops()
+    x = _bf(seeded((T, H, W, cin), 1))
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * k[0] * k[1] * k[2]) ** -0.5))
+    b, res = _bf(seeded((cout,), 3) * 0.1), _bf(seeded((T, H, W, cout), 4))
+    wp = ops.pack_conv_weight(w.to(DEV))
+    xin = F.pad(x.float().permute(3, 0, 1, 2)[None], (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0))
+    ref = F.conv3d(xin, w.float(), b.float())[0].permute(1, 2, 3, 0)
+    _like(ops.conv3d_cl(x.to(DEV), wp, b.to(DEV), k), ref, f"conv3d {cin}->{cout} {k}")
+    _like(ops.conv3d_cl(x.to(DEV), wp, b.to(DEV), k, residual=res.to(DEV)), ref + res.float(), "conv3d + residual")
+
+
+def test_vae_norms_round_once():
+    import torch.nn.functional as F
+    ops = _ops()
+    for C in (96, 192, 384):
+        x = _bf(seeded((2, 9, 11, C), 5) * 2)
+        g = _bf(1 + 0.1 * seeded((C,), 6))
+        for silu in (False, True):
+            out = ops.rmsnorm_cl(x.to(DEV), g.to(DEV), silu=silu)
+            ref = F.normalize(x.float(), dim=-1) * C ** 0.5 * g.float()           # WanRMS_norm.forward, model.py:216-222
+            _like(out, F.silu(ref) if silu else ref, f"rmsnorm_cl C={C} silu={silu}")
+    for C, hw in ((128, (40, 36)), (512, (33, 31))):
+        x = _bf(seeded((1,) + hw + (C,), 21) * 2 + 0.3)
+        g, b = _bf(1 + 0.1 * seeded((C,), 22)), _bf(0.1 * seeded((C,), 23))
+        for silu in (False, True):
+            y = ops.groupnorm_cl(x.to(DEV), g.to(DEV), b.to(DEV), silu=silu)
+            ref = F.group_norm(x.float().permute(0, 3, 1, 2), 32, g.float(), b.float(), eps=1e-6).permute(0, 2, 3, 1)
+            _like(y, F.silu(ref) if silu else ref, f"groupnorm_cl C={C} silu={silu}")

@@ -370,3 +370,22 @@ def test_single_frame_tiles_batched_pass_is_bit_identical():
         one = torch.cat([ops.conv3d_cl(xs[i:i + 1].contiguous(), w, b, (3, 3, 3)) for i in range(5)], dim=0)
         assert torch.equal(ops.conv3d_cl(xs, w, b, (3, 3, 3), independent_frames=True), one)
         assert not torch.equal(ops.conv3d_cl(xs, w, b, (3, 3, 3)), one)            # as one clip the frames DO mix
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,k", [(64, 64, 3, 9, 11, (1, 3, 3)), (96, 48, 1, 16, 8, (1, 3, 3)), (32, 32, 2, 5, 7, (3, 3, 3))])
+def test_conv_reads_through_a_nearest_2x_upsample(cin, cout, T, H, W, k):
+    """`apexmi_conv3d_cl_up2`: the convolution of the upsampled image without materialising it (WanUpsample + Conv2d,
+    reference vae/wan/model.py:225-237, :264-273) must equal upsample2x_cl followed by the plain convolution, bit for bit."""
+    from apex_studio_amd import ops
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * 9) ** -0.5)).to(DEV)
+    b = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    bp = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    bp[:cout] = b
+    two = ops.conv3d_cl(ops.upsample2x_cl(x), wp, bp, k)
+    one = ops.conv3d_cl(x, wp, bp, k, upsample2x=True)
+    assert one.shape == two.shape == (T, 2 * H, 2 * W, wp.shape[0]) and torch.equal(one, two)
+    ref = F.conv3d(F.pad(F.interpolate(x.float().cpu().permute(3, 0, 1, 2)[None], scale_factor=(1, 2, 2), mode="nearest"),
+                         (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0)), w.float().cpu(), b.float().cpu())[0]
+    assert _rel(one[..., :cout].cpu(), ref.permute(1, 2, 3, 0)) < 4e-3
