@@ -198,6 +198,257 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     }
 }
 
+// ---- v2: conv-shaped tiles ---------------------------------------------------------------------------------------
+// The 128x128 kernel above is co-limited by LDS bandwidth (64x64 wave tiles: 4 fragment reads per 4 MFMAs) and wastes
+// a quarter of the matrix work on the 96- and 192-channel stages that hold 3/4 of the Wan decode's FLOPs.  v2 keeps the
+// same LDS image, swizzle and tap gather but uses the GEMM's proportions: 512 threads (two waves per SIMD, ONE
+// workgroup per CU), wave tiles of MT x NT 32x32 MFMA tiles with more MFMAs than fragment reads (64x96: 5 reads per 6
+// MFMAs; 128x64: 6 per 8), and a workgroup tile whose N extent is the layer's channel count:
+//     Cout  96 : 512 x  96  (8 x 1 waves of  64 x 96)        Cout 192 / 384 : 256 x 192  (4 x 2 waves of 64 x 96)
+//     Cout 256k: 256 x 256  (2 x 4 waves of 128 x 64)        Cout <= 32 (conv_out): 512 x 32   Cout 64 / 128: 512 x 64, 256 x 128
+// The gather state is per LANE, not per chunk: all pieces of a lane share the K-chunk column (the swizzle term does not
+// depend on the piece), so one (tap, ci) pair advances per K-tile; per piece only the pixel index of its output position
+// and a 27-bit tap-validity mask are kept (computed once — the positions do not change along K).  Scope: stride 1, zero
+// padding, optionally read through the nearest 2x upsample; everything else stays on the kernel above.
+template <int WMW_, int WNW_, int MT_, int NT_>
+struct ConvCfg {
+    static constexpr int WMW = WMW_, WNW = WNW_, MT = MT_, NT = NT_;
+    static constexpr int NW = WMW * WNW, NTHR = NW * 64;
+    static constexpr int BM = WMW * MT * 32, BN = WNW * NT * 32;
+    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    static constexpr int A_LD = BM * 8 / NTHR;                  // 1 KiB pieces (8 rows) per wave per K-tile
+    static constexpr int W_PIECES = BN / 8;                     // 1 KiB pieces of the weight tile
+    static constexpr int W_LD = (W_PIECES + NW - 1) / NW;
+    static_assert(NW == 8 && BM % 64 == 0 && BN % 32 == 0, "v2 is written for 8 waves (a 4-wave, one-wave-per-SIMD 256x96 tile measured 30 % slower without a hand-rotated pipeline)");
+};
+
+template <typename CFG, int UP>
+__global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int tap_off[MAX_TAPS];
+    constexpr int BM2 = CFG::BM, BN2 = CFG::BN, MT = CFG::MT, NT = CFG::NT, NW = CFG::NW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / CFG::WNW, wn = wave % CFG::WNW;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    if (tid < a.ntaps) {
+        const int dt = tid / (a.kH * a.kW), r = tid % (a.kH * a.kW);
+        const int dy = r / a.kW, dx = r % a.kW;
+        tap_off[tid] = ((dt - (a.kT - 1)) & 0xff) | (((dy - a.py) & 0xff) << 8) | (((dx - a.px) & 0xff) << 16);
+    }
+
+    const int M = a.T * a.H * a.W;
+    const int nn = (a.Cout + BN2 - 1) / BN2;
+    const int nm = (M + BM2 - 1) / BM2;
+    const int s = xcd_remap(blockIdx.x, nm * nn);
+    const int pm = s / nn, pn = s % nn;
+    const int m0 = pm * BM2, n0 = pn * BN2;
+
+    // ---- gather state: byte offset of the piece's pixel + tap-validity mask per piece; (tap, ci) per lane ----
+    // Activation pieces go through buffer_load ... lds: a 32-bit byte offset per lane and no 64-bit address math; an
+    // out-of-range tap is given an offset past the descriptor's range, which reads as zeros (the padding).
+    uint32_t off[CFG::A_LD];
+    uint32_t vmask[CFG::A_LD];
+#pragma unroll
+    for (int i = 0; i < CFG::A_LD; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        const int m = min(m0 + row, M - 1);
+        const int t = m / (a.H * a.W);
+        const int r = m % (a.H * a.W);
+        const int y = r / a.W, x = r % a.W;
+        off[i] = (uint32_t)((t * a.Hin + (y >> UP)) * a.Win + (x >> UP)) * (uint32_t)(a.Cin * 2);
+        uint32_t mk = 0;
+        for (int tap = 0; tap < a.ntaps; ++tap) {
+            const int dt = tap / (a.kH * a.kW) - (a.kT - 1), rr = tap % (a.kH * a.kW);
+            const int dy = rr / a.kW - a.py, dx = rr % a.kW - a.px;
+            const bool ok = (unsigned)(t + dt) < (unsigned)a.T && (unsigned)(y + dy) < (unsigned)a.H &&
+                            (unsigned)(x + dx) < (unsigned)a.W;
+            mk |= (ok ? 1u : 0u) << tap;
+        }
+        vmask[i] = mk | ((uint32_t)(y & 1) << 27) | ((uint32_t)(x & 1) << 28);
+    }
+    auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((int64_t)a.T * a.Hin * a.Win * a.Cin * 2), 0x00020000);
+    const int cchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // (p & 7) ^ ((row >> 1) & 7), same for every piece
+    int a_tap = (cchunk * 8) / a.Cin, a_ci = (cchunk * 8) % a.Cin;
+    const char* w_src[CFG::W_LD];
+#pragma unroll
+    for (int i = 0; i < CFG::W_LD; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        w_src[i] = (const char*)(a.w + (int64_t)min(n0 + row, a.Cout - 1) * a.Kpad + cchunk * 8);
+    }
+    __syncthreads();   // tap_off
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nkt = a.Kext / BK;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * CFG::STAGE + wave * 1024;
+        int delta = 0, dy = 0, dx = 0;
+        uint32_t bit = 0;
+        if (a_tap < a.ntaps) {
+            const int o = tap_off[a_tap];
+            const int dt = (int)(int8_t)(o & 0xff);
+            dy = (int)(int8_t)((o >> 8) & 0xff);
+            dx = (int)(int8_t)((o >> 16) & 0xff);
+            int dpix = dt * a.Hin * a.Win;
+            if (!UP) dpix += dy * a.Win + dx;
+            delta = (dpix * a.Cin + a_ci) * 2;
+            bit = 1u << a_tap;
+        }
+#pragma unroll
+        for (int i = 0; i < CFG::A_LD; ++i) {
+            uint32_t o = off[i] + (uint32_t)delta;
+            if (UP) {   // stored pixel of upsampled (y + dy, x + dx): ((y & 1) + dy) >> 1 rows below (y >> 1), same in x
+                const int d = (((int)((vmask[i] >> 27) & 1u) + dy) >> 1) * a.Win + (((int)((vmask[i] >> 28) & 1u) + dx) >> 1);
+                o += (uint32_t)(d * a.Cin * 2);
+            }
+            o = (vmask[i] & bit) ? o : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(base + i * (NW * 1024)), 16,
+                                                     (int)o, 0, 0, 0);
+        }
+        a_tap += a.q64;
+        a_ci += a.r64;
+        if (a_ci >= a.Cin) {
+            a_ci -= a.Cin;
+            a_tap += 1;
+        }
+        const int64_t koff = (int64_t)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < CFG::W_LD; ++i)
+            if ((i + 1) * NW <= CFG::W_PIECES || i * NW + wave < CFG::W_PIECES)   // wave-uniform
+                glds16(w_src[i] + koff, base + CFG::A_BYTES + i * (NW * 1024));
+    };
+
+    int a_off[MT], a_sw[MT], w_off[NT], w_sw[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int r = wm * (MT * 32) + t * 32 + l31;
+        a_off[t] = r * 128;
+        a_sw[t] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = wn * (NT * 32) + t * 32 + l31;
+        w_off[t] = r * 128;
+        w_sw[t] = (r >> 1) & 7;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char* As = smem + (kt & 1) * CFG::STAGE;
+        const char* Ws = As + CFG::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + hi;
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(As + a_off[t] + ((c ^ a_sw[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(Ws + w_off[t] + ((c ^ w_sw[t]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias (+ residual) -> bf16; lane holds out[m][n .. n+3] per 8-column group ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * hi;
+                if (m >= M || n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
+                if (a.bias != nullptr) {
+                    const u32x2 b = *(const u32x2*)(a.bias + n);
+                    v[0] += bf16_lo(b[0]);
+                    v[1] += bf16_hi(b[0]);
+                    v[2] += bf16_lo(b[1]);
+                    v[3] += bf16_hi(b[1]);
+                }
+                if (a.res != nullptr) {
+                    const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
+                    v[0] += bf16_lo(r[0]);
+                    v[1] += bf16_hi(r[0]);
+                    v[2] += bf16_lo(r[1]);
+                    v[3] += bf16_hi(r[1]);
+                }
+                u32x2 o;
+                o[0] = pack_bf16(v[0], v[1]);
+                o[1] = pack_bf16(v[2], v[3]);
+                *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = o;
+            }
+    }
+}
+
+using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
+using CV_N64 = ConvCfg<8, 1, 2, 2>;    // 512 x 64
+using CV_N96 = ConvCfg<8, 1, 2, 3>;    // 512 x 96
+using CV_N128 = ConvCfg<4, 2, 2, 2>;   // 256 x 128
+using CV_N192 = ConvCfg<4, 2, 2, 3>;   // 256 x 192
+using CV_N256 = ConvCfg<2, 4, 4, 2>;   // 256 x 256
+
+int g_conv_v2 = 1;   // apexmi_tune_set("conv.v2", 0/1)
+
+template <typename CFG>
+int launch_v2(const ConvArgs& a, hipStream_t stream) {
+    const int64_t M = (int64_t)a.T * a.H * a.W;
+    const int nm = (int)((M + CFG::BM - 1) / CFG::BM), nn = (a.Cout + CFG::BN - 1) / CFG::BN;
+    static uint64_t attr[2] = {0, 0};
+    if (a.up) {
+        if (apexmi_once_per_device(attr[1]))
+            (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
+        hipLaunchKernelGGL((conv3d_v2_kernel<CFG, 1>), dim3(nm * nn), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
+    } else {
+        if (apexmi_once_per_device(attr[0]))
+            (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
+        hipLaunchKernelGGL((conv3d_v2_kernel<CFG, 0>), dim3(nm * nn), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
+    }
+    return apexmi_check_launch("conv3d_cl (v2)");
+}
+
+// tile choice: the N extent that wastes the fewest matrix columns; v2 only where it fills the chip
+int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
+    *taken = false;
+    const int64_t M = (int64_t)a.T * a.H * a.W;
+    if (!g_conv_v2 || a.replicate || a.sy != 1 || a.sx != 1 || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
+        (int64_t)a.T * a.Hin * a.Win * a.Cin * 2 >= ((int64_t)1 << 31))   // 32-bit byte offsets in the gather
+        return 0;
+    const int c = a.Cout;
+    *taken = true;
+    if (c <= 32) return launch_v2<CV_N32>(a, stream);
+    if (c <= 64) return launch_v2<CV_N64>(a, stream);
+    if (c <= 96) return launch_v2<CV_N96>(a, stream);
+    if (c <= 128) {           // 256 x 128 (64 x 64 wave tiles) measured 9 % slower than the 128 x 128 kernel: stay on it
+        *taken = false;
+        return 0;
+    }
+    if (c % 192 == 0 || (c > 128 && c <= 192)) return launch_v2<CV_N192>(a, stream);
+    if (c % 256 == 0) return launch_v2<CV_N256>(a, stream);
+    if (c % 128 == 0) return launch_v2<CV_N128>(a, stream);
+    return launch_v2<CV_N192>(a, stream);
+}
+
 // ---- channels-last elementwise companions --------------------------------------------------------
 
 // y = silu?( x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c] ) per position  (WanRMS_norm.forward, reference
@@ -426,6 +677,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 
 }  // namespace
+void apexmi_set_conv_v2(int v) { g_conv_v2 = v; }
 
 extern "C" size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C) {
     const int nblk = (int)((P + 1023) / 1024);
@@ -517,6 +769,9 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
                          2.0 * ((double)M * Cin + (double)Cout * Kext + (double)M * Cout));
+    bool taken = false;
+    const int rc2 = launch_v2_for(a, stream, &taken);
+    if (taken) return rc2;
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
     return apexmi_check_launch("conv3d_cl");
 }

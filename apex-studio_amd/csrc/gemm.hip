@@ -968,10 +968,15 @@ void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
 void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
+void apexmi_set_conv_v2(int v);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
     if (key && !strcmp(key, "gemm.tail")) {
         g_tail_split = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "conv.v2")) {
+        apexmi_set_conv_v2(value);
         return 0;
     }
     if (key && !strcmp(key, "attn.split")) {

@@ -163,6 +163,9 @@ int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk,
 /* Tuning knobs for A/B measurements (bench.py --tune, tests); defaults are the shipped choices:
  *   "gemm.config"  0 auto | 1 128x128 | 2 256x256 | 3 256x256 ping-pong 32x32x16 | 6 one wave per SIMD | 7 ping-pong 16x16x32
  *   "gemm.large"   tiling the auto rule picks for large problems (7)      "gemm.group_m"  rows of a tile-order group (8)
+ *   "conv.v2"      1 (default): stride-1 zero-padded convolutions over >= 65536 positions use the conv-shaped tiles
+ *                  (conv3d_v2_kernel: 512x96 / 256x192 / 256x256 / 512x32|64 by Cout); 0: always the 128x128 kernel.
+ *                  Bit-identical results either way.
  *   "gemm.tail"    1: a small last problem of a grouped launch after whole rounds of tiles goes out on the 128x128 tiling
  *   "attn.waves"   0 auto | 4..8 waves per attention workgroup            "attn.mfma"     32 | 16
  *   "attn.c4"      1: 4-cluster ping-pong kernel | 2: same + s_setprio | 0: plain loop

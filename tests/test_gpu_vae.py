@@ -389,3 +389,30 @@ def test_conv_reads_through_a_nearest_2x_upsample(cin, cout, T, H, W, k):
     ref = F.conv3d(F.pad(F.interpolate(x.float().cpu().permute(3, 0, 1, 2)[None], scale_factor=(1, 2, 2), mode="nearest"),
                          (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0)), w.float().cpu(), b.float().cpu())[0]
     assert _rel(one[..., :cout].cpu(), ref.permute(1, 2, 3, 0)) < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,k,up", [(96, 96, 5, 128, 128, (3, 3, 3), False), (192, 192, 3, 150, 160, (3, 3, 3), False),
+                                                 (192, 96, 2, 96, 100, (1, 3, 3), True), (384, 384, 9, 96, 96, (3, 3, 3), False),
+                                                 (96, 3, 3, 160, 144, (3, 3, 3), False), (256, 256, 1, 300, 260, (1, 3, 3), False),
+                                                 (64, 64, 2, 200, 180, (3, 3, 3), False), (96, 96, 1, 300, 300, (3, 3, 3), False)])
+def test_conv_v2_tiles_are_bit_identical_to_the_128x128_kernel(cin, cout, T, H, W, k, up):
+    """The conv-shaped tilings (512x96, 256x192, 256x256, 512x32/64; `conv.v2`) gather through buffer_load ... lds with a
+    per-piece tap-validity mask; same K order per output element as the 128x128 kernel, so the results must be equal
+    bit for bit — ragged M, the upsample fold, the single-frame tap skip and bias + residual included."""
+    from apex_studio_amd import lib, ops
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * k[0] * k[1] * k[2]) ** -0.5)).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    b = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    b[:cout] = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _bf(seeded((T, Ho, Wo, wp.shape[0]), 4)).to(DEV)
+    outs = []
+    try:
+        for v2 in (0, 1):
+            lib.tune_set("conv.v2", v2)
+            outs.append((ops.conv3d_cl(x, wp, b, k, upsample2x=up), ops.conv3d_cl(x, wp, b, k, residual=res, upsample2x=up)))
+    finally:
+        lib.tune_set("conv.v2", 1)
+    assert T * Ho * Wo >= 65536, "shape must be large enough for the v2 dispatch"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
