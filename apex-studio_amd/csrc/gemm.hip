@@ -962,59 +962,12 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     return launch_group(G, M, kind, stream);
 }
 
-void apexmi_set_attn_waves(int v);
-void apexmi_set_attn_mfma(int v);
-void apexmi_set_ln_wave(int v);
-void apexmi_set_attn_c4(int v);
-void apexmi_set_qk_group(int v);
-void apexmi_set_attn_split(int v);
-void apexmi_set_conv_v2(int v);
-
-extern "C" int apexmi_tune_set(const char* key, int value) {
-    if (key && !strcmp(key, "gemm.tail")) {
-        g_tail_split = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "conv.v2")) {
-        apexmi_set_conv_v2(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "attn.split")) {
-        apexmi_set_attn_split(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "qk.group")) {
-        apexmi_set_qk_group(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "attn.waves")) {
-        apexmi_set_attn_waves(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "attn.c4")) {
-        apexmi_set_attn_c4(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "ln.wave")) {
-        apexmi_set_ln_wave(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "attn.mfma")) {
-        apexmi_set_attn_mfma(value);
-        return 0;
-    }
-    if (key && !strcmp(key, "gemm.group_m")) {
-        g_group_m = value > 0 ? value : GROUP_M;
-        return 0;
-    }
-    if (key && !strcmp(key, "gemm.large")) {
-        g_large_cfg = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "gemm.config")) {
-        g_force_cfg = value;
-        return 0;
-    }
-    apexmi_set_error("tune_set: unknown key");
-    return 1;
+// tuning keys of this file (dispatched from apexmi_tune_set, runtime.hip)
+int apexmi_set_gemm_key(const char* key, int value) {
+    if (!strcmp(key, "gemm.tail")) g_tail_split = value;
+    else if (!strcmp(key, "gemm.group_m")) g_group_m = value > 0 ? value : GROUP_M;
+    else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
+    else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
+    else return 1;
+    return 0;
 }

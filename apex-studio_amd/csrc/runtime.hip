@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -111,4 +112,47 @@ extern "C" int apexmi_prof_read(double ms[APEXMI_NCLASS], int64_t launches[APEXM
         bytes[r.cls] += r.bytes;
     }
     return 0;
+}
+
+// ---- tuning switches (A/B levers; defaults are the shipped configuration, include/apexmi.h lists the keys) ----
+void apexmi_set_attn_waves(int v);
+void apexmi_set_attn_mfma(int v);
+void apexmi_set_ln_wave(int v);
+void apexmi_set_attn_c4(int v);
+void apexmi_set_qk_group(int v);
+void apexmi_set_attn_split(int v);
+void apexmi_set_conv_v2(int v);
+int apexmi_set_gemm_key(const char* key, int value);
+
+extern "C" int apexmi_tune_set(const char* key, int value) {
+    if (!key) {
+        apexmi_set_error("tune_set: null key");
+        return 1;
+    }
+    if (!strncmp(key, "gemm.", 5)) {
+        if (apexmi_set_gemm_key(key, value) == 0) return 0;
+    } else if (!strcmp(key, "conv.v2")) {
+        apexmi_set_conv_v2(value);
+        return 0;
+    } else if (!strcmp(key, "attn.split")) {
+        apexmi_set_attn_split(value);
+        return 0;
+    } else if (!strcmp(key, "qk.group")) {
+        apexmi_set_qk_group(value);
+        return 0;
+    } else if (!strcmp(key, "attn.waves")) {
+        apexmi_set_attn_waves(value);
+        return 0;
+    } else if (!strcmp(key, "attn.c4")) {
+        apexmi_set_attn_c4(value);
+        return 0;
+    } else if (!strcmp(key, "ln.wave")) {
+        apexmi_set_ln_wave(value);
+        return 0;
+    } else if (!strcmp(key, "attn.mfma")) {
+        apexmi_set_attn_mfma(value);
+        return 0;
+    }
+    apexmi_set_error("tune_set: unknown key");
+    return 1;
 }

@@ -40,9 +40,9 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, pol: Policy):
+        s = x if self.conv_shortcut is None else pol.r(self.conv_shortcut(x))      # storage points in launch order
         h = pol.r(self.conv1(pol.r(F.silu(self.norm1(x)))))
         h = self.conv2(pol.r(F.silu(self.norm2(h))))
-        s = x if self.conv_shortcut is None else pol.r(self.conv_shortcut(x))
         return pol.r(h + s)
 
 

@@ -68,7 +68,8 @@ class ResidualBlock(nn.Module):
         self.conv_shortcut = CausalConv3d(cin, cout, 1) if cin != cout else nn.Identity()
 
     def forward(self, x, pol: Policy):
-        h = pol.r(self.conv_shortcut(x))
+        # x is a stored tensor already: an Identity shortcut is not a new storage point
+        h = x if isinstance(self.conv_shortcut, nn.Identity) else pol.r(self.conv_shortcut(x))
         y = pol.r(self.conv1(pol.r(F.silu(self.norm1(x)))))
         y = self.conv2(pol.r(F.silu(self.norm2(y))))
         return pol.r(y + h)

@@ -78,7 +78,7 @@ def _flux_vae_pair(cfg, seed):
     sd = vae_synthetic_state_dict(orc, seed)
     for k in list(sd):                     # GroupNorm affine: weight ~ 1, bias small
         if ".norm" in k or "group_norm" in k or "conv_norm_out" in k:
-            sd[k] = (torch.ones_like(sd[k]) if k.endswith("weight") else torch.zeros_like(sd[k])) + 0.05 * sd[k].sign()
+            sd[k] = ((torch.ones_like(sd[k]) if k.endswith("weight") else torch.zeros_like(sd[k])) + 0.05 * sd[k].sign()).to(torch.bfloat16).float()   # bf16-representable, like every other weight
     orc.load_state_dict(sd, strict=True)
     vae = AutoencoderKL(**cfg, device=DEV, dtype=BF)
     vae.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)

@@ -122,3 +122,47 @@ def test_qwen_every_storage_point(name):
     free = m(**kw)[0]
     out, report = SP.run_forced(ops, m, plan, lambda: m(**kw)[0])
     _finish(f"qwen {name}", report, out, po, free, ref16)
+
+
+# ---- VAEs: one storage-writing op per oracle storage point, in order (tests/stage_parity.run_forced_vae) -------------
+def test_wan_vae_decode_every_storage_point():
+    """Wan / QwenImage 3-D VAE decoder, 3 latent frames (first frame, the "Rep" frame and a steady one): causal 3x3x3
+    convs, RMS norm + SiLU, mid-block attention, time_conv + frame interleave, upsample folded into the conv."""
+    from oracle.vae_wan import AutoencoderKLWanDecoder
+    from apex_studio_amd import ops
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from tests.golden.seeded import vae_synthetic_state_dict
+    cfg = dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True])
+    orc = AutoencoderKLWanDecoder(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, 13)
+    orc.load_state_dict(sd, strict=True)
+    vae = AutoencoderKLWan(**cfg, device=DEV, dtype=torch.bfloat16)
+    assert not vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=False).unexpected_keys
+    z = seeded((1, 16, 3, 20, 24), 61).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    ref16 = orc.decode(z.float(), policy=pol)
+    free = vae.decode(z.to(DEV), return_dict=False)[0]
+    out, report = SP.run_forced_vae(ops, pol.points, lambda: vae.decode(z.to(DEV), return_dict=False)[0])
+    worst, _ = SP.print_report("wan vae decode", report)
+    assert worst <= SP.STAGE_TOL, worst
+    e_out, e_free = _rel(out, ref16), _rel(free, ref16)
+    print(f"[stage wan vae decode] decoded output after the last forced point: rel {e_out:.2e}; free-running decode {e_free:.2e}")
+    assert e_out <= SP.STAGE_TOL and e_free < 2e-2
+
+
+def test_flux_vae_decode_every_storage_point():
+    """Flux 2-D VAE decoder: GroupNorm + SiLU, 3x3 convs, 1x1 shortcuts, single-head mid-block attention (flash kernel,
+    head dim 128), nearest-2x + conv upsamplers."""
+    from apex_studio_amd import ops
+    from tests.test_gpu_end_to_end import _flux_vae_pair
+    orc, vae = _flux_vae_pair(dict(latent_channels=16, block_out_channels=(32, 64, 128, 128), layers_per_block=1), 19)
+    z = seeded((1, 16, 20, 24), 63).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    ref16 = orc.decode(z.float(), policy=pol)
+    free = vae.decode(z.to(DEV), return_dict=False)[0]
+    out, report = SP.run_forced_vae(ops, pol.points, lambda: vae.decode(z.to(DEV), return_dict=False)[0])
+    worst, _ = SP.print_report("flux vae decode", report)
+    assert worst <= SP.STAGE_TOL, worst
+    e_out, e_free = _rel(out, ref16), _rel(free, ref16)
+    print(f"[stage flux vae decode] decoded output after the last forced point: rel {e_out:.2e}; free-running decode {e_free:.2e}")
+    assert e_out <= SP.STAGE_TOL and e_free < 2e-2

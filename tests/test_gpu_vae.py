@@ -153,7 +153,7 @@ def test_flux_vae_decode_matches_oracle():
     sd = vae_synthetic_state_dict(orc, 19)
     for k in list(sd):                     # GroupNorm affine: weight ~ 1, bias small (the generic rule made them N(0,..))
         if ".norm" in k or "group_norm" in k or "conv_norm_out" in k:
-            sd[k] = (torch.ones_like(sd[k]) if k.endswith("weight") else torch.zeros_like(sd[k])) + 0.05 * sd[k].sign()
+            sd[k] = ((torch.ones_like(sd[k]) if k.endswith("weight") else torch.zeros_like(sd[k])) + 0.05 * sd[k].sign()).to(torch.bfloat16).float()   # bf16-representable, like every other weight
     orc.load_state_dict(sd, strict=True)
     vae = AutoencoderKL(**cfg, device=DEV, dtype=torch.bfloat16)
     assert sorted(vae.state_dict().keys()) == sorted(sd.keys())
