@@ -42,6 +42,11 @@ struct ConvArgs {
                           // ZeroPad2d((0,1,0,1)) + stride-2 downsampling convolution of the VAE encoders)
     int up;               // 1: the input is read through a nearest 2x spatial upsample (H, W are the UPSAMPLED extents,
     int Hin, Win;         //    the stored image is Hin x Win = H/2 x W/2 and tap (y, x) reads pixel (y >> 1, x >> 1))
+    // fused RMS norm of the OUTPUT (v2 tiles that hold all Cout channels of a position): out_norm = [silu](y_bf16 /
+    // max(||y||, 1e-12) * sqrt(Cout) * gamma) from the bf16-rounded y = conv + bias (+ residual); out may be null
+    const bf16_t* norm_gamma;
+    bf16_t* out_norm;
+    int norm_silu;
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
@@ -222,7 +227,7 @@ struct ConvCfg {
     static_assert(NW == 8 && BM % 64 == 0 && BN % 32 == 0, "v2 is written for 8 waves (a 4-wave, one-wave-per-SIMD 256x96 tile measured 30 % slower without a hand-rotated pipeline)");
 };
 
-template <typename CFG, int UP>
+template <typename CFG, int UP, int NORM = 0>
 __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int tap_off[MAX_TAPS];
@@ -366,38 +371,155 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
         }
     }
 
-    // ---- epilogue: bias (+ residual) -> bf16; lane holds out[m][n .. n+3] per 8-column group ----
+    // ---- epilogue: bias (+ residual) -> bf16.  A lane holds out[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3, per 32-column
+    // tile; pairs of groups are exchanged with the other half-wave (v_permlane32_swap) into 8 CONSECUTIVE columns, so
+    // residual loads and stores are 16 bytes per lane (the GEMM's epilogue trick).
+    auto swap_pair = [](u32x2& x, u32x2& y) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            auto r = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);
+            x[i] = r[0];
+            y[i] = r[1];
+        }
+    };
+    float ssq[MT];
+    if (!NORM && (a.Cout & 7) != 0) {   // Cout = 4 (conv_out, 3 channels + pad): 8-byte accesses, no exchange
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * hi;
+                    if (m >= M || n >= a.Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
+                    if (a.bias != nullptr) {
+                        const u32x2 b = *(const u32x2*)(a.bias + n);
+                        v[0] += bf16_lo(b[0]);
+                        v[1] += bf16_hi(b[0]);
+                        v[2] += bf16_lo(b[1]);
+                        v[3] += bf16_hi(b[1]);
+                    }
+                    if (a.res != nullptr) {
+                        const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
+                        v[0] += bf16_lo(r[0]);
+                        v[1] += bf16_hi(r[0]);
+                        v[2] += bf16_lo(r[1]);
+                        v[3] += bf16_hi(r[1]);
+                    }
+                    *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        ssq[mt] = 0.0f;
         const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
+        const int64_t mrow = (int64_t)min(m, M - 1) * a.Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * hi;
-                if (m >= M || n >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
-                if (a.bias != nullptr) {
-                    const u32x2 b = *(const u32x2*)(a.bias + n);
-                    v[0] += bf16_lo(b[0]);
-                    v[1] += bf16_hi(b[0]);
-                    v[2] += bf16_lo(b[1]);
-                    v[3] += bf16_hi(b[1]);
-                }
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nb = n0 + wn * (NT * 32) + nt * 32;
+                const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
+                if (nb + 16 * pr >= a.Cout) continue;             // wave-uniform; lanes past Cout inside the pair store nothing
+                u32x2 ra = {0u, 0u}, rb = {0u, 0u};
                 if (a.res != nullptr) {
-                    const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
-                    v[0] += bf16_lo(r[0]);
-                    v[1] += bf16_hi(r[0]);
-                    v[2] += bf16_lo(r[1]);
-                    v[3] += bf16_hi(r[1]);
+                    const u32x4 rr = *(const u32x4*)(a.res + mrow + min(nst, a.Cout - 8));
+                    ra = u32x2{rr[0], rr[1]};
+                    rb = u32x2{rr[2], rr[3]};
+                    swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
                 }
-                u32x2 o;
-                o[0] = pack_bf16(v[0], v[1]);
-                o[1] = pack_bf16(v[2], v[3]);
-                *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = o;
+                u32x2 o[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * pr + q;
+                    const int n = min(nb + 8 * g + 4 * hi, a.Cout - 4);
+                    float v[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
+                    if (a.bias != nullptr) {
+                        const u32x2 b = *(const u32x2*)(a.bias + n);
+                        v[0] += bf16_lo(b[0]);
+                        v[1] += bf16_hi(b[0]);
+                        v[2] += bf16_lo(b[1]);
+                        v[3] += bf16_hi(b[1]);
+                    }
+                    const u32x2 r2 = q ? rb : ra;
+                    v[0] += bf16_lo(r2[0]);
+                    v[1] += bf16_hi(r2[0]);
+                    v[2] += bf16_lo(r2[1]);
+                    v[3] += bf16_hi(r2[1]);
+                    o[q][0] = pack_bf16(v[0], v[1]);
+                    o[q][1] = pack_bf16(v[2], v[3]);
+                    if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
+                        const float r0 = bf16_lo(o[q][0]), r1 = bf16_hi(o[q][0]), r2f = bf16_lo(o[q][1]), r3 = bf16_hi(o[q][1]);
+                        acc[nt][mt][4 * g + 0] = r0;
+                        acc[nt][mt][4 * g + 1] = r1;
+                        acc[nt][mt][4 * g + 2] = r2f;
+                        acc[nt][mt][4 * g + 3] = r3;
+                        if (nb + 8 * g + 4 * hi < a.Cout) ssq[mt] += r0 * r0 + r1 * r1 + r2f * r2f + r3 * r3;
+                    }
+                }
+                if (!NORM || a.out != nullptr) {
+                    swap_pair(o[0], o[1]);
+                    if (m < M && nst < a.Cout) *(u32x4*)(a.out + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                }
             }
+    }
+    if constexpr (NORM) {
+        // a row's channels: this lane's groups + those of lane ^ 32, and (WNW > 1) the other waves of the row through LDS
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ssq[mt] = sum_xor32(ssq[mt]);
+        if constexpr (CFG::WNW > 1) {
+            float* red = (float*)smem;          // the staging buffers are free: every wave is past its last fragment read
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (hi == 0) red[(wm * (MT * 32) + mt * 32 + l31) * CFG::WNW + wn] = ssq[mt];
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < CFG::WNW; ++w) t += red[(wm * (MT * 32) + mt * 32 + l31) * CFG::WNW + w];
+                ssq[mt] = t;
+            }
+        }
+        const float root_c = sqrtf((float)a.Cout);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
+            const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int nb = n0 + wn * (NT * 32) + nt * 32;
+                    const int nst = nb + 8 * (2 * pr + hi);
+                    if (nb + 16 * pr >= a.Cout) continue;
+                    u32x2 o[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * pr + q;
+                        const u32x2 gm = *(const u32x2*)(a.norm_gamma + min(nb + 8 * g + 4 * hi, a.Cout - 4));
+                        float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
+                                      acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
+                        if (a.norm_silu) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
+                        }
+                        o[q][0] = pack_bf16(y[0], y[1]);
+                        o[q][1] = pack_bf16(y[2], y[3]);
+                    }
+                    swap_pair(o[0], o[1]);
+                    if (m < M && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                }
+        }
     }
 }
 
@@ -410,21 +532,27 @@ using CV_N256 = ConvCfg<2, 4, 4, 2>;   // 256 x 256
 
 int g_conv_v2 = 1;   // apexmi_tune_set("conv.v2", 0/1)
 
-template <typename CFG>
+template <typename CFG, int UP, int NORM>
+int launch_v2_inst(const ConvArgs& a, hipStream_t stream, int grid) {
+    static uint64_t attr = 0;
+    if (apexmi_once_per_device(attr))
+        (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, UP, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
+    hipLaunchKernelGGL((conv3d_v2_kernel<CFG, UP, NORM>), dim3(grid), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
+    return apexmi_check_launch("conv3d_cl (v2)");
+}
+
+template <typename CFG, bool CAN_NORM = false>
 int launch_v2(const ConvArgs& a, hipStream_t stream) {
     const int64_t M = (int64_t)a.T * a.H * a.W;
     const int nm = (int)((M + CFG::BM - 1) / CFG::BM), nn = (a.Cout + CFG::BN - 1) / CFG::BN;
-    static uint64_t attr[2] = {0, 0};
-    if (a.up) {
-        if (apexmi_once_per_device(attr[1]))
-            (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
-        hipLaunchKernelGGL((conv3d_v2_kernel<CFG, 1>), dim3(nm * nn), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
-    } else {
-        if (apexmi_once_per_device(attr[0]))
-            (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
-        hipLaunchKernelGGL((conv3d_v2_kernel<CFG, 0>), dim3(nm * nn), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
+    if (a.out_norm != nullptr) {
+        if constexpr (CAN_NORM) {
+            if (nn == 1) return a.up ? launch_v2_inst<CFG, 1, 1>(a, stream, nm) : launch_v2_inst<CFG, 0, 1>(a, stream, nm);
+        }
+        apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of this tiling (see apexmi_conv3d_cl_norm_fusable)", a.Cout);
+        return 1;
     }
-    return apexmi_check_launch("conv3d_cl (v2)");
+    return a.up ? launch_v2_inst<CFG, 1, 0>(a, stream, nm * nn) : launch_v2_inst<CFG, 0, 0>(a, stream, nm * nn);
 }
 
 // tile choice: the N extent that wastes the fewest matrix columns; v2 only where it fills the chip
@@ -436,14 +564,14 @@ int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
         return 0;
     const int c = a.Cout;
     *taken = true;
-    if (c <= 32) return launch_v2<CV_N32>(a, stream);
-    if (c <= 64) return launch_v2<CV_N64>(a, stream);
-    if (c <= 96) return launch_v2<CV_N96>(a, stream);
+    if (c <= 32) return launch_v2<CV_N32, true>(a, stream);
+    if (c <= 64) return launch_v2<CV_N64, true>(a, stream);
+    if (c <= 96) return launch_v2<CV_N96, true>(a, stream);
     if (c <= 128) {           // 256 x 128 (64 x 64 wave tiles) measured 9 % slower than the 128 x 128 kernel: stay on it
         *taken = false;
         return 0;
     }
-    if (c % 192 == 0 || (c > 128 && c <= 192)) return launch_v2<CV_N192>(a, stream);
+    if (c % 192 == 0 || (c > 128 && c <= 192)) return launch_v2<CV_N192, true>(a, stream);
     if (c % 256 == 0) return launch_v2<CV_N256>(a, stream);
     if (c % 128 == 0) return launch_v2<CV_N128>(a, stream);
     return launch_v2<CV_N192>(a, stream);
@@ -708,7 +836,8 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
 static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
-                          int Ho = 0, int Wo = 0, int independent = 0, int up = 0) {
+                          int Ho = 0, int Wo = 0, int independent = 0, int up = 0, const void* norm_gamma = nullptr,
+                          void* out_norm = nullptr, int norm_silu = 0) {
     const int Hin = H, Win = W;
     if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
         H *= 2;
@@ -719,7 +848,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     if (Ho <= 0) Ho = H;
     if (Wo <= 0) Wo = W;
     hipStream_t stream = (hipStream_t)stream_;
-    APEXMI_REQUIRE(in && w && out && zeros, "conv3d_cl: null operand");
+    APEXMI_REQUIRE(in && w && (out || out_norm) && zeros, "conv3d_cl: null operand");
     APEXMI_REQUIRE(T > 0 && H > 0 && W > 0, "conv3d_cl: empty volume");
     APEXMI_REQUIRE(Cin % 8 == 0 && Cout % 4 == 0, "conv3d_cl: Cin=%d must be a multiple of 8, Cout=%d of 4", Cin, Cout);
     const int ntaps = kT * kH * kW;
@@ -765,6 +894,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.replicate = replicate;
     a.Ho = Ho; a.Wo = Wo; a.sy = sy; a.sx = sx; a.py = py; a.px = px;
     a.up = up ? 1 : 0; a.Hin = Hin; a.Win = Win;
+    a.norm_gamma = (const bf16_t*)norm_gamma; a.out_norm = (bf16_t*)out_norm; a.norm_silu = norm_silu;
     const int64_t M = (int64_t)T * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
@@ -772,6 +902,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     bool taken = false;
     const int rc2 = launch_v2_for(a, stream, &taken);
     if (taken) return rc2;
+    APEXMI_REQUIRE(out_norm == nullptr, "conv3d_cl_norm: this convolution does not run on the fused-norm tiles "
+                                        "(ask apexmi_conv3d_cl_norm_fusable first)");
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
     return apexmi_check_launch("conv3d_cl");
 }
@@ -787,6 +919,23 @@ extern "C" int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* b
                                     int kW, int independent, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
                           0, 0, independent, 1);
+}
+
+// can apexmi_conv3d_cl_norm run this shape?  (stride-1 zero-padded conv on the v2 tiles with every output channel of a
+// position inside one workgroup tile: Cout <= 96 or 128 < Cout <= 192)
+extern "C" int apexmi_conv3d_cl_norm_fusable(int T, int H, int W, int Cin, int Cout, int up) {
+    const int64_t M = (int64_t)T * H * W * (up ? 4 : 1);
+    return g_conv_v2 && M >= 65536 && (int64_t)T * H * W * Cin * 2 < ((int64_t)1 << 31) && (Cout <= 96 || (Cout > 128 && Cout <= 192));
+}
+
+extern "C" int apexmi_conv3d_cl_norm(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                     void* out_norm, const void* gamma, int silu, const void* zeros, int T, int H, int W,
+                                     int Cin, int Cout, int Kpad, int kT, int kH, int kW, int independent, int up,
+                                     apexmi_stream_t stream_) {
+    APEXMI_REQUIRE(out_norm && gamma, "conv3d_cl_norm: out_norm and gamma are required");
+    APEXMI_REQUIRE(Cout % 8 == 0, "conv3d_cl_norm: Cout=%d must be a multiple of 8", Cout);
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
+                          0, 0, independent, up, gamma, out_norm, silu);
 }
 
 extern "C" int apexmi_conv3d_cl_frames(const void* in, const void* w, const void* bias, const void* residual,

@@ -618,6 +618,38 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def conv3d_cl_norm_fusable(x: torch.Tensor, cout: int, upsample2x: bool = False) -> bool:
+    T, H, W, cin = x.shape
+    return bool(_l.load().apexmi_conv3d_cl_norm_fusable(T, H, W, cin, cout, 1 if upsample2x else 0))
+
+
+def conv3d_cl_norm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize, gamma: torch.Tensor,
+                   silu: bool = True, residual: Optional[torch.Tensor] = None, want_raw: bool = True,
+                   upsample2x: bool = False, independent_frames: bool = False):
+    """conv3d_cl with the RMS norm (+ SiLU) of its output fused into the epilogue: returns (y or None, norm(y)).
+    Shapes the fused tiles do not cover (`conv3d_cl_norm_fusable`) run as conv3d_cl + rmsnorm_cl — same values."""
+    _req(x, torch.bfloat16, "conv3d_cl_norm.x")
+    _req(gamma, torch.bfloat16, "conv3d_cl_norm.gamma")
+    cout, kpad = w_packed.shape
+    if gamma.numel() != cout or not conv3d_cl_norm_fusable(x, cout, upsample2x):
+        y = conv3d_cl(x, w_packed, bias, ksize, residual=residual, upsample2x=upsample2x, independent_frames=independent_frames)
+        g = gamma if gamma.numel() == cout else torch.cat([gamma, gamma.new_zeros(cout - gamma.numel())])
+        return (y if want_raw else None), rmsnorm_cl(y, g, silu=silu)
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous() and gamma.is_contiguous()
+    T, H, W, cin = x.shape
+    Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
+    y = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device) if want_raw else None
+    yn = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == yn.shape and residual.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl_norm(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), _ptr(y), yn.data_ptr(),
+                                         gamma.data_ptr(), 1 if silu else 0, _zeros16(x.device).data_ptr(), T, H, W, cin, cout,
+                                         kpad, int(ksize[0]), int(ksize[1]), int(ksize[2]), 1 if independent_frames else 0,
+                                         1 if upsample2x else 0, _stream())
+    _l.check(rc, "conv3d_cl_norm")
+    return y, yn
+
+
 def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """ZeroPad2d((0, 1, 0, 1)) + Conv2d(3x3, stride 2) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4] with
     Ho = (H - 2) // 2 + 1 (= H / 2 for even H); w_packed from pack_conv_weight of the [Cout, Cin, 3, 3] weight."""

@@ -298,15 +298,36 @@ class AutoencoderKLWan(nn.Module):
             self._indep = False
         return outs
 
-    def _res(self, blk: _Res, x):
-        h = x if isinstance(blk.conv_shortcut, nn.Identity) else self._conv(blk.conv_shortcut, x)
-        y = self._conv(blk.conv1, ops.rmsnorm_cl(x, blk.norm1.gamma.data.reshape(-1).contiguous(), silu=True))
-        return self._conv(blk.conv2, ops.rmsnorm_cl(y, blk.norm2.gamma.data.reshape(-1).contiguous(), silu=True),
-                          residual=h)
+    @staticmethod
+    def _gamma(n):
+        return n.gamma.data.reshape(-1).contiguous()
 
-    def _attn(self, blk: _Attn, x):
+    def _conv_norm(self, conv: _Conv, x, gamma, silu=True, residual=None, want_raw=True, upsample2x=False):
+        """A convolution whose output's RMS norm (+ SiLU) — the consumer's `norm1` / `norm2` / `norm_out` — is produced
+        in the conv's own epilogue (`apexmi_conv3d_cl_norm`) instead of a separate read-modify-write pass over the
+        tensor; shapes the fused tiles do not cover fall back to the two launches inside `ops.conv3d_cl_norm`."""
+        w, b = self._w(conv)
+        k = conv.ksize if len(conv.ksize) == 3 else (1,) + conv.ksize
+        g = gamma if gamma.numel() == w.shape[0] else torch.cat([gamma, gamma.new_zeros(w.shape[0] - gamma.numel())])
+        return ops.conv3d_cl_norm(x, w, b, k, g, silu=silu, residual=residual, want_raw=want_raw, upsample2x=upsample2x,
+                                  independent_frames=self._indep and k[0] > 1)
+
+    def _res(self, blk: _Res, x, xn=None, next_norm=None):
+        """WanResidualBlock (reference vae/wan/model.py:389-441).  `xn` = silu(norm1(x)) when the producer of x already
+        made it; `next_norm` = (gamma, silu) of the norm that will read this block's output.  conv1's output is read by
+        norm2 only, so it is never stored: conv1 writes silu(norm2(.)) directly.  Returns (out, normed out or None)."""
+        h = x if isinstance(blk.conv_shortcut, nn.Identity) else self._conv(blk.conv_shortcut, x)
+        if xn is None:
+            xn = ops.rmsnorm_cl(x, self._gamma(blk.norm1), silu=True)
+        _, n2 = self._conv_norm(blk.conv1, xn, self._gamma(blk.norm2), silu=True, want_raw=False)
+        if next_norm is None:
+            return self._conv(blk.conv2, n2, residual=h), None
+        return self._conv_norm(blk.conv2, n2, next_norm[0], silu=next_norm[1], residual=h)
+
+    def _attn(self, blk: _Attn, x, n=None):
         T, H, W, Cc = x.shape
-        n = ops.rmsnorm_cl(x, blk.norm.gamma.data.reshape(-1).contiguous())
+        if n is None:
+            n = ops.rmsnorm_cl(x, blk.norm.gamma.data.reshape(-1).contiguous())
         qkv = ops.gemm(n.view(T * H * W, Cc), blk.to_qkv.weight.data.reshape(3 * Cc, Cc), blk.to_qkv.bias.data)
         qkv = qkv.view(T, 1, H * W, 3 * Cc)
         o = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:])     # [T,1,HW,C] view
@@ -316,29 +337,46 @@ class AutoencoderKLWan(nn.Module):
                        gate=ones, residual=x.view(T * H * W, Cc))
         return out.view(T, H, W, Cc)
 
-    def _resample(self, up: _Resample, x):
+    def _resample(self, up: _Resample, x, next_norm=None):
         T = x.shape[0]
         if up.mode == "upsample3d" and T > 1 and not self._indep:
             y = self._conv(up.time_conv, x[1:].contiguous())        # never sees frame 0 (the "Rep" rule)
             x = torch.cat([x[:1], ops.time_interleave_cl(y)], dim=0)
         # WanUpsample (nearest-exact 2x) is folded into the convolution's gather: no 4x larger intermediate
-        return self._conv(up.resample[1], x, upsample2x=True)
+        if next_norm is None:
+            return self._conv(up.resample[1], x, upsample2x=True), None
+        return self._conv_norm(up.resample[1], x, next_norm[0], silu=next_norm[1], upsample2x=True)
 
     def _decode_tile(self, z):
-        """z [T, h, w, z_dim] channels-last -> [T', 8h, 8w, 4] (3 channels + 1 pad)."""
+        """z [T, h, w, z_dim] channels-last -> [T', 8h, 8w, 4] (3 channels + 1 pad).  Every RMS norm whose input comes
+        out of a convolution is produced by that convolution (`_conv_norm`); `xn` carries it to its consumer."""
         d = self.decoder
+        g = self._gamma
+        mid = d.mid_block
         x = self._conv(self.post_quant_conv, z)
-        x = self._conv(d.conv_in, x)
-        x = self._res(d.mid_block.resnets[0], x)
-        x = self._attn(d.mid_block.attentions[0], x)
-        x = self._res(d.mid_block.resnets[1], x)
+        x, xn = self._conv_norm(d.conv_in, x, g(mid.resnets[0].norm1))
+        x, xn = self._res(mid.resnets[0], x, xn, next_norm=(g(mid.attentions[0].norm), False))
+        x = self._attn(mid.attentions[0], x, xn)
+        # the chain of residual blocks / resamplers that follows; each one is told which norm reads its output
+        chain = [mid.resnets[1]]
         for up in d.up_blocks:
-            for r in up.resnets:
-                x = self._res(r, x)
+            chain += list(up.resnets)
             if up.upsamplers is not None:
-                x = self._resample(up.upsamplers[0], x)
-        x = ops.rmsnorm_cl(x, d.norm_out.gamma.data.reshape(-1).contiguous(), silu=True)
-        return self._conv(d.conv_out, x)
+                chain.append(up.upsamplers[0])
+        xn = None
+        for i, m in enumerate(chain):
+            nxt = chain[i + 1] if i + 1 < len(chain) else None
+            if nxt is None:
+                nn_ = (g(d.norm_out), True)
+            elif isinstance(nxt, _Res):
+                nn_ = (g(nxt.norm1), True)
+            else:
+                nn_ = None                          # a resampler reads the raw tensor
+            if isinstance(m, _Res):
+                x, xn = self._res(m, x, xn, next_norm=nn_)
+            else:
+                x, xn = self._resample(m, x, next_norm=nn_)
+        return self._conv(d.conv_out, xn)
 
     @torch.no_grad()
     def _decode_one(self, z):
@@ -391,10 +429,10 @@ class AutoencoderKLWan(nn.Module):
         e = self.encoder
         x = self._conv(e.conv_in, x)
         for blk in e.down_blocks:
-            x = self._down(blk, x) if isinstance(blk, _Down) else self._res(blk, x)
-        x = self._res(e.mid_block.resnets[0], x)
+            x = self._down(blk, x) if isinstance(blk, _Down) else self._res(blk, x)[0]
+        x = self._res(e.mid_block.resnets[0], x)[0]
         x = self._attn(e.mid_block.attentions[0], x)
-        x = self._res(e.mid_block.resnets[1], x)
+        x = self._res(e.mid_block.resnets[1], x)[0]
         x = self._conv(e.conv_out, ops.rmsnorm_cl(x, e.norm_out.gamma.data.reshape(-1).contiguous(), silu=True))
         return self._conv(self.quant_conv, x)
 

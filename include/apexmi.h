@@ -252,6 +252,19 @@ int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* bias, const 
                          const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                          int independent, apexmi_stream_t stream);
 
+/* Convolution with the RMS norm of its OUTPUT fused into the epilogue ("RMS-norm(channel) + SiLU"
+ * of WanResidualBlock.forward, vae/wan/model.py:389-441, and of the decoder's norm_out :1011-1017, moved from the
+ * consumer's prologue — where LDS-DMA staging bypasses the registers — into the PRODUCER's epilogue): besides (or instead
+ * of: out may be NULL) y = conv(in) + bias (+ residual) it writes out_norm = [silu](y / max(||y||_2, 1e-12) * sqrt(Cout)
+ * * gamma) per position, computed from the bf16-rounded y exactly as the separate apexmi_rmsnorm_cl pass would read it
+ * back.  Only for shapes whose every output channel of a position lies in one workgroup tile of the conv-shaped tilings:
+ * apexmi_conv3d_cl_norm_fusable(T, H, W, Cin, Cout, up) != 0 (H, W = stored extents).  up != 0: read through the nearest
+ * 2x upsample as apexmi_conv3d_cl_up2. */
+int apexmi_conv3d_cl_norm_fusable(int T, int H, int W, int Cin, int Cout, int up);
+int apexmi_conv3d_cl_norm(const void* in, const void* w, const void* bias, const void* residual, void* out, void* out_norm,
+                          const void* gamma, int silu, const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad,
+                          int kT, int kH, int kW, int independent, int up, apexmi_stream_t stream);
+
 /* N INDEPENDENT single-frame clips in one launch: in / out are [N, H, W, C] and every frame is convolved as if it were
  * a one-frame clip — of a causal kT-tap kernel only the last temporal tap touches data, the others fall in the zero
  * padding, so the launch iterates kH*kW taps from the last temporal slice of the packed weight.  (A single-frame call

@@ -416,3 +416,38 @@ def test_conv_v2_tiles_are_bit_identical_to_the_128x128_kernel(cin, cout, T, H, 
         lib.tune_set("conv.v2", 1)
     assert T * Ho * Wo >= 65536, "shape must be large enough for the v2 dispatch"
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,k,up,silu,res", [(96, 96, 5, 128, 128, (3, 3, 3), False, True, True),
+                                                          (192, 192, 3, 150, 160, (3, 3, 3), False, True, False),
+                                                          (192, 96, 2, 96, 100, (1, 3, 3), True, True, False),
+                                                          (96, 96, 1, 300, 300, (3, 3, 3), False, False, True),
+                                                          (384, 384, 3, 160, 160, (3, 3, 3), False, True, True),
+                                                          (64, 64, 2, 20, 20, (3, 3, 3), False, True, False)])
+def test_conv_with_fused_output_rmsnorm(cin, cout, T, H, W, k, up, silu, res):
+    """`apexmi_conv3d_cl_norm`: the RMS norm (+ SiLU) of the conv's output produced in the conv's epilogue.  Raw output
+    bit-identical to the plain conv; normed output against the separate rmsnorm_cl pass over that raw output: same
+    values read, f32 sum in a different order -> at most isolated 1-ulp flips (bar 2e-5 rel L2, 1 ulp).  The last two
+    shapes are NOT fusable (two N tiles / too small): the wrapper must give the same through its fallback."""
+    from apex_studio_amd import ops
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * k[0] * k[1] * k[2]) ** -0.5)).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    b = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    b[:cout] = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    g = _bf(1 + 0.1 * seeded((cout,), 5)).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    r = _bf(seeded((T, Ho, Wo, cout), 4)).to(DEV) if res else None
+    assert ops.conv3d_cl_norm_fusable(x, cout, up) == (cout <= 192 and T * Ho * Wo >= 65536)
+    plain = ops.conv3d_cl(x, wp, b, k, residual=r, upsample2x=up)
+    want = ops.rmsnorm_cl(plain, g, silu=silu)
+    raw, normed = ops.conv3d_cl_norm(x, wp, b, k, g, silu=silu, residual=r, upsample2x=up)
+    assert torch.equal(raw, plain)
+    none, normed2 = ops.conv3d_cl_norm(x, wp, b, k, g, silu=silu, residual=r, upsample2x=up, want_raw=False)
+    assert none is None and torch.equal(normed2, normed)
+    rel = _rel(normed.cpu(), want.cpu())
+    frac = float((normed != want).float().mean())
+    print(f"[fused norm] {cin}->{cout} up={up} silu={silu}: vs the separate pass rel {rel:.2e}, {frac:.2e} of elements differ")
+    assert rel < 2e-5 and frac < 1e-3
+    d = (normed.float() - want.float()).abs()
+    assert float((d / want.float().abs().clamp_min(1e-3)).max()) < 2.0 ** -6
