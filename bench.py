@@ -457,6 +457,7 @@ def run_queue(args, dev, rank, world):
     weak_clips = [{"kind": "flux", "seed": 100 + i, "cost": 2.5} for i in range(world)] + \
                  [{"kind": "wan", "seed": 200 + i, "cost": wan_cost} for i in range(world)]
     weak = render_queue.run_queue(weak_clips, runner)
+    _flush_c_stdio()
     if rank == 0:
         print(json.dumps({
             "metric": "queue_clips_per_hour", "value": res["clips_per_hour"], "unit": "clips/h", "n_gpus": world,
@@ -471,6 +472,14 @@ def run_queue(args, dev, rank, world):
                              "clips_per_hour": weak["clips_per_hour"], "makespan_s": weak["makespan"],
                              "busy_s": weak["busy"]},
             "broadcast": bcast}), flush=True)
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def spawn_ranks(args):
@@ -559,6 +568,7 @@ def main():
         _lib.tune_set(key, int(val))
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")        # no version banner on stdout next to the JSON line
         dist.init_process_group("nccl", device_id=dev)
 
     import apex_studio_amd  # noqa: F401
@@ -677,10 +687,12 @@ def main():
             del step, latents, clip_fn
             torch.cuda.empty_cache()
             out["wan"] = wan_half(dev)
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()           # RCCL's version banner sits in C stdio: get it out BEFORE the result line
+    if rank == 0:
+        print(json.dumps(out), flush=True)    # the ONE JSON line, last on stdout
 
 
 if __name__ == "__main__":
