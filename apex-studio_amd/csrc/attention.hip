@@ -371,6 +371,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     C4_BAR();                  // tile 0 visible
     if (late) C4_BAR();        // second half runs one cluster behind
+    if ((PRIO & 4) && late) __builtin_amdgcn_s_setprio(1);   // the younger half loses every age arbitration otherwise
     for (int t = 0; t < nt; ++t) {
         const char* Ks = smem + (t & 1) * ATT_STAGE;
         const char* Vs = Ks + K_TILE_BYTES;
@@ -387,13 +388,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.0f;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[ks * 2 + kt], qf[ks], sacc[kt], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
         C4_BAR();
         // ---- C3: V^T fragments -> the same registers, softmax beside the reads ----
 #pragma unroll
@@ -429,16 +430,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             }
-            float psum = 0.0f;
+            if (PRIO & 2) {
+                // packed f32 math: one v_pk_fma_f32 / v_pk_add_f32 per PAIR of scores (the accumulator registers of an
+                // MFMA are consecutive, so the pairs are already aligned) — 32 fewer VALU issues per tile and wave
+                const f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+                f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_run));
-                    sacc[kt][r] = pv;
-                    psum += pv;
-                }
-            l_run += psum;
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 x = {sacc[kt][r], sacc[kt][r + 1]};
+                        x = __builtin_elementwise_fma(x, c2, nm2);
+                        x[0] = fast_exp2(x[0]);
+                        x[1] = fast_exp2(x[1]);
+                        sacc[kt][r] = x[0];
+                        sacc[kt][r + 1] = x[1];
+                        ps2 += x;
+                    }
+                l_run += ps2[0] + ps2[1];
+            } else {
+                float psum = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = fast_exp2(fmaf(sacc[kt][r], scale_log2e, -m_run));
+                        sacc[kt][r] = pv;
+                        psum += pv;
+                    }
+                l_run += psum;
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -449,13 +470,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C4_LGKM_BAR();
         // ---- C4: O^T += V^T P^T ----
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[kk * 4 + dt], pf[kk], oacc[dt], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
         if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C4_BAR();
     }
@@ -934,8 +955,10 @@ int launch_generic(const void* q, const void* k, const void* v, void* out, int B
 }
 
 int g_attn_waves = 0;  // 0 auto, 4, 8 (apexmi_tune_set "attn.waves")
-int g_attn_c4 = 1;  // apexmi_tune_set("attn.c4", 0|1|2): 8-wave launches use the 4-cluster ping-pong kernel (shipped: -3.4 % per
-                    // attention launch in the Flux and HunyuanVideo steps); 0 = plain loop, 2 = with s_setprio in the matrix clusters
+int g_attn_c4 = 3;  // apexmi_tune_set("attn.c4", v): 0 = plain loop; v >= 1: 8-wave launches use the 4-cluster ping-pong kernel
+                    // (-3.4 % per attention launch in the Flux and HunyuanVideo steps) with the variant bits of (v - 1):
+                    // 1 = s_setprio in the matrix clusters (neutral), 2 = packed-f32 softmax (shipped: +0.5..0.9 %,
+                    // tools/attn_ab.py), 4 = static priority for waves 4..7 (-0.5 %)
 }  // namespace
 namespace {
 int g_attn_mfma = 32;  // 32: 32x32x16 kernel (shipped: 3 % faster in the Flux step), 16: 16x16x32 kernel (apexmi_tune_set "attn.mfma")
@@ -1056,9 +1079,16 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
     const bool m16 = g_attn_mfma == 16;
     if (nw == 8 && !m16 && g_attn_c4) {
         // ---- shipped path: 4-cluster kernel; a nearly empty last round is cut into ATT_NSPLIT key ranges ----
-        auto c4 = g_attn_c4 == 2 ? attn_fwd_d128_c4_kernel<8, 1> : attn_fwd_d128_c4_kernel<8, 0>;
-        static uint64_t c4_attr[2] = {};
-        if (apexmi_once_per_device(c4_attr[g_attn_c4 == 2]))
+        // bit 0: s_setprio around the matrix clusters; bit 1: packed-f32 softmax; bit 2: static priority for waves 4..7
+        const int var = (g_attn_c4 - 1) & 7;
+        static void (*const c4_tab[8])(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int,
+                                       int64_t, int64_t, int64_t, float, int, int, float*, float*) = {
+            attn_fwd_d128_c4_kernel<8, 0>, attn_fwd_d128_c4_kernel<8, 1>, attn_fwd_d128_c4_kernel<8, 2>,
+            attn_fwd_d128_c4_kernel<8, 3>, attn_fwd_d128_c4_kernel<8, 4>, attn_fwd_d128_c4_kernel<8, 5>,
+            attn_fwd_d128_c4_kernel<8, 6>, attn_fwd_d128_c4_kernel<8, 7>};
+        auto c4 = c4_tab[var];
+        static uint64_t c4_attr[8] = {};
+        if (apexmi_once_per_device(c4_attr[var]))
             (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         int tail = attn_tail(total, Sk);
         const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);

@@ -168,7 +168,9 @@ int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk,
  *                  Bit-identical results either way.
  *   "gemm.tail"    1: a small last problem of a grouped launch after whole rounds of tiles goes out on the 128x128 tiling
  *   "attn.waves"   0 auto | 4..8 waves per attention workgroup            "attn.mfma"     32 | 16
- *   "attn.c4"      1: 4-cluster ping-pong kernel | 2: same + s_setprio | 0: plain loop
+ *   "attn.c4"      0: plain loop | 1 + bits: 4-cluster ping-pong kernel, bit 0 s_setprio around the matrix clusters, bit 1
+ *                  packed-f32 softmax (v_pk_fma_f32 / v_pk_add_f32), bit 2 static priority for waves 4..7.  Default 3
+ *                  (= packed softmax: +0.5..0.9 % on the Flux / Qwen / Wan shapes; the other two bits measured neutral / -0.5 %)
  *   "attn.split"   1: a nearly empty last round runs as 4 key ranges + merge (needs the _ws entry point's scratch)
  *   "qk.group"     1: q/k norm + RoPE four heads per lane group with the V transpose in the same launch | 2: without | 0: one head
  *   "ln.wave"      1: wave-per-row LayerNorm kernel for C in {3072, 3584, 5120}
