@@ -47,7 +47,12 @@ struct ConvArgs {
     const bf16_t* norm_gamma;
     bf16_t* out_norm;
     int norm_silu;
+    // activation applied to conv + bias (+ residual) in f32 before the one bf16 rounding: 0 none, 1 leaky ReLU with
+    // `act_slope` (0.0 = ReLU) — the TAEHV blocks (conv, act) and act(conv + skip)
+    int act;
+    float act_slope;
 };
+APEXMI_DEVICE float conv_act(float v, int act, float slope) { return (act && v < 0.0f) ? v * slope : v; }
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,6 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
                     v[2] += bf16_lo(r[1]);
                     v[3] += bf16_hi(r[1]);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], a.act, a.act_slope);
                 u32x2 o;
                 o[0] = pack_bf16(v[0], v[1]);
                 o[1] = pack_bf16(v[2], v[3]);
@@ -410,6 +417,8 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
                         v[2] += bf16_lo(r[1]);
                         v[3] += bf16_hi(r[1]);
                     }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
                     *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
                 }
         }
@@ -454,6 +463,10 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
                     v[1] += bf16_hi(r2[0]);
                     v[2] += bf16_lo(r2[1]);
                     v[3] += bf16_hi(r2[1]);
+                    if (!NORM) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
+                    }
                     o[q][0] = pack_bf16(v[0], v[1]);
                     o[q][1] = pack_bf16(v[2], v[3]);
                     if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
@@ -682,6 +695,44 @@ __global__ __launch_bounds__(256) void time_interleave_cl_kernel(const bf16_t* _
     *(u32x4*)(y + idx * 8) = *(const u32x4*)(x + (((int64_t)(f >> 1) * HW + p) * 2 + (f & 1)) * C + c * 8);
 }
 
+// TAEHV input clamp (tae/model.py:24-26) behind the light VAE's 1/scaling_factor (hunyuanvideo15/model.py:1225-1226):
+// y = 3 tanh(x * inv / 3), f32 inside, one bf16 rounding
+__global__ __launch_bounds__(256) void tanh_clamp_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8,
+                                                         float inv) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    float v[8];
+    unpack8(*(const u32x4*)(x + idx * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 3.0f * tanhf(v[j] * inv * (1.0f / 3.0f));
+    *(u32x4*)(y + idx * 8) = pack8(v);
+}
+
+// TAEHV output (tae/model.py:318-333): clamp to [lo, hi], pixel-shuffle by r (channel c r^2 + i r + j -> pixel
+// (h r + i, w r + j) of image channel c) and drop the first t0 frames: x [T, H, W, Cs] -> y [C, T - t0, H r, W r]
+template <int R>
+__global__ __launch_bounds__(256) void pixel_shuffle_clamp_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int T,
+                                                                  int H, int W, int Cs, int C, int t0, float lo, float hi) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)C * (T - t0) * H * W;
+    if (idx >= n) return;
+    const int w = (int)(idx % W);
+    int64_t r = idx / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int t = (int)(r % (T - t0));
+    const int c = (int)(r / (T - t0));
+    const bf16_t* src = x + ((((int64_t)(t + t0) * H + h) * W + w) * Cs + c * (R * R));
+    bf16_t* dst = y + (((int64_t)c * (T - t0) + t) * (H * R) + (int64_t)h * R) * ((int64_t)W * R) + (int64_t)w * R;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float v = fminf(fmaxf(bf16_to_f32(src[i * R + j]), lo), hi);
+            dst[(int64_t)i * W * R + j] = f32_to_bf16(v);
+        }
+}
+
 // b[o, e, i] = a[o, e, i] * (1 - e/E) + b[o, e, i] * (e/E)   (blend_v / blend_h, model.py:1404-1422)
 __global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b,
                                                         int64_t outer, int E, int64_t inner, int64_t a_so,
@@ -837,7 +888,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
                           int Ho = 0, int Wo = 0, int independent = 0, int up = 0, const void* norm_gamma = nullptr,
-                          void* out_norm = nullptr, int norm_silu = 0) {
+                          void* out_norm = nullptr, int norm_silu = 0, int act = 0, float act_slope = 0.0f) {
     const int Hin = H, Win = W;
     if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
         H *= 2;
@@ -895,6 +946,9 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.Ho = Ho; a.Wo = Wo; a.sy = sy; a.sx = sx; a.py = py; a.px = px;
     a.up = up ? 1 : 0; a.Hin = Hin; a.Win = Win;
     a.norm_gamma = (const bf16_t*)norm_gamma; a.out_norm = (bf16_t*)out_norm; a.norm_silu = norm_silu;
+    APEXMI_REQUIRE(act == 0 || (act == 1 && out_norm == nullptr), "conv3d_cl: activation %d unsupported (0 none, 1 leaky ReLU; "
+                                                                  "not together with the fused norm)", act);
+    a.act = act; a.act_slope = act_slope;
     const int64_t M = (int64_t)T * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
@@ -936,6 +990,13 @@ extern "C" int apexmi_conv3d_cl_norm(const void* in, const void* w, const void* 
     APEXMI_REQUIRE(Cout % 8 == 0, "conv3d_cl_norm: Cout=%d must be a multiple of 8", Cout);
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
                           0, 0, independent, up, gamma, out_norm, silu);
+}
+
+extern "C" int apexmi_conv3d_cl_act(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                    const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                                    int kW, int independent, int up, int act, float slope, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1,
+                          0, 0, independent, up, nullptr, nullptr, 0, act, slope);
 }
 
 extern "C" int apexmi_conv3d_cl_frames(const void* in, const void* w, const void* bias, const void* residual,
@@ -1002,6 +1063,32 @@ extern "C" int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t 
     hipLaunchKernelGGL(time_interleave_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        (const bf16_t*)x, (bf16_t*)y, T, HW, C);
     return apexmi_check_launch("time_interleave_cl");
+}
+
+extern "C" int apexmi_tanh_clamp(const void* x, void* y, int64_t n, float inv_scale, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && n > 0 && n % 8 == 0, "tanh_clamp: n=%lld must be a positive multiple of 8", (long long)n);
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * (double)n);
+    hipLaunchKernelGGL(tanh_clamp_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)y, n / 8, inv_scale);
+    return apexmi_check_launch("tanh_clamp");
+}
+
+extern "C" int apexmi_pixel_shuffle_clamp(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo,
+                                          float hi, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && T > 0 && H > 0 && W > 0 && C > 0 && t0 >= 0 && t0 < T, "pixel_shuffle_clamp: bad arguments");
+    APEXMI_REQUIRE((r == 1 || r == 2) && Cs >= C * r * r, "pixel_shuffle_clamp: patch %d / channel stride %d unsupported", r, Cs);
+    const int64_t n = (int64_t)C * (T - t0) * H * W;
+    ApexmiProfScope prof(5, stream, 0.0, 4.0 * (double)n * r * r);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (r == 2)
+        hipLaunchKernelGGL(pixel_shuffle_clamp_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, T, H, W, Cs,
+                           C, t0, lo, hi);
+    else
+        hipLaunchKernelGGL(pixel_shuffle_clamp_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, T, H, W, Cs,
+                           C, t0, lo, hi);
+    return apexmi_check_launch("pixel_shuffle_clamp");
 }
 
 extern "C" int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,

@@ -92,7 +92,7 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             num_inference_steps: int = 50, guidance_scale: float = 6.0, guidance_rescale: float = 0.0, sigmas=None,
             seed: Optional[int] = None, generator: Optional[torch.Generator] = None, latents=None,
             return_latents: bool = False, progress_callback=None, output_type: Optional[str] = None, image=None,
-            image_embeds=None, **_ignored):
+            image_embeds=None, use_light_vae: bool = False, **_ignored):
         dev, dt = self.device, self.transformer.dtype
         B = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
@@ -139,7 +139,9 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
             return latents
         if self.decode_fn is None and self.vae is None:
             raise RuntimeError("hunyuanvideo15: no decode_fn / VAE attached; pass return_latents=True")
-        _emit(progress_callback, 0.94, "Decoding latents")
+        if self.decode_fn is None:
+            self.vae.enable_tiling(use_light_vae=use_light_vae)      # t2v.py:350 / i2v.py:396
+        _emit(progress_callback, 0.94, "Decoding latents to video with light VAE" if use_light_vae else "Decoding latents")
         video = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents)
         _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
         if output_type is not None:      # t2v.py: `self._tensor_to_frames(video)` — uint8 frames made on the GPU

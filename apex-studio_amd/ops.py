@@ -618,6 +618,51 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def conv3d_cl_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
+                  residual: Optional[torch.Tensor] = None, slope: Optional[float] = None, upsample2x: bool = False,
+                  independent_frames: bool = False) -> torch.Tensor:
+    """act(conv(x) + bias (+ residual)) with act = leaky ReLU(slope) (slope None: no activation), zero padding, causal in
+    time; upsample2x / independent_frames as conv3d_cl.  The TAEHV blocks (reference vae/tae/model.py:20-45)."""
+    _req(x, torch.bfloat16, "conv3d_cl_act.x")
+    _req(w_packed, torch.bfloat16, "conv3d_cl_act.w")
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, cin = x.shape
+    cout, kpad = w_packed.shape
+    Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
+    out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        assert bias.numel() == cout and bias.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl_act(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                        _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]), int(ksize[1]),
+                                        int(ksize[2]), 1 if independent_frames else 0, 1 if upsample2x else 0,
+                                        0 if slope is None else 1, 0.0 if slope is None else float(slope), _stream())
+    _l.check(rc, "conv3d_cl_act")
+    return out
+
+
+def tanh_clamp(x: torch.Tensor, inv_scale: float = 1.0) -> torch.Tensor:
+    """3 tanh(x * inv_scale / 3) (TAEHV `Clamp`, reference vae/tae/model.py:24-26)."""
+    _req(x, torch.bfloat16, "tanh_clamp.x")
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    out = torch.empty_like(x)
+    _l.check(_l.load().apexmi_tanh_clamp(x.data_ptr(), out.data_ptr(), x.numel(), float(inv_scale), _stream()), "tanh_clamp")
+    return out
+
+
+def pixel_shuffle_clamp(x: torch.Tensor, channels: int, r: int, trim: int = 0, lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
+    """x [T, H, W, Cs] channels-last -> [channels, T - trim, H r, W r]: clamp, F.pixel_shuffle(r), drop `trim` leading frames
+    (reference vae/tae/model.py:318-333)."""
+    _req(x, torch.bfloat16, "pixel_shuffle_clamp.x")
+    assert x.dim() == 4 and x.is_contiguous()
+    T, H, W, cs = x.shape
+    out = torch.empty((channels, T - trim, H * r, W * r), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().apexmi_pixel_shuffle_clamp(x.data_ptr(), out.data_ptr(), T, H, W, cs, channels, r, trim, float(lo),
+                                                  float(hi), _stream()), "pixel_shuffle_clamp")
+    return out
+
+
 def conv3d_cl_norm_fusable(x: torch.Tensor, cout: int, upsample2x: bool = False) -> bool:
     T, H, W, cin = x.shape
     return bool(_l.load().apexmi_conv3d_cl_norm_fusable(T, H, W, cin, cout, 1 if upsample2x else 0))

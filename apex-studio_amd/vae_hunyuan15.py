@@ -207,6 +207,13 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         self.tile_latent_min_height = self.tile_latent_min_width = 128 // spatial_compression_ratio
         self.tile_overlap_factor = 0.25
         self._packed: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        # the TAEHV "light" decoder (model.py:794-846): built lazily when `enable_tiling(use_light_vae=True)` asks for it, or
+        # at once when a path is configured and this module is not being built on the meta device
+        self.use_light_vae = False
+        self.light_vae_path = light_vae_path
+        self.light_vae = None
+        if light_vae_path is not None and not self.decoder.conv_in.conv.weight.is_meta:
+            self._ensure_light_vae_loaded()
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -237,10 +244,33 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         """Parameters were written in place (`weights.load_checkpoint_into`): drop the packed conv-weight cache."""
         self._packed = {}
 
+    def _ensure_light_vae_loaded(self) -> None:
+        """model.py:821-846."""
+        if self.light_vae is not None:
+            return
+        if not self.light_vae_path:
+            raise ValueError("Light VAE requested but `light_vae_path` is not set in the VAE config.")
+        from .vae_taehv import AutoencoderKLHunyuanVideo15Light
+        # on the main VAE's device (model.py:838-846); a VAE still on the meta device gets a CPU light VAE that follows the
+        # later `.to(device)` as a submodule
+        dev = None if self.device.type == "meta" else self.device
+        self.light_vae = AutoencoderKLHunyuanVideo15Light(taehv_checkpoint_path=self.light_vae_path,
+                                                          scaling_factor=self.config.scaling_factor, device=dev)
+
+    def set_light_vae(self, light_vae) -> None:
+        """Attach an already built `AutoencoderKLHunyuanVideo15Light` (weights streamed by the host's own loader)."""
+        self.light_vae = light_vae
+
     def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_latent_min_height=None,
-                      tile_latent_min_width=None, tile_overlap_factor=None, use_light_vae: bool = False):
-        if use_light_vae:
-            raise NotImplementedError("hunyuanvideo15_mi355 VAE: the TAEHV light decoder is not implemented")
+                      tile_latent_min_width=None, tile_overlap_factor=None, use_light_vae: Optional[bool] = None):
+        # model.py:848-888.  A call without `use_light_vae` (the engine's vae_decode issues one, base_engine.py:2051) leaves
+        # the switch as it is — what the reference's `if self.light_vae is None:` guard amounts to for such calls.  An
+        # explicit True / False is honoured at any time (the reference ignores it once its light VAE has been built, so a
+        # run could never go back to the full decoder; that defect is not mirrored).
+        if use_light_vae is not None:
+            if use_light_vae:
+                self._ensure_light_vae_loaded()
+            self.use_light_vae = bool(use_light_vae)
         self.use_tiling = True
         self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
         self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
@@ -448,6 +478,11 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
     @ops.on_model_device
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
+        if self.use_light_vae:
+            # model.py:958-962: the light decoder's [1, N, 3, T', H', W'] result is returned AS IS (no tuple, no
+            # DecoderOutput), which the caller's `[0]` turns into the video
+            self._ensure_light_vae_loaded()
+            return self.light_vae.decode(z, parallel=False, show_progress_bar=True, skip_trim=False)
         dec = torch.stack([self._decode_one(z[b]) for b in range(z.shape[0])], dim=0).to(z.dtype)
         if not return_dict:
             return (dec,)

@@ -267,6 +267,25 @@ int apexmi_conv3d_cl_norm(const void* in, const void* w, const void* bias, const
                           const void* gamma, int silu, const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad,
                           int kT, int kH, int kW, int independent, int up, apexmi_stream_t stream);
 
+/* Convolution with an activation in the epilogue — the TAEHV "light VAE" blocks (vae/tae/model.py:20-45: `conv, act`,
+ * `act(conv(cat[x, past]) + skip(x))`; selected by `use_light_vae`, vae/hunyuanvideo15/model.py:958-962, 1163-1234):
+ * out = act(conv(in) + bias (+ residual)) evaluated in f32, ONE bf16 rounding.  act: 0 none | 1 leaky ReLU with `slope`
+ * (0.0 = ReLU).  MemBlock's `conv(torch.cat([x, past], 1))` (:44, past = the previous frame, zeros before the first) IS a
+ * causal kT = 2 convolution: pack the [Cout, 2 Cin, 3, 3] weight with temporal tap 1 <- input channels [0, Cin) and tap 0 <-
+ * [Cin, 2 Cin).  independent / up as in apexmi_conv3d_cl_frames / apexmi_conv3d_cl_up2 (nn.Upsample(2) :239-251 folded
+ * into the following convolution's gather). */
+int apexmi_conv3d_cl_act(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                         const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                         int independent, int up, int act, float slope, apexmi_stream_t stream);
+/* TAEHV's input clamp behind the light VAE's 1/scaling_factor (vae/tae/model.py:24-26; hunyuanvideo15/model.py:1225):
+ * y = 3 tanh(x * inv_scale / 3) over n packed bf16 values (n % 8 == 0). */
+int apexmi_tanh_clamp(const void* x, void* y, int64_t n, float inv_scale, apexmi_stream_t stream);
+/* TAEHV's output tail (vae/tae/model.py:318-333): clamp to [lo, hi], F.pixel_shuffle by r in {1, 2} (channel c r^2 + i r + j
+ * -> pixel (h r + i, w r + j) of image channel c) and drop the first t0 frames; x [T, H, W, Cs] channels-last (Cs >= C r^2),
+ * y [C, T - t0, H r, W r]. */
+int apexmi_pixel_shuffle_clamp(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo, float hi,
+                               apexmi_stream_t stream);
+
 /* N INDEPENDENT single-frame clips in one launch: in / out are [N, H, W, C] and every frame is convolved as if it were
  * a one-frame clip — of a causal kT-tap kernel only the last temporal tap touches data, the others fall in the zero
  * padding, so the launch iterates kH*kW taps from the last temporal slice of the packed weight.  (A single-frame call

@@ -445,6 +445,46 @@ def gen_vae_hunyuan15_encode():
     print("vae_hunyuan15_encode.pt", {k: tuple(v["moments"].shape) for k, v in out.items() if isinstance(v, dict) and "moments" in v}, res)
 
 
+def gen_vae_taehv():
+    """The REFERENCE TAEHV decoder behind `use_light_vae` (vae/tae/model.py, wrapped by AutoencoderKLHunyuanVideo15Light,
+    vae/hunyuanvideo15/model.py:1163-1234) on seeded weights: sequential mode (what the engine runs, parallel=False) and
+    parallel mode, a 3-latent-frame clip and a single latent frame.  Channel widths are fixed by the reference class
+    (256/128/64/64); the spatial size is what keeps this small."""
+    install_vae_stubs()
+    import src.attention  # noqa: F401
+    _mod("src.utils.defaults", get_components_path=lambda *a, **k: "/tmp")
+    _mod("src.mixins.download_mixin", DownloadMixin=type("DownloadMixin", (), {}))
+    for name in ("src.vae.tae", "src.vae.tae.model"):
+        sys.modules.pop(name, None)
+    t = _mod("src.vae.tae")
+    t.__path__ = []
+    tae = load_by_path("src.vae.tae.model", "src/vae/tae/model.py")
+    ref_mod = load_by_path("ref_vae_hy15_light", "src/vae/hunyuanvideo15/model.py")
+    from oracle.vae_taehv import AutoencoderKLHunyuanVideo15Light as Orc
+    ref = ref_mod.AutoencoderKLHunyuanVideo15Light(taehv_checkpoint_path=None).eval()
+    assert isinstance(ref.taehv, tae.TAEHV)
+    orc = Orc().eval()
+    sd = vae_synthetic_state_dict(orc, 29)                       # taehv.decoder.* (the product's keys)
+    full = dict(ref.state_dict())
+    enc = vae_synthetic_state_dict(ref, 30)
+    full.update({k: v for k, v in enc.items() if k.startswith("taehv.encoder.")})
+    full.update(sd)
+    res = ref.load_state_dict(full, strict=True)
+    assert sorted(k for k in ref.state_dict() if k.startswith("taehv.decoder.")) == sorted(sd.keys())
+    out = dict(seed=29, keys=sorted(sd.keys()), all_keys=sorted(full.keys()), scaling_factor=ref.scaling_factor)
+    with torch.no_grad():
+        for name, shape, seed in (("clip", (1, 32, 3, 4, 6), 84), ("frame", (1, 32, 1, 6, 4), 85)):
+            z = seeded(shape, seed) * 1.5
+            seq = ref.decode(z.clone(), parallel=False, show_progress_bar=False)
+            par = ref.decode(z.clone(), parallel=True, show_progress_bar=False)
+            assert seq.shape[0] == 1 and seq.dim() == 6          # the reference's extra leading axis; callers take [0]
+            out[name] = dict(shape=shape, seed=seed, scale=1.5, sequential=seq[0].clone(),
+                             parallel_max_abs_diff=float((seq - par).abs().max()))
+    torch.save(out, os.path.join(OUT, "vae_taehv.pt"))
+    print("vae_taehv.pt", {k: tuple(v["sequential"].shape) for k, v in out.items() if isinstance(v, dict)}, res,
+          {k: v["parallel_max_abs_diff"] for k, v in out.items() if isinstance(v, dict)})
+
+
 def gen_unipc():
     """In-tree UniPC (reference scheduler/unipc.py) trajectory: 6 steps, shift 3, fp32 latents."""
     class SchedulerOutput:
@@ -713,6 +753,7 @@ def main():
     gen_vae_wan()
     gen_vae_wan_encode()
     gen_vae_hunyuan15()
+    gen_vae_taehv()
     gen_unipc()
     gen_lora()
     gen_fp_scaled()

@@ -107,7 +107,7 @@ def print_report(tag: str, report) -> Tuple[float, float]:
     return worst, mean
 
 
-VAE_OPS = ("conv3d_cl", "conv3d_cl_norm", "rmsnorm_cl", "groupnorm_cl", "gemm", "attention")
+VAE_OPS = ("conv3d_cl", "conv3d_cl_norm", "conv3d_cl_act", "tanh_clamp", "rmsnorm_cl", "groupnorm_cl", "gemm", "attention")
 
 
 def _oracle_rows(o: torch.Tensor) -> torch.Tensor:

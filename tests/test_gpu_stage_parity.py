@@ -166,3 +166,24 @@ def test_flux_vae_decode_every_storage_point():
     e_out, e_free = _rel(out, ref16), _rel(free, ref16)
     print(f"[stage flux vae decode] decoded output after the last forced point: rel {e_out:.2e}; free-running decode {e_free:.2e}")
     assert e_out <= SP.STAGE_TOL and e_free < 2e-2
+
+
+def test_taehv_light_vae_every_storage_point():
+    """TAEHV (HunyuanVideo-1.5 `use_light_vae`): input clamp, 3x3 convs with bias / residual / leaky-ReLU epilogues, MemBlock's
+    cat([x, past]) as a causal kT = 2 conv, TGrow GEMMs at the low resolution, upsample folded into the next conv — 36
+    storage points, each within the per-stage bar given the oracle's inputs; the pixel-shuffled, clamped, trimmed output
+    after the last forced point is then EXACT."""
+    from apex_studio_amd import ops
+    from tests.test_gpu_taehv import _light
+    hip, orc = _light(37)
+    z = (seeded((1, 32, 3, 10, 12), 65) * 1.3).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        ref16 = orc.decode(z.float(), pol)
+    free = hip.decode(z.to(DEV))[0]
+    out, report = SP.run_forced_vae(ops, pol.points, lambda: hip.decode(z.to(DEV))[0])
+    worst, _ = SP.print_report("taehv decode", report)
+    assert len(report) == 36 and worst <= SP.STAGE_TOL, (len(report), worst)
+    e_free = _rel(free, ref16)
+    print(f"[stage taehv decode] free-running decode {e_free:.2e}")
+    assert torch.equal(out.float().cpu(), ref16.to(torch.bfloat16).float()) and e_free < 2e-2

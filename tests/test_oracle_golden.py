@@ -182,6 +182,28 @@ def test_hunyuan15_vae_encoder_restatement_matches_reference(golden_dir):
     assert float((untiled - out).abs().max()) > 1e-3, "tiling must be observable"
 
 
+def test_taehv_light_vae_restatement_matches_reference(golden_dir):
+    """oracle.vae_taehv against the reference's TAEHV decoder wrapped by AutoencoderKLHunyuanVideo15Light (vae_taehv.pt, run
+    in sequential mode as the engine does; the parallel mode agreed to the recorded f32 noise): MemBlock memory = the
+    previous frame (zeros first), TGrow's channel blocks -> frames, nearest 2x upsamples, leaky ReLU 0.2, clamp, pixel
+    shuffle, 3 trimmed frames, and the `taehv.decoder.*` key set."""
+    from oracle.vae_taehv import AutoencoderKLHunyuanVideo15Light
+    from tests.golden.seeded import vae_synthetic_state_dict
+    g = _load(golden_dir, "vae_taehv.pt")
+    vae = AutoencoderKLHunyuanVideo15Light(scaling_factor=g["scaling_factor"]).eval()
+    assert sorted(vae.state_dict().keys()) == g["keys"]
+    assert set(g["keys"]) < set(g["all_keys"]) and all(k.startswith("taehv.encoder.") for k in set(g["all_keys"]) - set(g["keys"]))
+    vae.load_state_dict(vae_synthetic_state_dict(vae, g["seed"]), strict=True)
+    for name in ("clip", "frame"):
+        c = g[name]
+        out = vae.decode(seeded(c["shape"], c["seed"]) * c["scale"])
+        ref = c["sequential"]
+        assert out.shape == ref.shape and out.shape[2] == 4 * c["shape"][2] - 3
+        assert c["parallel_max_abs_diff"] < 1e-5
+        assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), (name, float((out - ref).abs().max()))
+        assert float(ref.abs().max()) <= 1.0 and float(ref.std()) > 0.05, "the fixture must exercise the decoder, not the clamp"
+
+
 def test_hunyuan15_wiring_matches_reference_blocks(golden_dir):
     """oracle.hunyuan15 against the reference's own HunyuanVideo-1.5 classes (hybrid oracle, float64 run): token
     refiner with a key-padding mask, t2v and i2v token orders, RoPE on latent tokens only, un-patchify."""
