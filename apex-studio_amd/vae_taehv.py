@@ -219,6 +219,10 @@ class AutoencoderKLHunyuanVideo15Light(nn.Module):
     def dtype(self):
         return self.taehv.dtype
 
+    @property
+    def device(self):
+        return self.taehv.device
+
     def load_taehv_weights(self, taehv_checkpoint_path: str) -> None:
         sd = self.taehv.patch_tgrow_layers(_read_checkpoint(taehv_checkpoint_path))
         self.taehv.load_state_dict({k: v.to(self.taehv.dtype) for k, v in sd.items()}, strict=True)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Time the VAE decodes alone (run under rocprofv3 --kernel-trace --stats for the per-kernel split).
-usage: vae_bench.py flux|wan|wan-untiled|wan-tile|hunyuan [reps]   (wan = the 4 x 7-tile decode the reference always
-takes; wan-tile = ONE of its 28 tiles, [1,16,21,32,32] -> [1,3,81,256,256]: same launches, short enough for --pmc passes)"""
+usage: vae_bench.py flux|wan|wan-untiled|wan-tile|hunyuan|taehv [reps]   (wan = the 4 x 7-tile decode the reference always
+takes; wan-tile = ONE of its 28 tiles, [1,16,21,32,32] -> [1,3,81,256,256]: same launches, short enough for --pmc passes;
+taehv = HunyuanVideo-1.5's light VAE on the same 480p x 121-frame latents as `hunyuan`)"""
 import os
 import sys
 import time
@@ -24,6 +25,12 @@ elif which == "hunyuan":      # HunyuanVideo-1.5 480p x 121 frames: latent [32, 
     vae = synth_vae_init(AutoencoderKLHunyuanVideo15(device=dev, dtype=torch.bfloat16), 7)
     vae.enable_tiling()
     z = torch.randn(1, 32, 31, 30, 52, device=dev).to(torch.bfloat16)
+elif which == "taehv":
+    from apex_studio_amd.vae_taehv import AutoencoderKLHunyuanVideo15Light
+    vae = synth_vae_init(AutoencoderKLHunyuanVideo15Light(device=dev), 8)
+    z = torch.randn(1, 32, 31, 30, 52, device=dev).to(torch.bfloat16)
+    _dec = vae.decode
+    vae.decode = lambda zz, return_dict=False: _dec(zz)           # returns [1, N, 3, T', H', W']; [0] below = the video
 else:
     from apex_studio_amd.vae_wan import AutoencoderKLWan
     vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
