@@ -51,6 +51,8 @@ struct ConvArgs {
     // `act_slope` (0.0 = ReLU) — the TAEHV blocks (conv, act) and act(conv + skip)
     int act;
     float act_slope;
+    // temporal stride (128x128 kernel only): output frame j reads input frames j * st + t0 + dt - (kT - 1); To output frames
+    int To, st, t0;
 };
 APEXMI_DEVICE float conv_act(float v, int act, float slope) { return (act && v < 0.0f) ? v * slope : v; }
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     }
     __syncthreads();
 
-    const int M = a.T * a.Ho * a.Wo;
+    const int M = a.To * a.Ho * a.Wo;
     const int nm = (M + BM - 1) / BM;
     const int nn = (a.Cout + BN - 1) / BN;
     const int s = xcd_remap(blockIdx.x, nm * nn);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
         const int p = (i * 4 + wave) * 64 + lane;
         const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, M - 1);
-        pos_t[i] = m / (a.Ho * a.Wo);
+        pos_t[i] = (m / (a.Ho * a.Wo)) * a.st + a.t0;
         const int r = m % (a.Ho * a.Wo);
         pos_y[i] = (r / a.Wo) * a.sy;   // input row / column of tap (0, 0) before the pad offset
         pos_x[i] = (r % a.Wo) * a.sx;
@@ -572,7 +574,7 @@ int launch_v2(const ConvArgs& a, hipStream_t stream) {
 int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
     *taken = false;
     const int64_t M = (int64_t)a.T * a.H * a.W;
-    if (!g_conv_v2 || a.replicate || a.sy != 1 || a.sx != 1 || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
+    if (!g_conv_v2 || a.replicate || a.sy != 1 || a.sx != 1 || a.st != 1 || a.t0 != 0 || a.To != a.T || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
         (int64_t)a.T * a.Hin * a.Win * a.Cin * 2 >= ((int64_t)1 << 31))   // 32-bit byte offsets in the gather
         return 0;
     const int c = a.Cout;
@@ -888,7 +890,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                           const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
                           int Ho = 0, int Wo = 0, int independent = 0, int up = 0, const void* norm_gamma = nullptr,
-                          void* out_norm = nullptr, int norm_silu = 0, int act = 0, float act_slope = 0.0f) {
+                          void* out_norm = nullptr, int norm_silu = 0, int act = 0, float act_slope = 0.0f, int st = 1,
+                          int t0 = 0, int To = 0) {
     const int Hin = H, Win = W;
     if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
         H *= 2;
@@ -949,7 +952,13 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     APEXMI_REQUIRE(act == 0 || (act == 1 && out_norm == nullptr), "conv3d_cl: activation %d unsupported (0 none, 1 leaky ReLU; "
                                                                   "not together with the fused norm)", act);
     a.act = act; a.act_slope = act_slope;
-    const int64_t M = (int64_t)T * Ho * Wo;
+    if (To <= 0) To = T;
+    APEXMI_REQUIRE(st >= 1 && t0 >= 0 && (To - 1) * st + t0 < T, "conv3d_cl: temporal stride %d / first frame %d / %d output frames "
+                                                                 "do not fit %d input frames", st, t0, To, T);
+    APEXMI_REQUIRE((st == 1 && t0 == 0 && To == T) || (!up && !independent && out_norm == nullptr && T > 1),
+                   "conv3d_cl: a temporal stride excludes the upsample / independent-frame / fused-norm modes");
+    a.To = To; a.st = st; a.t0 = t0;
+    const int64_t M = (int64_t)To * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
                          2.0 * ((double)M * Cin + (double)Cout * Kext + (double)M * Cout));
@@ -1013,6 +1022,14 @@ extern "C" int apexmi_conv3d_cl_strided(const void* in, const void* w, const voi
     APEXMI_REQUIRE(Ho > 0 && Wo > 0, "conv3d_cl_strided: empty output %dx%d", Ho, Wo);
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, stride_h,
                           stride_w, pad_top, pad_left, Ho, Wo);
+}
+
+extern "C" int apexmi_conv3d_cl_tstrided(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                         const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                                         int kW, int stride_t, int t_first, int To, apexmi_stream_t stream_) {
+    APEXMI_REQUIRE(To > 0, "conv3d_cl_tstrided: empty output");
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_, 1, 1, -1, -1, 0, 0,
+                          0, 0, nullptr, nullptr, 0, 0, 0.0f, stride_t, t_first, To);
 }
 
 extern "C" int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_time_interleave_cl": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp]),
     "apexmi_conv3d_cl_act": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 12 + [C.c_float, vp]),
+    "apexmi_conv3d_cl_tstrided": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 12 + [vp]),
     "apexmi_tanh_clamp": (C.c_int, [vp, vp, C.c_int64, C.c_float, vp]),
     "apexmi_pixel_shuffle_clamp": (C.c_int, [vp, vp] + [C.c_int] * 7 + [C.c_float, C.c_float, vp]),
     "apexmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

@@ -695,6 +695,25 @@ def conv3d_cl_norm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch
     return y, yn
 
 
+def conv3d_cl_tstrided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize, stride_t: int,
+                       t_first: int, out_frames: int) -> torch.Tensor:
+    """Causal conv3d evaluated only at input frames t_first, t_first + stride_t, ...: x [T,H,W,Cin] -> [out_frames,H,W,Cout4]
+    (WanResample "downsample3d" time_conv, reference vae/wan/model.py:340-365)."""
+    _req(x, torch.bfloat16, "conv3d_cl_tstrided.x")
+    _req(w_packed, torch.bfloat16, "conv3d_cl_tstrided.w")
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, cin = x.shape
+    cout, kpad = w_packed.shape
+    out = torch.empty((out_frames, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        assert bias.numel() == cout and bias.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl_tstrided(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), None, out.data_ptr(),
+                                             _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]), int(ksize[1]),
+                                             int(ksize[2]), int(stride_t), int(t_first), int(out_frames), _stream())
+    _l.check(rc, "conv3d_cl_tstrided")
+    return out
+
+
 def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """ZeroPad2d((0, 1, 0, 1)) + Conv2d(3x3, stride 2) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4] with
     Ho = (H - 2) // 2 + 1 (= H / 2 for even H); w_packed from pack_conv_weight of the [Cout, Cin, 3, 3] weight."""

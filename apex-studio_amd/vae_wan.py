@@ -420,8 +420,11 @@ class AutoencoderKLWan(nn.Module):
         w, b = self._w(dn.resample[1])
         x = ops.conv2d_cl_down2(x, w, b)
         if dn.mode == "downsample3d" and x.shape[0] > 1 and not self._indep:
-            y = self._conv(dn.time_conv, x)          # causal 3-tap convolution ending at every frame ...
-            x = torch.cat([x[:1], y[2::2]], dim=0)   # ... kept at frames 2, 4, ...; frame 0 passes through
+            # frame 0 passes through; output j >= 1 is the causal 3-tap convolution ending at frame 2j (temporal stride in
+            # the gather: only those frames are computed)
+            w, b = self._w(dn.time_conv)
+            y = ops.conv3d_cl_tstrided(x, w, b, dn.time_conv.ksize, 2, 2, (x.shape[0] - 1) // 2)
+            x = torch.cat([x[:1], y], dim=0)
         return x
 
     def _encode_tile(self, x):

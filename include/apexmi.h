@@ -305,6 +305,15 @@ int apexmi_conv3d_cl_strided(const void* in, const void* w, const void* bias, co
                              int stride_h, int stride_w, int pad_top, int pad_left, int Ho, int Wo,
                              apexmi_stream_t stream);
 
+/* Temporal stride: output frame j (0 <= j < To) is the causal convolution ENDING at input frame j * stride_t + t_first, i.e.
+ * it reads frames j * stride_t + t_first + dt - (kT - 1); out is [To, H, W, Cout].  WanResample "downsample3d" in its
+ * full-sequence form (vae/wan/model.py:340-365: `time_conv` = Conv3d((3,1,1), stride (2,1,1)) over the cached last frame +
+ * the chunk): frame 0 passes through and output j >= 1 convolves frames (2j-2, 2j-1, 2j) = stride_t 2, t_first 2,
+ * To = (T - 1) / 2 — half the work of convolving every frame and keeping every other one. */
+int apexmi_conv3d_cl_tstrided(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                              const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW,
+                              int stride_t, int t_first, int To, apexmi_stream_t stream);
+
 /* HunyuanVideo15CausalConv3d.forward (vae/hunyuanvideo15/model.py:52-90): the same implicit GEMM with REPLICATE padding
  * (coordinates clamped: two frames in front, one pixel around) instead of zeros. */
 int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual, void* out,

@@ -141,9 +141,12 @@ class Downsample(nn.Module):
             hf = dcae_downsample_rearrange(h[:, :, :1], 1, 2, 2)
             hf = torch.cat([hf, hf], dim=1)
             h = torch.cat([hf, dcae_downsample_rearrange(h[:, :, 1:], 2, 2, 2)], dim=2)
-            xf = group_mean(dcae_downsample_rearrange(x[:, :, :1], 1, 2, 2), self.cout)
-            xn = group_mean(dcae_downsample_rearrange(x[:, :, 1:], 2, 2, 2), self.cout)
-            sc = pol.r(torch.cat([xf, xn], dim=2))
+            xf = pol.r(group_mean(dcae_downsample_rearrange(x[:, :, :1], 1, 2, 2), self.cout))   # one storage point each:
+            if x.shape[2] > 1:                                                                      # the HIP path writes two
+                xn = pol.r(group_mean(dcae_downsample_rearrange(x[:, :, 1:], 2, 2, 2), self.cout))
+                sc = torch.cat([xf, xn], dim=2)
+            else:
+                sc = xf
         else:
             h = dcae_downsample_rearrange(h, 1, 2, 2)
             sc = pol.r(group_mean(dcae_downsample_rearrange(x, 1, 2, 2), self.cout))

@@ -107,7 +107,8 @@ def print_report(tag: str, report) -> Tuple[float, float]:
     return worst, mean
 
 
-VAE_OPS = ("conv3d_cl", "conv3d_cl_norm", "conv3d_cl_act", "tanh_clamp", "rmsnorm_cl", "groupnorm_cl", "gemm", "attention")
+VAE_OPS = ("conv3d_cl", "conv3d_cl_norm", "conv3d_cl_act", "conv3d_cl_tstrided", "conv2d_cl_down2", "tanh_clamp", "rmsnorm_cl", "groupnorm_cl", "gemm",
+           "attention", "attention_framecausal", "add", "group_mean")
 
 
 def _oracle_rows(o: torch.Tensor) -> torch.Tensor:
@@ -138,7 +139,7 @@ def run_forced_vae(ops_mod, points: Sequence[torch.Tensor], call: Callable[[], t
     orig = {n: getattr(ops_mod, n) for n in VAE_OPS}
 
     def take(name, out, label=""):
-        base = out.permute(0, 2, 1, 3) if name == "attention" else out      # attention returns a [B,H,S,D] view of [B,S,H,D]
+        base = out.permute(0, 2, 1, 3) if name in ("attention", "attention_framecausal") else out   # [B,H,S,D] views of [B,S,H,D]
         assert base.is_contiguous(), name
         got = base.reshape(-1, base.shape[-1])
         torch.cuda.synchronize()

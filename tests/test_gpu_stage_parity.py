@@ -8,6 +8,8 @@ path (timestep embedding -> MLP -> AdaLN projections) within 2e-6.  The free-run
 next to it: it sits at the bf16 noise floor (2e-3 .. 4e-3), as far from the oracle as the oracle's own bf16 emulation
 is from fp32.
 """
+import os
+
 import pytest
 import torch
 
@@ -187,3 +189,71 @@ def test_taehv_light_vae_every_storage_point():
     e_free = _rel(free, ref16)
     print(f"[stage taehv decode] free-running decode {e_free:.2e}")
     assert torch.equal(out.float().cpu(), ref16.to(torch.bfloat16).float()) and e_free < 2e-2
+
+
+def _vae_stage(tag, pol, ref16, run, free_tol=2e-2):
+    from apex_studio_amd import ops
+    free = run()
+    out, report = SP.run_forced_vae(ops, pol.points, run)
+    worst, _ = SP.print_report(tag, report)
+    assert worst <= SP.STAGE_TOL, worst
+    e_out, e_free = _rel(out, ref16), _rel(free, ref16)
+    print(f"[stage {tag}] output after the last forced point: rel {e_out:.2e}; free-running {e_free:.2e}; {len(report)} points")
+    assert e_out <= SP.STAGE_TOL and e_free < free_tol
+    return report
+
+
+def test_wan_vae_encode_every_storage_point(golden_dir):
+    """Wan / QwenImage VAE ENCODER (image-to-video / edit conditioning): strided 3x3 downsampling, full-sequence temporal
+    downsampling, mid-block attention, quant_conv — a 5-frame clip."""
+    from oracle.vae_wan import AutoencoderKLWanEncoder
+    from tests.golden.seeded import vae_synthetic_state_dict
+    from tests.test_gpu_vae import _hip_vae
+    g = torch.load(os.path.join(golden_dir, "vae_wan_encode.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = AutoencoderKLWanEncoder(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    vae = _hip_vae(cfg, sd)
+    x = seeded(g["x_shape"], g["x_seed"]).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        ref16 = orc.encode(x.float(), policy=pol)
+    _vae_stage("wan vae encode", pol, ref16, lambda: vae.encode(x.to(DEV), return_dict=False)[0].parameters)
+
+
+def _hy_vae_pair(seed):
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    from tests.golden.seeded import vae_synthetic_state_dict
+    cfg = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
+               layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
+    orc = Orc(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, seed)
+    orc.load_state_dict(sd, strict=True)
+    vae = AutoencoderKLHunyuanVideo15(**cfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    return orc, vae
+
+
+def test_hunyuan15_vae_decode_every_storage_point():
+    """HunyuanVideo-1.5 VAE decoder, one 3-latent-frame tile: replicate-padded causal convs, RMS norm + SiLU, frame-causal
+    mid-block attention, DCAE pixel-shuffle upsamplers (conv -> rearrange -> + repeated shortcut), conv_in's channel-repeat
+    shortcut."""
+    orc, vae = _hy_vae_pair(23)
+    z = seeded((1, 32, 3, 6, 8), 67).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        ref16 = orc.decode(z.float(), policy=pol)
+    _vae_stage("hunyuan15 vae decode", pol, ref16, lambda: vae.decode(z.to(DEV), return_dict=False)[0])
+
+
+def test_hunyuan15_vae_encode_every_storage_point():
+    """HunyuanVideo-1.5 VAE encoder, a 5-frame 64 x 96 clip: DCAE pixel-un-shuffle downsamplers with grouped-mean shortcuts
+    (first-frame rule of the temporal ones), the grouped-mean shortcut around conv_out."""
+    orc, vae = _hy_vae_pair(23)
+    x = seeded((1, 3, 5, 64, 96), 68).clamp(-1, 1).to(torch.bfloat16)
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        ref16 = orc.encode(x.float(), policy=pol)
+    _vae_stage("hunyuan15 vae encode", pol, ref16, lambda: vae.encode(x.to(DEV), return_dict=False)[0].parameters)

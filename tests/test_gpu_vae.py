@@ -451,3 +451,23 @@ def test_conv_with_fused_output_rmsnorm(cin, cout, T, H, W, k, up, silu, res):
     assert rel < 2e-5 and frac < 1e-3
     d = (normed.float() - want.float()).abs()
     assert float((d / want.float().abs().clamp_min(1e-3)).max()) < 2.0 ** -6
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W", [(64, 64, 9, 10, 12), (96, 96, 5, 7, 9), (32, 32, 3, 16, 16)])
+def test_conv3d_cl_temporal_stride(cin, cout, T, H, W):
+    """WanResample "downsample3d" time_conv in full-sequence form: output j >= 1 = causal 3x1x1 conv ending at frame 2j —
+    equal (bit for bit) to convolving every frame and keeping frames 2, 4, ..., and to Conv3d(stride=(2,1,1)) on frames 0.."""
+    from apex_studio_amd import ops
+    x = _bf(seeded((T, H, W, cin), 301))
+    w = _bf(seeded((cout, cin, 3, 1, 1), 302, scale=(3 * cin) ** -0.5))
+    b = _bf(seeded((cout,), 303) * 0.1)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    bp = b.to(DEV)
+    To = (T - 1) // 2
+    out = ops.conv3d_cl_tstrided(x.to(DEV), wp, bp, (3, 1, 1), 2, 2, To)
+    full = ops.conv3d_cl(x.to(DEV), wp, bp, (3, 1, 1))
+    assert out.shape == (To, H, W, cout) and torch.equal(out, full[2::2])
+    ref = F.conv3d(x.float().permute(3, 0, 1, 2)[None], w.float(), b.float(), stride=(2, 1, 1))[0].permute(1, 2, 3, 0)
+    assert ref.shape == out.shape and _rel(out.cpu(), ref) < 4e-3
+    with pytest.raises(RuntimeError):
+        ops.conv3d_cl_tstrided(x.to(DEV), wp, bp, (3, 1, 1), 2, 2, To + 1)
