@@ -54,7 +54,8 @@ class RefinerBlock(nn.Module):
         self.norm_out.linear = nn.Linear(dim, 2 * dim)
 
     def forward(self, x, temb, mask, pol: Policy):
-        a = pol.r(L.attn_processor_2_0_policy(self.attn, pol.r(self.norm1(x)), mask, pol))
+        # the projection output is not a storage point: the HIP GEMM adds gate * (o W^T + b) to the residual in f32 and rounds once
+        a = L.attn_processor_2_0_policy(self.attn, pol.r(self.norm1(x)), mask, pol)
         g = self.norm_out.linear(F.silu(temb))
         gate_msa, gate_mlp = g.chunk(2, dim=1)
         x = pol.r(x + a * gate_msa.unsqueeze(1))

@@ -416,6 +416,14 @@ def attn_processor_2_0_policy(attn: "DiffusersAttention", hidden_states: torch.T
     mask = None
     if attention_mask is not None:
         mask = attention_mask.reshape(B, 1, -1, attention_mask.shape[-1]).to(q.dtype)
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=False)
+    if pol.emulate_bf16 and (mask is None or (B == 1 and mask.shape[2] == 1)):
+        # the flash kernel's rounding points (P in bf16 against an integer running max); a key-padding mask drops the
+        # masked keys, which is also how the HIP token refiner applies it
+        if mask is not None:
+            keep = torch.nonzero(mask[0, 0, 0] == 0, as_tuple=False).flatten()
+            k, v = k.index_select(2, keep), v.index_select(2, keep)
+        o = sdpa(q, k, v, policy=pol)
+    else:
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=False)
     o = pol.r(o.transpose(1, 2).reshape(B, S, -1))
     return attn.to_out[0](o)
