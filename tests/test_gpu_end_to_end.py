@@ -11,6 +11,9 @@ classes through the engine's `run()`, once on the CPU oracle with the same seeds
   Qwen   engine/qwenimage/shared.py:346-477      condition image pixels -> tiled VAE encode -> 2 true-CFG steps with the
                                                  norm rescale (:422-429), prediction cut to the target tokens (:405-406)
                                                  -> decode -> frames
+  Hunyuan engine/hunyuanvideo15/i2v.py (+ shared) first-frame pixels -> tiled VAE encode -> condition latents + mask -> 3 CFG
+                                                 steps on bf16 latents -> tiled 3-D VAE decode -> frames, and the same latents
+                                                 through the TAEHV light VAE (`use_light_vae`)
 
 The sampler (scheduler classes, CFG arithmetic) is Python/torch in the reference and here; the oracle chain uses its own
 CPU instance of the same scheduler class (pinned by tests/test_scheduler.py against the reference's in-tree schedulers).
@@ -284,3 +287,90 @@ def test_qwen_edit_pixels_to_frames():
     print(f"[e2e qwen] packed condition latents (tiled VAE encode, posterior mode, normalised): rel {_rel(lat_c, ref16[0][1]):.2e}")
     _frame_report("qwen-edit 2 CFG steps", (lat_hip, dec_hip, frames_hip), (ref16[0][0],) + ref16[1:],
                   (ref32[0][0],) + ref32[1:])
+
+
+def test_hunyuan15_i2v_pixels_to_frames():
+    """HunyuanVideo-1.5 image-to-video (reference engine/hunyuanvideo15/i2v.py + shared): first-frame pixels
+    -> tiled VAE encode (posterior mode, normalised) -> condition latents + mask -> 3 FlowMatch-Euler steps with CFG (bf16
+    latents, as that engine keeps them) -> denormalise -> tiled VAE decode -> uint8 frames, and the same latents through the
+    TAEHV light VAE (`use_light_vae`), HIP engine vs the CPU oracle chain (bf16 storage policy and pure fp32)."""
+    from oracle import hunyuan15 as OH
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as OVae
+    from oracle.vae_taehv import AutoencoderKLHunyuanVideo15Light as OLight
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15I2VEngine
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    from apex_studio_amd.postprocess import tensor_to_frames
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    from apex_studio_amd.vae_taehv import AutoencoderKLHunyuanVideo15Light
+    cfg = dict(in_channels=65, out_channels=32, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+               num_refiner_layers=1, text_embed_dim=64, text_embed_2_dim=128, image_embed_dim=64)
+    orc = OH.HunyuanVideo15Transformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 21)
+    orc.load_state_dict(sd, strict=True)
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=BF)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    vcfg = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
+                layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
+    vorc = OVae(**vcfg).eval()
+    vsd = vae_synthetic_state_dict(vorc, 23)
+    vorc.load_state_dict(vsd, strict=True)
+    vorc.enable_tiling()
+    vae = AutoencoderKLHunyuanVideo15(**vcfg, device=DEV, dtype=BF)
+    vae.load_state_dict({k: v.to(BF) for k, v in vsd.items()}, strict=True)
+    lorc = OLight(scaling_factor=vorc.scaling_factor).eval()
+    lsd = vae_synthetic_state_dict(lorc, 29)
+    lorc.load_state_dict(lsd, strict=True)
+    light = AutoencoderKLHunyuanVideo15Light(scaling_factor=vorc.scaling_factor, device=DEV)
+    light.load_state_dict({k: v.to(BF) for k, v in lsd.items()}, strict=True)
+    vae.set_light_vae(light)
+
+    H, W, F_, steps, g = 160, 192, 9, 3, 4.0
+    img = seeded((1, 3, H, W), 91).clamp(-1, 1).to(BF)
+    pe, pe2 = seeded((1, 12, 64), 92).to(BF), seeded((1, 8, 128), 93).to(BF)
+    ne, ne2 = (pe * 0.5).to(BF), (pe2 * 0.5).to(BF)
+    m1, m2 = torch.ones(1, 12), torch.ones(1, 8)
+    m1[0, 9:] = 0
+    ie = seeded((1, 3, 64), 94).to(BF)
+    lat0 = seeded((1, 32, (F_ - 1) // 4 + 1, H // 16, W // 16), 95).to(BF)
+    eng = HunyuanVideo15I2VEngine(m, vae=vae, vision_num_semantic_tokens=3, vision_states_dim=64)
+    kw = dict(prompt_embeds=pe, prompt_embeds_mask=m1, prompt_embeds_2=pe2, prompt_embeds_mask_2=m2,
+              negative_prompt_embeds=ne, negative_prompt_embeds_mask=m1, negative_prompt_embeds_2=ne2,
+              negative_prompt_embeds_mask_2=m2, guidance_scale=g, height=H, width=W, num_frames=F_,
+              num_inference_steps=steps, latents=lat0, image_embeds=ie)
+    lat_hip = eng.run(image=img.to(DEV), return_latents=True, **kw)
+    dec_hip = eng.run(image=img.to(DEV), use_light_vae=False, **kw)
+    fr_hip = tensor_to_frames(dec_hip, "np")
+    dec_light = eng.run(image=img.to(DEV), use_light_vae=True, **kw)
+    fr_light = tensor_to_frames(dec_light, "np")
+    vae.enable_tiling(use_light_vae=False)
+
+    def chain(pol):
+        st = (lambda x: x.to(BF)) if pol.emulate_bf16 else (lambda x: x.float())
+        first = st(vorc.normalize_latents(st(vorc.encode(img.float().unsqueeze(2), policy=pol)[:, :32]).float()))   # mode()
+        cond = torch.zeros(1, 32, lat0.shape[2], H // 16, W // 16)
+        cond[:, :, 0] = first[:, :, 0].float()
+        mask = torch.zeros(1, 1, lat0.shape[2], H // 16, W // 16)
+        mask[:, :, 0] = 1.0
+        sch = FlowMatchEulerDiscreteScheduler(shift=7.0)          # the engine's default (t2v.py: flow shift 7)
+        ts = sch.set_timesteps(steps, sigmas=torch.linspace(1.0, 0.0, steps + 1, dtype=torch.float64)[:-1])
+        lat = st(lat0)
+        for t in ts:
+            x = torch.cat([lat.float(), cond, mask], dim=1)
+            tt = t.expand(1).to(BF).float()                       # `t.expand(B).to(latents.dtype)`, t2v.py:243-245
+            args = (x, tt)
+            pu = st(orc(*args, ne.float(), m1, ne2.float(), m2, ie.float(), policy=pol))
+            pc = st(orc(*args, pe.float(), m1, pe2.float(), m2, ie.float(), policy=pol))
+            pred = pu + g * (pc - pu)                             # in the storage dtype, as the engine computes it
+            lat = sch.step(pred, t, lat, return_dict=False)[0]
+        z = st(vorc.denormalize_latents(lat.float())).float()
+        dec = st(vorc.decode(z, policy=pol))
+        # the light path: the engine's denormalised latents, divided by the scaling factor again inside the light class
+        dec_l = st(lorc.decode(z, policy=pol))
+        return lat, dec, video_to_uint8_frames(dec), dec_l, video_to_uint8_frames(dec_l)
+
+    with torch.no_grad():
+        r16, r32 = chain(POL), chain(OL.FP32)
+    assert dec_hip.shape == r16[1].shape == (1, 3, F_, H, W) and dec_light.shape == r16[3].shape
+    _frame_report("hunyuan15 i2v 3 steps", (lat_hip, dec_hip, fr_hip), r16[:3], r32[:3])
+    _frame_report("hunyuan15 i2v light VAE", (lat_hip, dec_light, fr_light), (r16[0], r16[3], r16[4]), (r32[0], r32[3], r32[4]))
