@@ -433,8 +433,11 @@ def run_queue(args, dev, rank, world):
         if rank == 0:
             for i, m in enumerate(enc_mods):
                 _synth_text_init(m, 40 + i)
-        bcast["weights"] = dict(render_queue.broadcast_parameters(enc_mods + [fvae, wan.vae], src=0),
-                                what="T5-XXL + CLIP-L + UMT5-XXL text encoders + Flux 2-D VAE + Wan 3-D VAE")
+        what = "T5-XXL + CLIP-L + UMT5-XXL text encoders + Flux 2-D VAE + Wan 3-D VAE"
+        try:
+            bcast["weights"] = dict(render_queue.broadcast_parameters(enc_mods + [fvae, wan.vae], src=0), what=what)
+        except Exception as e:          # reported, never allowed to take the queue down (every rank built its own VAEs above)
+            bcast["weights"] = {"what": what, "error": f"{type(e).__name__}: {e}"[:300]}
         del enc_mods
         torch.cuda.empty_cache()
     wan_cost = 6.0 * args.queue_wan_steps
@@ -591,12 +594,15 @@ def main():
                  "rccl_ranks": dist.get_world_size()}
         mods, what, probe = (None, None, None) if args.no_shared_weights else shared_weights(args.workload, dev, rank)
         if mods is not None:
-            bcast["weights"] = dict(render_queue.broadcast_parameters(mods, src=0), what=what)
-            sums = probe(mods)                                  # every rank encodes the same ids with ITS copy
-            gathered = [torch.empty_like(sums) for _ in range(dist.get_world_size())]
-            dist.all_gather(gathered, sums)
-            bcast["weights"]["verified"] = bool(all(torch.equal(g, gathered[0]) for g in gathered)
-                                                and torch.isfinite(gathered[0]).all())
+            try:
+                bcast["weights"] = dict(render_queue.broadcast_parameters(mods, src=0), what=what)
+                sums = probe(mods)                              # every rank encodes the same ids with ITS copy
+                gathered = [torch.empty_like(sums) for _ in range(dist.get_world_size())]
+                dist.all_gather(gathered, sums)
+                bcast["weights"]["verified"] = bool(all(torch.equal(g, gathered[0]) for g in gathered)
+                                                    and torch.isfinite(gathered[0]).all())
+            except Exception as e:      # the exchange step is reported, never allowed to take the timed region down with it
+                bcast["weights"] = {"what": what, "error": f"{type(e).__name__}: {e}"[:300], "verified": False}
             del mods
             torch.cuda.empty_cache()
 
