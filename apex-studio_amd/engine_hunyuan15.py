@@ -29,6 +29,8 @@ def _emit(cb, p, msg):
 
 
 class HunyuanVideo15T2VEngine(EngineLoraMixin):
+    _passes_timestep_r = False
+
     def __init__(self, transformer, vae=None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
                  vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 16,
                  vision_num_semantic_tokens: int = 729, vision_states_dim: int = 1152, decode_fn=None):
@@ -65,14 +67,19 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         for i, t in enumerate(timesteps):
             x = torch.cat([latents.to(dt), cond_latents, mask], dim=1)
             timestep = t.expand(x.shape[0]).to(dt)
+            extra = {}
+            # i2v.py:281-288: r = the NEXT timestep (0 after the last); the reference's t2v loop never passes timestep_r
+            if self._passes_timestep_r and getattr(self.transformer.config, "use_meanflow", False):
+                tr = timesteps[i + 1] if i + 1 < n else torch.zeros((), device=t.device, dtype=t.dtype)
+                extra["timestep_r"] = tr.expand(x.shape[0]).to(dt)
             pred = None
             if uncond is not None:
                 with self.transformer.cache_context("pred_uncond"):
                     pred_u = self.transformer(hidden_states=x, image_embeds=image_embeds, timestep=timestep,
-                                              return_dict=False, **uncond)[0]
+                                              return_dict=False, **extra, **uncond)[0]
             with self.transformer.cache_context("pred_cond"):
                 pred_c = self.transformer(hidden_states=x, image_embeds=image_embeds, timestep=timestep,
-                                          return_dict=False, **cond)[0]
+                                          return_dict=False, **extra, **cond)[0]
             if uncond is not None:
                 pred = pred_u + guidance_scale * (pred_c - pred_u)
                 if guidance_rescale > 0.0:    # arXiv 2305.08891 §3.4, t2v.py:291-303
@@ -140,7 +147,12 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         if self.decode_fn is None and self.vae is None:
             raise RuntimeError("hunyuanvideo15: no decode_fn / VAE attached; pass return_latents=True")
         if self.decode_fn is None:
-            self.vae.enable_tiling(use_light_vae=use_light_vae)      # t2v.py:350 / i2v.py:396
+            try:
+                self.vae.enable_tiling(use_light_vae=use_light_vae)      # t2v.py:350 / i2v.py:396
+            except TypeError:                                            # a VAE class without the light-VAE switch
+                if use_light_vae:
+                    raise
+                self.vae.enable_tiling()
         _emit(progress_callback, 0.94, "Decoding latents to video with light VAE" if use_light_vae else "Decoding latents")
         video = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents)
         _emit(progress_callback, 1.0, "Completed text-to-video pipeline")
@@ -154,6 +166,8 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
 class HunyuanVideo15I2VEngine(HunyuanVideo15T2VEngine):
     """Image-to-video: `run(image=pixels [B|1, 3, H, W] in [-1, 1] (or first-frame latents [B|1, 32, 1, h, w]),
     image_embeds=SigLIP states [B|1, 729, 1152], ...)`; everything else as the text-to-video engine."""
+
+    _passes_timestep_r = True
 
     def vae_encode(self, image: torch.Tensor, sample_mode: str = "mode", generator=None) -> torch.Tensor:
         """BaseEngine.vae_encode: tiling on, encode, posterior mode / sample, normalise in the VAE dtype."""

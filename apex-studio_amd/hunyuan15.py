@@ -16,7 +16,8 @@ first (the reference concatenates latent tokens first — attention does not dep
 Around it: the token refiner (two masked self-attention blocks over the MLLM tokens with gates from the pooled
 prompt, "linear-silu" MLP), the ByT5 and image projections (erf GELU), the `[valid image | valid byt5 | valid mllm |
 invalid image | zeros | zeros]` token reorder (:1058-1108), AdaLayerNormContinuous + un-patchify.
-The MeanFlow branch (`use_meanflow`, `timestep_r`) is not implemented and raises.
+The MeanFlow branch (`use_meanflow`: a second timestep embedder for `timestep_r`, model.py:234-268) adds its embedding to
+temb with one more GEMV pair.
 """
 from __future__ import annotations
 
@@ -129,8 +130,6 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         super().__init__()
         if attention_head_dim != 128 or qk_norm != "rms_norm":
             raise _l.ApexMIError("hunyuanvideo15.mi355: attention_head_dim must be 128 and qk_norm 'rms_norm'")
-        if use_meanflow:
-            raise NotImplementedError("hunyuanvideo15.mi355: the MeanFlow (super-resolution) variant is not implemented")
         out_channels = out_channels or in_channels
         self.config = _Config(in_channels=in_channels, out_channels=out_channels, num_attention_heads=num_attention_heads,
                               attention_head_dim=attention_head_dim, num_layers=num_layers,
@@ -147,6 +146,8 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         self.context_embedder_2 = _ByT5(text_embed_2_dim, 2048, dim, **kw)
         self.time_embed = nn.Module()
         self.time_embed.timestep_embedder = _TimestepEmbedding(256, dim, **kw)
+        if use_meanflow:      # HunyuanVideo15TimeEmbedding (model.py:234-268): temb = embed(t) + embed_r(r)
+            self.time_embed.timestep_embedder_r = _TimestepEmbedding(256, dim, **kw)
         self.cond_type_embed = _Embedding(3, dim, **kw)
         self.transformer_blocks = nn.ModuleList(
             [_Block(dim, num_attention_heads, attention_head_dim, int(dim * mlp_ratio), **kw) for _ in range(num_layers)])
@@ -331,7 +332,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         return x
 
     @torch.no_grad()
-    def _forward_one(self, latent, timestep, text, mask, text2, mask2, image):
+    def _forward_one(self, latent, timestep, text, mask, text2, mask2, image, timestep_r=None):
         cfg = self.config
         dim, H = self.inner_dim, cfg.num_attention_heads
         pt, p = cfg.patch_size_t, cfg.patch_size
@@ -381,6 +382,11 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         ops.gemm(A, self._w_patch, self.x_embedder.proj.bias, out=Xi)
 
         self._temb(self.time_embed.timestep_embedder, t, out=ws.TEMB)
+        if timestep_r is not None:
+            ter = self.time_embed.timestep_embedder_r
+            tr = timestep_r.to(self.dtype).float().reshape(1)      # `timestep_r.expand(B).to(latents.dtype)`, i2v.py:281-286
+            hr = ops.gemv(ter.linear_1.weight, ops.timestep_embedding(tr, 256, scale=1.0), ter.linear_1.bias, post="silu")
+            ops.gemv(ter.linear_2.weight, hr, ter.linear_2.bias, out=ws.TEMB, accum=True)
         n_first = self._mod_first
         ops.gemv(self._mod_w[:n_first], ws.TEMB, self._mod_b[:n_first], out=ws.MOD[:, :n_first], pre_silu=True)
         mod_ready = None
@@ -438,8 +444,8 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
                 encoder_hidden_states_2: Optional[torch.Tensor] = None,
                 encoder_attention_mask_2: Optional[torch.Tensor] = None, image_embeds: Optional[torch.Tensor] = None,
                 attention_kwargs=None, rope_on_cpu=None, return_dict: bool = True):
-        if timestep_r is not None:
-            raise NotImplementedError("hunyuanvideo15.mi355: timestep_r (MeanFlow) is not implemented")
+        if timestep_r is not None and not self.config.use_meanflow:
+            raise ValueError("hunyuanvideo15.mi355: timestep_r given but the model was built with use_meanflow=False")
         self.pack()
         bf = torch.bfloat16
         outs = []
@@ -447,7 +453,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
             outs.append(self._forward_one(
                 hidden_states[b].to(bf).contiguous(), timestep[b:b + 1], encoder_hidden_states[b].to(bf).contiguous(),
                 encoder_attention_mask[b], encoder_hidden_states_2[b].to(bf).contiguous(), encoder_attention_mask_2[b],
-                image_embeds[b].to(bf).contiguous()))
+                image_embeds[b].to(bf).contiguous(), None if timestep_r is None else timestep_r[b:b + 1]))
         out = torch.stack(outs, dim=0).to(hidden_states.dtype)
         if not return_dict:
             return (out,)

@@ -164,9 +164,10 @@ class HunyuanVideo15Transformer3DModel(nn.Module):
                  attention_head_dim: int = 128, num_layers: int = 54, num_refiner_layers: int = 2, mlp_ratio: float = 4.0,
                  patch_size: int = 1, patch_size_t: int = 1, qk_norm: str = "rms_norm", text_embed_dim: int = 3584,
                  text_embed_2_dim: int = 1472, image_embed_dim: int = 1152, rope_theta: float = 256.0,
-                 rope_axes_dim=(16, 56, 56), **_unused):
+                 rope_axes_dim=(16, 56, 56), use_meanflow: bool = False, **_unused):
         super().__init__()
         dim = num_attention_heads * attention_head_dim
+        self.use_meanflow = use_meanflow
         self.p, self.pt, self.out_channels = patch_size, patch_size_t, out_channels or in_channels
         self.rope_axes_dim, self.rope_theta = tuple(rope_axes_dim), rope_theta
         self.x_embedder = nn.Module()
@@ -178,6 +179,8 @@ class HunyuanVideo15Transformer3DModel(nn.Module):
         self.time_embed = nn.Module()
         self.time_embed.time_proj = L.Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0)
         self.time_embed.timestep_embedder = L.TimestepEmbedding(in_channels=256, time_embed_dim=dim)
+        if use_meanflow:      # HunyuanVideo15TimeEmbedding, model.py:234-268 (time_proj_r has no parameters)
+            self.time_embed.timestep_embedder_r = L.TimestepEmbedding(in_channels=256, time_embed_dim=dim)
         self.cond_type_embed = nn.Embedding(3, dim)
         self.transformer_blocks = nn.ModuleList(
             [TransformerBlock(num_attention_heads, attention_head_dim, mlp_ratio) for _ in range(num_layers)])
@@ -186,7 +189,7 @@ class HunyuanVideo15Transformer3DModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, encoder_hidden_states_2,
-                encoder_attention_mask_2, image_embeds, policy: Policy = FP32):
+                encoder_attention_mask_2, image_embeds, policy: Policy = FP32, timestep_r=None):
         pol = policy
         B, _, F_, H, W = hidden_states.shape
         grid = (F_ // self.pt, H // self.p, W // self.p)
@@ -194,6 +197,9 @@ class HunyuanVideo15Transformer3DModel(nn.Module):
         # the engine passes `t.expand(B).to(latents.dtype)` (engine/hunyuanvideo15/t2v.py:243-245): bf16 with bf16 latents
         t = timestep.to(torch.bfloat16).float() if pol.emulate_bf16 else timestep.float()
         temb = self.time_embed.timestep_embedder(self.time_embed.time_proj(t))
+        if timestep_r is not None:
+            tr = timestep_r.to(torch.bfloat16).float() if pol.emulate_bf16 else timestep_r.float()
+            temb = temb + self.time_embed.timestep_embedder_r(self.time_embed.time_proj(tr))
         x = pol.r(self.x_embedder.proj(hidden_states).flatten(2).transpose(1, 2))
         c1 = self.context_embedder(encoder_hidden_states, t, encoder_attention_mask, pol)
         c1 = pol.r(c1 + self.cond_type_embed.weight[0])

@@ -552,6 +552,36 @@ def gen_hunyuan15_hybrid():
                     keys=sorted(sd.keys())), os.path.join(OUT, "hunyuan15_hybrid.pt"))
 
 
+def gen_hunyuan15_meanflow():
+    """The reference HunyuanVideo15Transformer3DModel built with use_meanflow=True (a second timestep embedder for
+    `timestep_r`, model.py:234-268), float64, i2v inputs, timestep 500 with timestep_r 300 and with timestep_r None."""
+    import src.attention  # noqa: F401
+    from src.transformer.hunyuanvideo15.base.model import HunyuanVideo15Transformer3DModel as Ref
+    from oracle.hunyuan15 import HunyuanVideo15Transformer3DModel as Orc
+    cfg = dict(TINY_HY15, use_meanflow=True)
+    ref = Ref(**cfg).eval()
+    orc = Orc(**cfg).eval()
+    sd = synthetic_state_dict(orc, 17)
+    assert sorted(sd.keys()) == sorted(ref.state_dict().keys()), set(sd) ^ set(ref.state_dict())
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.double()
+    inp = hy15_inputs()
+    img = seeded((1, 3, 64), 64)
+    outs = {}
+    for name, tr in (("r300", torch.tensor([300.0])), ("none", None)):
+        with torch.no_grad():
+            outs[name] = ref(hidden_states=inp["hidden_states"].double(), timestep=inp["timestep"].double(),
+                             timestep_r=None if tr is None else tr.double(),
+                             encoder_hidden_states=inp["encoder_hidden_states"].double(),
+                             encoder_attention_mask=inp["encoder_attention_mask"],
+                             encoder_hidden_states_2=inp["encoder_hidden_states_2"].double(),
+                             encoder_attention_mask_2=inp["encoder_attention_mask_2"],
+                             image_embeds=img.double(), return_dict=False)[0].float()
+        print("hunyuan15_meanflow", name, tuple(outs[name].shape), float(outs[name].abs().mean()))
+    torch.save(dict(config=cfg, seed=17, inputs=inp, image_embeds=img, timestep_r=torch.tensor([300.0]), out=outs,
+                    keys=sorted(sd.keys())), os.path.join(OUT, "hunyuan15_meanflow.pt"))
+
+
 def gen_lora():
     """Reference LoraConverter on seeded state dicts.  Stubs: the two rename tables imported from diffusers (only
     used for the legacy diffusers formats, not exercised) and src.quantize.ggml_ops (imported by converters/utils,
@@ -750,6 +780,7 @@ def main():
     gen_wan_hybrid()
     gen_qwen_hybrid()
     gen_hunyuan15_hybrid()
+    gen_hunyuan15_meanflow()
     gen_vae_wan()
     gen_vae_wan_encode()
     gen_vae_hunyuan15()

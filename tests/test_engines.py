@@ -184,3 +184,37 @@ def test_hunyuan15_i2v_condition_latents_mask_and_image_embeds():
     import pytest
     with pytest.raises(ValueError):
         eng2.run(**kw)
+
+
+def test_hunyuan15_meanflow_timestep_r_schedule():
+    """reference engine/hunyuanvideo15/i2v.py:281-288: with `config.use_meanflow` the i2v loop passes timestep_r = the NEXT
+    timestep (0 after the last), expanded to the batch in the latents' dtype; its t2v loop never passes one."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15I2VEngine, HunyuanVideo15T2VEngine
+    seen = []
+
+    class _Fake(_FakeHunyuan):
+        def __init__(self, meanflow):
+            super().__init__()
+            self.config = SimpleNamespace(in_channels=65, use_meanflow=meanflow)
+
+        def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, encoder_hidden_states_2,
+                     encoder_attention_mask_2, image_embeds, return_dict=False, **kw):
+            seen.append((float(timestep[0]), None if "timestep_r" not in kw else float(kw["timestep_r"][0])))
+            if "timestep_r" in kw:
+                assert kw["timestep_r"].shape == timestep.shape and kw["timestep_r"].dtype == hidden_states.dtype
+            return (hidden_states[:, :32] * 0.1,)
+
+    kw = dict(prompt_embeds=torch.ones(1, 6, 8), prompt_embeds_mask=torch.ones(1, 6), prompt_embeds_2=torch.ones(1, 4, 8),
+              prompt_embeds_mask_2=torch.ones(1, 4), height=64, width=96, num_frames=9, num_inference_steps=3,
+              generator=torch.Generator().manual_seed(0), return_latents=True)
+    first = torch.zeros(1, 32, 1, 4, 6)
+    HunyuanVideo15I2VEngine(_Fake(True)).run(image=first, **kw)
+    ts = [t for t, _ in seen]
+    assert len(seen) == 3 and [r for _, r in seen] == ts[1:] + [0.0] and ts == sorted(ts, reverse=True)
+    seen.clear()
+    HunyuanVideo15I2VEngine(_Fake(False)).run(image=first, **kw)
+    assert [r for _, r in seen] == [None] * 3
+    seen.clear()
+    HunyuanVideo15T2VEngine(_Fake(True)).run(**kw)
+    assert [r for _, r in seen] == [None] * 3

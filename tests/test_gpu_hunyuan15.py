@@ -139,3 +139,34 @@ def test_hunyuan15_i2v_engine_pixels_to_frames():
     assert _rel(other, lat) > 1e-3, "the first-frame condition must reach the transformer"
     frames = eng.run(image=img.to(DEV), output_type="np", **kw)
     assert frames.shape == (1, F_, H, W, 3) and frames.dtype.name == "uint8"
+
+
+def test_hunyuan15_meanflow_timestep_r(golden_dir):
+    """`use_meanflow=True` (reference model.py:234-268, i2v.py:281-288): temb = embed(t) + embed_r(r).  HIP vs the oracle and
+    vs the reference-wiring golden; r = None leaves the second embedder out; a model built without it refuses timestep_r."""
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    g = torch.load(os.path.join(golden_dir, "hunyuan15_meanflow.pt"), weights_only=False)
+    cfg = {k: v for k, v in g["config"].items() if k not in ("qk_norm", "mlp_ratio", "rope_theta", "rope_axes_dim", "patch_size",
+                                                               "patch_size_t")}
+    orc = OH.HunyuanVideo15Transformer3DModel(**g["config"]).eval()
+    sd = synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    assert sorted(m.state_dict().keys()) == g["keys"]
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    inp = dict(g["inputs"], image_embeds=g["image_embeds"])
+    dev = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k != "timestep" and "mask" not in k else v.to(DEV))
+           for k, v in inp.items()}
+    r = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 and k != "timestep" and "mask" not in k else v)
+         for k, v in inp.items()}
+    for name, tr in (("r300", g["timestep_r"]), ("none", None)):
+        out = m(return_dict=False, timestep_r=None if tr is None else tr.to(DEV), **dev)[0].float().cpu()
+        ref16 = orc(r["hidden_states"], r["timestep"], r["encoder_hidden_states"], r["encoder_attention_mask"],
+                    r["encoder_hidden_states_2"], r["encoder_attention_mask_2"], r["image_embeds"], policy=OL.BF16_STORAGE,
+                    timestep_r=tr)
+        e_like, e_gold = _rel(out, ref16), _rel(out, g["out"][name])
+        print(f"[hunyuan15 meanflow {name}] hip vs bf16-storage oracle {e_like:.3e}; vs reference-wiring f64 golden {e_gold:.3e}")
+        assert e_like < 6e-3 and e_gold < 3e-2
+    plain = HunyuanVideo15Transformer3DModel(**dict(cfg, use_meanflow=False), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        plain(return_dict=False, timestep_r=g["timestep_r"].to(DEV), **dev)

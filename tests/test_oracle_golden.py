@@ -315,3 +315,22 @@ def test_vae_encode_full_sequence_restatement_matches_streaming_reference(golden
     vae.enable_tiling(*g["tile"])
     assert torch.allclose(vae.encode(x), g["video_tiled"], atol=2e-5, rtol=1e-4)
     assert torch.allclose(vae.encode(x[:, :, :1]), g["image_tiled"], atol=2e-5, rtol=1e-4)
+
+
+def test_hunyuan15_meanflow_time_embedding_matches_reference(golden_dir):
+    """oracle.hunyuan15 built with use_meanflow=True against the reference class (hunyuan15_meanflow.pt, float64 run): the
+    second timestep embedder's output is added to temb when `timestep_r` is given and ignored when it is None."""
+    from oracle.hunyuan15 import HunyuanVideo15Transformer3DModel
+    g = torch.load(os.path.join(golden_dir, "hunyuan15_meanflow.pt"), weights_only=False)
+    m = HunyuanVideo15Transformer3DModel(**g["config"]).eval()
+    sd = synthetic_state_dict(m, g["seed"])
+    assert sorted(sd.keys()) == g["keys"] and any("timestep_embedder_r" in k for k in g["keys"])
+    m.load_state_dict(sd)
+    i = g["inputs"]
+    for name, tr in (("r300", g["timestep_r"]), ("none", None)):
+        out = m(i["hidden_states"], i["timestep"], i["encoder_hidden_states"], i["encoder_attention_mask"],
+                i["encoder_hidden_states_2"], i["encoder_attention_mask_2"], g["image_embeds"], timestep_r=tr)
+        ref = g["out"][name]
+        rel = float((out - ref).norm() / ref.norm())
+        assert rel < 1e-5, (name, rel)
+    assert float((g["out"]["r300"] - g["out"]["none"]).norm() / g["out"]["none"].norm()) > 1e-2
