@@ -11,7 +11,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-// MODE 0: LDS-DMA, MODE 1: plain VGPR load, MODE 2: ds_read_b128 instead of a memory load
+// MODE 0: LDS-DMA, MODE 1: plain VGPR load, MODE 2: ds_read_b128 instead of a memory load, MODE 3: buffer_load .. lds,
+// MODE 4: register-staged path — buffer_load_dwordx4 into a 4-deep VGPR ring, ds_write_b128 of the piece loaded 4 pieces ago
 template <int WAVES, int GAP, int MODE, int STAGGER, int ACCA = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void k(const char* src, float* out, unsigned long long* cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -30,6 +31,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k(const char* src, float* out, 
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 8 * 16384, 0x00020000);
     const int voff = (lane >> 3) * 16384 + (lane & 7) * 16;
     u32x4 sink = {0, 0, 0, 0};
+    u32x4 ring[4] = {};
+    int npiece = 0;
     if (STAGGER) {
         for (int i = 0; i < wave * STAGGER; ++i) asm volatile("s_nop 15");
     }
@@ -48,6 +51,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k(const char* src, float* out, 
                 } else if (MODE == 3) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + ((m / GAP) & 7) * 1024), 16, voff,
                                                          ((it * 32 + m) & 127) * 128, 0, 0);
+                } else if (MODE == 4) {
+                    const int slot = (m / GAP) & 3;      // compile-time after unrolling (32 % (4 GAP) == 0 for GAP in {2, 4, 8})
+                    if (npiece >= 4) {
+                        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        asm volatile("ds_write_b128 %0, %1" ::"v"((uint32_t)(uintptr_t)(dst + ((m / GAP) & 7) * 1024 + lane * 16)),
+                                     "v"(ring[slot])
+                                     : "memory");
+                    }
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ring[slot]) : "v"(voff), "s"(rsrc),
+                                 "s"(((it * 32 + m) & 127) * 128) : "memory");
+                    ++npiece;
                 } else if (MODE == 1) {
                     sink ^= *(const u32x4*)(p + (size_t)((it * 32 + m) & 127) * 128);
                 } else {
@@ -119,6 +133,10 @@ int main() {
     run<8, 4, 0, 0, 1>("8 waves, glds every 4, AGPR acc", src, out, cyc, blocks);
     run<8, 4, 3, 0, 1>("8 waves, buffer_load lds every 4, AGPR acc", src, out, cyc, blocks);
     run<4, 4, 0, 0, 1>("4 waves, glds every 4, AGPR acc", src, out, cyc, blocks);
+    run<8, 4, 4, 0>("8 waves, VGPR-staged (load + ds_write) every 4", src, out, cyc, blocks);
+    run<4, 4, 4, 0>("4 waves, VGPR-staged (load + ds_write) every 4", src, out, cyc, blocks);
+    run<8, 8, 4, 0>("8 waves, VGPR-staged (load + ds_write) every 8", src, out, cyc, blocks);
+    run<8, 4, 4, 0, 1>("8 waves, VGPR-staged every 4, AGPR acc", src, out, cyc, blocks);
     run<8, 1, 2, 0>("8 waves, ds_read_b128 every MFMA", src, out, cyc, blocks);
     run<4, 1, 2, 0>("4 waves, ds_read_b128 every MFMA", src, out, cyc, blocks);
     return 0;
