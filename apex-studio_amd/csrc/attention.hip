@@ -1018,6 +1018,8 @@ namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
+// (measured with the limit raised to 3/4 of a round: the Flux launch, 256 + 176 workgroups, gets 13 % SLOWER, 0.281 vs
+// 0.2485 ms — a 2/3-full last round already runs at the higher clock its idle CUs pay for)
 int attn_tail(int total, int Sk) {
     const int tail = total % ATT_NCU, rounds = total / ATT_NCU;
     return (g_attn_split && tail > 0 && tail * 4 <= ATT_NCU && rounds >= 1 && rounds <= 8 && Sk >= ATT_NSPLIT * 8 * KV) ? tail : 0;
