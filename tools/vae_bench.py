@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import apex_studio_amd  # noqa: E402,F401
 from bench import synth_vae_init  # noqa: E402
 
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):        # TUNE="conv.v2=2" etc. (apexmi_tune_set keys)
+    from apex_studio_amd import lib as _lib
+    _lib.tune_set(kv.split("=")[0], int(kv.split("=")[1]))
 which = sys.argv[1] if len(sys.argv) > 1 else "flux"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
