@@ -212,6 +212,170 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     }
 }
 
+// ---- shared epilogue of the conv-shaped kernels: acc[NT][MT] 32x32 tiles of one wave, mrow[mt] = output position (row
+// of the [positions, Cout] matrix) of this lane's row in m-tile mt or -1, wave (wm, wn) of a WMW x WNW wave grid, n0 = first
+// output channel of the workgroup tile ------------------------------------------------------------------------------------
+template <int MT, int NT, int WNW, int NORM>
+APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const int (&mrow)[MT], int n0, int wm, int wn,
+                                 int l31, int hi, char* smem) {
+    // ---- epilogue: bias (+ residual) -> bf16.  A lane holds out[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3, per 32-column
+    // tile; pairs of groups are exchanged with the other half-wave (v_permlane32_swap) into 8 CONSECUTIVE columns, so
+    // residual loads and stores are 16 bytes per lane (the GEMM's epilogue trick).
+    auto swap_pair = [](u32x2& x, u32x2& y) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            auto r = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);
+            x[i] = r[0];
+            y[i] = r[1];
+        }
+    };
+    float ssq[MT];
+    if (!NORM && (a.Cout & 7) != 0) {   // Cout = 4 (conv_out, 3 channels + pad): 8-byte accesses, no exchange
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mrow[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * hi;
+                    if (m < 0 || n >= a.Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
+                    if (a.bias != nullptr) {
+                        const u32x2 b = *(const u32x2*)(a.bias + n);
+                        v[0] += bf16_lo(b[0]);
+                        v[1] += bf16_hi(b[0]);
+                        v[2] += bf16_lo(b[1]);
+                        v[3] += bf16_hi(b[1]);
+                    }
+                    if (a.res != nullptr) {
+                        const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
+                        v[0] += bf16_lo(r[0]);
+                        v[1] += bf16_hi(r[0]);
+                        v[2] += bf16_lo(r[1]);
+                        v[3] += bf16_hi(r[1]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
+                    *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        ssq[mt] = 0.0f;
+        const int m = mrow[mt];
+        const int64_t mrow_b = (int64_t)max(m, 0) * a.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nb = n0 + wn * (NT * 32) + nt * 32;
+                const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
+                if (nb + 16 * pr >= a.Cout) continue;             // wave-uniform; lanes past Cout inside the pair store nothing
+                u32x2 ra = {0u, 0u}, rb = {0u, 0u};
+                if (a.res != nullptr) {
+                    const u32x4 rr = *(const u32x4*)(a.res + mrow_b + min(nst, a.Cout - 8));
+                    ra = u32x2{rr[0], rr[1]};
+                    rb = u32x2{rr[2], rr[3]};
+                    swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
+                }
+                u32x2 o[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * pr + q;
+                    const int n = min(nb + 8 * g + 4 * hi, a.Cout - 4);
+                    float v[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
+                    if (a.bias != nullptr) {
+                        const u32x2 b = *(const u32x2*)(a.bias + n);
+                        v[0] += bf16_lo(b[0]);
+                        v[1] += bf16_hi(b[0]);
+                        v[2] += bf16_lo(b[1]);
+                        v[3] += bf16_hi(b[1]);
+                    }
+                    const u32x2 r2 = q ? rb : ra;
+                    v[0] += bf16_lo(r2[0]);
+                    v[1] += bf16_hi(r2[0]);
+                    v[2] += bf16_lo(r2[1]);
+                    v[3] += bf16_hi(r2[1]);
+                    if (!NORM) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
+                    }
+                    o[q][0] = pack_bf16(v[0], v[1]);
+                    o[q][1] = pack_bf16(v[2], v[3]);
+                    if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
+                        const float r0 = bf16_lo(o[q][0]), r1 = bf16_hi(o[q][0]), r2f = bf16_lo(o[q][1]), r3 = bf16_hi(o[q][1]);
+                        acc[nt][mt][4 * g + 0] = r0;
+                        acc[nt][mt][4 * g + 1] = r1;
+                        acc[nt][mt][4 * g + 2] = r2f;
+                        acc[nt][mt][4 * g + 3] = r3;
+                        if (nb + 8 * g + 4 * hi < a.Cout) ssq[mt] += r0 * r0 + r1 * r1 + r2f * r2f + r3 * r3;
+                    }
+                }
+                if (!NORM || a.out != nullptr) {
+                    swap_pair(o[0], o[1]);
+                    if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                }
+            }
+    }
+    if constexpr (NORM) {
+        // a row's channels: this lane's groups + those of lane ^ 32, and (WNW > 1) the other waves of the row through LDS
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ssq[mt] = sum_xor32(ssq[mt]);
+        if constexpr (WNW > 1) {
+            float* red = (float*)smem;          // the staging buffers are free: every wave is past its last fragment read
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (hi == 0) red[(wm * (MT * 32) + mt * 32 + l31) * WNW + wn] = ssq[mt];
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WNW; ++w) t += red[(wm * (MT * 32) + mt * 32 + l31) * WNW + w];
+                ssq[mt] = t;
+            }
+        }
+        const float root_c = sqrtf((float)a.Cout);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mrow[mt];
+            const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int nb = n0 + wn * (NT * 32) + nt * 32;
+                    const int nst = nb + 8 * (2 * pr + hi);
+                    if (nb + 16 * pr >= a.Cout) continue;
+                    u32x2 o[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * pr + q;
+                        const u32x2 gm = *(const u32x2*)(a.norm_gamma + min(nb + 8 * g + 4 * hi, a.Cout - 4));
+                        float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
+                                      acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
+                        if (a.norm_silu) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
+                        }
+                        o[q][0] = pack_bf16(y[0], y[1]);
+                        o[q][1] = pack_bf16(y[2], y[3]);
+                    }
+                    swap_pair(o[0], o[1]);
+                    if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                }
+        }
+    }
+}
+
 // ---- v2: conv-shaped tiles ---------------------------------------------------------------------------------------
 // The 128x128 kernel above is co-limited by LDS bandwidth (64x64 wave tiles: 4 fragment reads per 4 MFMAs) and wastes
 // a quarter of the matrix work on the 96- and 192-channel stages that hold 3/4 of the Wan decode's FLOPs.  v2 keeps the
@@ -380,162 +544,13 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
         }
     }
 
-    // ---- epilogue: bias (+ residual) -> bf16.  A lane holds out[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3, per 32-column
-    // tile; pairs of groups are exchanged with the other half-wave (v_permlane32_swap) into 8 CONSECUTIVE columns, so
-    // residual loads and stores are 16 bytes per lane (the GEMM's epilogue trick).
-    auto swap_pair = [](u32x2& x, u32x2& y) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            auto r = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);
-            x[i] = r[0];
-            y[i] = r[1];
-        }
-    };
-    float ssq[MT];
-    if (!NORM && (a.Cout & 7) != 0) {   // Cout = 4 (conv_out, 3 channels + pad): 8-byte accesses, no exchange
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * (NT * 32) + nt * 32 + 8 * g + 4 * hi;
-                    if (m >= M || n >= a.Cout) continue;
-                    float v[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
-                    if (a.bias != nullptr) {
-                        const u32x2 b = *(const u32x2*)(a.bias + n);
-                        v[0] += bf16_lo(b[0]);
-                        v[1] += bf16_hi(b[0]);
-                        v[2] += bf16_lo(b[1]);
-                        v[3] += bf16_hi(b[1]);
-                    }
-                    if (a.res != nullptr) {
-                        const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
-                        v[0] += bf16_lo(r[0]);
-                        v[1] += bf16_hi(r[0]);
-                        v[2] += bf16_lo(r[1]);
-                        v[3] += bf16_hi(r[1]);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
-                    *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                }
-        }
-        return;
-    }
+    int mrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        ssq[mt] = 0.0f;
         const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
-        const int64_t mrow = (int64_t)min(m, M - 1) * a.Cout;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int nb = n0 + wn * (NT * 32) + nt * 32;
-                const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
-                if (nb + 16 * pr >= a.Cout) continue;             // wave-uniform; lanes past Cout inside the pair store nothing
-                u32x2 ra = {0u, 0u}, rb = {0u, 0u};
-                if (a.res != nullptr) {
-                    const u32x4 rr = *(const u32x4*)(a.res + mrow + min(nst, a.Cout - 8));
-                    ra = u32x2{rr[0], rr[1]};
-                    rb = u32x2{rr[2], rr[3]};
-                    swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
-                }
-                u32x2 o[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * pr + q;
-                    const int n = min(nb + 8 * g + 4 * hi, a.Cout - 4);
-                    float v[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
-                    if (a.bias != nullptr) {
-                        const u32x2 b = *(const u32x2*)(a.bias + n);
-                        v[0] += bf16_lo(b[0]);
-                        v[1] += bf16_hi(b[0]);
-                        v[2] += bf16_lo(b[1]);
-                        v[3] += bf16_hi(b[1]);
-                    }
-                    const u32x2 r2 = q ? rb : ra;
-                    v[0] += bf16_lo(r2[0]);
-                    v[1] += bf16_hi(r2[0]);
-                    v[2] += bf16_lo(r2[1]);
-                    v[3] += bf16_hi(r2[1]);
-                    if (!NORM) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
-                    }
-                    o[q][0] = pack_bf16(v[0], v[1]);
-                    o[q][1] = pack_bf16(v[2], v[3]);
-                    if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
-                        const float r0 = bf16_lo(o[q][0]), r1 = bf16_hi(o[q][0]), r2f = bf16_lo(o[q][1]), r3 = bf16_hi(o[q][1]);
-                        acc[nt][mt][4 * g + 0] = r0;
-                        acc[nt][mt][4 * g + 1] = r1;
-                        acc[nt][mt][4 * g + 2] = r2f;
-                        acc[nt][mt][4 * g + 3] = r3;
-                        if (nb + 8 * g + 4 * hi < a.Cout) ssq[mt] += r0 * r0 + r1 * r1 + r2f * r2f + r3 * r3;
-                    }
-                }
-                if (!NORM || a.out != nullptr) {
-                    swap_pair(o[0], o[1]);
-                    if (m < M && nst < a.Cout) *(u32x4*)(a.out + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
-                }
-            }
+        mrow[mt] = m < M ? m : -1;
     }
-    if constexpr (NORM) {
-        // a row's channels: this lane's groups + those of lane ^ 32, and (WNW > 1) the other waves of the row through LDS
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ssq[mt] = sum_xor32(ssq[mt]);
-        if constexpr (CFG::WNW > 1) {
-            float* red = (float*)smem;          // the staging buffers are free: every wave is past its last fragment read
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                if (hi == 0) red[(wm * (MT * 32) + mt * 32 + l31) * CFG::WNW + wn] = ssq[mt];
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float t = 0.0f;
-#pragma unroll
-                for (int w = 0; w < CFG::WNW; ++w) t += red[(wm * (MT * 32) + mt * 32 + l31) * CFG::WNW + w];
-                ssq[mt] = t;
-            }
-        }
-        const float root_c = sqrtf((float)a.Cout);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wm * (MT * 32) + mt * 32 + l31;
-            const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int nb = n0 + wn * (NT * 32) + nt * 32;
-                    const int nst = nb + 8 * (2 * pr + hi);
-                    if (nb + 16 * pr >= a.Cout) continue;
-                    u32x2 o[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int g = 2 * pr + q;
-                        const u32x2 gm = *(const u32x2*)(a.norm_gamma + min(nb + 8 * g + 4 * hi, a.Cout - 4));
-                        float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
-                                      acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
-                        if (a.norm_silu) {
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
-                        }
-                        o[q][0] = pack_bf16(y[0], y[1]);
-                        o[q][1] = pack_bf16(y[2], y[3]);
-                    }
-                    swap_pair(o[0], o[1]);
-                    if (m < M && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
-                }
-        }
-    }
+    conv_epilogue<MT, NT, CFG::WNW, NORM>(a, acc, mrow, n0, wm, wn, l31, hi, smem);
 }
 
 using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
