@@ -553,6 +553,136 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
     conv_epilogue<MT, NT, CFG::WNW, NORM>(a, acc, mrow, n0, wm, wn, l31, hi, smem);
 }
 
+// ---- direct ("slab") convolution, Cin = 96 ---------------------------------------------------------------------------------
+// The implicit GEMM above gathers every input element once per TAP through the LDS-DMA path (27 times for 3x3x3), and on the
+// 96-channel layers that gather, not the matrix pipe, is 3/4 of the time (conv_out, a tenth of the MFMA work on the same
+// gather, takes 3.7 ms where 96 -> 96 takes 4.95).  Here a workgroup owns an 8 x 32 block of output positions of one frame
+// and stages, per temporal tap, the haloed input slab (10 x 34 positions x 96 channels = 64 KiB) ONCE; the nine spatial taps
+// are shifted fragment reads inside LDS.  Weights stream through a 3-deep ring of half-tap chunks (96 rows x 48 channels).
+//   wave w = output row y0 + w, lane row l31 = column x0 + l31: a tap (dy, dx) reads slab position p = (w + 1 + dy) * 34 +
+//   (l31 + 1 + dx) — consecutive in the lane, so with the chunk ROTATION s = (c + ((p >> 2) & 3)) mod 12 (192-byte position
+//   pitch: 4-dword slot = 4 * ((-p) & 3) + s) every 16-lane group of a ds_read_b128 covers all 16 slots for every shift;
+//   weight rows (96-byte pitch) use chunk ^ ((n >> 3) & 1).
+// Scope: Cin == 96, 3x3 spatial taps with "same" zero padding, kT <= 3 causal, stride 1, Cout <= 96, no upsample.
+constexpr int SLAB_BYTES = 65536, SLAB_WCH = 9216, SLAB_LDS = 2 * SLAB_BYTES + 3 * SLAB_WCH;
+
+template <int NT, int NORM>
+__global__ __launch_bounds__(512, 2) void conv3d_slab96_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 8, TW = 32, SC = TW + 2, SPOS = (TH + 2) * SC;
+    constexpr int WP = 3 * NT;                         // 1 KiB pieces of a weight chunk (NT * 32 rows x 96 B)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
+    const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
+    const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int nk = min(a.kT, t + 1);                   // temporal taps that touch data (frames t - nk + 1 .. t)
+    const int kt_first = a.kT - nk;
+    const uint32_t frame_bytes = (uint32_t)(a.H * a.W) * 192u;
+
+    // ---- slab gather state: piece q = j * 8 + wave covers LDS bytes [q KiB, +1 KiB) = 64 slots of 16 B ----
+    uint32_t soff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int L = (j * 8 + wave) * 64 + lane;
+        const int p = L / 12, sl = L - p * 12;
+        int c = sl - ((p >> 2) & 3);
+        if (c < 0) c += 12;
+        const int r = p / SC, cx = p - r * SC;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + cx;
+        const bool ok = p < SPOS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        soff[j] = ok ? (uint32_t)((yy * a.W + xx) * 192 + c * 16) : 0x80000000u;
+    }
+    auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((int64_t)a.T * a.H * a.W * 192), 0x00020000);
+    auto slab_piece = [&](int sb, int f, int j) {
+        uint32_t o = soff[j];
+        if (!(o & 0x80000000u)) o += (uint32_t)f * frame_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + sb * SLAB_BYTES + (j * 8 + wave) * 1024),
+                                                 16, (int)o, 0, 0, 0);
+    };
+    // ---- weight chunk pieces: piece q (row n = L / 6, slot L % 6 holds chunk slot ^ ((n >> 3) & 1)) ----
+    const char* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (i == 0 ? wave : 8) * 64 + lane;
+        const int n = L / 6, sl = L - n * 6;
+        wsrc[i] = (const char*)(a.w + (int64_t)min(n, a.Cout - 1) * a.Kpad + ((sl ^ ((n >> 3) & 1)) * 8));
+    }
+    const int nchunks = nk * 18;
+    auto w_chunk = [&](int ci) {      // chunk ci = (temporal tap ki, spatial tap sp, channel half h)
+        const int ki = ci / 18, rem = ci - ki * 18;
+        const int64_t kbase = (int64_t)(((kt_first + ki) * 9 + (rem >> 1)) * 96 + 48 * (rem & 1)) * 2;
+        char* dst = smem + 2 * SLAB_BYTES + (ci % 3) * SLAB_WCH;
+        if (wave < (WP < 8 ? WP : 8)) glds16(wsrc[0] + kbase, dst + wave * 1024);
+        if (WP == 9 && wave == 0) glds16(wsrc[1] + kbase, dst + 8 * 1024);
+    };
+    const int nw = (wave < (WP < 8 ? WP : 8) ? 1 : 0) + ((WP == 9 && wave == 0) ? 1 : 0);   // this wave's loads per chunk
+
+    f32x16 acc[NT][1];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.0f;
+
+    // ---- prologue: first slab, chunks 0 and 1 ----
+#pragma unroll
+    for (int j = 0; j < 8; ++j) slab_piece(0, t - nk + 1, j);
+    w_chunk(0);
+    w_chunk(1);          // nchunks >= 18
+
+    int ki = 0, jl = 0;  // temporal tap index and iteration inside it
+    bool prev_slab = false;
+    for (int it = 0; it < nchunks; ++it) {
+        // loads issued after chunk `it`: the slab piece of the previous iteration and chunk it + 1
+        const int k = (prev_slab ? 1 : 0) + (it + 1 < nchunks ? nw : 0);
+        switch (k) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        }
+        __syncthreads();
+        prev_slab = ki + 1 < nk && jl < 8;
+        if (prev_slab) slab_piece((ki + 1) & 1, t - nk + 1 + ki + 1, jl);
+        if (it + 2 < nchunks) w_chunk(it + 2);
+
+        const int sp = jl >> 1, h = jl & 1;
+        const int dy = sp / 3, dx = sp - dy * 3;            // 0..2 = tap offset + 1
+        const int p = (wave + dy) * SC + (l31 + dx);
+        const int rot = (p >> 2) & 3;
+        const char* As = smem + (ki & 1) * SLAB_BYTES + p * 192;
+        const char* Ws = smem + 2 * SLAB_BYTES + (it % 3) * SLAB_WCH;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            int sa = 6 * h + 2 * ks + hi + rot;
+            if (sa >= 12) sa -= 12;
+            const bf16x8 af = *(const bf16x8*)(As + sa * 16);
+            bf16x8 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + l31;
+                wf[nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af, acc[nt][0], 0, 0, 0);
+        }
+        if (++jl == 18) {
+            jl = 0;
+            ++ki;
+        }
+    }
+
+    int mrow[1];
+    const int y = y0 + wave, x = x0 + l31;
+    mrow[0] = (y < a.H && x < a.W) ? (t * a.H + y) * a.W + x : -1;
+    conv_epilogue<1, NT, 1, NORM>(a, acc, mrow, 0, wave, 0, l31, hi, smem);
+}
+
+
 using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
 using CV_N64 = ConvCfg<8, 1, 2, 2>;    // 512 x 64
 using CV_N96 = ConvCfg<8, 1, 2, 3>;    // 512 x 96
@@ -561,6 +691,23 @@ using CV_N192 = ConvCfg<4, 2, 2, 3>;   // 256 x 192
 using CV_N256 = ConvCfg<2, 4, 4, 2>;   // 256 x 256
 
 int g_conv_v2 = 1;   // apexmi_tune_set("conv.v2", 0/1)
+int g_conv_slab = 1; // apexmi_tune_set("conv.slab", 0/1): direct convolution for the Cin = 96 layers
+
+template <int NT, int NORM>
+int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
+    static uint64_t attr = 0;
+    if (apexmi_once_per_device(attr))
+        (void)hipFuncSetAttribute((const void*)conv3d_slab96_kernel<NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS);
+    const int grid = a.T * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+    hipLaunchKernelGGL((conv3d_slab96_kernel<NT, NORM>), dim3(grid), dim3(512), SLAB_LDS, stream, a);
+    return apexmi_check_launch("conv3d_cl (slab)");
+}
+
+int launch_slab(const ConvArgs& a, hipStream_t stream) {
+    const int nt = (a.Cout + 31) / 32;
+    if (a.out_norm != nullptr) return nt == 1 ? launch_slab_inst<1, 1>(a, stream) : nt == 2 ? launch_slab_inst<2, 1>(a, stream) : launch_slab_inst<3, 1>(a, stream);
+    return nt == 1 ? launch_slab_inst<1, 0>(a, stream) : nt == 2 ? launch_slab_inst<2, 0>(a, stream) : launch_slab_inst<3, 0>(a, stream);
+}
 
 template <typename CFG, int UP, int NORM>
 int launch_v2_inst(const ConvArgs& a, hipStream_t stream, int grid) {
@@ -594,6 +741,8 @@ int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
         return 0;
     const int c = a.Cout;
     *taken = true;
+    if (g_conv_slab && a.Cin == 96 && c <= 96 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 && !a.up)
+        return launch_slab(a, stream);
     if (c <= 32) return launch_v2<CV_N32, true>(a, stream);
     if (c <= 64) return launch_v2<CV_N64, true>(a, stream);
     if (c <= 96) return launch_v2<CV_N96, true>(a, stream);
@@ -874,6 +1023,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 
 }  // namespace
 void apexmi_set_conv_v2(int v) { g_conv_v2 = v; }
+void apexmi_set_conv_slab(int v) { g_conv_slab = v; }
 
 extern "C" size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C) {
     const int nblk = (int)((P + 1023) / 1024);

@@ -122,6 +122,7 @@ void apexmi_set_attn_c4(int v);
 void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 void apexmi_set_conv_v2(int v);
+void apexmi_set_conv_slab(int v);
 int apexmi_set_gemm_key(const char* key, int value);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
@@ -133,6 +134,9 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         if (apexmi_set_gemm_key(key, value) == 0) return 0;
     } else if (!strcmp(key, "conv.v2")) {
         apexmi_set_conv_v2(value);
+        return 0;
+    } else if (!strcmp(key, "conv.slab")) {
+        apexmi_set_conv_slab(value);
         return 0;
     } else if (!strcmp(key, "attn.split")) {
         apexmi_set_attn_split(value);
