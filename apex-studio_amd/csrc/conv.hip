@@ -645,7 +645,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab96_kernel(const ConvArgs a)
             case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         }
-        __syncthreads();
+        // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         prev_slab = ki + 1 < nk && jl < 8;
         if (prev_slab) slab_piece((ki + 1) & 1, t - nk + 1 + ki + 1, jl);
         if (it + 2 < nchunks) w_chunk(it + 2);
@@ -683,6 +686,170 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab96_kernel(const ConvArgs a)
 }
 
 
+// General form of the slab kernel (shipped): Cin = 48 * S channels are walked in S slices of 48 (96-byte slab pitch, chunk ^
+// ((p >> 3) & 1) — the same swizzle as the weight rows), the slab of one (temporal tap, slice) is double buffered and the
+// loop runs temporal tap -> slice -> spatial tap, so the f32 accumulation order differs from the implicit GEMM's (tap ->
+// channel): the same values up to f32 summation order (1 bf16 ulp on ~3e-4 of the outputs).  Two shapes:
+//   MT = 2: 16 x 32 positions per workgroup, two rows per wave (every weight fragment feeds two MFMAs), Cout <= 96 (NT <= 3)
+//   MT = 1:  8 x 32 positions, one row per wave, 192 output channels per workgroup (NT = 6; blockIdx.y = N tile for Cout 384)
+// UP (runtime): the slab is read through the nearest 2x upsample (stored pixel (y >> 1, x >> 1)).
+template <int NT, int MT, int NORM>
+__global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 8 * MT, TW = 32, SC = TW + 2, SPOS = (TH + 2) * SC;
+    constexpr int NPJ = (SPOS * 96 + 8191) / 8192;       // slab pieces per wave (8 for MT = 2, 4 for MT = 1)
+    constexpr int SLABB = NPJ * 8192;
+    constexpr int WP = 3 * NT, WCH = NT * 32 * 96;       // weight chunk: NT * 32 rows x 96 B
+    constexpr int WLD = (WP + 7) / 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
+    const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
+    const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = blockIdx.y * (NT * 32);
+    const int S = a.Cin / 48;
+    const int nk = min(a.kT, t + 1);
+    const int kt_first = a.kT - nk;
+    const int nph = nk * S;                            // phases = (temporal tap, channel slice)
+    const uint32_t pos_bytes = (uint32_t)a.Cin * 2u;
+    const uint32_t frame_bytes = (uint32_t)(a.Hin * a.Win) * pos_bytes;
+
+    uint32_t soff[NPJ];
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) {
+        const int L = (j * 8 + wave) * 64 + lane;
+        const int p = L / 6, sl = L - p * 6;
+        const int c = sl ^ ((p >> 3) & 1);
+        const int r = p / SC, cx = p - r * SC;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + cx;
+        const bool ok = p < SPOS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        soff[j] = ok ? (uint32_t)((yy >> a.up) * a.Win + (xx >> a.up)) * pos_bytes + (uint32_t)(c * 16) : 0x80000000u;
+    }
+    auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((int64_t)a.T * a.Hin * a.Win * a.Cin * 2), 0x00020000);
+    // (no runtime divisions in the loop: phase / chunk coordinates are carried as counters)
+    auto slab_piece = [&](int buf, uint32_t phase_off, int j) {     // phase_off = frame * frame_bytes + slice * 96
+        uint32_t o = soff[j];
+        if (!(o & 0x80000000u)) o += phase_off;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + buf * SLABB + (j * 8 + wave) * 1024), 16,
+                                                 (int)o, 0, 0, 0);
+    };
+    const char* wsrc[WLD];
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+        const int L = (i * 8 + wave) * 64 + lane;
+        const int n = L / 6, sl = L - n * 6;
+        wsrc[i] = (const char*)(a.w + (int64_t)min(n0 + n, a.Cout - 1) * a.Kpad + ((sl ^ ((n >> 3) & 1)) * 8));
+    }
+    const int nchunks = nph * 9;
+    // chunk cursor (the chunk to ISSUE next): ring slot, spatial tap, slice, temporal tap -> byte offset into a weight row
+    int c_slot = 0, c_sp = 0, c_sl = 0;
+    int64_t c_tap_off = (int64_t)kt_first * 9 * a.Cin * 2;     // (temporal tap * 9) * Cin * 2 bytes
+    auto w_chunk_next = [&]() {
+        const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * 96;
+        char* dst = smem + 2 * SLABB + c_slot * WCH;
+#pragma unroll
+        for (int i = 0; i < WLD; ++i)
+            if ((i + 1) * 8 <= WP || i * 8 + wave < WP) glds16(wsrc[i] + kbase, dst + (i * 8 + wave) * 1024);   // wave-uniform
+        c_slot = c_slot == 2 ? 0 : c_slot + 1;
+        if (++c_sp == 9) {
+            c_sp = 0;
+            if (++c_sl == S) {
+                c_sl = 0;
+                c_tap_off += (int64_t)9 * a.Cin * 2;
+            }
+        }
+    };
+    int nw = 0;
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) nw += ((i + 1) * 8 <= WP || i * 8 + wave < WP) ? 1 : 0;
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.0f;
+
+    // next-phase cursor for the slab prefetch
+    uint32_t np_off = (uint32_t)(t - nk + 1) * frame_bytes;
+    int np_sl = 0;
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) slab_piece(0, np_off, j);
+    auto advance_phase = [&]() {
+        if (++np_sl == S) {
+            np_sl = 0;
+            np_off += frame_bytes - (uint32_t)(S - 1) * 96u;
+        } else {
+            np_off += 96u;
+        }
+    };
+    advance_phase();
+    w_chunk_next();
+    w_chunk_next();
+
+    int ph = 0, sp = 0, slot = 0;
+    bool prev_slab = false;
+    for (int it = 0; it < nchunks; ++it) {
+        // loads issued after chunk `it`: the slab piece of the previous iteration and chunk it + 1
+        const int k = (prev_slab ? 1 : 0) + (it + 1 < nchunks ? nw : 0);
+        switch (k) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+        // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        prev_slab = ph + 1 < nph && sp < NPJ;
+        if (prev_slab) slab_piece((ph + 1) & 1, np_off, sp);
+        if (it + 2 < nchunks) w_chunk_next();
+
+        const int dy = sp / 3, dx = sp - dy * 3;
+        const char* Sb = smem + (ph & 1) * SLABB;
+        const char* Ws = smem + 2 * SLABB + slot * WCH;
+        slot = slot == 2 ? 0 : slot + 1;
+        int pa[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) pa[m] = (MT * wave + m + dy) * SC + (l31 + dx);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + l31;
+                wf[nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[m], acc[nt][m], 0, 0, 0);
+        }
+        if (++sp == 9) {
+            sp = 0;
+            ++ph;
+            advance_phase();
+        }
+    }
+
+    int mrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = y0 + MT * wave + m, x = x0 + l31;
+        mrow[m] = (y < a.H && x < a.W) ? (t * a.H + y) * a.W + x : -1;
+    }
+    conv_epilogue<MT, NT, 1, NORM>(a, acc, mrow, n0, wave, 0, l31, hi, smem);
+}
+
 using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
 using CV_N64 = ConvCfg<8, 1, 2, 2>;    // 512 x 64
 using CV_N96 = ConvCfg<8, 1, 2, 3>;    // 512 x 96
@@ -691,22 +858,58 @@ using CV_N192 = ConvCfg<4, 2, 2, 3>;   // 256 x 192
 using CV_N256 = ConvCfg<2, 4, 4, 2>;   // 256 x 256
 
 int g_conv_v2 = 1;   // apexmi_tune_set("conv.v2", 0/1)
-int g_conv_slab = 1; // apexmi_tune_set("conv.slab", 0/1): direct convolution for the Cin = 96 layers
+int g_conv_slab = 2; // apexmi_tune_set("conv.slab", 0 | 1 | 2): direct convolution — 2 (shipped) the sliced kernel for every
+                     // eligible layer, 1 the order-preserving 8 x 32 form for Cin = 96 and the sliced kernel elsewhere, 0 off
 
 template <int NT, int NORM>
-int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
+int launch_slab96_inst(const ConvArgs& a, hipStream_t stream) {     // conv.slab = 1: the order-preserving 8 x 32 form, Cin = 96
     static uint64_t attr = 0;
     if (apexmi_once_per_device(attr))
         (void)hipFuncSetAttribute((const void*)conv3d_slab96_kernel<NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS);
     const int grid = a.T * ((a.H + 7) / 8) * ((a.W + 31) / 32);
     hipLaunchKernelGGL((conv3d_slab96_kernel<NT, NORM>), dim3(grid), dim3(512), SLAB_LDS, stream, a);
+    return apexmi_check_launch("conv3d_cl (slab 8x32)");
+}
+
+template <int NT, int MT, int NORM>
+int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
+    constexpr int SPOS = (8 * MT + 2) * 34, NPJ = (SPOS * 96 + 8191) / 8192;
+    constexpr int LDS = 2 * NPJ * 8192 + 3 * NT * 32 * 96;
+    static_assert(LDS <= 160 * 1024, "slab kernel LDS");
+    static uint64_t attr = 0;
+    if (apexmi_once_per_device(attr))
+        (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int gx = a.T * ((a.H + 8 * MT - 1) / (8 * MT)) * ((a.W + 31) / 32), gy = (a.Cout + NT * 32 - 1) / (NT * 32);
+    hipLaunchKernelGGL((conv3d_slab_kernel<NT, MT, NORM>), dim3(gx, gy), dim3(512), LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab)");
 }
 
+// which convolutions the slab kernels take: Cin a multiple of 48, 3x3 "same" spatial taps, kT <= 3, stride 1, zero padding
+bool slab_eligible(const ConvArgs& a) {
+    return g_conv_slab && a.Cin % 48 == 0 && a.Cin <= 384 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 &&
+           (a.Cout <= 192 || a.Cout % 192 == 0);
+}
+
 int launch_slab(const ConvArgs& a, hipStream_t stream) {
-    const int nt = (a.Cout + 31) / 32;
-    if (a.out_norm != nullptr) return nt == 1 ? launch_slab_inst<1, 1>(a, stream) : nt == 2 ? launch_slab_inst<2, 1>(a, stream) : launch_slab_inst<3, 1>(a, stream);
-    return nt == 1 ? launch_slab_inst<1, 0>(a, stream) : nt == 2 ? launch_slab_inst<2, 0>(a, stream) : launch_slab_inst<3, 0>(a, stream);
+    const bool norm = a.out_norm != nullptr;
+    if (g_conv_slab == 1 && a.Cin == 96 && a.Cout <= 96 && !a.up) {
+        const int nt = (a.Cout + 31) / 32;
+        if (norm) return nt == 1 ? launch_slab96_inst<1, 1>(a, stream) : nt == 2 ? launch_slab96_inst<2, 1>(a, stream) : launch_slab96_inst<3, 1>(a, stream);
+        return nt == 1 ? launch_slab96_inst<1, 0>(a, stream) : nt == 2 ? launch_slab96_inst<2, 0>(a, stream) : launch_slab96_inst<3, 0>(a, stream);
+    }
+    if (a.Cout <= 96) {
+        const int nt = (a.Cout + 31) / 32;
+        if (norm) return nt == 1 ? launch_slab_inst<1, 2, 1>(a, stream) : nt == 2 ? launch_slab_inst<2, 2, 1>(a, stream) : launch_slab_inst<3, 2, 1>(a, stream);
+        return nt == 1 ? launch_slab_inst<1, 2, 0>(a, stream) : nt == 2 ? launch_slab_inst<2, 2, 0>(a, stream) : launch_slab_inst<3, 2, 0>(a, stream);
+    }
+    if (norm) {
+        if (a.Cout > 192) {
+            apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of the slab kernel", a.Cout);
+            return 1;
+        }
+        return launch_slab_inst<6, 1, 1>(a, stream);
+    }
+    return launch_slab_inst<6, 1, 0>(a, stream);
 }
 
 template <typename CFG, int UP, int NORM>
@@ -741,8 +944,7 @@ int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
         return 0;
     const int c = a.Cout;
     *taken = true;
-    if (g_conv_slab && a.Cin == 96 && c <= 96 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 && !a.up)
-        return launch_slab(a, stream);
+    if (slab_eligible(a) && !(a.out_norm != nullptr && c > 192)) return launch_slab(a, stream);
     if (c <= 32) return launch_v2<CV_N32, true>(a, stream);
     if (c <= 64) return launch_v2<CV_N64, true>(a, stream);
     if (c <= 96) return launch_v2<CV_N96, true>(a, stream);

@@ -409,13 +409,84 @@ def test_conv_v2_tiles_are_bit_identical_to_the_128x128_kernel(cin, cout, T, H, 
     res = _bf(seeded((T, Ho, Wo, wp.shape[0]), 4)).to(DEV)
     outs = []
     try:
+        lib.tune_set("conv.slab", 0)       # the direct-convolution kernels take most of these shapes otherwise (tests below)
         for v2 in (0, 1):
             lib.tune_set("conv.v2", v2)
             outs.append((ops.conv3d_cl(x, wp, b, k, upsample2x=up), ops.conv3d_cl(x, wp, b, k, residual=res, upsample2x=up)))
     finally:
         lib.tune_set("conv.v2", 1)
+        lib.tune_set("conv.slab", 2)
     assert T * Ho * Wo >= 65536, "shape must be large enough for the v2 dispatch"
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+SLAB_CASES = [   # cin, cout, T, H, W, k, up, norm, res, independent
+    (96, 96, 5, 128, 128, (3, 3, 3), False, False, True, False),       # Wan full-resolution stage
+    (96, 96, 3, 131, 173, (3, 3, 3), False, True, False, False),       # ragged tiles, fused norm
+    (96, 3, 3, 160, 144, (3, 3, 3), False, False, False, False),       # conv_out: Cout 3 (+1 pad), narrow epilogue
+    (192, 192, 3, 150, 160, (3, 3, 3), False, True, True, False),      # 8 x 32 tiles, 192 channels in one wave, fused norm
+    (384, 384, 9, 96, 96, (3, 3, 3), False, False, True, False),       # two N tiles (blockIdx.y), 8 channel slices
+    (192, 96, 2, 96, 100, (1, 3, 3), True, False, False, False),       # read through the 2x upsample
+    (384, 192, 3, 80, 72, (1, 3, 3), True, True, False, False),
+    (96, 64, 7, 120, 101, (2, 3, 3), False, False, True, False),       # kT = 2
+    (192, 192, 12, 96, 96, (3, 3, 3), False, False, False, True),      # independent single-frame clips
+    (144, 160, 3, 150, 150, (3, 3, 3), False, False, False, False),    # Cout not a multiple of 32: masked columns
+    (48, 32, 4, 200, 180, (3, 3, 3), False, False, False, False),      # one slice: the implicit GEMM's summation order
+]
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,k,up,norm,res,indep", SLAB_CASES)
+def test_direct_convolution_kernels_against_the_implicit_gemm(cin, cout, T, H, W, k, up, norm, res, indep):
+    """`conv.slab`: the direct convolution (haloed input slab staged once per temporal tap and 48-channel slice, spatial taps
+    as shifted LDS reads) against the implicit-GEMM tiles on the same operands.  Same products, f32 sums in another order
+    (temporal tap -> slice -> spatial tap): at most 1 bf16 ulp apart on a few 1e-4 of the outputs (the fused norm output may
+    move by one more ulp), bit-identical when Cin is one slice; deterministic; and the order-preserving 8 x 32 form
+    (`conv.slab=1`, Cin = 96) is bit-identical to the implicit GEMM."""
+    from apex_studio_amd import lib, ops
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * k[0] * 9) ** -0.5)).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    b = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    b[:cout] = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    g = _bf(1 + 0.1 * seeded((wp.shape[0],), 5)).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    r = _bf(seeded((T, Ho, Wo, wp.shape[0]), 4)).to(DEV) if res else None
+    assert T * Ho * Wo >= 65536
+
+    def run():
+        if norm:
+            raw, nrm = ops.conv3d_cl_norm(x, wp, b, k, g, silu=True, residual=r, upsample2x=up, independent_frames=indep)
+            return torch.cat([raw.flatten(), nrm.flatten()])
+        return ops.conv3d_cl(x, wp, b, k, residual=r, upsample2x=up, independent_frames=indep).flatten()
+
+    outs = {}
+    try:
+        for v in (0, 1, 2):
+            lib.tune_set("conv.slab", v)
+            outs[v] = run()
+        assert torch.equal(run(), outs[2])
+    finally:
+        lib.tune_set("conv.slab", 2)
+    ref, got = outs[0].float(), outs[2].float()
+    rel = float((got - ref).norm() / ref.norm())
+    frac = float((outs[2] != outs[0]).float().mean())
+    ulps = float(((got - ref).abs() / (ref.abs() * 2.0 ** -7 + 1e-3)).max())
+    print(f"[slab] {cin}->{cout} k{k} up={up} norm={norm}: rel {rel:.2e}, {frac:.2e} of outputs differ, max {ulps:.2f} ulp")
+    assert rel < 1e-4 and frac < 2e-3 and ulps <= (2.01 if norm else 1.01)
+    if cin == 48:
+        assert torch.equal(outs[2], outs[0])
+    if cin == 96 and cout <= 96 and not up:
+        assert torch.equal(outs[1], outs[0]), "the 8 x 32 form keeps the implicit GEMM's summation order"
+    n = min(cout, 8)
+    xin = x.float().cpu().permute(3, 0, 1, 2)[None]
+    if up:
+        xin = F.interpolate(xin, scale_factor=(1, 2, 2))
+    if not norm and not indep:        # and against torch on a few output channels
+        ref_t = F.conv3d(F.pad(xin, (1, 1, 1, 1, k[0] - 1, 0)), w[:n].float().cpu(), b[:n].float().cpu())[0].permute(1, 2, 3, 0)
+        if res:
+            ref_t = ref_t + r[..., :n].float().cpu()
+        mine = outs[2].view(T, Ho, Wo, wp.shape[0])[..., :n].float().cpu()
+        assert _rel(mine, ref_t) < 4e-3
 
 
 @pytest.mark.parametrize("cin,cout,T,H,W,k,up,silu,res", [(96, 96, 5, 128, 128, (3, 3, 3), False, True, True),
