@@ -819,20 +819,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         int pa[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) pa[m] = (MT * wave + m + dy) * SC + (l31 + dx);
+        // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks are issued (the compiler then waits with
+        // lgkmcnt(reads in flight) instead of draining the LDS queue in front of every few MFMAs)
+        bf16x8 af[2][MT], wf[2][NT];
+        auto frags = [&](int ks, int bsel) {
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            bf16x8 af[MT], wf[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
+            for (int m = 0; m < MT; ++m) af[bsel][m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + l31;
-                wf[nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
+                wf[bsel][nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
             }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 2) frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[m], acc[nt][m], 0, 0, 0);
+                for (int m = 0; m < MT; ++m)
+                    acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][m], acc[nt][m], 0, 0, 0);
         }
         if (++sp == 9) {
             sp = 0;
