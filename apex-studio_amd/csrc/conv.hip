@@ -700,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     constexpr int NPJ = (SPOS * 96 + 8191) / 8192;       // slab pieces per wave (8 for MT = 2, 4 for MT = 1)
     constexpr int SLABB = NPJ * 8192;
     constexpr int WP = 3 * NT, WCH = NT * 32 * 96;       // weight chunk: NT * 32 rows x 96 B
-    constexpr int WLD = (WP + 7) / 8;
+    constexpr int WLD = (WP + 3) / 4;                    // weight pieces per issuing wave (waves 0..3)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -718,10 +718,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     const uint32_t pos_bytes = (uint32_t)a.Cin * 2u;
     const uint32_t frame_bytes = (uint32_t)(a.Hin * a.Win) * pos_bytes;
 
-    uint32_t soff[NPJ];
+    // DMA roles are split by wave, because vmcnt counts a wave's loads IN ORDER: a wait for a (fast, L2-resident) weight
+    // piece would also wait for every older (slow, HBM-latency) slab piece of the same wave.  Waves 0..3 issue only weight
+    // pieces and wait for them every chunk; waves 4..7 issue only slab pieces (2 * NPJ each per phase) and wait ONCE per
+    // phase, a whole phase after issuing them.
+    const bool loader = wave >= 4;
+    uint32_t soff[2 * NPJ];
 #pragma unroll
-    for (int j = 0; j < NPJ; ++j) {
-        const int L = (j * 8 + wave) * 64 + lane;
+    for (int j = 0; j < 2 * NPJ; ++j) {
+        const int L = (j * 4 + (wave & 3)) * 64 + lane;
         const int p = L / 6, sl = L - p * 6;
         const int c = sl ^ ((p >> 3) & 1);
         const int r = p / SC, cx = p - r * SC;
@@ -734,13 +739,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     auto slab_piece = [&](int buf, uint32_t phase_off, int j) {     // phase_off = frame * frame_bytes + slice * 96
         uint32_t o = soff[j];
         if (!(o & 0x80000000u)) o += phase_off;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + buf * SLABB + (j * 8 + wave) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + buf * SLABB + (j * 4 + (wave & 3)) * 1024), 16,
                                                  (int)o, 0, 0, 0);
     };
     const char* wsrc[WLD];
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
-        const int L = (i * 8 + wave) * 64 + lane;
+        const int L = (i * 4 + (wave & 3)) * 64 + lane;
         const int n = L / 6, sl = L - n * 6;
         wsrc[i] = (const char*)(a.w + (int64_t)min(n0 + n, a.Cout - 1) * a.Kpad + ((sl ^ ((n >> 3) & 1)) * 8));
     }
@@ -751,9 +756,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     auto w_chunk_next = [&]() {
         const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * 96;
         char* dst = smem + 2 * SLABB + c_slot * WCH;
+        if (!loader) {
 #pragma unroll
-        for (int i = 0; i < WLD; ++i)
-            if ((i + 1) * 8 <= WP || i * 8 + wave < WP) glds16(wsrc[i] + kbase, dst + (i * 8 + wave) * 1024);   // wave-uniform
+            for (int i = 0; i < WLD; ++i)
+                if ((i + 1) * 4 <= WP || i * 4 + wave < WP) glds16(wsrc[i] + kbase, dst + (i * 4 + wave) * 1024);   // wave-uniform
+        }
         c_slot = c_slot == 2 ? 0 : c_slot + 1;
         if (++c_sp == 9) {
             c_sp = 0;
@@ -763,9 +770,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
             }
         }
     };
-    int nw = 0;
+    int nw = 0;                                        // this wave's loads per weight chunk (0 for the slab loaders)
 #pragma unroll
-    for (int i = 0; i < WLD; ++i) nw += ((i + 1) * 8 <= WP || i * 8 + wave < WP) ? 1 : 0;
+    for (int i = 0; i < WLD; ++i) nw += (!loader && ((i + 1) * 4 <= WP || i * 4 + wave < WP)) ? 1 : 0;
 
     f32x16 acc[NT][MT];
 #pragma unroll
@@ -778,8 +785,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     // next-phase cursor for the slab prefetch
     uint32_t np_off = (uint32_t)(t - nk + 1) * frame_bytes;
     int np_sl = 0;
+    if (loader) {
 #pragma unroll
-    for (int j = 0; j < NPJ; ++j) slab_piece(0, np_off, j);
+        for (int j = 0; j < 2 * NPJ; ++j) slab_piece(0, np_off, j);
+    }
     auto advance_phase = [&]() {
         if (++np_sl == S) {
             np_sl = 0;
@@ -793,25 +802,27 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     w_chunk_next();
 
     int ph = 0, sp = 0, slot = 0;
-    bool prev_slab = false;
     for (int it = 0; it < nchunks; ++it) {
-        // loads issued after chunk `it`: the slab piece of the previous iteration and chunk it + 1
-        const int k = (prev_slab ? 1 : 0) + (it + 1 < nchunks ? nw : 0);
-        switch (k) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        if (loader) {
+            // the slab of this phase was issued during the previous phase (or the prologue): wait for it once, at the phase's
+            // first chunk; its pieces had a whole phase to land
+            if (sp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // loads of this wave issued after chunk `it`: chunk it + 1
+            const int k = it + 1 < nchunks ? nw : 0;
+            switch (k) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            }
         }
         // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        prev_slab = ph + 1 < nph && sp < NPJ;
-        if (prev_slab) slab_piece((ph + 1) & 1, np_off, sp);
-        if (it + 2 < nchunks) w_chunk_next();
-
         const int dy = sp / 3, dx = sp - dy * 3;
         const char* Sb = smem + (ph & 1) * SLABB;
         const char* Ws = smem + 2 * SLABB + slot * WCH;
@@ -819,30 +830,35 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         int pa[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) pa[m] = (MT * wave + m + dy) * SC + (l31 + dx);
-        // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks are issued (the compiler then waits with
-        // lgkmcnt(reads in flight) instead of draining the LDS queue in front of every few MFMAs)
-        bf16x8 af[2][MT], wf[2][NT];
-        auto frags = [&](int ks, int bsel) {
+        // order inside a chunk: all fragment reads -> this wave's DMA issues (their ~150 cycles apiece hide the LDS latency)
+        // -> the MFMAs, which then drain underneath the next chunk's wait / barrier / reads
+        bf16x8 af[3][MT], wf[3][NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[bsel][m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
+        for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + l31;
-                wf[bsel][nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
+                wf[ks][nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
             }
-        };
-        frags(0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (loader) {     // next phase's slab: two pieces per chunk over the first NPJ chunks of this phase
+            if (ph + 1 < nph && sp < NPJ) {
+                slab_piece((ph + 1) & 1, np_off, 2 * sp);
+                slab_piece((ph + 1) & 1, np_off, 2 * sp + 1);
+            }
+        } else if (it + 2 < nchunks) {
+            w_chunk_next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks < 2) frags(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][m], acc[nt][m], 0, 0, 0);
-        }
+                for (int m = 0; m < MT; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nt], af[ks][m], acc[nt][m], 0, 0, 0);
         if (++sp == 9) {
             sp = 0;
             ++ph;
