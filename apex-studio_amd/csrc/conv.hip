@@ -447,6 +447,10 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
             mk |= (ok ? 1u : 0u) << tap;
         }
         vmask[i] = mk | ((uint32_t)(y & 1) << 27) | ((uint32_t)(x & 1) << 28);
+        if (a.replicate) {   // replicate padding clamps coordinates per tap: keep (t, y, x) instead of an offset and a mask
+            off[i] = (uint32_t)t;
+            vmask[i] = ((uint32_t)y << 16) | (uint32_t)x;
+        }
     }
     auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((int64_t)a.T * a.Hin * a.Win * a.Cin * 2), 0x00020000);
     const int cchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // (p & 7) ^ ((row >> 1) & 7), same for every piece
@@ -483,6 +487,20 @@ __global__ __launch_bounds__(CFG::NTHR, 2) void conv3d_v2_kernel(const ConvArgs 
             delta = (dpix * a.Cin + a_ci) * 2;
             bit = 1u << a_tap;
         }
+        if (a.replicate) {   // wave-uniform: HunyuanVideo15CausalConv3d, F.pad(mode="replicate") == clamped tap coordinates
+            int dt = 0;
+            if (a_tap < a.ntaps) dt = (int)(int8_t)(tap_off[a_tap] & 0xff);
+#pragma unroll
+            for (int i = 0; i < CFG::A_LD; ++i) {
+                const int tc = max((int)off[i] + dt, 0);
+                const int yc = min(max((int)(vmask[i] >> 16) + dy, 0), a.H - 1);
+                const int xc = min(max((int)(vmask[i] & 0xffffu) + dx, 0), a.W - 1);
+                uint32_t o = (uint32_t)(((tc * a.H + yc) * a.W + xc) * a.Cin + a_ci) * 2u;
+                if (a_tap >= a.ntaps) o = 0x80000000u;      // K padding past the last tap: zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(base + i * (NW * 1024)), 16,
+                                                         (int)o, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < CFG::A_LD; ++i) {
             uint32_t o = off[i] + (uint32_t)delta;
@@ -911,7 +929,7 @@ int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
 
 // which convolutions the slab kernels take: Cin a multiple of 48, 3x3 "same" spatial taps, kT <= 3, stride 1, zero padding
 bool slab_eligible(const ConvArgs& a) {
-    return g_conv_slab && a.Cin % 48 == 0 && a.Cin <= 384 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 &&
+    return g_conv_slab && !a.replicate && a.Cin % 48 == 0 && a.Cin <= 384 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 &&
            (a.Cout <= 192 || a.Cout % 192 == 0);
 }
 
@@ -964,7 +982,7 @@ int launch_v2(const ConvArgs& a, hipStream_t stream) {
 int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
     *taken = false;
     const int64_t M = (int64_t)a.T * a.H * a.W;
-    if (!g_conv_v2 || a.replicate || a.sy != 1 || a.sx != 1 || a.st != 1 || a.t0 != 0 || a.To != a.T || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
+    if (!g_conv_v2 || (a.replicate && (a.up || a.H > 65535 || a.W > 65535)) || a.sy != 1 || a.sx != 1 || a.st != 1 || a.t0 != 0 || a.To != a.T || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
         (int64_t)a.T * a.Hin * a.Win * a.Cin * 2 >= ((int64_t)1 << 31))   // 32-bit byte offsets in the gather
         return 0;
     const int c = a.Cout;

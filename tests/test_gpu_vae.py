@@ -542,3 +542,30 @@ def test_conv3d_cl_temporal_stride(cin, cout, T, H, W):
     assert ref.shape == out.shape and _rel(out.cpu(), ref) < 4e-3
     with pytest.raises(RuntimeError):
         ops.conv3d_cl_tstrided(x.to(DEV), wp, bp, (3, 1, 1), 2, 2, To + 1)
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W", [(256, 256, 5, 120, 128), (128, 256, 3, 150, 161), (512, 512, 9, 96, 96),
+                                             (64, 3, 3, 160, 144), (1024, 1024, 3, 160, 144)])
+def test_conv_v2_tiles_with_replicate_padding(cin, cout, T, H, W):
+    """HunyuanVideo15CausalConv3d (replicate padding = clamped tap coordinates) on the conv-shaped tiles: the gather clamps
+    (t, y, x) per tap instead of testing a validity mask; bit-identical to the 128x128 kernel's replicate mode."""
+    from apex_studio_amd import lib, ops
+    k = (3, 3, 3)
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * 27) ** -0.5)).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    b = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    b[:cout] = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    res = _bf(seeded((T, H, W, wp.shape[0]), 4)).to(DEV)
+    outs = []
+    try:
+        for v2 in (0, 1):
+            lib.tune_set("conv.v2", v2)
+            outs.append(ops.conv3d_cl(x, wp, b, k, residual=res, replicate=True))
+    finally:
+        lib.tune_set("conv.v2", 1)
+    assert T * H * W >= 65536 and torch.equal(outs[0], outs[1])
+    n = min(cout, 8)
+    xin = F.pad(x.float().cpu().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0), mode="replicate")
+    ref = F.conv3d(xin, w[:n].float().cpu(), b[:n].float().cpu())[0].permute(1, 2, 3, 0) + res[..., :n].float().cpu()
+    assert _rel(outs[1][..., :n].float().cpu(), ref) < 4e-3
