@@ -711,13 +711,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab96_kernel(const ConvArgs a)
 //   MT = 2: 16 x 32 positions per workgroup, two rows per wave (every weight fragment feeds two MFMAs), Cout <= 96 (NT <= 3)
 //   MT = 1:  8 x 32 positions, one row per wave, 192 output channels per workgroup (NT = 6; blockIdx.y = N tile for Cout 384)
 // UP (runtime): the slab is read through the nearest 2x upsample (stored pixel (y >> 1, x >> 1)).
-template <int NT, int MT, int NORM>
+// SLW = channels per slice: 48 (96-byte pitch, 6 chunks, swizzle c ^ ((p >> 3) & 1), 3 k-steps) or 64 (128-byte pitch, 8 chunks,
+// c ^ ((p >> 1) & 7): 4-dword slot = 8 (p & 1) + swizzled chunk, 4 k-steps) — the latter for the channel counts of the
+// HunyuanVideo-1.5 / Flux / TAEHV decoders (64 .. 1024); a.replicate: clamped slab coordinates (F.pad(mode="replicate")).
+template <int SLW>
+APEXMI_DEVICE int slab_swz(int c, int p) { return SLW == 48 ? (c ^ ((p >> 3) & 1)) : (c ^ ((p >> 1) & 7)); }
+
+template <int NT, int MT, int NORM, int SLW = 48>
 __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
+    constexpr int CPP = SLW / 8, PITCH = SLW * 2, KS = SLW / 16;   // chunks per position, bytes per position, k-steps per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TH = 8 * MT, TW = 32, SC = TW + 2, SPOS = (TH + 2) * SC;
-    constexpr int NPJ = (SPOS * 96 + 8191) / 8192;       // slab pieces per wave (8 for MT = 2, 4 for MT = 1)
+    constexpr int NPJ = (SPOS * PITCH + 8191) / 8192;    // slab pieces per 8 waves (8 for MT = 2, 4 for MT = 1 at SLW 48)
     constexpr int SLABB = NPJ * 8192;
-    constexpr int WP = 3 * NT, WCH = NT * 32 * 96;       // weight chunk: NT * 32 rows x 96 B
+    constexpr int WCH = NT * 32 * PITCH, WP = WCH / 1024;   // weight chunk: NT * 32 rows x PITCH bytes
     constexpr int WLD = (WP + 3) / 4;                    // weight pieces per issuing wave (waves 0..3)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -729,8 +736,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
     const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * (NT * 32);
-    const int S = a.Cin / 48;
-    const int nk = min(a.kT, t + 1);
+    const int S = a.Cin / SLW;
+    const int nk = a.replicate ? a.kT : min(a.kT, t + 1);   // replicate: frames before the first repeat it
     const int kt_first = a.kT - nk;
     const int nph = nk * S;                            // phases = (temporal tap, channel slice)
     const uint32_t pos_bytes = (uint32_t)a.Cin * 2u;
@@ -745,10 +752,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2 * NPJ; ++j) {
         const int L = (j * 4 + (wave & 3)) * 64 + lane;
-        const int p = L / 6, sl = L - p * 6;
-        const int c = sl ^ ((p >> 3) & 1);
+        const int p = L / CPP, sl = L - p * CPP;
+        const int c = slab_swz<SLW>(sl, p);
         const int r = p / SC, cx = p - r * SC;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + cx;
+        int yy = y0 - 1 + r, xx = x0 - 1 + cx;
+        if (a.replicate) {
+            yy = min(max(yy, 0), a.H - 1);
+            xx = min(max(xx, 0), a.W - 1);
+        }
         const bool ok = p < SPOS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         soff[j] = ok ? (uint32_t)((yy >> a.up) * a.Win + (xx >> a.up)) * pos_bytes + (uint32_t)(c * 16) : 0x80000000u;
     }
@@ -764,15 +775,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
         const int L = (i * 4 + (wave & 3)) * 64 + lane;
-        const int n = L / 6, sl = L - n * 6;
-        wsrc[i] = (const char*)(a.w + (int64_t)min(n0 + n, a.Cout - 1) * a.Kpad + ((sl ^ ((n >> 3) & 1)) * 8));
+        const int n = L / CPP, sl = L - n * CPP;
+        wsrc[i] = (const char*)(a.w + (int64_t)min(n0 + n, a.Cout - 1) * a.Kpad + (slab_swz<SLW>(sl, n) * 8));
     }
     const int nchunks = nph * 9;
     // chunk cursor (the chunk to ISSUE next): ring slot, spatial tap, slice, temporal tap -> byte offset into a weight row
     int c_slot = 0, c_sp = 0, c_sl = 0;
     int64_t c_tap_off = (int64_t)kt_first * 9 * a.Cin * 2;     // (temporal tap * 9) * Cin * 2 bytes
     auto w_chunk_next = [&]() {
-        const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * 96;
+        const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * PITCH;
         char* dst = smem + 2 * SLABB + c_slot * WCH;
         if (!loader) {
 #pragma unroll
@@ -801,7 +812,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.0f;
 
     // next-phase cursor for the slab prefetch
-    uint32_t np_off = (uint32_t)(t - nk + 1) * frame_bytes;
+    int np_f = t - nk + 1;                              // frame of the next phase (may be < 0 under replicate padding: clamped)
+    uint32_t np_off = (uint32_t)max(np_f, 0) * frame_bytes;
     int np_sl = 0;
     if (loader) {
 #pragma unroll
@@ -810,9 +822,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     auto advance_phase = [&]() {
         if (++np_sl == S) {
             np_sl = 0;
-            np_off += frame_bytes - (uint32_t)(S - 1) * 96u;
+            ++np_f;
+            np_off = (uint32_t)max(np_f, 0) * frame_bytes;
         } else {
-            np_off += 96u;
+            np_off += (uint32_t)PITCH;
         }
     };
     advance_phase();
@@ -834,7 +847,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
                 case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
                 case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
                 case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
             }
         }
         // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
@@ -850,15 +864,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         for (int m = 0; m < MT; ++m) pa[m] = (MT * wave + m + dy) * SC + (l31 + dx);
         // order inside a chunk: all fragment reads -> this wave's DMA issues (their ~150 cycles apiece hide the LDS latency)
         // -> the MFMAs, which then drain underneath the next chunk's wait / barrier / reads
-        bf16x8 af[3][MT], wf[3][NT];
+        bf16x8 af[KS][MT], wf[KS][NT];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * 96 + (((2 * ks + hi) ^ ((pa[m] >> 3) & 1)) << 4));
+            for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * PITCH + (slab_swz<SLW>(2 * ks + hi, pa[m]) << 4));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + l31;
-                wf[ks][nt] = *(const bf16x8*)(Ws + n * 96 + (((2 * ks + hi) ^ ((n >> 3) & 1)) << 4));
+                wf[ks][nt] = *(const bf16x8*)(Ws + n * PITCH + (slab_swz<SLW>(2 * ks + hi, n) << 4));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -914,27 +928,40 @@ int launch_slab96_inst(const ConvArgs& a, hipStream_t stream) {     // conv.slab
     return apexmi_check_launch("conv3d_cl (slab 8x32)");
 }
 
-template <int NT, int MT, int NORM>
+template <int NT, int MT, int NORM, int SLW = 48>
 int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
-    constexpr int SPOS = (8 * MT + 2) * 34, NPJ = (SPOS * 96 + 8191) / 8192;
-    constexpr int LDS = 2 * NPJ * 8192 + 3 * NT * 32 * 96;
+    constexpr int SPOS = (8 * MT + 2) * 34, NPJ = (SPOS * SLW * 2 + 8191) / 8192;
+    constexpr int LDS = 2 * NPJ * 8192 + 3 * NT * 32 * SLW * 2;
     static_assert(LDS <= 160 * 1024, "slab kernel LDS");
     static uint64_t attr = 0;
     if (apexmi_once_per_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM, SLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int gx = a.T * ((a.H + 8 * MT - 1) / (8 * MT)) * ((a.W + 31) / 32), gy = (a.Cout + NT * 32 - 1) / (NT * 32);
-    hipLaunchKernelGGL((conv3d_slab_kernel<NT, MT, NORM>), dim3(gx, gy), dim3(512), LDS, stream, a);
+    hipLaunchKernelGGL((conv3d_slab_kernel<NT, MT, NORM, SLW>), dim3(gx, gy), dim3(512), LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab)");
 }
 
 // which convolutions the slab kernels take: Cin a multiple of 48, 3x3 "same" spatial taps, kT <= 3, stride 1, zero padding
+// 48-channel slices (16x32 / 8x32 tiles) where Cin is a multiple of 48; otherwise 64-channel slices on 8 x 32 tiles with 128
+// output channels per workgroup (Cout a multiple of 128: the HunyuanVideo-1.5 / Flux / TAEHV stages), replicate padding included
+bool slab48(const ConvArgs& a) { return a.Cin % 48 == 0 && !a.replicate && (a.Cout <= 192 || a.Cout % 192 == 0); }
+bool slab64(const ConvArgs& a) { return a.Cin % 64 == 0 && a.Cout % 128 == 0 && !a.up && a.H < 32768 && a.W < 32768; }
 bool slab_eligible(const ConvArgs& a) {
-    return g_conv_slab && !a.replicate && a.Cin % 48 == 0 && a.Cin <= 384 && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 &&
-           (a.Cout <= 192 || a.Cout % 192 == 0);
+    return g_conv_slab && a.kH == 3 && a.kW == 3 && a.py == 1 && a.px == 1 && a.kT <= 3 && (slab48(a) || slab64(a));
 }
 
 int launch_slab(const ConvArgs& a, hipStream_t stream) {
     const bool norm = a.out_norm != nullptr;
+    if (!slab48(a)) {     // 64-channel slices
+        if (norm) {
+            if (a.Cout > 128) {
+                apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of the slab kernel", a.Cout);
+                return 1;
+            }
+            return launch_slab_inst<4, 1, 1, 64>(a, stream);
+        }
+        return launch_slab_inst<4, 1, 0, 64>(a, stream);
+    }
     if (g_conv_slab == 1 && a.Cin == 96 && a.Cout <= 96 && !a.up) {
         const int nt = (a.Cout + 31) / 32;
         if (norm) return nt == 1 ? launch_slab96_inst<1, 1>(a, stream) : nt == 2 ? launch_slab96_inst<2, 1>(a, stream) : launch_slab96_inst<3, 1>(a, stream);
@@ -987,7 +1014,7 @@ int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
         return 0;
     const int c = a.Cout;
     *taken = true;
-    if (slab_eligible(a) && !(a.out_norm != nullptr && c > 192)) return launch_slab(a, stream);
+    if (slab_eligible(a) && !(a.out_norm != nullptr && c > (slab48(a) ? 192 : 128))) return launch_slab(a, stream);
     if (c <= 32) return launch_v2<CV_N32, true>(a, stream);
     if (c <= 64) return launch_v2<CV_N64, true>(a, stream);
     if (c <= 96) return launch_v2<CV_N96, true>(a, stream);

@@ -166,8 +166,9 @@ int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk,
  *   "conv.v2"      1 (default): stride-1 zero-padded convolutions over >= 65536 positions use the conv-shaped tiles
  *                  (conv3d_v2_kernel: 512x96 / 256x192 / 256x256 / 512x32|64 by Cout); 0: always the 128x128 kernel.
  *                  Bit-identical results either way.
- *   "conv.slab"    2 (default): stride-1, zero-padded 3x3 (x kT <= 3) convolutions with Cin a multiple of 48 (<= 384) and
- *                  Cout <= 192 or a multiple of 192, over >= 65536 positions, run as a DIRECT convolution (conv3d_slab_kernel:
+ *   "conv.slab"    2 (default): stride-1 3x3 (x kT <= 3) convolutions over >= 65536 positions with Cin a multiple of 48 and
+ *                  Cout <= 192 or a multiple of 192 (zero padding), or Cin a multiple of 64 and Cout a multiple of 128 (zero or
+ *                  replicate padding), run as a DIRECT convolution (conv3d_slab_kernel:
  *                  haloed input slab per temporal tap and 48-channel slice staged once, spatial taps as shifted LDS reads);
  *                  same products as the implicit GEMM, f32 sums in another order (<= 1 bf16 ulp on a few 1e-4 of the outputs).
  *                  1: Cin = 96 / Cout <= 96 layers on the order-preserving 8 x 32 form (bit-identical to the implicit GEMM).

@@ -559,13 +559,60 @@ def test_conv_v2_tiles_with_replicate_padding(cin, cout, T, H, W):
     res = _bf(seeded((T, H, W, wp.shape[0]), 4)).to(DEV)
     outs = []
     try:
+        lib.tune_set("conv.slab", 0)       # (the 64-channel-slice direct convolution takes most of these otherwise)
         for v2 in (0, 1):
             lib.tune_set("conv.v2", v2)
             outs.append(ops.conv3d_cl(x, wp, b, k, residual=res, replicate=True))
     finally:
         lib.tune_set("conv.v2", 1)
+        lib.tune_set("conv.slab", 2)
     assert T * H * W >= 65536 and torch.equal(outs[0], outs[1])
     n = min(cout, 8)
     xin = F.pad(x.float().cpu().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0), mode="replicate")
     ref = F.conv3d(xin, w[:n].float().cpu(), b[:n].float().cpu())[0].permute(1, 2, 3, 0) + res[..., :n].float().cpu()
     assert _rel(outs[1][..., :n].float().cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,k,repl,res", [
+    (128, 128, 9, 128, 128, (3, 3, 3), True, True),       # HunyuanVideo-1.5 last stage: replicate padding, Cout 128
+    (256, 128, 5, 107, 131, (3, 3, 3), True, False),      # ragged tiles
+    (256, 256, 5, 120, 128, (3, 3, 3), True, True),       # two N tiles
+    (512, 1024, 3, 160, 144, (3, 3, 3), True, False),     # DCAE up-projection widths
+    (128, 128, 1, 512, 512, (1, 3, 3), False, True),      # Flux 2-D VAE (zero padding, one frame)
+    (512, 512, 1, 256, 256, (1, 3, 3), False, False),
+    (256, 256, 6, 120, 106, (1, 3, 3), False, False),     # TAEHV stage
+    (64, 128, 4, 160, 144, (2, 3, 3), False, True),       # kT = 2
+])
+def test_direct_convolution_with_64_channel_slices(cin, cout, T, H, W, k, repl, res):
+    """The slab kernel's second slice width (64 channels, 128-byte pitch, chunk ^ ((p >> 1) & 7), 8 x 32 tiles x 128 output
+    channels) for channel counts that are multiples of 64 but not of 48, with zero OR replicate padding — against the
+    implicit-GEMM kernels on the same operands (f32 summation order differs: <= 1 bf16 ulp on a few 1e-4 of the outputs) and
+    against torch on a few channels."""
+    from apex_studio_amd import lib, ops
+    x = _bf(seeded((T, H, W, cin), 1)).to(DEV)
+    w = _bf(seeded((cout, cin) + k, 2, scale=(cin * k[0] * 9) ** -0.5)).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    b = torch.zeros(wp.shape[0], dtype=torch.bfloat16, device=DEV)
+    b[:cout] = _bf(seeded((cout,), 3) * 0.1).to(DEV)
+    r = _bf(seeded((T, H, W, wp.shape[0]), 4)).to(DEV) if res else None
+    assert T * H * W >= 65536
+    outs = {}
+    try:
+        for v in (0, 2):
+            lib.tune_set("conv.slab", v)
+            outs[v] = ops.conv3d_cl(x, wp, b, k, residual=r, replicate=repl)
+        assert torch.equal(ops.conv3d_cl(x, wp, b, k, residual=r, replicate=repl), outs[2])
+    finally:
+        lib.tune_set("conv.slab", 2)
+    ref, got = outs[0].float(), outs[2].float()
+    rel = float((got - ref).norm() / ref.norm())
+    frac = float((outs[2] != outs[0]).float().mean())
+    ulps = float(((got - ref).abs() / (ref.abs() * 2.0 ** -7 + 1e-3)).max())
+    print(f"[slab64] {cin}->{cout} k{k} replicate={repl}: rel {rel:.2e}, {frac:.2e} of outputs differ, max {ulps:.2f} ulp")
+    assert rel < 1e-4 and frac < 2e-3 and ulps <= 1.01
+    n = 8
+    xin = F.pad(x.float().cpu().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, k[0] - 1, 0), mode="replicate" if repl else "constant")
+    ref_t = F.conv3d(xin, w[:n].float().cpu(), b[:n].float().cpu())[0].permute(1, 2, 3, 0)
+    if res:
+        ref_t = ref_t + r[..., :n].float().cpu()
+    assert _rel(outs[2][..., :n].float().cpu(), ref_t) < 4e-3
