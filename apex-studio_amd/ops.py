@@ -733,6 +733,25 @@ def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torc
     return out
 
 
+def conv2d_cl_strided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 2, pad: int = 1) -> torch.Tensor:
+    """nn.Conv2d(3x3, stride, padding=pad) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4], Ho = (H + 2 pad - 3) // stride + 1
+    (the TAEHV encoder's downsampling convolutions, reference vae/tae/model.py:218, :223, :228)."""
+    _req(x, torch.bfloat16, "conv2d_cl_strided.x")
+    _req(w_packed, torch.bfloat16, "conv2d_cl_strided.w")
+    assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, cin = x.shape
+    cout, kpad = w_packed.shape
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        assert bias.numel() == cout and bias.is_contiguous()
+    rc = _l.load().apexmi_conv3d_cl_strided(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), None, out.data_ptr(),
+                                            _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, 1, 3, 3, stride, stride, pad, pad,
+                                            Ho, Wo, _stream())
+    _l.check(rc, "conv3d_cl_strided")
+    return out
+
+
 def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(x, torch.bfloat16, "rmsnorm_cl.x")

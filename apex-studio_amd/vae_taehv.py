@@ -3,7 +3,8 @@
 Mirrors what the engines use of the reference classes:
   * `TAEHV` (apps/api/src/vae/tae/model.py:179-333): constructor arguments, `decoder.*` state-dict keys (the Sequential's
     indices), `patch_tgrow_layers`, `decode_video(x [N, T, C, H, W], parallel, show_progress_bar)`, `frames_to_trim`.
-    Decoder only: `encoder.*` keys of a checkpoint are dropped on load (no engine of SURVEY.md §8 encodes with TAEHV).
+    `encode_video` too (`encoder.*` keys); the light-VAE wrapper below builds it decode-only and drops `encoder.*` keys on load
+    (no engine of SURVEY.md §8 encodes with TAEHV).
   * `AutoencoderKLHunyuanVideo15Light` (apps/api/src/vae/hunyuanvideo15/model.py:1163-1234): `taehv.*` keys,
     `decode(latents, parallel, show_progress_bar, skip_trim)` = TAEHV over latents / scaling_factor, returned with the
     reference's extra leading axis ([1, N, 3, T', H', W'] — its caller indexes [0], base_engine.py:2055-2057).
@@ -51,6 +52,13 @@ class _MemBlock(nn.Module):
         self.conv = nn.ModuleList([_Conv(2 * n, n, 3, **kw), _None(), _Conv(n, n, 3, **kw), _None(), _Conv(n, n, 3, **kw)])
 
 
+class _TPool(nn.Module):
+    def __init__(self, n, stride, **kw):
+        super().__init__()
+        self.stride = stride
+        self.conv = _Conv(n * stride, n, 1, bias=False, **kw)
+
+
 class _TGrow(nn.Module):
     def __init__(self, n, stride, **kw):
         super().__init__()
@@ -63,10 +71,11 @@ class TAEHV(nn.Module):
 
     def __init__(self, checkpoint_path: Optional[str] = None, decoder_time_upscale: Sequence[bool] = (True, True),
                  decoder_space_upscale: Sequence[bool] = (True, True, True), patch_size: int = 1, latent_channels: int = 32,
-                 model_type: str = "wan21", device=None, dtype=torch.bfloat16):
+                 model_type: str = "wan21", with_encoder: bool = True, device=None, dtype=torch.bfloat16):
         super().__init__()
         if dtype != torch.bfloat16:
             raise ValueError("taehv_mi355 computes in bf16")
+        self.with_encoder = with_encoder
         self.patch_size, self.latent_channels, self.image_channels, self.model_type = patch_size, latent_channels, 3, model_type
         self.is_cogvideox = checkpoint_path is not None and "taecvx" in checkpoint_path
         if model_type == "wan22":
@@ -83,6 +92,13 @@ class TAEHV(nn.Module):
                      _Conv(n[s], n[s + 1], 3, bias=False, **kw)]
         mods += [_None(), _Conv(n[3], self.image_channels * self.patch_size ** 2, 3, **kw)]
         self.decoder = nn.ModuleList(mods)
+        if with_encoder:      # tae/model.py:214-236 (the light VAE of HunyuanVideo-1.5 only decodes and is built without it)
+            enc = [_Conv(self.image_channels * self.patch_size ** 2, 64, 3, **kw), _None()]
+            for stride in (2, 2, 1):
+                enc += [_TPool(64, stride, **kw), _Conv(64, 64, 3, bias=False, **kw), _MemBlock(64, **kw), _MemBlock(64, **kw),
+                        _MemBlock(64, **kw)]
+            enc += [_Conv(64, self.latent_channels, 3, **kw)]
+            self.encoder = nn.ModuleList(enc)
         self._packed: Dict[int, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
         if checkpoint_path is not None:
             self.load_state_dict(self.patch_tgrow_layers(_read_checkpoint(checkpoint_path)))
@@ -115,14 +131,19 @@ class TAEHV(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         self._packed = {}
-        sd = {k: v for k, v in state_dict.items() if not k.startswith("encoder.")}       # decoder-only class
+        sd = state_dict if self.with_encoder else {k: v for k, v in state_dict.items() if not k.startswith("encoder.")}
         return super().load_state_dict(sd, strict=strict, assign=assign)
 
     # ---- kernels per layer ------------------------------------------------------------------------------------------
-    def _w(self, c: _Conv, mem: bool = False):
+    def _w(self, c: _Conv, mem: bool = False, pool: int = 0):
         p = self._packed.get(id(c))
         if p is None:
             wt = c.weight.data
+            if wt.shape[1] % 8:      # the encoder's RGB (x patch^2) input: channels zero-padded to a multiple of 8, as the activations are
+                wt = torch.cat([wt, wt.new_zeros(wt.shape[0], 8 - wt.shape[1] % 8, *wt.shape[2:])], dim=1)
+            if pool == 2:    # TPool: [n, 2n, 1, 1] over two stacked frames -> causal [n, n, kT=2, 1, 1], tap 0 = the earlier frame
+                n = wt.shape[0]
+                wt = torch.stack([wt[:, :n], wt[:, n:]], dim=2)
             if mem:      # [n, 2n, 3, 3] over cat([x, past]) -> causal [n, n, kT=2, 3, 3]: tap 1 = this frame, tap 0 = the previous
                 n = wt.shape[0]
                 wt = torch.stack([wt[:, n:], wt[:, :n]], dim=2)
@@ -184,8 +205,43 @@ class TAEHV(nn.Module):
         outs = [self._decode_clip(x[n].transpose(0, 1), _inv_scale, trim) for n in range(x.shape[0])]
         return torch.stack(outs, 0).transpose(1, 2)
 
-    def encode_video(self, *a, **k):
-        raise NotImplementedError("taehv_mi355 holds the decoder only (the light-VAE decode path of SURVEY.md §8f-3)")
+    @ops.on_model_device
+    def _encode_clip(self, x: torch.Tensor) -> torch.Tensor:
+        """x [T, 3 p^2, h, w] (pixel-unshuffled, T a multiple of 4) -> [T / 4, latent, h / 8, w / 8] bf16."""
+        e = self.encoder
+        T, C, H, W = x.shape
+        xc = torch.zeros((T, H, W, (C + 7) // 8 * 8), dtype=torch.bfloat16, device=self.device)
+        xc[..., :C] = x.to(self.device, torch.bfloat16).permute(0, 2, 3, 1)
+        x = self._conv(e[0], xc, True)
+        i = 2
+        for _ in range(3):
+            pool = e[i]
+            if pool.stride == 2:     # frames (2j, 2j + 1) stacked along the channels + 1x1 conv == a kT = 2 conv at temporal stride 2
+                w, _b = self._w(pool.conv, pool=2)
+                x = ops.conv3d_cl_tstrided(x, w, None, (2, 1, 1), 2, 1, x.shape[0] // 2)
+            else:
+                t_, h_, w_, c_ = x.shape
+                x = ops.gemm(x.view(t_ * h_ * w_, c_), pool.conv.weight.data.view(c_, c_)).view(t_, h_, w_, c_)
+            w, _b = self._w(e[i + 1])
+            x = ops.conv2d_cl_strided(x, w, None, stride=2, pad=1)
+            for b in range(3):
+                x = self._memblock(e[i + 2 + b], x)
+            i += 5
+        x = self._conv(e[17], x, False)
+        return x[..., :self.latent_channels].permute(0, 3, 1, 2)
+
+    def encode_video(self, x: torch.Tensor, parallel: bool = True, show_progress_bar: bool = True):
+        """x [N, T, 3, H, W] RGB in [0, 1] -> latents [N, T' / 4, C, H / (8 p), W / (8 p)] (tae/model.py:299-316); the clip is
+        padded at the end to a multiple of 4 frames by repeating the last one.  `parallel` selects nothing here."""
+        if not self.with_encoder:
+            raise RuntimeError("this TAEHV was built without its encoder (with_encoder=False: the decode-only light VAE)")
+        if x.dim() != 5 or x.shape[2] != self.image_channels:
+            raise ValueError(f"TAEHV operates on NTCHW RGB tensors, got {tuple(x.shape)}")
+        if self.patch_size > 1:
+            x = torch.nn.functional.pixel_unshuffle(x, self.patch_size)
+        if x.shape[1] % 4 != 0:
+            x = torch.cat([x, x[:, -1:].repeat_interleave(4 - x.shape[1] % 4, dim=1)], 1)
+        return torch.stack([self._encode_clip(x[n]) for n in range(x.shape[0])], 0)
 
 
 def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
@@ -210,7 +266,7 @@ class AutoencoderKLHunyuanVideo15Light(nn.Module):
         self.scaling_factor = scaling_factor
         self.taehv_checkpoint_path = taehv_checkpoint_path
         self.taehv = TAEHV(checkpoint_path=None, model_type=taehv_model_type, latent_channels=taehv_latent_channels,
-                           patch_size=taehv_patch_size, device=device, dtype=dtype)
+                           patch_size=taehv_patch_size, with_encoder=False, device=device, dtype=dtype)
         on_meta = self.taehv.decoder[1].weight.is_meta
         if load_on_init and taehv_checkpoint_path is not None and not on_meta:
             self.load_taehv_weights(taehv_checkpoint_path)

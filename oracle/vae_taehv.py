@@ -1,6 +1,7 @@
 """ORACLE — test infrastructure, not product code.
 
-fp32 CPU restatement of the TAEHV DECODER behind HunyuanVideo-1.5's `use_light_vae` switch, following
+fp32 CPU restatement of TAEHV — the DECODER behind HunyuanVideo-1.5's `use_light_vae` switch and the encoder
+half of the same class (`encode_video`, tae/model.py:214-236, :299-316; pinned by tests/golden/vae_taehv_encode.pt) —, following
   /root/reference/apps/api/src/vae/tae/model.py
       conv / Clamp / MemBlock / TGrow                   :20-66    (3x3 "same" Conv2d; 3 tanh(x/3); act(conv(cat[x, past]) +
                                                                    skip(x)); 1x1 conv whose channel blocks become frames)
@@ -109,6 +110,57 @@ class TAEHVDecoder(nn.Module):
             x = F.pixel_shuffle(x, self.patch_size)
         nt, c, h, w = x.shape
         return x.view(N, nt // N, c, h, w)[:, self.frames_to_trim:]
+
+
+class TPool(nn.Module):
+    """tae/model.py:48-56: `stride` consecutive frames stacked along the channels, then a 1x1 convolution."""
+
+    def __init__(self, n: int, stride: int):
+        super().__init__()
+        self.stride = stride
+        self.conv = nn.Conv2d(n * stride, n, 1, bias=False)
+
+    def forward(self, x, pol: Policy):
+        _, c, h, w = x.shape
+        return pol.r(self.conv(x.reshape(-1, self.stride * c, h, w)))
+
+
+class TAEHVEncoder(nn.Module):
+    """The `encoder` Sequential of TAEHV (tae/model.py:214-236) with the same indices, and `encode_video` (:299-316): pixel
+    un-shuffle by the patch size, the clip padded to a multiple of 4 frames by repeating the last one, NTCHW latents."""
+
+    def __init__(self, latent_channels: int = 32, patch_size: int = 2, image_channels: int = 3, model_type: str = "hy15"):
+        super().__init__()
+        self.patch_size, self.slope = patch_size, (0.2 if model_type == "hy15" else 0.0)
+        mods: List[nn.Module] = [nn.Conv2d(image_channels * patch_size ** 2, 64, 3, padding=1), nn.Identity()]
+        for stride in (2, 2, 1):
+            mods += [TPool(64, stride), nn.Conv2d(64, 64, 3, padding=1, stride=2, bias=False), MemBlock(64), MemBlock(64), MemBlock(64)]
+        mods += [nn.Conv2d(64, latent_channels, 3, padding=1)]
+        self.encoder = nn.ModuleList(mods)
+
+    def act(self, x):
+        return F.leaky_relu(x, self.slope)
+
+    def encode_video(self, x: torch.Tensor, policy: Policy = FP32) -> torch.Tensor:
+        """x [N, T, 3, H, W] in [0, 1] -> latents [N, T' / 4, C, H / (8 p), W / (8 p)]."""
+        pol, e = policy, self.encoder
+        if self.patch_size > 1:
+            x = F.pixel_unshuffle(x, self.patch_size)
+        if x.shape[1] % 4 != 0:
+            x = torch.cat([x, x[:, -1:].repeat_interleave(4 - x.shape[1] % 4, dim=1)], 1)
+        N, T, C, H, W = x.shape
+        x = pol.r(self.act(e[0](x.reshape(N * T, C, H, W))))
+        i = 2
+        for _ in range(3):
+            x = e[i](x, pol)                                   # TPool
+            x = pol.r(e[i + 1](x))                             # stride-2 conv, no bias, no activation
+            for b in range(3):
+                xx = x.reshape(N, -1, *x.shape[1:])
+                past = F.pad(xx, (0, 0, 0, 0, 0, 0, 1, 0))[:, :xx.shape[1]].reshape(x.shape)
+                x = e[i + 2 + b](x, past, self.act, pol)
+            i += 5
+        x = pol.r(e[17](x))
+        return x.view(N, -1, *x.shape[1:])
 
 
 class AutoencoderKLHunyuanVideo15Light(nn.Module):

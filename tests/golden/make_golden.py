@@ -485,6 +485,32 @@ def gen_vae_taehv():
           {k: v["parallel_max_abs_diff"] for k, v in out.items() if isinstance(v, dict)})
 
 
+def gen_vae_taehv_encode():
+    """The REFERENCE TAEHV encoder (vae/tae/model.py:214-236, encode_video :299-316), model_type "hy15": a 9-frame clip
+    (padded to 12 by repeating the last frame) and a 4-frame one, parallel and sequential mode."""
+    for name in ("src.vae.tae", "src.vae.tae.model"):
+        sys.modules.pop(name, None)
+    t = _mod("src.vae.tae")
+    t.__path__ = []
+    tae = load_by_path("src.vae.tae.model", "src/vae/tae/model.py")
+    from oracle.vae_taehv import TAEHVEncoder
+    ref = tae.TAEHV(checkpoint_path=None, model_type="hy15", latent_channels=32, patch_size=2).eval()
+    orc = TAEHVEncoder().eval()
+    sd = vae_synthetic_state_dict(orc, 31)
+    assert sorted(sd.keys()) == sorted(k for k in ref.state_dict() if k.startswith("encoder."))
+    res = ref.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("decoder.") for k in res.missing_keys)
+    out = dict(seed=31, keys=sorted(sd.keys()))
+    with torch.no_grad():
+        for name, shape, seed in (("clip9", (1, 9, 3, 64, 96), 86), ("clip4", (1, 4, 3, 32, 32), 87)):
+            x = (seeded(shape, seed) * 0.25 + 0.5).clamp(0, 1)
+            par = ref.encode_video(x.clone(), parallel=True, show_progress_bar=False)
+            seq = ref.encode_video(x.clone(), parallel=False, show_progress_bar=False)
+            out[name] = dict(shape=shape, seed=seed, latents=par.clone(), sequential_max_abs_diff=float((par - seq).abs().max()))
+    torch.save(out, os.path.join(OUT, "vae_taehv_encode.pt"))
+    print("vae_taehv_encode.pt", {k: (tuple(v["latents"].shape), v["sequential_max_abs_diff"]) for k, v in out.items() if isinstance(v, dict)})
+
+
 def gen_unipc():
     """In-tree UniPC (reference scheduler/unipc.py) trajectory: 6 steps, shift 3, fp32 latents."""
     class SchedulerOutput:
@@ -785,6 +811,7 @@ def main():
     gen_vae_wan_encode()
     gen_vae_hunyuan15()
     gen_vae_taehv()
+    gen_vae_taehv_encode()
     gen_unipc()
     gen_lora()
     gen_fp_scaled()

@@ -214,3 +214,29 @@ def test_hunyuan15_vae_light_switch_and_engine_flag():
     ref_frames = tensor_to_frames(ref.to(torch.bfloat16).to(DEV), "np")
     diff = (frames_light.astype("int16") - ref_frames.astype("int16"))
     assert abs(diff).max() <= 6 and abs(diff).mean() < 0.6, (abs(diff).max(), abs(diff).mean())
+
+
+def test_taehv_encoder_matches_reference_output_and_oracle(golden_dir):
+    """`TAEHV.encode_video` on HIP (pixel un-shuffle, last-frame padding, TPool as a kT = 2 convolution at temporal stride 2,
+    stride-2 3x3 convolutions, MemBlocks) vs the REFERENCE's fp32 latents (vae_taehv_encode.pt) and the oracle."""
+    from apex_studio_amd.vae_taehv import TAEHV
+    from oracle.vae_taehv import TAEHVEncoder
+    g = torch.load(os.path.join(golden_dir, "vae_taehv_encode.pt"), weights_only=False)
+    orc = TAEHVEncoder().eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    hip = TAEHV(checkpoint_path=None, model_type="hy15", latent_channels=32, patch_size=2, device=DEV)
+    res = hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("decoder.") for k in res.missing_keys)
+    for name in ("clip9", "clip4"):
+        c = g[name]
+        x = (seeded(c["shape"], c["seed"]) * 0.25 + 0.5).clamp(0, 1).to(torch.bfloat16)
+        out = hip.encode_video(x.to(DEV)).float().cpu()
+        with torch.no_grad():
+            ref16, ref32 = orc.encode_video(x.float(), OL.BF16_STORAGE), orc.encode_video(x.float())
+        assert out.shape == c["latents"].shape
+        e_ref, e_like, e_true, e_emul = _rel(out, c["latents"]), _rel(out, ref16), _rel(out, ref32), _rel(ref16, ref32)
+        print(f"[taehv encode {name}] hip vs reference fp32 {e_ref:.3e}; vs bf16-storage oracle {e_like:.3e}; vs fp32 oracle "
+              f"{e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
+        assert e_like < 2e-2 and e_ref < 3e-2 and e_true < 2 * e_emul + 2e-3
+        assert torch.equal(out, hip.encode_video(x.to(DEV)).float().cpu())

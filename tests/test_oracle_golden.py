@@ -334,3 +334,21 @@ def test_hunyuan15_meanflow_time_embedding_matches_reference(golden_dir):
         rel = float((out - ref).norm() / ref.norm())
         assert rel < 1e-5, (name, rel)
     assert float((g["out"]["r300"] - g["out"]["none"]).norm() / g["out"]["none"].norm()) > 1e-2
+
+
+def test_taehv_encoder_restatement_matches_reference(golden_dir):
+    """oracle.vae_taehv.TAEHVEncoder against the reference TAEHV.encode_video (vae_taehv_encode.pt; its sequential graph walk
+    agreed with the parallel mode to 1e-6): pixel un-shuffle, last-frame padding to a multiple of 4, TPool = frame pairs stacked
+    along the channels + 1x1 conv, stride-2 convs, MemBlocks."""
+    from oracle.vae_taehv import TAEHVEncoder
+    from tests.golden.seeded import vae_synthetic_state_dict
+    g = _load(golden_dir, "vae_taehv_encode.pt")
+    enc = TAEHVEncoder().eval()
+    assert sorted(enc.state_dict().keys()) == g["keys"]
+    enc.load_state_dict(vae_synthetic_state_dict(enc, g["seed"]), strict=True)
+    for name in ("clip9", "clip4"):
+        c = g[name]
+        with torch.no_grad():
+            out = enc.encode_video((seeded(c["shape"], c["seed"]) * 0.25 + 0.5).clamp(0, 1))
+        assert out.shape == c["latents"].shape and c["sequential_max_abs_diff"] < 1e-5
+        assert torch.allclose(out, c["latents"], atol=2e-5, rtol=1e-4), (name, float((out - c["latents"]).abs().max()))
