@@ -1009,12 +1009,25 @@ int launch_v2(const ConvArgs& a, hipStream_t stream) {
 int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
     *taken = false;
     const int64_t M = (int64_t)a.T * a.H * a.W;
-    if (!g_conv_v2 || (a.replicate && (a.up || a.H > 65535 || a.W > 65535)) || a.sy != 1 || a.sx != 1 || a.st != 1 || a.t0 != 0 || a.To != a.T || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 || M < 65536 ||
+    if (!g_conv_v2 || (a.replicate && (a.up || a.H > 65535 || a.W > 65535)) || a.sy != 1 || a.sx != 1 || a.st != 1 || a.t0 != 0 || a.To != a.T || a.Ho != a.H || a.Wo != a.W || a.ntaps > 27 ||
         (int64_t)a.T * a.Hin * a.Win * a.Cin * 2 >= ((int64_t)1 << 31))   // 32-bit byte offsets in the gather
         return 0;
     const int c = a.Cout;
     *taken = true;
-    if (slab_eligible(a) && !(a.out_norm != nullptr && c > (slab48(a) ? 192 : 128))) return launch_slab(a, stream);
+    if (slab_eligible(a) && !(a.out_norm != nullptr && c > (slab48(a) ? 192 : 128))) {
+        // the slab kernels need a round of workgroups and mostly full tiles, not 65536 positions: e.g. the 32 x 32 x 61-frame
+        // stages of the HunyuanVideo-1.5 decoder (62464 positions, 1024 channels = 1952 workgroups)
+        const bool two_rows = slab48(a) && c <= 96;
+        const int th = two_rows ? 16 : 8;
+        const int nty = (a.H + th - 1) / th, ntx = (a.W + 31) / 32;
+        const int64_t wgs = (int64_t)a.T * nty * ntx * (two_rows ? 1 : (c + (slab48(a) ? 191 : 127)) / (slab48(a) ? 192 : 128));
+        const double fill = (double)a.H * a.W / ((double)nty * th * ntx * 32);
+        if (M >= 65536 || (wgs >= 256 && fill >= 0.7)) return launch_slab(a, stream);
+    }
+    if (M < 65536) {
+        *taken = false;
+        return 0;
+    }
     if (c <= 32) return launch_v2<CV_N32, true>(a, stream);
     if (c <= 64) return launch_v2<CV_N64, true>(a, stream);
     if (c <= 96) return launch_v2<CV_N96, true>(a, stream);
