@@ -334,7 +334,8 @@ def wan_plan(points, cfg, affine_norm2: bool = True):
 
 
 # ---- generic teacher forcing: match every tensor an op wrote against the oracle's unconsumed storage points ----------------
-GEN_OPS = ("gemm", "gemm_grouped", "ln_modulate", "qkv_prepare", "attention_prepared", "attention", "add_rowvec")
+GEN_OPS = ("gemm", "gemm_grouped", "ln_modulate", "qkv_prepare", "attention_prepared", "attention", "add_rowvec",
+           "gather_rows", "attention_bias", "mul")
 
 
 def _op_outputs(name, args, kwargs, ret):
@@ -371,6 +372,7 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
     report = []
     rows = [_point_rows(p, joint).to("cuda") for p in points]
     used = [False] * len(rows)
+    partial = {}                 # point index -> row blocks already matched (a point written by several per-sample calls)
     orig = {n: getattr(ops_mod, n) for n in GEN_OPS}
 
     def claim(name, view):
@@ -378,10 +380,30 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
         C = Hh * D
         flat = view.reshape(R, C).float()
         covered = []
+        # the written tensor may also be ONE sample's rows of a batched point (per-sample attention calls): same width, the
+        # point's row count a multiple of R
+        for idx, ref in enumerate(rows):
+            if used[idx] or ref.shape[1] != C or ref.shape[0] <= R or ref.shape[0] % R:
+                continue
+            done = partial.setdefault(idx, set())
+            for blk in range(ref.shape[0] // R):
+                if blk in done:
+                    continue
+                want = ref[blk * R:(blk + 1) * R]
+                rel = float((flat - want).norm() / (want.norm() + 1e-30))
+                if rel < accept:
+                    done.add(blk)
+                    report.append((len(report), name, f"point {idx} {tuple(points[idx].shape)} rows {blk * R}+{R}", rel,
+                                   int((flat != want).sum()), want.numel()))
+                    if force:
+                        view.copy_(want.to(view.dtype).view(R, Hh, D))
+                    if len(done) == ref.shape[0] // R:
+                        used[idx] = True
+                    return
         while True:
             best = None
             for idx, ref in enumerate(rows):
-                if used[idx] or ref.shape[0] > R or ref.shape[1] > C or C % ref.shape[1]:
+                if used[idx] or idx in partial or ref.shape[0] > R or ref.shape[1] > C or C % ref.shape[1]:
                     continue
                 r, c = ref.shape
                 want = ref.to(flat.device)

@@ -301,3 +301,49 @@ def test_hunyuan15_transformer_every_storage_point(name, i2v):
     print(f"[stage hunyuan15 {name}] {len(report)} storage points, worst {worst:.2e}; output after the last forced point "
           f"{e_out:.2e}; free-running {e_free:.2e}")
     assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 6e-3
+
+
+@pytest.mark.parametrize("name", ["t5", "umt5", "clip"])
+def test_text_encoders_every_storage_point(golden_dir, name):
+    """T5 / UMT5 / CLIP-text encoders under teacher forcing: embedding gather, RMS / LayerNorm, fused QKV
+    projection, attention with relative-position bias / causal + key-padding mask, gated-GELU / quick-GELU MLPs with their
+    gate * y + residual epilogues.  The oracle's attention probabilities (a storage point of its materialised restatement)
+    live only inside `apexmi_attn_fwd_bias`'s workspace: they are the only points no op output matches."""
+    from oracle import text_encoders as OT
+    from apex_studio_amd import ops
+    from apex_studio_amd import text_encoders as TE
+    from tests.golden.seeded import text_encoder_state_dict
+    g = torch.load(os.path.join(golden_dir, "text_encoders.pt"), weights_only=False)
+    if name == "clip":
+        c, cfg = g["clip"], g["clip_config"]
+        orc = OT.CLIPTextModel(**cfg).eval()
+        # (the fixture's norm weights, 1 + 0.1 x, are not bf16-representable: both sides get the rounded values here)
+        sd = {k: v.to(torch.bfloat16).float() for k, v in text_encoder_state_dict(orc, c["seed"], 30, "layer_norm").items()}
+        orc.load_state_dict(sd, strict=True)
+        hip = TE.CLIPTextModel(cfg, device=DEV, dtype=torch.bfloat16)
+        hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+        ids, mask = g["clip_ids"], g["clip_mask"]
+    else:
+        c, cfg = g[name], g["t5_config"]
+        orc = OT.T5EncoderModel(**cfg, per_layer_bias=(name == "umt5")).eval()
+        sd = {k: v.to(torch.bfloat16).float() for k, v in text_encoder_state_dict(orc, c["seed"], 24, "layer_norm.weight").items()}
+        sd.pop("encoder.embed_tokens.weight")
+        orc.load_state_dict(sd, strict=False)
+        hip = (TE.UMT5EncoderModel if name == "umt5" else TE.T5EncoderModel)(cfg, device=DEV, dtype=torch.bfloat16)
+        hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=False)
+        ids, mask = g["t5_ids"], g["t5_mask"]
+    for m in (None, mask):
+        pol = SP.TracePolicy()
+        with torch.no_grad():
+            po = orc(ids, attention_mask=m, policy=pol).last_hidden_state
+        run = lambda: hip(input_ids=ids.to(DEV), attention_mask=None if m is None else m.to(DEV)).last_hidden_state   # noqa: E731
+        free = run()
+        out, report, left = SP.run_forced_generic(ops, pol.points, run)
+        worst, _ = SP.print_report(f"{name} masked={m is not None}", report)
+        B, S = ids.shape
+        stray = [i for i in left if not (pol.points[i].dim() == 4 and tuple(pol.points[i].shape[-2:]) == (S, S))]
+        assert not stray, [(i, tuple(pol.points[i].shape)) for i in stray]
+        e_out, e_free = _rel(out, po), _rel(free, po)
+        print(f"[stage {name} masked={m is not None}] {len(report)} storage points, worst {worst:.2e}; output after the last forced "
+              f"point {e_out:.2e}; free-running {e_free:.2e}")
+        assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 2e-2
