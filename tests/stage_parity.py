@@ -335,7 +335,7 @@ def wan_plan(points, cfg, affine_norm2: bool = True):
 
 # ---- generic teacher forcing: match every tensor an op wrote against the oracle's unconsumed storage points ----------------
 GEN_OPS = ("gemm", "gemm_grouped", "ln_modulate", "qkv_prepare", "attention_prepared", "attention", "add_rowvec",
-           "gather_rows", "attention_bias", "mul")
+           "gather_rows", "attention_bias", "mul", "rope_half_")
 
 
 def _op_outputs(name, args, kwargs, ret):
@@ -348,6 +348,8 @@ def _op_outputs(name, args, kwargs, ret):
         outs = [args[3][0]]                                                  # [1, S, H, 128]
     elif name == "attention":
         outs = [ret[0].permute(1, 0, 2)]                                     # [1, H, S, D] view of [1, S, H, D]
+    elif name == "rope_half_":
+        outs = [args[0]]                                                     # in place over the q | k columns of a fused buffer
     else:
         outs = [ret]
     return [o if o.dim() == 3 else o.unsqueeze(1) for o in outs]
@@ -363,7 +365,7 @@ def _point_rows(p: torch.Tensor, joint=None) -> torch.Tensor:
 
 
 def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[], torch.Tensor], joint=None,
-                       force: bool = True, accept: float = 2e-2):
+                       force: bool = True, accept: float = 2e-2, heads_first=None):
     """Teacher forcing without a hand-written plan.  Every tensor an op writes is searched for the oracle's unconsumed storage
     points: a point [r, c] may sit at the top or the bottom rows of the written tensor [R, C] (the two streams of a joint
     buffer) and at any column offset that is a multiple of c (q | k | v of a fused projection).  A right match is ~1e-5
@@ -371,6 +373,10 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
     Returns (output, report, indices of the points no op produced)."""
     report = []
     rows = [_point_rows(p, joint).to("cuda") for p in points]
+    # a heads-first 3-D point [H, S, D] (per-sample attention operands) is stored by the HIP path as [S, H * D]
+    for i, p in enumerate(points):
+        if p.dim() == 3 and heads_first is not None and tuple(p.shape[1:]) == tuple(heads_first):
+            rows[i] = p.permute(1, 0, 2).reshape(p.shape[1], -1).to("cuda")
     used = [False] * len(rows)
     partial = {}                 # point index -> row blocks already matched (a point written by several per-sample calls)
     orig = {n: getattr(ops_mod, n) for n in GEN_OPS}
@@ -385,7 +391,7 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
         for idx, ref in enumerate(rows):
             if used[idx] or ref.shape[1] != C or ref.shape[0] <= R or ref.shape[0] % R:
                 continue
-            done = partial.setdefault(idx, set())
+            done = partial.get(idx, set())
             for blk in range(ref.shape[0] // R):
                 if blk in done:
                     continue
@@ -393,6 +399,7 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
                 rel = float((flat - want).norm() / (want.norm() + 1e-30))
                 if rel < accept:
                     done.add(blk)
+                    partial[idx] = done
                     report.append((len(report), name, f"point {idx} {tuple(points[idx].shape)} rows {blk * R}+{R}", rel,
                                    int((flat != want).sum()), want.numel()))
                     if force:
@@ -403,12 +410,13 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
         while True:
             best = None
             for idx, ref in enumerate(rows):
-                if used[idx] or idx in partial or ref.shape[0] > R or ref.shape[1] > C or C % ref.shape[1]:
+                if used[idx] or idx in partial or ref.shape[0] > R or ref.shape[1] > C:
                     continue
                 r, c = ref.shape
                 want = ref.to(flat.device)
+                step = c if C % c == 0 else 64          # q | k | v blocks of unequal width (GQA): any 64-column boundary
                 for r0 in {0, R - r}:
-                    for c0 in range(0, C, c):
+                    for c0 in range(0, C - c + 1, step):
                         if any(r0 < b and a < r0 + r and c0 < d and cc < c0 + c for a, b, cc, d in covered):
                             continue
                         g = flat[r0:r0 + r, c0:c0 + c]

@@ -347,3 +347,34 @@ def test_text_encoders_every_storage_point(golden_dir, name):
         print(f"[stage {name} masked={m is not None}] {len(report)} storage points, worst {worst:.2e}; output after the last forced "
               f"point {e_out:.2e}; free-running {e_free:.2e}")
         assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 2e-2
+
+
+def test_qwen2_5_vl_text_every_storage_point(golden_dir):
+    """Qwen2.5-VL text decoder stack (the QwenImage prompt encoder), right-padded batch of two: RMS norm, fused
+    QKV projection with bias, multimodal RoPE in place on the q | k columns, GQA causal attention with a key-padding mask, SwiGLU
+    MLP, gate * y + residual epilogues.  Attention probabilities are the only oracle points no op output matches."""
+    from oracle import qwen2_5_vl as OQV  # noqa: F401
+    from apex_studio_amd import ops
+    from tests.test_gpu_qwen_vl import _models
+    g = torch.load(os.path.join(golden_dir, "qwen2_5_vl.pt"), weights_only=False)
+    orc, hip = _models(g)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in orc.state_dict().items()}      # bf16-representable on both sides
+    orc.load_state_dict(sd, strict=True)
+    hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    t = g["text"]
+    S = t["ids"].shape[1]
+    hd = g["text_config"]["hidden_size"] // g["text_config"]["num_attention_heads"]
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        po = orc(t["ids"], attention_mask=t["mask"], policy=pol).hidden_states[-1]
+    run = lambda: hip(input_ids=t["ids"].to(DEV), attention_mask=t["mask"].to(DEV), output_hidden_states=True).hidden_states[-1]   # noqa: E731
+    free = run()
+    out, report, left = SP.run_forced_generic(ops, pol.points, run, heads_first=(S, hd))
+    worst, _ = SP.print_report("qwen2.5-vl text", report)
+    stray = [i for i in left if not (tuple(pol.points[i].shape[-2:]) == (S, S))]
+    assert not stray, [(i, tuple(pol.points[i].shape)) for i in stray]
+    real = t["mask"].bool()
+    e_out, e_free = _rel(out.float().cpu()[real], po[real]), _rel(free.float().cpu()[real], po[real])
+    print(f"[stage qwen2.5-vl text] {len(report)} storage points, worst {worst:.2e}; output after the last forced point {e_out:.2e}; "
+          f"free-running {e_free:.2e}")
+    assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 2e-2
