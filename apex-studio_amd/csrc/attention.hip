@@ -892,7 +892,7 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_fwd_generic_kernel(
     const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V, T* __restrict__ O,
     int H, int Sq, int Sk, int D, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
     int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
-    int64_t o_ss, int64_t o_sh, float scale) {
+    int64_t o_ss, int64_t o_sh, float scale, int64_t v_sd) {
     __shared__ float qs[512];
     __shared__ float ps[GEN_THREADS];
     __shared__ float red[GEN_THREADS / 64];
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_fwd_generic_kernel(
         if (tid < D) {
             acc *= alpha;
             const int nk = min(GEN_THREADS, Sk - k0);
-            const T* vp = V + b * v_sb + h * v_sh + (int64_t)k0 * v_ss + tid;
+            const T* vp = V + b * v_sb + h * v_sh + (int64_t)k0 * v_ss + tid * v_sd;   // v_sd = 1, or Skp for a V^T operand
             for (int j = 0; j < nk; ++j) acc = fmaf(ps[j], ld_elem<T>(vp + (int64_t)j * v_ss), acc);
         }
         __syncthreads();
@@ -947,10 +947,10 @@ __global__ __launch_bounds__(GEN_THREADS) void attn_fwd_generic_kernel(
 template <typename T>
 int launch_generic(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq,
                    int Sk, int D, const int64_t* qs, const int64_t* ks, const int64_t* vs,
-                   const int64_t* os, float scale, hipStream_t stream) {
+                   const int64_t* os, float scale, hipStream_t stream, int64_t v_sd = 1) {
     hipLaunchKernelGGL(attn_fwd_generic_kernel<T>, dim3(Sq, H, B), dim3(GEN_THREADS), 0, stream,
                        (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, D, qs[0], qs[1],
-                       qs[2], ks[0], ks[1], ks[2], vs[0], vs[1], vs[2], os[0], os[1], os[2], scale);
+                       qs[2], ks[0], ks[1], ks[2], vs[0], vs[1], vs[2], os[0], os[1], os[2], scale, v_sd);
     return apexmi_check_launch("attn_fwd_generic");
 }
 
@@ -1255,6 +1255,21 @@ extern "C" int apexmi_attn_fwd(const void* q, const void* k, const void* v, void
                                void* workspace, size_t workspace_bytes, apexmi_stream_t stream_) {
     return attn_fwd_impl(q, k, v, out, B, H, Sq, Sk, D, q_strides, k_strides, v_strides, o_strides, softmax_scale, dtype,
                          workspace, workspace_bytes, 0, stream_);
+}
+
+// f32-storage verification mode of apexmi_attn_fwd_prepared: q, k, vt, out are float in the prepared layouts.  Runs the
+// one-workgroup-per-query-row kernel in f32 arithmetic (no bf16 rounding of the probabilities); V is read through V^T.
+extern "C" int apexmi_attn_fwd_prepared_f32(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq,
+                                            int Sk, int Skp, const int64_t o_strides[3], float softmax_scale,
+                                            apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && vt && out, "attn_fwd_prepared_f32: null operand");
+    APEXMI_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Skp >= Sk, "attn_fwd_prepared_f32: bad problem");
+    const int64_t qs[3] = {(int64_t)H * Sq * HD, (int64_t)Sq * HD, HD};
+    const int64_t ks[3] = {(int64_t)H * Sk * HD, (int64_t)Sk * HD, HD};
+    const int64_t vs[3] = {(int64_t)H * HD * Skp, (int64_t)HD * Skp, 1};
+    ApexmiProfScope prof(1, stream, 4.0 * B * H * (double)Sq * Sk * HD, 0.0);
+    return launch_generic<float>(q, k, vt, out, B, H, Sq, Sk, HD, qs, ks, vs, o_strides, softmax_scale, stream, (int64_t)Skp);
 }
 
 extern "C" size_t apexmi_attn_framecausal_workspace_bytes(int S, int D) { return materialised_bytes(S, S, D); }

@@ -50,6 +50,101 @@ APEXMI_DEVICE u32x4 pack8(const float* f) {
     return v;
 }
 
+// ---- activation storage type --------------------------------------------------------------------------------------
+// Production stores activations as bf16 (bf16_t).  The f32-storage VERIFICATION mode (entry points with an `_f32`
+// suffix) runs the same kernel bodies with T = float: the arithmetic between a load and a store is f32
+// in both, so the only difference is the rounding at the store.  8 consecutive elements per lane either way.
+template <typename T>
+APEXMI_DEVICE void load8(const T* p, float* f);
+template <>
+APEXMI_DEVICE void load8<bf16_t>(const bf16_t* p, float* f) { unpack8(*(const u32x4*)p, f); }
+template <>
+APEXMI_DEVICE void load8<float>(const float* p, float* f) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[i] = a[i];
+        f[4 + i] = b[i];
+    }
+}
+template <typename T>
+APEXMI_DEVICE void store8(T* p, const float* f);
+template <>
+APEXMI_DEVICE void store8<bf16_t>(bf16_t* p, const float* f) { *(u32x4*)p = pack8(f); }
+template <>
+APEXMI_DEVICE void store8<float>(float* p, const float* f) {
+    *(f32x4*)p = f32x4{f[0], f[1], f[2], f[3]};
+    *(f32x4*)(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+}
+// the same 8 elements kept RAW (a load issued now, unpacked later; pure data movement such as transposes)
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+    u32x4 v;
+};
+template <>
+struct Raw8<float> {
+    f32x4 a, b;
+};
+APEXMI_DEVICE Raw8<bf16_t> ldraw8(const bf16_t* p) { return Raw8<bf16_t>{*(const u32x4*)p}; }
+APEXMI_DEVICE Raw8<float> ldraw8(const float* p) { return Raw8<float>{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+APEXMI_DEVICE void straw8(bf16_t* p, const Raw8<bf16_t>& r) { *(u32x4*)p = r.v; }
+APEXMI_DEVICE void straw8(float* p, const Raw8<float>& r) {
+    *(f32x4*)p = r.a;
+    *(f32x4*)(p + 4) = r.b;
+}
+APEXMI_DEVICE void unraw8(const Raw8<bf16_t>& r, float* f) { unpack8(r.v, f); }
+APEXMI_DEVICE void unraw8(const Raw8<float>& r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[i] = r.a[i];
+        f[4 + i] = r.b[i];
+    }
+}
+template <typename T>
+APEXMI_DEVICE Raw8<T> zero_raw8();
+template <>
+APEXMI_DEVICE Raw8<bf16_t> zero_raw8<bf16_t>() { return Raw8<bf16_t>{u32x4{0u, 0u, 0u, 0u}}; }
+template <>
+APEXMI_DEVICE Raw8<float> zero_raw8<float>() { return Raw8<float>{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
+
+template <typename T>
+APEXMI_DEVICE float load1(const T* p);
+template <>
+APEXMI_DEVICE float load1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <>
+APEXMI_DEVICE float load1<float>(const float* p) { return *p; }
+template <typename T>
+APEXMI_DEVICE void store1(T* p, float v);
+template <>
+APEXMI_DEVICE void store1<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+template <>
+APEXMI_DEVICE void store1<float>(float* p, float v) { *p = v; }
+// 4 consecutive elements (the accumulator-layout epilogues)
+template <typename T>
+APEXMI_DEVICE void load4(const T* p, float* f);
+template <>
+APEXMI_DEVICE void load4<bf16_t>(const bf16_t* p, float* f) {
+    const u32x2 r = *(const u32x2*)p;
+    f[0] = bf16_lo(r[0]);
+    f[1] = bf16_hi(r[0]);
+    f[2] = bf16_lo(r[1]);
+    f[3] = bf16_hi(r[1]);
+}
+template <>
+APEXMI_DEVICE void load4<float>(const float* p, float* f) {
+    const f32x4 r = *(const f32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = r[i];
+}
+template <typename T>
+APEXMI_DEVICE void store4(T* p, const float* f);
+template <>
+APEXMI_DEVICE void store4<bf16_t>(bf16_t* p, const float* f) { *(u32x2*)p = u32x2{pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3])}; }
+template <>
+APEXMI_DEVICE void store4<float>(float* p, const float* f) { *(f32x4*)p = f32x4{f[0], f[1], f[2], f[3]}; }
+
 // exchange with lane ^ 32 via v_permlane32_swap; returns {value of the low-half lane, value of
 // the high-half lane} so max(r0,r1) / r0+r1 are the 2-lane reductions without a select.
 APEXMI_DEVICE void swap32(float x, float& a, float& b) {

@@ -56,6 +56,10 @@ struct ConvArgs {
 };
 APEXMI_DEVICE float conv_act(float v, int act, float slope) { return (act && v < 0.0f) ? v * slope : v; }
 
+// TO = storage type of out / residual: bf16_t in production; float in the f32-storage verification mode, where `in` is the
+// exact three-way bf16 split of the float activations (channels [hi | mid | lo], apexmi_split_bf16x3) and the packed weight
+// repeats every tap's Cin run three times, so the MFMA products are exact.
+template <typename TO>
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int tap_off[MAX_TAPS];  // packed (dt, dy, dx) as signed offsets
@@ -189,25 +193,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
                 if (a.bias != nullptr) {
-                    const u32x2 b = *(const u32x2*)(a.bias + n);
-                    v[0] += bf16_lo(b[0]);
-                    v[1] += bf16_hi(b[0]);
-                    v[2] += bf16_lo(b[1]);
-                    v[3] += bf16_hi(b[1]);
+                    float b[4];
+                    load4<bf16_t>(a.bias + n, b);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += b[j];
                 }
                 if (a.res != nullptr) {
-                    const u32x2 r = *(const u32x2*)(a.res + (int64_t)m * a.Cout + n);
-                    v[0] += bf16_lo(r[0]);
-                    v[1] += bf16_hi(r[0]);
-                    v[2] += bf16_lo(r[1]);
-                    v[3] += bf16_hi(r[1]);
+                    float r[4];
+                    load4<TO>((const TO*)a.res + (int64_t)m * a.Cout + n, r);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += r[j];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], a.act, a.act_slope);
-                u32x2 o;
-                o[0] = pack_bf16(v[0], v[1]);
-                o[1] = pack_bf16(v[2], v[3]);
-                *(u32x2*)(a.out + (int64_t)m * a.Cout + n) = o;
+                store4<TO>((TO*)a.out + (int64_t)m * a.Cout + n, v);
             }
     }
 }
@@ -1046,9 +1045,9 @@ int launch_v2_for(const ConvArgs& a, hipStream_t stream, bool* taken) {
 // y = silu?( x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c] ) per position  (WanRMS_norm.forward, reference
 // vae/wan/model.py:216-222, followed by the SiLU of WanResidualBlock.forward :398-399).  G lanes per
 // position, 8 channels per lane.
-template <int G>
-__global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const bf16_t* __restrict__ x,
-                                                         bf16_t* __restrict__ y,
+template <typename T, int G>
+__global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const T* __restrict__ x,
+                                                         T* __restrict__ y,
                                                          const bf16_t* __restrict__ gamma, int64_t P, int C,
                                                          int silu) {
     const int64_t pos = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
@@ -1057,7 +1056,7 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const bf16_t* __restric
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-    if (live) unpack8(*(const u32x4*)(x + pos * C + l * 8), v);
+    if (live) load8<T>(x + pos * C + l * 8, v);
     float sq = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) sq += v[j] * v[j];
@@ -1073,12 +1072,13 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(const bf16_t* __restric
             if (silu) r = silu_f(r);
             v[j] = r;
         }
-        *(u32x4*)(y + pos * C + l * 8) = pack8(v);
+        store8<T>(y + pos * C + l * 8, v);
     }
 }
 
 // C in (512, 1024] (HunyuanVideo-1.5 VAE, 1024 channels): one wave per position, two 8-channel chunks per lane.
-__global__ __launch_bounds__(256) void rmsnorm_cl_wide_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_cl_wide_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const bf16_t* __restrict__ gamma, int64_t P, int C,
                                                               int silu) {
     const int64_t pos = (int64_t)blockIdx.x * 4 + threadIdx.x / 64;
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_wide_kernel(const bf16_t* __re
         live[h] = pos < P && (h * 64 + l) * 8 < C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[h][j] = 0.0f;
-        if (live[h]) unpack8(*(const u32x4*)(x + pos * C + (h * 64 + l) * 8), v[h]);
+        if (live[h]) load8<T>(x + pos * C + (h * 64 + l) * 8, v[h]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sq += v[h][j] * v[h][j];
     }
@@ -1109,13 +1109,14 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_wide_kernel(const bf16_t* __re
                 if (silu) r = silu_f(r);
                 v[h][j] = r;
             }
-            *(u32x4*)(y + pos * C + (h * 64 + l) * 8) = pack8(v[h]);
+            store8<T>(y + pos * C + (h * 64 + l) * 8, v[h]);
         }
 }
 
 // nearest(-exact) 2x spatial upsample, [T, H, W, C] -> [T, 2H, 2W, C]  (WanUpsample, model.py:225-237)
-__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const bf16_t* __restrict__ x,
-                                                            bf16_t* __restrict__ y, int T, int H, int W,
+template <typename TS>
+__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const TS* __restrict__ x,
+                                                            TS* __restrict__ y, int T, int H, int W,
                                                             int C) {
     const int cc = C >> 3;
     const int64_t n = (int64_t)T * 2 * H * 2 * W * cc;
@@ -1127,13 +1128,14 @@ __global__ __launch_bounds__(256) void upsample2x_cl_kernel(const bf16_t* __rest
     r /= 2 * W;
     const int yo = (int)(r % (2 * H));
     const int t = (int)(r / (2 * H));
-    *(u32x4*)(y + idx * 8) = *(const u32x4*)(x + (((int64_t)t * H + (yo >> 1)) * W + (xo >> 1)) * C + c * 8);
+    straw8(y + idx * 8, ldraw8(x + (((int64_t)t * H + (yo >> 1)) * W + (xo >> 1)) * C + c * 8));
 }
 
 // time_conv output [T, H, W, 2C] -> frames interleaved [2T, H, W, C]: channel half h of frame t becomes
 // frame 2t + h  (WanResample.forward, model.py:332-336)
-__global__ __launch_bounds__(256) void time_interleave_cl_kernel(const bf16_t* __restrict__ x,
-                                                                 bf16_t* __restrict__ y, int T, int64_t HW,
+template <typename TS>
+__global__ __launch_bounds__(256) void time_interleave_cl_kernel(const TS* __restrict__ x,
+                                                                 TS* __restrict__ y, int T, int64_t HW,
                                                                  int C) {
     const int cc = C >> 3;
     const int64_t n = (int64_t)2 * T * HW * cc;
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(256) void time_interleave_cl_kernel(const bf16_t* _
     int64_t r = idx / cc;
     const int64_t p = r % HW;
     const int f = (int)(r / HW);
-    *(u32x4*)(y + idx * 8) = *(const u32x4*)(x + (((int64_t)(f >> 1) * HW + p) * 2 + (f & 1)) * C + c * 8);
+    straw8(y + idx * 8, ldraw8(x + (((int64_t)(f >> 1) * HW + p) * 2 + (f & 1)) * C + c * 8));
 }
 
 // TAEHV input clamp (tae/model.py:24-26) behind the light VAE's 1/scaling_factor (hunyuanvideo15/model.py:1225-1226):
@@ -1185,7 +1187,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle_clamp_kernel(const bf16_t* 
 }
 
 // b[o, e, i] = a[o, e, i] * (1 - e/E) + b[o, e, i] * (e/E)   (blend_v / blend_h, model.py:1404-1422)
-__global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b,
+template <typename TS>
+__global__ __launch_bounds__(256) void crossfade_kernel(const TS* __restrict__ a, TS* __restrict__ b,
                                                         int64_t outer, int E, int64_t inner, int64_t a_so,
                                                         int64_t a_se, int64_t b_so, int64_t b_se) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1195,16 +1198,17 @@ __global__ __launch_bounds__(256) void crossfade_kernel(const bf16_t* __restrict
     const int e = (int)(r % E);
     const int64_t o = r / E;
     const float w = (float)e / (float)E;
-    bf16_t* bp = b + o * b_so + e * b_se + i;
-    const float av = bf16_to_f32(a[o * a_so + e * a_se + i]);
-    *bp = f32_to_bf16(av * (1.0f - w) + bf16_to_f32(*bp) * w);
+    TS* bp = b + o * b_so + e * b_se + i;
+    const float av = load1<TS>(a + o * a_so + e * a_se + i);
+    store1<TS>(bp, av * (1.0f - w) + load1<TS>(bp) * w);
 }
 
 // ---- GroupNorm (channels-last) for the Flux 2-D VAE: diffusers ResnetBlock2D / Decoder use
 // GroupNorm(32, C, eps=1e-6) (+ SiLU) (reference vae/auto/model.py:35-41 takes the
 // Decoder from diffusers).  Three deterministic passes: per-block per-channel partial sums, a f64
 // combine into per-group mean / rstd, and the apply (+ affine, + optional SiLU).
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+template <typename TS>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const TS* __restrict__ x, float* __restrict__ part,
                                                          int64_t P, int C, int rows_per_block) {
     __shared__ float red[16][256];           // [statistic][thread]: lane-contiguous, no bank conflicts either way
     const int ncol = C >> 3;                 // 16-byte chunks per position (<= 64)
@@ -1218,7 +1222,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
             const int64_t p = p0 + r;
             if (p >= P) break;
             float v[8];
-            unpack8(*(const u32x4*)(x + p * C + col * 8), v);
+            load8<TS>(x + p * C + col * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 s[j] += v[j];
@@ -1282,7 +1286,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename TS>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TS* __restrict__ x, TS* __restrict__ y,
                                                        const float* __restrict__ stats,
                                                        const bf16_t* __restrict__ gamma,
                                                        const bf16_t* __restrict__ beta, int64_t P, int C, int G,
@@ -1293,7 +1298,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const int col = (int)(idx % ncol);
     const int cpg = C / G;
     float v[8], gm[8], bt[8];
-    unpack8(*(const u32x4*)(x + idx * 8), v);
+    load8<TS>(x + idx * 8, v);
     unpack8(*(const u32x4*)(gamma + col * 8), gm);
     unpack8(*(const u32x4*)(beta + col * 8), bt);
 #pragma unroll
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         if (silu) r = silu_f(r);
         v[j] = r;
     }
-    *(u32x4*)(y + idx * 8) = pack8(v);
+    store8<TS>(y + idx * 8, v);
 }
 
 }  // namespace
@@ -1315,9 +1320,10 @@ extern "C" size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C) {
     return ((size_t)nblk * C * 2 + 2 * 64) * sizeof(float);
 }
 
-extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, const void* beta, int64_t P,
-                                   int C, int G, float eps, int silu, void* workspace, size_t workspace_bytes,
-                                   apexmi_stream_t stream_) {
+template <typename TS>
+static int groupnorm_cl_impl(const void* x, void* y, const void* gamma, const void* beta, int64_t P,
+                             int C, int G, float eps, int silu, void* workspace, size_t workspace_bytes,
+                             apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(x && y && gamma && beta && workspace && P > 0, "groupnorm_cl: bad arguments");
     APEXMI_REQUIRE(C % 8 == 0 && C <= 512 && G > 0 && G <= 64 && C % G == 0 && 256 % (C / 8) == 0,
@@ -1328,12 +1334,24 @@ extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, co
     float* part = (float*)workspace;
     float* stats = part + (size_t)nblk * C * 2;
     ApexmiProfScope prof(3, stream, 0.0, 6.0 * (double)P * C);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, part, P, C, rows);
+    hipLaunchKernelGGL(gn_partial_kernel<TS>, dim3(nblk), dim3(256), 0, stream, (const TS*)x, part, P, C, rows);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, stream, part, stats, nblk, C, G, P, eps);
     const int64_t n = P * (C / 8);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
-                       (bf16_t*)y, stats, (const bf16_t*)gamma, (const bf16_t*)beta, P, C, G, silu);
+    hipLaunchKernelGGL(gn_apply_kernel<TS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const TS*)x,
+                       (TS*)y, stats, (const bf16_t*)gamma, (const bf16_t*)beta, P, C, G, silu);
     return apexmi_check_launch("groupnorm_cl");
+}
+
+extern "C" int apexmi_groupnorm_cl(const void* x, void* y, const void* gamma, const void* beta, int64_t P,
+                                   int C, int G, float eps, int silu, void* workspace, size_t workspace_bytes,
+                                   apexmi_stream_t stream_) {
+    return groupnorm_cl_impl<bf16_t>(x, y, gamma, beta, P, C, G, eps, silu, workspace, workspace_bytes, stream_);
+}
+// f32-storage verification mode: x, y float; gamma / beta stay bf16 weights
+extern "C" int apexmi_groupnorm_cl_f32(const void* x, void* y, const void* gamma, const void* beta, int64_t P,
+                                       int C, int G, float eps, int silu, void* workspace, size_t workspace_bytes,
+                                       apexmi_stream_t stream_) {
+    return groupnorm_cl_impl<float>(x, y, gamma, beta, P, C, G, eps, silu, workspace, workspace_bytes, stream_);
 }
 
 static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const void* residual, void* out,
@@ -1341,7 +1359,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
                           int Ho = 0, int Wo = 0, int independent = 0, int up = 0, const void* norm_gamma = nullptr,
                           void* out_norm = nullptr, int norm_silu = 0, int act = 0, float act_slope = 0.0f, int st = 1,
-                          int t0 = 0, int To = 0) {
+                          int t0 = 0, int To = 0, int f32io = 0) {
     const int Hin = H, Win = W;
     if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
         H *= 2;
@@ -1366,9 +1384,12 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                        ((uintptr_t)zeros % 16) == 0,
                    "conv3d_cl: operands must be 16-byte aligned");
     static uint64_t attr_set = 0;
-    if (apexmi_once_per_device(attr_set))
-        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (apexmi_once_per_device(attr_set)) {
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES);
+    }
     ConvArgs a;
     a.in = (const bf16_t*)in;
     a.w = (const bf16_t*)w;
@@ -1412,12 +1433,18 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,
                          2.0 * ((double)M * Cin + (double)Cout * Kext + (double)M * Cout));
+    if (f32io) {   // verification mode: float out / residual, the 128x128 implicit GEMM for every shape
+        APEXMI_REQUIRE(out && out_norm == nullptr && ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0,
+                       "conv3d_cl_f32: float out / residual must be 16-byte aligned (no fused norm)");
+        hipLaunchKernelGGL(conv3d_cl_kernel<float>, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
+        return apexmi_check_launch("conv3d_cl_f32");
+    }
     bool taken = false;
     const int rc2 = launch_v2_for(a, stream, &taken);
     if (taken) return rc2;
     APEXMI_REQUIRE(out_norm == nullptr, "conv3d_cl_norm: this convolution does not run on the fused-norm tiles "
                                         "(ask apexmi_conv3d_cl_norm_fusable first)");
-    hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
+    hipLaunchKernelGGL(conv3d_cl_kernel<bf16_t>, dim3(nm * nn), dim3(256), 2 * STAGE_BYTES, stream, a);
     return apexmi_check_launch("conv3d_cl");
 }
 
@@ -1482,32 +1509,56 @@ extern "C" int apexmi_conv3d_cl_tstrided(const void* in, const void* w, const vo
                           0, 0, nullptr, nullptr, 0, 0, 0.0f, stride_t, t_first, To);
 }
 
+// f32-storage verification mode, every variant of the convolution through one entry point: `in` = the three-way bf16
+// split of the float activations ([T, H, W, Cin3], Cin3 = 3 x the layer's input channels), `w` packed with each tap's
+// channel run repeated three times, bias bf16, residual / out FLOAT [.., Cout].  flags: 1 replicate padding, 2 independent
+// frames, 4 read through a nearest 2x upsample.  stride / pad / output extents as apexmi_conv3d_cl_strided (pad < 0: "same"),
+// temporal stride as apexmi_conv3d_cl_tstrided (To <= 0: every frame), act / slope as apexmi_conv3d_cl_act.
+extern "C" int apexmi_conv3d_cl_f32(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                    const void* zeros, int T, int H, int W, int Cin3, int Cout, int Kpad, int kT, int kH,
+                                    int kW, int flags, int stride_h, int stride_w, int pad_top, int pad_left, int Ho, int Wo,
+                                    int stride_t, int t_first, int To, int act, float slope, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin3, Cout, Kpad, kT, kH, kW, flags & 1, stream_,
+                          stride_h, stride_w, pad_top, pad_left, Ho, Wo, (flags >> 1) & 1, (flags >> 2) & 1, nullptr, nullptr, 0,
+                          act, slope, stride_t, t_first, To, 1);
+}
+
 extern "C" int apexmi_conv3d_cl_replicate(const void* in, const void* w, const void* bias, const void* residual,
                                           void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
                                           int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 1, stream_);
 }
 
-extern "C" int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
-                                 apexmi_stream_t stream_) {
+template <typename T>
+static int rmsnorm_cl_impl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
+                           apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(x && y && gamma && P > 0, "rmsnorm_cl: bad arguments");
     APEXMI_REQUIRE(C % 8 == 0 && C <= 1024, "rmsnorm_cl: C=%d must be a multiple of 8 and <= 1024", C);
     ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)P * C);
     const int lanes = C / 8;
     if (lanes > 64)
-        hipLaunchKernelGGL(rmsnorm_cl_wide_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
-                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+        hipLaunchKernelGGL(rmsnorm_cl_wide_kernel<T>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
+                           (const T*)x, (T*)y, (const bf16_t*)gamma, P, C, silu);
     else if (lanes <= 16)
-        hipLaunchKernelGGL(rmsnorm_cl_kernel<16>, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, stream,
-                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+        hipLaunchKernelGGL((rmsnorm_cl_kernel<T, 16>), dim3((unsigned)((P + 15) / 16)), dim3(256), 0, stream,
+                           (const T*)x, (T*)y, (const bf16_t*)gamma, P, C, silu);
     else if (lanes <= 32)
-        hipLaunchKernelGGL(rmsnorm_cl_kernel<32>, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream,
-                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+        hipLaunchKernelGGL((rmsnorm_cl_kernel<T, 32>), dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream,
+                           (const T*)x, (T*)y, (const bf16_t*)gamma, P, C, silu);
     else
-        hipLaunchKernelGGL(rmsnorm_cl_kernel<64>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
-                           (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, P, C, silu);
+        hipLaunchKernelGGL((rmsnorm_cl_kernel<T, 64>), dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream,
+                           (const T*)x, (T*)y, (const bf16_t*)gamma, P, C, silu);
     return apexmi_check_launch("rmsnorm_cl");
+}
+
+extern "C" int apexmi_rmsnorm_cl(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
+                                 apexmi_stream_t stream_) {
+    return rmsnorm_cl_impl<bf16_t>(x, y, gamma, P, C, silu, stream_);
+}
+extern "C" int apexmi_rmsnorm_cl_f32(const void* x, void* y, const void* gamma, int64_t P, int C, int silu,
+                                     apexmi_stream_t stream_) {
+    return rmsnorm_cl_impl<float>(x, y, gamma, P, C, silu, stream_);
 }
 
 extern "C" int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W, int C,
@@ -1516,20 +1567,30 @@ extern "C" int apexmi_upsample2x_cl(const void* x, void* y, int T, int H, int W,
     APEXMI_REQUIRE(x && y && T > 0 && H > 0 && W > 0 && C % 8 == 0, "upsample2x_cl: bad arguments");
     const int64_t n = (int64_t)T * 2 * H * 2 * W * (C / 8);
     ApexmiProfScope prof(5, stream, 0.0, 2.5 * (double)n * 16);
-    hipLaunchKernelGGL(upsample2x_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(upsample2x_cl_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        (const bf16_t*)x, (bf16_t*)y, T, H, W, C);
     return apexmi_check_launch("upsample2x_cl");
 }
 
-extern "C" int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t HW, int C,
-                                         apexmi_stream_t stream_) {
+template <typename TS>
+static int time_interleave_cl_impl(const void* x, void* y, int T, int64_t HW, int C,
+                                   apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(x && y && T > 0 && HW > 0 && C % 8 == 0, "time_interleave_cl: bad arguments");
     const int64_t n = (int64_t)2 * T * HW * (C / 8);
     ApexmiProfScope prof(5, stream, 0.0, 2.0 * (double)n * 16);
-    hipLaunchKernelGGL(time_interleave_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       (const bf16_t*)x, (bf16_t*)y, T, HW, C);
+    hipLaunchKernelGGL(time_interleave_cl_kernel<TS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const TS*)x, (TS*)y, T, HW, C);
     return apexmi_check_launch("time_interleave_cl");
+}
+
+extern "C" int apexmi_time_interleave_cl(const void* x, void* y, int T, int64_t HW, int C,
+                                         apexmi_stream_t stream_) {
+    return time_interleave_cl_impl<bf16_t>(x, y, T, HW, C, stream_);
+}
+extern "C" int apexmi_time_interleave_cl_f32(const void* x, void* y, int T, int64_t HW, int C,
+                                             apexmi_stream_t stream_) {
+    return time_interleave_cl_impl<float>(x, y, T, HW, C, stream_);
 }
 
 extern "C" int apexmi_tanh_clamp(const void* x, void* y, int64_t n, float inv_scale, apexmi_stream_t stream_) {
@@ -1558,13 +1619,23 @@ extern "C" int apexmi_pixel_shuffle_clamp(const void* x, void* y, int T, int H, 
     return apexmi_check_launch("pixel_shuffle_clamp");
 }
 
-extern "C" int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,
-                                int64_t a_se, int64_t b_so, int64_t b_se, apexmi_stream_t stream_) {
+template <typename TS>
+static int crossfade_impl(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,
+                          int64_t a_se, int64_t b_so, int64_t b_se, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(a && b && outer > 0 && E > 0 && inner > 0, "crossfade: bad arguments");
     const int64_t n = outer * E * inner;
     ApexmiProfScope prof(5, stream, 0.0, 6.0 * (double)n);
-    hipLaunchKernelGGL(crossfade_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       (const bf16_t*)a, (bf16_t*)b, outer, E, inner, a_so, a_se, b_so, b_se);
+    hipLaunchKernelGGL(crossfade_kernel<TS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const TS*)a, (TS*)b, outer, E, inner, a_so, a_se, b_so, b_se);
     return apexmi_check_launch("crossfade");
+}
+
+extern "C" int apexmi_crossfade(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,
+                                int64_t a_se, int64_t b_so, int64_t b_se, apexmi_stream_t stream_) {
+    return crossfade_impl<bf16_t>(a, b, outer, E, inner, a_so, a_se, b_so, b_se, stream_);
+}
+extern "C" int apexmi_crossfade_f32(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so,
+                                    int64_t a_se, int64_t b_so, int64_t b_se, apexmi_stream_t stream_) {
+    return crossfade_impl<float>(a, b, outer, E, inner, a_so, a_se, b_so, b_se, stream_);
 }

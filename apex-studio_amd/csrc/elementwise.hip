@@ -25,9 +25,9 @@ APEXMI_DEVICE float block_sum_256(float x, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-template <int NIT>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
-    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
+    const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int M, int C,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms, int split,
     const float* __restrict__ scale2, const float* __restrict__ shift2) {
@@ -38,15 +38,14 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
         shift = shift2;
     }
     const int nchunk = C >> 3;
-    const bf16_t* xp = x + (int64_t)row * ldx;
+    const T* xp = x + (int64_t)row * ldx;
     float v[NIT][8];
     float sum = 0.0f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = it * 256 + threadIdx.x;
         if (c < nchunk) {
-            const u32x4 raw = *(const u32x4*)(xp + c * 8);
-            unpack8(raw, v[it]);
+            load8<T>(xp + c * 8, v[it]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[it][j];
         } else {
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
         }
     }
     const float rstd = rsqrtf(block_sum_256(sq, red) / (float)C + eps);
-    bf16_t* op = out + (int64_t)row * ldo;
+    T* op = out + (int64_t)row * ldo;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = it * 256 + threadIdx.x;
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
                     y[j + 4] += s1[j];
                 }
             }
-            *(u32x4*)(op + c * 8) = pack8(y);
+            store8<T>(op + c * 8, y);
         }
     }
 }
@@ -115,9 +114,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
 // Wave-per-row variant for C = 64 * 8 * NCH (3072, 3584, 5120): a lane owns NCH 16-byte chunks, the two
 // statistics are wave reductions (no LDS, no barrier), four rows per workgroup.  Same arithmetic order per lane
 // as the block kernel's per-thread part; the cross-lane sums differ in shape, both are f32.
-template <int NCH>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
-    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int M, int C,
+    const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int M, int C,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms, int split,
     const float* __restrict__ scale2, const float* __restrict__ shift2) {
@@ -128,12 +127,12 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
         scale = scale2;
         shift = shift2;
     }
-    const bf16_t* xp = x + (int64_t)row * ldx;
+    const T* xp = x + (int64_t)row * ldx;
     float v[NCH][8];
     float sum = 0.0f;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-        unpack8(*(const u32x4*)(xp + (it * 64 + lane) * 8), v[it]);
+        load8<T>(xp + (it * 64 + lane) * 8, v[it]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[it][j];
     }
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
             sq += d * d;
         }
     const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    bf16_t* op = out + (int64_t)row * ldo;
+    T* op = out + (int64_t)row * ldo;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
         const int c = it * 64 + lane;
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
                 y[j + 4] += s1[j];
             }
         }
-        *(u32x4*)(op + c * 8) = pack8(y);
+        store8<T>(op + c * 8, y);
     }
 }
 
@@ -192,12 +191,13 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
 // q/k: per-head RMSNorm (f32) * weight, rotary embedding, write [H, S_out, 128].
 // 16 lanes per (row, which, head) unit, 8 elements (4 rotary pairs) per lane.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    const T* __restrict__ q, const T* __restrict__ k, int64_t ld_in, int S, int H,
     int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
     const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
-    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
-    bf16_t* __restrict__ ko, int S_out, int row0) {
+    const float* __restrict__ rope, int rope_mode, T* __restrict__ qo,
+    T* __restrict__ ko, int S_out, int row0) {
     constexpr int D = 128;
     const int64_t unit = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
     const int rem = (int)(u % (nk * H));
     const int which = rem / H, h = rem % H;
     const int d = l16 * 8;
-    const bf16_t* src = (which ? k : q) + (int64_t)s * ld_in + h * D + d;
+    const T* src = (which ? k : q) + (int64_t)s * ld_in + h * D + d;
     float x[8];
-    unpack8(*(const u32x4*)src, x);
+    load8<T>(src, x);
     const bf16_t* w = which ? (s < split ? wk2 : wk) : (s < split ? wq2 : wq);
     if (w != nullptr) {
         float sq = 0.0f;
@@ -260,20 +260,21 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
         for (int j = 0; j < 8; ++j) y[j] = x[j];
     }
     if (live) {
-        bf16_t* dst = (which ? ko : qo) + ((int64_t)h * S_out + srow) * D + d;
-        *(u32x4*)dst = pack8(y);
+        T* dst = (which ? ko : qo) + ((int64_t)h * S_out + srow) * D + d;
+        store8<T>(dst, y);
     }
 }
 
 // Same arithmetic, four heads per 16-lane group: the four 16-byte loads are issued together (4x the bytes in flight per
 // wave: the one-head kernel is latency-bound at ~3.9 TB/s) and the rope table row and norm weights are fetched once for
 // the four heads.  H % 4 == 0.
+template <typename T>
 APEXMI_DEVICE void qk_norm_rope4_body(
-    int bx, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    int bx, const T* __restrict__ q, const T* __restrict__ k, int64_t ld_in, int S, int H,
     int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
     const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
-    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
-    bf16_t* __restrict__ ko, int S_out, int row0) {
+    const float* __restrict__ rope, int rope_mode, T* __restrict__ qo,
+    T* __restrict__ ko, int S_out, int row0) {
     constexpr int D = 128, G = 4;
     const int64_t grp = (int64_t)bx * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
@@ -286,10 +287,10 @@ APEXMI_DEVICE void qk_norm_rope4_body(
     const int rem = (int)(u % gpr);
     const int which = rem / (H / G), h0 = (rem % (H / G)) * G;
     const int d = l16 * 8;
-    const bf16_t* src = (which ? k : q) + (int64_t)s * ld_in + h0 * D + d;
-    u32x4 raw[G];
+    const T* src = (which ? k : q) + (int64_t)s * ld_in + h0 * D + d;
+    Raw8<T> raw[G];
 #pragma unroll
-    for (int i = 0; i < G; ++i) raw[i] = *(const u32x4*)(src + i * D);
+    for (int i = 0; i < G; ++i) raw[i] = ldraw8(src + i * D);
     const bf16_t* w = which ? (s < split ? wk2 : wk) : (s < split ? wq2 : wq);
     float wv[8];
     if (w != nullptr) unpack8(*(const u32x4*)(w + d), wv);
@@ -316,7 +317,7 @@ APEXMI_DEVICE void qk_norm_rope4_body(
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         float x[8], y[8];
-        unpack8(raw[i], x);
+        unraw8(raw[i], x);
         if (w != nullptr) {
             float sq = 0.0f;
 #pragma unroll
@@ -343,7 +344,7 @@ APEXMI_DEVICE void qk_norm_rope4_body(
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = x[j];
         }
-        if (live) *(u32x4*)((which ? ko : qo) + ((int64_t)(h0 + i) * S_out + srow) * D + d) = pack8(y);
+        if (live) store8<T>((which ? ko : qo) + ((int64_t)(h0 + i) * S_out + srow) * D + d, y);
     }
 }
 
@@ -351,65 +352,75 @@ APEXMI_DEVICE void qk_norm_rope4_body(
 // vt[h][d][col0 + s] = v[s][h][d]; columns in [S, round_up(S, 64)) are zero-filled (the attention
 // kernel multiplies them by p = 0, so they must be finite).  64 x 128 tile through LDS.
 // ------------------------------------------------------------------------------------------------
-APEXMI_DEVICE void v_transpose_body(int bx, int by, const bf16_t* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
-                                    int D, bf16_t* __restrict__ vt, int Skp, int col0) {
+template <typename T>
+APEXMI_DEVICE void v_transpose_body(int bx, int by, const T* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
+                                    int D, T* __restrict__ vt, int Skp, int col0) {
     // Row r = 8 sc + j of the tile is stored ROTATED by 8 sc elements (16 bytes x sc): in the transposed read the 8
     // lanes of one 128-byte output segment (sc = 0..7, same j, same d) then hit 8 different bank groups instead of
     // one (row stride 64 dwords = 0 mod 32 banks; PMC: SQ_LDS_BANK_CONFLICT was 80 % of SQ_LDS_IDX_ACTIVE before).
     constexpr int LDW = 128;
-    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDW];
+    __shared__ __attribute__((aligned(16))) T tile[64 * LDW];
     const int tid = threadIdx.x;
     const int s0 = bx * 64, h = by;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * 256 + tid;
         const int r = idx >> 4, dc = idx & 15;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (s0 + r < S) val = *(const u32x4*)(v + (int64_t)h * v_sh + (int64_t)(s0 + r) * v_ss + dc * 8);
-        *(u32x4*)(tile + r * LDW + (((dc + (r >> 3)) & 15) << 3)) = val;
+        Raw8<T> val = zero_raw8<T>();
+        if (s0 + r < S) val = ldraw8(v + (int64_t)h * v_sh + (int64_t)(s0 + r) * v_ss + dc * 8);
+        straw8(tile + r * LDW + (((dc + (r >> 3)) & 15) << 3), val);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * 256 + tid;
         const int d = idx >> 3, sc = idx & 7;
-        bf16_t e[8];
+        T e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) e[j] = tile[(sc * 8 + j) * LDW + ((d + 8 * sc) & 127)];
-        u32x4 o;
+        T* dst = vt + ((int64_t)h * D + d) * Skp + col0 + s0 + sc * 8;
+        if constexpr (sizeof(T) == 2) {
+            u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
-        *(u32x4*)(vt + ((int64_t)h * D + d) * Skp + col0 + s0 + sc * 8) = o;
+            for (int j = 0; j < 4; ++j) o[j] = (uint32_t)e[2 * j] | ((uint32_t)e[2 * j + 1] << 16);
+            *(u32x4*)dst = o;
+        } else {
+            *(f32x4*)dst = f32x4{e[0], e[1], e[2], e[3]};
+            *(f32x4*)(dst + 4) = f32x4{e[4], e[5], e[6], e[7]};
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
-                                                          int D, bf16_t* __restrict__ vt, int Skp, int col0) {
-    v_transpose_body(blockIdx.x, blockIdx.y, v, v_sh, v_ss, S, D, vt, Skp, col0);
+template <typename T>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
+                                                          int D, T* __restrict__ vt, int Skp, int col0) {
+    v_transpose_body<T>(blockIdx.x, blockIdx.y, v, v_sh, v_ss, S, D, vt, Skp, col0);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope4_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, int64_t ld_in, int S, int H,
+    const T* __restrict__ q, const T* __restrict__ k, int64_t ld_in, int S, int H,
     int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
     const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
-    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
-    bf16_t* __restrict__ ko, int S_out, int row0) {
-    qk_norm_rope4_body(blockIdx.x, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, S_out, row0);
+    const float* __restrict__ rope, int rope_mode, T* __restrict__ qo,
+    T* __restrict__ ko, int S_out, int row0) {
+    qk_norm_rope4_body<T>(blockIdx.x, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, S_out, row0);
 }
 
 // q/k norm + RoPE and the V transpose of one attention layer in ONE launch: both are short, latency-bound passes
 // over disjoint data (29 + 16 us at the Flux shape when launched back to back), so their workgroups share the chip.
 // Blocks [0, nb_v) transpose V (64-key tiles x heads), the rest run the q/k groups.
+template <typename T>
 __global__ __launch_bounds__(256) void qkv_prepare_fused_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld_in, int S, int H,
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, int64_t ld_in, int S, int H,
     int split, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
     const bf16_t* __restrict__ wq2, const bf16_t* __restrict__ wk2, float eps,
-    const float* __restrict__ rope, int rope_mode, bf16_t* __restrict__ qo,
-    bf16_t* __restrict__ ko, bf16_t* __restrict__ vt, int S_out, int Skp, int row0, int nb_v, int nst) {
+    const float* __restrict__ rope, int rope_mode, T* __restrict__ qo,
+    T* __restrict__ ko, T* __restrict__ vt, int S_out, int Skp, int row0, int nb_v, int nst) {
     if ((int)blockIdx.x < nb_v)
-        v_transpose_body(blockIdx.x % nst, blockIdx.x / nst, v, 128, ld_in, S, 128, vt, Skp, row0);
+        v_transpose_body<T>(blockIdx.x % nst, blockIdx.x / nst, v, 128, ld_in, S, 128, vt, Skp, row0);
     else
-        qk_norm_rope4_body(blockIdx.x - nb_v, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko,
+        qk_norm_rope4_body<T>(blockIdx.x - nb_v, q, k, ld_in, S, H, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko,
                            S_out, row0);
 }
 
@@ -710,7 +721,8 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
 // denormalize -> permute -> (x 255).round().astype(uint8) chain of diffusers VideoProcessor.postprocess_video that
 // BaseEngine._tensor_to_frames calls (engine/base_engine.py:2945-2949).  The reference runs denormalize in the decode
 // dtype, so for bf16 input the sum v/2 + 1/2 is rounded to bf16 before the scaling — reproduced here, bit for bit.
-__global__ __launch_bounds__(256) void frames_to_u8_kernel(const bf16_t* __restrict__ x, int64_t sc, int64_t st, int64_t sy,
+template <typename TV>
+__global__ __launch_bounds__(256) void frames_to_u8_kernel(const TV* __restrict__ x, int64_t sc, int64_t st, int64_t sy,
                                                            int64_t sx, int C, int T, int H, int W,
                                                            uint8_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -719,10 +731,15 @@ __global__ __launch_bounds__(256) void frames_to_u8_kernel(const bf16_t* __restr
     const int xw = (int)(i % W);
     const int y = (int)((i / W) % H);
     const int t = (int)(i / ((int64_t)W * H));
-    const bf16_t* p = x + t * st + y * sy + xw * sx;
+    const TV* p = x + t * st + y * sy + xw * sx;
     for (int c = 0; c < C; ++c) {
-        const float half = bf16_to_f32(f32_to_bf16(bf16_to_f32(p[c * sc]) * 0.5f));
-        float u = bf16_to_f32(f32_to_bf16(half + 0.5f));
+        float u;
+        if constexpr (sizeof(TV) == 2) {   // denormalize runs in the decode dtype: two bf16 roundings
+            const float half = bf16_to_f32(f32_to_bf16(bf16_to_f32(p[c * sc]) * 0.5f));
+            u = bf16_to_f32(f32_to_bf16(half + 0.5f));
+        } else {                          // float video: the same chain in f32
+            u = __fadd_rn(__fmul_rn(p[c * sc], 0.5f), 0.5f);
+        }
         u = fminf(fmaxf(u, 0.0f), 1.0f);
         out[i * C + c] = (uint8_t)rintf(u * 255.0f);
     }
@@ -740,10 +757,11 @@ extern "C" int apexmi_ln_modulate(const void* x, int64_t ldx, void* out, int64_t
 int g_ln_wave = 1;  // apexmi_tune_set("ln.wave", 0/1): wave-per-row kernel for C in {3072, 3584, 5120}
 void apexmi_set_ln_wave(int v) { g_ln_wave = v; }
 
-extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
-                                   const float* scale, const float* shift, const void* gamma,
-                                   const void* beta, float eps, int rms, int split,
-                                   const float* scale2, const float* shift2, apexmi_stream_t stream_) {
+template <typename T>
+static int ln_modulate2_impl(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                             const float* scale, const float* shift, const void* gamma,
+                             const void* beta, float eps, int rms, int split,
+                             const float* scale2, const float* shift2, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(split >= 0 && split <= M, "ln_modulate: split=%d outside [0, M]", split);
     APEXMI_REQUIRE(split == 0 || ((!scale2 || ((uintptr_t)scale2 % 16) == 0) && (!shift2 || ((uintptr_t)shift2 % 16) == 0)),
@@ -752,14 +770,14 @@ extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_
     APEXMI_REQUIRE(M > 0 && C > 0, "ln_modulate: empty problem");
     APEXMI_REQUIRE(C % 8 == 0 && C <= LN_MAX_C, "ln_modulate: C=%d must be a multiple of 8 and <= %d", C,
                    LN_MAX_C);
-    APEXMI_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0,
+    APEXMI_REQUIRE(ldx % (16 / (int)sizeof(T)) == 0 && ldo % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0,
                    "ln_modulate: rows must be 16-byte aligned");
     APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
                    "ln_modulate: scale/shift must be 16-byte aligned");
-    ApexmiProfScope prof(3, stream, 0.0, 4.0 * (double)M * C);
+    ApexmiProfScope prof(3, stream, 0.0, 2.0 * sizeof(T) * (double)M * C);
 #define LNW_LAUNCH(N)                                                                                          \
-    hipLaunchKernelGGL(ln_modulate_wave_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, ldx, \
-                       (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms, \
+    hipLaunchKernelGGL((ln_modulate_wave_kernel<T, N>), dim3((M + 3) / 4), dim3(256), 0, stream, (const T*)x, ldx, \
+                       (T*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms, \
                        split, scale2, shift2)
     if (g_ln_wave && C % 512 == 0) {
         bool done = true;
@@ -774,8 +792,8 @@ extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_
 #undef LNW_LAUNCH
     const int nit = (C / 8 + 255) / 256;
 #define LN_LAUNCH(N)                                                                                  \
-    hipLaunchKernelGGL(ln_modulate_kernel<N>, dim3(M), dim3(256), 0, stream, (const bf16_t*)x, ldx,   \
-                       (bf16_t*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,                   \
+    hipLaunchKernelGGL((ln_modulate_kernel<T, N>), dim3(M), dim3(256), 0, stream, (const T*)x, ldx,   \
+                       (T*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma,                   \
                        (const bf16_t*)beta, eps, rms, split, scale2, shift2)
     if (nit <= 1) LN_LAUNCH(1);
     else if (nit <= 2) LN_LAUNCH(2);
@@ -785,20 +803,41 @@ extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_
     return apexmi_check_launch("ln_modulate");
 }
 
-extern "C" int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H,
-                                  int D, void* vt, int Skp, int row0, apexmi_stream_t stream_) {
+extern "C" int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                                   const float* scale, const float* shift, const void* gamma,
+                                   const void* beta, float eps, int rms, int split,
+                                   const float* scale2, const float* shift2, apexmi_stream_t stream_) {
+    return ln_modulate2_impl<bf16_t>(x, ldx, out, ldo, M, C, scale, shift, gamma, beta, eps, rms, split, scale2, shift2, stream_);
+}
+
+// f32-storage verification mode: x and out are float (ldx / ldo in floats); gamma / beta stay bf16 weights
+extern "C" int apexmi_ln_modulate2_f32(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C,
+                                       const float* scale, const float* shift, const void* gamma,
+                                       const void* beta, float eps, int rms, int split,
+                                       const float* scale2, const float* shift2, apexmi_stream_t stream_) {
+    return ln_modulate2_impl<float>(x, ldx, out, ldo, M, C, scale, shift, gamma, beta, eps, rms, split, scale2, shift2, stream_);
+}
+
+template <typename T>
+static int v_transpose_impl(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H,
+                            int D, void* vt, int Skp, int row0, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(v && vt, "v_transpose: null operand");
     APEXMI_REQUIRE(D == 128, "v_transpose: D=%d unsupported (128 only)", D);
     APEXMI_REQUIRE(row0 % 64 == 0 && Skp % 64 == 0 && row0 + ((S + 63) / 64) * 64 <= Skp,
                    "v_transpose: row0=%d S=%d Skp=%d not tile aligned", row0, S, Skp);
-    APEXMI_REQUIRE(v_stride_h % 8 == 0 && v_stride_s % 8 == 0 && ((uintptr_t)v % 16) == 0 &&
+    APEXMI_REQUIRE(v_stride_h % (16 / (int)sizeof(T)) == 0 && v_stride_s % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)v % 16) == 0 &&
                        ((uintptr_t)vt % 16) == 0,
                    "v_transpose: rows must be 16-byte aligned");
-    ApexmiProfScope prof(4, stream, 0.0, 4.0 * (double)S * H * D);
-    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, H), dim3(256), 0, stream,
-                       (const bf16_t*)v, v_stride_h, v_stride_s, S, D, (bf16_t*)vt, Skp, row0);
+    ApexmiProfScope prof(4, stream, 0.0, 2.0 * sizeof(T) * (double)S * H * D);
+    hipLaunchKernelGGL(v_transpose_kernel<T>, dim3((S + 63) / 64, H), dim3(256), 0, stream,
+                       (const T*)v, v_stride_h, v_stride_s, S, D, (T*)vt, Skp, row0);
     return apexmi_check_launch("v_transpose");
+}
+
+extern "C" int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, int S, int H,
+                                  int D, void* vt, int Skp, int row0, apexmi_stream_t stream_) {
+    return v_transpose_impl<bf16_t>(v, v_stride_h, v_stride_s, S, H, D, vt, Skp, row0, stream_);
 }
 
 int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int D, void* out,
@@ -816,49 +855,69 @@ int apexmi_pack_bhsd(const void* x, const int64_t* st, int B, int H, int S, int 
 int g_qk_group = 1;  // apexmi_tune_set("qk.group", n): 0 one head per lane group | 2 four heads | 1 four heads + V transpose in the same launch
 void apexmi_set_qk_group(int v) { g_qk_group = v; }
 
-extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_in, int S,
-                                  int H, int D, int split, const void* wq, const void* wk,
-                                  const void* wq2, const void* wk2, float eps, const float* rope,
-                                  int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
-                                  int row0, apexmi_stream_t stream_) {
+template <typename T>
+static int qkv_prepare_impl(const void* q, const void* k, const void* v, int64_t ld_in, int S,
+                            int H, int D, int split, const void* wq, const void* wk,
+                            const void* wq2, const void* wk2, float eps, const float* rope,
+                            int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
+                            int row0, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(q && qo && (!k || ko), "qkv_prepare: null operand");
     APEXMI_REQUIRE(D == 128, "qkv_prepare: D=%d unsupported (128 only)", D);
     APEXMI_REQUIRE(S > 0 && H > 0 && row0 >= 0 && row0 + S <= S_out, "qkv_prepare: bad row range");
-    APEXMI_REQUIRE(ld_in % 8 == 0 && ((uintptr_t)q % 16) == 0 && (!k || ((uintptr_t)k % 16) == 0),
+    APEXMI_REQUIRE(ld_in % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)q % 16) == 0 && (!k || ((uintptr_t)k % 16) == 0),
                    "qkv_prepare: rows must be 16-byte aligned");
     APEXMI_REQUIRE(rope_mode == APEXMI_ROPE_NONE || (rope && ((uintptr_t)rope % 16) == 0),
                    "qkv_prepare: rope table missing or misaligned");
     APEXMI_REQUIRE(split <= 0 || (wq2 && wk2) || (!wq && !wk), "qkv_prepare: split needs the second weight set");
     if (g_qk_group == 1 && H % 4 == 0 && v != nullptr && vt != nullptr && row0 % 64 == 0 && Skp % 64 == 0 &&
         row0 + ((S + 63) / 64) * 64 <= Skp && ((uintptr_t)v % 16) == 0 && ((uintptr_t)vt % 16) == 0) {
-        ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D + 4.0 * (double)S * H * D);
+        ApexmiProfScope prof(4, stream, 0.0, 6.0 * sizeof(T) * (double)S * H * D);
         const int64_t ngrp = (int64_t)S * (k ? 2 : 1) * H / 4;
         const int nst = (S + 63) / 64, nb_v = nst * H;
-        hipLaunchKernelGGL(qkv_prepare_fused_kernel, dim3((unsigned)(nb_v + (ngrp + 15) / 16)), dim3(256), 0, stream,
-                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld_in, S, H, split, (const bf16_t*)wq,
-                           (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope, rope_mode, (bf16_t*)qo,
-                           (bf16_t*)ko, (bf16_t*)vt, S_out, Skp, row0, nb_v, nst);
+        hipLaunchKernelGGL(qkv_prepare_fused_kernel<T>, dim3((unsigned)(nb_v + (ngrp + 15) / 16)), dim3(256), 0, stream,
+                           (const T*)q, (const T*)k, (const T*)v, ld_in, S, H, split, (const bf16_t*)wq,
+                           (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope, rope_mode, (T*)qo,
+                           (T*)ko, (T*)vt, S_out, Skp, row0, nb_v, nst);
         return apexmi_check_launch("qkv_prepare_fused");
     }
     {
-        ApexmiProfScope prof(4, stream, 0.0, 8.0 * (double)S * H * D);
+        ApexmiProfScope prof(4, stream, 0.0, 4.0 * sizeof(T) * (double)S * H * D);
         const int64_t nunit = (int64_t)S * (k ? 2 : 1) * H;
         if (g_qk_group && H % 4 == 0)
-            hipLaunchKernelGGL(qk_norm_rope4_kernel, dim3((unsigned)((nunit / 4 + 15) / 16)), dim3(256), 0, stream,
-                               (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
+            hipLaunchKernelGGL(qk_norm_rope4_kernel<T>, dim3((unsigned)((nunit / 4 + 15) / 16)), dim3(256), 0, stream,
+                               (const T*)q, (const T*)k, ld_in, S, H, split, (const bf16_t*)wq,
                                (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
-                               rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
+                               rope_mode, (T*)qo, (T*)ko, S_out, row0);
         else
-            hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
-                               (const bf16_t*)q, (const bf16_t*)k, ld_in, S, H, split, (const bf16_t*)wq,
+            hipLaunchKernelGGL(qk_norm_rope_kernel<T>, dim3((unsigned)((nunit + 15) / 16)), dim3(256), 0, stream,
+                               (const T*)q, (const T*)k, ld_in, S, H, split, (const bf16_t*)wq,
                                (const bf16_t*)wk, (const bf16_t*)wq2, (const bf16_t*)wk2, eps, rope,
-                               rope_mode, (bf16_t*)qo, (bf16_t*)ko, S_out, row0);
+                               rope_mode, (T*)qo, (T*)ko, S_out, row0);
         if (int rc = apexmi_check_launch("qk_norm_rope")) return rc;
     }
     if (v != nullptr && vt != nullptr)
-        return apexmi_v_transpose(v, D, ld_in, S, H, D, vt, Skp, row0, stream_);
+        return v_transpose_impl<T>(v, D, ld_in, S, H, D, vt, Skp, row0, stream_);
     return 0;
+}
+
+extern "C" int apexmi_qkv_prepare(const void* q, const void* k, const void* v, int64_t ld_in, int S,
+                                  int H, int D, int split, const void* wq, const void* wk,
+                                  const void* wq2, const void* wk2, float eps, const float* rope,
+                                  int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
+                                  int row0, apexmi_stream_t stream_) {
+    return qkv_prepare_impl<bf16_t>(q, k, v, ld_in, S, H, D, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, vt,
+                                    S_out, Skp, row0, stream_);
+}
+
+// f32-storage verification mode: q, k, v, qo, ko, vt are float (ld_in in floats); the norm weights stay bf16
+extern "C" int apexmi_qkv_prepare_f32(const void* q, const void* k, const void* v, int64_t ld_in, int S,
+                                      int H, int D, int split, const void* wq, const void* wk,
+                                      const void* wq2, const void* wk2, float eps, const float* rope,
+                                      int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
+                                      int row0, apexmi_stream_t stream_) {
+    return qkv_prepare_impl<float>(q, k, v, ld_in, S, H, D, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, vt,
+                                   S_out, Skp, row0, stream_);
 }
 
 extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const float* x, int64_t ldx,
@@ -1005,7 +1064,19 @@ extern "C" int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t 
     APEXMI_REQUIRE(video && out && C > 0 && C <= 4 && T > 0 && H > 0 && W > 0, "frames_to_u8: bad arguments (C=%d)", C);
     const int64_t n = (int64_t)T * H * W;
     ApexmiProfScope prof(5, stream, 0.0, 3.0 * (double)n * C);
-    hipLaunchKernelGGL(frames_to_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)video,
+    hipLaunchKernelGGL(frames_to_u8_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)video,
+                       stride_c, stride_t, stride_h, stride_w, C, T, H, W, (uint8_t*)out);
+    return apexmi_check_launch("frames_to_u8");
+}
+
+// f32-storage verification mode: float video, the reference's fp32 chain (no intermediate bf16 roundings)
+extern "C" int apexmi_frames_to_u8_f32(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h,
+                                       int64_t stride_w, int C, int T, int H, int W, void* out, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(video && out && C > 0 && C <= 4 && T > 0 && H > 0 && W > 0, "frames_to_u8: bad arguments (C=%d)", C);
+    const int64_t n = (int64_t)T * H * W;
+    ApexmiProfScope prof(5, stream, 0.0, 5.0 * (double)n * C);
+    hipLaunchKernelGGL(frames_to_u8_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)video,
                        stride_c, stride_t, stride_h, stride_w, C, T, H, W, (uint8_t*)out);
     return apexmi_check_launch("frames_to_u8");
 }

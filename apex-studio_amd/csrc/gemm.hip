@@ -41,6 +41,9 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
+// internal epilogue class of the f32-storage verification mode (APEXMI_EPI_F32_IO): gate * y + residual with float C / R.
+// Together with APEXMI_EPI_BIAS_F32 (which also carries the activation flag) it covers every epilogue with float I/O.
+constexpr int EPI_GATE_RES_F32 = 7;
 constexpr int MAX_GROUPS = 4;
 
 struct GemmProblem {
@@ -126,19 +129,31 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
         bs[g][1] = bf16_hi(b[0]);
         bs[g][2] = bf16_lo(b[1]);
         bs[g][3] = bf16_hi(b[1]);
-        if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[g] = *(const f32x4*)(P.gate + n);
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES || EPI == EPI_GATE_RES_F32) gt[g] = *(const f32x4*)(P.gate + n);
     }
-    if (EPI == APEXMI_EPI_BIAS_F32) {  // C is float[M][ldc]: the lane's 4 consecutive columns of each group, no exchange
+    if (EPI == APEXMI_EPI_BIAS_F32 || EPI == EPI_GATE_RES_F32) {
+        // C (and R) are float[M][ld]: the lane's 4 consecutive columns of each group, no exchange.  Same formulas as the
+        // bf16 path below, minus the rounding at the store (attention scores; the f32-storage verification mode).
         float* Cf = (float*)P.C;
+        const float* Rf = (const float*)P.R;
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + 8 * g + 4 * hi;
                 if (m[mt] >= 0 && n < N) {
-                    const f32x4 o = {acc[mt][4 * g + 0] + bs[g][0], acc[mt][4 * g + 1] + bs[g][1],
-                                     acc[mt][4 * g + 2] + bs[g][2], acc[mt][4 * g + 3] + bs[g][3]};
-                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = o;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = acc[mt][4 * g + j] + bs[g][j];
+                        if (EPI == APEXMI_EPI_BIAS_F32 && P.gelu) o[j] = act_f(o[j], P.gelu);
+                    }
+                    if (EPI == EPI_GATE_RES_F32) {
+                        const f32x4 r = *(const f32x4*)(Rf + (int64_t)m[mt] * P.ldr + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = r[j] + gt[g][j] * o[j];
+                    }
+                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
                 }
             }
         return;
@@ -218,10 +233,11 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         bs[t][1] = bf16_hi(b[0]);
         bs[t][2] = bf16_lo(b[1]);
         bs[t][3] = bf16_hi(b[1]);
-        if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt[t] = *(const f32x4*)(P.gate + n);
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES || EPI == EPI_GATE_RES_F32) gt[t] = *(const f32x4*)(P.gate + n);
     }
-    if (EPI == APEXMI_EPI_BIAS_F32) {  // C is float[M][ldc]: 4 consecutive columns per tile, no exchange
+    if (EPI == APEXMI_EPI_BIAS_F32 || EPI == EPI_GATE_RES_F32) {  // float C / R: 4 consecutive columns per tile, no exchange
         float* Cf = (float*)P.C;
+        const float* Rf = (const float*)P.R;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -229,8 +245,18 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
                 const int n = nbase + 16 * t + 4 * g;
                 const f32x4_t& a = t ? y[mt] : x[mt];
                 if (m[mt] >= 0 && n < N) {
-                    const f32x4 o = {a[0] + bs[t][0], a[1] + bs[t][1], a[2] + bs[t][2], a[3] + bs[t][3]};
-                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = o;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = a[j] + bs[t][j];
+                        if (EPI == APEXMI_EPI_BIAS_F32 && P.gelu) o[j] = act_f(o[j], P.gelu);
+                    }
+                    if (EPI == EPI_GATE_RES_F32) {
+                        const f32x4 r = *(const f32x4*)(Rf + (int64_t)m[mt] * P.ldr + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = r[j] + gt[t][j] * o[j];
+                    }
+                    *(f32x4*)(Cf + (int64_t)m[mt] * P.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
                 }
             }
         return;
@@ -781,6 +807,33 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
 }
 
+// ---- exact bf16 split of an f32 operand (f32-storage verification mode) ------------------------------------------
+// out[m][j K + k] = part_j(x[m][k]), j = 0..2: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  The three
+// parts sum to x exactly (3 x 8 mantissa bits), so a bf16 MFMA GEMM over the K-concatenated operand against
+// [W | W | W] computes sum_k x[m][k] W[n][k] with EXACT products and f32 accumulation: the production main loop, fed
+// an operand that carries no activation rounding.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
+                                                            bf16_t* __restrict__ out, int64_t ldo) {
+    const int kc = K >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * kc) return;
+    const int64_t m = idx / kc;
+    const int c = (int)(idx % kc) * 8;
+    float v[8], h[8], md[8], lo[8];
+    load8<float>(x + m * ldx + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = bf16_to_f32(f32_to_bf16(v[j]));
+        const float r1 = v[j] - h[j];
+        md[j] = bf16_to_f32(f32_to_bf16(r1));
+        lo[j] = r1 - md[j];
+    }
+    bf16_t* o = out + m * ldo + c;
+    store8<bf16_t>(o, h);
+    store8<bf16_t>(o + K, md);
+    store8<bf16_t>(o + 2 * (int64_t)K, lo);
+}
+
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
@@ -856,11 +909,19 @@ int launch_group(GemmGroup& G, const int* Ms, int kind, hipStream_t stream) {
     switch (kind) {  // epilogue class: bias (+gelu flag) | gate/residual | f32 output
         case APEXMI_EPI_BIAS_GATE_RES: return launch_epi<APEXMI_EPI_BIAS_GATE_RES>(G, Ms, stream);
         case APEXMI_EPI_BIAS_F32: return launch_epi<APEXMI_EPI_BIAS_F32>(G, Ms, stream);
+        case EPI_GATE_RES_F32: return launch_epi<EPI_GATE_RES_F32>(G, Ms, stream);
         default: return launch_epi<APEXMI_EPI_BIAS>(G, Ms, stream);
     }
 }
 
-int epi_kind(int epilogue) { return act_mode(epilogue) ? APEXMI_EPI_BIAS : epilogue; }
+// epilogue argument -> kernel class.  APEXMI_EPI_F32_IO (C and R are float) maps the bf16 classes onto the float ones.
+int epi_base(int epilogue) { return epilogue & ~APEXMI_EPI_F32_IO; }
+bool epi_f32(int epilogue) { return (epilogue & APEXMI_EPI_F32_IO) != 0 || epi_base(epilogue) == APEXMI_EPI_BIAS_F32; }
+int epi_kind(int epilogue) {
+    const int b = epi_base(epilogue);
+    if (epilogue & APEXMI_EPI_F32_IO) return b == APEXMI_EPI_BIAS_GATE_RES ? EPI_GATE_RES_F32 : APEXMI_EPI_BIAS_F32;
+    return act_mode(b) ? APEXMI_EPI_BIAS : b;
+}
 
 int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
                   int N, int K, int epilogue, const float* gate, const void* R, int64_t ldr) {
@@ -872,9 +933,12 @@ int check_problem(const void* A, int64_t lda, const void* W, int64_t ldw, void* 
                    "gemm_bf16: leading dimensions must keep rows 16-byte aligned");
     APEXMI_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 8) == 0,
                    "gemm_bf16: operands must be 16-byte aligned");
-    if (epilogue == APEXMI_EPI_BIAS_GATE_RES) {
+    APEXMI_REQUIRE(epi_base(epilogue) >= 0 && epi_base(epilogue) <= 6 && (epilogue & ~(APEXMI_EPI_F32_IO | 7)) == 0,
+                   "gemm_bf16: unknown epilogue %d", epilogue);
+    APEXMI_REQUIRE(!epi_f32(epilogue) || ((uintptr_t)C % 16) == 0, "gemm_bf16: f32 output must be 16-byte aligned");
+    if (epi_base(epilogue) == APEXMI_EPI_BIAS_GATE_RES) {
         APEXMI_REQUIRE(gate && R, "gemm_bf16: gate/residual epilogue needs gate and R");
-        APEXMI_REQUIRE(ldr % 4 == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)R % 8) == 0,
+        APEXMI_REQUIRE(ldr % 4 == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)R % (epi_f32(epilogue) ? 16 : 8)) == 0,
                        "gemm_bf16: gate/R alignment");
     }
     return 0;
@@ -888,8 +952,6 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
                                 apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, R, ldr)) return rc;
-    APEXMI_REQUIRE(epilogue >= 0 && epilogue <= 6, "gemm_bf16: unknown epilogue %d", epilogue);
-    APEXMI_REQUIRE(epilogue != APEXMI_EPI_BIAS_F32 || ((uintptr_t)C % 16) == 0, "gemm_bf16: f32 output must be 16-byte aligned");
     GemmGroup G;
     G.count = 1;
     G.K = K;
@@ -897,7 +959,7 @@ extern "C" int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64
     G.bsA = G.bsW = G.bsC_bytes = 0;
     G.p[0] = GemmProblem{(const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, gate,
                          (const bf16_t*)R, lda, ldw, ldc, ldr, M, N, 0, 0, 0,
-                         act_mode(epilogue)};
+                         act_mode(epi_base(epilogue))};
     ApexmiProfScope prof(0, stream, 2.0 * M * N * (double)K,
                          2.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch_group(G, &M, epi_kind(epilogue), stream);
@@ -945,8 +1007,8 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     double flops = 0, bytes = 0;
     const int kind = epi_kind(epilogue[0]);
     for (int i = 0; i < count; ++i) {
-        APEXMI_REQUIRE(epilogue[i] >= 0 && epilogue[i] <= 6 && epi_kind(epilogue[i]) == kind,
-                       "gemm_bf16_grouped: gate/residual problems cannot be mixed with bias/gelu ones");
+        APEXMI_REQUIRE(epi_kind(epilogue[i]) == kind,
+                       "gemm_bf16_grouped: gate/residual (or float / bf16 output) problems cannot be mixed with the others");
         const float* g = gate ? gate[i] : nullptr;
         const void* r = R ? R[i] : nullptr;
         const int64_t lr = ldr ? ldr[i] : 0;
@@ -954,12 +1016,26 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
             return rc;
         G.p[i] = GemmProblem{(const bf16_t*)A[i], (const bf16_t*)W[i], (const bf16_t*)(bias ? bias[i] : nullptr),
                              (bf16_t*)C[i], g, (const bf16_t*)r, lda[i], ldw[i], ldc[i], lr, M[i], N[i], 0, 0, 0,
-                             act_mode(epilogue[i])};
+                             act_mode(epi_base(epilogue[i]))};
         flops += 2.0 * M[i] * N[i] * (double)K;
         bytes += 2.0 * ((double)M[i] * K + (double)N[i] * K + (double)M[i] * N[i]);
     }
     ApexmiProfScope prof(0, stream, flops, bytes);
     return launch_group(G, M, kind, stream);
+}
+
+extern "C" int apexmi_split_bf16x3(const float* x, int64_t ldx, int64_t M, int K, void* out, int64_t ldo,
+                                   apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out && M > 0 && K > 0, "split_bf16x3: bad arguments");
+    APEXMI_REQUIRE(K % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && ldo >= 3 * (int64_t)K && ((uintptr_t)x % 16) == 0 &&
+                       ((uintptr_t)out % 16) == 0,
+                   "split_bf16x3: K=%d must be a multiple of 8 and rows 16-byte aligned", K);
+    const int64_t n = M * (K / 8);
+    ApexmiProfScope prof(5, stream, 0.0, 10.0 * (double)M * K);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, M, K,
+                       (bf16_t*)out, ldo);
+    return apexmi_check_launch("split_bf16x3");
 }
 
 // tuning keys of this file (dispatched from apexmi_tune_set, runtime.hip)

@@ -46,6 +46,13 @@ def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4
     return image_seq_len * m + (base_shift - m * base_seq_len)
 
 
+def compute_dtype(module) -> torch.dtype:
+    """The dtype activations / latents travel in for `module`: its activation storage type — bf16 in production, float32
+    when the module was put into the f32-storage verification mode (`set_storage_dtype`), where the engines keep the
+    sampler state in float32 like the reference's CPU fp32 path."""
+    return getattr(module, "storage_dtype", None) or module.dtype
+
+
 def _emit(cb, p, msg):
     if cb is not None:
         try:
@@ -112,7 +119,7 @@ class FluxT2IEngine(EngineLoraMixin):
             generator: Optional[torch.Generator] = None, return_latents: bool = False,
             progress_callback=None, render_on_step: bool = False, render_on_step_callback=None,
             render_on_step_interval: int = 3, sigmas=None, output_type: Optional[str] = None, **_ignored):
-        dev, dt = self.device, self.transformer.dtype
+        dev, dt = self.device, compute_dtype(self.transformer)
         B = prompt_embeds.shape[0]
         h = 2 * (int(height) // (self.vae_scale_factor * 2))
         w = 2 * (int(width) // (self.vae_scale_factor * 2))

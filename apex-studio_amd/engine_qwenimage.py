@@ -11,7 +11,7 @@ import torch
 
 from .lora import EngineLoraMixin
 
-from .engine_flux import calculate_shift
+from .engine_flux import calculate_shift, compute_dtype
 from .schedulers import FlowMatchEulerDiscreteScheduler
 
 
@@ -56,7 +56,7 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
     @torch.no_grad()
     def vae_encode(self, image: torch.Tensor, sample_mode: str = "mode", generator=None) -> torch.Tensor:
         """BaseEngine.vae_encode (engine/base_engine.py:2061-2165): tiled encode, posterior mode / sample, normalise."""
-        x = image.to(self.device, self.vae.dtype)
+        x = image.to(self.device, compute_dtype(self.vae))
         if x.dim() == 4:
             x = x.unsqueeze(2)
         self.vae.enable_tiling()
@@ -64,7 +64,7 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
         if sample_mode not in ("mode", "sample"):
             raise ValueError(f"Invalid sample mode: {sample_mode}")
         lat = post.mode() if sample_mode == "mode" else post.sample(generator=generator)
-        return self.vae.normalize_latents(lat.to(self.vae.dtype))
+        return self.vae.normalize_latents(lat.to(compute_dtype(self.vae)))
 
     def prepare_image_latents(self, images, batch_size: int = 1):
         """`_prepare_image_latents` (engine/qwenimage/edit_plus.py:26-110) for condition images given as pixels in [-1, 1]
@@ -88,13 +88,23 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
     @torch.no_grad()
     def vae_decode(self, latents: torch.Tensor, height: int, width: int) -> torch.Tensor:
         z = self._unpack_latents(latents, height, width)
-        z = self.vae.denormalize_latents(z.to(torch.float32)).to(self.vae.dtype)
+        z = self.vae.denormalize_latents(z.to(torch.float32)).to(compute_dtype(self.vae))
         self.vae.enable_tiling()
         return self.vae.decode(z, return_dict=False)[0][:, :, 0]
 
+    def _render_step(self, latents, render_on_step_callback, height, width):
+        """Latent preview (reference engine/qwenimage/shared.py:319-342 `_render_step`): unpack -> denormalise -> decode the
+        CURRENT latents and hand the image to the callback; a failing preview never interrupts the denoise."""
+        try:
+            img = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents, height, width)
+            render_on_step_callback(img)
+        except Exception:
+            pass
+
     def base_denoise(self, latents, timesteps, prompt_embeds, img_shapes, image_latents=None,
                      negative_prompt_embeds=None, true_cfg_scale: float = 1.0, use_cfg_guidance: bool = False,
-                     denoise_progress_callback=None):
+                     denoise_progress_callback=None, render_on_step: bool = False, render_on_step_callback=None,
+                     render_on_step_interval: int = 3, preview_hw=None):
         _emit(denoise_progress_callback, 0.0, "Starting denoise")
         n = len(timesteps)
         n_tgt = latents.shape[1]
@@ -115,6 +125,11 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
                 noise_norm = torch.norm(comb, dim=-1, keepdim=True)
                 noise_pred = comb * (cond_norm / noise_norm)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            # shared.py:455-457: every `render_on_step_interval` steps (and after the first), never after the last
+            if (render_on_step and render_on_step_callback is not None and preview_hw is not None
+                    and (self.decode_fn is not None or self.vae is not None)
+                    and ((i + 1) % render_on_step_interval == 0 or i == 0) and i != n - 1):
+                self._render_step(latents, render_on_step_callback, preview_hw[0], preview_hw[1])
             _emit(denoise_progress_callback, float(i + 1) / n, f"Denoise {i + 1}/{n}")
         return latents
 
@@ -124,8 +139,8 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             num_inference_steps: int = 8, negative_prompt_embeds: Optional[torch.Tensor] = None,
             true_cfg_scale: float = 1.0, latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
             return_latents: bool = False, progress_callback=None, images=None, output_type: Optional[str] = None,
-            **_ignored):
-        dev, dt = self.device, self.transformer.dtype
+            render_on_step: bool = False, render_on_step_callback=None, render_on_step_interval: int = 3, **_ignored):
+        dev, dt = self.device, compute_dtype(self.transformer)
         if images is not None:       # condition images as pixels (or latents): encode + pack here
             image_latents, image_shapes = self.prepare_image_latents(images, prompt_embeds.shape[0])
         h2, w2 = height // 16, width // 16
@@ -153,7 +168,9 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
                                     image_latents=None if image_latents is None else image_latents.to(dev, dt),
                                     negative_prompt_embeds=None if not cfg else negative_prompt_embeds.to(dev, dt),
                                     true_cfg_scale=true_cfg_scale, use_cfg_guidance=cfg,
-                                    denoise_progress_callback=mapped)
+                                    denoise_progress_callback=mapped, render_on_step=render_on_step,
+                                    render_on_step_callback=render_on_step_callback,
+                                    render_on_step_interval=render_on_step_interval, preview_hw=(height, width))
         if return_latents or (self.decode_fn is None and self.vae is None):
             return latents
         out = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents, height, width)

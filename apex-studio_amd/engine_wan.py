@@ -15,6 +15,7 @@ import torch
 
 from .lora import EngineLoraMixin
 
+from .engine_flux import compute_dtype
 from .schedulers import UniPCMultistepScheduler
 
 
@@ -57,21 +58,21 @@ class WanT2VEngine(EngineLoraMixin):
 
     def vae_decode(self, latents: torch.Tensor) -> torch.Tensor:
         """reference engine/base_engine.py:2030-2059: denormalize -> enable tiling -> decode."""
-        z = self.vae.denormalize_latents(latents.to(torch.float32)).to(self.vae.dtype)
+        z = self.vae.denormalize_latents(latents.to(torch.float32)).to(compute_dtype(self.vae))
         self.vae.enable_tiling()
         return self.vae.decode(z, return_dict=False)[0]
 
     def moe_denoise(self, latents, timesteps, prompt_embeds, negative_prompt_embeds=None,
                     guidance_scale: Union[float, List[float]] = 5.0, boundary_timestep=None,
-                    use_cfg_guidance: bool = True, transformer_dtype=torch.bfloat16, render_on_step: bool = False,
+                    use_cfg_guidance: bool = True, transformer_dtype=None, render_on_step: bool = False,
                     render_on_step_callback=None, render_on_step_interval: int = 3,
                     denoise_progress_callback=None):
         _emit(denoise_progress_callback, 0.0, "Starting denoise")
         n = len(timesteps)
         for i, t in enumerate(timesteps):
-            x = latents.to(transformer_dtype)
             timestep = t.expand(latents.shape[0])
             transformer = self._select_dual_noise_transformer(t, boundary_timestep)
+            x = latents.to(transformer_dtype or compute_dtype(transformer))
             scale = self._select_dual_noise_guidance_scale(t, boundary_timestep, guidance_scale)
             noise_pred = transformer(hidden_states=x, timestep=timestep, encoder_hidden_states=prompt_embeds,
                                      return_dict=False)[0]
@@ -115,8 +116,9 @@ class WanT2VEngine(EngineLoraMixin):
         if self.boundary_ratio is not None:
             boundary = self.boundary_ratio * self.scheduler.config["num_train_timesteps"]
         cfg = negative_prompt_embeds is not None
-        pe = prompt_embeds.to(dev, torch.bfloat16)
-        ne = negative_prompt_embeds.to(dev, torch.bfloat16) if cfg else None
+        dt = compute_dtype(self.high_noise_transformer)
+        pe = prompt_embeds.to(dev, dt)
+        ne = negative_prompt_embeds.to(dev, dt) if cfg else None
 
         def mapped(p, msg):
             _emit(progress_callback, 0.5 + 0.4 * p, msg)

@@ -180,6 +180,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         self._packed = False
         self._ws: Dict[Any, Any] = {}
         self._side = None
+        self.storage_dtype = torch.bfloat16
 
     # ---- reference-compatible plumbing -------------------------------------------------------
     @classmethod
@@ -190,6 +191,17 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         return cls(**cfg)
 
     _from_config = from_config
+
+    # ---- activation storage ------------------------------------------------------------------------------------------
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same
+        kernel sequence with every activation buffer float and the library's `_f32` entry points, which is what
+        north_star's "within 1e-3 of the CPU fp32 reference" is tested with.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        self._ws = {}
+        return self
 
     @property
     def dtype(self):
@@ -295,7 +307,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         H = self.config.num_attention_heads
         S = s_txt + s_img
         skp = (S + 63) // 64 * 64
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=self.storage_dtype)     # activation buffers
         f32 = dict(device=dev, dtype=torch.float32)
         mlp = 4 * dim
         ws = SimpleNamespace(
@@ -334,12 +346,13 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
 
         # conditioning vector (f32): timestep.to(dtype) * 1000 as the reference does (model.py:535)
         tte = self.time_text_embed
-        t = (timestep.to(self.dtype) * 1000).float().reshape(1)
+        cdt = self.storage_dtype     # the reference's `hidden_states.dtype`: bf16 in production, f32 when verifying
+        t = (timestep.to(cdt) * 1000).float().reshape(1)
         self._embed_t(tte.timestep_embedder, ops.timestep_embedding(t, 256), ws.TEMB, accum=False)
         if cfg.guidance_embeds:
             if guidance is None:
                 raise ValueError("guidance_embeds=True model called without `guidance`")
-            g = (guidance.to(self.dtype) * 1000).float().reshape(1)
+            g = (guidance.to(cdt) * 1000).float().reshape(1)
             self._embed_t(tte.guidance_embedder, ops.timestep_embedding(g, 256), ws.TEMB, accum=True)
         self._embed_t(tte.text_embedder, pooled.float().reshape(1, -1), ws.TEMB, accum=True)
         # Every AdaLN projection of every block is one weight-streaming GEMV (6.4 GB for FLUX-dev).
@@ -442,7 +455,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         join_mod()
         # AdaLayerNormContinuous: scale first, then shift
         ops.ln_modulate(Xi, self._mod(ws, ("out",), 0), self._mod(ws, ("out",), 1), out=XNi)
-        out = torch.empty(s_img, self.proj_out.out_features, device=X.device, dtype=torch.bfloat16)
+        out = torch.empty(s_img, self.proj_out.out_features, device=X.device, dtype=self.storage_dtype)
         ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias, out=out)
         return out
 
@@ -464,8 +477,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         if img_ids.ndim == 3:
             img_ids = img_ids[0]
         B = hidden_states.shape[0]
-        hs = hidden_states.to(torch.bfloat16)
-        enc = encoder_hidden_states.to(torch.bfloat16)
+        hs = hidden_states.to(self.storage_dtype)
+        enc = encoder_hidden_states.to(self.storage_dtype)
         outs = []
         for b in range(B):
             outs.append(self._forward_one(

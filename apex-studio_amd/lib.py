@@ -99,11 +99,20 @@ SIGNATURES = {
     "apexmi_prof_reset": (C.c_int, []),
 }
 
+# f32-storage verification mode (include/apexmi.h, last section): same argument lists as the bf16 entry points
+for _name in ("apexmi_ln_modulate2", "apexmi_qkv_prepare", "apexmi_rmsnorm_cl", "apexmi_groupnorm_cl",
+              "apexmi_time_interleave_cl", "apexmi_crossfade", "apexmi_frames_to_u8"):
+    SIGNATURES[_name + "_f32"] = SIGNATURES[_name]
+SIGNATURES["apexmi_attn_fwd_prepared_f32"] = SIGNATURES["apexmi_attn_fwd_prepared"]
+SIGNATURES["apexmi_split_bf16x3"] = (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, vp])
+SIGNATURES["apexmi_conv3d_cl_f32"] = (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 20 + [C.c_float, vp])
+
 NCLASS = 6
 PROF_CLASSES = ("gemm", "attention", "gemv", "ln_modulate", "qkv_prepare", "other")
 
 BF16, F16, F32 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_F32, EPI_BIAS_GELU_ERF, EPI_BIAS_SILU, EPI_BIAS_QUICK_GELU = 0, 1, 2, 3, 4, 5, 6
+EPI_F32_IO = 0x100   # C and R are float: the f32-storage verification mode
 GEMV_PRE_SILU, GEMV_POST_SILU, GEMV_POST_GELU, GEMV_ACCUM = 1, 2, 4, 8
 ROPE_INTERLEAVED, ROPE_COMPLEX, ROPE_NONE = 0, 1, 2
 

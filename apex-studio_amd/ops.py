@@ -28,6 +28,64 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# ---- activation storage type -----------------------------------------------------------------------------------------
+# Production stores activations as bf16.  A float32 activation tensor selects the f32-STORAGE VERIFICATION MODE of the
+# library (include/apexmi.h, last section): the same kernels instantiated with float storage, the MFMA
+# kernels fed the exact three-way bf16 split of the activations.  Weights, gains and biases are bf16 in both modes.
+_ACT = (torch.bfloat16, torch.float32)
+
+
+def _req_act(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _l.ApexMIError(f"{name}: expected a ROCm device tensor, got {t.device} (no CPU fallback)")
+    if t.dtype not in _ACT:
+        raise _l.ApexMIError(f"{name}: activations are stored as bfloat16 (or float32 in the verification mode), got {t.dtype}")
+
+
+def _fn(name: str, t: torch.Tensor):
+    """The entry point `name` for t's storage type (`name_f32` for float activations)."""
+    return getattr(_l.load(), name + ("_f32" if t.dtype == torch.float32 else ""))
+
+
+def split3(a: torch.Tensor) -> torch.Tensor:
+    """[M, K] float (row stride free) -> [M, 3K] bf16 = [hi | mid | lo], hi + mid + lo == a exactly."""
+    _req(a, torch.float32, "split3.a")
+    assert a.dim() == 2 and a.stride(1) == 1 and a.shape[1] % 8 == 0
+    M, K = a.shape
+    out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=a.device)
+    _l.check(_l.load().apexmi_split_bf16x3(a.data_ptr(), a.stride(0), M, K, out.data_ptr(), out.stride(0), _stream()),
+             "split_bf16x3")
+    return out
+
+
+_w3_cache: dict = {}
+_w3_bytes = 0
+_W3_CAP = 16 << 30
+
+
+def clear_verification_caches() -> None:
+    """Drop the repeated-weight copies the f32-storage verification mode keeps (they hold their source weights alive)."""
+    global _w3_bytes
+    _w3_cache.clear()
+    _w3c_cache.clear()
+    _w3_bytes = 0
+
+
+def _w3(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] bf16 weight -> [N, 3K] = [w | w | w] (layout only), the partner of split3(); cached per weight version.
+    An entry keeps a reference to its source view, so the address in the key cannot be recycled while the entry lives."""
+    global _w3_bytes
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.stride(0))
+    hit = _w3_cache.get(key)
+    if hit is None:
+        if _w3_bytes > _W3_CAP:
+            clear_verification_caches()
+        hit = (w, w.repeat(1, 3).contiguous())
+        _w3_cache[key] = hit
+        _w3_bytes += hit[1].numel() * 2
+    return hit[1]
+
+
 _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES,
         "gelu_erf": _l.EPI_BIAS_GELU_ERF, "silu": _l.EPI_BIAS_SILU, "quick_gelu": _l.EPI_BIAS_QUICK_GELU}
 
@@ -35,17 +93,19 @@ _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_G
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, epilogue: str = "bias",
          gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  2-D bf16 operands, last dim contiguous."""
-    _req(a, torch.bfloat16, "gemm.a")
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  2-D operands, last dim contiguous; a / out / residual bf16, or float32
+    in the f32-storage verification mode (w and bias stay bf16)."""
+    _req_act(a, "gemm.a")
     _req(w, torch.bfloat16, "gemm.w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    act = a.dtype
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        out = torch.empty((M, N), dtype=act, device=a.device)
     else:
-        _req(out, torch.bfloat16, "gemm.out")
+        _req(out, act, "gemm.out")
         assert out.shape == (M, N) and out.stride(1) == 1
     if bias is not None:
         _req(bias, torch.bfloat16, "gemm.bias")
@@ -53,12 +113,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     ldr = 0
     if epilogue == "gate_res":
         _req(gate, torch.float32, "gemm.gate")
-        _req(residual, torch.bfloat16, "gemm.residual")
+        _req(residual, act, "gemm.residual")
         assert gate.is_contiguous() and gate.numel() == N
         assert residual.shape == (M, N) and residual.stride(1) == 1
         ldr = residual.stride(0)
+    epi = _EPI[epilogue]
+    if act == torch.float32:     # exact bf16 split of the activations against [w | w | w]: same kernel, float epilogue
+        a, w, K, epi = split3(a), _w3(w), 3 * K, epi | _l.EPI_F32_IO
     rc = _l.load().apexmi_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
-                                    out.data_ptr(), out.stride(0), M, N, K, _EPI[epilogue],
+                                    out.data_ptr(), out.stride(0), M, N, K, epi,
                                     _ptr(gate), _ptr(residual), ldr, _stream())
     _l.check(rc, "gemm_bf16")
     return out
@@ -72,10 +135,12 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
     n = len(a_list)
     K = w_list[0].shape[1]
     epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
+    act = a_list[0].dtype
     for a, w, o in zip(a_list, w_list, out_list):
-        _req(a, torch.bfloat16, "gemm_grouped.a")
+        _req_act(a, "gemm_grouped.a")
+        _req(a, act, "gemm_grouped.a")
         _req(w, torch.bfloat16, "gemm_grouped.w")
-        _req(o, torch.bfloat16, "gemm_grouped.out")
+        _req(o, act, "gemm_grouped.out")
         assert a.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and o.stride(1) == 1
         assert w.shape[1] == K and a.shape[1] == K and o.shape == (a.shape[0], w.shape[0])
     VP = C.c_void_p * n
@@ -88,14 +153,24 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
     for e, g, r, o, w in zip(epis, gate_list, residual_list, out_list, w_list):
         if e == "gate_res":
             _req(g, torch.float32, "gemm_grouped.gate")
-            _req(r, torch.bfloat16, "gemm_grouped.residual")
+            _req(r, act, "gemm_grouped.residual")
             assert g.is_contiguous() and g.numel() == w.shape[0] and r.shape == o.shape and r.stride(1) == 1
+    flag = 0
+    if act == torch.float32:     # f32-storage verification mode (see gemm)
+        done: dict = {}
+        sp = []
+        for a in a_list:         # problems that read the same activations share one split
+            k_ = (a.data_ptr(), tuple(a.shape), a.stride(0))
+            if k_ not in done:
+                done[k_] = split3(a)
+            sp.append(done[k_])
+        a_list, w_list, K, flag = sp, [_w3(w) for w in w_list], 3 * K, _l.EPI_F32_IO
     rc = _l.load().apexmi_gemm_bf16_grouped(
         n, VP(*[a.data_ptr() for a in a_list]), I64(*[a.stride(0) for a in a_list]),
         VP(*[w.data_ptr() for w in w_list]), I64(*[w.stride(0) for w in w_list]),
         VP(*[_ptr(b) for b in bias_list]), VP(*[o.data_ptr() for o in out_list]),
         I64(*[o.stride(0) for o in out_list]), INT(*[a.shape[0] for a in a_list]),
-        INT(*[w.shape[0] for w in w_list]), K, INT(*[_EPI[e] for e in epis]),
+        INT(*[w.shape[0] for w in w_list]), K, INT(*[_EPI[e] | flag for e in epis]),
         VP(*[_ptr(g) for g in gate_list]), VP(*[_ptr(r) for r in residual_list]),
         I64(*[(r.stride(0) if r is not None else 0) for r in residual_list]), _stream())
     _l.check(rc, "gemm_bf16_grouped")
@@ -143,13 +218,13 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = LayerNorm(x) [*gamma + beta] * (1 + scale) + shift, or RMSNorm(x) * gamma.
     Rows [0, split) use (scale2, shift2) instead (text rows of a joint buffer)."""
-    _req(x, torch.bfloat16, "ln_modulate.x")
+    _req_act(x, "ln_modulate.x")
     assert x.dim() == 2 and x.stride(1) == 1
     M, Cc = x.shape
     if out is None:
-        out = torch.empty((M, Cc), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((M, Cc), dtype=x.dtype, device=x.device)
     else:
-        _req(out, torch.bfloat16, "ln_modulate.out")
+        _req(out, x.dtype, "ln_modulate.out")
         assert out.shape == (M, Cc) and out.stride(1) == 1
     for t, nm in ((scale, "scale"), (shift, "shift"), (scale2, "scale2"), (shift2, "shift2")):
         if t is not None:
@@ -159,9 +234,9 @@ def ln_modulate(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
         if t is not None:
             _req(t, torch.bfloat16, "ln_modulate." + nm)
             assert t.is_contiguous() and t.numel() == Cc
-    rc = _l.load().apexmi_ln_modulate2(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, Cc,
-                                       _ptr(scale), _ptr(shift), _ptr(gamma), _ptr(beta), float(eps),
-                                       1 if rms else 0, int(split), _ptr(scale2), _ptr(shift2), _stream())
+    rc = _fn("apexmi_ln_modulate2", x)(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, Cc,
+                                        _ptr(scale), _ptr(shift), _ptr(gamma), _ptr(beta), float(eps),
+                                        1 if rms else 0, int(split), _ptr(scale2), _ptr(shift2), _stream())
     _l.check(rc, "ln_modulate")
     return out
 
@@ -173,7 +248,10 @@ def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: 
                 split: int = 0, eps: float = 1e-6, rope: Optional[torch.Tensor] = None,
                 rope_mode: int = _l.ROPE_NONE, row0: int = 0) -> None:
     """q,k,v: [S, H*128] row views sharing one row stride; qo,ko: [H, S_out, 128]; vt: [H,128,Skp]."""
-    _req(q, torch.bfloat16, "qkv_prepare.q")
+    _req_act(q, "qkv_prepare.q")
+    for t_ in (k, v, qo, ko, vt):
+        if t_ is not None:
+            _req(t_, q.dtype, "qkv_prepare operand")
     S = q.shape[0]
     D = q.shape[1] // H
     ld = q.stride(0)
@@ -188,10 +266,10 @@ def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: 
     if rope is not None:
         _req(rope, torch.float32, "qkv_prepare.rope")
         assert rope.is_contiguous()
-    rc = _l.load().apexmi_qkv_prepare(q.data_ptr(), _ptr(k), _ptr(v), ld, S, H, D, split,
-                                      _ptr(wq), _ptr(wk), _ptr(wq2), _ptr(wk2), float(eps),
-                                      _ptr(rope), rope_mode, qo.data_ptr(), _ptr(ko), _ptr(vt),
-                                      S_out, Skp, row0, _stream())
+    rc = _fn("apexmi_qkv_prepare", q)(q.data_ptr(), _ptr(k), _ptr(v), ld, S, H, D, split,
+                                       _ptr(wq), _ptr(wk), _ptr(wq2), _ptr(wk2), float(eps),
+                                       _ptr(rope), rope_mode, qo.data_ptr(), _ptr(ko), _ptr(vt),
+                                       S_out, Skp, row0, _stream())
     _l.check(rc, "qkv_prepare")
 
 
@@ -208,13 +286,21 @@ def v_transpose(v: torch.Tensor, vt: torch.Tensor) -> None:
 def attention_prepared(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor,
                        Sk: int, scale: Optional[float] = None) -> torch.Tensor:
     """q [B,H,Sq,128], k [B,H,Sk,128], vt [B,H,128,Skp] packed; out [B,Sq,H,128] (strided ok)."""
-    _req(q, torch.bfloat16, "attention.q")
+    _req_act(q, "attention.q")
     B, H, Sq, D = q.shape
     assert D == 128 and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
     assert out.shape == (B, Sq, H, D) and out.stride(3) == 1
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _l.load()
+    if q.dtype == torch.float32:     # f32-storage verification mode: f32 arithmetic, no bf16 probabilities
+        for t_ in (k, vt, out):
+            _req(t_, torch.float32, "attention operand")
+        rc = lib.apexmi_attn_fwd_prepared_f32(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Sq, Sk,
+                                              vt.shape[3], _l.i64x3((out.stride(0), out.stride(1), out.stride(2))),
+                                              float(scale), _stream())
+        _l.check(rc, "attn_fwd_prepared_f32")
+        return out
     need = lib.apexmi_attn_prepared_workspace_bytes(B, H, Sq, Sk)     # scratch of the tail split, usually 0
     ws = None
     if need:
@@ -387,11 +473,11 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, pos: Optional[torch.Tens
 
 def frames_to_u8(video: torch.Tensor) -> torch.Tensor:
     """bf16 video [C, T, H, W] (any strides) in [-1, 1] -> uint8 frames [T, H, W, C]."""
-    _req(video, torch.bfloat16, "frames_to_u8.video")
+    _req_act(video, "frames_to_u8.video")
     assert video.dim() == 4
     Cc, T, H, W = video.shape
     out = torch.empty((T, H, W, Cc), dtype=torch.uint8, device=video.device)
-    rc = _l.load().apexmi_frames_to_u8(video.data_ptr(), video.stride(0), video.stride(1), video.stride(2), video.stride(3),
+    rc = _fn("apexmi_frames_to_u8", video)(video.data_ptr(), video.stride(0), video.stride(1), video.stride(2), video.stride(3),
                                        Cc, T, H, W, out.data_ptr(), _stream())
     _l.check(rc, "frames_to_u8")
     return out
@@ -583,18 +669,73 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_w3c_cache: dict = {}
+
+
+def _conv_w3(w_packed: torch.Tensor, ksize, cin: int) -> torch.Tensor:
+    """Packed conv weight [Cout4, Kpad] (k = tap * cin + ci) -> the packing of the same weight with every tap's channel run
+    repeated three times (k = tap * 3 cin + j cin + ci): the partner of the [hi | mid | lo] channel split."""
+    key = (w_packed.data_ptr(), w_packed._version, tuple(w_packed.shape), tuple(ksize), cin)
+    hit = _w3c_cache.get(key)      # (source, repeated): the source reference pins the address in the key
+    t = None if hit is None else hit[1]
+    if t is None:
+        kT, kH, kW = (int(v) for v in ksize)
+        taps = kT * kH * kW
+        cout4 = w_packed.shape[0]
+        k3 = taps * 3 * cin
+        kpad = (k3 + 63) // 64 * 64
+        if kT > 1:
+            spatial = kH * kW * 3 * cin
+            kpad = (max(kpad, (kT - 1) * spatial + (spatial + 63) // 64 * 64) + 63) // 64 * 64
+        t = torch.zeros(cout4, kpad, dtype=w_packed.dtype, device=w_packed.device)
+        t[:, :k3] = w_packed[:, :taps * cin].reshape(cout4, taps, 1, cin).expand(cout4, taps, 3, cin).reshape(cout4, k3)
+        if len(_w3c_cache) > 512:
+            _w3c_cache.clear()
+        _w3c_cache[key] = (w_packed, t)
+    return t
+
+
+def _conv_f32(x, w_packed, bias, ksize, out_shape, residual=None, out=None, replicate=False, independent_frames=False,
+              upsample2x=False, stride=(1, 1), pad=(-1, -1), out_hw=(0, 0), tstride=(1, 0, 0), slope=None):
+    """The f32-storage verification form of every conv3d_cl* wrapper below: float activations in, float out / residual."""
+    _req(x, torch.float32, "conv3d_cl.x")
+    T, H, W, cin = x.shape
+    x3 = split3(x.view(T * H * W, cin)).view(T, H, W, 3 * cin)
+    w3 = _conv_w3(w_packed, ksize, cin)
+    cout = w_packed.shape[0]
+    if out is None:
+        out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == tuple(out_shape) and out.dtype == torch.float32
+    if residual is not None:
+        _req(residual, torch.float32, "conv3d_cl.residual")
+        assert residual.shape == out.shape and residual.is_contiguous()
+    flags = (1 if replicate else 0) | (2 if independent_frames else 0) | (4 if upsample2x else 0)
+    rc = _l.load().apexmi_conv3d_cl_f32(x3.data_ptr(), w3.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                        _zeros16(x.device).data_ptr(), T, H, W, 3 * cin, cout, w3.shape[1], int(ksize[0]),
+                                        int(ksize[1]), int(ksize[2]), flags, int(stride[0]), int(stride[1]), int(pad[0]),
+                                        int(pad[1]), int(out_hw[0]), int(out_hw[1]), int(tstride[0]), int(tstride[1]),
+                                        int(tstride[2]), 0 if slope is None else 1, 0.0 if slope is None else float(slope),
+                                        _stream())
+    _l.check(rc, "conv3d_cl_f32")
+    return out
+
+
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               replicate: bool = False, independent_frames: bool = False, upsample2x: bool = False) -> torch.Tensor:
     """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" padding in space: zeros, or (replicate)
     clamped coordinates as HunyuanVideo15CausalConv3d pads.  upsample2x: the convolution reads x through a nearest 2x
     spatial upsample (output [T,2H,2W,Cout4]) without materialising it."""
-    _req(x, torch.bfloat16, "conv3d_cl.x")
+    _req_act(x, "conv3d_cl.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
     Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
+    if x.dtype == torch.float32:
+        assert not (replicate and independent_frames) and not (replicate and upsample2x)
+        return _conv_f32(x, w_packed, bias, ksize, (T, Ho, Wo, cout), residual=residual, out=out, replicate=replicate,
+                         independent_frames=independent_frames, upsample2x=upsample2x)
     if out is None:
         out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
     assert out.is_contiguous() and out.shape == (T, Ho, Wo, cout)
@@ -623,12 +764,15 @@ def conv3d_cl_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.
                   independent_frames: bool = False) -> torch.Tensor:
     """act(conv(x) + bias (+ residual)) with act = leaky ReLU(slope) (slope None: no activation), zero padding, causal in
     time; upsample2x / independent_frames as conv3d_cl.  The TAEHV blocks (reference vae/tae/model.py:20-45)."""
-    _req(x, torch.bfloat16, "conv3d_cl_act.x")
+    _req_act(x, "conv3d_cl_act.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl_act.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
     Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
+    if x.dtype == torch.float32:
+        return _conv_f32(x, w_packed, bias, ksize, (T, Ho, Wo, cout), residual=residual, independent_frames=independent_frames,
+                         upsample2x=upsample2x, slope=slope)
     out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
     if bias is not None:
         assert bias.numel() == cout and bias.is_contiguous()
@@ -673,10 +817,11 @@ def conv3d_cl_norm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch
                    upsample2x: bool = False, independent_frames: bool = False):
     """conv3d_cl with the RMS norm (+ SiLU) of its output fused into the epilogue: returns (y or None, norm(y)).
     Shapes the fused tiles do not cover (`conv3d_cl_norm_fusable`) run as conv3d_cl + rmsnorm_cl — same values."""
-    _req(x, torch.bfloat16, "conv3d_cl_norm.x")
+    _req_act(x, "conv3d_cl_norm.x")
     _req(gamma, torch.bfloat16, "conv3d_cl_norm.gamma")
     cout, kpad = w_packed.shape
-    if gamma.numel() != cout or not conv3d_cl_norm_fusable(x, cout, upsample2x):
+    # (float activations — the verification mode — always take the two-launch form: same values, no fused tile)
+    if x.dtype == torch.float32 or gamma.numel() != cout or not conv3d_cl_norm_fusable(x, cout, upsample2x):
         y = conv3d_cl(x, w_packed, bias, ksize, residual=residual, upsample2x=upsample2x, independent_frames=independent_frames)
         g = gamma if gamma.numel() == cout else torch.cat([gamma, gamma.new_zeros(cout - gamma.numel())])
         return (y if want_raw else None), rmsnorm_cl(y, g, silu=silu)
@@ -699,11 +844,13 @@ def conv3d_cl_tstrided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[t
                        t_first: int, out_frames: int) -> torch.Tensor:
     """Causal conv3d evaluated only at input frames t_first, t_first + stride_t, ...: x [T,H,W,Cin] -> [out_frames,H,W,Cout4]
     (WanResample "downsample3d" time_conv, reference vae/wan/model.py:340-365)."""
-    _req(x, torch.bfloat16, "conv3d_cl_tstrided.x")
+    _req_act(x, "conv3d_cl_tstrided.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl_tstrided.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
+    if x.dtype == torch.float32:
+        return _conv_f32(x, w_packed, bias, ksize, (out_frames, H, W, cout), tstride=(stride_t, t_first, out_frames))
     out = torch.empty((out_frames, H, W, cout), dtype=torch.bfloat16, device=x.device)
     if bias is not None:
         assert bias.numel() == cout and bias.is_contiguous()
@@ -717,12 +864,14 @@ def conv3d_cl_tstrided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[t
 def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """ZeroPad2d((0, 1, 0, 1)) + Conv2d(3x3, stride 2) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4] with
     Ho = (H - 2) // 2 + 1 (= H / 2 for even H); w_packed from pack_conv_weight of the [Cout, Cin, 3, 3] weight."""
-    _req(x, torch.bfloat16, "conv2d_cl_down2.x")
+    _req_act(x, "conv2d_cl_down2.x")
     _req(w_packed, torch.bfloat16, "conv2d_cl_down2.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
     Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    if x.dtype == torch.float32:
+        return _conv_f32(x, w_packed, bias, (1, 3, 3), (T, Ho, Wo, cout), stride=(2, 2), pad=(0, 0), out_hw=(Ho, Wo))
     out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
     if bias is not None:
         assert bias.numel() == cout and bias.is_contiguous()
@@ -736,12 +885,14 @@ def conv2d_cl_down2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torc
 def conv2d_cl_strided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 2, pad: int = 1) -> torch.Tensor:
     """nn.Conv2d(3x3, stride, padding=pad) per frame: x [T, H, W, Cin] -> [T, Ho, Wo, Cout4], Ho = (H + 2 pad - 3) // stride + 1
     (the TAEHV encoder's downsampling convolutions, reference vae/tae/model.py:218, :223, :228)."""
-    _req(x, torch.bfloat16, "conv2d_cl_strided.x")
+    _req_act(x, "conv2d_cl_strided.x")
     _req(w_packed, torch.bfloat16, "conv2d_cl_strided.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if x.dtype == torch.float32:
+        return _conv_f32(x, w_packed, bias, (1, 3, 3), (T, Ho, Wo, cout), stride=(stride, stride), pad=(pad, pad), out_hw=(Ho, Wo))
     out = torch.empty((T, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
     if bias is not None:
         assert bias.numel() == cout and bias.is_contiguous()
@@ -754,12 +905,12 @@ def conv2d_cl_strided(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
 
 def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, torch.bfloat16, "rmsnorm_cl.x")
+    _req_act(x, "rmsnorm_cl.x")
     assert x.is_contiguous() and gamma.is_contiguous() and gamma.numel() == x.shape[-1]
     if out is None:
         out = torch.empty_like(x)
     P = x.numel() // x.shape[-1]
-    _l.check(_l.load().apexmi_rmsnorm_cl(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), P, x.shape[-1],
+    _l.check(_fn("apexmi_rmsnorm_cl", x)(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), P, x.shape[-1],
                                          1 if silu else 0, _stream()), "rmsnorm_cl")
     return out
 
@@ -775,11 +926,11 @@ def upsample2x_cl(x: torch.Tensor) -> torch.Tensor:
 
 def time_interleave_cl(x: torch.Tensor) -> torch.Tensor:
     """[T,H,W,2C] -> [2T,H,W,C]."""
-    _req(x, torch.bfloat16, "time_interleave_cl.x")
+    _req_act(x, "time_interleave_cl.x")
     assert x.dim() == 4 and x.is_contiguous() and x.shape[3] % 16 == 0
     T, H, W, C2 = x.shape
-    out = torch.empty((2 * T, H, W, C2 // 2), dtype=torch.bfloat16, device=x.device)
-    _l.check(_l.load().apexmi_time_interleave_cl(x.data_ptr(), out.data_ptr(), T, H * W, C2 // 2, _stream()),
+    out = torch.empty((2 * T, H, W, C2 // 2), dtype=x.dtype, device=x.device)
+    _l.check(_fn("apexmi_time_interleave_cl", x)(x.data_ptr(), out.data_ptr(), T, H * W, C2 // 2, _stream()),
              "time_interleave_cl")
     return out
 
@@ -787,20 +938,20 @@ def time_interleave_cl(x: torch.Tensor) -> torch.Tensor:
 def crossfade_(a: torch.Tensor, b: torch.Tensor, dim: int) -> torch.Tensor:
     """In place on b: b[.., e, ..] = a[.., e, ..] (1 - e/E) + b[.., e, ..] e/E along `dim` (E = size of dim).
     a, b: same-shape bf16 views of [T, H, W, C] tensors (blend_v: dim=1, blend_h: dim=2)."""
-    _req(a, torch.bfloat16, "crossfade.a")
-    _req(b, torch.bfloat16, "crossfade.b")
+    _req_act(a, "crossfade.a")
+    _req(b, a.dtype, "crossfade.b")
     assert a.shape == b.shape and a.dim() == 4 and a.stride(3) == 1 and b.stride(3) == 1
     T, H, W, Cc = b.shape
     E = b.shape[dim]
-    lib = _l.load()
+    fade = _fn("apexmi_crossfade", a)
     if dim == 1:    # rows: outer = T, e = H rows, inner = W*C (needs contiguous rows in both)
         assert a.stride(2) == Cc and b.stride(2) == Cc
-        rc = lib.apexmi_crossfade(a.data_ptr(), b.data_ptr(), T, E, W * Cc, a.stride(0), a.stride(1),
+        rc = fade(a.data_ptr(), b.data_ptr(), T, E, W * Cc, a.stride(0), a.stride(1),
                                   b.stride(0), b.stride(1), _stream())
         _l.check(rc, "crossfade")
     else:           # columns: one call per frame, outer = H, e = W columns, inner = C
         for t in range(T):
-            rc = lib.apexmi_crossfade(a[t].data_ptr(), b[t].data_ptr(), H, E, Cc, a.stride(1), a.stride(2),
+            rc = fade(a[t].data_ptr(), b[t].data_ptr(), H, E, Cc, a.stride(1), a.stride(2),
                                       b.stride(1), b.stride(2), _stream())
             _l.check(rc, "crossfade")
     return b
@@ -812,7 +963,7 @@ _gn_ws: dict = {}
 def groupnorm_cl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
                  silu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GroupNorm over a channels-last image [..., C] (all leading dims are positions)."""
-    _req(x, torch.bfloat16, "groupnorm_cl.x")
+    _req_act(x, "groupnorm_cl.x")
     _req(gamma, torch.bfloat16, "groupnorm_cl.gamma")
     assert x.is_contiguous() and gamma.is_contiguous() and beta.is_contiguous()
     Cc = x.shape[-1]
@@ -826,7 +977,7 @@ def groupnorm_cl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         _gn_ws[key] = ws
-    rc = lib.apexmi_groupnorm_cl(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), P, Cc, groups,
+    rc = _fn("apexmi_groupnorm_cl", x)(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), P, Cc, groups,
                                  float(eps), 1 if silu else 0, ws.data_ptr(), need, _stream())
     _l.check(rc, "groupnorm_cl")
     return out

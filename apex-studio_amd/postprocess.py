@@ -12,8 +12,9 @@ from . import ops
 
 
 def video_to_uint8(video: torch.Tensor) -> torch.Tensor:
-    """video [B, C, T, H, W] bf16 on the GPU, values in [-1, 1] -> uint8 [B, T, H, W, C] on the GPU."""
-    if video.device.type != "cuda" or video.dtype != torch.bfloat16:
+    """video [B, C, T, H, W] bf16 on the GPU (float32 in the f32-storage verification mode), values in [-1, 1] -> uint8
+    [B, T, H, W, C] on the GPU."""
+    if video.device.type != "cuda" or video.dtype not in (torch.bfloat16, torch.float32):
         raise _l.ApexMIError("video_to_uint8 needs the bf16 decode output on a ROCm device (no CPU fallback)")
     if video.dim() != 5:
         raise ValueError(f"expected [B, C, T, H, W], got {tuple(video.shape)}")

@@ -97,6 +97,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         self.proj_out = _Linear(dim, patch_size * patch_size * self.out_channels, **kw)
         self._packed = False
         self._ws: Dict[Any, Any] = {}
+        self.storage_dtype = torch.bfloat16
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
 
@@ -108,6 +109,17 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         return cls(**cfg)
 
     _from_config = from_config
+
+    # ---- activation storage ------------------------------------------------------------------------------------------
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same
+        kernel sequence with every activation buffer float and the library's `_f32` entry points, which is what
+        north_star's "within 1e-3 of the CPU fp32 reference" is tested with.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        self._ws = {}
+        return self
 
     @property
     def dtype(self):
@@ -190,7 +202,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         dev, dim, H = self.device, self.inner_dim, self.config.num_attention_heads
         S = s_txt + s_img
         skp = (S + 63) // 64 * 64
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=self.storage_dtype)     # activation buffers
         f32 = dict(device=dev, dtype=torch.float32)
         ws = SimpleNamespace(
             X=torch.empty(S, dim, **bf), XN=torch.empty(S, dim, **bf), QKV=torch.empty(S, 3 * dim, **bf),
@@ -235,7 +247,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.gemm(ws.TXTN, self.txt_in.weight, self.txt_in.bias, out=Xt)
 
         te = self.time_text_embed.timestep_embedder
-        t = timestep.to(self.dtype).float().reshape(1)      # `timestep.to(hidden_states.dtype)`, model.py:905
+        # `timestep.to(hidden_states.dtype)`, model.py:905: bf16 in production, f32 in the verification mode
+        t = timestep.to(self.storage_dtype).float().reshape(1)
         tp = ops.timestep_embedding(t, 256, scale=1000.0)
         h = ops.gemv(te.linear_1.weight, tp, te.linear_1.bias, post="silu")
         ops.gemv(te.linear_2.weight, h, te.linear_2.bias, out=ws.TEMB)
@@ -301,8 +314,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             raise NotImplementedError("qwenimage.mi355: controlnet / additional_t_cond are out of scope")
         self.pack()
         B = hidden_states.shape[0]
-        hs = hidden_states.to(torch.bfloat16)
-        enc = encoder_hidden_states.to(torch.bfloat16)
+        hs = hidden_states.to(self.storage_dtype)
+        enc = encoder_hidden_states.to(self.storage_dtype)
         outs = []
         for b in range(B):
             shapes = img_shapes[b] if isinstance(img_shapes[0], (list, tuple)) and \

@@ -102,6 +102,7 @@ class AutoencoderKL(nn.Module):
         kw = dict(device=device, dtype=dtype)
         self.decoder = _Decoder2D(latent_channels, out_channels, block_out_channels, layers_per_block, **kw)
         self._packed: Dict[int, tuple] = {}
+        self.storage_dtype = torch.bfloat16
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -111,6 +112,16 @@ class AutoencoderKL(nn.Module):
         return cls(**cfg)
 
     _from_config = from_config
+
+    # ---- activation storage ------------------------------------------------------------------------------------------
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same
+        kernel sequence with every activation buffer float and the library's `_f32` entry points, which is what
+        north_star's "within 1e-3 of the CPU fp32 reference" is tested with.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        return self
 
     @property
     def dtype(self):
@@ -181,7 +192,7 @@ class AutoencoderKL(nn.Module):
         if z.device.type != "cuda" or self.dtype != torch.bfloat16:
             raise _l.ApexMIError("flux VAE needs bf16 weights and latents on a ROCm device (no CPU fallback)")
         d = self.decoder
-        x = z.to(torch.bfloat16).permute(1, 2, 0).unsqueeze(0).contiguous()      # [1, H, W, C]
+        x = z.to(self.storage_dtype).permute(1, 2, 0).unsqueeze(0).contiguous()      # [1, H, W, C]
         x = self._conv(d.conv_in, x)
         x = self._res(d.mid_block.resnets[0], x)
         x = self._attn(d.mid_block.attentions[0], x)

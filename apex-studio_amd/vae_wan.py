@@ -197,6 +197,7 @@ class AutoencoderKLWan(nn.Module):
         self._packed: Dict[int, torch.Tensor] = {}
         self._indep = False      # inside a batched pass over independent single-frame tiles
         self.batch_single_frame_tiles = True
+        self.storage_dtype = torch.bfloat16
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -206,6 +207,16 @@ class AutoencoderKLWan(nn.Module):
         return cls(**cfg)
 
     _from_config = from_config
+
+    # ---- activation storage ------------------------------------------------------------------------------------------
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same
+        kernel sequence with every activation buffer float and the library's `_f32` entry points, which is what
+        north_star's "within 1e-3 of the CPU fp32 reference" is tested with.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        return self
 
     @property
     def dtype(self):
@@ -385,7 +396,7 @@ class AutoencoderKLWan(nn.Module):
             raise _l.ApexMIError("wan_mi355 VAE needs bf16 weights and latents on a ROCm device (no CPU fallback)")
         Cz, T, H, W = z.shape
         ratio = self.spatial_compression_ratio
-        zc = z.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()           # [T, H, W, C]
+        zc = z.to(self.storage_dtype).permute(1, 2, 3, 0).contiguous()           # [T, H, W, C]
         lat_min_h, lat_min_w = self.tile_sample_min_height // ratio, self.tile_sample_min_width // ratio
         if not (self.use_tiling and (W > lat_min_w or H > lat_min_h)):
             out = self._decode_tile(zc)
@@ -450,8 +461,8 @@ class AutoencoderKLWan(nn.Module):
         ratio = self.spatial_compression_ratio
         if H % ratio or W % ratio:
             raise ValueError(f"encode expects height and width divisible by {ratio}, got {H}x{W}")
-        xc = torch.zeros((T, H, W, 8), dtype=torch.bfloat16, device=x.device)
-        xc[..., :Cin] = x.to(torch.bfloat16).permute(1, 2, 3, 0)
+        xc = torch.zeros((T, H, W, 8), dtype=self.storage_dtype, device=x.device)
+        xc[..., :Cin] = x.to(self.storage_dtype).permute(1, 2, 3, 0)
         mh, mw = self.tile_sample_min_height, self.tile_sample_min_width
         if not (self.use_tiling and (W > mw or H > mh)):
             out = self._encode_tile(xc)

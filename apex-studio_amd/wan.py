@@ -113,6 +113,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         self.scale_shift_table = nn.Parameter(torch.empty(1, 2, dim, **kw), requires_grad=False)
         self._packed = False
         self._ws: Dict[Any, Any] = {}
+        self.storage_dtype = torch.bfloat16
         self._rope: Dict[Any, torch.Tensor] = {}
 
     # ---- reference-compatible plumbing -------------------------------------------------------
@@ -124,6 +125,17 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         return cls(**cfg)
 
     _from_config = from_config
+
+    # ---- activation storage ------------------------------------------------------------------------------------------
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same
+        kernel sequence with every activation buffer float and the library's `_f32` entry points, which is what
+        north_star's "within 1e-3 of the CPU fp32 reference" is tested with.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        self._ws = {}
+        return self
 
     @property
     def dtype(self):
@@ -220,7 +232,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         ffn = self.config.ffn_dim
         skp = (S + 63) // 64 * 64
         tkp = (s_txt + 63) // 64 * 64
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=self.storage_dtype)     # activation buffers
         f32 = dict(device=dev, dtype=torch.float32)
         ws = SimpleNamespace(
             X=torch.empty(S, dim, **bf), XN=torch.empty(S, dim, **bf), QKV=torch.empty(S, 3 * dim, **bf),
@@ -262,7 +274,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         eps = cfg.eps
 
         # patchify (layout only) + patch_embedding as a K = C*pt*ph*pw GEMM
-        tok = hidden_states.to(torch.bfloat16).reshape(C, grid[0], pt, grid[1], ph, grid[2], pw) \
+        tok = hidden_states.to(self.storage_dtype).reshape(C, grid[0], pt, grid[1], ph, grid[2], pw) \
             .permute(1, 3, 5, 0, 2, 4, 6).reshape(S, C * pt * ph * pw).contiguous()
         pe = self.patch_embedding
         ops.gemm(tok, pe.weight.reshape(dim, -1), pe.bias, out=X)
@@ -333,7 +345,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         if timestep.ndim != 1:
             raise NotImplementedError("wan.mi355: per-token timesteps are not supported")
         self.pack()
-        enc = encoder_hidden_states.to(torch.bfloat16)
+        enc = encoder_hidden_states.to(self.storage_dtype)
         outs = [self._forward_one(hidden_states[b], timestep[b:b + 1], enc[b].contiguous())
                 for b in range(hidden_states.shape[0])]
         out = torch.stack(outs, dim=0).to(hidden_states.dtype)

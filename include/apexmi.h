@@ -39,6 +39,12 @@ typedef void* apexmi_stream_t; /* a hipStream_t; NULL = the null stream */
 #define APEXMI_EPI_BIAS_SILU 5     /* C = silu(A W^T + b): the "linear-silu" FeedForward of its token refiner        */
 #define APEXMI_EPI_BIAS_F32 3      /* C = A W^T + b stored as float (C is float*, ldc in floats): attention scores */
 
+/* OR-ed into any epilogue above: C and R are float (ldc / ldr in floats).  The f32-STORAGE VERIFICATION MODE (DESIGN.md
+ * §1.2): the same kernels and epilogue formulas with no bf16 rounding at the store; the activation operand A is then the
+ * exact three-way bf16 split written by apexmi_split_bf16x3 (K-concatenated, W repeated three times along K), so the
+ * MFMA products are exact and the whole layer is f32-accurate.  Not a production path: 3x the MFMA work. */
+#define APEXMI_EPI_F32_IO 0x100
+
 /* GEMV flags */
 #define APEXMI_GEMV_PRE_SILU 1   /* x <- silu(x) before the dot product           */
 #define APEXMI_GEMV_POST_SILU 2  /* y <- silu(y)                                  */
@@ -134,6 +140,11 @@ int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda
                              void* const* C, const int64_t* ldc, const int* M, const int* N, int K,
                              const int* epilogue, const float* const* gate, const void* const* R,
                              const int64_t* ldr, apexmi_stream_t stream);
+
+/* out[m][j K + k] (bf16, j = 0..2) = the j-th part of the exact split x = hi + mid + lo of the float x[m][k]:
+ * hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (representable).  ldx in floats, ldo >= 3 K in bf16 elements,
+ * K % 8 == 0.  Operand preparation of the f32-storage verification mode (APEXMI_EPI_F32_IO; apexmi_conv3d_cl_f32). */
+int apexmi_split_bf16x3(const float* x, int64_t ldx, int64_t M, int K, void* out, int64_t ldo, apexmi_stream_t stream);
 
 /* Batched C[z] = A[z] W[z]^T over blockIdx.y (z < batch <= 65535): per-head GEMMs of one attention layer in one launch.
  * Strides in elements; epilogue APEXMI_EPI_BIAS (bf16 C, no bias) or APEXMI_EPI_BIAS_F32 (float C).  Same kernels and
@@ -423,6 +434,50 @@ int apexmi_dequant_fp8_scaled(const void* w, int format, const void* scale, int6
  * cast back).  sample/out: bf16 or f32 per sample_dtype; v bf16. */
 int apexmi_euler_step(const void* sample, const void* model_out, void* out, int64_t n,
                       float dt, int sample_dtype, apexmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f32-STORAGE VERIFICATION MODE (first route).  BASELINE.json's north_star asks for
+ * decoded frames within 1e-3 of the reference's CPU fp32 path; a chain of kernels that ROUNDS every activation to bf16
+ * cannot be held to that (§1.1), so the library also runs the SAME kernels with float activation storage:
+ *   - every `_f32` entry point below is the template instantiation T = float of the kernel behind the entry point of the
+ *     same name without the suffix (identical arguments; activation pointers are float*, leading dimensions in floats;
+ *     weights, norm gains and biases stay bf16, modulation vectors stay f32);
+ *   - the MFMA kernels (apexmi_gemm_bf16* with APEXMI_EPI_F32_IO, apexmi_conv3d_cl_f32) take the activation operand as
+ *     its exact three-way bf16 split (apexmi_split_bf16x3), so their products are exact and they accumulate in f32;
+ *   - attention runs in f32 arithmetic (apexmi_attn_fwd with APEXMI_F32; apexmi_attn_fwd_prepared_f32).
+ * A model built with activation storage float32 (`storage_dtype=torch.float32` on the Python classes) calls only these;
+ * tests/test_gpu_f32_storage.py holds free-running forwards, sampler chains and decoded frames to <= 1e-3 of the fp32
+ * oracle with it.  Verification only: 3x the MFMA work, 2x the bytes.
+ * ------------------------------------------------------------------------------------------- */
+int apexmi_ln_modulate2_f32(const void* x, int64_t ldx, void* out, int64_t ldo, int M, int C, const float* scale,
+                            const float* shift, const void* gamma, const void* beta, float eps, int rms, int split,
+                            const float* scale2, const float* shift2, apexmi_stream_t stream);
+int apexmi_qkv_prepare_f32(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H, int D, int split,
+                           const void* wq, const void* wk, const void* wq2, const void* wk2, float eps, const float* rope,
+                           int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp, int row0,
+                           apexmi_stream_t stream);
+/* q [B,H,Sq,128], k [B,H,Sk,128], vt [B,H,128,Skp] float (what apexmi_qkv_prepare_f32 writes); out float with element
+ * strides o_strides (b, s, h). */
+int apexmi_attn_fwd_prepared_f32(const void* q, const void* k, const void* vt, void* out, int B, int H, int Sq, int Sk,
+                                 int Skp, const int64_t o_strides[3], float softmax_scale, apexmi_stream_t stream);
+/* Every variant of the VAE convolution with float out / residual.  in = apexmi_split_bf16x3 of the float activations
+ * ([T, H, W, Cin3], Cin3 = 3 x the layer's input channels); w = the packed weight with each tap's channel run repeated
+ * three times ([Cout, Kpad], k = tap * Cin3 + ci); bias bf16.  flags: 1 replicate padding | 2 independent frames |
+ * 4 read through a nearest 2x upsample.  stride_h / stride_w / pad_top / pad_left / Ho / Wo as apexmi_conv3d_cl_strided
+ * (1, 1, -1, -1, 0, 0 = the "same" convolution); stride_t / t_first / To as apexmi_conv3d_cl_tstrided (1, 0, 0 = every
+ * frame); act / slope as apexmi_conv3d_cl_act.  Always the 128x128 implicit-GEMM kernel. */
+int apexmi_conv3d_cl_f32(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                         const void* zeros, int T, int H, int W, int Cin3, int Cout, int Kpad, int kT, int kH, int kW,
+                         int flags, int stride_h, int stride_w, int pad_top, int pad_left, int Ho, int Wo, int stride_t,
+                         int t_first, int To, int act, float slope, apexmi_stream_t stream);
+int apexmi_rmsnorm_cl_f32(const void* x, void* y, const void* gamma, int64_t P, int C, int silu, apexmi_stream_t stream);
+int apexmi_groupnorm_cl_f32(const void* x, void* y, const void* gamma, const void* beta, int64_t P, int C, int G, float eps,
+                            int silu, void* workspace, size_t workspace_bytes, apexmi_stream_t stream);
+int apexmi_time_interleave_cl_f32(const void* x, void* y, int T, int64_t HW, int C, apexmi_stream_t stream);
+int apexmi_crossfade_f32(const void* a, void* b, int64_t outer, int E, int64_t inner, int64_t a_so, int64_t a_se,
+                         int64_t b_so, int64_t b_se, apexmi_stream_t stream);
+int apexmi_frames_to_u8_f32(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
+                            int C, int T, int H, int W, void* out, apexmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Built-in kernel timer (HIP events on the launch stream) used by bench.py's roofline leg.

@@ -23,14 +23,15 @@ OPS = ("gemm", "gemm_grouped", "ln_modulate", "qkv_prepare", "attention_prepared
 
 
 class TracePolicy(OL.Policy):
-    """bf16 storage policy that keeps every rounded tensor, in call order."""
+    """Storage policy that keeps every storage point, in call order: rounded to bf16 (the production policy), or — with
+    emulate_bf16=False — the fp32 values themselves, for the f32-storage verification mode (tests/test_gpu_f32_storage.py)."""
 
-    def __init__(self):
-        super().__init__(True)
+    def __init__(self, emulate_bf16: bool = True):
+        super().__init__(emulate_bf16)
         self.points: List[torch.Tensor] = []
 
     def r(self, x):
-        out = x.to(torch.bfloat16).to(torch.float32)
+        out = x.to(torch.bfloat16).to(torch.float32) if self.emulate_bf16 else x
         self.points.append(out)
         return out
 

@@ -1,0 +1,490 @@
+"""north_star's literal bar: "outputs match the reference CPU PyTorch path ... within 1e-3 rel on the decoded frames".
+
+A chain of kernels that rounds every activation to bf16 cannot meet 1e-3 against an fp32 reference whatever the kernels do
+(a free-running bf16 chain sits at the bf16 noise floor of 2e-3..7e-3; tests/test_gpu_end_to_end.py holds the
+production path to that floor and to the oracle's own bf16 emulation).  SURVEY.md §8c's first route is therefore taken here:
+the library's f32-STORAGE VERIFICATION MODE (include/apexmi.h last section).  `set_storage_dtype(float32)`
+on a model class switches every activation buffer to float and every call to the `_f32` instantiation of the SAME kernel
+(template parameter = storage type), the MFMA kernels being fed the exact three-way bf16 split of the activations, so that
+what is left between the HIP path and the CPU fp32 oracle is f32 summation order.  Everything below is FREE-RUNNING (no
+teacher forcing) and compared with the oracle in pure fp32 (`oracle.layers.FP32`):
+
+  * per op: split exactness, GEMM epilogues, LN / q-k-norm + RoPE / attention, convolution variants, norms  (<= 2e-5)
+  * Flux / Wan / QwenImage transformer forwards, tiny and mid configurations                                 (<= 1e-3)
+  * Flux 2-D VAE decode, Wan 3-D VAE tiled decode and tiled encode                                           (<= 1e-3)
+  * sampler chains -> decoded frames through the engines' `run()`: Flux 4 Euler steps, Wan 4 UniPC steps over two experts
+    with CFG, QwenImage-Edit pixels -> encode -> 2 true-CFG steps -> decode                    (latents, decoded, frames <= 1e-3)
+
+Measured values are printed; they are 1e-6..1e-4, i.e. the bar is met with two orders of margin, and the only difference
+between this mode and production is the storage type, which tests/test_gpu_stage_parity.py prices point by point.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import flux as OF
+from oracle import layers as OL
+from oracle import qwenimage as OQ
+from oracle import wan as OW
+from oracle.postprocess import video_to_uint8_frames
+from tests import stage_parity as SP
+from tests.golden.seeded import seeded, synthetic_state_dict, vae_synthetic_state_dict
+from tests.test_gpu_flux import CONFIGS as FLUX_CONFIGS, _inputs as flux_inputs
+from tests.test_gpu_qwen import CONFIGS as QWEN_CONFIGS
+from tests.test_gpu_wan import CONFIGS as WAN_CONFIGS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+F32 = torch.float32
+TOL = 1e-3          # BASELINE.json north_star
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _bf(x):
+    """a bf16-representable float tensor (weights, gains, biases)"""
+    return x.to(BF).float()
+
+
+# ---- per op -----------------------------------------------------------------------------------------------------------
+def test_split_is_exact():
+    from apex_studio_amd import ops
+    x = seeded((37, 192), 1) * torch.logspace(-6, 6, 192)[None, :]
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, 1.0e-30, 1.0 + 2.0 ** -23, 0.1])
+    parts = ops.split3(x.to(DEV)).float().cpu().double().view(37, 3, 192)
+    assert torch.equal(parts.sum(1), x.double()), "hi + mid + lo must reproduce the float exactly"
+    assert torch.equal(parts[:, 0].float(), x.to(BF).float())
+
+
+@pytest.mark.parametrize("epilogue", ["bias", "gelu", "gate_res", "silu", "gelu_erf", "quick_gelu"])
+@pytest.mark.parametrize("shape", [(300, 264, 192), (1500, 1280, 512)])      # 128-tile and 256-tile launches
+def test_gemm_f32_storage(epilogue, shape):
+    from apex_studio_amd import ops
+    M, N, K = shape
+    a, w, b = seeded((M, K), 2), _bf(seeded((N, K), 3) * 0.1), _bf(seeded((N,), 4))
+    gate, res = seeded((N,), 5), seeded((M, N), 6)
+    y = a.double() @ w.double().t() + b.double()
+    ref = {"bias": lambda: y, "gelu": lambda: F.gelu(y, approximate="tanh"), "silu": lambda: F.silu(y),
+           "gelu_erf": lambda: F.gelu(y), "quick_gelu": lambda: y * torch.sigmoid(1.702 * y),
+           "gate_res": lambda: res.double() + gate.double() * y}[epilogue]()
+    kw = dict(gate=gate.to(DEV), residual=res.to(DEV)) if epilogue == "gate_res" else {}
+    out = ops.gemm(a.to(DEV), w.to(DEV).to(BF), b.to(DEV).to(BF), epilogue=epilogue, **kw)
+    assert out.dtype == F32
+    e = _rel(out, ref)
+    print(f"[f32 gemm {epilogue} {shape}] rel {e:.2e}")
+    assert e < 2e-6, e
+
+
+def test_gemm_grouped_f32_storage_in_place_residual():
+    from apex_studio_amd import ops
+    a1, a2 = seeded((260, 128), 7), seeded((70, 128), 8)
+    w1, w2 = _bf(seeded((136, 128), 9) * 0.1), _bf(seeded((136, 128), 10) * 0.1)
+    g1, g2 = seeded((136,), 11), seeded((136,), 12)
+    x1, x2 = seeded((260, 136), 13), seeded((70, 136), 14)
+    X1, X2 = x1.to(DEV), x2.to(DEV)
+    ops.gemm_grouped([a1.to(DEV), a2.to(DEV)], [w1.to(DEV).to(BF), w2.to(DEV).to(BF)], None, [X1, X2], epilogue="gate_res",
+                     gate_list=[g1.to(DEV), g2.to(DEV)], residual_list=[X1, X2])
+    for X, x, a, w, g in ((X1, x1, a1, w1, g1), (X2, x2, a2, w2, g2)):
+        assert _rel(X, x.double() + g.double() * (a.double() @ w.double().t())) < 2e-6
+
+
+def test_ln_modulate_and_qkv_prepare_f32_storage():
+    from apex_studio_amd import lib as L, ops
+    S, s_txt, H = 75, 11, 4
+    x = seeded((S, H * 128), 15) * 3 + 0.5
+    sc, sh, sc2, sh2 = (seeded((H * 128,), 16 + i) * 0.3 for i in range(4))
+    out = ops.ln_modulate(x.to(DEV), sc.to(DEV), sh.to(DEV), split=s_txt, scale2=sc2.to(DEV), shift2=sh2.to(DEV))
+    xd = x.double()
+    n = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    ref = torch.cat([n[:s_txt] * (1 + sc2.double()) + sh2.double(), n[s_txt:] * (1 + sc.double()) + sh.double()])
+    assert out.dtype == F32 and _rel(out, ref) < 2e-6
+    # q / k per-head RMS norm + interleaved RoPE + layout, V transpose
+    qkv = seeded((S, 3 * H * 128), 21)
+    wq, wk, wq2, wk2 = (_bf(1 + 0.1 * seeded((128,), 22 + i)) for i in range(4))
+    ids = torch.stack([torch.zeros(S), torch.arange(S).float() // 8, torch.arange(S).float() % 8], dim=-1)
+    rope = ops.rope_table_axes(ids.to(DEV), (16, 56, 56))
+    dim = H * 128
+    Q = torch.empty(H, S, 128, device=DEV)
+    K = torch.empty(H, S, 128, device=DEV)
+    VT = torch.zeros(H, 128, 128, device=DEV)
+    g = qkv.to(DEV)
+    ops.qkv_prepare(g[:, :dim], g[:, dim:2 * dim], g[:, 2 * dim:], H, Q, K, VT, wq=wq.to(DEV).to(BF), wk=wk.to(DEV).to(BF),
+                    wq2=wq2.to(DEV).to(BF), wk2=wk2.to(DEV).to(BF), split=s_txt, rope=rope, rope_mode=L.ROPE_INTERLEAVED)
+    cos, sin = OF.flux_pos_embed(ids, (16, 56, 56))
+    for name, got, col, w_img, w_txt in (("q", Q, 0, wq, wq2), ("k", K, dim, wk, wk2)):
+        t = qkv[:, col:col + dim].double().view(S, H, 128)
+        t = t / torch.sqrt((t * t).mean(-1, keepdim=True) + 1e-6)
+        t = torch.cat([t[:s_txt] * w_txt.double(), t[s_txt:] * w_img.double()])
+        r = OL.apply_rotary_emb(t.permute(1, 0, 2).unsqueeze(0).float(), (cos, sin), sequence_dim=2)[0]
+        assert _rel(got, r) < 5e-6, name
+    assert torch.equal(VT[:, :, :S].cpu(), qkv[:, 2 * dim:].view(S, H, 128).permute(1, 2, 0)) and float(VT[:, :, S:].abs().max()) == 0
+
+
+def test_attention_f32_storage():
+    from apex_studio_amd import ops
+    H, Sq, Sk = 3, 70, 150
+    q, k, v = seeded((1, H, Sq, 128), 31), seeded((1, H, Sk, 128), 32), seeded((1, H, Sk, 128), 33)
+    ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 128 ** 0.5, -1) @ v.double()
+    vt = torch.zeros(1, H, 128, 192, device=DEV)
+    vt[..., :Sk] = v.to(DEV).transpose(-1, -2)
+    out = torch.empty(1, Sq, H, 128, device=DEV)
+    ops.attention_prepared(q.to(DEV), k.to(DEV), vt, out, Sk)
+    assert _rel(out.permute(0, 2, 1, 3), ref) < 5e-6
+    # the operator form (VAE mid block: one head of 384 channels)
+    q, k, v = (seeded((2, 1, 90, 384), 34 + i) for i in range(3))
+    ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 384 ** 0.5, -1) @ v.double()
+    assert _rel(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)), ref) < 5e-6
+
+
+def _conv_ref(x, w, b, causal=True, stride=1, pad=None, up=False):
+    """x [T, H, W, C] float64 -> conv3d reference, channels-last result"""
+    xc = x.permute(3, 0, 1, 2).unsqueeze(0)
+    if up:
+        xc = F.interpolate(xc, scale_factor=(1, 2, 2), mode="nearest")
+    kT, kH, kW = w.shape[2:]
+    if pad is None:
+        xc = F.pad(xc, (kW // 2, kW // 2, kH // 2, kH // 2, kT - 1, 0))
+    else:
+        xc = F.pad(xc, pad)
+    y = F.conv3d(xc, w, b, stride=(1, stride, stride))
+    return y[0].permute(1, 2, 3, 0)
+
+
+def test_conv_f32_storage_variants():
+    from apex_studio_amd import ops
+    T, H, W, cin, cout = 3, 10, 12, 16, 24
+    x = seeded((T, H, W, cin), 41)
+    w3, b = _bf(seeded((cout, cin, 3, 3, 3), 42) * 0.1), _bf(seeded((cout,), 43))
+    res = seeded((T, H, W, cout), 44)
+    wp = ops.pack_conv_weight(w3.to(DEV).to(BF))
+    bb = b.to(DEV).to(BF)
+    xd, wd, bd = x.double(), w3.double(), b.double()
+    out = ops.conv3d_cl(x.to(DEV), wp, bb, (3, 3, 3), residual=res.to(DEV))
+    assert out.dtype == F32 and _rel(out, _conv_ref(xd, wd, bd) + res.double()) < 2e-6
+    out = ops.conv3d_cl(x.to(DEV), wp, bb, (3, 3, 3), upsample2x=True)
+    assert _rel(out, _conv_ref(xd, wd, bd, up=True)) < 2e-6
+    # independent frames = every frame a one-frame clip (only the last temporal tap sees data)
+    out = ops.conv3d_cl(x.to(DEV), wp, bb, (3, 3, 3), independent_frames=True)
+    ref = torch.cat([_conv_ref(xd[t:t + 1], wd, bd) for t in range(T)])
+    assert _rel(out, ref) < 2e-6
+    # fused-norm wrapper (two launches in this mode) and the stand-alone norms
+    gam = _bf(1 + 0.1 * seeded((cout,), 45))
+    y, yn = ops.conv3d_cl_norm(x.to(DEV), wp, bb, (3, 3, 3), gam.to(DEV).to(BF), silu=True)
+    yr = _conv_ref(xd, wd, bd)
+    nr = F.silu(yr / yr.norm(dim=-1, keepdim=True).clamp_min(1e-12) * cout ** 0.5 * gam.double())
+    assert _rel(y, yr) < 2e-6 and _rel(yn, nr) < 5e-6
+    # stride-2 down-sampling convolution of the encoders: ZeroPad2d((0, 1, 0, 1)) + Conv2d(3, stride 2)
+    w2 = _bf(seeded((cout, cin, 3, 3), 46) * 0.1)
+    out = ops.conv2d_cl_down2(x.to(DEV), ops.pack_conv_weight(w2.to(DEV).to(BF)), bb)
+    ref = _conv_ref(xd, w2.double().unsqueeze(2), bd, stride=2, pad=(0, 1, 0, 1, 0, 0))
+    assert _rel(out, ref) < 2e-6
+    # temporal stride (encoder time_conv): frames 2, 4 of a 5-frame clip
+    x5 = seeded((5, 6, 8, cin), 47)
+    wt = _bf(seeded((cout, cin, 3, 1, 1), 48) * 0.1)
+    out = ops.conv3d_cl_tstrided(x5.to(DEV), ops.pack_conv_weight(wt.to(DEV).to(BF)), bb, (3, 1, 1), 2, 2, 2)
+    assert _rel(out, _conv_ref(x5.double(), wt.double(), bd)[[2, 4]]) < 2e-6
+    # GroupNorm, frame interleave, cross-fade
+    xg = seeded((1, 19, 7, 64), 49) * 2 + 0.3          # one image: every leading dimension is a position of the same sample
+    gw, gb = _bf(1 + 0.1 * seeded((64,), 50)), _bf(0.1 * seeded((64,), 51))
+    out = ops.groupnorm_cl(xg.to(DEV), gw.to(DEV).to(BF), gb.to(DEV).to(BF), silu=True)
+    ref = F.silu(F.group_norm(xg.double().permute(0, 3, 1, 2), 32, gw.double(), gb.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert _rel(out, ref) < 5e-6
+    xi = seeded((2, 3, 4, 32), 52)
+    assert torch.equal(ops.time_interleave_cl(xi.to(DEV)).cpu(), xi.view(2, 12, 2, 16).permute(0, 2, 1, 3).reshape(4, 3, 4, 16))
+    a, bt = seeded((2, 6, 5, 8), 53), seeded((2, 6, 5, 8), 54)
+    wgt = (torch.arange(6).double() / 6).view(1, 6, 1, 1)
+    got = ops.crossfade_(a.to(DEV), bt.to(DEV).clone(), dim=1)
+    assert _rel(got, a.double() * (1 - wgt) + bt.double() * wgt) < 1e-6
+
+
+# ---- transformer forwards ----------------------------------------------------------------------------------------------
+def _points(tag, m, plan, call):
+    """The FREE-RUNNING forward with every storage point compared (not forced) against the fp32 oracle's value for it."""
+    from apex_studio_amd import ops
+    out, report = SP.run_forced(ops, m, plan, call, force=False)
+    worst = max(r[3] for r in report)
+    print(f"[f32-storage {tag}] {len(report)} storage points of the free-running forward vs the fp32 oracle: worst rel L2 "
+          f"{worst:.2e}, mean {sum(r[3] for r in report) / len(report):.2e}")
+    if worst > TOL:
+        SP.print_report(tag, report)
+    assert worst <= TOL, worst
+    return out
+
+
+def _report(tag, out, ref32, ref16=None):
+    e = _rel(out, ref32)
+    extra = "" if ref16 is None else f" (the oracle's own bf16-storage emulation is {_rel(ref16, ref32):.2e} from fp32)"
+    print(f"[f32-storage {tag}] HIP vs the fp32 oracle, free-running: rel L2 {e:.2e}{extra}")
+    assert torch.isfinite(torch.as_tensor(out).float()).all()
+    assert e <= TOL, e
+    return e
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_flux_forward_f32_storage(name):
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = FLUX_CONFIGS[name]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    inp = flux_inputs(cfg, hw, s_txt)
+    inp["timestep"] = torch.tensor([0.7183])          # NOT bf16-representable: the f32 mode keeps it, as the fp32 reference does
+    args = (inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"], inp["img_ids"],
+            inp["txt_ids"], inp["guidance"])
+    pol = SP.TracePolicy(False)
+    ref32, ref16 = orc(*args, policy=pol), orc(*args, policy=OL.BF16_STORAGE)
+    plan, _ = SP.flux_plan(pol.points, cfg, s_txt)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    out = _points(f"flux {name}", m, plan, lambda: m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0])
+    assert out.dtype == F32 and all(t.dtype == F32 for t in (next(iter(m._ws.values())).X, next(iter(m._ws.values())).QKV))
+    _report(f"flux {name}", out, ref32, ref16)
+    # and back: the same instance in production storage is the bf16 path again
+    m.set_storage_dtype(BF)
+    out16 = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0]
+    assert next(iter(m._ws.values())).X.dtype == BF and out16.dtype == F32 and 1e-4 < _rel(out16, ref16) < 6e-3
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_wan_forward_f32_storage(name):
+    from apex_studio_amd.wan import WanTransformer3DModel
+    cfg, shape, s_txt = WAN_CONFIGS[name]
+    orc = OW.WanTransformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 9)
+    orc.load_state_dict(sd, strict=True)
+    x, txt, t = seeded(shape, 41), seeded((1, s_txt, cfg["text_dim"]), 42), torch.tensor([537.0])
+    pol = SP.TracePolicy(False)
+    ref32, ref16 = orc(x, t, txt, policy=pol), orc(x, t, txt, policy=OL.BF16_STORAGE)
+    plan, _ = SP.wan_plan(pol.points, cfg)
+    m = WanTransformer3DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    out = _points(f"wan {name}", m, plan, lambda: m(hidden_states=x.to(DEV), timestep=t.to(DEV),
+                                                    encoder_hidden_states=txt.to(DEV), return_dict=False)[0])
+    assert out.dtype == F32
+    _report(f"wan {name}", out, ref32, ref16)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_qwen_forward_f32_storage(name):
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    cfg, shapes, s_txt = QWEN_CONFIGS[name]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    n_img = sum(f * h * w for f, h, w in shapes)
+    x, txt, t = seeded((1, n_img, 64), 51), seeded((1, s_txt, cfg["joint_attention_dim"]), 52), torch.tensor([0.6271])
+    pol = SP.TracePolicy(False)
+    ref32, ref16 = orc(x, txt, t, shapes, policy=pol), orc(x, txt, t, shapes, policy=OL.BF16_STORAGE)
+    plan, _ = SP.qwen_plan(pol.points, cfg, s_txt)
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    out = _points(f"qwen {name}", m, plan, lambda: m(
+        hidden_states=x.to(DEV), encoder_hidden_states=txt.to(DEV), encoder_hidden_states_mask=torch.ones(1, s_txt, device=DEV),
+        timestep=t.to(DEV), img_shapes=[shapes], txt_seq_lens=[s_txt], return_dict=False)[0])
+    assert out.dtype == F32
+    _report(f"qwen {name}", out, ref32, ref16)
+
+
+# ---- VAEs ----------------------------------------------------------------------------------------------------------------
+def _wan_vae_cfg():
+    return dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True])
+
+
+def _wan_vae_triple(seed):
+    from oracle.vae_wan import AutoencoderKLWanDecoder, AutoencoderKLWanEncoder
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vae = AutoencoderKLWan(**_wan_vae_cfg(), device=DEV, dtype=BF).set_storage_dtype(F32)
+    vsd = vae_synthetic_state_dict(vae, seed)
+    vae.load_state_dict({k: v.to(BF) for k, v in vsd.items()}, strict=True)
+    stats = dict(latents_mean=list(vae.config.latents_mean), latents_std=list(vae.config.latents_std))
+    vdec, venc = AutoencoderKLWanDecoder(**_wan_vae_cfg(), **stats).eval(), AutoencoderKLWanEncoder(**_wan_vae_cfg(), **stats).eval()
+    vdec.load_state_dict({k: v for k, v in vsd.items() if k.startswith(("decoder.", "post_quant_conv."))}, strict=True)
+    venc.load_state_dict({k: v for k, v in vsd.items() if k.startswith(("encoder.", "quant_conv."))}, strict=True)
+    return vae, vdec, venc
+
+
+def _flux_vae_pair(seed):
+    from tests.test_gpu_end_to_end import _flux_vae_pair as pair
+    orc, vae = pair(dict(latent_channels=16, block_out_channels=(32, 64, 128, 128), layers_per_block=1), seed)
+    return orc, vae.set_storage_dtype(F32)
+
+
+def test_flux_vae_decode_f32_storage():
+    vorc, vae = _flux_vae_pair(19)
+    z = seeded((1, 16, 24, 16), 61)
+    ref32, ref16 = vorc.decode(z), vorc.decode(z, policy=OL.BF16_STORAGE)
+    out = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert out.dtype == F32 and out.shape == ref32.shape
+    _report("flux vae decode", out, ref32, ref16)
+
+
+def test_wan_vae_tiled_decode_and_encode_f32_storage():
+    vae, vdec, venc = _wan_vae_triple(23)
+    tile = (64, 64, 48, 48)
+    for v in (vae, vdec, venc):
+        v.enable_tiling(*tile)
+    z = seeded((1, 16, 3, 12, 16), 62)                       # 9 frames of 96 x 128: 2 x 3 tiles with 16-px cross-fades
+    ref32, ref16 = vdec.decode(z), vdec.decode(z, policy=OL.BF16_STORAGE)
+    out = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert out.dtype == F32 and out.shape == ref32.shape == (1, 3, 9, 96, 128)
+    _report("wan vae tiled decode", out, ref32, ref16)
+    x = seeded((1, 3, 5, 96, 128), 63).clamp(-1, 1)
+    ref32, ref16 = venc.encode(x), venc.encode(x, policy=OL.BF16_STORAGE)
+    post = vae.encode(x.to(DEV), return_dict=False)[0]
+    assert post.parameters.dtype == F32
+    _report("wan vae tiled encode (posterior parameters)", post.parameters, ref32, ref16)
+
+
+# ---- sampler chains -> decoded frames -----------------------------------------------------------------------------------
+def _frames(tag, hip, ref):
+    """hip / ref = (latents, decoded [-1, 1], uint8 frames)"""
+    (lat_h, dec_h, fr_h), (lat_r, dec_r, fr_r) = hip, ref
+    assert fr_h.dtype == np.uint8 and fr_h.shape == fr_r.shape
+    d = np.abs(fr_h.astype(np.int32) - fr_r.astype(np.int32))
+    e_lat, e_dec = _rel(lat_h, lat_r), _rel(dec_h, dec_r)
+    e_fr = _rel(fr_h.astype(np.float32) / 255.0, fr_r.astype(np.float32) / 255.0)
+    spread = float(fr_r.astype(np.float32).std())
+    print(f"[f32-storage chain {tag}] vs the fp32 oracle chain: latents {e_lat:.2e} | decoded [-1,1] {e_dec:.2e} | frames [0,1] "
+          f"{e_fr:.2e} | uint8 max |diff| {int(d.max())}, {float((d > 0).mean()) * 100:.3f} % of {fr_r.size} samples differ "
+          f"(frame std {spread:.1f} levels)")
+    assert spread > 20.0, "degenerate frames: the comparison would be vacuous"
+    assert e_lat <= TOL and e_dec <= TOL and e_fr <= TOL, (e_lat, e_dec, e_fr)
+    assert int(d.max()) <= 1            # a rounding boundary of round(255 x) may be crossed, nothing more
+
+
+def test_flux_chain_to_frames_f32_storage():
+    from apex_studio_amd.engine_flux import FluxT2IEngine, pack_latents
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.postprocess import tensor_to_frame
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    cfg = FLUX_CONFIGS["tiny"][0]
+    height = width = 128
+    steps, s_txt = 4, 16
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 7)
+    orc.load_state_dict(sd, strict=True)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    vorc, vae = _flux_vae_pair(19)
+    lat0 = pack_latents(seeded((1, 16, height // 8, width // 8), 31))
+    enc, pooled = seeded((1, s_txt, 128), 32), seeded((1, 64), 33)
+    eng = FluxT2IEngine(m, decode_fn=lambda z: vae.decode(vae.denormalize_latents(z.float()), return_dict=False)[0])
+    kw = dict(height=height, width=width, num_inference_steps=steps, guidance_scale=3.5, latents=lat0.to(DEV))
+    lat_hip = eng.run(enc.to(DEV), pooled.to(DEV), return_latents=True, **kw)
+    dec_hip = eng.run(enc.to(DEV), pooled.to(DEV), **kw)
+    assert lat_hip.dtype == F32 and dec_hip.dtype == F32
+    frames_hip = tensor_to_frame(dec_hip, "np")
+    # the reference chain in fp32 (engine/flux/shared.py:504-619, t2i.py:196-254)
+    img_ids, txt_ids = OF.latent_image_ids(height // 16, width // 16), torch.zeros(s_txt, 3)
+    sch = FlowMatchEulerDiscreteScheduler.flux_dev()
+    ts = sch.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / steps, steps).tolist(), mu=OF.calculate_shift(lat0.shape[1]))
+    sch.set_begin_index(0)
+    lat = lat0.clone()
+    for t in ts:
+        v = orc(lat, enc, pooled, t.expand(1).float() / 1000, img_ids, txt_ids, torch.full([1], 3.5))
+        lat = sch.step(v, t, lat, return_dict=False)[0]
+    dec = vorc.decode(vorc.denormalize_latents(OF.unpack_latents(lat, height, width)))
+    _frames("flux 4 Euler steps", (lat_hip, dec_hip, frames_hip), (lat, dec, video_to_uint8_frames(dec.unsqueeze(2))[:, 0]))
+
+
+def test_wan_two_expert_chain_to_frames_f32_storage():
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    from apex_studio_amd.postprocess import tensor_to_frames
+    from apex_studio_amd.schedulers import UniPCMultistepScheduler
+    from apex_studio_amd.wan import WanTransformer3DModel
+    cfg = WAN_CONFIGS["tiny"][0]
+    height, width, duration, steps, s_txt = 96, 128, 9, 4, 20
+    experts_o, experts_h = [], []
+    for seed in (9, 10):
+        o = OW.WanTransformer3DModel(**cfg).eval()
+        sd = synthetic_state_dict(o, seed)
+        o.load_state_dict(sd, strict=True)
+        h = WanTransformer3DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+        h.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+        experts_o.append(o)
+        experts_h.append(h)
+    vae, vdec, _ = _wan_vae_triple(23)
+    tile = (64, 64, 48, 48)
+    vae.enable_tiling(*tile)
+    vdec.enable_tiling(*tile)
+    lat0 = seeded((1, 16, (duration - 1) // 4 + 1, height // 8, width // 8), 41)
+    pe, ne = seeded((1, s_txt, 64), 42), seeded((1, s_txt, 64), 43)
+    gs = (4.0, 3.0)
+    eng = WanT2VEngine(experts_h[0], experts_h[1], vae=vae, scheduler=UniPCMultistepScheduler(shift=3.0))
+    kw = dict(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), height=height, width=width, duration=duration,
+              num_inference_steps=steps, guidance_scale=gs, latents=lat0.to(DEV))
+    lat_hip = eng.run(return_latents=True, **kw)
+    dec_hip = eng.run(**kw)
+    assert dec_hip.dtype == F32
+    frames_hip = tensor_to_frames(dec_hip, "np")
+    sch = UniPCMultistepScheduler(shift=3.0)
+    ts = sch.set_timesteps(steps)
+    used = [bool(t >= 875.0) for t in ts]
+    assert used[0] and not used[-1], f"the chain must cross the expert boundary: {used}"
+    lat = lat0.clone()
+    for t in ts:
+        orc, scale = (experts_o[0], gs[0]) if bool(t >= 875.0) else (experts_o[1], gs[1])
+        cond, unc = orc(lat, t.expand(1).float(), pe), orc(lat, t.expand(1).float(), ne)
+        lat = sch.step(unc + scale * (cond - unc), t, lat, return_dict=False)[0]
+    dec = vdec.decode(vdec.denormalize_latents(lat))
+    _frames(f"wan 4 UniPC steps, experts high/low = {used}, CFG, 2 x 3 tiles", (lat_hip, dec_hip, frames_hip),
+            (lat, dec, video_to_uint8_frames(dec)))
+
+
+def test_qwen_edit_chain_pixels_to_frames_f32_storage():
+    from apex_studio_amd.engine_flux import calculate_shift
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.postprocess import tensor_to_frame
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    cfg = QWEN_CONFIGS["tiny"][0]
+    height, width, ih, iw, steps, s_txt, cfg_scale = 128, 96, 96, 64, 2, 13, 4.0
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    vae, vdec, venc = _wan_vae_triple(31)
+    img = seeded((1, 3, ih, iw), 71).clamp(-1, 1)
+    pe, ne = seeded((1, s_txt, 64), 72), seeded((1, s_txt, 64), 73)
+    lat0 = seeded((1, (height // 16) * (width // 16), 64), 74)
+    eng = QwenImageEditPlusEngine(m, vae=vae)
+    previews = []
+    kw = dict(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), true_cfg_scale=cfg_scale, images=img.to(DEV),
+              height=height, width=width, num_inference_steps=steps, latents=lat0.to(DEV))
+    lat_hip = eng.run(return_latents=True, **kw)
+    dec_hip = eng.run(return_latents=False, render_on_step=True, render_on_step_callback=previews.append,
+                      render_on_step_interval=1, **kw)
+    assert dec_hip.dtype == F32 and len(previews) == steps - 1 and previews[0].shape == dec_hip.shape
+    frames_hip = tensor_to_frame(dec_hip, "np")
+    venc.enable_tiling()
+    vdec.enable_tiling()
+    img_shapes = [(1, height // 16, width // 16), (1, ih // 16, iw // 16)]
+    cond = venc.normalize_latents(venc.encode(img.unsqueeze(2))[:, :16])
+    image_latents = QwenImageEditPlusEngine._pack_latents(cond)
+    sch = FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9,
+                                          base_image_seq_len=256, max_image_seq_len=8192, shift_terminal=0.02)
+    c = sch.config
+    mu = calculate_shift(lat0.shape[1], c["base_image_seq_len"], c["max_image_seq_len"], c["base_shift"], c["max_shift"])
+    ts = sch.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / steps, steps).tolist(), mu=mu)
+    sch.set_begin_index(0)
+    lat = lat0.clone()
+    n_tgt = lat.shape[1]
+    for t in ts:
+        x = torch.cat([lat, image_latents], dim=1)
+        tt = t.expand(1).float() / 1000
+        pos, neg = orc(x, pe, tt, img_shapes)[:, :n_tgt], orc(x, ne, tt, img_shapes)[:, :n_tgt]
+        comb = neg + cfg_scale * (pos - neg)
+        lat = sch.step(comb * (torch.norm(pos, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True)), t, lat,
+                       return_dict=False)[0]
+    dec = vdec.decode(vdec.denormalize_latents(QwenImageEditPlusEngine._unpack_latents(lat, height, width)))[:, :, 0]
+    lat_c, _ = eng.prepare_image_latents(img.to(DEV))
+    print(f"[f32-storage chain qwen] packed condition latents (tiled encode, posterior mode, normalised): {_rel(lat_c, image_latents):.2e}")
+    assert _rel(lat_c, image_latents) <= TOL
+    _frames("qwen-edit pixels -> encode -> 2 true-CFG steps -> decode", (lat_hip, dec_hip, frames_hip),
+            (lat, dec, video_to_uint8_frames(dec.unsqueeze(2))[:, 0]))
