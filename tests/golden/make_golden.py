@@ -959,6 +959,77 @@ def gen_leaf_pins():
     print("leaf_pins.pt", sorted(out))
 
 
+def gen_leaf_pins2():
+    """tests/golden/leaf_pins2.pt (round 3): the two remaining cheap pins of DESIGN.md §1.
+      dynamic time shift   scheduler/rf.py:94-95 `time_shift`; scheduler/unipc.py:275-276 (the same closed form as a
+                           method); scheduler/flow_match_pair.py:41-60 `FlowMatchScheduler.set_timesteps` with
+                           `exponential_shift` + `shift_terminal` (:118-129 `calculate_shift`) — the Flux / QwenImage
+                           FlowMatch-Euler schedule: linspace -> exp(mu) shift -> terminal stretch
+      2-D VAE decoder      preprocess/diffusion_edge/taming/modules/diffusionmodules/model.py:462-580, the LDM `Decoder`
+      TOPOLOGY             (the class the FLUX.1 autoencoder is an instance of: ch 128, ch_mult (1, 2, 4, 4), 2 res blocks,
+                           z 16) with its ResnetBlock / AttnBlock / Upsample (:38-203).  The weights are drawn in the
+                           DIFFUSERS key space (what oracle/vae_flux.py and the HIP class load) and renamed to the LDM
+                           keys by `to_ldm` below, the published correspondence of the two layouts: mid.block_i <->
+                           mid_block.resnets.i-1, mid.attn_1.{norm,q,k,v,proj_out} <-> mid_block.attentions.0.{group_norm,
+                           to_q,to_k,to_v,to_out.0} (1x1 conv <-> linear), up.L <-> up_blocks.(n-1-L), nin_shortcut <->
+                           conv_shortcut, norm_out <-> conv_norm_out."""
+    out = {}
+    rf = extract_defs("src/scheduler/rf.py", ["time_shift"])
+    t = torch.linspace(1.0, 1.0 / 28, 28, dtype=torch.float64)
+    out["time_shift"] = [dict(mu=mu, sigma=sg, t=t.clone(), out=rf["time_shift"](mu, sg, t)) for mu, sg in
+                         ((0.5, 1.0), (1.15, 1.0), (0.8266, 1.0), (0.9, 2.0))]
+    fm = extract_defs("src/scheduler/flow_match_pair.py", ["FlowMatchScheduler"])
+    cases = []
+    for steps, seq_len, terminal in ((8, 4096, 0.02), (28, 1024, None), (4, 8192 + 4096, 0.02), (50, 256, 0.02)):
+        sch = fm["FlowMatchScheduler"](num_inference_steps=steps, exponential_shift=True, shift_terminal=terminal,
+                                       sigma_max=1.0, sigma_min=1.0 / steps, exponential_shift_mu=0.8)
+        sch.set_timesteps(steps, dynamic_shift_len=seq_len)
+        cases.append(dict(steps=steps, seq_len=seq_len, shift_terminal=terminal, mu=sch.calculate_shift(seq_len),
+                          sigmas=sch.sigmas.clone(), timesteps=sch.timesteps.clone()))
+    out["flow_match_pair"] = cases
+
+    from oracle.vae_flux import AutoencoderKLDecoder
+    tm = extract_defs("src/preprocess/diffusion_edge/taming/modules/diffusionmodules/model.py",
+                      ["nonlinearity", "Normalize", "Upsample", "ResnetBlock", "AttnBlock", "Decoder"])
+
+    def to_ldm(sd, n_up):
+        ldm = {}
+        for k, v in sd.items():
+            assert k.startswith("decoder."), k
+            k2 = k[len("decoder."):]
+            k2 = k2.replace("mid_block.resnets.0.", "mid.block_1.").replace("mid_block.resnets.1.", "mid.block_2.")
+            if k2.startswith("mid_block.attentions.0."):
+                k2 = k2.replace("mid_block.attentions.0.", "mid.attn_1.").replace("group_norm.", "norm.") \
+                       .replace("to_q.", "q.").replace("to_k.", "k.").replace("to_v.", "v.").replace("to_out.0.", "proj_out.")
+                if k2.endswith("weight") and v.dim() == 2:
+                    v = v[:, :, None, None]            # nn.Linear <-> 1x1 convolution
+            if k2.startswith("up_blocks."):
+                i = int(k2.split(".")[1])
+                rest = k2.split(".", 2)[2]
+                rest = rest.replace("resnets.", "block.").replace("upsamplers.0.conv.", "upsample.conv.")
+                k2 = f"up.{n_up - 1 - i}.{rest}"
+            k2 = k2.replace("conv_shortcut.", "nin_shortcut.").replace("conv_norm_out.", "norm_out.")
+            ldm[k2] = v
+        return ldm
+
+    dec = []
+    for tag, cfg, seed, hw in (("flux_shape", dict(latent_channels=16, block_out_channels=(32, 64, 128, 128), layers_per_block=2), 161, (12, 10)),
+                               ("three_levels", dict(latent_channels=8, block_out_channels=(32, 64, 64), layers_per_block=1), 162, (9, 14))):
+        orc = AutoencoderKLDecoder(**cfg).eval()
+        sd = vae_synthetic_state_dict(orc, seed)
+        ch = cfg["block_out_channels"]
+        ref = tm["Decoder"](ch=ch[0], out_ch=3, ch_mult=tuple(c // ch[0] for c in ch), num_res_blocks=cfg["layers_per_block"],
+                            attn_resolutions=[], in_channels=3, resolution=64, z_channels=cfg["latent_channels"]).eval()
+        missing, unexpected = ref.load_state_dict(to_ldm(sd, len(ch)), strict=True)
+        z = seeded((1, cfg["latent_channels"]) + hw, seed + 10)
+        with torch.no_grad():
+            dec.append(dict(tag=tag, cfg=cfg, seed=seed, z_seed=seed + 10, z_shape=tuple(z.shape), out=ref(z),
+                            ldm_keys=sorted(ref.state_dict().keys())))
+    out["ldm_decoder"] = dec
+    torch.save(out, os.path.join(OUT, "leaf_pins2.pt"))
+    print("leaf_pins2.pt", sorted(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py text_encoders vae_hunyuan15 ...
         os.makedirs(OUT, exist_ok=True)

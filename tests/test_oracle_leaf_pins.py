@@ -185,3 +185,62 @@ def test_flowmatch_euler_matches_the_in_tree_scheduler(pins):
     for i, t in enumerate(ts):
         x = s.step(seeded(c["shape"], c["x_seed"] + 1 + i), t, x, return_dict=False)[0]
         _close(x, c["traj"][i], 1e-6)
+
+
+# ---- round 3: the remaining cheap pins (tests/golden/leaf_pins2.pt, `gen_leaf_pins2`) ---------------------------------
+@pytest.fixture(scope="module")
+def pins2(golden_dir):
+    return torch.load(os.path.join(golden_dir, "leaf_pins2.pt"), weights_only=False)
+
+
+def test_dynamic_time_shift_is_the_in_tree_closed_form(pins2):
+    """e^mu / (e^mu + (1/t - 1)^sigma): reference scheduler/rf.py:94-95 (= unipc.py:275-276) against the product
+    scheduler's `_time_shift` and the oracle's numpy restatement."""
+    import numpy as np
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from oracle.schedulers import flow_sigmas
+    s = FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=True)
+    for c in pins2["time_shift"]:
+        got = s._time_shift(c["mu"], c["sigma"], c["t"])
+        assert got.dtype == torch.float64
+        _close(got, c["out"], 1e-12)
+        if c["sigma"] == 1.0:
+            assert np.allclose(flow_sigmas(c["t"].numpy(), mu=c["mu"])[:-1], c["out"].float().numpy(), atol=1e-7, rtol=0)
+
+
+def test_dynamic_shift_schedule_matches_the_in_tree_flowmatch_scheduler(pins2):
+    """linspace(1, 1/N, N) -> exponential shift with mu = calculate_shift(sequence length) -> terminal stretch -> x1000:
+    reference scheduler/flow_match_pair.py:41-60, :118-129 against FlowMatchEulerDiscreteScheduler.set_timesteps(sigmas=, mu=)
+    as the Flux / QwenImage engines call it (engine_flux.py, engine_qwenimage.py)."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd.engine_flux import calculate_shift
+    from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    for c in pins2["flow_match_pair"]:
+        mu = calculate_shift(c["seq_len"], 256, 8192, 0.5, 0.9)
+        assert abs(mu - c["mu"]) < 1e-12
+        s = FlowMatchEulerDiscreteScheduler(shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9,
+                                            base_image_seq_len=256, max_image_seq_len=8192,
+                                            shift_terminal=c["shift_terminal"])
+        n = c["steps"]
+        ts = s.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / n, n).tolist(), mu=mu)
+        _close(s.sigmas[:-1], c["sigmas"], 2e-7)
+        _close(ts, c["timesteps"], 2e-4)
+        assert float(s.sigmas[-1]) == 0.0
+
+
+def test_flux_vae_decoder_topology_is_the_ldm_decoder(pins2):
+    """oracle/vae_flux.py's Decoder (the diffusers `Decoder` layout the FLUX.1 VAE checkpoint and the HIP class use) against
+    the reference's in-tree LDM `Decoder` (preprocess/diffusion_edge/taming/modules/diffusionmodules/model.py:462-580) run
+    on the same weights through the published key correspondence: block order, `layers_per_block + 1` resnets per level,
+    upsampler on every level but the last, channel schedule, norm_out -> SiLU -> conv_out.  The strict load of the renamed
+    state dict into the reference class in `gen_leaf_pins2` already pins names, shapes and counts."""
+    for c in pins2["ldm_decoder"]:
+        orc = OV.AutoencoderKLDecoder(**c["cfg"]).eval()
+        sd = vae_synthetic_state_dict(orc, c["seed"])
+        orc.load_state_dict(sd, strict=True)
+        assert len(sd) == len(c["ldm_keys"])
+        out = orc.decode(seeded(c["z_shape"], c["z_seed"]))
+        assert out.shape == c["out"].shape
+        rel = float((out - c["out"]).norm() / c["out"].norm())
+        assert rel < 1e-5, (c["tag"], rel)
