@@ -1090,8 +1090,8 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
             attn_fwd_d128_c4_kernel<8, 6>, attn_fwd_d128_c4_kernel<8, 7>};
         auto c4 = c4_tab[var];
         static uint64_t c4_attr[8] = {};
-        if (apexmi_once_per_device(c4_attr[var]))
-            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        APEXMI_SET_ATTR_ONCE(c4_attr[var],
+            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
         int tail = attn_tail(total, Sk);
         const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
         if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
@@ -1125,8 +1125,8 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
         default: apexmi_set_error("attn_fwd_prepared: attn.waves=%d not in [4,8]", nw); return 1;
     }
     static uint64_t attr_done[2][9] = {};
-    if (apexmi_once_per_device(attr_done[m16][nw]))
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+    APEXMI_SET_ATTR_ONCE(attr_done[m16][nw],
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
     hipLaunchKernelGGL(kern, dim3(total), dim3(nw * 64), 2 * ATT_STAGE, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total,
                        o_strides[0], o_strides[1], o_strides[2], c);

@@ -203,15 +203,28 @@ APEXMI_DEVICE int xcd_remap(int bid, int total) {
 }
 
 // ---- host side -------------------------------------------------------------------------------
-// Function attributes (dynamic LDS size) are per DEVICE: `mask` holds one bit per device ordinal; true the first time
-// the calling thread's current device asks.  The launch wrappers run with the operand tensors' device current.
-static inline bool apexmi_once_per_device(uint64_t& mask) {
+// Function attributes (dynamic LDS size) are per DEVICE: `mask` holds one bit per device ordinal (0..63).  Use:
+//     if (apexmi_attr_needed(mask)) { hipFuncSetAttribute(...); apexmi_attr_done(mask); }
+// The bit is set only AFTER the attribute calls returned, so a second host thread on the same device either sees the bit
+// (attribute applied) or applies the attribute itself again — harmless — and never launches ahead of it.  Devices with an
+// ordinal >= 64 simply set the attribute on every call.
+static inline bool apexmi_attr_needed(const uint64_t& mask) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    const bool first = !(__atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED) & bit);
-    return first;
+    return dev >= 64 || !(__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & (1ull << dev));
 }
+static inline void apexmi_attr_done(uint64_t& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 64) (void)__atomic_fetch_or(&mask, 1ull << dev, __ATOMIC_RELEASE);
+}
+#define APEXMI_SET_ATTR_ONCE(mask, ...)      \
+    do {                                     \
+        if (apexmi_attr_needed(mask)) {      \
+            __VA_ARGS__;                     \
+            apexmi_attr_done(mask);          \
+        }                                    \
+    } while (0)
 void apexmi_set_error(const char* fmt, ...);
 int apexmi_check_launch(const char* what);
 

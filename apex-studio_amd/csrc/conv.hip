@@ -920,8 +920,8 @@ int g_conv_slab = 2; // apexmi_tune_set("conv.slab", 0 | 1 | 2): direct convolut
 template <int NT, int NORM>
 int launch_slab96_inst(const ConvArgs& a, hipStream_t stream) {     // conv.slab = 1: the order-preserving 8 x 32 form, Cin = 96
     static uint64_t attr = 0;
-    if (apexmi_once_per_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3d_slab96_kernel<NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS);
+    APEXMI_SET_ATTR_ONCE(attr,
+        (void)hipFuncSetAttribute((const void*)conv3d_slab96_kernel<NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS));
     const int grid = a.T * ((a.H + 7) / 8) * ((a.W + 31) / 32);
     hipLaunchKernelGGL((conv3d_slab96_kernel<NT, NORM>), dim3(grid), dim3(512), SLAB_LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab 8x32)");
@@ -933,8 +933,8 @@ int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * NPJ * 8192 + 3 * NT * 32 * SLW * 2;
     static_assert(LDS <= 160 * 1024, "slab kernel LDS");
     static uint64_t attr = 0;
-    if (apexmi_once_per_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM, SLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    APEXMI_SET_ATTR_ONCE(attr,
+        (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM, SLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int gx = a.T * ((a.H + 8 * MT - 1) / (8 * MT)) * ((a.W + 31) / 32), gy = (a.Cout + NT * 32 - 1) / (NT * 32);
     hipLaunchKernelGGL((conv3d_slab_kernel<NT, MT, NORM, SLW>), dim3(gx, gy), dim3(512), LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab)");
@@ -984,8 +984,8 @@ int launch_slab(const ConvArgs& a, hipStream_t stream) {
 template <typename CFG, int UP, int NORM>
 int launch_v2_inst(const ConvArgs& a, hipStream_t stream, int grid) {
     static uint64_t attr = 0;
-    if (apexmi_once_per_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, UP, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE);
+    APEXMI_SET_ATTR_ONCE(attr,
+        (void)hipFuncSetAttribute((const void*)conv3d_v2_kernel<CFG, UP, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CFG::STAGE));
     hipLaunchKernelGGL((conv3d_v2_kernel<CFG, UP, NORM>), dim3(grid), dim3(CFG::NTHR), 2 * CFG::STAGE, stream, a);
     return apexmi_check_launch("conv3d_cl (v2)");
 }
@@ -1384,12 +1384,12 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                        ((uintptr_t)zeros % 16) == 0,
                    "conv3d_cl: operands must be 16-byte aligned");
     static uint64_t attr_set = 0;
-    if (apexmi_once_per_device(attr_set)) {
+    APEXMI_SET_ATTR_ONCE(attr_set, {
         (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * STAGE_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * STAGE_BYTES);
-    }
+    });
     ConvArgs a;
     a.in = (const bf16_t*)in;
     a.w = (const bf16_t*)w;
@@ -1465,7 +1465,8 @@ extern "C" int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* b
 // position inside one workgroup tile: Cout <= 96 or 128 < Cout <= 192)
 extern "C" int apexmi_conv3d_cl_norm_fusable(int T, int H, int W, int Cin, int Cout, int up) {
     const int64_t M = (int64_t)T * H * W * (up ? 4 : 1);
-    return g_conv_v2 && M >= 65536 && (int64_t)T * H * W * Cin * 2 < ((int64_t)1 << 31) && (Cout <= 96 || (Cout > 128 && Cout <= 192));
+    return g_conv_v2 && M >= 65536 && (int64_t)T * H * W * Cin * 2 < ((int64_t)1 << 31) && Cout % 8 == 0 &&
+           (Cout <= 96 || (Cout > 128 && Cout <= 192));
 }
 
 extern "C" int apexmi_conv3d_cl_norm(const void* in, const void* w, const void* bias, const void* residual, void* out,

@@ -842,9 +842,9 @@ int g_tail_split = 1; // tune key gemm.tail: a small last problem of a grouped l
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     static uint64_t attr_set = 0;
-    if (apexmi_once_per_device(attr_set))
+    APEXMI_SET_ATTR_ONCE(attr_set,
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<CFG, EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS));
     int t = 0;
     for (int i = 0; i < G.count; ++i) {
         G.p[i].M = Ms[i];

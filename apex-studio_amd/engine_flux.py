@@ -62,15 +62,41 @@ def _emit(cb, p, msg):
 
 
 class FluxT2IEngine(EngineLoraMixin):
-    """engine.run(...) for Flux text-to-image with pre-computed prompt embeddings."""
+    """engine.run(...) for Flux text-to-image: prompts (token ids, or strings when the text encoders carry tokenizers) or
+    pre-computed prompt embeddings in, image out."""
 
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
-                 decode_fn: Optional[Callable[[torch.Tensor], object]] = None, vae_scale_factor: int = 8):
+                 decode_fn: Optional[Callable[[torch.Tensor], object]] = None, vae_scale_factor: int = 8,
+                 text_encoder=None, text_encoder_2=None):
+        from .prompt import TextEncoder
         self.transformer = transformer
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler.flux_dev()
         self.decode_fn = decode_fn
         self.vae_scale_factor = vae_scale_factor
         self.num_channels_latents = transformer.config.in_channels // 4
+        # CLIP-L (pooled) and T5-XXL (sequence), as the manifest names them (flux-dev-text-to-image yml:59-90)
+        wrap = lambda m: m if m is None or isinstance(m, TextEncoder) else TextEncoder(m)      # noqa: E731
+        self.text_encoder, self.text_encoder_2 = wrap(text_encoder), wrap(text_encoder_2)
+
+    def encode_prompt(self, prompt=None, prompt_2=None, prompt_ids=None, prompt_2_ids=None, num_images: int = 1,
+                      text_encoder_kwargs=None, text_encoder_2_kwargs=None):
+        """`FluxShared.encode_prompt` (R/src/engine/flux/shared.py:215-345): pooled CLIP embedding + T5 sequence embedding.
+        Returns (prompt_embeds, pooled_prompt_embeds, text_ids).  Manifest defaults: 77 / 512 tokens, `pad_with_zero` false."""
+        from .prompt import split_ids
+        if self.text_encoder is None or self.text_encoder_2 is None:
+            raise RuntimeError("FluxT2IEngine: prompts need text_encoder (CLIP) and text_encoder_2 (T5); or pass prompt_embeds")
+        k1 = dict(max_sequence_length=77, pad_with_zero=False, **(text_encoder_kwargs or {}))
+        k2 = dict(max_sequence_length=512, pad_with_zero=False, **(text_encoder_2_kwargs or {}))
+        if prompt_2 is None and prompt_2_ids is None:            # `if not prompt_2: prompt_2 = prompt` — same TEXT for both encoders
+            if prompt is None:
+                raise ValueError("token ids are per tokenizer: pass prompt_2_ids (T5) next to prompt_ids (CLIP)")
+            prompt_2 = prompt
+        a = dict(text=prompt) if prompt_ids is None else dict(zip(("input_ids", "attention_mask"), split_ids(prompt_ids)))
+        b = dict(text=prompt_2) if prompt_2_ids is None else dict(zip(("input_ids", "attention_mask"), split_ids(prompt_2_ids)))
+        pooled = self.text_encoder.encode(num_videos_per_prompt=num_images, output_type="pooler_output", **a, **k1)
+        embeds = self.text_encoder_2.encode(num_videos_per_prompt=num_images, output_type="hidden_states", **b, **k2)
+        text_ids = torch.zeros(embeds.shape[1], 3, device=embeds.device, dtype=embeds.dtype)
+        return embeds, pooled, text_ids
 
     @property
     def device(self):
@@ -113,13 +139,22 @@ class FluxT2IEngine(EngineLoraMixin):
         return latents
 
     @torch.no_grad()
-    def run(self, prompt_embeds: torch.Tensor, pooled_prompt_embeds: torch.Tensor, height: int = 1024,
-            width: int = 1024, num_inference_steps: int = 28, guidance_scale: float = 3.5,
+    def run(self, prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
+            height: int = 1024, width: int = 1024, num_inference_steps: int = 28, guidance_scale: float = 3.5,
             latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
             generator: Optional[torch.Generator] = None, return_latents: bool = False,
             progress_callback=None, render_on_step: bool = False, render_on_step_callback=None,
-            render_on_step_interval: int = 3, sigmas=None, output_type: Optional[str] = None, **_ignored):
+            render_on_step_interval: int = 3, sigmas=None, output_type: Optional[str] = None,
+            prompt=None, prompt_2=None, prompt_ids=None, prompt_2_ids=None, num_images: int = 1,
+            text_encoder_kwargs=None, text_encoder_2_kwargs=None, **_ignored):
+        """`engine.run(prompt=..., height=..., ...)` as the render queue calls it (R/src/api/ray_tasks.py:2775-2812,
+        R/src/engine/flux/t2i.py:15-260).  Either prompts — `prompt` / `prompt_2` strings (text encoders with tokenizers) or
+        `prompt_ids` (CLIP) + `prompt_2_ids` (T5) — or the pre-computed `prompt_embeds` + `pooled_prompt_embeds`."""
         dev, dt = self.device, compute_dtype(self.transformer)
+        if prompt_embeds is None:
+            _emit(progress_callback, 0.05, "Encoding prompt")
+            prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt(prompt, prompt_2, prompt_ids, prompt_2_ids, num_images,
+                                                                        text_encoder_kwargs, text_encoder_2_kwargs)
         B = prompt_embeds.shape[0]
         h = 2 * (int(height) // (self.vae_scale_factor * 2))
         w = 2 * (int(width) // (self.vae_scale_factor * 2))

@@ -147,11 +147,12 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         if self.decode_fn is None and self.vae is None:
             raise RuntimeError("hunyuanvideo15: no decode_fn / VAE attached; pass return_latents=True")
         if self.decode_fn is None:
-            try:
+            import inspect
+            if "use_light_vae" in inspect.signature(self.vae.enable_tiling).parameters:
                 self.vae.enable_tiling(use_light_vae=use_light_vae)      # t2v.py:350 / i2v.py:396
-            except TypeError:                                            # a VAE class without the light-VAE switch
-                if use_light_vae:
-                    raise
+            elif use_light_vae:
+                raise TypeError(f"{type(self.vae).__name__}.enable_tiling has no light-VAE switch (use_light_vae=True)")
+            else:
                 self.vae.enable_tiling()
         _emit(progress_callback, 0.94, "Decoding latents to video with light VAE" if use_light_vae else "Decoding latents")
         video = self.decode_fn(latents) if self.decode_fn is not None else self.vae_decode(latents)
@@ -201,7 +202,9 @@ class HunyuanVideo15I2VEngine(HunyuanVideo15T2VEngine):
         return cond, mask
 
     @torch.no_grad()
-    def run(self, image=None, image_embeds=None, *args, **kwargs):
+    def run(self, *args, image=None, image_embeds=None, **kwargs):
+        """Same positional arguments as the text-to-video `run` (prompt embeddings first); `image` / `image_embeds` are
+        keyword-only."""
         if image is None:
             raise ValueError("hunyuanvideo15 i2v: `image` is required")
         kwargs.setdefault("guidance_scale", 1.0)          # i2v.py:103: CFG off unless asked for

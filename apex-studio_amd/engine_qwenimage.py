@@ -25,9 +25,10 @@ def _emit(cb, p, msg):
 
 class QwenImageEditPlusEngine(EngineLoraMixin):
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, decode_fn=None,
-                 vae=None):
+                 vae=None, text_encoder=None):
         self.transformer = transformer
         self.vae = vae
+        self.text_encoder = text_encoder        # Qwen2_5_VLForConditionalGeneration (prompt + condition images -> embeddings)
         # Qwen-Image scheduler_config.json: dynamic exponential shifting, base/max shift 0.5/0.9,
         # base/max seq 256/8192, shift_terminal 0.02
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(
@@ -133,14 +134,35 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             _emit(denoise_progress_callback, float(i + 1) / n, f"Denoise {i + 1}/{n}")
         return latents
 
+    def encode_prompt(self, prompt_inputs, drop_idx: int = 64, num_images_per_prompt: int = 1):
+        """`_get_qwen_prompt_embeds` with condition images (R/src/engine/qwenimage/shared.py:100-282, edit_plus.py:190-230):
+        `prompt_inputs` = what the Qwen2.5-VL processor returns for the edit template + images (input_ids, attention_mask,
+        pixel_values, image_grid_thw; the processor is a CPU `transformers` object); the 64 template tokens are dropped."""
+        from .prompt import qwen_prompt_embeds
+        if self.text_encoder is None:
+            raise RuntimeError("QwenImageEditPlusEngine: prompts need a text_encoder (Qwen2.5-VL); or pass prompt_embeds")
+        get = prompt_inputs.get if isinstance(prompt_inputs, dict) else (lambda k, d=None: getattr(prompt_inputs, k, d))
+        return qwen_prompt_embeds(self.text_encoder, get("input_ids"), get("attention_mask"), get("pixel_values"),
+                                  get("image_grid_thw"), drop_idx=drop_idx, num_images_per_prompt=num_images_per_prompt,
+                                  dtype=compute_dtype(self.transformer))
+
     @torch.no_grad()
-    def run(self, prompt_embeds: torch.Tensor, image_latents: Optional[torch.Tensor] = None,
+    def run(self, prompt_embeds: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None,
             image_shapes: Sequence[Tuple[int, int]] = (), height: int = 1024, width: int = 1024,
             num_inference_steps: int = 8, negative_prompt_embeds: Optional[torch.Tensor] = None,
             true_cfg_scale: float = 1.0, latents: Optional[torch.Tensor] = None, seed: Optional[int] = None,
             return_latents: bool = False, progress_callback=None, images=None, output_type: Optional[str] = None,
-            render_on_step: bool = False, render_on_step_callback=None, render_on_step_interval: int = 3, **_ignored):
+            render_on_step: bool = False, render_on_step_callback=None, render_on_step_interval: int = 3,
+            prompt_inputs=None, negative_prompt_inputs=None, drop_idx: int = 64, **_ignored):
+        """`engine.run(prompt=..., image_list=..., ...)` of the EditPlus engine (R/src/engine/qwenimage/edit_plus.py:112-426) from
+        the point where the processor has run: `prompt_inputs` / `negative_prompt_inputs` (token ids + pixel patches of the
+        condition images) go through Qwen2.5-VL here; `images` (pixels) through the VAE encoder; or pass the embeddings."""
         dev, dt = self.device, compute_dtype(self.transformer)
+        if prompt_embeds is None:
+            _emit(progress_callback, 0.05, "Encoding prompt")
+            prompt_embeds, _ = self.encode_prompt(prompt_inputs, drop_idx)
+            if negative_prompt_inputs is not None:
+                negative_prompt_embeds, _ = self.encode_prompt(negative_prompt_inputs, drop_idx)
         if images is not None:       # condition images as pixels (or latents): encode + pack here
             image_latents, image_shapes = self.prepare_image_latents(images, prompt_embeds.shape[0])
         h2, w2 = height // 16, width // 16

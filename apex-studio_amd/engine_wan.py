@@ -30,7 +30,10 @@ def _emit(cb, p, msg):
 class WanT2VEngine(EngineLoraMixin):
     def __init__(self, high_noise_transformer, low_noise_transformer=None, vae=None,
                  scheduler: Optional[UniPCMultistepScheduler] = None, boundary_ratio: Optional[float] = 0.875,
-                 vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 8):
+                 vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 8, text_encoder=None):
+        from .prompt import TextEncoder
+        self.text_encoder = text_encoder if text_encoder is None or isinstance(text_encoder, TextEncoder) \
+            else TextEncoder(text_encoder)                      # UMT5-XXL (manifest wan-2.2-a14b-text-to-video yml)
         self.high_noise_transformer = high_noise_transformer
         self.low_noise_transformer = low_noise_transformer or high_noise_transformer
         self.vae = vae
@@ -90,14 +93,33 @@ class WanT2VEngine(EngineLoraMixin):
             _emit(denoise_progress_callback, float(i + 1) / n, f"Denoising step {i + 1}/{n}")
         return latents
 
+    def encode_prompt(self, prompt=None, prompt_ids=None, num_videos: int = 1, text_encoder_kwargs=None):
+        """`self.text_encoder.encode(prompt, num_videos_per_prompt=..., **text_encoder_kwargs)` of R/src/engine/wan/t2v.py:77-95
+        with the manifest's `use_attention_mask: true`: 512 tokens, masked encoder, embeddings past the prompt's length zeroed."""
+        from .prompt import split_ids
+        if self.text_encoder is None:
+            raise RuntimeError("WanT2VEngine: prompts need a text_encoder (UMT5); or pass prompt_embeds")
+        kw = dict(use_attention_mask=True, **(text_encoder_kwargs or {}))
+        a = dict(text=prompt) if prompt_ids is None else dict(zip(("input_ids", "attention_mask"), split_ids(prompt_ids)))
+        return self.text_encoder.encode(num_videos_per_prompt=num_videos, **a, **kw)
+
     @torch.no_grad()
-    def run(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor] = None,
+    def run(self, prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
             height: int = 720, width: int = 1280, duration: int = 81, num_inference_steps: int = 30,
             guidance_scale: Union[float, List[float]] = (4.0, 3.0), seed: Optional[int] = None,
             generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
             return_latents: bool = False, progress_callback=None, render_on_step: bool = False,
-            render_on_step_callback=None, render_on_step_interval: int = 3, output_type: Optional[str] = None, **_ignored):
+            render_on_step_callback=None, render_on_step_interval: int = 3, output_type: Optional[str] = None,
+            prompt=None, negative_prompt=None, prompt_ids=None, negative_prompt_ids=None, num_videos: int = 1,
+            text_encoder_kwargs=None, **_ignored):
+        """`engine.run(prompt=..., negative_prompt=..., ...)` (R/src/engine/wan/t2v.py:12-247): prompts as strings (text
+        encoder with a tokenizer) or token ids `(input_ids, attention_mask)`, or pre-computed embeddings."""
         dev = self.device
+        if prompt_embeds is None:
+            _emit(progress_callback, 0.05, "Encoding prompt")
+            prompt_embeds = self.encode_prompt(prompt, prompt_ids, num_videos, text_encoder_kwargs)
+            if negative_prompt is not None or negative_prompt_ids is not None:
+                negative_prompt_embeds = self.encode_prompt(negative_prompt, negative_prompt_ids, num_videos, text_encoder_kwargs)
         B = prompt_embeds.shape[0]
         num_latent_frames = (duration - 1) // self.vae_scale_factor_temporal + 1
         shape = (B, self.num_channels_latents, num_latent_frames, height // self.vae_scale_factor_spatial,

@@ -145,6 +145,7 @@ def _repoint(params, packed_rows):
 
 
 class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
+    _converter_base = "flux.base"      # which key-converter table original-format weight files / LoRAs go through (converters.py)
     _supports_gradient_checkpointing = False
     _no_split_modules = ["_DoubleBlock", "_SingleBlock"]
 

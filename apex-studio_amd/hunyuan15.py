@@ -118,6 +118,7 @@ class _Embedding(nn.Module):
 
 
 class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
+    _converter_base = "hunyuanvideo15.base"      # which key-converter table original-format weight files / LoRAs go through (converters.py)
     _no_split_modules = ["_Block", "_RefinerBlock"]
 
     def __init__(self, in_channels: int = 65, out_channels: int = 32, num_attention_heads: int = 16,

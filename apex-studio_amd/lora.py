@@ -53,33 +53,44 @@ def state_dict_type(keys: Iterable[str]) -> str:
     return "peft"
 
 
-def normalize_lora_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """PEFT-keyed copy of `sd` with alpha folded into the factors: what `LoraConverter().convert(sd)` returns for
-    the PEFT and lora_down/lora_up ("base") formats.  The Kohya single-file format (module path flattened with
-    underscores) and the two legacy diffusers formats are rejected: their rename tables live in diffusers."""
+def normalize_lora_state_dict(sd: Dict[str, torch.Tensor], model_keys: Optional[Sequence[str]] = None
+                              ) -> Dict[str, torch.Tensor]:
+    """PEFT-keyed copy of `sd` with alpha folded into the factors: what `LoraConverter().convert(sd, model_keys)` returns
+    (lora_converter.py:166-183) for the PEFT, lora_down / lora_up ("base") and Kohya single-file formats.  The two legacy
+    diffusers formats are rejected: their rename tables (DIFFUSERS_TO_PEFT, DIFFUSERS_OLD_TO_PEFT) live in the absent
+    diffusers package."""
+    from .converters import KeyConverter, kohya_to_peft
     kind = state_dict_type(sd.keys())
-    if kind not in ("peft", "base"):
-        raise ValueError(f"LoRA state dict format '{kind}' is not supported by the MI355X backend; "
-                         f"convert it to PEFT (lora_A / lora_B) keys first")
-    out: Dict[str, torch.Tensor] = {}
-    for k, v in sd.items():
-        if k.endswith(".diff") or k.endswith(".diff_b") or "scaled_fp8" in k:   # special_keys_map :92-96
-            continue
-        nk = k
-        if kind == "base":
-            for src, dst in _DOWN.items():
-                nk = nk.replace(src, dst)
-            for p in PREFIXES:                       # BaseConverter strips a unanimous known prefix
-                if nk.startswith(p):
-                    nk = nk[len(p):]
-                    break
-        out[nk] = v
-    for k in [k for k in out if k.endswith(".alpha")]:
-        down_key, up_key = k[:-len(".alpha")] + ".lora_A.weight", k[:-len(".alpha")] + ".lora_B.weight"
+    out: Dict[str, torch.Tensor] = dict(sd)
+    if kind == "kohya_ss":
+        kohya_to_peft(out)
+    elif kind == "base":
+        conv = KeyConverter()
+        conv.rename = dict(_DOWN)
+        conv.post = {".diff_b": conv.drop, ".diff": conv.drop, "scaled_fp8": conv.drop}   # special_keys_map :92-96
+        conv.convert(out, model_keys)
+    elif kind != "peft":
+        raise ValueError(f"LoRA state dict format '{kind}' is not supported by the MI355X backend (its rename table lives in "
+                         f"diffusers); convert it to PEFT (lora_A / lora_B) keys first")
+    for k in [k for k in out if ".alpha" in k]:                 # scale_alpha :152-164
+        down_key, up_key = k.replace(".alpha", ".lora_A.weight"), k.replace(".alpha", ".lora_B.weight")
         if down_key in out and up_key in out:
             sdn, sup = alpha_scales(out[down_key].shape[0], float(out[k].item()))
             out[down_key] = out[down_key] * sdn
             out[up_key] = out[up_key] * sup
+    return out
+
+
+def convert_lora_state_dict(sd: Dict[str, torch.Tensor], model_base: str = "", model_keys: Optional[Sequence[str]] = None
+                            ) -> Dict[str, torch.Tensor]:
+    """`LoraManager.maybe_convert_state_dict` (manager.py:633-644): normalise to PEFT keys, run the MODEL's key converter
+    over the LoRA keys (so `diffusion_model.blocks.N.self_attn.q.lora_down.weight` of the lightx2v files, or a fused
+    `double_blocks.N.img_attn.qkv.lora_up` of a BFL-keyed Flux LoRA, land on `blocks.N.attn1.to_q.lora_A.weight` /
+    per-projection factors), then strip wrapper prefixes against the model's keys."""
+    from .converters import KeyConverter, get_transformer_converter
+    out = normalize_lora_state_dict(sd, model_keys)
+    get_transformer_converter(model_base).convert(out, model_keys)
+    KeyConverter().strip_prefixes(out, model_keys)
     return out
 
 
@@ -166,7 +177,8 @@ class LoraAdapterMixin:
         ads = self._lora_state()
         if adapter_name in ads:
             raise ValueError(f"adapter '{adapter_name}' is already loaded")
-        mods = split_modules(normalize_lora_state_dict(state_dict), prefix)
+        keys = [k for k, _ in self.named_parameters()]
+        mods = split_modules(convert_lora_state_dict(state_dict, getattr(self, "_converter_base", ""), keys), prefix)
         if not mods:
             raise ValueError("no LoRA tensors found in the state dict")
         for m, d in mods.items():                      # validate before touching anything

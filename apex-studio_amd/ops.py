@@ -822,9 +822,13 @@ def conv3d_cl_norm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch
     cout, kpad = w_packed.shape
     # (float activations — the verification mode — always take the two-launch form: same values, no fused tile)
     if x.dtype == torch.float32 or gamma.numel() != cout or not conv3d_cl_norm_fusable(x, cout, upsample2x):
+        if gamma.numel() != cout:
+            # the RMS norm divides by sqrt(channel count): a gamma shorter than the packed Cout (a Cout that is not a multiple
+            # of 4 gets zero rows in the packed weight) would silently normalise over the padded width
+            raise _l.ApexMIError(f"conv3d_cl_norm: gamma has {gamma.numel()} entries for {cout} (packed) output channels; the "
+                                 f"fused / separate RMS norm needs the layer's channel count to equal the packed one")
         y = conv3d_cl(x, w_packed, bias, ksize, residual=residual, upsample2x=upsample2x, independent_frames=independent_frames)
-        g = gamma if gamma.numel() == cout else torch.cat([gamma, gamma.new_zeros(cout - gamma.numel())])
-        return (y if want_raw else None), rmsnorm_cl(y, g, silu=silu)
+        return (y if want_raw else None), rmsnorm_cl(y, gamma, silu=silu)
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous() and gamma.is_contiguous()
     T, H, W, cin = x.shape
     Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)

@@ -66,6 +66,7 @@ class _TimeTextEmbed(nn.Module):
 
 
 class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
+    _converter_base = "qwenimage.base"      # which key-converter table original-format weight files / LoRAs go through (converters.py)
     _no_split_modules = ["_QwenBlock"]
 
     def __init__(self, patch_size: int = 2, in_channels: int = 64, out_channels: Optional[int] = 16,

@@ -85,6 +85,17 @@ def broadcast_parameters(modules, src: int = 0, group=None, bucket_bytes: int = 
                 "world": 1, "tensors": len(tensors), "buckets": 0}
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = tensors[0].device
+    # every rank must have built the same (order, size, dtype) list — the dedup of tied weights keys on data_ptr, so a tie that
+    # exists on one rank only would shift every later offset and the receivers would silently get wrong bytes.  Compare a
+    # digest of the layout on ALL ranks before anything moves, and fail on all of them together.
+    import hashlib
+    layout = hashlib.sha256(repr([(t.numel(), str(t.dtype)) for t in tensors]).encode()).digest()[:8]
+    mine = torch.frombuffer(bytearray(layout), dtype=torch.uint8).to(dev)
+    seen = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine, group=group)
+    if any(not torch.equal(s.cpu(), mine.cpu()) for s in seen):
+        raise RuntimeError(f"broadcast_parameters: rank {rank} enumerates {len(tensors)} tensors with a different (size, dtype) "
+                           f"layout than another rank — construct the same classes with the same configuration on every rank")
     pad = 16 * world                                          # every bucket a multiple of the world size and 16 B
     buckets, cur, cur_n = [], [], 0
     for t in tensors:

@@ -140,8 +140,10 @@ class _Posterior:
         return self.mean
 
     def sample(self, generator=None):
-        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
-        return self.mean + self.std * noise.to(self.mean.dtype)
+        # diffusers' DiagonalGaussianDistribution draws with randn_tensor(dtype=parameters.dtype): same stream, same values
+        dev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=dev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
 
 
 class _Decoder(nn.Module):
@@ -381,7 +383,7 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
     @torch.no_grad()
     def _encode_one(self, x):
         """x [3, T, H, W] in [-1, 1] -> moments [2 C, T', H/16, W/16] bf16 (`_encode` / `tiled_encode`, model.py:890-897,
-        :994-1058: 256-px tiles at stride 192, blended over 25 % of a latent tile)."""
+        :994-1058: 128-px tiles at stride 96, blended over 25 % of a latent tile)."""
         if x.device.type != "cuda" or self.dtype != torch.bfloat16:
             raise _l.ApexMIError("hunyuanvideo15_mi355 VAE needs bf16 weights and pixels on a ROCm device (no CPU fallback)")
         Cc, T, H, W = x.shape

@@ -319,8 +319,7 @@ class AutoencoderKLWan(nn.Module):
         tensor; shapes the fused tiles do not cover fall back to the two launches inside `ops.conv3d_cl_norm`."""
         w, b = self._w(conv)
         k = conv.ksize if len(conv.ksize) == 3 else (1,) + conv.ksize
-        g = gamma if gamma.numel() == w.shape[0] else torch.cat([gamma, gamma.new_zeros(w.shape[0] - gamma.numel())])
-        return ops.conv3d_cl_norm(x, w, b, k, g, silu=silu, residual=residual, want_raw=want_raw, upsample2x=upsample2x,
+        return ops.conv3d_cl_norm(x, w, b, k, gamma, silu=silu, residual=residual, want_raw=want_raw, upsample2x=upsample2x,
                                   independent_frames=self._indep and k[0] > 1)
 
     def _res(self, blk: _Res, x, xn=None, next_norm=None):

@@ -79,6 +79,7 @@ class _Conv3dParams(nn.Module):
 
 
 class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
+    _converter_base = "wan.base"      # which key-converter table original-format weight files / LoRAs go through (converters.py)
     _no_split_modules = ["_WanBlock"]
 
     def __init__(self, patch_size: Tuple[int, int, int] = (1, 2, 2), num_attention_heads: int = 40,

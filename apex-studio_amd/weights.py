@@ -20,18 +20,36 @@ import torch
 FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 
 
-def iter_checkpoint(files: Sequence[str]) -> Iterator[Tuple[str, Callable[[], torch.Tensor]]]:
-    """(key, loader) for every tensor of every shard; `loader()` reads that one tensor to the host."""
+def iter_checkpoint(files: Sequence[str], converter=None, key_map: Optional[Dict[str, str]] = None,
+                    model_keys: Optional[Sequence[str]] = None) -> Iterator[Tuple[str, Callable[[], torch.Tensor]]]:
+    """(key, loader) for every tensor of every shard; `loader()` reads that one tensor to the host.
+
+    With a `converter` (converters.get_transformer_converter: original-format Wan / BFL-Flux files), every file's keys go
+    through `key_map` and the converter FIRST, as the reference does per weight file (loader_mixin.py:462-473) — but on
+    placeholders: no tensor is read to decide the plan, and a target that is a row range of a fused tensor (q / k / v of
+    `img_attn.qkv.weight`, the four parts of `linear1`) is read with safetensors' `get_slice`."""
+    from .converters import Src
     for path in files:
         if path.endswith(".safetensors"):
             from safetensors import safe_open
             f = safe_open(path, framework="pt", device="cpu")
-            for k in f.keys():
-                yield k, (lambda f=f, k=k: f.get_tensor(k))
+            if converter is None:
+                for k in f.keys():
+                    yield remap_key(k, key_map), (lambda f=f, k=k: f.get_tensor(k))
+                continue
+            plan = {remap_key(k, key_map): Src(k, tuple(f.get_slice(k).get_shape())) for k in f.keys()}
+            get, rows = f.get_tensor, (lambda k, a, b, f=f: f.get_slice(k)[a:b])
         else:
             sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
-            for k, v in sd.items():
-                yield k, (lambda v=v: v)
+            if converter is None:
+                for k, v in sd.items():
+                    yield remap_key(k, key_map), (lambda v=v: v)
+                continue
+            plan = {remap_key(k, key_map): Src(k, tuple(v.shape)) for k, v in sd.items()}
+            get, rows = sd.__getitem__, None
+        converter.convert(plan, list(model_keys) if model_keys is not None else None)
+        for k, src in plan.items():
+            yield k, (lambda src=src, get=get, rows=rows: src.read(get, rows))
 
 
 def remap_key(key: str, key_map: Optional[Dict[str, str]]) -> str:
@@ -45,16 +63,26 @@ def remap_key(key: str, key_map: Optional[Dict[str, str]]) -> str:
 
 @torch.no_grad()
 def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: Optional[Dict[str, str]] = None,
-                         strict: bool = False) -> Tuple[List[str], List[str]]:
+                         strict: bool = False, converter="auto") -> Tuple[List[str], List[str]]:
     """Stream `files` into `model` (already on the GPU, bf16).  Returns (missing_keys, unexpected_keys) like
     `load_state_dict(strict=False)`; `strict=True` raises on either.  Shapes must match exactly, except that a
-    0-d / 1-element `scale_weight` may pair with any weight (scaled_layer.py:444-493)."""
+    0-d / 1-element `scale_weight` may pair with any weight (scaled_layer.py:444-493).
+
+    `converter`: the checkpoint key converter the files go through per file, as the reference's loader does
+    (loader_mixin.py:473 `converter.convert(state_dict, model_keys)`): "auto" = the table of the model's family
+    (`model._converter_base`; original-format Wan / BFL-Flux files are renamed and split on the fly, diffusers-keyed files
+    pass through the converter's own already-converted test), None = keys are taken as they are, or a converters.KeyConverter."""
     from . import ops
     targets: Dict[str, torch.Tensor] = dict(model.named_parameters())
     targets.update({k: v for k, v in model.named_buffers() if k not in targets})
     if any(not t.is_cuda for t in targets.values()):
         raise RuntimeError("load_checkpoint_into: move the model to the GPU first (there is no CPU path)")
-    entries = [(remap_key(k, key_map), ld) for k, ld in iter_checkpoint(files)]
+    if converter == "auto":
+        from .converters import NoOpKeyConverter, get_transformer_converter
+        converter = get_transformer_converter(getattr(model, "_converter_base", ""))
+        if isinstance(converter, NoOpKeyConverter):
+            converter = None
+    entries = list(iter_checkpoint(files, converter, key_map, list(targets)))
     scales = {k[:-len("scale_weight")]: ld for k, ld in entries if k.endswith("scale_weight")}
     seen, unexpected = set(), []
     for key, ld in entries:

@@ -170,7 +170,8 @@ def load_by_path(name, rel):
     return mod
 
 
-from tests.golden.seeded import seeded, synthetic_state_dict, text_encoder_state_dict, vae_synthetic_state_dict  # noqa: E402
+from tests.golden.seeded import (seeded, spec_tensors, synthetic_state_dict, tensor_digest, text_encoder_state_dict,  # noqa: E402
+                                 vae_synthetic_state_dict)
 
 
 def gen_attention():
@@ -957,6 +958,131 @@ def gen_leaf_pins():
                              sigmas=sch.sigmas.clone(), traj=traj)
     torch.save(out, os.path.join(OUT, "leaf_pins.pt"))
     print("leaf_pins.pt", sorted(out))
+
+
+from tests.golden.make_golden_specs import flux_original_spec, wan_original_spec  # noqa: E402
+
+
+def gen_convert():
+    """tests/golden/convert_keys.pt: the reference's OWN checkpoint / LoRA key converters run on seeded original-format state
+    dicts (dict operations and torch.chunk / split / cat only):
+      WanTransformerConverter, FluxTransformerConverter   R/src/converters/transformer_converters.py:134-198, 1372-1840
+      LoraManager.maybe_convert_state_dict's pipeline      R/src/lora/manager.py:633-644 (LoraConverter -> model converter ->
+                                                           prefix strip), incl. the Kohya un-flattening lora_converter.py:185-255
+    Stubs: src.quantize.ggml_ops' cat / chunk / split are torch's for plain tensors (their GGML branches need the gguf
+    package); the diffusers rename tables of the two legacy LoRA formats are not exercised.  The fixture holds input specs
+    (key -> shape, seed base) and the converted keys with their tensors."""
+    _mod("diffusers.utils.state_dict_utils", DIFFUSERS_TO_PEFT={}, DIFFUSERS_OLD_TO_PEFT={})
+    q = _mod("src.quantize")
+    q.__path__ = []
+    _mod("src.quantize.ggml_ops", ggml_cat=lambda ts, dim=0: torch.cat(list(ts), dim=dim),
+         ggml_chunk=lambda t, n, dim=0: torch.chunk(t, n, dim=dim), ggml_split=lambda t, s, dim=0: torch.split(t, s, dim=dim))
+    import diffusers
+    if not hasattr(diffusers, "ModelMixin"):
+        diffusers.ModelMixin = type("ModelMixin", (), {})
+    cp = _mod("src.converters")
+    cp.__path__ = [os.path.join(REF, "src/converters")]
+    tc = load_by_path("src.converters.transformer_converters", "src/converters/transformer_converters.py")
+    lc = load_by_path("ref_lora_converter2", "src/lora/lora_converter.py")
+    from oracle import flux as OF, wan as OW
+    wan_cfg = dict(patch_size=(1, 2, 2), num_attention_heads=1, attention_head_dim=64, in_channels=16, out_channels=16, text_dim=32,
+                   freq_dim=32, ffn_dim=128, num_layers=2, cross_attn_norm=True, eps=1e-6)
+    flux_cfg = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=1,
+                    joint_attention_dim=96, pooled_projection_dim=48, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    wan_keys = sorted(OW.WanTransformer3DModel(**wan_cfg).state_dict().keys())
+    flux_keys = sorted(OF.FluxTransformer2DModel(**flux_cfg).state_dict().keys())
+    cases = {}
+
+    def run(name, conv_fn, spec, seed0, model_keys, prefix="", extra=None):
+        sd = {prefix + k: v for k, v in spec_tensors(spec, seed0).items()}
+        if extra:
+            sd.update(extra)
+        inp_keys = list(sd)
+        out = conv_fn({k: v.clone() for k, v in sd.items()}, None if model_keys is None else list(model_keys))
+        cases[name] = dict(spec={k: tuple(v) for k, v in spec.items()}, seed0=seed0, prefix=prefix, model_keys=model_keys,
+                           extra=extra, inp_keys=inp_keys, out={k: tensor_digest(v) for k, v in out.items()})
+        print("convert", name, len(inp_keys), "->", len(out), sorted(out)[:2])
+
+    # 1. Wan original file, with and without model keys; 2. the same behind `model.diffusion_model.` with fp8 markers
+    run("wan_original", lambda sd, mk: tc.WanTransformerConverter().convert(sd, mk), wan_original_spec(), 1000, wan_keys)
+    run("wan_original_no_model_keys", lambda sd, mk: tc.WanTransformerConverter().convert(sd, mk), wan_original_spec(), 1000, None)
+    scales = {f"model.diffusion_model.blocks.{i}.self_attn.{n}.scale_weight": torch.tensor(0.5 + i + j)
+              for i in range(2) for j, n in enumerate(("q", "k", "v", "o"))}
+    scales["model.diffusion_model.scaled_fp8"] = torch.zeros(2)
+    # reference quirk, pinned as it is: the ".diff" drop marker is a substring of ".diffusion_model", so a file whose keys are
+    # wrapped in `model.diffusion_model.` loses EVERY key in the Wan converter's pre-pass (the Kijai files are not wrapped)
+    run("wan_fp8_wrapped", lambda sd, mk: tc.WanTransformerConverter().convert(sd, mk), wan_original_spec(), 1100, wan_keys,
+        prefix="model.diffusion_model.", extra=scales)
+    run("wan_fp8_kijai", lambda sd, mk: tc.WanTransformerConverter().convert(sd, mk), wan_original_spec(), 1100, wan_keys,
+        extra={k[len("model.diffusion_model."):]: v for k, v in scales.items()})
+    run("wan_already_converted", lambda sd, mk: tc.WanTransformerConverter().convert(sd, mk),
+        {k: tuple(v.shape) for k, v in OW.WanTransformer3DModel(**wan_cfg).state_dict().items()}, 1200, wan_keys)
+    # 3. Flux BFL file (guidance group, fused qkv / linear1, final-layer swap); a shard that holds only half of a linear1 pair
+    run("flux_bfl", lambda sd, mk: tc.FluxTransformerConverter().convert(sd, mk), flux_original_spec(), 2000, flux_keys)
+    run("flux_bfl_no_model_keys", lambda sd, mk: tc.FluxTransformerConverter().convert(sd, mk), flux_original_spec(), 2000, None)
+    half = {k: v for k, v in flux_original_spec().items() if k.startswith("single_blocks.1.") and not k.endswith("linear1.bias")}
+    half.update({k: v for k, v in flux_original_spec().items() if k.startswith("guidance_in.in_layer")})
+    run("flux_partial_shard", lambda sd, mk: tc.FluxTransformerConverter().convert(sd, mk), half, 2100, None)
+    run("flux_already_converted", lambda sd, mk: tc.FluxTransformerConverter().convert(sd, mk),
+        {k: tuple(v.shape) for k, v in OF.FluxTransformer2DModel(**flux_cfg).state_dict().items()}, 2200, flux_keys)
+
+    # 4. LoRAs through LoraManager.maybe_convert_state_dict's pipeline
+    def lora_pipeline(conv_cls):
+        def f(sd, mk):
+            l = lc.LoraConverter()
+            l.convert(sd, mk)
+            conv_cls().convert(sd, mk)
+            l._strip_known_prefixes_inplace(sd, model_keys=mk)
+            return sd
+        return f
+    r = 4
+    lx = {}
+    for i in range(2):
+        for a, n in (("self_attn", "q"), ("self_attn", "o"), ("cross_attn", "k"), ("cross_attn", "v")):
+            m = f"diffusion_model.blocks.{i}.{a}.{n}"
+            lx[m + ".lora_down.weight"] = (r, 64)
+            lx[m + ".lora_up.weight"] = (64, r)
+            lx[m + ".alpha"] = ()
+        lx[f"diffusion_model.blocks.{i}.ffn.0.lora_down.weight"] = (r, 64)
+        lx[f"diffusion_model.blocks.{i}.ffn.0.lora_up.weight"] = (128, r)
+        lx[f"diffusion_model.blocks.{i}.ffn.2.lora_down.weight"] = (r, 128)
+        lx[f"diffusion_model.blocks.{i}.ffn.2.lora_up.weight"] = (64, r)
+        lx[f"diffusion_model.blocks.{i}.cross_attn.k.diff_b"] = (64,)
+        lx[f"diffusion_model.blocks.{i}.cross_attn.norm_k.diff"] = (64,)
+    run("wan_lightx2v_lora", lora_pipeline(tc.WanTransformerConverter), lx, 3000, wan_keys)
+    fl = {}
+    D = 3072      # a LoRA file does not reveal the model width: the reference falls back to FLUX.1-dev's (3072, mlp ratio 4)
+    for kind_a, kind_b, pre in (("lora_A", "lora_B", ""), ("lora_down", "lora_up", "unet.")):
+        i = 0 if kind_a == "lora_A" else 1
+        for s_ in ("img_attn", "txt_attn"):
+            fl[f"{pre}double_blocks.{i}.{s_}.qkv.{kind_a}.weight"] = (r, D)
+            fl[f"{pre}double_blocks.{i}.{s_}.qkv.{kind_b}.weight"] = (3 * D, r)
+            fl[f"{pre}double_blocks.{i}.{s_}.proj.{kind_a}.weight"] = (r, D)
+            fl[f"{pre}double_blocks.{i}.{s_}.proj.{kind_b}.weight"] = (D, r)
+        fl[f"{pre}single_blocks.{i}.linear1.{kind_a}.weight"] = (r, D)
+        fl[f"{pre}single_blocks.{i}.linear1.{kind_b}.weight"] = (7 * D, r)
+        fl[f"{pre}single_blocks.{i}.linear2.{kind_a}.weight"] = (r, 5 * D)
+        fl[f"{pre}single_blocks.{i}.linear2.{kind_b}.weight"] = (D, r)
+    run("flux_bfl_lora_peft_keys", lora_pipeline(tc.FluxTransformerConverter), {k: v for k, v in fl.items() if "lora_A" in k or "lora_B" in k},
+        3100, flux_keys)
+    run("flux_bfl_lora_base_keys", lora_pipeline(tc.FluxTransformerConverter), {k: v for k, v in fl.items() if "lora_down" in k or "lora_up" in k},
+        3200, flux_keys)
+    ko = {}
+    for m, (o, i_) in (("lora_unet_double_blocks_0_img_attn_qkv", (3 * D, D)), ("lora_unet_double_blocks_0_txt_attn_proj", (D, D)),
+                       ("lora_unet_single_blocks_1_linear2", (D, 5 * D)), ("lora_unet_double_blocks_1_img_mlp_0", (4 * D, D)),
+                       ("lora_unet_single_blocks_0_linear1", (7 * D, D)), ("lora_unet_final_layer_linear", (64, D))):
+        ko[m + ".lora_down.weight"] = (r, i_)
+        ko[m + ".lora_up.weight"] = (o, r)
+        ko[m + ".alpha"] = ()
+    run("flux_kohya_lora", lora_pipeline(tc.FluxTransformerConverter), ko, 3300, flux_keys)
+    kw = {}
+    for m, (o, i_) in (("lora_unet_blocks_0_self_attn_q", (64, 64)), ("lora_unet_blocks_1_cross_attn_o", (64, 64)),
+                       ("lora_unet_blocks_1_ffn_0", (128, 64))):
+        kw[m + ".lora_down.weight"] = (r, i_)
+        kw[m + ".lora_up.weight"] = (o, r)
+        kw[m + ".alpha"] = ()
+    run("wan_kohya_lora", lora_pipeline(tc.WanTransformerConverter), kw, 3400, wan_keys)
+    torch.save(dict(cases=cases, wan_cfg=wan_cfg, flux_cfg=flux_cfg), os.path.join(OUT, "convert_keys.pt"))
 
 
 def gen_leaf_pins2():

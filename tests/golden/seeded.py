@@ -54,3 +54,17 @@ def text_encoder_state_dict(model, seed: int, norm_seed: int, norm_tag: str):
     for k in [k for k in sd if k.endswith("embed_tokens.weight") or k.endswith("patch_embed.proj.weight")]:
         sd[k] = sd[k] * 16.0           # O(1) embeddings, as trained ones are (the synthetic draw is 1/sqrt(fan_in))
     return sd
+
+
+def spec_tensors(spec, seed0):
+    """key -> seeded tensor (seed = seed0 + index in sorted key order); 0-d entries become scalars."""
+    return {k: (seeded(tuple(sh), seed0 + i) if len(sh) else torch.tensor(float(1 + (seed0 + i) % 7)))
+            for i, (k, sh) in enumerate(sorted(spec.items()))}
+
+
+def tensor_digest(t):
+    """(shape, dtype, sha1 of the contiguous bytes): the converters only move, slice and re-join tensors, and the LoRA alpha
+    folding multiplies by powers of two, so equality is exact and a digest pins it as well as the values would."""
+    import hashlib
+    t = t.detach().contiguous()
+    return tuple(t.shape), str(t.dtype), hashlib.sha1(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"").hexdigest()

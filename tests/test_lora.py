@@ -37,8 +37,9 @@ def test_oracle_fold_alpha_matches_reference():
 def test_unsupported_formats_and_shapes_raise():
     import apex_studio_amd  # noqa: F401
     from apex_studio_amd import lora
-    with pytest.raises(ValueError, match="kohya_ss"):
-        lora.normalize_lora_state_dict({"lora_unet_blocks_0_attn1_to_k.lora_down.weight": torch.zeros(4, 8)})
+    # Kohya single-file keys are accepted since round 3 (restatement of lora_converter.py:185-255, tests/test_converters.py)
+    out = lora.normalize_lora_state_dict({"lora_unet_double_blocks_0_img_attn_proj.lora_down.weight": torch.zeros(4, 8)})
+    assert list(out) == ["unet.double_blocks.0.img_attn.proj.lora_A.weight"]
     with pytest.raises(ValueError, match="diffusers_old"):
         lora.normalize_lora_state_dict({"blocks.0.attn.to_q_lora.down.weight": torch.zeros(4, 8)})
     with pytest.raises(ValueError, match="lacks"):

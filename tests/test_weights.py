@@ -124,3 +124,103 @@ def test_streaming_loader_into_packed_flux(tmp_path):
               str(tmp_path / "d.safetensors"))
     with pytest.raises(TypeError, match="not fp8"):
         weights.load_checkpoint_into(m, [str(tmp_path / "d.safetensors")])
+
+
+# ---------------------------------------------------------------- original-format files (round 3)
+def _original_files(tmp_path):
+    """An ORIGINAL-format Wan file whose attention projections are fp8-scaled (the Kijai layout: `blocks.N.self_attn.q.weight`
+    in float8_e4m3fn + `blocks.N.self_attn.q.scale_weight` + a `scaled_fp8` marker) and a BFL-format Flux file, written as
+    safetensors; returns (paths, the state dicts as real tensors, model configs)."""
+    from oracle import flux as OF, wan as OWan
+    from safetensors.torch import save_file
+    from tests.golden.make_golden_specs import flux_original_spec, wan_original_spec
+    from tests.golden.seeded import spec_tensors
+    wan_cfg = dict(patch_size=(1, 2, 2), num_attention_heads=1, attention_head_dim=128, in_channels=16, out_channels=16,
+                   text_dim=64, freq_dim=256, ffn_dim=256, num_layers=2, cross_attn_norm=True, eps=1e-6)
+    flux_cfg = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128,
+                    num_attention_heads=1, joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True,
+                    axes_dims_rope=(16, 56, 56))
+    wan = {k: v.to(torch.bfloat16) for k, v in spec_tensors(wan_original_spec(dim=128, ffn=256, text_dim=64, freq=256), 5000).items()}
+    for k in [k for k in wan if ".self_attn." in k and k.endswith(".weight") and wan[k].dim() == 2]:
+        w = wan[k].float()
+        s = (w.abs().max() / 448.0).reshape(())
+        wan[k] = (w / s).to(torch.float8_e4m3fn)
+        wan[k[:-len("weight")] + "scale_weight"] = s
+    wan["scaled_fp8"] = torch.zeros(2, dtype=torch.float8_e4m3fn)
+    flux = {k: v.to(torch.bfloat16) for k, v in spec_tensors(flux_original_spec(dim=128, txt=128, pooled=64), 6000).items()}
+    pw, pf = str(tmp_path / "wan_orig.safetensors"), str(tmp_path / "flux_bfl.safetensors")
+    save_file({k: v.contiguous() for k, v in wan.items()}, pw)
+    save_file({k: v.contiguous() for k, v in flux.items()}, pf)
+    return (pw, pf), (wan, flux), (wan_cfg, flux_cfg), (OWan, OF)
+
+
+def test_original_format_files_stream_through_the_converter(tmp_path):
+    """iter_checkpoint(converter=...): the per-file plan built on placeholders yields exactly what converting the real
+    tensors yields (which tests/test_converters.py pins to the reference), fused tensors are read by row range."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import converters as CV, weights
+    (pw, pf), (wan, flux), (wan_cfg, flux_cfg), (OWan, OF) = _original_files(tmp_path)
+    for path, sd, conv, orc in ((pw, wan, CV.WanKeyConverter, OWan.WanTransformer3DModel(**wan_cfg)),
+                                (pf, flux, CV.FluxKeyConverter, OF.FluxTransformer2DModel(**flux_cfg))):
+        mk = list(orc.state_dict().keys())
+        want = conv().convert(dict(sd), list(mk))
+        got = {k: ld() for k, ld in weights.iter_checkpoint([path], conv(), None, mk)}
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k].reshape(-1).view(torch.uint8), want[k].contiguous().reshape(-1).view(torch.uint8)), k
+        extra = {k for k in got if k not in mk}
+        assert extra == {k for k in got if k.endswith("scale_weight")}, extra      # every other key is a model parameter
+        assert set(mk) - set(got) == set()
+
+
+@pytest.mark.gpu
+def test_original_format_checkpoints_load_into_the_packed_models(tmp_path):
+    """An original-key, fp8-scaled Wan file and a BFL Flux file through `load_checkpoint_into` (converter = the family's
+    table): every parameter of the packed model equals the converted (and dequantised) tensor bit for bit, nothing is
+    missing, only the consumed `scale_weight` entries are left over."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import converters as CV, weights
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from apex_studio_amd.wan import WanTransformer3DModel
+    (pw, pf), (wan, flux), (wan_cfg, flux_cfg), _ = _original_files(tmp_path)
+    for path, sd, conv, cls, cfg in ((pw, wan, CV.WanKeyConverter, WanTransformer3DModel, wan_cfg),
+                                     (pf, flux, CV.FluxKeyConverter, FluxTransformer2DModel, flux_cfg)):
+        m = cls(**cfg, device=DEV, dtype=torch.bfloat16)
+        m.pack()
+        missing, unexpected = weights.load_checkpoint_into(m, [path])
+        assert missing == [] and unexpected == [], (missing[:4], unexpected[:4])
+        want = conv().convert(dict(sd), [k for k, _ in m.named_parameters()])
+        got = m.state_dict()
+        for k, v in want.items():
+            if k.endswith("scale_weight"):
+                continue
+            if v.dtype in weights.FP8_DTYPES:
+                v = OW.dequant(v, want[k[:-len("weight")] + "scale_weight"])
+            assert torch.equal(got[k].cpu(), v.to(torch.bfloat16)), k
+
+
+@pytest.mark.gpu
+def test_lightx2v_keyed_lora_merges_like_its_peft_twin(golden_dir):
+    """A LoRA keyed like the lightx2v Wan files (`diffusion_model.blocks.N.self_attn.q.lora_down.weight`, alpha, diff
+    vectors) loaded into the HIP Wan model merges to the same weights, bit for bit, as the same adapter given in PEFT keys."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import lora
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from oracle import wan as OWan
+    from tests.golden.seeded import spec_tensors, synthetic_state_dict
+    c = torch.load(os.path.join(golden_dir, "convert_keys.pt"), weights_only=False)
+    case, cfg = c["cases"]["wan_lightx2v_lora"], c["wan_cfg"]
+    sd_model = synthetic_state_dict(OWan.WanTransformer3DModel(**cfg), 9)
+    raw = spec_tensors(case["spec"], case["seed0"])
+    twins = []
+    for form in ("lightx2v", "peft"):
+        m = WanTransformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+        m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd_model.items()}, strict=True)
+        m.pack()
+        sd = raw if form == "lightx2v" else lora.convert_lora_state_dict(raw, "wan.base", [k for k, _ in m.named_parameters()])
+        m.load_lora_adapter({k: v.clone() for k, v in sd.items()}, adapter_name="lx")
+        twins.append({k: v.clone() for k, v in m.state_dict().items()})
+    changed = [k for k in twins[0] if not torch.equal(twins[0][k].cpu().float(), sd_model[k].to(torch.bfloat16).float())]
+    assert len(changed) == 12 and all(".attn" in k or ".ffn" in k for k in changed), changed
+    for k in twins[0]:
+        assert torch.equal(twins[0][k], twins[1][k]), k

@@ -63,18 +63,22 @@ def flux(steps):
     model.pack()
     vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
     eng = FluxT2IEngine(model, decode_fn=lambda z: vae.decode(vae.denormalize_latents(z.float()).to(vae.dtype),
-                                                               return_dict=False)[0])
+                                                               return_dict=False)[0], text_encoder=clip, text_encoder_2=t5)
     ids5 = torch.randint(3, 30000, (1, 512), device=dev)
     idsc = torch.randint(3, 49000, (1, 77), device=dev)
     idsc[0, 40] = 49407
     result = {}
     for rep in range(2):            # the first pass packs weights and sizes workspaces
         tm = Timer()
-        emb = tm("t5_xxl_encode", lambda: t5(input_ids=ids5).last_hidden_state)
-        pooled = tm("clip_l_encode", lambda: clip(input_ids=idsc).pooler_output)
+        emb, pooled, _ = tm("clip_l+t5_xxl_encode", lambda: eng.encode_prompt(prompt_ids=idsc, prompt_2_ids=ids5))
         img = tm(f"denoise_{steps}_steps+vae_decode", lambda: eng.run(emb, pooled, num_inference_steps=steps, seed=1))
         frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frame(img, "uint8"))
-        result = dict(tm.t, total_ms=round(sum(tm.t.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
+        # and the whole clip as ONE engine call: token ids in, uint8 frames out
+        whole = tm("engine.run(prompt_ids -> uint8 frames)", lambda: eng.run(prompt_ids=idsc, prompt_2_ids=ids5,
+                                                                             num_inference_steps=steps, seed=1, output_type="uint8"))
+        assert torch.equal(whole, frames)
+        stages = {k: v for k, v in tm.t.items() if not k.startswith("engine.run")}
+        result = dict(tm.t, total_ms=round(sum(stages.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
     return result
 
 
@@ -87,7 +91,7 @@ def qwen(steps):
     model = QwenImageTransformer2DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=2)
     model.pack()
     vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
-    eng = QwenImageEditPlusEngine(model, vae=vae)
+    eng = QwenImageEditPlusEngine(model, vae=vae, text_encoder=vl)
     IMG = vl.config.image_token_id
     seq = list(range(100, 164)) + [IMG] * 196 + list(range(300, 420))          # template + one 392x392 view + prompt
     ids = torch.tensor([seq], device=dev)
@@ -97,15 +101,19 @@ def qwen(steps):
     result = {}
     for rep in range(2):
         tm = Timer()
-        hs = tm("qwen2_5_vl_7b_encode", lambda: vl(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=pix,
-                                                    image_grid_thw=grid, output_hidden_states=True).hidden_states[-1])
-        emb = hs[:, 64:]                                                        # drop the template tokens
+        inputs = dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=pix, image_grid_thw=grid)
+        emb, _ = tm("qwen2_5_vl_7b_encode", lambda: eng.encode_prompt(inputs, drop_idx=64))       # template tokens dropped
         lat = tm("vae_encode_1024", lambda: eng.prepare_image_latents(image))
         img = tm(f"denoise_{steps}_steps+vae_decode",
                  lambda: eng.run(prompt_embeds=emb, image_latents=lat[0], image_shapes=lat[1], height=1024, width=1024,
                                  num_inference_steps=steps, seed=1, return_latents=False))
         frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frame(img, "uint8"))
-        result = dict(tm.t, total_ms=round(sum(tm.t.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
+        whole = tm("engine.run(ids + pixels -> uint8 frames)",
+                   lambda: eng.run(prompt_inputs=inputs, images=image, height=1024, width=1024, num_inference_steps=steps, seed=1,
+                                   output_type="uint8"))
+        assert torch.equal(whole, frames)
+        stages = {k: v for k, v in tm.t.items() if not k.startswith("engine.run")}
+        result = dict(tm.t, total_ms=round(sum(stages.values()), 2), frames=list(frames.shape), dtype=str(frames.dtype))
     return result
 
 
@@ -116,13 +124,13 @@ def wan(steps):
     umt5 = init(TE.UMT5EncoderModel({}, device=dev), 1)
     hi = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(2)
     lo = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(3)
-    eng = WanT2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6))
+    eng = WanT2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6), text_encoder=umt5)
     ids = torch.randint(3, 30000, (1, 512), device=dev)
     mask = torch.ones_like(ids)
     mask[0, 300:] = 0
     tm = Timer()
-    emb = tm("umt5_xxl_encode", lambda: umt5(input_ids=ids, attention_mask=mask).last_hidden_state)
-    emb = tm("umt5_xxl_encode", lambda: umt5(input_ids=ids, attention_mask=mask).last_hidden_state)     # second pass
+    emb = tm("umt5_xxl_encode", lambda: eng.encode_prompt(prompt_ids=(ids, mask)))
+    emb = tm("umt5_xxl_encode", lambda: eng.encode_prompt(prompt_ids=(ids, mask)))     # second pass
     video = tm(f"denoise_{steps}_steps+vae_decode", lambda: eng.run(prompt_embeds=emb, height=720, width=1280, duration=81,
                                                                     num_inference_steps=steps, seed=1))
     frames = tm("frames_to_u8", lambda: postprocess.tensor_to_frames(video, "uint8"))
