@@ -85,8 +85,8 @@ class FluxT2IEngine(EngineLoraMixin):
         from .prompt import split_ids
         if self.text_encoder is None or self.text_encoder_2 is None:
             raise RuntimeError("FluxT2IEngine: prompts need text_encoder (CLIP) and text_encoder_2 (T5); or pass prompt_embeds")
-        k1 = dict(max_sequence_length=77, pad_with_zero=False, **(text_encoder_kwargs or {}))
-        k2 = dict(max_sequence_length=512, pad_with_zero=False, **(text_encoder_2_kwargs or {}))
+        k1 = {"max_sequence_length": 77, "pad_with_zero": False, **(text_encoder_kwargs or {})}
+        k2 = {"max_sequence_length": 512, "pad_with_zero": False, **(text_encoder_2_kwargs or {})}
         if prompt_2 is None and prompt_2_ids is None:            # `if not prompt_2: prompt_2 = prompt` — same TEXT for both encoders
             if prompt is None:
                 raise ValueError("token ids are per tokenizer: pass prompt_2_ids (T5) next to prompt_ids (CLIP)")

@@ -99,7 +99,7 @@ class WanT2VEngine(EngineLoraMixin):
         from .prompt import split_ids
         if self.text_encoder is None:
             raise RuntimeError("WanT2VEngine: prompts need a text_encoder (UMT5); or pass prompt_embeds")
-        kw = dict(use_attention_mask=True, **(text_encoder_kwargs or {}))
+        kw = {"use_attention_mask": True, **(text_encoder_kwargs or {})}
         a = dict(text=prompt) if prompt_ids is None else dict(zip(("input_ids", "attention_mask"), split_ids(prompt_ids)))
         return self.text_encoder.encode(num_videos_per_prompt=num_videos, **a, **kw)
 

@@ -76,7 +76,7 @@ def test_wan_ids_to_frames():
     from apex_studio_amd.engine_wan import WanT2VEngine
     from apex_studio_amd.vae_wan import AutoencoderKLWan
     from apex_studio_amd.wan import WanTransformer3DModel
-    cfg = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=64,
+    cfg = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=128,
                freq_dim=256, ffn_dim=512, num_layers=2, cross_attn_norm=True, eps=1e-6)
     experts = []
     for seed in (9, 10):
@@ -86,7 +86,7 @@ def test_wan_ids_to_frames():
     vae = AutoencoderKLWan(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True],
                            device=DEV, dtype=BF)
     vae.load_state_dict({k: v.to(BF) for k, v in vae_synthetic_state_dict(vae, 23).items()}, strict=True)
-    umt5 = _init(TE.UMT5EncoderModel(dict(vocab_size=150, d_model=64, d_kv=64, d_ff=128, num_layers=2, num_heads=1), device=DEV), 5)
+    umt5 = _init(TE.UMT5EncoderModel(dict(vocab_size=150, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2), device=DEV), 5)
     eng = WanT2VEngine(experts[0], experts[1], vae=vae, text_encoder=umt5)
     g = torch.Generator().manual_seed(6)
     ids, nids = torch.randint(3, 150, (1, 24), generator=g), torch.randint(3, 150, (1, 24), generator=g)
@@ -98,7 +98,7 @@ def test_wan_ids_to_frames():
     _frames_ok(frames, (1, 5, 64, 96, 3))
     pe = eng.encode_prompt(prompt_ids=(ids, mask), text_encoder_kwargs=dict(max_sequence_length=24))
     ne = eng.encode_prompt(prompt_ids=(nids, nmask), text_encoder_kwargs=dict(max_sequence_length=24))
-    assert pe.shape == (1, 24, 64) and float(pe[0, 17:].abs().sum()) == 0.0 and float(pe[0, :17].abs().sum()) > 0.0
+    assert pe.shape == (1, 24, 128) and float(pe[0, 17:].abs().sum()) == 0.0 and float(pe[0, :17].abs().sum()) > 0.0
     assert np.array_equal(frames, eng.run(prompt_embeds=pe, negative_prompt_embeds=ne, **kw))
 
 
