@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--queue-wan-steps", type=int, default=30)
     ap.add_argument("--no-shared-weights", action="store_true",
                     help="N>1: broadcast only the prompt embeddings, not the text-encoder/VAE weights")
+    ap.add_argument("--exchange-timeout", type=float, default=600.0,
+                    help="N>1: seconds the weight exchange step (after the timed region) may take before the line is printed without it")
     ap.add_argument("--no-wan", action="store_true", help="N=1 flux: skip the Wan-2.2 720p half of the headline metric")
     ap.add_argument("--tune", type=str, default="", help="debug A/B: comma list of key=value for apexmi_tune_set")
     return ap.parse_args()
@@ -589,22 +591,9 @@ def main():
     step, latents, reset, shared_inputs, clip_fn, label = build(args, dev, rank, total)
 
     bcast = None
-    if distributed:   # the ONE exchange step: shared text-encoder / VAE weights + shared prompt embeddings from rank 0
+    if distributed:   # shared prompt embeddings from rank 0 (small: plain broadcasts); the WEIGHT exchange follows the timed region
         bcast = {"embeddings": render_queue.broadcast_shared(list(shared_inputs), src=0),
                  "rccl_ranks": dist.get_world_size()}
-        mods, what, probe = (None, None, None) if args.no_shared_weights else shared_weights(args.workload, dev, rank)
-        if mods is not None:
-            try:
-                bcast["weights"] = dict(render_queue.broadcast_parameters(mods, src=0), what=what)
-                sums = probe(mods)                              # every rank encodes the same ids with ITS copy
-                gathered = [torch.empty_like(sums) for _ in range(dist.get_world_size())]
-                dist.all_gather(gathered, sums)
-                bcast["weights"]["verified"] = bool(all(torch.equal(g, gathered[0]) for g in gathered)
-                                                    and torch.isfinite(gathered[0]).all())
-            except Exception as e:      # the exchange step is reported, never allowed to take the timed region down with it
-                bcast["weights"] = {"what": what, "error": f"{type(e).__name__}: {e}"[:300], "verified": False}
-            del mods
-            torch.cuda.empty_cache()
 
     for i in range(args.warmup):
         latents = step(i, latents)
@@ -624,6 +613,62 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(latents.float()).all().item())
+
+    def core_line(extra_bcast=None):
+        """The driver's line from what is known right after the timed region (the watchdog below prints exactly this)."""
+        ms = 1e3 * elapsed / args.steps
+        full_ = not args.layers
+        tf_ = STEP_TFLOP[args.workload]
+        b = dict(bcast or {})
+        if extra_bcast:
+            b.update(extra_bcast)
+        return {"metric": "denoise_steps_per_sec", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": args.gpus,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": label, "clips_in_flight": args.gpus, "parallelism": f"clip-per-gpu x{args.gpus}",
+                           "step_tflop": tf_ if full_ else None},
+                "world": world, "rccl_ranks": world if distributed else 1,
+                "model_tflops_per_gpu": (tf_ / (ms * 1e-3)) if full_ else None,
+                "mfma_utilisation_step": (tf_ / (ms * 1e-3) / PEAK_BF16_TFLOPS) if full_ else None,
+                "finite": finite, "broadcast": b or None}
+
+    # The ONE exchange step of the queue — shared text-encoder / VAE weights from rank 0, scatter + all-gather per 1 GiB
+    # bucket, every rank then encodes the same ids with ITS copy and the results are compared bit for bit — runs AFTER the
+    # timed region and under a watchdog: N > 1 executes for the first time on the driver's node, and a stuck collective must
+    # cost the weights report, not the measured line.  On expiry rank 0 prints the line with the failure recorded and every
+    # rank leaves; an exception on a rank is gathered (MIN over an ok flag) so that no rank reports success alone.
+    if distributed and not args.no_shared_weights:
+        import threading
+        mods, what, probe = shared_weights(args.workload, dev, rank)
+        if mods is not None:
+            def bail():
+                if rank == 0:
+                    _flush_c_stdio()
+                    print(json.dumps(core_line({"weights": {"what": what, "verified": False,
+                                                           "error": f"exchange step exceeded {args.exchange_timeout} s"}})),
+                          flush=True)
+                os._exit(0)
+            timer = threading.Timer(args.exchange_timeout, bail)
+            timer.daemon = True
+            timer.start()
+            err = None
+            try:
+                w = dict(render_queue.broadcast_parameters(mods, src=0), what=what)
+                sums = probe(mods)                              # every rank encodes the same ids with ITS copy
+                gathered = [torch.empty_like(sums) for _ in range(dist.get_world_size())]
+                dist.all_gather(gathered, sums)
+                w["verified"] = bool(all(torch.equal(g, gathered[0]) for g in gathered) and torch.isfinite(gathered[0]).all())
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"[:300]
+                w = {"what": what, "error": err, "verified": False}
+            ok = torch.tensor([0 if err else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # reached by every rank that is not stuck; the watchdog covers the rest
+            timer.cancel()
+            if int(ok.item()) == 0 and not err:
+                w = dict(w, verified=False, error="another rank failed in the exchange step")
+            bcast["weights"] = w
+            del mods
+            torch.cuda.empty_cache()
 
     roofline = None
     kernels = {}
@@ -674,19 +719,9 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         full = not args.layers
         tf = STEP_TFLOP[args.workload]
-        out = {
-            "metric": "denoise_steps_per_sec", "value": world * args.steps / elapsed, "unit": "steps/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": label, "clips_in_flight": args.gpus, "parallelism": f"clip-per-gpu x{args.gpus}",
-                       "step_tflop": tf if full else None},
-            "world": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
-            "model_tflops_per_gpu": (tf / (ms_per_step * 1e-3)) if full else None,
-            "mfma_utilisation_step": (tf / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS) if full else None,
-            "sec_per_clip": clip["sec_per_clip"] if clip else None, "clip": clip,
-            "finite": finite, "roofline": roofline, "kernels": kernels, "broadcast": bcast,
-        }
+        out = core_line()
+        out.update({"sec_per_clip": clip["sec_per_clip"] if clip else None, "clip": clip, "roofline": roofline,
+                    "kernels": kernels})
         if not args.no_cpu_baseline and args.gpus == 1 and args.workload in ("flux", "qwen", "wan"):
             out["cpu_baseline"] = {"flux": cpu_baseline, "qwen": cpu_baseline_qwen, "wan": cpu_baseline_wan}[args.workload]()
         if args.workload == "flux" and args.gpus == 1 and full and not args.no_wan:

@@ -118,6 +118,67 @@ def test_broadcast_parameters_world2():
     assert packed0 == {"stale": 1} and packed1 == {}, "the receiver's packed-weight cache must be invalidated, the sender's kept"
 
 
+def _run_world(target, world, timeout=240, extra=()):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_broadcast_parameters_world4_uneven_tails():
+    """The same exchange step at world 4 (the scatter + all-gather path with 4 peers; bucket sizes that are not multiples of
+    the world size or of 16 bytes leave ragged tails in the staging buffer)."""
+    out = _run_world(_param_worker, 4)
+    assert all(o[1] for o in out), "every parameter on every rank must equal rank 0's"
+    assert len({o[2] for o in out}) == 1 and len({o[3] for o in out}) == 1 and out[0][3] > 1
+    assert out[0][5] == {"stale": 1} and all(o[5] == {} for o in out[1:])
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    sizes = [1, 3, 17, 4097, (1 << 20) + 5, 9 << 20, (9 << 20) + 3, 33]        # odd byte counts, some past the scatter threshold
+    gen = torch.Generator().manual_seed(7)
+    want = [torch.randint(0, 255, (n,), generator=gen, dtype=torch.uint8) for n in sizes]
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for i, w in enumerate(want):
+                self.register_buffer(f"b{i}", w.clone() if rank == 0 else torch.zeros_like(w))
+    m = M()
+    stats = rq.broadcast_parameters([m], src=0, bucket_bytes=(10 << 20) + 1)
+    ok = all(torch.equal(getattr(m, f"b{i}"), w) for i, w in enumerate(want))
+    # a rank that enumerates a different layout: EVERY rank raises, nobody is left waiting in a collective
+    m2 = M()
+    if rank == world - 1:
+        m2.register_buffer("extra", torch.zeros(5))
+    try:
+        rq.broadcast_parameters([m2], src=0)
+        raised = False
+    except RuntimeError as e:
+        raised = "layout" in str(e)
+    q.put((rank, bool(ok), stats["buckets"], raised))
+    dist.destroy_process_group()
+
+
+def test_broadcast_ragged_sizes_and_layout_mismatch_world4():
+    out = _run_world(_ragged_worker, 4)
+    assert all(o[1] for o in out) and out[0][2] >= 2
+    assert all(o[3] for o in out), "a layout mismatch must raise on every rank"
+
+
 def test_bench_refuses_to_fake_multi_gpu():
     """`python bench.py --gpus 2` must start 2 ranks or fail loudly — never one process reporting n_gpus 2."""
     import subprocess
