@@ -303,4 +303,6 @@ def test_wan_block_at_75600_tokens_vs_oracle_rows(host_threads):
     e_rows, e_delta = _rel(got, ref), _rel(got - x_in[rows], ref - x_in[rows])
     print(f"[full length] wan block at S 75 600 (d 5120): 256 sampled rows vs the oracle fed the HIP activations: rel L2 {e_rows:.2e} "
           f"on the rows, {e_delta:.2e} on the block's contribution")
-    assert e_rows < 1e-3 and e_delta < 6e-3
+    # block 0's input is the patch embedding (small), so the rows ARE the block's contribution: seven storage points deep,
+    # free-running inside the block — the bf16 noise floor (tests/stage_parity.py), not the per-kernel 5e-4
+    assert e_rows < 6e-3 and e_delta < 6e-3
