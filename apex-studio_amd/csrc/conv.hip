@@ -53,6 +53,9 @@ struct ConvArgs {
     float act_slope;
     // temporal stride (128x128 kernel only): output frame j reads input frames j * st + t0 + dt - (kT - 1); To output frames
     int To, st, t0;
+    unsigned long long* prof;   // cycle-stamp buffer of ONE workgroup (tools/conv_prof.py; null in production)
+    int dbg;                    // timing experiments on the prefetch kernel (WRONG results; tools/conv_ablate.py): 1 no weight DMA,
+                                // 2 no slab DMA inside the loop
 };
 APEXMI_DEVICE float conv_act(float v, int act, float slope) { return (act && v < 0.0f) ? v * slope : v; }
 
@@ -906,6 +909,316 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     conv_epilogue<MT, NT, 1, NORM>(a, acc, mrow, n0, wave, 0, l31, hi, smem);
 }
 
+// Register-prefetch form of the slab kernel (shipped, conv.pp = 1).  Same slab / weight-chunk images, same (temporal tap ->
+// slice -> spatial tap) accumulation order and therefore the same bits as conv3d_slab_kernel; what changes is WHEN things
+// are issued.  Measured on the kernel above (s_memtime stamps, profiles/r03_vae_conv_*): a wave's chunk is a serial chain
+// barrier -> 15 fragment reads (~520 cycles until the last returns) -> DMA issue (~190 cycles a piece) -> 18 MFMAs (576),
+// ~2060 cycles per chunk against 1152 cycles of matrix work per SIMD — LDS latency and DMA issue are exposed once per
+// chunk in every wave, and skewing the two waves of a SIMD against each other does not shorten either wave's chain.  Here
+//   * the fragments of chunk c + 1 are read (into a second register set) at the START of interval c, so their latency runs
+//     under the MFMAs of chunk c; the weight ring is 4 deep so that chunk c + 1 is already visible at barrier c;
+//   * every wave carries an equal share of the DMA pieces (slab and weights) and issues them BETWEEN k-step groups of its
+//     MFMAs — the two waves of a SIMD at different groups (wave < 4 after the first, wave >= 4 after the last but one), so
+//     one of them always has matrix work while the other sits in the DMA issue;
+//   * the wait before the barrier is vmcnt(pieces issued in this interval): in-order retirement then guarantees chunk c + 2's
+//     weights (issued an interval ago) and, from spatial tap 7 on, the whole next slab.
+// The 192-channel stages run as 4 row pairs x 2 channel halves (WNW = 2: NT = 3, MT = 2 per wave — 15 fragment reads per
+// 18 MFMAs instead of the 21 of the one-row form), the 64-channel-slice stages as 4 row pairs x 2 halves of 64.
+template <int NT, int MT, int WNW, int NORM, int SLW = 48, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(const ConvArgs a) {
+    constexpr int CPP = SLW / 8, PITCH = SLW * 2, KS = SLW / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RG = NW / WNW;                              // row groups (waves along M)
+    constexpr int TH = RG * MT, TW = 32, SC = TW + 2, SPOS = (TH + 2) * SC;
+    constexpr int NSP = (SPOS * PITCH + 1023) / 1024;         // 1 KiB slab pieces
+    constexpr int NPJ = (NSP + NW - 1) / NW;                  // ... per wave
+    constexpr int SPT = (NPJ + 6) / 7;                        // ... per wave and spatial tap (taps 0..6 carry the next slab)
+    constexpr int SLABB = NSP * 1024;
+    constexpr int WROWS = WNW * NT * 32;                      // weight rows per chunk
+    constexpr int WCH = WROWS * PITCH, WP = WCH / 1024;       // weight chunk bytes / pieces
+    constexpr int WLN = (WP + NW - 1) / NW;                   // weight pieces per wave and chunk
+    static_assert(NPJ <= 16 && WLN <= 5 && SPT <= 3, "piece tables");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WNW, wn = wave - wr * WNW;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool late = NW == 8 && wave >= 4;                    // the SIMD partner of wave - 4: takes its DMA stall later
+
+    const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
+    const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
+    const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = blockIdx.y * WROWS;
+    const int S = a.Cin / SLW;
+    const int nk = a.replicate ? a.kT : min(a.kT, t + 1);
+    const int kt_first = a.kT - nk;
+    const int nph = nk * S;
+    const int nchunks = nph * 9;
+    const uint32_t pos_bytes = (uint32_t)a.Cin * 2u;
+    const uint32_t frame_bytes = (uint32_t)(a.Hin * a.Win) * pos_bytes;
+
+    // ---- DMA tables: slab piece q = NW j + wave, weight piece q = NW i + wave (1 KiB = 64 lanes x 16 bytes each)
+    uint32_t soff[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        soff[j] = 0x80000000u;
+        if (j < NPJ) {
+            const int L = (j * NW + wave) * 64 + lane;
+            const int p = L / CPP, sl = L - p * CPP;
+            const int c = slab_swz<SLW>(sl, p);
+            const int r = p / SC, cx = p - r * SC;
+            int yy = y0 - 1 + r, xx = x0 - 1 + cx;
+            if (a.replicate) {
+                yy = min(max(yy, 0), a.H - 1);
+                xx = min(max(xx, 0), a.W - 1);
+            }
+            const bool ok = p < SPOS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            if (ok) soff[j] = (uint32_t)((yy >> a.up) * a.Win + (xx >> a.up)) * pos_bytes + (uint32_t)(c * 16);
+        }
+    }
+    auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((int64_t)a.T * a.Hin * a.Win * a.Cin * 2), 0x00020000);
+    auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((int64_t)a.Cout * a.Kpad * 2), 0x00020000);
+    int wvoff[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        if (i < WLN) {
+            const int L = (i * NW + wave) * 64 + lane;
+            const int n = L / CPP, sl = L - n * CPP;
+            wvoff[i] = min(n0 + n, a.Cout - 1) * (a.Kpad * 2) + slab_swz<SLW>(sl, n) * 16;
+        }
+
+    auto slab_piece = [&](int buf, uint32_t phase_off, uint32_t o, int j) {
+        if (!(o & 0x80000000u)) o += phase_off;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + buf * SLABB + (j * NW + wave) * 1024), 16,
+                                                 (int)o, 0, 0, 0);
+    };
+    // issue cursor over weight chunks
+    int c_slot = 0, c_sp = 0, c_sl = 0;
+    int c_tap_off = kt_first * 9 * a.Cin * 2;
+    auto w_piece = [&](auto I) -> int {                         // piece i of the chunk under the cursor; 1 if this wave has it
+        constexpr int i = decltype(I)::value;
+        if (i * NW + wave >= WP || (a.dbg & 1)) return 0;
+        const int kbase = c_tap_off + c_sp * (a.Cin * 2) + c_sl * PITCH;
+        char* dst = smem + 2 * SLABB + c_slot * WCH;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (i * NW + wave) * 1024), 16, wvoff[i], kbase, 0,
+                                                 0);
+        return 1;
+    };
+    auto w_advance = [&]() {
+        c_slot = (c_slot + 1) & 3;
+        if (++c_sp == 9) {
+            c_sp = 0;
+            if (++c_sl == S) {
+                c_sl = 0;
+                c_tap_off += 9 * a.Cin * 2;
+            }
+        }
+    };
+    auto w_chunk_all = [&]() {
+        (void)w_piece(std::integral_constant<int, 0>{});
+        if constexpr (WLN > 1) (void)w_piece(std::integral_constant<int, 1>{});
+        if constexpr (WLN > 2) (void)w_piece(std::integral_constant<int, 2>{});
+        if constexpr (WLN > 3) (void)w_piece(std::integral_constant<int, 3>{});
+        if constexpr (WLN > 4) (void)w_piece(std::integral_constant<int, 4>{});
+        w_advance();
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.0f;
+
+    // next-phase cursor of the slab prefetch
+    int np_f = t - nk + 1;
+    uint32_t np_off = (uint32_t)max(np_f, 0) * frame_bytes;
+    int np_sl = 0;
+    auto advance_phase = [&]() {
+        if (++np_sl == S) {
+            np_sl = 0;
+            ++np_f;
+            np_off = (uint32_t)max(np_f, 0) * frame_bytes;
+        } else {
+            np_off += (uint32_t)PITCH;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j)
+        if (j * NW + wave < NSP) slab_piece(0, np_off, soff[j], j);
+    advance_phase();
+    w_chunk_all();
+    if (nchunks > 1) w_chunk_all();
+    if (nchunks > 2) w_chunk_all();
+
+    // ---- fragment reads: cursor (phase parity, spatial tap, ring slot) of the chunk to READ next
+    int r_buf = 0, r_sp = 0, r_slot = 0;
+    const int wrow = wn * (NT * 32) + l31;                     // this lane's first weight row inside the chunk
+    bf16x8 af[2][KS][MT], wf[2][KS][NT];
+    constexpr int NR = KS * (MT + NT), NM = KS * NT * MT;      // fragment reads / MFMAs per chunk
+    const char* rbase[MT + NT];                                // LDS row addresses of the chunk being read
+    int rkey[MT + NT];                                         // ... and their swizzle keys (position / weight row)
+    auto read_setup = [&]() {
+        const int dy = r_sp / 3, dx = r_sp - dy * 3;
+        const char* Sb = smem + r_buf * SLABB;
+        const char* Ws = smem + 2 * SLABB + r_slot * WCH;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            rkey[m] = (MT * wr + m + dy) * SC + (l31 + dx);
+            rbase[m] = Sb + rkey[m] * PITCH;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            rkey[MT + nt] = wrow + nt * 32;
+            rbase[MT + nt] = Ws + rkey[MT + nt] * PITCH;
+        }
+        r_slot = (r_slot + 1) & 3;
+        if (++r_sp == 9) {
+            r_sp = 0;
+            r_buf ^= 1;
+        }
+    };
+    auto read_one = [&](auto SET, auto R) {                   // read r of the chunk: k-step r / (MT + NT), operand r % (MT + NT)
+        constexpr int s = decltype(SET)::value, r = decltype(R)::value;
+        constexpr int ks = r / (MT + NT), o = r % (MT + NT);
+        const bf16x8 v = *(const bf16x8*)(rbase[o] + (slab_swz<SLW>(2 * ks + hi, rkey[o]) << 4));
+        if constexpr (o < MT) af[s][ks][o] = v;
+        else wf[s][ks][o - MT] = v;
+    };
+    auto read_range = [&](auto SET, auto LO, auto HI, auto&& self) {
+        constexpr int lo = decltype(LO)::value, hi_ = decltype(HI)::value;
+        if constexpr (lo < hi_) {
+            read_one(SET, LO);
+            self(SET, std::integral_constant<int, lo + 1>{}, HI, self);
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_setup();
+    read_range(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NR>{}, read_range);
+    // (the builtin, not inline asm: the compiler's own waitcnt bookkeeping must SEE that no fragment read is pending at the
+    // top of an interval — otherwise it guards the first MFMA with lgkmcnt(0), i.e. waits for the prefetch just issued)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0)
+
+    int ph = 0, sp = 0;                                        // the chunk whose MFMAs run in this interval
+    // One interval = the NM MFMAs of chunk `it` with everything else issued in their shadow: after MFMA i, the wave issues
+    // its share of chunk it + 1's fragment reads (into the other register set; past the last chunk they read stale LDS,
+    // unused) and, at slots that differ between the two waves of a SIMD, one DMA piece.  An MFMA holds the pipe for 32
+    // cycles and the wave for ~4: the instructions between two MFMAs cost nothing as long as they fit that shadow.
+    constexpr int DSTR = NM >= 16 ? 2 : 1;                     // MFMA slots between two DMA pieces
+    const int dbase = late ? NM / 2 : 1;                       // first DMA slot of this wave
+    auto slot = [&](auto SET, auto I, int it, int& issued) {
+        constexpr int s = decltype(SET)::value, i = decltype(I)::value;
+        constexpr int ks = i / (NT * MT), nt = (i / MT) % NT, m = i % MT;
+        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][ks][nt], af[s][ks][m], acc[nt][m], 0, 0, 0);
+        if constexpr (i == 0) read_setup();                   // address arithmetic of chunk it + 1: under the first MFMA
+        else read_range(std::integral_constant<int, s ^ 1>{}, std::integral_constant<int, (i - 1) * NR / (NM - 1)>{},
+                        std::integral_constant<int, i * NR / (NM - 1)>{}, read_range);
+        // DMA piece d of this interval (weights of chunk it + 3 first, then the next slab's share of this tap) at slot dbase + DSTR d
+#pragma unroll
+        for (int d = 0; d < WLN + SPT; ++d) {
+            constexpr bool may_early = true;
+            if ((i - 1) % DSTR == 0 || (i - NM / 2) % DSTR == 0) {
+                if (i == dbase + DSTR * d) {
+                    if (d < WLN) {
+                        if (it + 3 < nchunks) {
+                            if (d == 0) issued += w_piece(std::integral_constant<int, 0>{});
+                            if (d == 1) { if constexpr (WLN > 1) issued += w_piece(std::integral_constant<int, 1>{}); }
+                            if (d == 2) { if constexpr (WLN > 2) issued += w_piece(std::integral_constant<int, 2>{}); }
+                            if (d == 3) { if constexpr (WLN > 3) issued += w_piece(std::integral_constant<int, 3>{}); }
+                            if (d == 4) { if constexpr (WLN > 4) issued += w_piece(std::integral_constant<int, 4>{}); }
+                            if (d == WLN - 1) w_advance();
+                        }
+                    } else if (ph + 1 < nph && sp < 7 && !(a.dbg & 2)) {
+#pragma unroll
+                        for (int j = 0; j < NPJ; ++j)
+                            if (j % SPT == d - WLN && j * 7 / NPJ == sp && j * NW + wave < NSP) {
+                                slab_piece((ph + 1) & 1, np_off, soff[j], j);
+                                ++issued;
+                            }
+                    }
+                }
+            }
+            (void)may_early;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto slots = [&](auto SET, auto I, int it, int& issued, auto&& self) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NM) {
+            slot(SET, I, it, issued);
+            self(SET, std::integral_constant<int, i + 1>{}, it, issued, self);
+        }
+    };
+    const bool prof = a.prof != nullptr && blockIdx.x == 300 && blockIdx.y == 0;
+    unsigned long long pf_issue = 0, pf_vm = 0, pf_lgkm = 0, pf_bar = 0, pf_t3 = 0;
+#define STAMP(x) do { if (prof) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    auto interval = [&](auto SET, int it) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        STAMP(t0);
+        __builtin_amdgcn_sched_barrier(0);
+        int issued = 0;
+        slots(SET, std::integral_constant<int, 0>{}, it, issued, slots);
+        STAMP(t1);
+        switch (issued) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
+        STAMP(t2);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the prefetched set (long complete by now)
+        if (prof) {
+            if (it > 0) pf_bar += t0 - pf_t3;
+            pf_issue += t1 - t0;
+            pf_vm += t2 - t1;
+        }
+        STAMP(t3);
+        if (prof) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pf_lgkm += t3 - t2;
+            pf_t3 = t3;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++sp == 9) {
+            sp = 0;
+            ++ph;
+            advance_phase();
+        }
+    };
+    for (int it = 0; it < nchunks; it += 2) {
+        interval(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nchunks) interval(std::integral_constant<int, 1>{}, it + 1);
+    }
+
+#undef STAMP
+    if (prof && lane == 0) {
+        unsigned long long* o = a.prof + wave * 8;
+        o[0] = pf_bar;
+        o[1] = pf_issue;
+        o[2] = pf_vm;
+        o[3] = pf_lgkm;
+        o[5] = (unsigned long long)nchunks;
+    }
+    int mrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = y0 + MT * wr + m, x = x0 + l31;
+        mrow[m] = (y < a.H && x < a.W) ? (t * a.H + y) * a.W + x : -1;
+    }
+    conv_epilogue<MT, NT, WNW, NORM>(a, acc, mrow, n0, wr, wn, l31, hi, smem);
+}
+
 using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
 using CV_N64 = ConvCfg<8, 1, 2, 2>;    // 512 x 64
 using CV_N96 = ConvCfg<8, 1, 2, 3>;    // 512 x 96
@@ -927,6 +1240,10 @@ int launch_slab96_inst(const ConvArgs& a, hipStream_t stream) {     // conv.slab
     return apexmi_check_launch("conv3d_cl (slab 8x32)");
 }
 
+int g_conv_dbg = 0;
+uintptr_t g_conv_prof = 0;   // apexmi_tune_set("conv.prof_lo" / "conv.prof_hi", halves of a device pointer): 8 waves x 8 counters
+int g_conv_pp = 1;   // apexmi_tune_set("conv.pp", 0..3): see launch_slab
+
 template <int NT, int MT, int NORM, int SLW = 48>
 int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
     constexpr int SPOS = (8 * MT + 2) * 34, NPJ = (SPOS * SLW * 2 + 8191) / 8192;
@@ -940,6 +1257,20 @@ int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
     return apexmi_check_launch("conv3d_cl (slab)");
 }
 
+template <int NT, int MT, int WNW, int NORM, int SLW = 48, int NW = 8>
+int launch_slabp_inst(const ConvArgs& a, hipStream_t stream) {
+    constexpr int TH = (NW / WNW) * MT, SPOS = (TH + 2) * 34, NSP = (SPOS * SLW * 2 + 1023) / 1024;
+    constexpr int WROWS = WNW * NT * 32;
+    constexpr int LDS = 2 * NSP * 1024 + 4 * WROWS * SLW * 2;
+    static_assert(LDS <= 160 * 1024, "slab kernel LDS");
+    static uint64_t attr = 0;
+    APEXMI_SET_ATTR_ONCE(attr, (void)hipFuncSetAttribute((const void*)conv3d_slabp_kernel<NT, MT, WNW, NORM, SLW, NW>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    const int gx = a.T * ((a.H + TH - 1) / TH) * ((a.W + 31) / 32), gy = (a.Cout + WROWS - 1) / WROWS;
+    hipLaunchKernelGGL((conv3d_slabp_kernel<NT, MT, WNW, NORM, SLW, NW>), dim3(gx, gy), dim3(NW * 64), LDS, stream, a);
+    return apexmi_check_launch("conv3d_cl (slab, prefetch)");
+}
+
 // which convolutions the slab kernels take: Cin a multiple of 48, 3x3 "same" spatial taps, kT <= 3, stride 1, zero padding
 // 48-channel slices (16x32 / 8x32 tiles) where Cin is a multiple of 48; otherwise 64-channel slices on 8 x 32 tiles with 128
 // output channels per workgroup (Cout a multiple of 128: the HunyuanVideo-1.5 / Flux / TAEHV stages), replicate padding included
@@ -951,15 +1282,16 @@ bool slab_eligible(const ConvArgs& a) {
 
 int launch_slab(const ConvArgs& a, hipStream_t stream) {
     const bool norm = a.out_norm != nullptr;
+    // conv.pp: 1 (shipped) = per shape, whichever schedule measured faster (profiles/r03_vae_conv_schedules.md): the register-
+    // prefetch kernel on the 192-channel-wide tiles (+4..10 %), the serial-chunk kernel elsewhere; 0 / 2 = one of them
+    // everywhere it exists; 3 = the prefetch kernel as 4 waves of twice the tile (A/B only, no fused norm)
     if (!slab48(a)) {     // 64-channel slices
-        if (norm) {
-            if (a.Cout > 128) {
-                apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of the slab kernel", a.Cout);
-                return 1;
-            }
-            return launch_slab_inst<4, 1, 1, 64>(a, stream);
+        if (norm && a.Cout > 128) {
+            apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of the slab kernel", a.Cout);
+            return 1;
         }
-        return launch_slab_inst<4, 1, 0, 64>(a, stream);
+        if (g_conv_pp == 2) return norm ? launch_slabp_inst<2, 2, 2, 1, 64>(a, stream) : launch_slabp_inst<2, 2, 2, 0, 64>(a, stream);
+        return norm ? launch_slab_inst<4, 1, 1, 64>(a, stream) : launch_slab_inst<4, 1, 0, 64>(a, stream);
     }
     if (g_conv_slab == 1 && a.Cin == 96 && a.Cout <= 96 && !a.up) {
         const int nt = (a.Cout + 31) / 32;
@@ -968,6 +1300,11 @@ int launch_slab(const ConvArgs& a, hipStream_t stream) {
     }
     if (a.Cout <= 96) {
         const int nt = (a.Cout + 31) / 32;
+        if (g_conv_pp == 3 && nt == 3 && !norm) return launch_slabp_inst<3, 4, 1, 0, 48, 4>(a, stream);
+        if (g_conv_pp >= 2) {
+            if (norm) return nt == 1 ? launch_slabp_inst<1, 2, 1, 1>(a, stream) : nt == 2 ? launch_slabp_inst<2, 2, 1, 1>(a, stream) : launch_slabp_inst<3, 2, 1, 1>(a, stream);
+            return nt == 1 ? launch_slabp_inst<1, 2, 1, 0>(a, stream) : nt == 2 ? launch_slabp_inst<2, 2, 1, 0>(a, stream) : launch_slabp_inst<3, 2, 1, 0>(a, stream);
+        }
         if (norm) return nt == 1 ? launch_slab_inst<1, 2, 1>(a, stream) : nt == 2 ? launch_slab_inst<2, 2, 1>(a, stream) : launch_slab_inst<3, 2, 1>(a, stream);
         return nt == 1 ? launch_slab_inst<1, 2, 0>(a, stream) : nt == 2 ? launch_slab_inst<2, 2, 0>(a, stream) : launch_slab_inst<3, 2, 0>(a, stream);
     }
@@ -976,9 +1313,10 @@ int launch_slab(const ConvArgs& a, hipStream_t stream) {
             apexmi_set_error("conv3d_cl_norm: Cout=%d does not fit one N tile of the slab kernel", a.Cout);
             return 1;
         }
-        return launch_slab_inst<6, 1, 1>(a, stream);
+        return g_conv_pp ? launch_slabp_inst<3, 2, 2, 1>(a, stream) : launch_slab_inst<6, 1, 1>(a, stream);
     }
-    return launch_slab_inst<6, 1, 0>(a, stream);
+    if (g_conv_pp == 3) return launch_slabp_inst<3, 4, 2, 0, 48, 4>(a, stream);
+    return g_conv_pp ? launch_slabp_inst<3, 2, 2, 0>(a, stream) : launch_slab_inst<6, 1, 0>(a, stream);
 }
 
 template <typename CFG, int UP, int NORM>
@@ -1314,6 +1652,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TS* __restrict__ x,
 }  // namespace
 void apexmi_set_conv_v2(int v) { g_conv_v2 = v; }
 void apexmi_set_conv_slab(int v) { g_conv_slab = v; }
+void apexmi_set_conv_pp(int v) { g_conv_pp = v; }
+void apexmi_set_conv_dbg(int v) { g_conv_dbg = v; }
+void apexmi_set_conv_prof(int half, int v) {
+    if (half) g_conv_prof = (g_conv_prof & 0xffffffffull) | ((uintptr_t)(uint32_t)v << 32);
+    else g_conv_prof = (g_conv_prof & ~(uintptr_t)0xffffffffull) | (uint32_t)v;
+}
 
 extern "C" size_t apexmi_groupnorm_workspace_bytes(int64_t P, int C) {
     const int nblk = (int)((P + 1023) / 1024);
@@ -1429,6 +1773,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     APEXMI_REQUIRE((st == 1 && t0 == 0 && To == T) || (!up && !independent && out_norm == nullptr && T > 1),
                    "conv3d_cl: a temporal stride excludes the upsample / independent-frame / fused-norm modes");
     a.To = To; a.st = st; a.t0 = t0;
+    a.prof = (unsigned long long*)g_conv_prof;
+    a.dbg = g_conv_dbg;
     const int64_t M = (int64_t)To * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,

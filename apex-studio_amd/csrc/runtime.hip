@@ -123,6 +123,9 @@ void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 void apexmi_set_conv_v2(int v);
 void apexmi_set_conv_slab(int v);
+void apexmi_set_conv_pp(int v);
+void apexmi_set_conv_dbg(int v);
+void apexmi_set_conv_prof(int half, int v);
 int apexmi_set_gemm_key(const char* key, int value);
 
 extern "C" int apexmi_tune_set(const char* key, int value) {
@@ -137,6 +140,15 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         return 0;
     } else if (!strcmp(key, "conv.slab")) {
         apexmi_set_conv_slab(value);
+        return 0;
+    } else if (!strcmp(key, "conv.prof_lo") || !strcmp(key, "conv.prof_hi")) {
+        apexmi_set_conv_prof(key[10] == 'h', value);
+        return 0;
+    } else if (!strcmp(key, "conv.dbg")) {
+        apexmi_set_conv_dbg(value);
+        return 0;
+    } else if (!strcmp(key, "conv.pp")) {
+        apexmi_set_conv_pp(value);
         return 0;
     } else if (!strcmp(key, "attn.split")) {
         apexmi_set_attn_split(value);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the slab kernel's schedules (`conv.pp` 0 = every wave in phase, 1 = half-chunk skew), interleaved rounds on one box, and
-bit-identity of the two (the same sums in the same order)."""
+"""A/B of the slab kernel's schedules (`conv.pp` 0 = serial chunks everywhere, 1 = shipped per-shape choice, 2 = register prefetch everywhere, 3 =
+register prefetch with 4 waves of twice the tile where instantiated), interleaved rounds on one box, and bit-identity of all of them (the same sums in the same order)."""
 import json
 import os
 import sys
@@ -24,10 +24,11 @@ for name, (cin, cout, T, H, W, k, up) in {**CASES, **EXTRA}.items():
     fl = 2.0 * T * H * W * (4 if up else 1) * cout * cin * k[0] * 9
     res, outs = {}, {}
     for rnd in range(3):
-        for v in (0, 1):
+        for v in (0, 1, 2, 3):
             lib.tune_set("conv.pp", v)
             res.setdefault(v, []).append(round(tm(lambda: ops.conv3d_cl(x, wp, b, k, upsample2x=up)), 3))
             outs[v] = ops.conv3d_cl(x, wp, b, k, upsample2x=up)
     print(json.dumps({"case": name, "ms": res, "TFLOPs": {v: round(fl / min(res[v]) / 1e9, 1) for v in res},
-                      "speedup": round(min(res[0]) / min(res[1]), 3), "bit_identical": bool(torch.equal(outs[0], outs[1]))}), flush=True)
+                      "speedup": {v: round(min(res[0]) / min(res[v]), 3) for v in (1, 2, 3)},
+                      "bit_identical": bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}), flush=True)
 lib.tune_set("conv.pp", 1)

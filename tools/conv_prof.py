@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Cycle stamps (s_memtime) of one workgroup of the slab kernel's PP = 1 loop: per wave, cycles per chunk spent waiting at the
-barrier, in the A segment (G0: fragment reads, G1: MFMA issue), the B segment (G0: MFMA issue, G1: fragment reads), the LDS-DMA
-issue and the vmcnt wait.  Stamping costs ~10 % and serialises the segments it brackets."""
+"""Cycle stamps (s_memtime) of one workgroup of the prefetch slab kernel: per wave, cycles per interval spent waiting at the barrier,
+issuing the interval's instructions (MFMAs with the next chunk's fragment reads and the DMA pieces in their shadow), in the
+vmcnt wait and the lgkmcnt wait.  The stamps are read back after the interval's own lgkmcnt(0), so they add no wait."""
 import ctypes
 import json
 import os
@@ -21,7 +21,7 @@ p = buf.data_ptr()
 lo, hi = p & 0xffffffff, p >> 32
 lib.tune_set("conv.prof_lo", ctypes.c_int32(lo).value)
 lib.tune_set("conv.prof_hi", ctypes.c_int32(hi).value)
-lib.tune_set("conv.pp", 1)
+lib.tune_set("conv.pp", 2)
 for name in ("96->96 3x3x3 (full res)", "192->192 3x3x3 (half res)"):
     cin, cout, T, H, W, k, up = CASES[name]
     x = torch.randn(T, H, W, cin, generator=g, device=DEV).to(torch.bfloat16)
@@ -32,8 +32,9 @@ for name in ("96->96 3x3x3 (full res)", "192->192 3x3x3 (half res)"):
     torch.cuda.synchronize()
     r = buf.view(8, 8).cpu().tolist()
     n = max(r[0][5], 1)
-    rows = {f"wave{w_}": {"barrier": round(r[w_][0] / n), "A": round(r[w_][1] / n), "B": round(r[w_][2] / n), "dma": round(r[w_][3] / n),
-                          "vmcnt": round(r[w_][4] / n), "sum": round(sum(r[w_][:5]) / n)} for w_ in range(8)}
+    rows = {f"wave{w_}": {"barrier": round(r[w_][0] / n), "issue(reads+mfma+dma)": round(r[w_][1] / n), "vmcnt": round(r[w_][2] / n),
+                          "lgkm": round(r[w_][3] / n), "sum": round(sum(r[w_][:4]) / n)} for w_ in range(8)}
     print(json.dumps({"case": name, "ms_with_stamps": round(ms, 3), "chunks": n, "cycles_per_chunk": rows}), flush=True)
 lib.tune_set("conv.prof_lo", 0)
 lib.tune_set("conv.prof_hi", 0)
+lib.tune_set("conv.pp", 1)
