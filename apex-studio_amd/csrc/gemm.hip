@@ -55,6 +55,19 @@ struct GemmProblem {
     const bf16_t* R;
     int64_t lda, ldw, ldc, ldr;
     int M, N, nm, nn, tile0, gelu;
+    // fused q/k/v preparation (apexmi_gemm_bf16_grouped_qkv): this problem is a fused QKV projection, N = 3 H 128; its rows
+    // are rows [row0, row0 + M) of the joint sequence; nq / nk = the per-head RMSNorm weights of ITS stream.  C is not written.
+    int qkv, row0;
+    const bf16_t* nq;
+    const bf16_t* nk;
+};
+struct QkvShared {           // outputs of the fused preparation, shared by the problems of a launch
+    bf16_t* qo;              // [H, S_out, 128]
+    bf16_t* ko;              // [H, S_out, 128]
+    bf16_t* vt;              // [H, 128, Skp]
+    const float* rope;       // [2, S_out, 128] f32 (cos | sin), interleaved pairs
+    int S_out, Skp, inner;   // inner = H * 128
+    float eps;
 };
 struct GemmGroup {
     GemmProblem p[MAX_GROUPS];
@@ -62,6 +75,7 @@ struct GemmGroup {
     // batched mode (count == 1): blockIdx.y selects the batch element; strides in elements of A / W, bytes of C
     int batch;
     int64_t bsA, bsW, bsC_bytes;
+    QkvShared qs;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -300,6 +314,151 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         if (m[mt] >= 0 && nst < N) {
             const u32x4 o = {x0, x1, y0, y1};
             *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;
+        }
+    }
+}
+
+// Fused q/k/v preparation in the epilogue of the 256x256 tile on v_mfma_f32_16x16x32_bf16 (what qkv_prepare_fused_kernel,
+// elementwise.hip, does in a separate pass over the [S, 3 H 128] projection: reference transformer/flux/base/attention.py:62-94
+// — unflatten, norm_q / norm_k, apply_rotary_emb, the [B, H, S, D] layout, and V^T for the attention kernel's PV product).
+// A 256-column tile is two whole heads of q, of k or of v (256 | H 128); a head's 128 columns sit in two waves (wn, wn ^ 1).
+//   q / k: y = bf16(acc + bias) — the value the unfused path stores — then per (row, head) sum of squares IN THE SAME ORDER as
+//          qk_norm_rope4_body (8 columns in the lane, then the butterfly over the 16 eight-column chunks: chunk ^ 8 is the
+//          partner wave (through LDS), chunk ^ 4 the lane's other 32-column slab, chunk ^ 2 / ^ 1 lanes ^ 16 / ^ 32), the same
+//          rsqrt, weight and interleaved rotation: bit-identical outputs, written 16 bytes per lane into [H, S_out, 128].
+//   v:     the bf16 tile goes through the (now free) staging LDS, rotated per row, and leaves transposed: 8 consecutive
+//          sequence positions per lane, 128-byte runs per d-row of [H, 128, Skp].
+// Rows >= M are not stored; the zero padding of V^T beyond S_out is the caller's (the workspace is allocated zeroed).
+APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, const QkvShared& Q, int M, int m0, int n0,
+                                  int wave, int wm, int wn, int lane, char* smem) {
+    const int g = lane >> 4, c = lane & 15;
+    const int which = n0 / Q.inner;                    // 0 q, 1 k, 2 v: block-uniform
+    const int ncol0 = n0 - which * Q.inner;            // first column of the tile inside q / k / v
+    // bf16(acc + bias) of (slab p, m-tile mt): 8 consecutive columns per lane.  Recomputed where it is needed instead of kept
+    // (64 registers on top of the 128 accumulators would spill)
+    float bs[2][4];                                    // bias of the slab being processed (reloaded per slab: registers)
+    auto load_bias = [&](int p) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x2 b = {0u, 0u};
+            if (P.bias != nullptr) b = *(const u32x2*)(P.bias + n0 + wn * 64 + p * 32 + 16 * t + 4 * g);
+            bs[t][0] = bf16_lo(b[0]);
+            bs[t][1] = bf16_hi(b[0]);
+            bs[t][2] = bf16_lo(b[1]);
+            bs[t][3] = bf16_hi(b[1]);
+        }
+    };
+    auto rounded = [&](int p, int mt) -> u32x4 {
+        const f32x4_t& x = acc16[2 * p][mt];
+        const f32x4_t& y = acc16[2 * p + 1][mt];
+        uint32_t x0 = pack_bf16(x[0] + bs[0][0], x[1] + bs[0][1]), x1 = pack_bf16(x[2] + bs[0][2], x[3] + bs[0][3]);
+        uint32_t y0 = pack_bf16(y[0] + bs[1][0], y[1] + bs[1][1]), y1 = pack_bf16(y[2] + bs[1][2], y[3] + bs[1][3]);
+        swap16(x0, y0);
+        swap16(x1, y1);
+        return u32x4{x0, x1, y0, y1};
+    };
+    const int cw = 16 * (g & 1) + 8 * (g >> 1);        // first of the lane's 8 columns inside a 32-column slab
+    __syncthreads();                                    // every wave is out of the main loop's fragment reads
+    if (which == 2) {
+        // ---- V^T: tile[r][d] (256 x 256 bf16), row r rotated by ((r >> 3) + 4 (r & 7)) sixteen-byte chunks
+        bf16_t* tile = (bf16_t*)smem;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            load_bias(p);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int r = wm * 128 + mt * 16 + c;
+                const int dch = (wn * 64 + p * 32 + cw) >> 3;
+                *(u32x4*)(tile + r * 256 + (((dch + (r >> 3) + 4 * (r & 7)) & 31) << 3)) = rounded(p, mt);
+            }
+        }
+        __syncthreads();
+        const int tid = wave * 64 + lane;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int idx = i * 512 + tid;
+            const int sc = idx & 7, d = (idx >> 3) & 255, sc_hi = idx >> 11;     // 8 lanes = 8 consecutive position chunks of one d
+            const int s8 = (sc_hi * 8 + sc) * 8;                                // first of the 8 positions (tile row)
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = s8 + j;
+                const uint32_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
+                if (j & 1) w[j >> 1] |= e << 16;
+                else w[j >> 1] = e;
+            }
+            const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
+            if (m0 + s8 < M)
+                *(u32x4*)(Q.vt + ((int64_t)h * 128 + dd) * Q.Skp + P.row0 + m0 + s8) = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        return;
+    }
+    // ---- q / k: RMS norm over the head, rotation, [H, S_out, 128]
+    float* red = (float*)smem;                          // [8 waves][16 = slab x m-tile][64 lanes]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        load_bias(p);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            float x[8];
+            unpack8(rounded(p, mt), x);
+            float sq = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += x[j] * x[j];
+            red[(wave * 16 + p * 8 + mt) * 64 + lane] = sq;
+        }
+    }
+    __syncthreads();
+    const bf16_t* nw = which ? P.nk : P.nq;
+    const int h = (ncol0 >> 7) + (wn >> 1);
+    bf16_t* dst_base = (which ? Q.ko : Q.qo) + (int64_t)h * Q.S_out * 128;
+    float rinv[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const float a0 = red[(wave * 16 + mt) * 64 + lane] + red[((wave ^ 1) * 16 + mt) * 64 + lane];          // chunk ^ 8: the partner wave
+        const float a1 = red[(wave * 16 + 8 + mt) * 64 + lane] + red[((wave ^ 1) * 16 + 8 + mt) * 64 + lane];
+        float sq = a0 + a1;                                                              // chunk ^ 4: the other slab
+        sq += __shfl_xor(sq, 16, 64);                                                    // chunk ^ 2
+        sq += __shfl_xor(sq, 32, 64);                                                    // chunk ^ 1
+        rinv[mt] = rsqrtf(sq * (1.0f / 128) + Q.eps);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int d = (wn & 1) * 64 + p * 32 + cw;      // column inside the head
+        load_bias(p);
+        float wv[8];
+        if (nw != nullptr) unpack8(*(const u32x4*)(nw + d), wv);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wm * 128 + mt * 16 + c;
+            const int srow = P.row0 + min(m, M - 1);
+            float x[8], y[8];
+            unpack8(rounded(p, mt), x);
+            if (nw != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = x[j] * rinv[mt] * wv[j];
+            }
+            const float* cp = Q.rope + (int64_t)srow * 128 + d;
+            const float* sp = Q.rope + (int64_t)Q.S_out * 128 + (int64_t)srow * 128 + d;
+            const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+            float cs[8], sn[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cs[j] = c0[j];
+                cs[j + 4] = c1[j];
+                sn[j] = s0[j];
+                sn[j + 4] = s1[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                y[2 * q] = fmaf(x[2 * q], cs[2 * q], -(x[2 * q + 1] * sn[2 * q]));
+                y[2 * q + 1] = fmaf(x[2 * q + 1], cs[2 * q + 1], x[2 * q] * sn[2 * q + 1]);
+            }
+            if (m < M)
+                *(u32x4*)(dst_base + (int64_t)srow * 128 + d) =
+                    u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+            if (mt & 1) __builtin_amdgcn_sched_barrier(0);   // two rows' table loads in flight at a time, not sixteen (registers)
         }
     }
 }
@@ -785,6 +944,12 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 
     // ---- epilogue ----
     if constexpr (CFG::SCHED == 5) {
+        if constexpr (EPI == APEXMI_EPI_BIAS) {
+            if (P.qkv) {                                // block-uniform
+                qkv_epilogue16(acc16, P, G.qs, M, m0, n0, wave, wm, wn, lane, smem);
+                return;
+            }
+        }
         int mrow16[8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -1022,6 +1187,64 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     }
     ApexmiProfScope prof(0, stream, flops, bytes);
     return launch_group(G, M, kind, stream);
+}
+
+extern "C" int apexmi_gemm_qkv_fusable(int64_t m_total, int n_max, int K) {
+    return (g_force_cfg == 0 || g_force_cfg == 7) && g_large_cfg == 7 && m_total >= 1024 && n_max >= 1024 && K >= 256 && K % BK == 0;
+}
+
+extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, const int64_t* lda, const void* const* W,
+                                            const int64_t* ldw, const void* const* bias, void* const* C, const int64_t* ldc,
+                                            const int* M, const int* N, int K, const int* epilogue, const int* is_qkv,
+                                            const void* const* norm_q, const void* const* norm_k, const int* row0, int H,
+                                            float eps, const float* rope, void* q_out, void* k_out, void* vt_out, int S_out,
+                                            int Skp, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(count >= 1 && count <= MAX_GROUPS, "gemm_bf16_grouped_qkv: count=%d not in [1,%d]", count, MAX_GROUPS);
+    APEXMI_REQUIRE(is_qkv && row0 && rope && q_out && k_out && vt_out && H > 0, "gemm_bf16_grouped_qkv: null argument");
+    APEXMI_REQUIRE(H % 2 == 0 && S_out > 0 && Skp >= S_out && Skp % 8 == 0, "gemm_bf16_grouped_qkv: H=%d must be even, Skp=%d a multiple of 8 >= S_out=%d",
+                   H, Skp, S_out);
+    APEXMI_REQUIRE(((uintptr_t)rope % 16) == 0 && ((uintptr_t)q_out % 16) == 0 && ((uintptr_t)k_out % 16) == 0 && ((uintptr_t)vt_out % 16) == 0,
+                   "gemm_bf16_grouped_qkv: rope / outputs must be 16-byte aligned");
+    GemmGroup G;
+    G.count = count;
+    G.K = K;
+    G.batch = 1;
+    G.bsA = G.bsW = G.bsC_bytes = 0;
+    G.qs = QkvShared{(bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, rope, S_out, Skp, H * 128, eps};
+    double flops = 0, bytes = 0;
+    int64_t mtot = 0;
+    int nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        APEXMI_REQUIRE(epi_kind(epilogue[i]) == APEXMI_EPI_BIAS, "gemm_bf16_grouped_qkv: bias-class epilogues only (got %d)", epilogue[i]);
+        void* c = is_qkv[i] ? q_out : C[i];               // a fused problem writes no C
+        const int64_t lc = is_qkv[i] ? 128 : ldc[i];
+        if (int rc = check_problem(A[i], lda[i], W[i], ldw[i], c, lc, M[i], N[i], K, epilogue[i], nullptr, nullptr, 0)) return rc;
+        G.p[i] = GemmProblem{(const bf16_t*)A[i], (const bf16_t*)W[i], (const bf16_t*)(bias ? bias[i] : nullptr), (bf16_t*)c,
+                             nullptr, nullptr, lda[i], ldw[i], lc, 0, M[i], N[i], 0, 0, 0, act_mode(epi_base(epilogue[i]))};
+        if (is_qkv[i]) {
+            APEXMI_REQUIRE(N[i] == 3 * H * 128 && epi_base(epilogue[i]) == APEXMI_EPI_BIAS,
+                           "gemm_bf16_grouped_qkv: a fused problem has N = 3 H 128 = %d (got %d) and the plain bias epilogue", 3 * H * 128, N[i]);
+            APEXMI_REQUIRE(M[i] % 8 == 0 && row0[i] % 8 == 0 && row0[i] >= 0 && row0[i] + M[i] <= S_out,
+                           "gemm_bf16_grouped_qkv: rows [%d, %d) must be 8-aligned and inside S_out=%d", row0[i], row0[i] + M[i], S_out);
+            const void* nq = norm_q ? norm_q[i] : nullptr;
+            const void* nk = norm_k ? norm_k[i] : nullptr;
+            APEXMI_REQUIRE(((uintptr_t)nq % 16) == 0 && ((uintptr_t)nk % 16) == 0, "gemm_bf16_grouped_qkv: norm weights must be 16-byte aligned");
+            G.p[i].qkv = 1;
+            G.p[i].row0 = row0[i];
+            G.p[i].nq = (const bf16_t*)nq;
+            G.p[i].nk = (const bf16_t*)nk;
+        }
+        mtot += M[i];
+        nmax = N[i] > nmax ? N[i] : nmax;
+        flops += 2.0 * M[i] * N[i] * (double)K;
+        bytes += 2.0 * ((double)M[i] * K + (double)N[i] * K + (double)M[i] * N[i]);
+    }
+    // the fused epilogue exists on the shipped 256x256 / 16x16x32 tiling only: the caller keeps the separate pass otherwise
+    APEXMI_REQUIRE(apexmi_gemm_qkv_fusable(mtot, nmax, K),
+                   "gemm_bf16_grouped_qkv: needs the 256x256 v_mfma_f32_16x16x32 tiling (gemm.config / gemm.large = 7, >= 1024 rows)");
+    ApexmiProfScope prof(0, stream, flops, bytes);
+    return launch_cfg<CFG_256P16, APEXMI_EPI_BIAS>(G, M, stream);
 }
 
 extern "C" int apexmi_split_bf16x3(const float* x, int64_t ldx, int64_t M, int K, void* out, int64_t ldo,

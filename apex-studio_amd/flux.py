@@ -182,6 +182,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         self._ws: Dict[Any, Any] = {}
         self._side = None
         self.storage_dtype = torch.bfloat16
+        # q/k/v preparation in the QKV GEMM's epilogue where the launch allows it (see _forward_one; APEX_FLUX_FUSE_QKV=0: A/B)
+        self.fuse_qkv = os.environ.get("APEX_FLUX_FUSE_QKV", "1") != "0"
 
     # ---- reference-compatible plumbing -------------------------------------------------------
     @classmethod
@@ -385,6 +387,13 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
 
         nblk = 0
         overlap = os.environ.get("APEX_FLUX_OVERLAP") == "1"
+        # fused q/k/v preparation (apexmi_gemm_bf16_grouped_qkv): bit-identical to the two-pass path; `fuse_qkv = False` keeps
+        # the [S, 3 dim] projection as a storage point (tests/stage_parity.py reads it)
+        fuse = self.fuse_qkv and self.storage_dtype == torch.bfloat16 and self.transformer_blocks is not None
+        fuse_d = fuse and len(self.transformer_blocks) > 0 and ops.qkv_fusable(
+            [XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H)
+        fuse_s = fuse and len(self.single_transformer_blocks) > 0 and ops.qkv_fusable(
+            [XN, XN], [self.single_transformer_blocks[0]._wqkv, self.single_transformer_blocks[0].proj_mlp.weight], [0, 0], H)
         if overlap and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
 
@@ -403,11 +412,17 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             mt = lambda j: self._mod(ws, ("d", i, "txt"), j)  # noqa: E731
             # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             ops.ln_modulate(X, mi(1), mi(0), out=XN, split=s_txt, scale2=mt(1), shift2=mt(0))
-            ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
-                             [QKV[s_txt:], QKV[:s_txt]])
-            ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
-                            wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
-                            split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
+            if fuse_d:
+                # q/k norm + RoPE + [H, S, D] layout and V^T leave the QKV GEMM's epilogue: no [S, 3 dim] round trip
+                ops.gemm_grouped_qkv([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [None, None], "bias",
+                                     [1, 1], [a.norm_q.weight, a.norm_added_q.weight], [a.norm_k.weight, a.norm_added_k.weight],
+                                     [s_txt, 0], H, 1e-6, rope, Qp[0], Kp[0], VT[0])
+            else:
+                ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
+                                 [QKV[s_txt:], QKV[:s_txt]])
+                ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
+                                wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
+                                split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(Qp, Kp, VT, att_v, S)
             ops.gemm_grouped([att[s_txt:], att[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
                              [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",
@@ -440,13 +455,18 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                     mlp_done = torch.cuda.Event()
                     mlp_done.record(self._side)
                 ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
+            elif fuse_s:
+                ops.gemm_grouped_qkv([XN, XN], [blk._wqkv, blk.proj_mlp.weight], [blk._bqkv, blk.proj_mlp.bias],
+                                     [None, CAT[:, dim:]], ["bias", "gelu"], [1, 0], [a.norm_q.weight, None],
+                                     [a.norm_k.weight, None], [0, 0], H, 1e-6, rope, Qp[0], Kp[0], VT[0])
             else:
                 # QKV and MLP-up read the same XN: one launch, 1512 tiles = 5.9 rounds of the 256 CUs
                 ops.gemm_grouped([XN, XN], [blk._wqkv, blk.proj_mlp.weight], [blk._bqkv, blk.proj_mlp.bias],
                                  [QKV, CAT[:, dim:]], epilogue=["bias", "gelu"])
-            ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
-                            wk=a.norm_k.weight, split=0, eps=1e-6, rope=rope,
-                            rope_mode=_l.ROPE_INTERLEAVED)
+            if overlap or not fuse_s:
+                ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
+                                wk=a.norm_k.weight, split=0, eps=1e-6, rope=rope,
+                                rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(Qp, Kp, VT, att_v, S)
             if overlap:
                 torch.cuda.current_stream().wait_event(mlp_done)

@@ -39,6 +39,11 @@ SIGNATURES = {
                                            C.POINTER(vp), C.POINTER(vp), c_i64p, C.POINTER(C.c_int),
                                            C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(vp),
                                            C.POINTER(vp), c_i64p, vp]),
+    "apexmi_gemm_bf16_grouped_qkv": (C.c_int, [C.c_int, C.POINTER(vp), c_i64p, C.POINTER(vp), c_i64p, C.POINTER(vp),
+                                               C.POINTER(vp), c_i64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp),
+                                               C.POINTER(C.c_int), C.c_int, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "apexmi_gemm_qkv_fusable": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "apexmi_gemm_bf16_batched": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_attn_bias_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -176,6 +176,57 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
     _l.check(rc, "gemm_bf16_grouped")
 
 
+def qkv_fusable(a_list, w_list, row0, H: int) -> bool:
+    """Would gemm_grouped_qkv() take this launch?  (bf16 storage, 8-aligned row ranges, the 256x256 16x16x32 tiling.)"""
+    if any(a.dtype != torch.bfloat16 for a in a_list) or H % 2 or any(int(r) % 8 for r in row0):
+        return False
+    if any(a.shape[0] % 8 for a in a_list):
+        return False
+    return bool(_l.load().apexmi_gemm_qkv_fusable(sum(a.shape[0] for a in a_list), max(w.shape[0] for w in w_list),
+                                                  w_list[0].shape[1]))
+
+
+def gemm_grouped_qkv(a_list, w_list, bias_list, out_list, epilogue, is_qkv, norm_q, norm_k, row0, H: int, eps: float,
+                     rope: torch.Tensor, qo: torch.Tensor, ko: torch.Tensor, vt: torch.Tensor) -> None:
+    """gemm_grouped() with qkv_prepare() fused into the epilogue of the problems flagged in `is_qkv` (fused QKV projections,
+    N = 3 H 128): q / k leave normalised per head, rotated and laid out [H, S_out, 128], v leaves transposed [H, 128, Skp];
+    bit-identical to gemm_grouped + qkv_prepare.  out_list[i] of a fused problem is ignored (may be None).  bf16 storage only;
+    raises (apexmi error) when the launch would not run on the 256x256 16x16x32 tiling — callers keep the two-pass path then."""
+    import ctypes as C
+    n = len(a_list)
+    K = w_list[0].shape[1]
+    epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
+    for a, w, o, f in zip(a_list, w_list, out_list, is_qkv):
+        _req(a, torch.bfloat16, "gemm_grouped_qkv.a")
+        _req(w, torch.bfloat16, "gemm_grouped_qkv.w")
+        assert a.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and a.shape[1] == K
+        if not f:
+            _req(o, torch.bfloat16, "gemm_grouped_qkv.out")
+            assert o.stride(1) == 1 and o.shape == (a.shape[0], w.shape[0])
+    for t_ in (qo, ko, vt):
+        _req(t_, torch.bfloat16, "gemm_grouped_qkv output")
+        assert t_.is_contiguous()
+    _req(rope, torch.float32, "gemm_grouped_qkv.rope")
+    S_out = qo.shape[1]
+    assert qo.shape == ko.shape == (H, S_out, 128) and vt.shape[:2] == (H, 128) and rope.is_contiguous()
+    assert rope.shape == (2, S_out, 128)
+    VP = C.c_void_p * n
+    I64 = C.c_int64 * n
+    INT = C.c_int * n
+    none = [None] * n
+    bias_list = bias_list or none
+    rc = _l.load().apexmi_gemm_bf16_grouped_qkv(
+        n, VP(*[a.data_ptr() for a in a_list]), I64(*[a.stride(0) for a in a_list]),
+        VP(*[w.data_ptr() for w in w_list]), I64(*[w.stride(0) for w in w_list]), VP(*[_ptr(b) for b in bias_list]),
+        VP(*[_ptr(o) if not f else None for o, f in zip(out_list, is_qkv)]),
+        I64(*[(o.stride(0) if (o is not None and not f) else 0) for o, f in zip(out_list, is_qkv)]),
+        INT(*[a.shape[0] for a in a_list]), INT(*[w.shape[0] for w in w_list]), K, INT(*[_EPI[e] for e in epis]),
+        INT(*[1 if f else 0 for f in is_qkv]), VP(*[_ptr(t_) for t_ in (norm_q or none)]), VP(*[_ptr(t_) for t_ in (norm_k or none)]),
+        INT(*[int(r) for r in row0]), int(H), float(eps), rope.data_ptr(), qo.data_ptr(), ko.data_ptr(), vt.data_ptr(), S_out,
+        vt.shape[2], _stream())
+    _l.check(rc, "gemm_bf16_grouped_qkv")
+
+
 def gemv(w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, pre_silu: bool = False, post: Optional[str] = None,
          accum: bool = False) -> torch.Tensor:

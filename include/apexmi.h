@@ -141,6 +141,28 @@ int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda
                              const int* epilogue, const float* const* gate, const void* const* R,
                              const int64_t* ldr, apexmi_stream_t stream);
 
+/* apexmi_gemm_bf16_grouped with the q/k/v preparation of the attention processors fused into the epilogue of the fused-QKV
+ * projection (reference transformer/flux/base/attention.py:62-94: unflatten to heads, norm_q / norm_k (RMSNorm over the head,
+ * eps), apply_rotary_emb on interleaved pairs, the [B, H, S, D] layout; plus V^T for this library's attention kernel) — what
+ * apexmi_qkv_prepare does as a separate pass over the [S, 3 H 128] projection, with bit-identical results (the projection is
+ * rounded to bf16 exactly where the separate path stores it, and the sums run in the same order).
+ *   is_qkv[i] != 0: problem i is a fused QKV projection, N[i] = 3 H 128 ([q | k | v] rows of W); its M[i] rows are rows
+ *     [row0[i], row0[i] + M[i]) of the joint sequence (8-aligned); norm_q[i] / norm_k[i] = the RMSNorm weights (bf16[128]) of
+ *     its stream (the text stream of a joint block brings norm_added_q / norm_added_k); C[i] / ldc[i] are ignored.
+ *   is_qkv[i] == 0: an ordinary bias-class problem of the same launch (the single block's MLP up-projection with GELU).
+ *   q_out, k_out: bf16 [H, S_out, 128]; vt_out: bf16 [H, 128, Skp] (Skp >= S_out, a multiple of 8; columns >= S_out are not
+ *   written — allocate it zeroed); rope: f32 [2, S_out, 128] (cos | sin rows as apexmi_rope_table_axes writes them).
+ * Exists on the shipped 256 x 256 v_mfma_f32_16x16x32 tiling only (total M >= 1024; gemm.config / gemm.large left at 7):
+ * returns an error otherwise, and the caller keeps apexmi_gemm_bf16_grouped + apexmi_qkv_prepare. */
+/* 1 when a grouped launch with this total row count, largest N and K would run on the tiling that has the fused epilogue. */
+int apexmi_gemm_qkv_fusable(int64_t m_total, int n_max, int K);
+int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, const int64_t* lda, const void* const* W,
+                                 const int64_t* ldw, const void* const* bias, void* const* C, const int64_t* ldc,
+                                 const int* M, const int* N, int K, const int* epilogue, const int* is_qkv,
+                                 const void* const* norm_q, const void* const* norm_k, const int* row0, int H, float eps,
+                                 const float* rope, void* q_out, void* k_out, void* vt_out, int S_out, int Skp,
+                                 apexmi_stream_t stream);
+
 /* out[m][j K + k] (bf16, j = 0..2) = the j-th part of the exact split x = hi + mid + lo of the float x[m][k]:
  * hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (representable).  ldx in floats, ldo >= 3 K in bf16 elements,
  * K % 8 == 0.  Operand preparation of the f32-storage verification mode (APEXMI_EPI_F32_IO; apexmi_conv3d_cl_f32). */

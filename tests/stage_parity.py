@@ -88,12 +88,19 @@ def run_forced(ops_mod, model, plan: List[Stage], call: Callable[[], torch.Tenso
 
     for n in OPS:
         setattr(ops_mod, n, wrap(n))
+    # the [S, 3 dim] QKV projection is a storage point of the plan: keep the two-pass path (the fused epilogue is asserted
+    # bit-identical to it in tests/test_gpu_gemm_qkv.py, kernel by kernel and over a whole forward)
+    fused = getattr(model, "fuse_qkv", None)
+    if fused is not None:
+        model.fuse_qkv = False
     try:
         out = call()
         torch.cuda.synchronize()
     finally:
         for n in OPS:
             setattr(ops_mod, n, orig[n])
+        if fused is not None:
+            model.fuse_qkv = fused
     leftover = sum(1 for _ in it)
     assert leftover == 0, f"{leftover} planned stages never ran"
     return out, report

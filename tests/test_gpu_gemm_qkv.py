@@ -1,0 +1,134 @@
+"""The q/k/v preparation fused into the QKV GEMM's epilogue (`apexmi_gemm_bf16_grouped_qkv`) against the two-pass path it
+replaces (`apexmi_gemm_bf16_grouped` + `apexmi_qkv_prepare`, each of which has its own oracle parity tests): the projection is
+rounded to bf16 where the two-pass path stores it and every sum runs in the same order, so the bar is BIT-IDENTITY — of the three
+outputs kernel by kernel (joint img / txt streams, ragged row counts, the single block's QKV + MLP-up launch), and of a whole
+Flux forward with the fusion on and off."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).to(dtype)
+
+
+def _rope(S, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    ang = torch.rand(S, 64, generator=g, device=DEV) * 6.283
+    cos = ang.cos().repeat_interleave(2, dim=1)
+    sin = ang.sin().repeat_interleave(2, dim=1)
+    return torch.stack([cos, sin]).contiguous().float()
+
+
+@pytest.mark.parametrize("m_img,m_txt", [(1280, 256), (1096, 72), (1024, 0)])
+def test_joint_streams_bit_identical_to_two_pass(m_img, m_txt):
+    from apex_studio_amd import lib as _l, ops
+    H, K = 4, 512
+    inner, S = H * 128, m_img + m_txt
+    skp = (S + 63) // 64 * 64
+    xs = [_rand((m_img, K), 1), _rand((max(m_txt, 8), K), 2)][:2 if m_txt else 1]
+    ws = [_rand((3 * inner, K), 3, K ** -0.5), _rand((3 * inner, K), 4, K ** -0.5)][:len(xs)]
+    bs = [_rand((3 * inner,), 5, 0.1), _rand((3 * inner,), 6, 0.1)][:len(xs)]
+    nq = [_rand((128,), 7) * 0.2 + 1, _rand((128,), 8) * 0.2 + 1]
+    nk = [_rand((128,), 9) * 0.2 + 1, _rand((128,), 10) * 0.2 + 1]
+    rope = _rope(S, 11)
+    row0 = [m_txt, 0][:len(xs)]
+    # two-pass reference
+    qkv = torch.empty(S, 3 * inner, device=DEV, dtype=torch.bfloat16)
+    outs = [qkv[m_txt:], qkv[:m_txt]][:len(xs)]
+    ops.gemm_grouped(xs, ws, bs, outs)
+    q0, k0 = (torch.empty(H, S, 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt0 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    ops.qkv_prepare(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], H, q0, k0, vt0, wq=nq[0], wk=nk[0],
+                    wq2=nq[1] if m_txt else None, wk2=nk[1] if m_txt else None, split=m_txt, eps=1e-6, rope=rope,
+                    rope_mode=_l.ROPE_INTERLEAVED)
+    # fused
+    assert ops.qkv_fusable(xs, ws, row0, H)
+    q1, k1 = (torch.full((H, S, 128), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt1 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_grouped_qkv(xs, ws, bs, [None] * len(xs), "bias", [1] * len(xs), nq[:len(xs)], nk[:len(xs)], row0, H, 1e-6, rope,
+                         q1, k1, vt1)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q0), int((q1 != q0).sum())
+    assert torch.equal(k1, k0), int((k1 != k0).sum())
+    assert torch.equal(vt1, vt0), int((vt1 != vt0).sum())
+
+
+def test_single_block_launch_with_mlp_up_bit_identical():
+    from apex_studio_amd import lib as _l, ops
+    H, K, S, mlp = 4, 512, 1160, 2048
+    inner = H * 128
+    skp = (S + 63) // 64 * 64
+    x = _rand((S, K), 21)
+    wqkv, wmlp = _rand((3 * inner, K), 22, K ** -0.5), _rand((mlp, K), 23, K ** -0.5)
+    bqkv, bmlp = _rand((3 * inner,), 24, 0.1), _rand((mlp,), 25, 0.1)
+    nq, nk = _rand((128,), 26) * 0.2 + 1, _rand((128,), 27) * 0.2 + 1
+    rope = _rope(S, 28)
+    qkv = torch.empty(S, 3 * inner, device=DEV, dtype=torch.bfloat16)
+    up0 = torch.empty(S, mlp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_grouped([x, x], [wqkv, wmlp], [bqkv, bmlp], [qkv, up0], epilogue=["bias", "gelu"])
+    q0, k0 = (torch.empty(H, S, 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt0 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    ops.qkv_prepare(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], H, q0, k0, vt0, wq=nq, wk=nk, split=0, eps=1e-6,
+                    rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
+    q1, k1 = (torch.empty(H, S, 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt1 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    up1 = torch.empty(S, mlp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_grouped_qkv([x, x], [wqkv, wmlp], [bqkv, bmlp], [None, up1], ["bias", "gelu"], [1, 0], [nq, None], [nk, None], [0, 0],
+                         H, 1e-6, rope, q1, k1, vt1)
+    torch.cuda.synchronize()
+    assert torch.equal(up1, up0) and torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(vt1, vt0)
+
+
+def test_refused_when_the_tiling_has_no_fused_epilogue():
+    from apex_studio_amd import lib as _l, ops
+    x, w = _rand((256, 512), 1), _rand((1536, 512), 2)
+    assert not ops.qkv_fusable([x], [w], [0], 4)                       # under 1024 rows: the 128x128 tiling
+    big = _rand((1024, 512), 3)
+    assert ops.qkv_fusable([big], [w], [0], 4)
+    _l.tune_set("gemm.config", 3)
+    try:
+        assert not ops.qkv_fusable([big], [w], [0], 4)
+        q = torch.empty(4, 1024, 128, device=DEV, dtype=torch.bfloat16)
+        with pytest.raises(RuntimeError):
+            ops.gemm_grouped_qkv([big], [w], [None], [None], "bias", [1], [None], [None], [0], 4, 1e-6, _rope(1024, 4), q, q.clone(),
+                                 torch.zeros(4, 128, 1024, device=DEV, dtype=torch.bfloat16))
+    finally:
+        _l.tune_set("gemm.config", 0)
+
+
+def test_flux_forward_identical_with_and_without_the_fusion():
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from tests.golden.seeded import seeded, synthetic_state_dict
+    from oracle import flux as OF
+    cfg = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=4,
+               joint_attention_dim=256, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    h2 = w2 = 32
+    s_txt = 72
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    sd = synthetic_state_dict(m, 5)              # the HIP model's own parameter names are the diffusers names
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    inp = dict(hidden_states=seeded((1, h2 * w2, 64), 31).to(DEV).to(torch.bfloat16),
+               encoder_hidden_states=seeded((1, s_txt, 256), 32).to(DEV).to(torch.bfloat16),
+               pooled_projections=seeded((1, 64), 33).to(DEV).to(torch.bfloat16), timestep=torch.tensor([0.5], device=DEV),
+               guidance=torch.tensor([4.0], device=DEV), img_ids=OF.latent_image_ids(h2, w2).to(DEV),
+               txt_ids=torch.zeros(s_txt, 3, device=DEV))
+    launched = []
+    from apex_studio_amd import ops
+    orig = ops.gemm_grouped_qkv
+    ops.gemm_grouped_qkv = lambda *a, **k: (launched.append(1), orig(*a, **k))[1]
+    try:
+        m.fuse_qkv = True
+        a = m(return_dict=False, **inp)[0].clone()
+        n_fused = len(launched)
+        m.fuse_qkv = False
+        b = m(return_dict=False, **inp)[0].clone()
+    finally:
+        ops.gemm_grouped_qkv = orig
+    torch.cuda.synchronize()
+    assert n_fused == 4 and len(launched) == 4          # 2 joint + 2 single blocks took the fused launch, none when off
+    assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0
+    assert torch.equal(a, b)
