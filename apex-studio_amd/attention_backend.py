@@ -6,9 +6,15 @@ Honours the calling convention of every backend in the reference's attention_reg
     fn(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, softmax_scale=None, **kwargs) -> Tensor
 
 q:[B,H,Sq,D], k,v:[B,H,Sk,D] (possibly permuted, non-contiguous views); returns [B,H,Sq,D] in q's
-dtype without aliasing or modifying the inputs; enqueues on torch's current stream; no host sync.
-Masks, dropout and causal attention are not on the hot path: they raise, they do
-not fall back.
+dtype without aliasing or modifying the inputs; enqueues on torch's current stream; no host sync when
+`attn_mask` is None (every hot-path call: the reference forwards `attn_mask=attention_mask`, which is None there —
+flux/base/attention.py:89-94, wan/base/attention.py:397-399, qwenimage/base/model.py:555-562).
+
+A KEY-PADDING mask (bool keep-mask or additive 0 / -inf mask that does not vary along the query or head dimension:
+[B, Sk], [B, 1, 1, Sk], [1, 1, 1, Sk], ...) — what a padded prompt batch brings — is honoured exactly: softmax over the
+kept keys only, by running the same kernel over each sample's kept keys (a prefix is a view, anything else one gather).
+It costs one host sync (the kept-key count sizes the launch).  Masks that vary along the query dimension, dropout and causal
+attention are not on any call site of the path: they raise, they do not fall back.
 """
 from __future__ import annotations
 
@@ -22,13 +28,49 @@ KEY = "hip_mfma"
 
 def hip_mfma(q, k, v, attn_mask=None, dropout_p: float = 0.0, is_causal: bool = False,
              softmax_scale=None, **kwargs):
-    if attn_mask is not None:
-        raise ApexMIError("hip_mfma: attn_mask is not supported (no hot-path call site passes one)")
     if dropout_p:
         raise ApexMIError("hip_mfma: dropout is not supported (inference only)")
     if is_causal:
         raise ApexMIError("hip_mfma: causal attention is not supported")
-    return ops.attention(q, k, v, softmax_scale)
+    if attn_mask is None:
+        return ops.attention(q, k, v, softmax_scale)
+    keep = _key_keep_mask(attn_mask, q.shape[0], k.shape[2])
+    if bool(keep.all()):
+        return ops.attention(q, k, v, softmax_scale)
+    B, H, Sq, D = q.shape
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
+    counts = keep.sum(dim=1).tolist()
+    for b in range(B):
+        n = int(counts[b])
+        if n == 0:
+            raise ApexMIError(f"hip_mfma: attn_mask drops every key of sample {b}")
+        kb, vb = k[b:b + 1], v[b:b + 1]
+        if bool(keep[b, :n].all()):               # a padded tail: the kept keys are a prefix (views, no copy)
+            kb, vb = kb[:, :, :n], vb[:, :, :n]
+        else:
+            idx = keep[b].nonzero().flatten()
+            kb, vb = kb.index_select(2, idx), vb.index_select(2, idx)
+        out[b:b + 1].copy_(ops.attention(q[b:b + 1], kb, vb, softmax_scale))
+    return out
+
+
+def _key_keep_mask(attn_mask: torch.Tensor, B: int, Sk: int) -> torch.Tensor:
+    """attn_mask (bool keep-mask, or additive: finite-and-not-hugely-negative = keep) -> bool [B, Sk]; raises unless the mask
+    is constant along the head and query dimensions."""
+    m = attn_mask
+    if m.dim() == 2:
+        if m.shape[-1] != Sk or m.shape[0] not in (1, B):
+            raise ApexMIError(f"hip_mfma: attn_mask shape {tuple(m.shape)} is not a [B, Sk] key-padding mask")
+        m = m[:, None, None, :]
+    if m.dim() == 3:
+        m = m[:, None]
+    if m.dim() != 4 or m.shape[-1] != Sk or m.shape[1] != 1 or m.shape[2] != 1 or m.shape[0] not in (1, B):
+        raise ApexMIError(f"hip_mfma: attn_mask of shape {tuple(attn_mask.shape)} varies along the head / query dimension; only "
+                          "key-padding masks ([B, Sk], [B, 1, 1, Sk]) are supported")
+    keep = m[:, 0, 0, :]
+    if keep.dtype != torch.bool:
+        keep = torch.isfinite(keep) & (keep > -1e4)
+    return keep.expand(B, Sk)
 
 
 def available() -> bool:

@@ -94,6 +94,7 @@ struct Cfg {
 };
 using CFG_128 = Cfg<128, 128, 2, 2, 0>;
 using CFG_256 = Cfg<256, 256, 2, 4, 0>;
+using CFG_128E = Cfg<128, 128, 2, 4, 0>;   // 128x128 block on EIGHT waves (64x32 each): half the LDS-DMA pieces per wave and K-tile
 using CFG_256P = Cfg<256, 256, 2, 4, 1>;
 using CFG_256W = Cfg<256, 256, 2, 2, 4>;
 using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
-int g_tail_split = 1; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling
+int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
@@ -1056,6 +1057,9 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
                 T.p[0] = G.p[li];
                 G.count = li;
                 if (int rc = launch_cfg<CFG_256P16, EPI>(G, Ms, stream)) return rc;
+                // the tail launch is under one workgroup per CU, i.e. a latency chain per K-tile whose length is the LDS-DMA
+                // pieces a wave issues (~150 cycles each): eight waves per 128x128 tile issue 4 per K-tile, four waves 8
+                if (g_tail_split == 2) return launch_cfg<CFG_128E, EPI>(T, Ms + li, stream);
                 return launch_cfg<CFG_128, EPI>(T, Ms + li, stream);
             }
         }
@@ -1063,6 +1067,7 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     switch (cfg) {
         case 1: return launch_cfg<CFG_128, EPI>(G, Ms, stream);
         case 2: return launch_cfg<CFG_256, EPI>(G, Ms, stream);
+        case 8: return launch_cfg<CFG_128E, EPI>(G, Ms, stream);
         case 6: return launch_cfg<CFG_256W, EPI>(G, Ms, stream);
         case 7: return launch_cfg<CFG_256P16, EPI>(G, Ms, stream);
         default:

@@ -22,6 +22,7 @@ temb with one more GEMV pair.
 from __future__ import annotations
 
 import contextlib
+import os
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple
 
@@ -158,6 +159,8 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         self._ws: Dict[Any, Any] = {}
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
+        # q/k/v preparation in the QKV GEMM's epilogue where the launch allows it (APEX_FUSE_QKV=0: A/B)
+        self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"
 
     # ---- the duck-typed surface LoaderMixin / the engines use ----
     @classmethod
@@ -406,6 +409,11 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
 
         q_in, k_in, v_in = QKV[:, :dim], QKV[:, dim:2 * dim], QKV[:, 2 * dim:]
         att_v = ATT.unflatten(-1, (H, 128)).unsqueeze(0)
+        # fused q/k/v preparation (apexmi_gemm_bf16_grouped_qkv) where the launch allows it: bf16 storage, 8-aligned streams,
+        # >= 1024 rows; `fuse_qkv = False` keeps the [S, 3 dim] projection as a storage point (tests/stage_parity.py)
+        fuse = (getattr(self, "fuse_qkv", True) and getattr(self, "storage_dtype", torch.bfloat16) == torch.bfloat16
+                and len(self.transformer_blocks) > 0 and tuple(rope.shape) == (2, S, 128)
+                and ops.qkv_fusable([XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H))
         for i, blk in enumerate(self.transformer_blocks):
             if i == 1 and mod_ready is not None:
                 torch.cuda.current_stream().wait_event(mod_ready)
@@ -416,10 +424,17 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
             mt = lambda j: ws.MOD[0, base + (6 + j) * dim: base + (7 + j) * dim]        # noqa: E731  condition stream
             # AdaLayerNormZero chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
             ops.ln_modulate(X, mi(1), mi(0), out=XN, split=s_txt, scale2=mt(1), shift2=mt(0))
-            ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [QKV[s_txt:], QKV[:s_txt]])
-            ops.qkv_prepare(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], wq=a.norm_q.weight, wk=a.norm_k.weight,
-                            wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight, split=s_txt, eps=1e-6, rope=rope,
-                            rope_mode=_l.ROPE_INTERLEAVED)
+            if fuse:
+                # q/k norm + RoPE + [H, S, D] layout and V^T leave the QKV GEMM's epilogue (bit-identical to the two passes)
+                ops.gemm_grouped_qkv([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [None, None], "bias",
+                                     [1, 1], [a.norm_q.weight, a.norm_added_q.weight], [a.norm_k.weight, a.norm_added_k.weight],
+                                     [s_txt, 0], H, 1e-6, rope, ws.Q[0], ws.K[0], ws.VT[0])
+            else:
+                ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
+                                 [QKV[s_txt:], QKV[:s_txt]])
+                ops.qkv_prepare(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], wq=a.norm_q.weight,
+                                wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
+                                split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(ws.Q, ws.K, ws.VT, att_v, S)
             ops.gemm_grouped([ATT[s_txt:], ATT[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
                              [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",

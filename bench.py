@@ -297,7 +297,8 @@ def build_qwen(args, dev, rank, total):
     from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
     from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler
     from apex_studio_amd.engine_flux import calculate_shift
-    model = QwenImageTransformer2DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=4321 + rank)
+    kw = {"num_layers": int(args.layers.split(",")[0])} if args.layers else {}     # debug depth (PMC passes), invalid as a result
+    model = QwenImageTransformer2DModel(device=dev, dtype=torch.bfloat16, **kw).init_synthetic(seed=4321 + rank)
     model.pack()
     g = torch.Generator(device=dev).manual_seed(200 + rank)
     latents = torch.randn(1, 4096, 64, generator=g, device=dev).to(torch.bfloat16)
@@ -697,14 +698,18 @@ def main():
         # inside this process: the committed summary is used ONLY if it was taken from the kernel source this binary
         # was built from (sha256 recorded next to it); otherwise null — never a stale constant.
         traffic, traffic_src = None, None
-        src_file, pmc_file = (("gemm.hip", "r02_pmc_gemm.json") if dom == "gemm" else ("attention.hip", "r02_pmc_attn_wan.json"))
-        pmc = os.path.join(ROOT, "profiles", pmc_file)
-        if os.path.exists(pmc) and ((dom == "gemm" and args.workload == "flux") or (dom == "attention" and args.workload == "wan")):
-            import hashlib
+        import glob
+        import hashlib
+        src_file = "gemm.hip" if dom == "gemm" else "attention.hip"
+        suffix = {("gemm", "flux"): "pmc_gemm.json", ("gemm", "qwen"): "pmc_gemm_qwen.json",
+                  ("attention", "wan"): "pmc_attn_wan.json"}.get((dom, args.workload))
+        with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
+            src_hash = hashlib.sha256(f.read()).hexdigest()
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{suffix}")), reverse=True) if suffix else []:
             rec = json.load(open(pmc))
-            with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
-                if rec.get("source_sha256") == hashlib.sha256(f.read()).hexdigest():
-                    traffic, traffic_src = rec.get("traffic_bytes_per_launch"), f"profiles/{pmc_file}"
+            if rec.get("source_sha256") == src_hash:
+                traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
+                break
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_c4_kernel",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],

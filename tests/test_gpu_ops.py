@@ -676,3 +676,32 @@ def test_gemm_grouped_tail_problem_on_small_tiling():
     for tail in (1, 0):
         _check(outs[tail], ref.cpu(), 3e-3, f"grouped tail={tail}")
     assert torch.equal(outs[1][Mt:], outs[0][Mt:])          # the image rows come from the same kernel either way
+
+
+def test_attention_backend_key_padding_masks():
+    """`hip_mfma(q, k, v, attn_mask=...)` for the mask forms a padded prompt batch brings (the reference forwards
+    `attn_mask=attention_mask` at every call site): bool keep-masks and additive 0 / -inf masks, [B, Sk] and [B, 1, 1, Sk],
+    padded tails and holes, against torch's masked softmax in f32.  Query-varying masks still raise."""
+    import torch.nn.functional as F
+    from apex_studio_amd import attention_backend as ab
+    from apex_studio_amd.lib import ApexMIError
+    g = torch.Generator(device="cuda").manual_seed(17)
+    B, H, Sq, Sk, D = 3, 4, 192, 320, 128
+    q, k, v = (torch.randn(B, H, s, D, generator=g, device="cuda").to(torch.bfloat16) for s in (Sq, Sk, Sk))
+    keep = torch.ones(B, Sk, dtype=torch.bool, device="cuda")
+    keep[0, 200:] = False                    # padded tail
+    keep[1, 17:40] = False                   # a hole
+    keep[1, 300:] = False
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float(), attn_mask=keep[:, None, None, :])
+    add = torch.zeros(B, 1, 1, Sk, device="cuda").masked_fill(~keep[:, None, None, :], float("-inf"))
+    for m in (keep, keep[:, None, None, :], add, add.to(torch.bfloat16)):
+        out = ab.hip_mfma(q, k, v, attn_mask=m)
+        assert out.shape == ref.shape and out.dtype == q.dtype
+        rel = float((out.float() - ref).norm() / ref.norm())
+        assert rel < 4e-3, rel
+    full = ab.hip_mfma(q, k, v, attn_mask=torch.ones(1, 1, 1, Sk, dtype=torch.bool, device="cuda"))
+    assert torch.equal(full, ab.hip_mfma(q, k, v))
+    with pytest.raises(ApexMIError):
+        ab.hip_mfma(q, k, v, attn_mask=torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device="cuda"))
+    with pytest.raises(ApexMIError):
+        ab.hip_mfma(q, k, v, attn_mask=torch.zeros(B, Sk, dtype=torch.bool, device="cuda"))

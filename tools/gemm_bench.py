@@ -17,7 +17,7 @@ SHAPES_ALL = [  # (name, M, N, K, epilogue)
     ("qkv_joint", 4608, 9216, 3072, "bias"), ("mlp_up_single", 4608, 12288, 3072, "gelu"),
     ("proj_out_single", 4608, 3072, 15360, "gate_res"), ("attn_out_img", 4096, 3072, 3072, "gate_res"),
     ("ff_down_img", 4096, 3072, 12288, "gate_res"), ("ff_up_img", 4096, 12288, 3072, "gelu"),
-    ("qkv_txt", 512, 9216, 3072, "bias"),
+    ("qkv_txt", 512, 9216, 3072, "bias"), ("qwen_ff_up_txt", 256, 12288, 3072, "gelu"), ("qwen_ff_down_txt", 256, 3072, 12288, "gate_res"),
     ("t_4608_3072_12288", 4608, 3072, 12288, "gate_res"), ("t_4096_3072_15360", 4096, 3072, 15360, "gate_res"),
     ("t_4096_3072_8192", 4096, 3072, 8192, "gate_res"), ("t_4096_3072_12352", 4096, 3072, 12352, "gate_res"),
     ("t_4096_4096_12288", 4096, 4096, 12288, "gate_res"), ("square_4096", 4096, 4096, 4096, "bias"),

@@ -2,14 +2,18 @@
 # HBM-side traffic + MFMA-pipe occupancy of the dominant kernel of the Flux step (gemm_bf16_kernel) from separate
 # rocprofv3 --pmc passes (kernel-trace only beside the counters), on a DEPTH-REDUCED step (3 double + 6 single blocks:
 # the per-launch figures do not depend on the depth, and counter collection costs ~50 ms per dispatch).
-# Writes gpurun_out/pmc_gemm/r02_pmc_gemm.json (copy to profiles/): per-launch means over the step's GEMM launches,
+# WORKLOAD=qwen: the same over a 3-block QwenImage-Edit step.
+# Writes gpurun_out/pmc_gemm/r03_pmc_gemm[_qwen].json (copy to profiles/): per-launch means over the step's GEMM launches,
 # FETCH_SIZE doubled per MI355X_MICROARCH.md, and the sha256 of csrc/gemm.hip the binary was built from.
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_gemm
+W=${WORKLOAD:-flux}                 # flux | qwen
+OUT=$R/gpurun_out/pmc_gemm_$W
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
+TAG=$([ "$W" = flux ] && echo r03_pmc_gemm || echo r03_pmc_gemm_$W)
+export TAG W
+CMD="python $R/bench.py --workload $W --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
 T=${PROF_TIMEOUT:-420}
 timeout $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o g -- $CMD > $OUT/fetch.log 2>&1; echo "fetch $?"
 timeout $T rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/write -o g -- $CMD > $OUT/write.log 2>&1; echo "write $?"
@@ -18,7 +22,7 @@ cd $R
 python - <<'PY'
 import csv, glob, hashlib, json, os
 root = os.environ["GRAFT_REPO_ROOT"]
-out = root + "/gpurun_out/pmc_gemm/"
+out = root + "/gpurun_out/pmc_gemm_" + os.environ["W"] + "/"
 def means(sub, pick):
     vals, durs = {}, []
     for f in glob.glob(out + sub + "/**/*counter_collection.csv", recursive=True):
@@ -34,7 +38,7 @@ f, (n, ns_f) = means("fetch", "gemm_bf16_kernel")
 w, _ = means("write", "gemm_bf16_kernel")
 s, _ = means("sq", "gemm_bf16_kernel")
 res = {"kernel": "gemm_bf16_kernel<Cfg<256,256,2,4,5>> (ping-pong, v_mfma_f32_16x16x32_bf16), all epilogues",
-       "command": "python bench.py --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan",
+       "command": "python bench.py --workload %s --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan" % os.environ["W"],
        "source_sha256": hashlib.sha256(open(root + "/apex-studio_amd/csrc/gemm.hip", "rb").read()).hexdigest(),
        "dispatches": n, "avg_duration_ns_under_pmc": ns_f}
 if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
@@ -52,7 +56,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in s:
         res["mfma_pipe_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES summed over the chip / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs): share of SIMD-cycles with the matrix pipe busy"
     if s.get("SQ_LDS_IDX_ACTIVE"):
         res["lds_bank_conflict_share"] = s.get("SQ_LDS_BANK_CONFLICT", 0.0) / s["SQ_LDS_IDX_ACTIVE"]
-json.dump(res, open(out + "r02_pmc_gemm.json", "w"), indent=1)
+json.dump(res, open(out + os.environ["TAG"] + ".json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
