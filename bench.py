@@ -494,7 +494,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and os.environ.get("APEX_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node; an {args.gpus}-GPU "
                          f"result needs {args.gpus} ranks, one per GPU — refusing to run")
     s = socket.socket()
@@ -566,6 +566,11 @@ def main():
                          f"one rank of this job")
     import torch.distributed as dist
     distributed = world > 1 or os.environ.get("APEX_FORCE_DIST") == "1"   # force: RCCL smoke test on one GPU
+    # APEX_BENCH_SHARE_GPU=1 (DEBUG, invalid as a result): every rank on cuda:0 over gloo — rehearses the N > 1 control flow
+    # (rank spawn, barriers, max-over-ranks, the exchange step's failure path: gloo has no CUDA scatter) on a one-GPU box
+    share_gpu = os.environ.get("APEX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     for kv in filter(None, args.tune.split(",")):
@@ -575,7 +580,10 @@ def main():
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("NCCL_DEBUG", "WARN")        # no version banner on stdout next to the JSON line
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import apex_studio_amd  # noqa: F401
     from apex_studio_amd import lib, render_queue
@@ -631,7 +639,7 @@ def main():
                 "world": world, "rccl_ranks": world if distributed else 1,
                 "model_tflops_per_gpu": (tf_ / (ms * 1e-3)) if full_ else None,
                 "mfma_utilisation_step": (tf_ / (ms * 1e-3) / PEAK_BF16_TFLOPS) if full_ else None,
-                "finite": finite, "broadcast": b or None}
+                "finite": finite, "broadcast": b or None, **({"debug_shared_gpu": True} if share_gpu else {})}
 
     # The ONE exchange step of the queue — shared text-encoder / VAE weights from rank 0, scatter + all-gather per 1 GiB
     # bucket, every rank then encodes the same ids with ITS copy and the results are compared bit for bit — runs AFTER the
@@ -733,12 +741,22 @@ def main():
             del step, latents, clip_fn
             torch.cuda.empty_cache()
             out["wan"] = wan_half(dev)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
     _flush_c_stdio()           # RCCL's version banner sits in C stdio: get it out BEFORE the result line
     if rank == 0:
         print(json.dumps(out), flush=True)    # the ONE JSON line, last on stdout
+    if distributed:
+        # The line is out: a rank that never reaches this barrier (or a teardown that hangs) must not hold the job open —
+        # leave after a minute whatever happens.
+        import threading
+        t = threading.Timer(60.0, lambda: os._exit(0))
+        t.daemon = True
+        t.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001  (teardown only; the result is already printed)
+            print(f"[bench] teardown: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        t.cancel()
 
 
 if __name__ == "__main__":
