@@ -177,3 +177,27 @@ def test_flux_full_width_one_plus_one_blocks_match_oracle(host_threads):
     plan, po = SP.flux_plan(pol.points, cfg, 512)
     forced, report = SP.run_forced(ops, m, plan, lambda: m(return_dict=False, **g)[0])
     SP.assert_stages("flux full width 1+1", report, forced, po)
+
+
+def test_rotary_table_cache_follows_the_position_ids():
+    """The rotary table is kept across calls while the SAME id tensors come back unmodified (a sampler loop): an in-place edit
+    (`_version`) or another tensor object recomputes it."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["tiny"]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 7).items()}, strict=True)
+    inp = _inputs(cfg, hw, s_txt)
+    g = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k in
+             ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV)) for k, v in inp.items()}
+    a = m(return_dict=False, **g)[0].clone()
+    table = m._rope_cache[3]
+    b = m(return_dict=False, **g)[0].clone()
+    assert m._rope_cache[3] is table and torch.equal(a, b)           # second call: cached
+    g["img_ids"].add_(5.0)                                            # in-place edit of the SAME tensor
+    c = m(return_dict=False, **g)[0].clone()
+    assert m._rope_cache[3] is not table and not torch.equal(a, c)
+    m._rope_cache = None
+    assert torch.equal(c, m(return_dict=False, **g)[0])
+    g2 = dict(g, img_ids=g["img_ids"].clone())                        # another tensor object with the same values
+    table2 = m._rope_cache[3]
+    assert torch.equal(c, m(return_dict=False, **g2)[0]) and m._rope_cache[3] is not table2
