@@ -290,6 +290,26 @@ def test_hunyuan15_vae_encode_matches_reference_and_oracle(golden_dir):
     assert torch.allclose(vae.normalize_latents(torch.tensor(2.0)), torch.tensor(2.0 * 1.03682))
 
 
+def test_hunyuan15_vae_tiles_on_side_streams_are_bit_identical(golden_dir):
+    """`decode_streams` tiles of the tiled decode run on their own HIP streams (the low-resolution stages launch far fewer
+    workgroups than the chip has slots): same kernels on the same data, so 1, 2 and 5 streams must give the same bits, repeated
+    calls included (stream reuse, allocator hand-over between streams)."""
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    cfg = torch.load(os.path.join(golden_dir, "vae_hunyuan15.pt"), weights_only=False)["config"]
+    vae = AutoencoderKLHunyuanVideo15(**cfg, device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vae_synthetic_state_dict(vae, 3).items()}, strict=True)
+    vae.enable_tiling(tile_sample_min_height=64, tile_sample_min_width=64, tile_latent_min_height=4, tile_latent_min_width=4)
+    z = seeded((1, cfg["latent_channels"], 3, 10, 14), 5).to(DEV).to(torch.bfloat16)          # 4 x 5 = 20 tiles
+    outs = {}
+    for ns in (1, 2, 5, 2, 1):
+        vae.decode_streams = ns
+        o = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all()
+        outs.setdefault(ns, o)
+        assert torch.equal(o, outs[1]), ns
+
+
 # ---- Wan / QwenImage VAE encode (the B-model `.encode` contract, SURVEY.md §8b) ------------------------------------
 
 @pytest.mark.parametrize("cin,cout,T,H,W", [(32, 32, 3, 16, 20), (64, 64, 1, 33, 18), (96, 96, 2, 64, 48)])
