@@ -342,6 +342,7 @@ def wan_plan(points, cfg, affine_norm2: bool = True):
 
 
 # ---- generic teacher forcing: match every tensor an op wrote against the oracle's unconsumed storage points ----------------
+SLOT_HEADS = (2, 4, 8, 12, 16, 20, 24, 28, 32, 40)
 GEN_OPS = ("gemm", "gemm_grouped", "ln_modulate", "qkv_prepare", "attention_prepared", "attention", "add_rowvec",
            "gather_rows", "attention_bias", "mul", "rope_half_")
 
@@ -430,17 +431,37 @@ def run_forced_generic(ops_mod, points: Sequence[torch.Tensor], call: Callable[[
                         g = flat[r0:r0 + r, c0:c0 + c]
                         rel = float((g - want).norm() / (want.norm() + 1e-30))
                         if rel < accept and (best is None or rel < best[0]):
-                            best = (rel, idx, r0, c0, int((g != want).sum()), want)
+                            best = (rel, idx, r0, c0, int((g != want).sum()), want, None)
+                # heads narrower than the kernels' 128-wide slots (Qwen2.5-VL vision: 80): the HIP buffers keep every head in a
+                # 128-column slot (zeros behind it); the point [r, nh * dv] sits in a block of nh slots
+                for nh in SLOT_HEADS:
+                    dv = c // nh
+                    if c % nh or dv >= 128 or dv % 8 or nh * 128 > C:
+                        continue
+                    bw = nh * 128
+                    for r0 in {0, R - r}:
+                        for c0 in range(0, C - bw + 1, bw):
+                            if any(r0 < b and a < r0 + r and c0 < d and cc < c0 + bw for a, b, cc, d in covered):
+                                continue
+                            g = flat[r0:r0 + r, c0:c0 + bw].reshape(r, nh, 128)[:, :, :dv].reshape(r, c)
+                            rel = float((g - want).norm() / (want.norm() + 1e-30))
+                            if rel < accept and (best is None or rel < best[0]):
+                                best = (rel, idx, r0, c0, int((g != want).sum()), want, (nh, dv))
             if best is None:
                 break
-            rel, idx, r0, c0, nd, want = best
+            rel, idx, r0, c0, nd, want, slot = best
             r, c = want.shape
             used[idx] = True
-            covered.append((r0, r0 + r, c0, c0 + c))
-            report.append((len(report), name, f"point {idx} {tuple(points[idx].shape)} @ rows {r0}+{r} cols {c0}+{c}", rel, nd,
-                           want.numel()))
+            covered.append((r0, r0 + r, c0, c0 + (c if slot is None else slot[0] * 128)))
+            report.append((len(report), name, f"point {idx} {tuple(points[idx].shape)} @ rows {r0}+{r} cols {c0}+{c}"
+                           + ("" if slot is None else f" in {slot[0]} x 128 slots"), rel, nd, want.numel()))
             if force:
-                if Hh == 1:
+                if slot is not None:
+                    nh, dv = slot
+                    tgt = view.reshape(R, C)[r0:r0 + r, c0:c0 + nh * 128].unflatten(1, (nh, 128))
+                    assert tgt.data_ptr() == view.reshape(R, C)[r0:r0 + r, c0:].data_ptr(), "slot view must alias the op's storage"
+                    tgt[:, :, :dv].copy_(want.to(view.dtype).view(r, nh, dv))
+                elif Hh == 1:
                     view[r0:r0 + r, 0, c0:c0 + c].copy_(want.to(view.dtype))
                 else:
                     assert c == C, "a point inside a heads-layout tensor must span every head"

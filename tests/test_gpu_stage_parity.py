@@ -379,3 +379,40 @@ def test_qwen2_5_vl_text_every_storage_point(golden_dir):
     print(f"[stage qwen2.5-vl text] {len(report)} storage points, worst {worst:.2e}; output after the last forced point {e_out:.2e}; "
           f"free-running {e_free:.2e}")
     assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 2e-2
+
+
+def test_qwen2_5_vl_vision_tower_every_storage_point(golden_dir):
+    """Qwen2.5-VL VISION tower (the image half of the QwenImage-Edit prompt encoder) with two images: patch
+    embedding as a GEMM, the window permutation, RMS norm, fused QKV + rotate-half RoPE on the q | k columns, windowed /
+    per-image block-diagonal attention, SwiGLU MLP, the 2 x 2 patch merger.  Teacher forcing through the generic runner: every
+    tensor an op writes is matched against the oracle's storage points (DESIGN.md §1.1 bar 2)."""
+    from apex_studio_amd import ops
+    from tests.test_gpu_qwen_vl import _models
+    g = torch.load(os.path.join(golden_dir, "qwen2_5_vl.pt"), weights_only=False)
+    orc, hip = _models(g)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in orc.state_dict().items()}      # bf16-representable on both sides
+    orc.load_state_dict(sd, strict=True)
+    hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    im = g["image"]
+    px = im["pixel_values"].to(torch.bfloat16).float()
+    pol = SP.TracePolicy()
+    with torch.no_grad():
+        po = orc.model.visual(px, im["grid"], pol)
+    run = lambda: hip.get_image_features(px.to(DEV), im["grid"])   # noqa: E731
+    free = run()
+    S = px.shape[0]
+    hd = g["vision_config"]["hidden_size"] // g["vision_config"]["num_heads"]
+    d = g["vision_config"]["hidden_size"]
+    # the oracle keeps q / k after the rotation as [S, H, hd]: one row per position for the matcher
+    points = [p.reshape(S, d) if (p.dim() == 3 and p.shape[0] == S and p.shape[1] * p.shape[2] == d) else p for p in pol.points]
+    out, report, left = SP.run_forced_generic(ops, points, run, heads_first=(S, hd))
+    worst, _ = SP.print_report("qwen2.5-vl vision", report)
+    shapes = [(i, tuple(pol.points[i].shape)) for i in left]
+    print(f"[stage qwen2.5-vl vision] {len(report)} of {len(pol.points)} storage points matched, unmatched {shapes[:12]}")
+    e_out, e_free = _rel(out.float().cpu(), po), _rel(free.float().cpu(), po)
+    print(f"[stage qwen2.5-vl vision] worst {worst:.2e}; output after the last forced point {e_out:.2e}; free-running {e_free:.2e}")
+    # attention probabilities ([H, S, S]) live only inside the attention call's workspace; everything else must be matched
+    # ... and the pixel input itself (point 0: rounded by the caller, written by no op)
+    stray = [i for i in left if i != 0 and not (pol.points[i].dim() >= 2 and tuple(pol.points[i].shape[-2:]) == (S, S))]
+    assert len(report) >= 8 * len(orc.model.visual.blocks) and not stray, [(i, tuple(pol.points[i].shape)) for i in stray][:8]
+    assert worst <= SP.STAGE_TOL and e_out <= SP.STAGE_TOL and e_free < 2e-2
