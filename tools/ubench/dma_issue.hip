@@ -5,7 +5,7 @@
 //   C  plain buffer_load_dwordx4 into VGPRs (no LDS)                  D  as A but dword pieces (256 B each)
 //   E  as A with 8 independent v_fma between the pieces (is it a fixed wave-side stall or queue back-pressure?)
 // All loads hit L2 (a 1 MiB window read over and over).
-//   hipcc --offload-arch=gfx950 -O3 -o dma_issue dma_issue.hip && ./dma_issue
+//   hipcc --offload-arch=gfx950 -O3 -o bin/dma_issue dma_issue.hip && bin/dma_issue   (bin/ is git-ignored; it ships to the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
