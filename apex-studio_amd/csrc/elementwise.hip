@@ -612,20 +612,20 @@ __global__ __launch_bounds__(256) void dequant_fp8_scaled_kernel(const uint8_t* 
 
 // out[r, c] = x[r, c] + v[c] (bf16 in / out, f32 add): `tokens + cond_type_embed(type)` of the HunyuanVideo-1.5
 // conditioning streams (transformer/hunyuanvideo15/base/model.py:1013-1056)
-__global__ __launch_bounds__(256) void add_rowvec_bf16_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
-                                                              int64_t ldo, int64_t rows, int cols) {
+template <typename T>     // T: storage type of x / out (bf16_t in production, float in the f32-storage verification mode); v is a weight
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const T* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ v,
+                                                         T* __restrict__ out, int64_t ldo, int64_t rows, int cols) {
     const int nch = cols >> 3;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * nch) return;
     const int64_t r = idx / nch;
     const int c = (int)(idx % nch) * 8;
     float a[8], b[8];
-    unpack8(*(const u32x4*)(x + r * ldx + c), a);
+    load8<T>(x + r * ldx + c, a);
     unpack8(*(const u32x4*)(v + c), b);
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] += b[j];
-    *(u32x4*)(out + r * ldo + c) = pack8(a);
+    store8<T>(out + r * ldo + c, a);
 }
 
 // out = a + b (bf16, f32 add): `h + shortcut` of HunyuanVideo15Upsample.forward / Decoder3D.forward after the DCAE
@@ -1010,9 +1010,22 @@ extern "C" int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v,
                    "add_rowvec_bf16: rows must be 16-byte aligned and cols a multiple of 8");
     ApexmiProfScope prof(5, stream, 0.0, 4.0 * rows * cols);
     const int64_t n = rows * (cols / 8);
-    hipLaunchKernelGGL(add_rowvec_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+    hipLaunchKernelGGL(add_rowvec_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        ldx, (const bf16_t*)v, (bf16_t*)out, ldo, rows, cols);
     return apexmi_check_launch("add_rowvec_bf16");
+}
+
+extern "C" int apexmi_add_rowvec_f32(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
+                                     int cols, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && v && out && rows > 0 && cols > 0, "add_rowvec_f32: bad arguments");
+    APEXMI_REQUIRE(cols % 8 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                       ((uintptr_t)out % 16) == 0,
+                   "add_rowvec_f32: rows must be 16-byte aligned and cols a multiple of 8");
+    const int64_t n = rows * (cols / 8);
+    hipLaunchKernelGGL(add_rowvec_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)x, ldx,
+                       (const bf16_t*)v, (float*)out, ldo, rows, cols);
+    return apexmi_check_launch("add_rowvec_f32");
 }
 
 __global__ __launch_bounds__(256) void group_mean_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,

@@ -159,6 +159,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         self._ws: Dict[Any, Any] = {}
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
+        self.storage_dtype = torch.bfloat16
         # q/k/v preparation in the QKV GEMM's epilogue where the launch allows it (APEX_FUSE_QKV=0: A/B)
         self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"
 
@@ -272,7 +273,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         inner = self.transformer_blocks[0].ff.net[0].proj.weight.shape[0] if len(self.transformer_blocks) else 4 * dim
         S = s_txt + s_img
         skp = (S + 63) // 64 * 64
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=self.storage_dtype)     # activations: bf16, or float in the verification mode
         f32 = dict(device=dev, dtype=torch.float32)
         ws = SimpleNamespace(
             X=torch.empty(S, dim, **bf), XN=torch.empty(S, dim, **bf), QKV=torch.empty(S, 3 * dim, **bf),
@@ -281,6 +282,15 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
             TEMB=torch.empty(1, dim, **f32))
         self._ws = {key: ws}
         return ws
+
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE — the same kernel
+        sequence with every activation buffer float and the library's `_f32` entry points.  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        self._ws = {}
+        return self
 
     def _rope_table(self, grid: Tuple[int, int, int], s_txt: int):
         key = (grid, s_txt)
@@ -308,7 +318,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         # masked mean over tokens = (mask / n) @ text, as a GEMV with text^T as the weight operand (K padded to 8)
         kp = (T1 + 7) // 8 * 8
         xt = torch.zeros(Cc, kp, device=text.device, dtype=torch.bfloat16)
-        xt[:, :T1] = text.t()
+        xt[:, :T1] = text.t().to(torch.bfloat16)    # (an input: bf16-representable in either storage mode)
         wv = torch.zeros(1, kp, device=text.device, dtype=torch.float32)
         wv[0, :T1] = mask.float() / float(n_valid)
         pooled = ops.gemv(xt, wv)
@@ -343,7 +353,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         Cin, F_, Hh, Ww = latent.shape
         grid = (F_ // pt, Hh // p, Ww // p)
         s_img = grid[0] * grid[1] * grid[2]
-        t = timestep.to(self.dtype).float().reshape(1)        # `t.expand(B).to(latents.dtype)`, engine t2v.py:243-245
+        t = timestep.to(self.storage_dtype).float().reshape(1)   # `t.expand(B).to(latents.dtype)`, engine t2v.py:243-245
         E = self.cond_type_embed.weight
 
         # ---- condition streams ----
@@ -356,7 +366,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         is_t2v = bool((image == 0).all())
         n3 = image.shape[0]
         if is_t2v:
-            c3 = E[2].reshape(1, dim).expand(n3, dim)          # `projection * 0.0 + cond_type_embed(2)`, :1031-1056
+            c3 = E[2].reshape(1, dim).expand(n3, dim).to(self.storage_dtype)   # `projection * 0.0 + cond_type_embed(2)`, :1031-1056
         else:
             ie = self.image_embedder
             h = ops.ln_modulate(image, gamma=ie.norm_in.weight, beta=ie.norm_in.bias, eps=1e-5)
@@ -381,14 +391,14 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         Xt.copy_(cond)
         # patchify: [C, F, H, W] -> [S, C*pt*p*p] (Conv3d with kernel = stride = patch is a GEMM over patches)
         pat = latent.reshape(Cin, grid[0], pt, grid[1], p, grid[2], p).permute(1, 3, 5, 0, 2, 4, 6).reshape(s_img, -1)
-        A = torch.zeros(s_img, self._w_patch.shape[1], device=latent.device, dtype=torch.bfloat16)
+        A = torch.zeros(s_img, self._w_patch.shape[1], device=latent.device, dtype=self.storage_dtype)
         A[:, :pat.shape[1]] = pat
         ops.gemm(A, self._w_patch, self.x_embedder.proj.bias, out=Xi)
 
         self._temb(self.time_embed.timestep_embedder, t, out=ws.TEMB)
         if timestep_r is not None:
             ter = self.time_embed.timestep_embedder_r
-            tr = timestep_r.to(self.dtype).float().reshape(1)      # `timestep_r.expand(B).to(latents.dtype)`, i2v.py:281-286
+            tr = timestep_r.to(self.storage_dtype).float().reshape(1)   # `timestep_r.expand(B).to(latents.dtype)`, i2v.py:281-286
             hr = ops.gemv(ter.linear_1.weight, ops.timestep_embedding(tr, 256, scale=1.0), ter.linear_1.bias, post="silu")
             ops.gemv(ter.linear_2.weight, hr, ter.linear_2.bias, out=ws.TEMB, accum=True)
         n_first = self._mod_first
@@ -463,7 +473,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
         if timestep_r is not None and not self.config.use_meanflow:
             raise ValueError("hunyuanvideo15.mi355: timestep_r given but the model was built with use_meanflow=False")
         self.pack()
-        bf = torch.bfloat16
+        bf = self.storage_dtype
         outs = []
         for b in range(hidden_states.shape[0]):
             outs.append(self._forward_one(

@@ -88,6 +88,7 @@ SIGNATURES = {
     "apexmi_rope_table_axes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, vp, vp]),
     "apexmi_add_bcast_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
     "apexmi_add_rowvec_bf16": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]),
+    "apexmi_add_rowvec_f32": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]),
     "apexmi_frames_to_u8": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       vp, vp]),
     "apexmi_mul_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),

@@ -626,17 +626,18 @@ def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 def add_rowvec(x: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[r, :] = x[r, :] + v  (bf16 [rows, cols] + bf16 [cols], f32 add)."""
-    _req(x, torch.bfloat16, "add_rowvec.x")
+    """out[r, :] = x[r, :] + v  (bf16 [rows, cols] + bf16 [cols], f32 add; x / out float in the f32-storage mode)."""
+    _req_act(x, "add_rowvec.x")
     _req(v, torch.bfloat16, "add_rowvec.v")
     assert x.dim() == 2 and x.stride(1) == 1 and v.is_contiguous() and v.numel() == x.shape[1]
     if out is None:
-        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
     else:
-        _req(out, torch.bfloat16, "add_rowvec.out")
+        _req(out, x.dtype, "add_rowvec.out")
         assert out.shape == x.shape and out.stride(1) == 1
-    _l.check(_l.load().apexmi_add_rowvec_bf16(x.data_ptr(), x.stride(0), v.data_ptr(), out.data_ptr(), out.stride(0),
-                                              x.shape[0], x.shape[1], _stream()), "add_rowvec_bf16")
+    fn = getattr(_l.load(), "apexmi_add_rowvec_f32" if x.dtype == torch.float32 else "apexmi_add_rowvec_bf16")
+    _l.check(fn(x.data_ptr(), x.stride(0), v.data_ptr(), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], _stream()),
+             "add_rowvec")
     return out
 
 

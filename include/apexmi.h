@@ -399,6 +399,9 @@ int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t row
  * (hunyuanvideo15 model.py:1013-1056 `encoder_hidden_states + cond_type_embed(...)`). */
 int apexmi_add_rowvec_bf16(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
                            int cols, apexmi_stream_t stream);
+/* the same with float x / out (f32-storage verification mode; v stays a bf16 weight) */
+int apexmi_add_rowvec_f32(const void* x, int64_t ldx, const void* v, void* out, int64_t ldo, int64_t rows,
+                           int cols, apexmi_stream_t stream);
 
 /* out = a + b, n bf16 elements (n % 8 == 0): `h + shortcut` after the DCAE rearranges of the HunyuanVideo-1.5 VAE
  * (vae/hunyuanvideo15/model.py:274, :709-711). */

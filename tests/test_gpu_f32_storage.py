@@ -10,7 +10,7 @@ what is left between the HIP path and the CPU fp32 oracle is f32 summation order
 teacher forcing) and compared with the oracle in pure fp32 (`oracle.layers.FP32`):
 
   * per op: split exactness, GEMM epilogues, LN / q-k-norm + RoPE / attention, convolution variants, norms  (<= 2e-5)
-  * Flux / Wan / QwenImage transformer forwards, tiny and mid configurations                                 (<= 1e-3)
+  * Flux / Wan / QwenImage / HunyuanVideo-1.5 transformer forwards, tiny and mid configurations              (<= 1e-3)
   * Flux 2-D VAE decode, Wan 3-D VAE tiled decode and tiled encode                                           (<= 1e-3)
   * sampler chains -> decoded frames through the engines' `run()`: Flux 4 Euler steps, Wan 4 UniPC steps over two experts
     with CFG, QwenImage-Edit pixels -> encode -> 2 true-CFG steps -> decode                    (latents, decoded, frames <= 1e-3)
@@ -288,6 +288,30 @@ def test_qwen_forward_f32_storage(name):
         timestep=t.to(DEV), img_shapes=[shapes], txt_seq_lens=[s_txt], return_dict=False)[0])
     assert out.dtype == F32
     _report(f"qwen {name}", out, ref32, ref16)
+
+
+@pytest.mark.parametrize("i2v", [False, True])
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_hunyuan15_forward_f32_storage(name, i2v):
+    """HunyuanVideo-1.5 transformer: token refiner with a key-padding mask, the three condition streams and
+    their reorder, MM-DiT double-stream blocks — free-running with float storage against the fp32 oracle."""
+    from oracle import hunyuan15 as OH
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    from tests.test_gpu_hunyuan15 import CONFIGS as HY_CONFIGS, _inputs as hy_inputs, _oracle as hy_oracle
+    cfg, fhw, t1, v1, t2, v2 = HY_CONFIGS[name]
+    orc = OH.HunyuanVideo15Transformer3DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 15)
+    orc.load_state_dict(sd, strict=True)
+    inp = hy_inputs(cfg, fhw, t1, v1, t2, v2, i2v)
+    ref32, ref16 = hy_oracle(orc, inp), hy_oracle(orc, inp, OL.BF16_STORAGE)
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    g = {k: (_bf(v).to(DEV) if v.dtype == torch.float32 and k != "timestep" and "mask" not in k else v.to(DEV))
+         for k, v in inp.items()}
+    out = m(return_dict=False, **g)[0]
+    torch.cuda.synchronize()
+    assert out.dtype == F32 and out.shape == ref32.shape
+    _report(f"hunyuan15 {name} {'i2v' if i2v else 't2v'}", out, ref32, ref16)
 
 
 # ---- VAEs ----------------------------------------------------------------------------------------------------------------
