@@ -630,16 +630,16 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const T* __restrict__ x
 
 // out = a + b (bf16, f32 add): `h + shortcut` of HunyuanVideo15Upsample.forward / Decoder3D.forward after the DCAE
 // rearranges (vae/hunyuanvideo15/model.py:274, :709-711), where the two addends come out of different layouts
-__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                       bf16_t* __restrict__ out, int64_t n8) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n8) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     float x[8], y[8];
-    unpack8(*(const u32x4*)(a + i * 8), x);
-    unpack8(*(const u32x4*)(b + i * 8), y);
+    load8<T>(a + i * 8, x);
+    load8<T>(b + i * 8, y);
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] += y[j];
-    *(u32x4*)(out + i * 8) = pack8(x);
+    store8<T>(out + i * 8, x);
 }
 
 // out = a * b (bf16, f32 product): `hidden_gelu * hidden_linear` of T5DenseGatedActDense (transformers
@@ -1054,9 +1054,19 @@ extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t 
     APEXMI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0,
                    "add_bf16: operands must be 16-byte aligned");
     ApexmiProfScope prof(5, stream, 0.0, 6.0 * n);
-    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
+    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)out, n / 8);
     return apexmi_check_launch("add_bf16");
+}
+
+extern "C" int apexmi_add_f32(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "add_f32: n=%lld must be a positive multiple of 8", (long long)n);
+    APEXMI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                   "add_f32: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(add_kernel<float>, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const float*)a,
+                       (const float*)b, (float*)out, n / 8);
+    return apexmi_check_launch("add_f32");
 }
 
 extern "C" int apexmi_rope_half(void* x, int64_t ldx, int64_t rows, int heads, int head_stride, int D, const float* cos_,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "apexmi_conv3d_cl_norm_fusable": (C.c_int, [C.c_int] * 6),
     "apexmi_conv3d_cl_norm": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp] + [C.c_int] * 11 + [vp]),
     "apexmi_add_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "apexmi_add_f32": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "apexmi_group_mean_bf16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_rmsnorm_cl": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -546,13 +546,14 @@ def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = a + b for contiguous bf16 tensors of equal shape (numel a multiple of 8)."""
-    _req(a, torch.bfloat16, "add.a")
-    _req(b, torch.bfloat16, "add.b")
+    """out = a + b for contiguous tensors of equal shape (bf16; float in the f32-storage mode; numel a multiple of 8)."""
+    _req_act(a, "add.a")
+    _req(b, a.dtype, "add.b")
     assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty_like(a)
-    _l.check(_l.load().apexmi_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add_bf16")
+    fn = getattr(_l.load(), "apexmi_add_f32" if a.dtype == torch.float32 else "apexmi_add_bf16")
+    _l.check(fn(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
     return out
 
 

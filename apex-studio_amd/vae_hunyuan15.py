@@ -209,6 +209,7 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         self.tile_latent_min_height = self.tile_latent_min_width = 128 // spatial_compression_ratio
         self.tile_overlap_factor = 0.25
         self._packed: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.storage_dtype = torch.bfloat16
         self.decode_streams = 2      # spatial tiles decoded side by side on their own HIP streams (see _decode_tiles)
         self._streams: list = []
         # the TAEHV "light" decoder (model.py:794-846): built lazily when `enable_tiling(use_light_vae=True)` asks for it, or
@@ -264,6 +265,16 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
     def set_light_vae(self, light_vae) -> None:
         """Attach an already built `AutoencoderKLHunyuanVideo15Light` (weights streamed by the host's own loader)."""
         self.light_vae = light_vae
+
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE of the DECODER: every
+        activation float, the library's `_f32` entry points (the convolutions on the exact three-way bf16 split), and the
+        frame-causal mid-block attention as one f32 attention call per frame over the keys of the frames up to it — the same
+        softmax, without the bf16 probabilities of the materialised production path.  Weights stay bf16; encode stays bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        return self
 
     def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_latent_min_height=None,
                       tile_latent_min_width=None, tile_overlap_factor=None, use_light_vae: Optional[bool] = None):
@@ -332,7 +343,12 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         S = T * H * W
         n = ops.rmsnorm_cl(x, self._g(blk.norm)).view(S, Cc)
         q, k, v = (self._conv1(m, n).view(1, 1, S, Cc) for m in (blk.to_q, blk.to_k, blk.to_v))
-        o = ops.attention_framecausal(q, k, v, H * W).permute(0, 2, 1, 3).reshape(S, Cc)
+        if x.dtype == torch.float32:     # verification mode: frame f's queries over the keys of frames <= f, f32 softmax
+            hw = H * W
+            o = torch.cat([ops.attention(q[:, :, f * hw:(f + 1) * hw], k[:, :, :(f + 1) * hw], v[:, :, :(f + 1) * hw])
+                           for f in range(T)], dim=2).permute(0, 2, 1, 3).reshape(S, Cc)
+        else:
+            o = ops.attention_framecausal(q, k, v, H * W).permute(0, 2, 1, 3).reshape(S, Cc)
         ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
         return self._conv1(blk.proj_out, o, epilogue="gate_res", gate=ones, residual=x.view(S, Cc)).view(T, H, W, Cc)
 
@@ -481,7 +497,7 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         if z.device.type != "cuda" or self.dtype != torch.bfloat16:
             raise _l.ApexMIError("hunyuanvideo15_mi355 VAE needs bf16 weights and latents on a ROCm device (no CPU fallback)")
         _, T, H, W = z.shape
-        zc = z.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+        zc = z.to(self.storage_dtype).permute(1, 2, 3, 0).contiguous()
         tlh, tlw = self.tile_latent_min_height, self.tile_latent_min_width
         if not (self.use_tiling and (W > tlw or H > tlh)):
             out = self._decode_tile(zc)

@@ -406,6 +406,8 @@ int apexmi_add_rowvec_f32(const void* x, int64_t ldx, const void* v, void* out, 
 /* out = a + b, n bf16 elements (n % 8 == 0): `h + shortcut` after the DCAE rearranges of the HunyuanVideo-1.5 VAE
  * (vae/hunyuanvideo15/model.py:274, :709-711). */
 int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
+/* the same on float tensors (f32-storage verification mode) */
+int apexmi_add_f32(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream);
 
 /* out[p, c] = mean_{g < gs} x[p, c * gs + g] (f32 sum, one bf16 rounding), x bf16 [P, C * gs], out bf16 [P, C]: the
  * grouped channel mean of the DCAE shortcuts of the HunyuanVideo-1.5 VAE ENCODER (vae/hunyuanvideo15/model.py:318-331

@@ -11,7 +11,7 @@ teacher forcing) and compared with the oracle in pure fp32 (`oracle.layers.FP32`
 
   * per op: split exactness, GEMM epilogues, LN / q-k-norm + RoPE / attention, convolution variants, norms  (<= 2e-5)
   * Flux / Wan / QwenImage / HunyuanVideo-1.5 transformer forwards, tiny and mid configurations              (<= 1e-3)
-  * Flux 2-D VAE decode, Wan 3-D VAE tiled decode and tiled encode                                           (<= 1e-3)
+  * Flux 2-D VAE decode, Wan 3-D VAE tiled decode and tiled encode, HunyuanVideo-1.5 VAE decode (tiled)      (<= 1e-3)
   * sampler chains -> decoded frames through the engines' `run()`: Flux 4 Euler steps, Wan 4 UniPC steps over two experts
     with CFG, QwenImage-Edit pixels -> encode -> 2 true-CFG steps -> decode                    (latents, decoded, frames <= 1e-3)
 
@@ -345,6 +345,30 @@ def test_flux_vae_decode_f32_storage():
     out = vae.decode(z.to(DEV), return_dict=False)[0]
     assert out.dtype == F32 and out.shape == ref32.shape
     _report("flux vae decode", out, ref32, ref16)
+
+
+def test_hunyuan15_vae_decode_f32_storage(golden_dir):
+    """HunyuanVideo-1.5 3-D VAE decode (replicate-padded causal convolutions, RMS norms, frame-causal mid-block attention, DCAE
+    pixel-shuffle upsamplers with the first-frame rule, tiled + cross-faded): untiled and tiled, float storage, free-running,
+    against the fp32 oracle — which `tests/golden/vae_hunyuan15.pt` pins bit for bit to the reference class."""
+    import os
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    g = torch.load(os.path.join(golden_dir, "vae_hunyuan15.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = Orc(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    z = _bf(seeded(g["z_shape"], g["z_seed"]))
+    vae = AutoencoderKLHunyuanVideo15(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    vae.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    for tiled in (False, True):
+        if tiled:
+            vae.enable_tiling()
+            orc.enable_tiling()
+        out = vae.decode(z.to(DEV), return_dict=False)[0]
+        assert out.dtype == F32
+        _report(f"hunyuan15 vae decode tiled={tiled}", out, orc.decode(z), orc.decode(z, policy=OL.BF16_STORAGE))
 
 
 def test_wan_vae_tiled_decode_and_encode_f32_storage():
