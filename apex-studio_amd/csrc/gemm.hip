@@ -31,7 +31,7 @@
 // lane-linear).  Operands are fed swapped (MFMA "A" = W rows, "B" = activation rows) so a lane holds
 // four consecutive output columns of one row -> 8-byte epilogue accesses.
 // Up to 4 problems sharing (N, K, epilogue) run in ONE launch (the img / txt streams of a double
-// block), tile ids are remapped so each XCD owns a contiguous run of tiles, grouped 8 tiles tall.
+// block), tile ids are remapped so each XCD owns a contiguous run of tiles, grouped GROUP_M tiles tall.
 #include "common.h"
 
 #include <cstring>
@@ -40,7 +40,8 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int GROUP_M = 8;
+constexpr int GROUP_M = 6;   // tiles tall per group: an XCD's 32 concurrent tiles as ~6 x 5.3 (squarer than 8 x 4: fewer panel fetches per
+                             // tile; interleaved A/B, profiles/r03_ab_gemm_group_m.log: Flux -0.4 %, Qwen -1.1 %, Wan -0.6 % vs 8)
 // internal epilogue class of the f32-storage verification mode (APEXMI_EPI_F32_IO): gate * y + residual with float C / R.
 // Together with APEXMI_EPI_BIAS_F32 (which also carries the activation flag) it covers every epilogue with float I/O.
 constexpr int EPI_GATE_RES_F32 = 7;
