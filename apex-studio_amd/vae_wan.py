@@ -196,6 +196,8 @@ class AutoencoderKLWan(nn.Module):
         self.tile_sample_stride_height = self.tile_sample_stride_width = 192
         self._packed: Dict[int, torch.Tensor] = {}
         self._indep = False      # inside a batched pass over independent single-frame tiles
+        self.tile_streams = 2            # video tiles decoded / encoded side by side on HIP streams (see _run_tiles_on_streams)
+        self._streams: list = []
         self.batch_single_frame_tiles = True
         self.storage_dtype = torch.bfloat16
 
@@ -294,7 +296,7 @@ class AutoencoderKLWan(nn.Module):
         (`apexmi_conv3d_cl_frames`; the temporal resamplers are identities for one frame): a 1024x1024 image is 4 shape
         groups instead of 36 launch-bound tile passes, with bit-identical results."""
         if len(tiles) == 1 or tiles[0].shape[0] != 1 or not self.batch_single_frame_tiles:
-            return [fn(t) for t in tiles]
+            return self._run_tiles_on_streams(fn, tiles)
         groups: Dict[tuple, List[int]] = {}
         for i, t in enumerate(tiles):
             groups.setdefault(tuple(t.shape), []).append(i)
@@ -307,6 +309,31 @@ class AutoencoderKLWan(nn.Module):
                     outs[i] = y[n:n + 1]
         finally:
             self._indep = False
+        return outs
+
+    def _run_tiles_on_streams(self, fn, tiles):
+        """Video tiles are independent until the cross-fades, and the first (lowest-resolution) stages of a tile launch fewer
+        workgroups than the chip has slots: `tile_streams` tiles run side by side on their own HIP streams so those launches
+        overlap (the full-size launches of the late stages simply queue).  Same kernels on the same data: bit-identical to the
+        sequential walk (`tile_streams = 1`).  The first tile runs on the calling stream and fills the packed-weight caches."""
+        ns = max(1, min(int(self.tile_streams), len(tiles) - 1))
+        if ns <= 1 or len(tiles) < 3 or not tiles[0].is_cuda:
+            return [fn(t) for t in tiles]
+        main = torch.cuda.current_stream()
+        if len(self._streams) < ns:
+            self._streams += [torch.cuda.Stream(device=tiles[0].device) for _ in range(ns - len(self._streams))]
+        outs = [fn(tiles[0])]
+        for s_ in self._streams[:ns]:
+            s_.wait_stream(main)
+        for n, t in enumerate(tiles[1:]):
+            st = self._streams[n % ns]
+            with torch.cuda.stream(st):
+                t.record_stream(st)
+                y = fn(t)
+                y.record_stream(main)
+                outs.append(y)
+        for s_ in self._streams[:ns]:
+            main.wait_stream(s_)
         return outs
 
     @staticmethod

@@ -310,6 +310,28 @@ def test_hunyuan15_vae_tiles_on_side_streams_are_bit_identical(golden_dir):
         assert torch.equal(o, outs[1]), ns
 
 
+def test_wan_vae_tiles_on_side_streams_are_bit_identical():
+    """`tile_streams` video tiles of the tiled Wan decode / encode run on their own HIP streams: 1, 2 and 4 streams must give the
+    same bits, repeated calls included."""
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    vae = AutoencoderKLWan(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True],
+                           device=DEV, dtype=torch.bfloat16)
+    vae.load_state_dict({k: v.to(torch.bfloat16) for k, v in vae_synthetic_state_dict(vae, 9).items()}, strict=True)
+    vae.enable_tiling(64, 64, 48, 48)
+    z = seeded((1, 16, 3, 20, 26), 4).to(DEV).to(torch.bfloat16)             # 3 x 4 latent tiles of 8 x 8, stride 6
+    x = seeded((1, 3, 5, 160, 176), 6).clamp(-1, 1).to(DEV).to(torch.bfloat16)
+    dec, enc = {}, {}
+    for ns in (1, 2, 4, 2, 1):
+        vae.tile_streams = ns
+        d = vae.decode(z, return_dict=False)[0]
+        e = vae.encode(x, return_dict=False)[0].parameters
+        torch.cuda.synchronize()
+        assert torch.isfinite(d.float()).all() and torch.isfinite(e.float()).all()
+        dec.setdefault(ns, d)
+        enc.setdefault(ns, e)
+        assert torch.equal(d, dec[1]) and torch.equal(e, enc[1]), ns
+
+
 # ---- Wan / QwenImage VAE encode (the B-model `.encode` contract, SURVEY.md §8b) ------------------------------------
 
 @pytest.mark.parametrize("cin,cout,T,H,W", [(32, 32, 3, 16, 20), (64, 64, 1, 33, 18), (96, 96, 2, 64, 48)])
