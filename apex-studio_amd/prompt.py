@@ -17,7 +17,7 @@ supplied; `input_ids=` / `attention_mask=` take already tokenised prompts (there
 container, so the GPU tests feed ids)."""
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import torch
 
