@@ -330,7 +330,8 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
 //          rsqrt, weight and interleaved rotation: bit-identical outputs, written 16 bytes per lane into [H, S_out, 128].
 //   v:     the bf16 tile goes through the (now free) staging LDS, rotated per row, and leaves transposed: 8 consecutive
 //          sequence positions per lane, 128-byte runs per d-row of [H, 128, Skp].
-// Rows >= M are not stored; the zero padding of V^T beyond S_out is the caller's (the workspace is allocated zeroed).
+// Rows >= M are not stored; the zero padding of V^T beyond S_out is the caller's (the workspace is allocated zeroed).  A stream
+// whose row range is not 8-aligned takes an element-wise (still coalesced) V^T store; q / k rows have no alignment to keep.
 APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, const QkvShared& Q, int M, int m0, int n0,
                                   int wave, int wm, int wn, int lane, char* smem) {
     const int g = lane >> 4, c = lane & 15;
@@ -376,6 +377,19 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
         }
         __syncthreads();
         const int tid = wave * 64 + lane;
+        if (((P.row0 | M) & 7) != 0) {
+            // a stream that does not start (or end) on an 8-position boundary of the joint sequence (prompt lengths are what they
+            // are): 16-byte stores would be misaligned, so one element per lane, a wave = 64 consecutive positions of one d-row
+            // (a contiguous 128-byte run) — 8 x the store instructions of the aligned form, the same bytes
+            for (int i = 0; i < 128; ++i) {
+                const int idx = i * 512 + tid;
+                const int r = idx & 255, d = idx >> 8;
+                const bf16_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
+                const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
+                if (m0 + r < M) Q.vt[((int64_t)h * 128 + dd) * Q.Skp + P.row0 + m0 + r] = e;
+            }
+            return;
+        }
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int idx = i * 512 + tid;
@@ -1231,8 +1245,8 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
         if (is_qkv[i]) {
             APEXMI_REQUIRE(N[i] == 3 * H * 128 && epi_base(epilogue[i]) == APEXMI_EPI_BIAS,
                            "gemm_bf16_grouped_qkv: a fused problem has N = 3 H 128 = %d (got %d) and the plain bias epilogue", 3 * H * 128, N[i]);
-            APEXMI_REQUIRE(M[i] % 8 == 0 && row0[i] % 8 == 0 && row0[i] >= 0 && row0[i] + M[i] <= S_out,
-                           "gemm_bf16_grouped_qkv: rows [%d, %d) must be 8-aligned and inside S_out=%d", row0[i], row0[i] + M[i], S_out);
+            APEXMI_REQUIRE(row0[i] >= 0 && row0[i] + M[i] <= S_out,
+                           "gemm_bf16_grouped_qkv: rows [%d, %d) must lie inside S_out=%d", row0[i], row0[i] + M[i], S_out);
             const void* nq = norm_q ? norm_q[i] : nullptr;
             const void* nk = norm_k ? norm_k[i] : nullptr;
             APEXMI_REQUIRE(((uintptr_t)nq % 16) == 0 && ((uintptr_t)nk % 16) == 0, "gemm_bf16_grouped_qkv: norm weights must be 16-byte aligned");

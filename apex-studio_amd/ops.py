@@ -177,10 +177,8 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
 
 
 def qkv_fusable(a_list, w_list, row0, H: int) -> bool:
-    """Would gemm_grouped_qkv() take this launch?  (bf16 storage, 8-aligned row ranges, the 256x256 16x16x32 tiling.)"""
-    if any(a.dtype != torch.bfloat16 for a in a_list) or H % 2 or any(int(r) % 8 for r in row0):
-        return False
-    if any(a.shape[0] % 8 for a in a_list):
+    """Would gemm_grouped_qkv() take this launch?  (bf16 storage, an even head count, the 256x256 16x16x32 tiling.)"""
+    if any(a.dtype != torch.bfloat16 for a in a_list) or H % 2:
         return False
     return bool(_l.load().apexmi_gemm_qkv_fusable(sum(a.shape[0] for a in a_list), max(w.shape[0] for w in w_list),
                                                   w_list[0].shape[1]))

@@ -147,7 +147,7 @@ int apexmi_gemm_bf16_grouped(int count, const void* const* A, const int64_t* lda
  * apexmi_qkv_prepare does as a separate pass over the [S, 3 H 128] projection, with bit-identical results (the projection is
  * rounded to bf16 exactly where the separate path stores it, and the sums run in the same order).
  *   is_qkv[i] != 0: problem i is a fused QKV projection, N[i] = 3 H 128 ([q | k | v] rows of W); its M[i] rows are rows
- *     [row0[i], row0[i] + M[i]) of the joint sequence (8-aligned); norm_q[i] / norm_k[i] = the RMSNorm weights (bf16[128]) of
+ *     [row0[i], row0[i] + M[i]) of the joint sequence (any alignment: an unaligned stream stores its V^T element-wise); norm_q[i] / norm_k[i] = the RMSNorm weights (bf16[128]) of
  *     its stream (the text stream of a joint block brings norm_added_q / norm_added_k); C[i] / ldc[i] are ignored.
  *   is_qkv[i] == 0: an ordinary bias-class problem of the same launch (the single block's MLP up-projection with GELU).
  *   q_out, k_out: bf16 [H, S_out, 128]; vt_out: bf16 [H, 128, Skp] (Skp >= S_out, a multiple of 8; columns >= S_out are not

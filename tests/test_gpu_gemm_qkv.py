@@ -23,13 +23,13 @@ def _rope(S, seed):
     return torch.stack([cos, sin]).contiguous().float()
 
 
-@pytest.mark.parametrize("m_img,m_txt", [(1280, 256), (1096, 72), (1024, 0)])
+@pytest.mark.parametrize("m_img,m_txt", [(1280, 256), (1096, 72), (1024, 0), (1091, 77), (1100, 3)])
 def test_joint_streams_bit_identical_to_two_pass(m_img, m_txt):
     from apex_studio_amd import lib as _l, ops
     H, K = 4, 512
     inner, S = H * 128, m_img + m_txt
     skp = (S + 63) // 64 * 64
-    xs = [_rand((m_img, K), 1), _rand((max(m_txt, 8), K), 2)][:2 if m_txt else 1]
+    xs = [_rand((m_img, K), 1), _rand((max(m_txt, 1), K), 2)][:2 if m_txt else 1]
     ws = [_rand((3 * inner, K), 3, K ** -0.5), _rand((3 * inner, K), 4, K ** -0.5)][:len(xs)]
     bs = [_rand((3 * inner,), 5, 0.1), _rand((3 * inner,), 6, 0.1)][:len(xs)]
     nq = [_rand((128,), 7) * 0.2 + 1, _rand((128,), 8) * 0.2 + 1]
