@@ -54,6 +54,8 @@ struct ConvArgs {
     // temporal stride (128x128 kernel only): output frame j reads input frames j * st + t0 + dt - (kT - 1); To output frames
     int To, st, t0;
     unsigned long long* prof;   // cycle-stamp buffer of ONE workgroup (tools/conv_prof.py; null in production)
+    int Tc;                     // > 0: the T frames are T / Tc independent CLIPS of Tc frames stacked along T (the spatial tiles of a
+                                // tiled VAE decode in one launch): the causal temporal taps stop at a clip's first frame
     int dbg;                    // timing experiments on the prefetch kernel (WRONG results; tools/conv_ablate.py): 1 no weight DMA,
                                 // 2 no slab DMA inside the loop
 };
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
     const int m0 = pm * BM, n0 = pn * BN;
 
     // ---- per-lane A rows (output positions) and running (tap, ci) of the lane's 16-byte chunk ----
-    int pos_t[4], pos_y[4], pos_x[4], a_tap[4], a_ci[4];
+    int pos_t[4], pos_y[4], pos_x[4], a_tap[4], a_ci[4], pos_lo[4];
     const char* w_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
         const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, M - 1);
         pos_t[i] = (m / (a.Ho * a.Wo)) * a.st + a.t0;
+        pos_lo[i] = a.Tc > 0 ? (pos_t[i] / a.Tc) * a.Tc : 0;    // first frame of this position's clip
         const int r = m % (a.Ho * a.Wo);
         pos_y[i] = (r / a.Wo) * a.sy;   // input row / column of tap (0, 0) before the pad offset
         pos_x[i] = (r % a.Wo) * a.sx;
@@ -127,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
                 const int yi = pos_y[i] + (int)(int8_t)((o >> 8) & 0xff);
                 const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
                 if (a.replicate) {   // HunyuanVideo15CausalConv3d: F.pad(..., mode="replicate") == clamped coordinates
-                    const int tc = max(ti, 0), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
+                    const int tc = max(ti, pos_lo[i]), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
                     src = a.in + ((int64_t)(tc * a.Hin + (yc >> a.up)) * a.Win + (xc >> a.up)) * a.Cin + a_ci[i];
-                } else if ((unsigned)ti < (unsigned)a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
+                } else if (ti >= pos_lo[i] && ti < a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
                     src = a.in + ((int64_t)(ti * a.Hin + (yi >> a.up)) * a.Win + (xi >> a.up)) * a.Cin + a_ci[i];
                 }
             }
@@ -1703,7 +1706,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
                           int replicate, apexmi_stream_t stream_, int sy = 1, int sx = 1, int py = -1, int px = -1,
                           int Ho = 0, int Wo = 0, int independent = 0, int up = 0, const void* norm_gamma = nullptr,
                           void* out_norm = nullptr, int norm_silu = 0, int act = 0, float act_slope = 0.0f, int st = 1,
-                          int t0 = 0, int To = 0, int f32io = 0) {
+                          int t0 = 0, int To = 0, int f32io = 0, int clip_frames = 0) {
     const int Hin = H, Win = W;
     if (up) {          // H, W arrive as the STORED extents; the convolution runs over the 2x upsampled image
         H *= 2;
@@ -1773,6 +1776,10 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     APEXMI_REQUIRE((st == 1 && t0 == 0 && To == T) || (!up && !independent && out_norm == nullptr && T > 1),
                    "conv3d_cl: a temporal stride excludes the upsample / independent-frame / fused-norm modes");
     a.To = To; a.st = st; a.t0 = t0;
+    APEXMI_REQUIRE(clip_frames >= 0 && (clip_frames == 0 || (T % clip_frames == 0 && st == 1 && t0 == 0 && To == T && !up &&
+                                                             !independent && out_norm == nullptr)),
+                   "conv3d_cl: clip_frames=%d must divide T=%d (stride-1 plain convolutions only)", clip_frames, T);
+    a.Tc = clip_frames == T ? 0 : clip_frames;
     a.prof = (unsigned long long*)g_conv_prof;
     a.dbg = g_conv_dbg;
     const int64_t M = (int64_t)To * Ho * Wo;
@@ -1786,7 +1793,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
         return apexmi_check_launch("conv3d_cl_f32");
     }
     bool taken = false;
-    const int rc2 = launch_v2_for(a, stream, &taken);
+    // stacked clips: the clip boundary lives in the 128x128 kernel's gather only (the conv-shaped / slab tiles walk frames)
+    const int rc2 = a.Tc > 0 ? 0 : launch_v2_for(a, stream, &taken);
     if (taken) return rc2;
     APEXMI_REQUIRE(out_norm == nullptr, "conv3d_cl_norm: this convolution does not run on the fused-norm tiles "
                                         "(ask apexmi_conv3d_cl_norm_fusable first)");
@@ -1798,6 +1806,13 @@ extern "C" int apexmi_conv3d_cl(const void* in, const void* w, const void* bias,
                                 void* out, const void* zeros, int T, int H, int W, int Cin, int Cout,
                                 int Kpad, int kT, int kH, int kW, apexmi_stream_t stream_) {
     return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, 0, stream_);
+}
+
+extern "C" int apexmi_conv3d_cl_clips(const void* in, const void* w, const void* bias, const void* residual, void* out,
+                                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
+                                      int kW, int replicate, int clip_frames, apexmi_stream_t stream_) {
+    return conv3d_cl_impl(in, w, bias, residual, out, zeros, T, H, W, Cin, Cout, Kpad, kT, kH, kW, replicate, stream_, 1, 1, -1,
+                          -1, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0.0f, 1, 0, 0, 0, clip_frames);
 }
 
 extern "C" int apexmi_conv3d_cl_up2(const void* in, const void* w, const void* bias, const void* residual, void* out,

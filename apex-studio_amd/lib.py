@@ -64,6 +64,7 @@ SIGNATURES = {
                                      C.c_int, vp]),
     "apexmi_conv3d_cl": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "apexmi_conv3d_cl_replicate": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "apexmi_conv3d_cl_clips": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 11 + [vp]),
     "apexmi_conv3d_cl_strided": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 15 + [vp]),
     "apexmi_conv3d_cl_frames": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "apexmi_conv3d_cl_up2": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 10 + [vp]),

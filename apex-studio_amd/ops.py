@@ -773,10 +773,12 @@ def _conv_f32(x, w_packed, bias, ksize, out_shape, residual=None, out=None, repl
 
 def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ksize,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              replicate: bool = False, independent_frames: bool = False, upsample2x: bool = False) -> torch.Tensor:
+              replicate: bool = False, independent_frames: bool = False, upsample2x: bool = False,
+              clip_frames: int = 0) -> torch.Tensor:
     """x [T,H,W,Cin] bf16 contiguous -> [T,H,W,Cout4]; causal in time, "same" padding in space: zeros, or (replicate)
     clamped coordinates as HunyuanVideo15CausalConv3d pads.  upsample2x: the convolution reads x through a nearest 2x
-    spatial upsample (output [T,2H,2W,Cout4]) without materialising it."""
+    spatial upsample (output [T,2H,2W,Cout4]) without materialising it.  clip_frames: the T frames are T / clip_frames
+    independent clips stacked along T (the tiles of a tiled decode in one launch, `apexmi_conv3d_cl_clips`)."""
     _req_act(x, "conv3d_cl.x")
     _req(w_packed, torch.bfloat16, "conv3d_cl.w")
     assert x.dim() == 4 and x.is_contiguous() and w_packed.is_contiguous()
@@ -785,6 +787,8 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
     if x.dtype == torch.float32:
         assert not (replicate and independent_frames) and not (replicate and upsample2x)
+        if clip_frames and clip_frames != T:
+            raise _l.ApexMIError("conv3d_cl: stacked clips are not part of the f32-storage verification mode")
         return _conv_f32(x, w_packed, bias, ksize, (T, Ho, Wo, cout), residual=residual, out=out, replicate=replicate,
                          independent_frames=independent_frames, upsample2x=upsample2x)
     if out is None:
@@ -800,6 +804,13 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                                             _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]),
                                             int(ksize[1]), int(ksize[2]), 1 if independent_frames else 0, _stream())
         _l.check(rc, "conv3d_cl_up2")
+        return out
+    if clip_frames and clip_frames != T:
+        assert not independent_frames and T % int(clip_frames) == 0
+        rc = _l.load().apexmi_conv3d_cl_clips(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                              _zeros16(x.device).data_ptr(), T, H, W, cin, cout, kpad, int(ksize[0]),
+                                              int(ksize[1]), int(ksize[2]), 1 if replicate else 0, int(clip_frames), _stream())
+        _l.check(rc, "conv3d_cl_clips")
         return out
     fn = (_l.load().apexmi_conv3d_cl_replicate if replicate else
           _l.load().apexmi_conv3d_cl_frames if independent_frames else _l.load().apexmi_conv3d_cl)

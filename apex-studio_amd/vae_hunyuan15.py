@@ -210,6 +210,10 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         self.tile_overlap_factor = 0.25
         self._packed: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.storage_dtype = torch.bfloat16
+        # up blocks (after conv_in + mid) whose launches cover all equally shaped tiles at once; measured on the 480p x 121-frame
+        # decode (tools/hunyuan_vae_streams_ab.py): 0 / 1 / 2 = 2382 / 2366 / 2351 ms at 7 / 10 / 26 GiB peak — 1 by default; stages
+        # whose single-tile launch already takes the conv-shaped tiles must stay outside (another summation order)
+        self.batch_head_blocks = 1
         self.decode_streams = 2      # spatial tiles decoded side by side on their own HIP streams (see _decode_tiles)
         self._streams: list = []
         # the TAEHV "light" decoder (model.py:794-846): built lazily when `enable_tiling(use_light_vae=True)` asks for it, or
@@ -321,9 +325,10 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
             self._packed[key] = p
         return p
 
-    def _cconv(self, c: _CConv, x, residual=None):
+    def _cconv(self, c: _CConv, x, residual=None, clip=0):
+        """`clip`: frames per clip when x stacks several tiles' clips along T (0 = one clip)."""
         w, b = self._w(c, c.conv.weight, c.conv.bias)
-        return ops.conv3d_cl(x, w, b, (3, 3, 3), residual=residual, replicate=True)
+        return ops.conv3d_cl(x, w, b, (3, 3, 3), residual=residual, replicate=True, clip_frames=clip)
 
     def _conv1(self, c: _Conv1, x2d, **kw):
         return ops.gemm(x2d, c.weight.data.reshape(c.weight.shape[0], c.weight.shape[1]), c.bias.data, **kw)
@@ -332,13 +337,15 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
     def _g(n: _Gamma):
         return n.gamma.data.reshape(-1).contiguous()
 
-    def _res(self, blk: _Res, x):
+    def _res(self, blk: _Res, x, clip=0):
         T, H, W, Cc = x.shape
-        h = self._cconv(blk.conv1, ops.rmsnorm_cl(x, self._g(blk.norm1), silu=True))
+        h = self._cconv(blk.conv1, ops.rmsnorm_cl(x, self._g(blk.norm1), silu=True), clip=clip)
         sc = x if blk.conv_shortcut is None else self._conv1(blk.conv_shortcut, x.view(T * H * W, Cc)).view(T, H, W, -1)
-        return self._cconv(blk.conv2, ops.rmsnorm_cl(h, self._g(blk.norm2), silu=True), residual=sc)
+        return self._cconv(blk.conv2, ops.rmsnorm_cl(h, self._g(blk.norm2), silu=True), residual=sc, clip=clip)
 
-    def _attn(self, blk: _Attn, x):
+    def _attn(self, blk: _Attn, x, clip=0):
+        if clip and clip != x.shape[0]:      # stacked clips: the frame-causal attention is per clip
+            return torch.cat([self._attn(blk, x[i:i + clip]) for i in range(0, x.shape[0], clip)], dim=0)
         T, H, W, Cc = x.shape
         S = T * H * W
         n = ops.rmsnorm_cl(x, self._g(blk.norm)).view(S, Cc)
@@ -352,9 +359,27 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
         return self._conv1(blk.proj_out, o, epilogue="gate_res", gate=ones, residual=x.view(S, Cc)).view(T, H, W, Cc)
 
-    def _upsample(self, up: _Upsample, x):
-        h = self._cconv(up.conv, x)
-        if up.temporal:
+    def _upsample(self, up: _Upsample, x, clip=0):
+        h = self._cconv(up.conv, x, clip=clip)
+        if up.temporal and clip and clip != x.shape[0]:
+            # stacked clips: the first-frame rule applies to every clip's first frame.  Both rearrangements treat frames
+            # independently, so all first frames go through the (1, 2, 2) form at once and all others through (2, 2, 2)
+            B = x.shape[0] // clip
+
+            def split(t):
+                t5 = t.view(B, clip, *t.shape[1:])
+                return t5[:, :1].reshape(B, *t.shape[1:]), t5[:, 1:].reshape(B * (clip - 1), *t.shape[1:])
+
+            def join(first, rest):           # [B, ...], [B * 2 (clip - 1), ...] -> [B * (2 clip - 1), ...]
+                rest = rest.view(B, 2 * (clip - 1), *rest.shape[1:])
+                return torch.cat([first.unsqueeze(1), rest], dim=1).reshape(B * (2 * clip - 1), *first.shape[1:])
+            h0, h1 = split(h)
+            hf = _rearrange_cl(h0, 1, 2, 2)
+            h = join(hf[..., : hf.shape[-1] // 2], _rearrange_cl(h1, 2, 2, 2))
+            x0, x1 = split(x)
+            sc = join(_rearrange_cl(x0, 1, 2, 2).repeat_interleave(up.repeats // 2, dim=-1),
+                      _rearrange_cl(x1, 2, 2, 2).repeat_interleave(up.repeats, dim=-1))
+        elif up.temporal:
             hf = _rearrange_cl(h[:1], 1, 2, 2)
             hf = hf[..., : hf.shape[-1] // 2]
             h = torch.cat([hf, _rearrange_cl(h[1:], 2, 2, 2)], dim=0)
@@ -447,19 +472,36 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
             return (post,)
         return SimpleNamespace(latent_dist=post)
 
-    def _decode_tile(self, z):
-        """z [T, h, w, latent_channels] channels-last -> [4 (T - 1) + 1, 16 h, 16 w, 4] (3 channels + 1 pad)."""
+    def _decode_head(self, z, clip, nblocks):
+        """conv_in, the mid block and the first `nblocks` up blocks over z [B * clip, h, w, latent_channels] = B tiles' clips
+        stacked along T (B = 1: an ordinary tile).  Returns (x, frames per clip now)."""
         d = self.decoder
-        x = self._cconv(d.conv_in, z, residual=z.repeat_interleave(d.repeat, dim=-1).contiguous())
-        x = self._res(d.mid_block.resnets[0], x)
-        x = self._attn(d.mid_block.attentions[0], x)
-        x = self._res(d.mid_block.resnets[1], x)
-        for ub in d.up_blocks:
+        x = self._cconv(d.conv_in, z, residual=z.repeat_interleave(d.repeat, dim=-1).contiguous(), clip=clip)
+        x = self._res(d.mid_block.resnets[0], x, clip)
+        x = self._attn(d.mid_block.attentions[0], x, clip)
+        x = self._res(d.mid_block.resnets[1], x, clip)
+        for ub in list(d.up_blocks)[:nblocks]:
+            for r in ub.resnets:
+                x = self._res(r, x, clip)
+            if ub.upsamplers is not None:
+                x = self._upsample(ub.upsamplers[0], x, clip)
+                if ub.upsamplers[0].temporal:
+                    clip = 2 * clip - 1
+        return x, clip
+
+    def _decode_tail(self, x, nblocks):
+        d = self.decoder
+        for ub in list(d.up_blocks)[nblocks:]:
             for r in ub.resnets:
                 x = self._res(r, x)
             if ub.upsamplers is not None:
                 x = self._upsample(ub.upsamplers[0], x)
         return self._cconv(d.conv_out, ops.rmsnorm_cl(x, self._g(d.norm_out), silu=True))
+
+    def _decode_tile(self, z):
+        """z [T, h, w, latent_channels] channels-last -> [4 (T - 1) + 1, 16 h, 16 w, 4] (3 channels + 1 pad)."""
+        x, _ = self._decode_head(z, z.shape[0], len(self.decoder.up_blocks))
+        return self._decode_tail(x, len(self.decoder.up_blocks))
 
     def _decode_tiles(self, ztiles):
         """Every spatial tile through the decoder.  The tiles are independent until the cross-fades, and the decoder's
@@ -468,15 +510,39 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         by side on their own HIP streams, so those launches overlap, while the full-size launches of the late stages simply queue.
         Same kernels on the same data: bit-identical to the sequential walk (`decode_streams = 1`)."""
         flat = [(i, j, zt) for i, row in enumerate(ztiles) for j, zt in enumerate(row)]
+        nb = max(0, min(int(self.batch_head_blocks), len(self.decoder.up_blocks)))
+        if self.storage_dtype != torch.bfloat16:
+            nb = 0                       # the verification mode walks tile by tile
+        if nb > 0 and len(flat) > 1:
+            # The lowest-resolution stages (conv_in, mid block, the first `batch_head_blocks` up blocks) of ALL equally shaped
+            # tiles run as ONE launch per layer over the tiles' clips stacked along T (`apexmi_conv3d_cl_clips`: a 31-frame
+            # 8 x 8-latent tile is 1984 positions = 128 workgroups in the 1024-channel stages; 32 of them fill the chip);
+            # bit-identical to the tile-by-tile walk.  The rest of each tile follows, side by side on the streams below.
+            groups: Dict[tuple, list] = {}
+            for n, (_, _, zt) in enumerate(flat):
+                groups.setdefault(tuple(zt.shape), []).append(n)
+            heads = [None] * len(flat)
+            for idxs in groups.values():
+                T0 = flat[idxs[0]][2].shape[0]
+                x, clip = self._decode_head(torch.cat([flat[n][2] for n in idxs], dim=0), T0, nb)
+                for b, n in enumerate(idxs):
+                    heads[n] = x[b * clip:(b + 1) * clip]
+            flat = [(i, j, h) for (i, j, _), h in zip(flat, heads)]
+            tile_fn = lambda h: self._decode_tail(h, nb)   # noqa: E731
+        else:
+            tile_fn = self._decode_tile
         ns = max(1, min(int(self.decode_streams), len(flat)))
         if ns == 1:
-            return [[self._decode_tile(zt) for zt in row] for row in ztiles]
+            out = [[None] * len(row) for row in ztiles]
+            for i, j, zt in flat:
+                out[i][j] = tile_fn(zt)
+            return out
         main = torch.cuda.current_stream()
         if len(self._streams) < ns:
             self._streams += [torch.cuda.Stream(device=self.device) for _ in range(ns - len(self._streams))]
         out = [[None] * len(row) for row in ztiles]
         i0, j0, z0 = flat[0]
-        out[i0][j0] = self._decode_tile(z0)      # on the main stream: fills the packed-weight caches every other tile reads
+        out[i0][j0] = tile_fn(z0)                # on the main stream: fills the packed-weight caches every other tile reads
         flat = flat[1:]
         for s_ in self._streams[:ns]:
             s_.wait_stream(main)                 # the latents and the packed weights are ready on the main stream
@@ -484,7 +550,7 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
             st = self._streams[n % ns]
             with torch.cuda.stream(st):
                 zt.record_stream(st)
-                t = self._decode_tile(zt)
+                t = tile_fn(zt)
                 t.record_stream(main)            # consumed (cross-faded, concatenated) on the main stream below
                 out[i][j] = t
         for s_ in self._streams[:ns]:

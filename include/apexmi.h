@@ -285,6 +285,15 @@ int apexmi_v_transpose(const void* v, int64_t v_stride_h, int64_t v_stride_s, in
 int apexmi_conv3d_cl(const void* in, const void* w, const void* bias, const void* residual, void* out,
                      const void* zeros, int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH,
                      int kW, apexmi_stream_t stream);
+/* apexmi_conv3d_cl (replicate = 0) / apexmi_conv3d_cl_replicate (1) over T / clip_frames independent CLIPS stacked along T: the
+ * spatial tiles of a tiled VAE decode in ONE launch where a single tile's convolution would launch fewer workgroups than the
+ * chip has slots (the 1024-channel 8 x 8-latent stages of the HunyuanVideo-1.5 decoder, R/src/vae/hunyuanvideo15/model.py:1060-1119:
+ * 45 tiles of 1984 positions).  The causal temporal taps stop at every clip's first frame (zero / replicated there, as for a
+ * single clip); each frame is its own image spatially.  Bit-identical to one call per clip.  clip_frames must divide T. */
+int apexmi_conv3d_cl_clips(const void* in, const void* w, const void* bias, const void* residual, void* out, const void* zeros,
+                           int T, int H, int W, int Cin, int Cout, int Kpad, int kT, int kH, int kW, int replicate,
+                           int clip_frames, apexmi_stream_t stream);
+
 /* The same convolution read THROUGH a nearest 2x spatial upsample: in is [T, H, W, Cin], out [T, 2H, 2W, Cout], tap
  * (y, x) of the upsampled image reads stored pixel (y >> 1, x >> 1).  Replaces WanUpsample (nearest-exact 2x,
  * vae/wan/model.py:225-237) + the Conv2d of WanResample "upsample2d/3d" (:264-273) and diffusers' Upsample2D of the Flux

@@ -301,6 +301,7 @@ def test_hunyuan15_vae_tiles_on_side_streams_are_bit_identical(golden_dir):
     vae.enable_tiling(tile_sample_min_height=64, tile_sample_min_width=64, tile_latent_min_height=4, tile_latent_min_width=4)
     z = seeded((1, cfg["latent_channels"], 3, 10, 14), 5).to(DEV).to(torch.bfloat16)          # 4 x 5 = 20 tiles
     outs = {}
+    vae.batch_head_blocks = 0
     for ns in (1, 2, 5, 2, 1):
         vae.decode_streams = ns
         o = vae.decode(z, return_dict=False)[0]
@@ -308,6 +309,13 @@ def test_hunyuan15_vae_tiles_on_side_streams_are_bit_identical(golden_dir):
         assert torch.isfinite(o.float()).all()
         outs.setdefault(ns, o)
         assert torch.equal(o, outs[1]), ns
+    # ... and with the lowest-resolution stages of all equally shaped tiles in ONE launch per layer (clips stacked along T,
+    # apexmi_conv3d_cl_clips; the first-frame rule of the temporal upsamplers per clip; frame-causal attention per clip)
+    for nb in (1, 2, 4):
+        vae.batch_head_blocks, vae.decode_streams = nb, 2
+        o = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o, outs[1]), nb
 
 
 def test_wan_vae_tiles_on_side_streams_are_bit_identical():
