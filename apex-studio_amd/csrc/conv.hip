@@ -54,6 +54,7 @@ struct ConvArgs {
     // temporal stride (128x128 kernel only): output frame j reads input frames j * st + t0 + dt - (kT - 1); To output frames
     int To, st, t0;
     unsigned long long* prof;   // cycle-stamp buffer of ONE workgroup (tools/conv_prof.py; null in production)
+    int torder;                 // slab kernels: temporal taps by input frame mod 3 + frame-fastest tile order (see slab_tap_of_step)
     int Tc;                     // > 0: the T frames are T / Tc independent CLIPS of Tc frames stacked along T (the spatial tiles of a
                                 // tiled VAE decode in one launch): the causal temporal taps stop at a clip's first frame
     int dbg;                    // timing experiments on the prefetch kernel (WRONG results; tools/conv_ablate.py): 1 no weight DMA,
@@ -719,6 +720,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab96_kernel(const ConvArgs a)
 // SLW = channels per slice: 48 (96-byte pitch, 6 chunks, swizzle c ^ ((p >> 3) & 1), 3 k-steps) or 64 (128-byte pitch, 8 chunks,
 // c ^ ((p >> 1) & 7): 4-dword slot = 8 (p & 1) + swizzled chunk, 4 k-steps) — the latter for the channel counts of the
 // HunyuanVideo-1.5 / Flux / TAEHV decoders (64 .. 1024); a.replicate: clamped slab coordinates (F.pad(mode="replicate")).
+// Temporal-tap order of the slab kernels (conv.torder = 1): the nk taps of output frame t are visited in the order of their
+// INPUT frame index mod 3, not oldest first.  Workgroups of the same spatial tile and consecutive frames run side by side on one XCD
+// (frame-fastest tile order below) and each needs the frames {t-2, t-1, t}: visiting "the frame = j mod 3" at step j makes the
+// three of them read the SAME input slab at the same time, so two of the three reads are L2 hits instead of fabric fetches
+// (rocprofv3: 3.37 GB fetched per 96->96 launch for a 1.02 GB input before).  Only the f32 summation order over the temporal taps
+// changes (it now depends on t mod 3).  step j -> tap index k in [0, nk).
+APEXMI_DEVICE int slab_tap_of_step(int j, int t, int nk, int torder) {
+    if (!torder || nk != 3) return j;
+    int k = (j + 2 - t) % 3;
+    return k < 0 ? k + 3 : k;
+}
+
 template <int SLW>
 APEXMI_DEVICE int slab_swz(int c, int p) { return SLW == 48 ? (c ^ ((p >> 3) & 1)) : (c ^ ((p >> 1) & 7)); }
 
@@ -738,7 +751,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
 
     const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
     const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
-    const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    int tx, ty, t;
+    if (a.torder) {            // frame fastest: the same tile of consecutive frames runs side by side
+        t = b % a.T;
+        const int tile = b / a.T;
+        tx = tile % ntx, ty = tile / ntx;
+    } else {
+        tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    }
     const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * (NT * 32);
     const int S = a.Cin / SLW;
@@ -786,7 +806,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     const int nchunks = nph * 9;
     // chunk cursor (the chunk to ISSUE next): ring slot, spatial tap, slice, temporal tap -> byte offset into a weight row
     int c_slot = 0, c_sp = 0, c_sl = 0;
-    int64_t c_tap_off = (int64_t)kt_first * 9 * a.Cin * 2;     // (temporal tap * 9) * Cin * 2 bytes
+    int c_step = 0;                                            // temporal step of the issue cursor (-> tap through slab_tap_of_step)
+    int64_t c_tap_off = (int64_t)(kt_first + slab_tap_of_step(0, t, nk, a.torder)) * 9 * a.Cin * 2;   // (temporal tap * 9) * Cin * 2 bytes
     auto w_chunk_next = [&]() {
         const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * PITCH;
         char* dst = smem + 2 * SLABB + c_slot * WCH;
@@ -800,7 +821,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
             c_sp = 0;
             if (++c_sl == S) {
                 c_sl = 0;
-                c_tap_off += (int64_t)9 * a.Cin * 2;
+                ++c_step;
+                c_tap_off = (int64_t)(kt_first + slab_tap_of_step(min(c_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2;
             }
         }
     };
@@ -817,7 +839,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.0f;
 
     // next-phase cursor for the slab prefetch
-    int np_f = t - nk + 1;                              // frame of the next phase (may be < 0 under replicate padding: clamped)
+    int np_step = 0;
+    int np_f = t - nk + 1 + slab_tap_of_step(0, t, nk, a.torder);   // frame of the next phase (may be < 0 under replicate padding: clamped)
     uint32_t np_off = (uint32_t)max(np_f, 0) * frame_bytes;
     int np_sl = 0;
     if (loader) {
@@ -827,7 +850,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     auto advance_phase = [&]() {
         if (++np_sl == S) {
             np_sl = 0;
-            ++np_f;
+            ++np_step;
+            np_f = t - nk + 1 + slab_tap_of_step(min(np_step, nk - 1), t, nk, a.torder);
             np_off = (uint32_t)max(np_f, 0) * frame_bytes;
         } else {
             np_off += (uint32_t)PITCH;
@@ -950,7 +974,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
 
     const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
     const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
-    const int tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    int tx, ty, t;
+    if (a.torder) {            // frame fastest: the same tile of consecutive frames runs side by side
+        t = b % a.T;
+        const int tile = b / a.T;
+        tx = tile % ntx, ty = tile / ntx;
+    } else {
+        tx = b % ntx, ty = (b / ntx) % nty, t = b / (ntx * nty);
+    }
     const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * WROWS;
     const int S = a.Cin / SLW;
@@ -998,7 +1029,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     };
     // issue cursor over weight chunks
     int c_slot = 0, c_sp = 0, c_sl = 0;
-    int c_tap_off = kt_first * 9 * a.Cin * 2;
+    int c_step = 0;
+    int c_tap_off = (kt_first + slab_tap_of_step(0, t, nk, a.torder)) * 9 * a.Cin * 2;
     auto w_piece = [&](auto I) -> int {                         // piece i of the chunk under the cursor; 1 if this wave has it
         constexpr int i = decltype(I)::value;
         if (i * NW + wave >= WP || (a.dbg & 1)) return 0;
@@ -1014,7 +1046,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
             c_sp = 0;
             if (++c_sl == S) {
                 c_sl = 0;
-                c_tap_off += 9 * a.Cin * 2;
+                ++c_step;
+                c_tap_off = (kt_first + slab_tap_of_step(min(c_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2;
             }
         }
     };
@@ -1036,13 +1069,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
             for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.0f;
 
     // next-phase cursor of the slab prefetch
-    int np_f = t - nk + 1;
+    int np_step = 0;
+    int np_f = t - nk + 1 + slab_tap_of_step(0, t, nk, a.torder);
     uint32_t np_off = (uint32_t)max(np_f, 0) * frame_bytes;
     int np_sl = 0;
     auto advance_phase = [&]() {
         if (++np_sl == S) {
             np_sl = 0;
-            ++np_f;
+            ++np_step;
+            np_f = t - nk + 1 + slab_tap_of_step(min(np_step, nk - 1), t, nk, a.torder);
             np_off = (uint32_t)max(np_f, 0) * frame_bytes;
         } else {
             np_off += (uint32_t)PITCH;
@@ -1244,6 +1279,7 @@ int launch_slab96_inst(const ConvArgs& a, hipStream_t stream) {     // conv.slab
 }
 
 int g_conv_dbg = 0;
+int g_conv_torder = 1;   // apexmi_tune_set("conv.torder", 0/1): see slab_tap_of_step (1 shipped)
 uintptr_t g_conv_prof = 0;   // apexmi_tune_set("conv.prof_lo" / "conv.prof_hi", halves of a device pointer): 8 waves x 8 counters
 int g_conv_pp = 1;   // apexmi_tune_set("conv.pp", 0..3): see launch_slab
 
@@ -1657,6 +1693,7 @@ void apexmi_set_conv_v2(int v) { g_conv_v2 = v; }
 void apexmi_set_conv_slab(int v) { g_conv_slab = v; }
 void apexmi_set_conv_pp(int v) { g_conv_pp = v; }
 void apexmi_set_conv_dbg(int v) { g_conv_dbg = v; }
+void apexmi_set_conv_torder(int v) { g_conv_torder = v; }
 void apexmi_set_conv_prof(int half, int v) {
     if (half) g_conv_prof = (g_conv_prof & 0xffffffffull) | ((uintptr_t)(uint32_t)v << 32);
     else g_conv_prof = (g_conv_prof & ~(uintptr_t)0xffffffffull) | (uint32_t)v;
@@ -1782,6 +1819,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const void* bias, const
     a.Tc = clip_frames == T ? 0 : clip_frames;
     a.prof = (unsigned long long*)g_conv_prof;
     a.dbg = g_conv_dbg;
+    a.torder = g_conv_torder;
     const int64_t M = (int64_t)To * Ho * Wo;
     const int nm = (int)((M + BM - 1) / BM), nn = (Cout + BN - 1) / BN;
     ApexmiProfScope prof(0, stream, 2.0 * M * Cout * (double)ntaps_eff * Cin,

@@ -125,6 +125,7 @@ void apexmi_set_conv_v2(int v);
 void apexmi_set_conv_slab(int v);
 void apexmi_set_conv_pp(int v);
 void apexmi_set_conv_dbg(int v);
+void apexmi_set_conv_torder(int v);
 void apexmi_set_conv_prof(int half, int v);
 int apexmi_set_gemm_key(const char* key, int value);
 
@@ -143,6 +144,9 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         return 0;
     } else if (!strcmp(key, "conv.prof_lo") || !strcmp(key, "conv.prof_hi")) {
         apexmi_set_conv_prof(key[10] == 'h', value);
+        return 0;
+    } else if (!strcmp(key, "conv.torder")) {
+        apexmi_set_conv_torder(value);
         return 0;
     } else if (!strcmp(key, "conv.dbg")) {
         apexmi_set_conv_dbg(value);
