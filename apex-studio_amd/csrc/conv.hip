@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
     const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
     int tx, ty, t;
-    if (a.torder) {            // frame fastest: the same tile of consecutive frames runs side by side
+    if (a.torder && a.kT == 3) {   // frame fastest: the same tile of consecutive frames runs side by side (they share input frames)
         t = b % a.T;
         const int tile = b / a.T;
         tx = tile % ntx, ty = tile / ntx;
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     const int ntx = (a.W + TW - 1) / TW, nty = (a.H + TH - 1) / TH;
     const int b = xcd_remap(blockIdx.x, a.T * nty * ntx);
     int tx, ty, t;
-    if (a.torder) {            // frame fastest: the same tile of consecutive frames runs side by side
+    if (a.torder && a.kT == 3) {   // frame fastest: the same tile of consecutive frames runs side by side (they share input frames)
         t = b % a.T;
         const int tile = b / a.T;
         tx = tile % ntx, ty = tile / ntx;
