@@ -244,7 +244,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
 // Tail mode (nsplit > 1): the launch covers the workgroups s_base .. of the (head, q-block) order that would otherwise
 // form a nearly empty last round, each cut into nsplit key ranges; a workgroup writes its normalised partial output
 // (bf16) and the log2-sum-exp of its rows, attn_combine_kernel merges them.
-template <int NW, int PRIO>
+// NS = LDS stages of the K / V^T tiles: 2 (shipped: tile t + 1 is staged during tile t and waited for three clusters later) or 3
+// (tile t + 2 staged during tile t: a whole tile more of slack for loads that miss L2 — `attn.stages`, A/B).
+template <int NW, int PRIO, int NS = 2>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int H, int Sq, int Sk_all, int Skp, int nqb, int total, int64_t o_sb,
@@ -368,12 +370,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         C4_BAR();                                                \
     } while (0)
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NS == 3 && nt > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile 0 (this wave's 4 pieces of tile 1 may still fly)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     C4_BAR();                  // tile 0 visible
+    int slot = 0;              // LDS stage of tile t
     if (late) C4_BAR();        // second half runs one cluster behind
     if ((PRIO & 4) && late) __builtin_amdgcn_s_setprio(1);   // the younger half loses every age arbitration otherwise
     for (int t = 0; t < nt; ++t) {
-        const char* Ks = smem + (t & 1) * ATT_STAGE;
+        const char* Ks = smem + (NS == 2 ? (t & 1) : slot) * ATT_STAGE;
         const char* Vs = Ks + K_TILE_BYTES;
         // ---- C1: K fragments -> registers; LDS-DMA of the next tile (its stage was last read two clusters ago) ----
 #pragma unroll
@@ -381,7 +389,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
                 kv[ks * 2 + kt] = *(const bf16x8*)(Ks + k_off[kt] + (((ks * 2 + hi) ^ k_sw[kt]) << 4));
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        if (NS == 2) {
+            if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        } else if (t + 2 < nt) {
+            stage(slot == 0 ? 2 : slot - 1, t + 2);             // (slot + 2) % 3: the stage tile t - 1 was read from
+        }
         C4_LGKM_BAR();
         // ---- C2: S^T = K Q^T ----
 #pragma unroll
@@ -467,7 +479,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         }
         // this wave's LDS-DMA pieces of tile t+1 must have landed before the barrier that opens the first cluster
         // reading them: the early half's C1(t+1) follows ITS C4(t) and the late half's C3(t) in the same slot
-        if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (late) {
+            if (NS == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t + 1; t + 2's pieces may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         C4_LGKM_BAR();
         // ---- C4: O^T += V^T P^T ----
         if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
@@ -477,8 +492,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
             for (int dt = 0; dt < 4; ++dt)
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[kk * 4 + dt], pf[kk], oacc[dt], 0, 0, 0);
         if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
-        if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!late) {
+            if (NS == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         C4_BAR();
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
     if (!late) C4_BAR();       // balance the barrier count of the two halves
 #undef C4_BAR
@@ -1016,6 +1035,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
+int g_attn_stages = 2;  // apexmi_tune_set("attn.stages", 2/3): LDS stages of the shipped 4-cluster kernel
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
 // (measured with the limit raised to 3/4 of a round: the Flux launch, 256 + 176 workgroups, gets 13 % SLOWER, 0.281 vs
@@ -1089,21 +1109,24 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
             attn_fwd_d128_c4_kernel<8, 3>, attn_fwd_d128_c4_kernel<8, 4>, attn_fwd_d128_c4_kernel<8, 5>,
             attn_fwd_d128_c4_kernel<8, 6>, attn_fwd_d128_c4_kernel<8, 7>};
         auto c4 = c4_tab[var];
-        static uint64_t c4_attr[8] = {};
-        APEXMI_SET_ATTR_ONCE(c4_attr[var],
-            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
+        const bool s3 = g_attn_stages == 3 && var == 2;          // the 3-stage form exists for the shipped variant only
+        if (s3) c4 = attn_fwd_d128_c4_kernel<8, 2, 3>;
+        const int c4_lds = (s3 ? 3 : 2) * ATT_STAGE;
+        static uint64_t c4_attr[9] = {};
+        APEXMI_SET_ATTR_ONCE(c4_attr[s3 ? 8 : var],
+            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, c4_lds));
         int tail = attn_tail(total, Sk);
         const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
         if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
         const int main_wgs = total - tail;
-        hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
+        hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), c4_lds, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
                            o_strides[2], c, 0, 1, (float*)nullptr, (float*)nullptr);
         if (int rc = apexmi_check_launch("attn_fwd_d128")) return rc;
         if (tail) {
             float* opart = (float*)workspace;
             float* lse = (float*)((char*)workspace + (size_t)tail * ATT_NSPLIT * 256 * HD * 4);
-            hipLaunchKernelGGL(c4, dim3(tail * ATT_NSPLIT), dim3(512), 2 * ATT_STAGE, stream, (const bf16_t*)q,
+            hipLaunchKernelGGL(c4, dim3(tail * ATT_NSPLIT), dim3(512), c4_lds, stream, (const bf16_t*)q,
                                (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total, o_strides[0],
                                o_strides[1], o_strides[2], c, main_wgs, ATT_NSPLIT, opart, lse);
             if (int rc = apexmi_check_launch("attn_fwd_d128 (tail)")) return rc;
@@ -1136,6 +1159,7 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
 void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
 void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
+void apexmi_set_attn_stages(int v) { g_attn_stages = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && (int64_t)Sq * Sk >= 256 * 256)

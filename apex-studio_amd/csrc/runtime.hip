@@ -119,6 +119,7 @@ void apexmi_set_attn_waves(int v);
 void apexmi_set_attn_mfma(int v);
 void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
+void apexmi_set_attn_stages(int v);
 void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 void apexmi_set_conv_v2(int v);
@@ -159,6 +160,9 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         return 0;
     } else if (!strcmp(key, "qk.group")) {
         apexmi_set_qk_group(value);
+        return 0;
+    } else if (!strcmp(key, "attn.stages")) {
+        apexmi_set_attn_stages(value);
         return 0;
     } else if (!strcmp(key, "attn.waves")) {
         apexmi_set_attn_waves(value);
