@@ -1018,6 +1018,8 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
+int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x256 tiles) that goes out as its own launch (96 = the text
+                       // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
 template <typename CFG, int EPI>
@@ -1059,14 +1061,15 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         // (QwenImage's feed-forward up-projection: image stream 32 x 48 = 1536 tiles = 6 rounds, text stream 48 tiles):
         // a partial round costs about half a full one however few tiles it holds (tools/gemm_rounds.py: +66 us for 48
         // tiles on a 577 us launch), so the tail problem goes out as its own 128x128-tiled launch (192 quarter-size
-        // tiles, under one round of the two-workgroups-per-CU kernel).
+        // tiles, under one round of the two-workgroups-per-CU kernel).  Round 3: with the eight-wave 128x128 tiling the same holds
+        // for Flux's FF-up (3 x 256 image tiles + 96 text tiles): g_tail_max 64 -> 96.
         if (cfg == 7 && g_tail_split && G.count >= 2 && G.batch == 1) {
             int64_t lead = 0;
             for (int i = 0; i + 1 < G.count; ++i)
                 lead += (int64_t)((Ms[i] + 255) / 256) * ((G.p[i].N + 255) / 256);
             const int li = G.count - 1;
             const int64_t last = (int64_t)((Ms[li] + 255) / 256) * ((G.p[li].N + 255) / 256);
-            if (lead >= 256 && lead % 256 == 0 && last <= 64) {
+            if (lead >= 256 && lead % 256 == 0 && last <= g_tail_max) {
                 GemmGroup T = G;
                 T.count = 1;
                 T.p[0] = G.p[li];
@@ -1284,6 +1287,7 @@ extern "C" int apexmi_split_bf16x3(const float* x, int64_t ldx, int64_t M, int K
 // tuning keys of this file (dispatched from apexmi_tune_set, runtime.hip)
 int apexmi_set_gemm_key(const char* key, int value) {
     if (!strcmp(key, "gemm.tail")) g_tail_split = value;
+    else if (!strcmp(key, "gemm.tail_max")) g_tail_max = value;
     else if (!strcmp(key, "gemm.group_m")) g_group_m = value > 0 ? value : GROUP_M;
     else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
