@@ -12,4 +12,12 @@ Layout (only what the hot path needs):
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# HIP runtime: keep kernel arguments in device memory instead of host memory read over the fabric at every kernel start.  A
+# denoise step is ~400 dependent launches; measured on the Flux step 69.23 -> 68.83 ms (-0.6 %, interleaved, same box).  Read by
+# the runtime when it initialises (the first HIP call of the process), so this takes effect when the package is imported before
+# any GPU work; an explicit setting in the environment wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 from . import lib  # noqa: F401

@@ -46,6 +46,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # as the package sets it on import (apex-studio_amd/__init__.py); before torch
 
 import torch  # noqa: E402
 
