@@ -391,6 +391,111 @@ APEXMI_DEVICE void v_transpose_body(int bx, int by, const T* __restrict__ v, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wan's q / k path in ONE pass (reference transformer/wan/base/attention.py:305-413 with InplaceRMSNorm,
+// transformer/efficiency/mod.py:24-35): RMSNorm over ALL H * 128 channels of a row (affine), the result rounded to the storage
+// type exactly where the in-place norm writes it, rotary embedding, [H, S_out, 128] layout — what ln_modulate(rms) on q,
+// ln_modulate(rms) on k and qk_norm_rope do as three passes, with the same arithmetic in the same order (one wave per row, lane
+// `l` holds elements (it * 64 + l) * 8 .. + 7; wave_sum of the squares): bit-identical.  Units: row * nk + which.  The leading
+// nb_v workgroups transpose V (v_transpose_body) when there is one.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+APEXMI_DEVICE void round_to_storage(float (&y)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 p = pack8(y);
+        unpack8(p, y);
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void qk_rms_rope_rows_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, int64_t ld_in, int S, int H,
+    const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, float eps, const float* __restrict__ rope, int rope_mode,
+    T* __restrict__ qo, T* __restrict__ ko, T* __restrict__ vt, int S_out, int Skp, int row0, int nb_v, int nst) {
+    if ((int)blockIdx.x < nb_v) {
+        v_transpose_body<T>(blockIdx.x % nst, blockIdx.x / nst, v, 128, ld_in, S, 128, vt, Skp, row0);
+        return;
+    }
+    constexpr int D = 128;
+    const int C = NCH * 512;
+    const int lane = threadIdx.x & 63;
+    const int nk = k != nullptr ? 2 : 1;
+    const int64_t unit = (int64_t)(blockIdx.x - nb_v) * 4 + (threadIdx.x >> 6);
+    if (unit >= (int64_t)S * nk) return;                 // whole waves leave together
+    const int s = (int)(unit / nk), which = (int)(unit % nk);
+    const T* xp = (which ? k : q) + (int64_t)s * ld_in;
+    const bf16_t* w = which ? wk : wq;
+    float x[NCH][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        load8<T>(xp + (it * 64 + lane) * 8, x[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += x[it][j];
+    }
+    (void)sum;
+    float sq = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = x[it][j] - 0.0f;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const int srow = row0 + s;
+    T* dst = which ? ko : qo;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int c = it * 64 + lane;                    // 8-element chunk of the row
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (x[it][j] - 0.0f) * rstd;
+        if (w != nullptr) {
+            float g[8];
+            unpack8(*(const u32x4*)(w + c * 8), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] *= g[j];
+        }
+        round_to_storage<T>(y);                          // the storage point of the in-place norm
+        const int h = c >> 4, l16 = c & 15, d = l16 * 8;
+        float o[8];
+        if (rope_mode == APEXMI_ROPE_INTERLEAVED) {
+            const float* cp = rope + (int64_t)srow * D + d;
+            const float* sp = rope + (int64_t)S_out * D + (int64_t)srow * D + d;
+            const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+            float cs[8], sn[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cs[j] = c0[j];
+                cs[j + 4] = c1[j];
+                sn[j] = s0[j];
+                sn[j + 4] = s1[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = fmaf(y[2 * i], cs[2 * i], -(y[2 * i + 1] * sn[2 * i]));
+                o[2 * i + 1] = fmaf(y[2 * i + 1], cs[2 * i + 1], y[2 * i] * sn[2 * i + 1]);
+            }
+        } else if (rope_mode == APEXMI_ROPE_COMPLEX) {
+            const float* tp = rope + ((int64_t)srow * (D / 2) + l16 * 4) * 2;
+            const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
+            const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+            const float sn[4] = {t0[1], t0[3], t1[1], t1[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = fmaf(y[2 * i], cs[i], -(y[2 * i + 1] * sn[i]));
+                o[2 * i + 1] = fmaf(y[2 * i], sn[i], y[2 * i + 1] * cs[i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = y[j];
+        }
+        store8<T>(dst + ((int64_t)h * S_out + srow) * D + d, o);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ v, int64_t v_sh, int64_t v_ss, int S,
                                                           int D, T* __restrict__ vt, int Skp, int col0) {
@@ -918,6 +1023,50 @@ extern "C" int apexmi_qkv_prepare_f32(const void* q, const void* k, const void* 
                                       int row0, apexmi_stream_t stream_) {
     return qkv_prepare_impl<float>(q, k, v, ld_in, S, H, D, split, wq, wk, wq2, wk2, eps, rope, rope_mode, qo, ko, vt,
                                    S_out, Skp, row0, stream_);
+}
+
+template <typename T>
+static int qk_rms_rope_rows_impl(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H, const void* wq,
+                                 const void* wk, float eps, const float* rope, int rope_mode, void* qo, void* ko, void* vt,
+                                 int S_out, int Skp, int row0, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    constexpr int al = 16 / (int)sizeof(T);
+    APEXMI_REQUIRE(q && qo && S > 0 && H > 0, "qk_rms_rope_rows: bad arguments");
+    APEXMI_REQUIRE((k == nullptr) == (ko == nullptr) && (v == nullptr) == (vt == nullptr), "qk_rms_rope_rows: k / ko and v / vt come in pairs");
+    // the widths whose stand-alone RMSNorm runs on the one-wave-per-row kernel: the fused pass keeps ITS summation order
+    APEXMI_REQUIRE(H * 128 == 3072 || H * 128 == 5120,
+                   "qk_rms_rope_rows: H * 128 = %d is not 3072 / 5120; use the three-pass path", H * 128);
+    APEXMI_REQUIRE(ld_in % al == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                       ((uintptr_t)qo % 16) == 0 && ((uintptr_t)ko % 16) == 0 && ((uintptr_t)vt % 16) == 0 &&
+                       ((uintptr_t)wq % 16) == 0 && ((uintptr_t)wk % 16) == 0 && ((uintptr_t)rope % 16) == 0,
+                   "qk_rms_rope_rows: operands must be 16-byte aligned");
+    APEXMI_REQUIRE(row0 >= 0 && row0 + S <= S_out && (rope_mode == APEXMI_ROPE_NONE || rope != nullptr), "qk_rms_rope_rows: rows / rope");
+    APEXMI_REQUIRE(vt == nullptr || (Skp >= row0 + S && Skp % 8 == 0 && row0 % 8 == 0), "qk_rms_rope_rows: V^T needs Skp >= rows, 8-aligned");
+    const int nst = (S + 63) / 64;
+    const int nb_v = vt ? nst * H : 0;
+    const int64_t units = (int64_t)S * (k ? 2 : 1);
+    const unsigned grid = (unsigned)(nb_v + (units + 3) / 4);
+    ApexmiProfScope prof(4, stream, 0.0, (double)sizeof(T) * 2.0 * (double)S * H * 128 * (k ? 2 : 1) + (v ? (double)sizeof(T) * 2.0 * S * H * 128 : 0.0));
+#define QRR_LAUNCH(N)                                                                                                         \
+    hipLaunchKernelGGL((qk_rms_rope_rows_kernel<T, N>), dim3(grid), dim3(256), 0, stream, (const T*)q, (const T*)k, (const T*)v, \
+                       ld_in, S, H, (const bf16_t*)wq, (const bf16_t*)wk, eps, rope, rope_mode, (T*)qo, (T*)ko, (T*)vt, S_out,    \
+                       Skp, row0, nb_v, nst)
+    if (H * 128 == 3072) QRR_LAUNCH(6);
+    else QRR_LAUNCH(10);
+#undef QRR_LAUNCH
+    return apexmi_check_launch("qk_rms_rope_rows");
+}
+
+extern "C" int apexmi_qk_rms_rope_rows(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H, const void* wq,
+                                       const void* wk, float eps, const float* rope, int rope_mode, void* qo, void* ko,
+                                       void* vt, int S_out, int Skp, int row0, apexmi_stream_t stream_) {
+    return qk_rms_rope_rows_impl<bf16_t>(q, k, v, ld_in, S, H, wq, wk, eps, rope, rope_mode, qo, ko, vt, S_out, Skp, row0, stream_);
+}
+
+extern "C" int apexmi_qk_rms_rope_rows_f32(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H,
+                                           const void* wq, const void* wk, float eps, const float* rope, int rope_mode, void* qo,
+                                           void* ko, void* vt, int S_out, int Skp, int row0, apexmi_stream_t stream_) {
+    return qk_rms_rope_rows_impl<float>(q, k, v, ld_in, S, H, wq, wk, eps, rope, rope_mode, qo, ko, vt, S_out, Skp, row0, stream_);
 }
 
 extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const float* x, int64_t ldx,

@@ -322,6 +322,37 @@ def qkv_prepare(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], H: 
     _l.check(rc, "qkv_prepare")
 
 
+def qk_rms_rope_rows(q: torch.Tensor, k: Optional[torch.Tensor], v: Optional[torch.Tensor], H: int, qo: torch.Tensor,
+                     ko: Optional[torch.Tensor], vt: Optional[torch.Tensor], wq: Optional[torch.Tensor] = None,
+                     wk: Optional[torch.Tensor] = None, eps: float = 1e-6, rope: Optional[torch.Tensor] = None,
+                     rope_mode: int = _l.ROPE_NONE, row0: int = 0) -> None:
+    """Wan's q / k preparation in one pass: RMSNorm over all H * 128 channels of every q (and k) row (weights wq / wk of that
+    width), rounded to the storage type where the in-place norm of the reference writes it, RoPE, [H, S_out, 128] layout; v
+    (optional) transposed to [H, 128, Skp].  Bit-identical to ln_modulate(rms) on q, on k, then qkv_prepare."""
+    _req_act(q, "qk_rms_rope_rows.q")
+    for t_ in (k, v, qo, ko, vt):
+        if t_ is not None:
+            _req(t_, q.dtype, "qk_rms_rope_rows operand")
+    S, ld = q.shape[0], q.stride(0)
+    assert q.shape[1] == H * 128 and (k is None or k.stride(0) == ld) and (v is None or v.stride(0) == ld)
+    assert qo.is_contiguous() and qo.shape[0] == H and (k is None) == (ko is None) and (v is None) == (vt is None)
+    assert ko is None or (ko.is_contiguous() and ko.shape == qo.shape)
+    Skp = 0
+    if vt is not None:
+        assert vt.is_contiguous() and vt.shape[0] == H and vt.shape[1] == 128
+        Skp = vt.shape[2]
+    for w_ in (wq, wk):
+        if w_ is not None:
+            _req(w_, torch.bfloat16, "qk_rms_rope_rows weight")
+            assert w_.is_contiguous() and w_.numel() == H * 128
+    if rope is not None:
+        _req(rope, torch.float32, "qk_rms_rope_rows.rope")
+        assert rope.is_contiguous()
+    rc = _fn("apexmi_qk_rms_rope_rows", q)(q.data_ptr(), _ptr(k), _ptr(v), ld, S, H, _ptr(wq), _ptr(wk), float(eps), _ptr(rope),
+                                           rope_mode, qo.data_ptr(), _ptr(ko), _ptr(vt), qo.shape[1], Skp, row0, _stream())
+    _l.check(rc, "qk_rms_rope_rows")
+
+
 def v_transpose(v: torch.Tensor, vt: torch.Tensor) -> None:
     """v: [S, H, 128] view (any row/head stride) -> vt [H, 128, Skp] zero padded."""
     _req(v, torch.bfloat16, "v_transpose.v")

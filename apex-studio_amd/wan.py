@@ -16,6 +16,8 @@ raise NotImplementedError.
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 import math
 from types import SimpleNamespace
@@ -115,6 +117,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         self._packed = False
         self._ws: Dict[Any, Any] = {}
         self.storage_dtype = torch.bfloat16
+        self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"     # see _forward_one
         self._rope: Dict[Any, torch.Tensor] = {}
 
     # ---- reference-compatible plumbing -------------------------------------------------------
@@ -295,16 +298,23 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
 
         q_in, k_in, v_in = QKV[:, :dim], QKV[:, dim:2 * dim], QKV[:, 2 * dim:]
         att_v = ATT.unflatten(-1, (H, 128)).unsqueeze(0)
+        # q / k across-heads RMSNorm + RoPE + layout (+ V^T) as one pass (apexmi_qk_rms_rope_rows, bit-identical to the three it
+        # replaces); `fuse_qkv = False` keeps the normalised [S, dim] q / k as storage points (tests/stage_parity.py)
+        fuse = self.fuse_qkv and dim in (3072, 5120)
         for i, blk in enumerate(self.blocks):
             a1, a2 = blk.attn1, blk.attn2
             m = lambda j: ws.MOD[i, j * dim:(j + 1) * dim]  # noqa: E731 shift, scale, gate, c_shift, c_scale, c_gate
             # 1. self attention
             ops.ln_modulate(X, m(1), m(0), out=XN, eps=eps)
             ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
-            ops.ln_modulate(q_in, gamma=a1.norm_q.weight, out=q_in, eps=eps, rms=True)
-            ops.ln_modulate(k_in, gamma=a1.norm_k.weight, out=k_in, eps=eps, rms=True)
-            ops.qkv_prepare(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], rope=rope,
-                            rope_mode=_l.ROPE_INTERLEAVED)
+            if fuse:       # across-heads RMSNorm of q and k + RoPE + layout + V^T in one read of the projection
+                ops.qk_rms_rope_rows(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], wq=a1.norm_q.weight, wk=a1.norm_k.weight,
+                                     eps=eps, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
+            else:
+                ops.ln_modulate(q_in, gamma=a1.norm_q.weight, out=q_in, eps=eps, rms=True)
+                ops.ln_modulate(k_in, gamma=a1.norm_k.weight, out=k_in, eps=eps, rms=True)
+                ops.qkv_prepare(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], rope=rope,
+                                rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(ws.Q, ws.K, ws.VT, att_v, S)
             ops.gemm(ATT, a1.to_out[0].weight, a1.to_out[0].bias, out=X, epilogue="gate_res", gate=m(2),
                      residual=X)
@@ -315,10 +325,14 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
             else:
                 src = X
             ops.gemm(src, a2.to_q.weight, a2.to_q.bias, out=q_in)
-            ops.ln_modulate(q_in, gamma=a2.norm_q.weight, out=q_in, eps=eps, rms=True)
+            if fuse:
+                ops.qk_rms_rope_rows(q_in, None, None, H, ws.Q[0], None, None, wq=a2.norm_q.weight, eps=eps)
+            else:
+                ops.ln_modulate(q_in, gamma=a2.norm_q.weight, out=q_in, eps=eps, rms=True)
             ops.gemm(ws.CTX, blk._wkv2, blk._bkv2, out=ws.KV2)
             ops.ln_modulate(ws.KV2[:, :dim], gamma=a2.norm_k.weight, out=ws.KV2[:, :dim], eps=eps, rms=True)
-            ops.qkv_prepare(q_in, None, None, H, ws.Q[0], None, None)
+            if not fuse:
+                ops.qkv_prepare(q_in, None, None, H, ws.Q[0], None, None)
             ops.qkv_prepare(ws.KV2[:, :dim], None, ws.KV2[:, dim:], H, ws.K2[0], None, ws.VT2[0])
             ops.attention_prepared(ws.Q, ws.K2, ws.VT2, att_v, s_txt)
             ops.gemm(ATT, a2.to_out[0].weight, a2.to_out[0].bias, out=X, epilogue="gate_res", gate=self._ones,

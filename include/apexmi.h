@@ -244,6 +244,20 @@ int apexmi_ln_modulate2(const void* x, int64_t ldx, void* out, int64_t ldo, int 
                         float eps, int rms, int split, const float* scale2, const float* shift2,
                         apexmi_stream_t stream);
 
+/* Wan's q / k preparation in ONE pass (reference transformer/wan/base/attention.py:305-413; InplaceRMSNorm,
+ * transformer/efficiency/mod.py:24-35; apply_wan_rope_inplace, transformer/efficiency/ops.py:112-160): RMSNorm over ALL H * 128
+ * channels of every q and k row (affine weights wq / wk of H * 128 elements, bf16), the result rounded to the storage type where
+ * the reference's in-place norm writes it, rotary embedding (rope_mode as apexmi_qkv_prepare), layout [H, S_out, 128]; v (optional)
+ * leaves transposed [H, 128, Skp].  Equals apexmi_ln_modulate2(rms) on q, on k, then apexmi_qkv_prepare without norm weights, bit
+ * for bit, in one read of the projection.  k / ko and v / vt may be NULL together (the query side of cross-attention).
+ * H * 128 in {3072, 5120} (the widths whose stand-alone norm uses the same one-wave-per-row reduction).  _f32: float q / k / v / outputs (f32-storage verification mode). */
+int apexmi_qk_rms_rope_rows(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H, const void* wq, const void* wk,
+                            float eps, const float* rope, int rope_mode, void* qo, void* ko, void* vt, int S_out, int Skp,
+                            int row0, apexmi_stream_t stream);
+int apexmi_qk_rms_rope_rows_f32(const void* q, const void* k, const void* v, int64_t ld_in, int S, int H, const void* wq,
+                                const void* wk, float eps, const float* rope, int rope_mode, void* qo, void* ko, void* vt,
+                                int S_out, int Skp, int row0, apexmi_stream_t stream);
+
 /* Per-head RMSNorm on q,k + rotary embedding, written in attention layout, and V transposed.
  * Replaces the unflatten / norm_q / norm_k / cat / apply_rotary_emb / permute chain of
  * FluxAttnProcessor.__call__ (transformer/flux/base/attention.py:62-94).

@@ -161,3 +161,65 @@ def test_fused_epilogue_race_screen():
         else:
             assert all(torch.equal(a, b) for a, b in zip(cur, ref)), it
     assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[2].float()).all()
+
+
+@pytest.mark.parametrize("H,S,mode", [(24, 333, "interleaved"), (24, 200, "complex"), (40, 130, "interleaved"), (40, 64, "none")])
+def test_wan_rms_rope_rows_bit_identical_to_three_passes(H, S, mode):
+    """`apexmi_qk_rms_rope_rows` (Wan: RMSNorm across all heads of q and k, RoPE, layout, V^T in one pass) against the three
+    passes it replaces — ln_modulate(rms) in place on q, on k, then qkv_prepare — and its q-only form (cross-attention)."""
+    from apex_studio_amd import lib as _l, ops
+    dim = H * 128
+    skp = (S + 63) // 64 * 64
+    qkv = _rand((S, 3 * dim), 51)
+    wq, wk = _rand((dim,), 52) * 0.2 + 1, _rand((dim,), 53) * 0.2 + 1
+    rm = {"interleaved": _l.ROPE_INTERLEAVED, "complex": _l.ROPE_COMPLEX, "none": _l.ROPE_NONE}[mode]
+    rope = None
+    if mode == "interleaved":
+        rope = _rope(S, 54)
+    elif mode == "complex":
+        g = torch.Generator(device=DEV).manual_seed(55)
+        ang = torch.rand(S, 64, generator=g, device=DEV) * 6.283
+        rope = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().float()        # [S, 64, 2]
+    ref = qkv.clone()
+    q_in, k_in, v_in = ref[:, :dim], ref[:, dim:2 * dim], ref[:, 2 * dim:]
+    ops.ln_modulate(q_in, gamma=wq, out=q_in, eps=1e-6, rms=True)
+    ops.ln_modulate(k_in, gamma=wk, out=k_in, eps=1e-6, rms=True)
+    q0, k0 = (torch.empty(H, S, 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt0 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    ops.qkv_prepare(q_in, k_in, v_in, H, q0, k0, vt0, rope=rope, rope_mode=rm)
+    q1, k1 = (torch.full((H, S, 128), 5.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt1 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    x = qkv.clone()
+    ops.qk_rms_rope_rows(x[:, :dim], x[:, dim:2 * dim], x[:, 2 * dim:], H, q1, k1, vt1, wq=wq, wk=wk, eps=1e-6, rope=rope,
+                         rope_mode=rm)
+    torch.cuda.synchronize()
+    assert torch.equal(x, qkv), "the projection itself is not modified"
+    assert torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(vt1, vt0)
+    q2 = torch.empty_like(q1)
+    ops.qk_rms_rope_rows(x[:, :dim], None, None, H, q2, None, None, wq=wq, eps=1e-6, rope=rope, rope_mode=rm)
+    assert torch.equal(q2, q0)
+
+
+def test_wan_forward_identical_with_and_without_the_fused_rows_pass():
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from tests.golden.seeded import seeded, synthetic_state_dict
+    cfg = dict(patch_size=(1, 2, 2), num_attention_heads=24, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=256,
+               freq_dim=256, ffn_dim=2048, num_layers=2, cross_attn_norm=True, eps=1e-6, rope_max_seq_len=1024)
+    m = WanTransformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 13).items()}, strict=True)
+    inp = dict(hidden_states=seeded((1, 16, 3, 16, 20), 61).to(DEV).to(torch.bfloat16), timestep=torch.tensor([700.0], device=DEV),
+               encoder_hidden_states=seeded((1, 40, 256), 62).to(DEV).to(torch.bfloat16))
+    calls = []
+    from apex_studio_amd import ops
+    orig = ops.qk_rms_rope_rows
+    ops.qk_rms_rope_rows = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        m.fuse_qkv = True
+        a = m(return_dict=False, **inp)[0].clone()
+        n = len(calls)
+        m.fuse_qkv = False
+        b = m(return_dict=False, **inp)[0].clone()
+    finally:
+        ops.qk_rms_rope_rows = orig
+    assert n == 4 and len(calls) == 4                    # 2 blocks x (self + cross query side)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
