@@ -303,7 +303,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         self._packed = True
 
     def _workspace(self, s_txt: int, s_img: int):
-        key = (s_txt, s_img)
+        # one workspace per (shape, HIP stream): two clips may run through one resident model on two streams
+        key = (s_txt, s_img, torch.cuda.current_stream().cuda_stream)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -321,7 +322,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             FFH=torch.empty(S, mlp, **bf), MOD=torch.empty(1, self._mod_total, **f32),
             TEMB=torch.empty(1, dim, **f32), OUT=torch.empty(s_img, self.proj_out.out_features, **bf),
         )
-        self._ws = {key: ws}  # one shape resident at a time
+        self._ws = {k: v for k, v in self._ws.items() if k[:2] == key[:2]}  # one shape resident at a time
+        self._ws[key] = ws
         return ws
 
     # ---- the denoise step --------------------------------------------------------------------

@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""A/B: two Flux-1024 clips on ONE GPU, back to back on one stream vs concurrently on two HIP streams (one resident
+model, per-stream workspaces).  The question is whether the tile-quantisation gaps of the B=1 step (216/648/864 GEMM
+tiles and 432 attention workgroups on 256 CUs) can be filled by a second clip, given that the chip is power-bound.
+Interleaved rounds in one process; prints one JSON line.  Not the headline metric (BASELINE's config is B=1, one
+clip per GPU): a render-queue option."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import apex_studio_amd  # noqa: E402,F401
+from apex_studio_amd.engine_flux import calculate_shift, latent_image_ids  # noqa: E402
+from apex_studio_amd.flux import FluxTransformer2DModel  # noqa: E402
+from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import FLUX_DEV, S_IMG, S_TXT  # noqa: E402
+
+DEV = torch.device("cuda:0")
+STEPS = int(os.environ.get("STEPS", "8"))
+ROUNDS = int(os.environ.get("ROUNDS", "3"))
+
+
+def main():
+    model = FluxTransformer2DModel(**FLUX_DEV, device=DEV, dtype=torch.bfloat16).init_synthetic(seed=1234)
+    model.pack()
+    img_ids = latent_image_ids(64, 64).to(DEV)
+    txt_ids = torch.zeros(S_TXT, 3, device=DEV)
+    guidance = torch.full([1], 3.5, device=DEV, dtype=torch.float32)
+
+    class Clip:
+        def __init__(self, seed):
+            g = torch.Generator(device=DEV).manual_seed(seed)
+            self.lat0 = torch.randn(1, S_IMG, 64, generator=g, device=DEV).to(torch.bfloat16)
+            self.enc = torch.randn(1, S_TXT, 4096, generator=g, device=DEV).to(torch.bfloat16)
+            self.pooled = torch.randn(1, 768, generator=g, device=DEV).to(torch.bfloat16)
+            self.sched = FlowMatchEulerDiscreteScheduler.flux_dev()
+            self.stream = torch.cuda.Stream(device=DEV)
+            self.reset()
+
+        def reset(self):
+            n = STEPS + 2
+            self.ts = self.sched.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / n, n).tolist(),
+                                               mu=calculate_shift(S_IMG), device=DEV)
+            self.sched.set_begin_index(0)
+            self.lat = self.lat0.clone()
+            self.i = 0
+
+        def step(self):
+            t = self.ts[self.i]
+            v = model(hidden_states=self.lat, timestep=t.expand(1).to(self.lat.dtype) / 1000, guidance=guidance,
+                      pooled_projections=self.pooled, encoder_hidden_states=self.enc, txt_ids=txt_ids,
+                      img_ids=img_ids, return_dict=False)[0]
+            self.lat = self.sched.step(v, t, self.lat, return_dict=False)[0]
+            self.i += 1
+
+    a, b = Clip(1), Clip(2)
+
+    def run(concurrent):
+        a.reset()
+        b.reset()
+        sa = a.stream
+        sb = b.stream if concurrent else a.stream
+        for c, s in ((a, sa), (b, sb)):          # one warm-up step each
+            with torch.cuda.stream(s):
+                c.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if concurrent:
+            for _ in range(STEPS):
+                with torch.cuda.stream(sa):
+                    a.step()
+                with torch.cuda.stream(sb):
+                    b.step()
+        else:
+            for c in (a, b):
+                with torch.cuda.stream(sa):
+                    for _ in range(STEPS):
+                        c.step()
+        t_cpu = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, t_cpu, a.lat.float().clone(), b.lat.float().clone()
+
+    res = {"seq": [], "conc": [], "cpu_enqueue_ms_per_step": []}
+    ref = None
+    same = True
+    for _ in range(ROUNDS):
+        for mode in ("seq", "conc"):
+            dt, t_cpu, la, lb = run(mode == "conc")
+            res[mode].append(round(1e3 * dt / (2 * STEPS), 3))
+            if mode == "conc":
+                res["cpu_enqueue_ms_per_step"].append(round(1e3 * t_cpu / (2 * STEPS), 3))
+            if ref is None:
+                ref = (la, lb)
+            else:
+                same = same and torch.equal(ref[0], la) and torch.equal(ref[1], lb)
+    best = {m: min(res[m]) for m in ("seq", "conc")}
+    print(json.dumps({"workload": "flux-dev 1024x1024, two clips on one GPU", "steps_per_clip": STEPS,
+                      "ms_per_step_per_clip": res, "best": best,
+                      "aggregate_steps_per_sec": {m: round(1e3 / best[m], 3) for m in best},
+                      "gain": round(best["seq"] / best["conc"] - 1.0, 4),
+                      "results_identical_across_modes": bool(same)}))
+
+
+if __name__ == "__main__":
+    main()
