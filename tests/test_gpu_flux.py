@@ -201,3 +201,37 @@ def test_rotary_table_cache_follows_the_position_ids():
     g2 = dict(g, img_ids=g["img_ids"].clone())                        # another tensor object with the same values
     table2 = m._rope_cache[3]
     assert torch.equal(c, m(return_dict=False, **g2)[0]) and m._rope_cache[3] is not table2
+
+
+def test_batch_of_images_on_streams_is_bit_identical_to_the_sequential_walk():
+    """`num_images` > 1 (reference engine/flux/t2i.py:88 hands the transformer a batch): the images of a batch run side by side
+    on `batch_streams` HIP streams, each with its own workspaces.  Same kernels on the same data: the result must equal the
+    sequential walk (`batch_streams = 1`) and the per-image B=1 calls bit for bit, on the first call (cold rotary table, cold
+    workspaces) and on repeats, at a size where the launches overlap (mid config, 464 tokens) and with an odd batch."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["mid"]
+    B = 3
+    sd = None
+    outs = {}
+    for ns in (2, 1):
+        m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+        sd = sd or {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 11).items()}
+        m.load_state_dict(sd, strict=True)
+        m.batch_streams = ns
+        g = dict(hidden_states=seeded((B, hw[0] * hw[1], cfg["in_channels"]), 41).to(DEV).to(torch.bfloat16),
+                 encoder_hidden_states=seeded((B, s_txt, cfg["joint_attention_dim"]), 42).to(DEV).to(torch.bfloat16),
+                 pooled_projections=seeded((B, cfg["pooled_projection_dim"]), 43).to(DEV).to(torch.bfloat16),
+                 timestep=torch.tensor([0.5, 0.25, 0.75], device=DEV), guidance=torch.tensor([4.0, 3.5, 2.0], device=DEV),
+                 img_ids=OF.latent_image_ids(*hw).to(DEV), txt_ids=torch.zeros(s_txt, 3, device=DEV))
+        first = m(return_dict=False, **g)[0].clone()                 # cold: the table and the workspaces are made in this call
+        reps = [m(return_dict=False, **g)[0].clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(first, r) for r in reps)
+        assert len(m._bstreams) == (2 if ns == 2 else 0)
+        outs[ns] = first
+        if ns == 1:
+            for b in range(B):
+                one = m(return_dict=False, **{k: (v[b:b + 1] if k not in ("img_ids", "txt_ids") else v) for k, v in g.items()})[0]
+                assert torch.equal(one[0], first[b])
+    assert torch.isfinite(outs[2].float()).all() and torch.equal(outs[1], outs[2])
+    assert not torch.equal(outs[2][0], outs[2][1])

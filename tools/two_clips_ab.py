@@ -58,6 +58,30 @@ def main():
             self.lat = self.sched.step(v, t, self.lat, return_dict=False)[0]
             self.i += 1
 
+    if os.environ.get("MODE") == "batch":      # one B=2 forward (num_images = 2): model.batch_streams 1 vs 2
+        g = torch.Generator(device=DEV).manual_seed(5)
+        kw = dict(hidden_states=torch.randn(2, S_IMG, 64, generator=g, device=DEV).to(torch.bfloat16),
+                  encoder_hidden_states=torch.randn(2, S_TXT, 4096, generator=g, device=DEV).to(torch.bfloat16),
+                  pooled_projections=torch.randn(2, 768, generator=g, device=DEV).to(torch.bfloat16),
+                  timestep=torch.tensor([0.7, 0.7], device=DEV, dtype=torch.bfloat16), guidance=guidance.expand(2),
+                  txt_ids=txt_ids, img_ids=img_ids, return_dict=False)
+        res, outs = {1: [], 2: []}, {}
+        for _ in range(ROUNDS):
+            for ns in (1, 2):
+                model.batch_streams = ns
+                outs[ns] = model(**kw)[0].clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(STEPS):
+                    model(**kw)
+                torch.cuda.synchronize()
+                res[ns].append(round(1e3 * (time.perf_counter() - t0) / (2 * STEPS), 3))
+        print(json.dumps({"workload": "flux-dev 1024x1024 forward, B = 2 (num_images 2)", "forwards": STEPS,
+                          "ms_per_image_forward": {f"batch_streams={k}": v for k, v in res.items()},
+                          "gain": round(min(res[1]) / min(res[2]) - 1.0, 4),
+                          "results_identical": bool(torch.equal(outs[1], outs[2]))}))
+        return
+
     a, b = Clip(1), Clip(2)
 
     def run(concurrent):
