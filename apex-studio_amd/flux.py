@@ -530,21 +530,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             # quantisation gaps (216 / 648 / 864 GEMM tiles and 432 attention workgroups on 256 CUs): `batch_streams` images run
             # side by side on their own HIP streams (own workspaces, `_workspace`) and fill them — +4 % images/s measured
             # (profiles/r03_two_clips_ab.json), same kernels on the same data, bit-identical to the sequential walk.
-            main = torch.cuda.current_stream()
             self._rope(txt_ids, img_ids)        # table made on the calling stream, before the side streams fork from it
-            if len(self._bstreams) < ns:
-                self._bstreams += [torch.cuda.Stream(device=hs.device) for _ in range(ns - len(self._bstreams))]
-            for s_ in self._bstreams[:ns]:
-                s_.wait_stream(main)
-            outs = []
-            for b in range(B):
-                st = self._bstreams[b % ns]
-                with torch.cuda.stream(st):
-                    y = one(b)
-                    y.record_stream(main)
-                    outs.append(y)
-            for s_ in self._bstreams[:ns]:
-                main.wait_stream(s_)
+            outs = ops.run_on_streams(self._bstreams, ns, B, one, hs.device)
         out = torch.stack(outs, dim=0).to(hidden_states.dtype)
         if not return_dict:
             return (out,)

@@ -1080,6 +1080,29 @@ def groupnorm_cl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group
     return out
 
 
+# ---- independent items on side streams ----------------------------------------------------------------------------
+def run_on_streams(streams: list, ns: int, n_items: int, fn, device):
+    """`fn(i)` for i in range(n_items) — independent pieces of one call (the images of a batch) — side by side on `ns` HIP
+    streams forked from the calling stream and joined back into it; `streams` is the caller's pool (grown on demand).  Each
+    result is marked as used by the calling stream (the caching allocator keys blocks on the stream that allocated them).  The
+    callee's scratch must be per stream (the models key their workspaces on the stream; the op workspaces above already do)."""
+    main = torch.cuda.current_stream()
+    if len(streams) < ns:
+        streams += [torch.cuda.Stream(device=device) for _ in range(ns - len(streams))]
+    for s_ in streams[:ns]:
+        s_.wait_stream(main)
+    outs = []
+    for i in range(n_items):
+        st = streams[i % ns]
+        with torch.cuda.stream(st):
+            y = fn(i)
+            y.record_stream(main)
+            outs.append(y)
+    for s_ in streams[:ns]:
+        main.wait_stream(s_)
+    return outs
+
+
 # ---- device guard ------------------------------------------------------------------------------------------------
 # Every wrapper above enqueues on `torch.cuda.current_stream()` of the CURRENT device.  A model living on cuda:1
 # while the caller's current device is cuda:0 would otherwise launch on device 0's stream with device-1 pointers.

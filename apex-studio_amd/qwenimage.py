@@ -20,7 +20,7 @@ from __future__ import annotations
 import contextlib
 import os
 from types import SimpleNamespace
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -104,6 +104,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
+        self.batch_streams = 2           # images of a batch on side-by-side HIP streams (forward); 1 = sequential
+        self._bstreams: List[Any] = []
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -199,7 +201,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         self._packed = True
 
     def _workspace(self, s_txt: int, s_img: int):
-        key = (s_txt, s_img)
+        key = (s_txt, s_img, torch.cuda.current_stream().cuda_stream)   # per stream: the images of a batch run side by side
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -214,7 +216,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             VT=torch.zeros(1, H, 128, skp, **bf), ATT=torch.empty(S, dim, **bf),
             FFH=torch.empty(S, 4 * dim, **bf), TXTN=torch.empty(s_txt, self.config.joint_attention_dim, **bf),
             MOD=torch.empty(1, self._mod_total, **f32), TEMB=torch.empty(1, dim, **f32))
-        self._ws = {key: ws}
+        self._ws = {k: v for k, v in self._ws.items() if k[:2] == key[:2]}  # one shape resident at a time
+        self._ws[key] = ws
         return ws
 
     def _rope_table(self, shapes, s_txt: int):
@@ -331,11 +334,20 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         B = hidden_states.shape[0]
         hs = hidden_states.to(self.storage_dtype)
         enc = encoder_hidden_states.to(self.storage_dtype)
-        outs = []
-        for b in range(B):
-            shapes = img_shapes[b] if isinstance(img_shapes[0], (list, tuple)) and \
+        def shapes_of(b):
+            return img_shapes[b] if isinstance(img_shapes[0], (list, tuple)) and \
                 isinstance(img_shapes[0][0], (list, tuple)) else img_shapes
-            outs.append(self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes))
+
+        def one(b):
+            return self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes_of(b))
+
+        ns = min(int(self.batch_streams), B)
+        if ns <= 1 or not hs.is_cuda or any(shapes_of(b) != shapes_of(0) for b in range(1, B)):
+            outs = [one(b) for b in range(B)]
+        else:
+            # the images of a batch side by side on HIP streams (see flux.py forward; same mechanism, bit-identical results)
+            self._rope_table(shapes_of(0), enc.shape[1])     # made on the calling stream, before the side streams fork
+            outs = ops.run_on_streams(self._bstreams, ns, B, one, hs.device)
         out = torch.stack(outs, dim=0).to(hidden_states.dtype)
         if not return_dict:
             return (out,)

@@ -136,3 +136,36 @@ def test_qwen_edit_pixels_in_pixels_out():
     frames = eng.run(images=img.to(DEV), return_latents=False, output_type="np", **kw)
     from oracle.postprocess import video_to_uint8_frames
     assert frames.shape == (1, 128, 96, 3) and (frames == video_to_uint8_frames(out.cpu().unsqueeze(2))[:, 0]).all()
+
+
+def test_batch_of_images_on_streams_is_bit_identical_to_the_sequential_walk():
+    """A batch (`num_images` > 1) runs its images side by side on `batch_streams` HIP streams with per-stream workspaces: equal bit
+    for bit to the sequential walk and to the per-image calls, cold (rotary table and workspaces made in the call) and on repeats."""
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    cfg, shapes, s_txt = CONFIGS["mid"]
+    B = 3
+    n_img = sum(f * h * w for f, h, w in shapes)
+    sd, outs = None, {}
+    for ns in (2, 1):
+        m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+        sd = sd or {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 12).items()}
+        m.load_state_dict(sd, strict=True)
+        m.batch_streams = ns
+        kw = dict(hidden_states=seeded((B, n_img, 64), 61).to(DEV).to(torch.bfloat16),
+                  encoder_hidden_states=seeded((B, s_txt, cfg["joint_attention_dim"]), 62).to(DEV).to(torch.bfloat16),
+                  encoder_hidden_states_mask=torch.ones(B, s_txt, device=DEV), timestep=torch.tensor([0.5, 0.25, 0.75], device=DEV),
+                  img_shapes=[shapes] * B, txt_seq_lens=[s_txt] * B, return_dict=False)
+        first = m(**kw)[0].clone()
+        reps = [m(**kw)[0].clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(first, r) for r in reps)
+        assert len(m._bstreams) == (2 if ns == 2 else 0)
+        outs[ns] = first
+        if ns == 1:
+            for b in range(B):
+                one = m(**dict(kw, hidden_states=kw["hidden_states"][b:b + 1], encoder_hidden_states=kw["encoder_hidden_states"][b:b + 1],
+                               encoder_hidden_states_mask=kw["encoder_hidden_states_mask"][b:b + 1], timestep=kw["timestep"][b:b + 1],
+                               img_shapes=[shapes], txt_seq_lens=[s_txt]))[0]
+                assert torch.equal(one[0], first[b])
+    assert torch.isfinite(outs[2].float()).all() and torch.equal(outs[1], outs[2])
+    assert not torch.equal(outs[2][0], outs[2][1])
