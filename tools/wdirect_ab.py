@@ -73,8 +73,14 @@ def main():
     o0 = ops.gemm(a, w, b).clone()
     lib.tune_set("gemm.wdirect", 2)
     o2 = ops.gemm(a, pack_w(w), b).clone()
+    lib.tune_set("gemm.wdirect", 3)
+    o3 = ops.gemm(a, w, b).clone()
+    lib.tune_set("gemm.wdirect", 4)
+    o4 = ops.gemm(a, pack_w(w), b).clone()
+    rep = all(torch.equal(ops.gemm(a, pack_w(w), b), o4) for _ in range(8))
     lib.tune_set("gemm.wdirect", 0)
-    print(json.dumps({"packed_bit_identical": bool(torch.equal(o0, o2))}), flush=True)
+    print(json.dumps({"packed_bit_identical": bool(torch.equal(o0, o2)), "landing_bit_identical": bool(torch.equal(o0, o3)),
+                      "landing_packed_bit_identical": bool(torch.equal(o0, o4)), "repeatable": bool(rep)}), flush=True)
     shapes = [("qkv_mlp_single", 4608, 21504, 3072, "bias"), ("proj_out_single", 4608, 3072, 15360, "gate_res"),
               ("ff_down_img", 4096, 3072, 12288, "gate_res"), ("ff_up_img", 4096, 12288, 3072, "gelu"),
               ("attn_out_img", 4096, 3072, 3072, "gate_res"), ("square_8192", 8192, 8192, 8192, "bias")]
@@ -94,11 +100,11 @@ def main():
         kw = dict(epilogue=epi)
         if epi == "gate_res":
             kw.update(gate=gate, residual=out)
-        r = {0: [], 1: [], 2: []}
+        r = {0: [], 1: [], 2: [], 3: [], 4: []}
         for _ in range(3):
-            for wd in (0, 1, 2):
+            for wd in (0, 1, 2, 3, 4):
                 lib.tune_set("gemm.wdirect", wd)
-                src = wsp if wd == 2 else ws
+                src = wsp if wd in (2, 4) else ws
 
                 def nw():
                     st["i"] = (st["i"] + 1) % len(src)
@@ -106,7 +112,7 @@ def main():
                 ms = timeit(lambda: ops.gemm(a, nw(), b, out=out, **kw))
                 r[wd].append(round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1))
         lib.tune_set("gemm.wdirect", 0)
-        print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "tflops": {"lds_staged": r[0], "weights_direct": r[1], "weights_direct_packed": r[2]}}), flush=True)
+        print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "tflops": {"lds_staged": r[0], "weights_direct": r[1], "weights_direct_packed": r[2], "landing_regs": r[3], "landing_regs_packed": r[4]}}), flush=True)
 
 
 if __name__ == "__main__":
