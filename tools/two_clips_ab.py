@@ -25,7 +25,37 @@ STEPS = int(os.environ.get("STEPS", "8"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 
 
+def qwen_batch():
+    """B = 2 forward of the QwenImage-Edit step (S_img 8192 + S_txt 256 per image): model.batch_streams 1 vs 2."""
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    model = QwenImageTransformer2DModel(device=DEV, dtype=torch.bfloat16).init_synthetic(seed=4321)
+    model.pack()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(1, 64, 64), (1, 64, 64)]
+    kw = dict(hidden_states=torch.randn(2, 8192, 64, generator=g, device=DEV).to(torch.bfloat16),
+              encoder_hidden_states=torch.randn(2, 256, 3584, generator=g, device=DEV).to(torch.bfloat16),
+              encoder_hidden_states_mask=None, timestep=torch.tensor([0.7, 0.7], device=DEV, dtype=torch.bfloat16),
+              img_shapes=[shapes, shapes], txt_seq_lens=[256, 256], return_dict=False)
+    res, outs = {1: [], 2: []}, {}
+    for _ in range(ROUNDS):
+        for ns in (1, 2):
+            model.batch_streams = ns
+            outs[ns] = model(**kw)[0].clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(STEPS):
+                model(**kw)
+            torch.cuda.synchronize()
+            res[ns].append(round(1e3 * (time.perf_counter() - t0) / (2 * STEPS), 3))
+    print(json.dumps({"workload": "qwenimage-edit-2509 forward, B = 2", "forwards": STEPS,
+                      "ms_per_image_forward": {f"batch_streams={k}": v for k, v in res.items()},
+                      "gain": round(min(res[1]) / min(res[2]) - 1.0, 4),
+                      "results_identical": bool(torch.equal(outs[1], outs[2]))}))
+
+
 def main():
+    if os.environ.get("WORKLOAD") == "qwen":
+        return qwen_batch()
     model = FluxTransformer2DModel(**FLUX_DEV, device=DEV, dtype=torch.bfloat16).init_synthetic(seed=1234)
     model.pack()
     img_ids = latent_image_ids(64, 64).to(DEV)
