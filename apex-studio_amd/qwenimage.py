@@ -216,12 +216,16 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             VT=torch.zeros(1, H, 128, skp, **bf), ATT=torch.empty(S, dim, **bf),
             FFH=torch.empty(S, 4 * dim, **bf), TXTN=torch.empty(s_txt, self.config.joint_attention_dim, **bf),
             MOD=torch.empty(1, self._mod_total, **f32), TEMB=torch.empty(1, dim, **f32))
-        self._ws = {k: v for k, v in self._ws.items() if k[:2] == key[:2]}  # one shape resident at a time
+        # a few workspaces stay resident (the images of a batch on two streams; the cond / uncond passes of true CFG with their own
+        # text lengths, engine_qwenimage.py): the oldest goes when a fifth shows up
+        while len(self._ws) >= 4:
+            self._ws.pop(next(iter(self._ws)))
         self._ws[key] = ws
         return ws
 
     def _rope_table(self, shapes, s_txt: int):
-        key = (tuple(tuple(int(v) for v in s) for s in shapes), s_txt)
+        # keyed on the stream too: a table is made and read on one stream only (no cross-stream ordering to get wrong)
+        key = (tuple(tuple(int(v) for v in s) for s in shapes), s_txt, torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0)
         t = self._rope.get(key)
         if t is None:
             vids, max_idx = [], 0
@@ -234,7 +238,9 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             tt = torch.arange(max_idx, max_idx + s_txt)
             ids = torch.cat([torch.stack([tt, tt, tt], dim=-1)] + vids, dim=0).float().to(self.device)
             t = ops.rope_table_axes(ids.contiguous(), self.config.axes_dims_rope, 10000.0)
-            self._rope = {key: t}
+            while len(self._rope) >= 4:
+                self._rope.pop(next(iter(self._rope)))
+            self._rope[key] = t
         return t
 
     @torch.no_grad()
@@ -346,7 +352,6 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             outs = [one(b) for b in range(B)]
         else:
             # the images of a batch side by side on HIP streams (see flux.py forward; same mechanism, bit-identical results)
-            self._rope_table(shapes_of(0), enc.shape[1])     # made on the calling stream, before the side streams fork
             outs = ops.run_on_streams(self._bstreams, ns, B, one, hs.device)
         out = torch.stack(outs, dim=0).to(hidden_states.dtype)
         if not return_dict:

@@ -169,3 +169,34 @@ def test_batch_of_images_on_streams_is_bit_identical_to_the_sequential_walk():
                 assert torch.equal(one[0], first[b])
     assert torch.isfinite(outs[2].float()).all() and torch.equal(outs[1], outs[2])
     assert not torch.equal(outs[2][0], outs[2][1])
+
+
+def test_true_cfg_passes_on_two_streams_are_bit_identical_to_back_to_back():
+    """True CFG = a conditional and an unconditional forward per step (reference engine/qwenimage/shared.py:346-477): the engine
+    runs the unconditional one on a side HIP stream (`cfg_streams`).  With different text lengths for the two prompts (own
+    workspaces and rotary tables per pass) the latents of a 3-step chain must equal the back-to-back walk bit for bit, from a
+    cold model (weights packed, tables and workspaces made inside the first step)."""
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    cfg, shapes, s_txt = CONFIGS["mid"]
+    n_img = sum(f * h * w for f, h, w in shapes)
+    n_tgt = shapes[0][0] * shapes[0][1] * shapes[0][2]
+    sd, outs = None, {}
+    for streams in (True, False):
+        m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+        sd = sd or {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 13).items()}
+        m.load_state_dict(sd, strict=True)
+        eng = QwenImageEditPlusEngine(m)
+        eng.cfg_streams = streams
+        lat = seeded((1, n_tgt, 64), 81).to(DEV).to(torch.bfloat16)
+        cond = seeded((1, n_img - n_tgt, 64), 82).to(DEV).to(torch.bfloat16)
+        pe = seeded((1, s_txt, cfg["joint_attention_dim"]), 83).to(DEV).to(torch.bfloat16)
+        ne = seeded((1, s_txt - 20, cfg["joint_attention_dim"]), 84).to(DEV).to(torch.bfloat16)
+        ts = eng.scheduler.set_timesteps(sigmas=[1.0, 0.66, 0.33], mu=0.7, device=DEV)
+        eng.scheduler.set_begin_index(0)
+        out = eng.base_denoise(lat, ts, pe, [shapes], image_latents=cond, negative_prompt_embeds=ne, true_cfg_scale=4.0,
+                               use_cfg_guidance=True)
+        torch.cuda.synchronize()
+        assert (eng._cfg_stream is not None) == streams
+        outs[streams] = out.clone()
+    assert torch.isfinite(outs[True].float()).all() and torch.equal(outs[True], outs[False])

@@ -53,9 +53,41 @@ def qwen_batch():
                       "results_identical": bool(torch.equal(outs[1], outs[2]))}))
 
 
+def qwen_cfg():
+    """QwenImage-Edit true-CFG steps (conditional + unconditional forward per step): engine.cfg_streams False vs True."""
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    model = QwenImageTransformer2DModel(device=DEV, dtype=torch.bfloat16).init_synthetic(seed=4321)
+    eng = QwenImageEditPlusEngine(model)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lat = torch.randn(1, 4096, 64, generator=g, device=DEV).to(torch.bfloat16)
+    cond = torch.randn(1, 4096, 64, generator=g, device=DEV).to(torch.bfloat16)
+    pe = torch.randn(1, 256, 3584, generator=g, device=DEV).to(torch.bfloat16)
+    ne = torch.randn(1, 200, 3584, generator=g, device=DEV).to(torch.bfloat16)
+    shapes = [[(1, 64, 64), (1, 64, 64)]]
+    res, outs = {False: [], True: []}, {}
+    for _ in range(ROUNDS + 1):
+        for st in (False, True):
+            eng.cfg_streams = st
+            ts = eng.scheduler.set_timesteps(sigmas=torch.linspace(1.0, 1.0 / STEPS, STEPS).tolist(), mu=0.8, device=DEV)
+            eng.scheduler.set_begin_index(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs[st] = eng.base_denoise(lat, ts, pe, shapes, image_latents=cond, negative_prompt_embeds=ne, true_cfg_scale=4.0,
+                                        use_cfg_guidance=True)
+            torch.cuda.synchronize()
+            res[st].append(round(1e3 * (time.perf_counter() - t0) / STEPS, 3))
+    print(json.dumps({"workload": "qwenimage-edit-2509 true-CFG step (cond + uncond forward, S_img 8192, text 256 / 200)",
+                      "steps": STEPS, "ms_per_step": {f"cfg_streams={k}": v[1:] for k, v in res.items()},
+                      "gain": round(min(res[False][1:]) / min(res[True][1:]) - 1.0, 4),
+                      "results_identical": bool(torch.equal(outs[False], outs[True]))}))
+
+
 def main():
     if os.environ.get("WORKLOAD") == "qwen":
         return qwen_batch()
+    if os.environ.get("WORKLOAD") == "qwen_cfg":
+        return qwen_cfg()
     model = FluxTransformer2DModel(**FLUX_DEV, device=DEV, dtype=torch.bfloat16).init_synthetic(seed=1234)
     model.pack()
     img_ids = latent_image_ids(64, 64).to(DEV)
