@@ -3,7 +3,8 @@
 model, per-stream workspaces).  The question is whether the tile-quantisation gaps of the B=1 step (216/648/864 GEMM
 tiles and 432 attention workgroups on 256 CUs) can be filled by a second clip, given that the chip is power-bound.
 Interleaved rounds in one process; prints one JSON line.  Not the headline metric (BASELINE's config is B=1, one
-clip per GPU): a render-queue option."""
+clip per GPU): a render-queue option.  `MODE=batch`: one B = 2 Flux forward with `model.batch_streams` 1 vs 2; `WORKLOAD=qwen`: the
+same for Qwen-Image; `WORKLOAD=qwen_cfg`: Qwen-Image true-CFG steps with `engine.cfg_streams` off / on."""
 import json
 import os
 import sys
