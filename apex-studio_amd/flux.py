@@ -342,12 +342,16 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         while the SAME tensor objects come back unmodified (the cache holds references to them, so their storage cannot be
         recycled under another tensor, and an in-place edit bumps `_version`)."""
         rk = self._rope_cache
-        if (rk is not None and rk[0] is txt_ids and rk[1] is img_ids and rk[2] == (txt_ids._version, img_ids._version)
+        ver = (ops.tensor_version(txt_ids), ops.tensor_version(img_ids))
+        # inference tensors (ids built inside the host's `@torch.inference_mode()` run, R/src/engine/registry.py:196) carry no
+        # version counter: an in-place edit would go unseen, so the table is rebuilt for them (one ~20 us launch per step)
+        cacheable = ver[0] is not None and ver[1] is not None
+        if (cacheable and rk is not None and rk[0] is txt_ids and rk[1] is img_ids and rk[2] == ver
                 and rk[4] == self.storage_dtype):
             return rk[3]
         ids = torch.cat((txt_ids, img_ids), dim=0).float()
         rope = ops.rope_table_axes(ids, self.config.axes_dims_rope, 10000.0)
-        self._rope_cache = (txt_ids, img_ids, (txt_ids._version, img_ids._version), rope, self.storage_dtype)
+        self._rope_cache = (txt_ids, img_ids, ver, rope, self.storage_dtype) if cacheable else None
         return rope
 
     @torch.no_grad()

@@ -71,11 +71,21 @@ def clear_verification_caches() -> None:
     _w3_bytes = 0
 
 
+def tensor_version(t: torch.Tensor):
+    """`t._version`, or None for an inference tensor (created under `torch.inference_mode()`, as everything inside the
+    reference's `UniversalEngine.run` is — `R/src/engine/registry.py:196`): those do not track a version counter and
+    reading it raises, so callers must not cache on them across calls."""
+    return None if t.is_inference() else t._version
+
+
 def _w3(w: torch.Tensor) -> torch.Tensor:
     """[N, K] bf16 weight -> [N, 3K] = [w | w | w] (layout only), the partner of split3(); cached per weight version.
     An entry keeps a reference to its source view, so the address in the key cannot be recycled while the entry lives."""
     global _w3_bytes
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.stride(0))
+    ver = tensor_version(w)
+    if ver is None:                 # inference tensor: no version counter to key on — rebuild, never cache
+        return w.repeat(1, 3).contiguous()
+    key = (w.data_ptr(), ver, tuple(w.shape), w.stride(0))
     hit = _w3_cache.get(key)
     if hit is None:
         if _w3_bytes > _W3_CAP:
@@ -757,8 +767,9 @@ _w3c_cache: dict = {}
 def _conv_w3(w_packed: torch.Tensor, ksize, cin: int) -> torch.Tensor:
     """Packed conv weight [Cout4, Kpad] (k = tap * cin + ci) -> the packing of the same weight with every tap's channel run
     repeated three times (k = tap * 3 cin + j cin + ci): the partner of the [hi | mid | lo] channel split."""
-    key = (w_packed.data_ptr(), w_packed._version, tuple(w_packed.shape), tuple(ksize), cin)
-    hit = _w3c_cache.get(key)      # (source, repeated): the source reference pins the address in the key
+    ver = tensor_version(w_packed)
+    key = (w_packed.data_ptr(), ver, tuple(w_packed.shape), tuple(ksize), cin)
+    hit = None if ver is None else _w3c_cache.get(key)   # (source, repeated): the source reference pins the address in the key
     t = None if hit is None else hit[1]
     if t is None:
         kT, kH, kW = (int(v) for v in ksize)
@@ -773,7 +784,8 @@ def _conv_w3(w_packed: torch.Tensor, ksize, cin: int) -> torch.Tensor:
         t[:, :k3] = w_packed[:, :taps * cin].reshape(cout4, taps, 1, cin).expand(cout4, taps, 3, cin).reshape(cout4, k3)
         if len(_w3c_cache) > 512:
             _w3c_cache.clear()
-        _w3c_cache[key] = (w_packed, t)
+        if ver is not None:
+            _w3c_cache[key] = (w_packed, t)
     return t
 
 

@@ -203,6 +203,33 @@ def test_rotary_table_cache_follows_the_position_ids():
     assert torch.equal(c, m(return_dict=False, **g2)[0]) and m._rope_cache[3] is not table2
 
 
+def test_forward_under_inference_mode_matches_no_grad():
+    """The host drives the model inside `@torch.inference_mode()` (R/src/engine/registry.py:196): ids built there are inference
+    tensors, which carry no `_version` — the rotary-table cache must not read it.  Same bits as under no_grad,
+    the table is rebuilt per call for such ids, and an in-place edit of them is honoured."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["tiny"]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 7).items()}, strict=True)
+    inp = _inputs(cfg, hw, s_txt)
+
+    def dev(d):
+        return {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k in
+                    ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV)) for k, v in d.items()}
+    ref = m(return_dict=False, **dev(inp))[0].clone()
+    with torch.inference_mode():
+        g = dev(inp)
+        g["img_ids"] = g["img_ids"] + 0.0                              # created inside: an inference tensor
+        assert g["img_ids"].is_inference()
+        a = m(return_dict=False, **g)[0].clone()
+        b = m(return_dict=False, **g)[0].clone()
+        assert m._rope_cache is None                                    # nothing cached on version-less tensors
+        g["img_ids"].add_(5.0)
+        c = m(return_dict=False, **g)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref) and not torch.equal(c, ref)
+
+
 def test_batch_of_images_on_streams_is_bit_identical_to_the_sequential_walk():
     """`num_images` > 1 (reference engine/flux/t2i.py:88 hands the transformer a batch): the images of a batch run side by side
     on `batch_streams` HIP streams, each with its own workspaces.  Same kernels on the same data: the result must equal the

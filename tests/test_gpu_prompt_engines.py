@@ -69,6 +69,9 @@ def test_flux_ids_to_frames():
     assert emb.shape == (1, 40, 128) and pooled.shape == (1, 128)
     assert np.array_equal(frames, eng.run(emb, pooled, **kw))
     assert not np.array_equal(frames, eng.run(prompt_ids=idsc, prompt_2_ids=(ids5 + 1) % 120, **kw)), "the prompt must matter"
+    # as the host calls it: UniversalEngine.run is @torch.inference_mode() (R/src/engine/registry.py:196)
+    with torch.inference_mode():
+        assert np.array_equal(frames, eng.run(prompt_ids=idsc, prompt_2_ids=ids5, **kw))
 
 
 def test_wan_ids_to_frames():
@@ -100,6 +103,8 @@ def test_wan_ids_to_frames():
     ne = eng.encode_prompt(prompt_ids=(nids, nmask), text_encoder_kwargs=dict(max_sequence_length=24))
     assert pe.shape == (1, 24, 128) and float(pe[0, 17:].abs().sum()) == 0.0 and float(pe[0, :17].abs().sum()) > 0.0
     assert np.array_equal(frames, eng.run(prompt_embeds=pe, negative_prompt_embeds=ne, **kw))
+    with torch.inference_mode():                       # as the host's UniversalEngine.run calls it
+        assert np.array_equal(frames, eng.run(prompt_ids=(ids, mask), negative_prompt_ids=(nids, nmask), **kw))
 
 
 def test_qwen_edit_ids_and_pixels_to_frames(golden_dir):
@@ -128,5 +133,7 @@ def test_qwen_edit_ids_and_pixels_to_frames(golden_dir):
     n_valid = int(im["mask"].sum())
     assert emb.shape == (1, n_valid - 4, cfg["joint_attention_dim"]) and int(msk.sum()) == n_valid - 4
     assert np.array_equal(frames, eng.run(prompt_embeds=emb, **kw))
+    with torch.inference_mode():                       # as the host's UniversalEngine.run calls it
+        assert np.array_equal(frames, eng.run(prompt_inputs=inputs, **kw))
     other = dict(inputs, pixel_values=inputs["pixel_values"] * 0.5)
     assert not np.array_equal(frames, eng.run(prompt_inputs=other, **kw)), "the condition image must reach the prompt embedding"
