@@ -18,6 +18,8 @@ import os as _os
 # denoise step is ~400 dependent launches; measured on the Flux step 69.23 -> 68.83 ms (-0.6 %, interleaved, same box).  Read by
 # the runtime when it initialises (the first HIP call of the process), so this takes effect when the package is imported before
 # any GPU work; an explicit setting in the environment wins.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# The ONE process-environment side effect of importing this package (INTEGRATION.md "Knobs"); APEX_MI355_KEEP_ENV=1 leaves the environment alone.
+if _os.environ.get("APEX_MI355_KEEP_ENV", "0") in ("", "0"):
+    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from . import lib  # noqa: F401

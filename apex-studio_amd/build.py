@@ -27,6 +27,8 @@ def _hipcc() -> str:
 
 
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("APEXMI_DEBUG", "0") not in ("", "0"):
+    FLAGS.append("-DAPEXMI_DEBUG")     # experiment knobs of tools/conv_prof.py / conv_ablate.py (apexmi_tune_set "conv.dbg", "conv.prof_*")
 
 
 def _digest(paths: list[str], extra: str = "") -> str:

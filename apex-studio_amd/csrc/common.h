@@ -227,6 +227,8 @@ static inline void apexmi_attr_done(uint64_t& mask) {
     } while (0)
 void apexmi_set_error(const char* fmt, ...);
 int apexmi_check_launch(const char* what);
+// device pointer of the live clock probe's two counters on the current device, or nullptr while the probe is off (runtime.hip)
+unsigned long long* apexmi_clk_ptr();
 
 struct ApexmiProfScope {
     int cls;

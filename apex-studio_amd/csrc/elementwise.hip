@@ -114,76 +114,86 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
 // Wave-per-row variant for C = 64 * 8 * NCH (3072, 3584, 5120): a lane owns NCH 16-byte chunks, the two
 // statistics are wave reductions (no LDS, no barrier), four rows per workgroup.  Same arithmetic order per lane
 // as the block kernel's per-thread part; the cross-lane sums differ in shape, both are f32.
-template <typename T, int NCH>
+template <typename T, int NCH, int NR>
 __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(
     const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int M, int C,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps, int rms, int split,
     const float* __restrict__ scale2, const float* __restrict__ shift2) {
+    // NR rows per wave (`ln.wave` = NR): all NR rows' loads are issued before the first reduction, so a wave has NR x NCH
+    // 16-byte loads in flight and the second row's statistics / stores overlap the first row's store drain.  Per row the
+    // arithmetic is the same for every NR (bit-identical outputs).
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    if (row < split) {
-        scale = scale2;
-        shift = shift2;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
+    if (row0 >= M) return;
+    float v[NR][NCH][8];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int row = min(row0 + r, M - 1);
+        const T* xp = x + (int64_t)row * ldx;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) load8<T>(xp + (it * 64 + lane) * 8, v[r][it]);
     }
-    const T* xp = x + (int64_t)row * ldx;
-    float v[NCH][8];
-    float sum = 0.0f;
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        load8<T>(xp + (it * 64 + lane) * 8, v[it]);
+    for (int r = 0; r < NR; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        const float* sc = row < split ? scale2 : scale;
+        const float* sh = row < split ? shift2 : shift;
+        float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += v[it][j];
-    }
-    const float mean = rms ? 0.0f : wave_sum(sum) / (float)C;
-    float sq = 0.0f;
+        for (int it = 0; it < NCH; ++it)
 #pragma unroll
-    for (int it = 0; it < NCH; ++it)
+            for (int j = 0; j < 8; ++j) sum += v[r][it][j];
+        const float mean = rms ? 0.0f : wave_sum(sum) / (float)C;
+        float sq = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = v[it][j] - mean;
-            sq += d * d;
-        }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    T* op = out + (int64_t)row * ldo;
+        for (int it = 0; it < NCH; ++it)
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int c = it * 64 + lane;
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (v[it][j] - mean) * rstd;
-        if (gamma != nullptr) {
-            float g[8];
-            unpack8(*(const u32x4*)(gamma + c * 8), g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] *= g[j];
-        }
-        if (beta != nullptr) {
-            float bt[8];
-            unpack8(*(const u32x4*)(beta + c * 8), bt);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] += bt[j];
-        }
-        if (scale != nullptr) {
-            const f32x4 s0 = *(const f32x4*)(scale + c * 8);
-            const f32x4 s1 = *(const f32x4*)(scale + c * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] *= 1.0f + s0[j];
-                y[j + 4] *= 1.0f + s1[j];
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[r][it][j] - mean;
+                sq += d * d;
             }
-        }
-        if (shift != nullptr) {
-            const f32x4 s0 = *(const f32x4*)(shift + c * 8);
-            const f32x4 s1 = *(const f32x4*)(shift + c * 8 + 4);
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        T* op = out + (int64_t)row * ldo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] += s0[j];
-                y[j + 4] += s1[j];
+        for (int it = 0; it < NCH; ++it) {
+            const int c = it * 64 + lane;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (v[r][it][j] - mean) * rstd;
+            if (gamma != nullptr) {
+                float g[8];
+                unpack8(*(const u32x4*)(gamma + c * 8), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] *= g[j];
             }
+            if (beta != nullptr) {
+                float bt[8];
+                unpack8(*(const u32x4*)(beta + c * 8), bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] += bt[j];
+            }
+            if (sc != nullptr) {
+                const f32x4 s0 = *(const f32x4*)(sc + c * 8);
+                const f32x4 s1 = *(const f32x4*)(sc + c * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] *= 1.0f + s0[j];
+                    y[j + 4] *= 1.0f + s1[j];
+                }
+            }
+            if (sh != nullptr) {
+                const f32x4 s0 = *(const f32x4*)(sh + c * 8);
+                const f32x4 s1 = *(const f32x4*)(sh + c * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] += s0[j];
+                    y[j + 4] += s1[j];
+                }
+            }
+            store8<T>(op + c * 8, y);
         }
-        store8<T>(op + c * 8, y);
     }
 }
 
@@ -594,6 +604,72 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
     }
 }
 
+// The same product for MB rows of x in ONE pass over W (the modulation table of a whole clip: every step's conditioning
+// vector against the 6.4 GB of stacked AdaLN projections, read once instead of once per step).  Per (n, m) the arithmetic is
+// gemv_kernel's, operation for operation: a lane owns chunks lane, lane + 64, ... in ascending order, the same fmaf chain
+// inside a chunk, the same butterfly — so row m of this kernel is BIT-IDENTICAL to a single-row launch on x[m].
+// x rows sit in LDS split into the chunks' low / high halves (xs0 / xs1: consecutive lanes read consecutive 16 bytes).
+template <int MB>
+__global__ __launch_bounds__(512) void gemv_rows_kernel(const bf16_t* __restrict__ W, int64_t ldw,
+                                                        const bf16_t* __restrict__ bias,
+                                                        const float* __restrict__ x, int64_t ldx,
+                                                        float* __restrict__ y, int64_t ldy, int M, int N, int K,
+                                                        int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                       // [MB][2][K / 2]
+    const int m0 = blockIdx.y * MB;
+    const int mb = min(MB, M - m0);
+    const int half = K >> 1;
+    for (int i = threadIdx.x; i < MB * K; i += 512) {
+        const int r = i / K, k = i - r * K;
+        float v = 0.0f;
+        if (r < mb) {
+            v = x[(int64_t)(m0 + r) * ldx + k];
+            if (flags & APEXMI_GEMV_PRE_SILU) v = silu_f(v);
+        }
+        xs[r * K + ((k >> 2) & 1) * half + (k >> 3) * 4 + (k & 3)] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int nw = gridDim.x * 8;
+    const int nchunk = K >> 3;
+    for (int n = gw; n < N; n += nw) {
+        const bf16_t* wp = W + (int64_t)n * ldw;
+        float acc[MB];
+#pragma unroll
+        for (int r = 0; r < MB; ++r) acc[r] = 0.0f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float w[8];
+            unpack8(*(const u32x4*)(wp + c * 8), w);
+#pragma unroll
+            for (int r = 0; r < MB; ++r) {
+                const f32x4 x0 = *(const f32x4*)(xs + r * K + c * 4);
+                const f32x4 x1 = *(const f32x4*)(xs + r * K + half + c * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[r] = fmaf(w[j], x0[j], acc[r]);
+                    acc[r] = fmaf(w[j + 4], x1[j], acc[r]);
+                }
+            }
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int r = 0; r < MB; ++r) {
+            const float t = wave_sum(acc[r]);
+            if (lane == r) mine = t;
+        }
+        if (lane < mb) {
+            if (bias != nullptr) mine += bf16_to_f32(bias[n]);
+            if (flags & APEXMI_GEMV_POST_SILU) mine = silu_f(mine);
+            if (flags & APEXMI_GEMV_POST_GELU) mine = gelu_tanh_f(mine);
+            float* yp = y + (int64_t)(m0 + lane) * ldy + n;
+            if (flags & APEXMI_GEMV_ACCUM) mine += *yp;
+            *yp = mine;
+        }
+    }
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out,
                                           int M, int dim, float scale, int flip, float shift,
                                           const float* __restrict__ freqs) {
@@ -880,10 +956,17 @@ static int ln_modulate2_impl(const void* x, int64_t ldx, void* out, int64_t ldo,
     APEXMI_REQUIRE((!scale || ((uintptr_t)scale % 16) == 0) && (!shift || ((uintptr_t)shift % 16) == 0),
                    "ln_modulate: scale/shift must be 16-byte aligned");
     ApexmiProfScope prof(3, stream, 0.0, 2.0 * sizeof(T) * (double)M * C);
-#define LNW_LAUNCH(N)                                                                                          \
-    hipLaunchKernelGGL((ln_modulate_wave_kernel<T, N>), dim3((M + 3) / 4), dim3(256), 0, stream, (const T*)x, ldx, \
+#define LNW_LAUNCH_R(N, R)                                                                                          \
+    hipLaunchKernelGGL((ln_modulate_wave_kernel<T, N, R>), dim3((M + 4 * R - 1) / (4 * R)), dim3(256), 0, stream, (const T*)x, ldx, \
                        (T*)out, ldo, M, C, scale, shift, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms, \
                        split, scale2, shift2)
+#define LNW_LAUNCH(N)                         \
+    do {                                      \
+        if (g_ln_wave >= 2 && sizeof(T) == 2) \
+            LNW_LAUNCH_R(N, 2);               \
+        else                                  \
+            LNW_LAUNCH_R(N, 1);               \
+    } while (0)
     if (g_ln_wave && C % 512 == 0) {
         bool done = true;
         switch (C / 512) {
@@ -894,6 +977,7 @@ static int ln_modulate2_impl(const void* x, int64_t ldx, void* out, int64_t ldo,
         }
         if (done) return apexmi_check_launch("ln_modulate");
     }
+#undef LNW_LAUNCH_R
 #undef LNW_LAUNCH
     const int nit = (C / 8 + 255) / 256;
 #define LN_LAUNCH(N)                                                                                  \
@@ -1074,14 +1158,34 @@ extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const f
                            apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(W && x && y, "gemv: null operand");
-    APEXMI_REQUIRE(M > 0 && M <= 8 && N > 0 && K > 0, "gemv: bad shape M=%d N=%d K=%d", M, N, K);
+    APEXMI_REQUIRE(M > 0 && M <= 4096 && N > 0 && K > 0, "gemv: bad shape M=%d N=%d K=%d", M, N, K);
     APEXMI_REQUIRE(K % 8 == 0 && K <= 16384, "gemv: K=%d must be a multiple of 8 and <= 16384", K);
     APEXMI_REQUIRE(ldw % 8 == 0 && ((uintptr_t)W % 16) == 0, "gemv: W rows must be 16-byte aligned");
-    int grid = (N + 3) / 4;
-    if (grid > 4096) grid = 4096;
     ApexmiProfScope prof(2, stream, 2.0 * M * (double)N * K, 2.0 * (double)N * K);
-    hipLaunchKernelGGL(gemv_kernel, dim3(grid, M), dim3(256), (size_t)K * 4, stream, (const bf16_t*)W,
-                       ldw, (const bf16_t*)bias, x, ldx, y, ldy, N, K, flags);
+    if (M == 1) {
+        int grid = (N + 3) / 4;
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(gemv_kernel, dim3(grid, M), dim3(256), (size_t)K * 4, stream, (const bf16_t*)W,
+                           ldw, (const bf16_t*)bias, x, ldx, y, ldy, N, K, flags);
+        return apexmi_check_launch("gemv");
+    }
+    // several rows of x: one pass over W per group of MB rows (MB x K floats of LDS <= 128 KiB), each row bit-identical to the
+    // single-row kernel
+    int grid = (N + 7) / 8;
+    if (grid > 2048) grid = 2048;
+#define GEMV_ROWS(MB)                                                                                                   \
+    do {                                                                                                                \
+        static uint64_t attr_##MB = 0;                                                                                  \
+        APEXMI_SET_ATTR_ONCE(attr_##MB, (void)hipFuncSetAttribute((const void*)gemv_rows_kernel<MB>,                    \
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+        hipLaunchKernelGGL((gemv_rows_kernel<MB>), dim3(grid, (M + MB - 1) / MB), dim3(512), (size_t)MB * K * 4, stream, \
+                           (const bf16_t*)W, ldw, (const bf16_t*)bias, x, ldx, y, ldy, M, N, K, flags);                 \
+    } while (0)
+    const int cap = (128 * 1024) / (K * 4);
+    if (cap >= 8 && M > 4) GEMV_ROWS(8);
+    else if (cap >= 4 && M > 2) GEMV_ROWS(4);
+    else GEMV_ROWS(2);
+#undef GEMV_ROWS
     return apexmi_check_launch("gemv");
 }
 

@@ -77,6 +77,10 @@ struct GemmGroup {
     int batch;
     int64_t bsA, bsW, bsC_bytes;
     QkvShared qs;
+    // live clock probe (apexmi_clk_enable): when non-null, every workgroup adds the shader cycles (s_memtime) and the 100 MHz
+    // reference ticks (s_memrealtime) its K-loop took to clk[0] / clk[1]: sum(cycles) / sum(ticks) x 100 MHz = the effective
+    // shader clock WHILE this kernel runs inside the real step (the number the "power-bound" argument of DESIGN.md rests on)
+    unsigned long long* clk;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -545,6 +549,11 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
             for (int j = 0; j < 8; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const int nkt = G.K / BK;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (G.clk != nullptr) {          // kernel-uniform
+        clk_c0 = __builtin_readcyclecounter();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * CFG::STAGE + wave * 1024;
@@ -958,6 +967,14 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #undef PP_BAR
     }
 
+    if (G.clk != nullptr) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(G.clk, c1 - clk_c0);
+            atomicAdd(G.clk + 1, r1 - clk_r0);
+        }
+    }
+
     // ---- epilogue ----
     if constexpr (CFG::SCHED == 5) {
         if constexpr (EPI == APEXMI_EPI_BIAS) {
@@ -1038,6 +1055,7 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     }
     G.total = t;
     G.group_m = g_group_m;
+    G.clk = apexmi_clk_ptr();
     hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t, G.batch), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }

@@ -114,6 +114,54 @@ extern "C" int apexmi_prof_read(double ms[APEXMI_NCLASS], int64_t launches[APEXM
     return 0;
 }
 
+// ---- live clock probe: shader cycles and 100 MHz reference ticks summed over the GEMM workgroups' K-loops -------------------
+namespace {
+bool g_clk_on = false;
+unsigned long long* g_clk_dev[64] = {};
+}  // namespace
+unsigned long long* apexmi_clk_ptr() {
+    if (!g_clk_on) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < 64 ? g_clk_dev[dev] : nullptr;
+}
+extern "C" int apexmi_clk_enable(int on) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) {
+        apexmi_set_error("clk_enable: device ordinal %d out of range", dev);
+        return 1;
+    }
+    if (on && g_clk_dev[dev] == nullptr) {
+        hipError_t e = hipMalloc((void**)&g_clk_dev[dev], 2 * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            apexmi_set_error("clk_enable: %s", hipGetErrorString(e));
+            return 1;
+        }
+    }
+    if (on) (void)hipMemset(g_clk_dev[dev], 0, 2 * sizeof(unsigned long long));
+    g_clk_on = on != 0;
+    return 0;
+}
+extern "C" int apexmi_clk_read(uint64_t* cycles, uint64_t* ref_ticks) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!cycles || !ref_ticks || dev < 0 || dev >= 64 || g_clk_dev[dev] == nullptr) {
+        apexmi_set_error("clk_read: the probe was never enabled on this device");
+        return 1;
+    }
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h, g_clk_dev[dev], sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        apexmi_set_error("clk_read: %s", hipGetErrorString(e));
+        return 1;
+    }
+    *cycles = h[0];
+    *ref_ticks = h[1];
+    return 0;
+}
+
 // ---- tuning switches (A/B levers; defaults are the shipped configuration, include/apexmi.h lists the keys) ----
 void apexmi_set_attn_waves(int v);
 void apexmi_set_attn_mfma(int v);
@@ -143,14 +191,21 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
     } else if (!strcmp(key, "conv.slab")) {
         apexmi_set_conv_slab(value);
         return 0;
+#ifdef APEXMI_DEBUG   // experiment knobs of tools/conv_prof.py / conv_ablate.py: `conv.dbg` skips DMA (WRONG results) and
+                      // `conv.prof_*` makes the kernels write cycle stamps through a caller-supplied pointer — never in a release build
     } else if (!strcmp(key, "conv.prof_lo") || !strcmp(key, "conv.prof_hi")) {
         apexmi_set_conv_prof(key[10] == 'h', value);
         return 0;
-    } else if (!strcmp(key, "conv.torder")) {
-        apexmi_set_conv_torder(value);
-        return 0;
     } else if (!strcmp(key, "conv.dbg")) {
         apexmi_set_conv_dbg(value);
+        return 0;
+#else
+    } else if (!strcmp(key, "conv.prof_lo") || !strcmp(key, "conv.prof_hi") || !strcmp(key, "conv.dbg")) {
+        apexmi_set_error("tune_set: '%s' is a debug knob; rebuild with APEXMI_DEBUG=1 (python -m apex_studio_amd.build)", key);
+        return 1;
+#endif
+    } else if (!strcmp(key, "conv.torder")) {
+        apexmi_set_conv_torder(value);
         return 0;
     } else if (!strcmp(key, "conv.pp")) {
         apexmi_set_conv_pp(value);

@@ -110,20 +110,46 @@ class FluxT2IEngine(EngineLoraMixin):
                      preview_hw=None):
         _emit(denoise_progress_callback, 0.0, "Starting denoise")
         n = len(timesteps)
+        # The sampler's timesteps are known here: every step's AdaLN modulation vectors in one pass over the stacked projection
+        # weights instead of one 6.4 GB GEMV per step (`begin_schedule`, bit-identical rows); a transformer without the hook (the
+        # reference's own class behind this engine) just runs as before.
+        scheduled = hasattr(self.transformer, "begin_schedule") and n > 0
+        if scheduled:
+            B = latents.shape[0]
+            self.transformer.begin_schedule(
+                torch.stack([t.expand(B).to(latents.dtype) / 1000 for t in timesteps]), guidance,
+                [pooled_prompt_embeds] + ([negative_pooled_prompt_embeds] if use_cfg_guidance else []))
+        try:
+            latents = self._denoise_loop(latents, timesteps, guidance, prompt_embeds, pooled_prompt_embeds, text_ids, latent_ids,
+                                         negative_prompt_embeds, negative_pooled_prompt_embeds, negative_text_ids, true_cfg_scale,
+                                         use_cfg_guidance, render_on_step, render_on_step_callback, render_on_step_interval,
+                                         denoise_progress_callback, preview_hw, scheduled)
+        finally:
+            if scheduled:
+                self.transformer.end_schedule()
+        _emit(denoise_progress_callback, 1.0, "Denoise finished")
+        return latents
+
+    def _denoise_loop(self, latents, timesteps, guidance, prompt_embeds, pooled_prompt_embeds, text_ids, latent_ids,
+                      negative_prompt_embeds, negative_pooled_prompt_embeds, negative_text_ids, true_cfg_scale, use_cfg_guidance,
+                      render_on_step, render_on_step_callback, render_on_step_interval, denoise_progress_callback, preview_hw,
+                      scheduled):
+        n = len(timesteps)
         for i, t in enumerate(timesteps):
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            jkw = {"joint_attention_kwargs": {"modulation_step": i}} if scheduled else {}
             with self.transformer.cache_context("cond"):
                 noise_pred = self.transformer(
                     hidden_states=latents, timestep=timestep / 1000, guidance=guidance,
                     pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds,
-                    txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
+                    txt_ids=text_ids, img_ids=latent_ids, return_dict=False, **jkw)[0]
             if use_cfg_guidance:
                 with self.transformer.cache_context("uncond"):
                     neg = self.transformer(
                         hidden_states=latents, timestep=timestep / 1000, guidance=guidance,
                         pooled_projections=negative_pooled_prompt_embeds,
                         encoder_hidden_states=negative_prompt_embeds, txt_ids=negative_text_ids,
-                        img_ids=latent_ids, return_dict=False)[0]
+                        img_ids=latent_ids, return_dict=False, **jkw)[0]
                 noise_pred = neg + true_cfg_scale * (noise_pred - neg)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if (render_on_step and render_on_step_callback and self.decode_fn is not None
@@ -135,7 +161,6 @@ class FluxT2IEngine(EngineLoraMixin):
                 except Exception:
                     pass
             _emit(denoise_progress_callback, float(i + 1) / n, f"Denoise {i + 1}/{n}")
-        _emit(denoise_progress_callback, 1.0, "Denoise finished")
         return latents
 
     @torch.no_grad()

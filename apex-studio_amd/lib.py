@@ -109,6 +109,8 @@ SIGNATURES = {
     "apexmi_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "apexmi_prof_reset": (C.c_int, []),
+    "apexmi_clk_enable": (C.c_int, [C.c_int]),
+    "apexmi_clk_read": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 # f32-storage verification mode (include/apexmi.h, last section): same argument lists as the bf16 entry points
@@ -174,6 +176,17 @@ def tune_set(key: str, value: int) -> None:
 
 def prof_enable(on: bool) -> None:
     check(load().apexmi_prof_enable(1 if on else 0))
+
+
+def clk_enable(on: bool) -> None:
+    check(load().apexmi_clk_enable(1 if on else 0), "clk_enable")
+
+
+def clk_read() -> dict:
+    """Effective shader clock over the GEMM K-loops since `clk_enable(True)`: summed `s_memtime` cycles / summed 100 MHz ticks."""
+    c, r = C.c_uint64(0), C.c_uint64(0)
+    check(load().apexmi_clk_read(C.byref(c), C.byref(r)), "clk_read")
+    return {"cycles": int(c.value), "ref_ticks": int(r.value), "ghz": (0.1 * c.value / r.value) if r.value else None}
 
 
 def prof_reset() -> None:

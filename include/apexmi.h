@@ -541,6 +541,14 @@ int apexmi_prof_read(double ms[APEXMI_NCLASS], int64_t launches[APEXMI_NCLASS],
                      double flops[APEXMI_NCLASS], double bytes[APEXMI_NCLASS]);
 int apexmi_prof_reset(void);
 
+/* Live clock probe (bench.py's `roofline.clock_ghz`): while enabled, every GEMM workgroup adds the shader cycles
+ * (`s_memtime`) and the 100 MHz reference ticks (`s_memrealtime`) its K-loop took to two device counters.
+ * cycles / ref_ticks x 100 MHz = the effective shader clock while the dominant kernel runs inside the real step —
+ * what the DVFS ("power-bound") reading of the roofline fraction rests on.  enable(1) zeroes the counters;
+ * read() synchronises the device.  Nothing in the reference corresponds to it (measurement only). */
+int apexmi_clk_enable(int on);
+int apexmi_clk_read(uint64_t* cycles, uint64_t* ref_ticks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,45 @@ def test_rotary_table_cache_follows_the_position_ids():
     assert torch.equal(c, m(return_dict=False, **g2)[0]) and m._rope_cache[3] is not table2
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors(B):
+    """`begin_schedule`: the AdaLN vectors of every step of a clip from ONE pass over the stacked projection
+    weights.  Each table row must equal the vector block the per-step GEMVs write, and a forward that reads the table must
+    equal the forward that computes its own — bit for bit; a call with another pooled tensor, without the step index or after
+    `end_schedule()` silently takes the per-step path."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["mid"]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 7).items()}, strict=True)
+    n = 5
+    ts = torch.linspace(1.0, 0.2, n, device=DEV).to(torch.bfloat16)
+    g = dict(hidden_states=seeded((B, hw[0] * hw[1], cfg["in_channels"]), 41).to(DEV).to(torch.bfloat16),
+             encoder_hidden_states=seeded((B, s_txt, cfg["joint_attention_dim"]), 42).to(DEV).to(torch.bfloat16),
+             pooled_projections=seeded((B, cfg["pooled_projection_dim"]), 43).to(DEV).to(torch.bfloat16),
+             guidance=torch.tensor([4.0, 2.5][:B], device=DEV),
+             img_ids=OF.latent_image_ids(*hw).to(DEV), txt_ids=torch.zeros(s_txt, 3, device=DEV))
+    plain = [m(return_dict=False, timestep=ts[i].expand(B), **g)[0].clone() for i in range(n)]
+    mods = []
+    for i in range(n):                                   # the per-step vector blocks, image 0
+        m(return_dict=False, timestep=ts[i].expand(1), **{k: (v[:1] if k not in ("img_ids", "txt_ids") else v) for k, v in g.items()})
+        torch.cuda.synchronize()
+        mods.append(m._ws[(s_txt, hw[0] * hw[1], torch.cuda.current_stream().cuda_stream)].MOD.clone())
+    m.begin_schedule(ts, g["guidance"], g["pooled_projections"])
+    (sc,) = m._sched.values()
+    assert sc.table.shape == (n * B, m._mod_total)
+    for i in range(n):
+        assert torch.equal(sc.table[i * B:i * B + 1], mods[i]), i
+        out = m(return_dict=False, timestep=ts[i].expand(B), joint_attention_kwargs={"modulation_step": i}, **g)[0]
+        assert torch.equal(out, plain[i]), i
+    # not part of the clip: another pooled tensor / no index / index out of range -> per-step path, same bits
+    other = dict(g, pooled_projections=g["pooled_projections"].clone())
+    assert torch.equal(m(return_dict=False, timestep=ts[1].expand(B), joint_attention_kwargs={"modulation_step": 3}, **other)[0], plain[1])
+    assert torch.equal(m(return_dict=False, timestep=ts[2].expand(B), **g)[0], plain[2])
+    assert torch.equal(m(return_dict=False, timestep=ts[2].expand(B), joint_attention_kwargs={"modulation_step": 9}, **g)[0], plain[2])
+    m.end_schedule()
+    assert torch.equal(m(return_dict=False, timestep=ts[4].expand(B), joint_attention_kwargs={"modulation_step": 0}, **g)[0], plain[4])
+
+
 def test_forward_under_inference_mode_matches_no_grad():
     """The host drives the model inside `@torch.inference_mode()` (R/src/engine/registry.py:196): ids built there are inference
     tensors, which carry no `_version` — the rotary-table cache must not read it.  Same bits as under no_grad,

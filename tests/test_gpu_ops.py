@@ -207,6 +207,26 @@ def test_gemv(N, K, pre, post):
     assert torch.allclose(y2.cpu(), 2 * ref, atol=4e-4, rtol=4e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 70, 256), (5, 301, 768), (28, 517, 3072), (9, 64, 5120), (3, 40, 16384)])
+@pytest.mark.parametrize("pre,post,accum", [(True, None, False), (False, "silu", False), (False, None, True)])
+def test_gemv_rows_are_bit_identical_to_single_row_launches(M, N, K, pre, post, accum):
+    """M > 1 takes the multi-row kernel (one pass over W per group of rows, x rows in LDS): the modulation table of a whole clip.
+    Every row must equal the single-row launch on that x — same per-lane chunk order, same fmaf chain, same butterfly."""
+    ops = _ops()
+    w, b = _bf(seeded((N, K), 31, scale=K ** -0.5)).to(DEV), _bf(seeded((N,), 32)).to(DEV)
+    x = seeded((M, K), 33).to(DEV)
+    y0 = seeded((M, N), 34).to(DEV)
+    kw = dict(pre_silu=pre, post=post, accum=accum)
+    many = ops.gemv(w, x, b, out=y0.clone() if accum else None, **kw)
+    for m in range(M):
+        one = ops.gemv(w, x[m:m + 1], b, out=y0[m:m + 1].clone() if accum else None, **kw)
+        assert torch.equal(one[0], many[m]), (m, float((one[0] - many[m]).abs().max()))
+    # strided output rows (a column block of a wider table) and no bias
+    wide = torch.zeros(M, N + 24, device=DEV)
+    ops.gemv(w, x, None, out=wide[:, 8:8 + N], pre_silu=pre, post=post)
+    assert torch.equal(wide[:, 8:8 + N], ops.gemv(w, x, None, pre_silu=pre, post=post)) and float(wide[:, :8].abs().sum()) == 0.0
+
+
 # ------------------------------------------------------------------------------------ LN / modulate
 @pytest.mark.parametrize("M,C", [(5, 256), (131, 3072), (64, 5120), (33, 3584)])
 def test_ln_modulate(M, C):
