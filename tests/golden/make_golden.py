@@ -609,19 +609,29 @@ def gen_hunyuan15_meanflow():
                     keys=sorted(sd.keys())), os.path.join(OUT, "hunyuan15_meanflow.pt"))
 
 
-def gen_lora():
-    """Reference LoraConverter on seeded state dicts.  Stubs: the two rename tables imported from diffusers (only
-    used for the legacy diffusers formats, not exercised) and src.quantize.ggml_ops (imported by converters/utils,
-    unused on this path)."""
+def install_converter_stubs():
+    """What the reference's converters import besides themselves, for gen_lora and gen_convert alike: the two diffusers rename
+    tables of the legacy LoRA formats (not exercised) and src.quantize.ggml_ops, whose cat / chunk / split are torch's for plain
+    tensors (their GGML branches need the gguf package).  Every `src.converters.*` module an earlier generator imported is
+    dropped first, so that the reference's `from src.quantize.ggml_ops import ...` binds to THESE stubs whatever ran before
+    (gen_convert after gen_lora saw gen_lora's `ggml_chunk = None`)."""
+    for name in [n for n in sys.modules if n == "src.converters" or n.startswith("src.converters.")]:
+        sys.modules.pop(name, None)
     _mod("diffusers.utils.state_dict_utils", DIFFUSERS_TO_PEFT={}, DIFFUSERS_OLD_TO_PEFT={})
     q = _mod("src.quantize")
     q.__path__ = []
-    _mod("src.quantize.ggml_ops", ggml_cat=None, ggml_chunk=None)
+    _mod("src.quantize.ggml_ops", ggml_cat=lambda ts, dim=0: torch.cat(list(ts), dim=dim),
+         ggml_chunk=lambda t, n, dim=0: torch.chunk(t, n, dim=dim), ggml_split=lambda t, s, dim=0: torch.split(t, s, dim=dim))
     import diffusers
     if not hasattr(diffusers, "ModelMixin"):
         diffusers.ModelMixin = type("ModelMixin", (), {})
     cp = _mod("src.converters")
     cp.__path__ = [os.path.join(REF, "src/converters")]
+
+
+def gen_lora():
+    """Reference LoraConverter on seeded state dicts (stubs: install_converter_stubs)."""
+    install_converter_stubs()
     mod = load_by_path("ref_lora_converter", "src/lora/lora_converter.py")
     conv = mod.LoraConverter()
     cases = {}
@@ -798,29 +808,6 @@ def gen_qwen2_5_vl():
     print("qwen2_5_vl", float(a.hidden_states[-1].abs().mean()), float(b.hidden_states[-1].abs().mean()), float(vis.abs().mean()))
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    install_stubs()
-    gen_attention()
-    gen_efficiency()
-    gen_flux_hybrid()
-    gen_wan_hybrid()
-    gen_qwen_hybrid()
-    gen_hunyuan15_hybrid()
-    gen_hunyuan15_meanflow()
-    gen_vae_wan()
-    gen_vae_wan_encode()
-    gen_vae_hunyuan15()
-    gen_vae_taehv()
-    gen_vae_taehv_encode()
-    gen_unipc()
-    gen_lora()
-    gen_fp_scaled()
-    gen_text_encoders()
-    gen_qwen2_5_vl()
-
-
-
 # ---- leaf pins: the reference's IN-TREE copies of the diffusers leaves -----------------------------------------------
 def extract_defs(rel, names, ns=None):
     """Execute only the named top-level functions / classes of a reference source file (by AST), in a namespace that
@@ -972,16 +959,7 @@ def gen_convert():
     Stubs: src.quantize.ggml_ops' cat / chunk / split are torch's for plain tensors (their GGML branches need the gguf
     package); the diffusers rename tables of the two legacy LoRA formats are not exercised.  The fixture holds input specs
     (key -> shape, seed base) and the converted keys with their tensors."""
-    _mod("diffusers.utils.state_dict_utils", DIFFUSERS_TO_PEFT={}, DIFFUSERS_OLD_TO_PEFT={})
-    q = _mod("src.quantize")
-    q.__path__ = []
-    _mod("src.quantize.ggml_ops", ggml_cat=lambda ts, dim=0: torch.cat(list(ts), dim=dim),
-         ggml_chunk=lambda t, n, dim=0: torch.chunk(t, n, dim=dim), ggml_split=lambda t, s, dim=0: torch.split(t, s, dim=dim))
-    import diffusers
-    if not hasattr(diffusers, "ModelMixin"):
-        diffusers.ModelMixin = type("ModelMixin", (), {})
-    cp = _mod("src.converters")
-    cp.__path__ = [os.path.join(REF, "src/converters")]
+    install_converter_stubs()
     tc = load_by_path("src.converters.transformer_converters", "src/converters/transformer_converters.py")
     lc = load_by_path("ref_lora_converter2", "src/lora/lora_converter.py")
     from oracle import flux as OF, wan as OW
@@ -1156,11 +1134,90 @@ def gen_leaf_pins2():
     print("leaf_pins2.pt", sorted(out))
 
 
+# Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
+            "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
+            "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
+# the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
+FAST = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+        "convert"]
+
+
+def generate(names, out_dir):
+    """Run the named generators in ONE process, in the given order, writing into `out_dir`."""
+    global OUT
+    OUT = out_dir
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    for name in names:
+        globals()["gen_" + name]()
+
+
+def _same(a, b, path, bad):
+    """Deep bit-equality of two loaded fixtures (NaN == NaN: the fp8 tables hold NaN code points); mismatching paths -> bad."""
+    if torch.is_tensor(a) or torch.is_tensor(b):
+        ok = (torch.is_tensor(a) and torch.is_tensor(b) and a.dtype == b.dtype and a.shape == b.shape
+              and bool(torch.equal(a.view(torch.uint8) if a.dtype.itemsize == 1 else a, b.view(torch.uint8) if b.dtype.itemsize == 1 else b)
+                       or (a.is_floating_point() and torch.equal(torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0))
+                           and torch.equal(a.float().isnan(), b.float().isnan()))))
+        if not ok:
+            bad.append(path)
+    elif isinstance(a, dict) and isinstance(b, dict):
+        if set(a) != set(b):
+            bad.append(f"{path} (keys differ)")
+        for k in a:
+            if k in b:
+                _same(a[k], b[k], f"{path}[{k!r}]", bad)
+    elif isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        if len(a) != len(b):
+            bad.append(f"{path} (length differs)")
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]", bad)
+    elif isinstance(a, float) and isinstance(b, float):
+        if not (a == b or (a != a and b != b)):
+            bad.append(path)
+    elif a != b:
+        bad.append(path)
+
+
+def check(names, committed=None):
+    """Regenerate the named fixtures into a temporary directory and compare every file written with the committed one, bit for
+    bit.  Returns (files compared, mismatches)."""
+    import tempfile
+    committed = committed or os.path.join(REPO, "tests", "golden")
+    bad, files = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        generate(names, tmp)
+        for fn in sorted(os.listdir(tmp)):
+            files.append(fn)
+            ref = os.path.join(committed, fn)
+            if not os.path.exists(ref):
+                bad.append(f"{fn}: not committed")
+                continue
+            _same(torch.load(os.path.join(tmp, fn), weights_only=False), torch.load(ref, weights_only=False), fn, bad)
+    return files, bad
+
+
+def main(argv):
+    """make_golden.py                     regenerate ALL fixtures in place
+       make_golden.py NAME [NAME ...]     regenerate the named ones (generator names: see FIXTURES)
+       make_golden.py --check [fast|all|NAME ...]   regenerate to a temporary directory, assert bit-equality with the committed files"""
+    if argv and argv[0] == "--check":
+        sel = argv[1:] or ["all"]
+        names = FIXTURES if sel == ["all"] else FAST if sel == ["fast"] else sel
+        files, bad = check(names)
+        print(f"[check] {len(names)} generators -> {len(files)} files compared, {len(bad)} mismatches")
+        for b in bad[:50]:
+            print("  MISMATCH", b)
+        return 1 if bad else 0
+    names = argv or FIXTURES
+    unknown = [n for n in names if "gen_" + n not in globals()]
+    if unknown:
+        print("unknown fixtures:", unknown, "known:", FIXTURES)
+        return 2
+    generate(names, OUT)
+    return 0
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py text_encoders vae_hunyuan15 ...
-        os.makedirs(OUT, exist_ok=True)
-        install_stubs()
-        for name in sys.argv[1:]:
-            globals()["gen_" + name]()
-    else:
-        main()
+    sys.exit(main(sys.argv[1:]))
