@@ -356,14 +356,13 @@ def test_taehv_encoder_restatement_matches_reference(golden_dir):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/apps/api"), reason="the reference is only present in the build container")
 def test_fixture_recipe_reproduces_the_committed_files():
-    """`make_golden.py --check fast`: the generators that finish in seconds are re-run in ONE fresh process against
-    /root/reference (in the order that used to break `gen_convert`) and every file they write must equal the
-    committed fixture bit for bit.  `--check all` (minutes) covers the remaining ten generators the same way."""
+    """`make_golden.py --check all`: every generator is re-run in ONE fresh process against /root/reference (in the order that
+    used to break `gen_convert`) and every file written must equal the committed fixture bit for bit (≈20 s)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check", "fast"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check", "all"],
                        capture_output=True, text=True, timeout=600, cwd=root)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
-    assert "11 files compared, 0 mismatches" in r.stdout, tail
+    assert "21 generators -> 21 files compared, 0 mismatches" in r.stdout, tail

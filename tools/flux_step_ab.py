@@ -5,7 +5,9 @@ switches applied before a timed run of N steps, arms alternate for ROUNDS rounds
   ARMS="base;modtable=0;ln.wave=2"   (';' separates arms, ',' separates switches inside an arm)
      modtable=0|1      per-clip modulation table (begin_schedule) off / on            [default on]
      <tune key>=<int>  apexmi_tune_set                                                 (reset to DEFAULTS after the arm)
-     env:NAME=VALUE    os.environ for the arm (attributes read per call only)
+     env:NAME=VALUE    os.environ for the arm (variables read per call only)
+     attr:NAME=INT     model attribute for the arm (e.g. attr:fuse_qkv=0)
+  CLK=1                also report the live shader clock over the GEMM K-loops of each run (apexmi_clk_*)
   STEPS=12 ROUNDS=3
 
 Prints one JSON line per (round, arm) and a summary (median ms/step per arm, bit-identity of the final latents across arms)."""
@@ -25,10 +27,11 @@ from apex_studio_amd.flux import FluxTransformer2DModel  # noqa: E402
 from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
 
 DEV = "cuda"
-DEFAULTS = {"ln.wave": 1, "gemm.group_m": 6}      # shipped values of the keys an arm may set (restored after the arm)
+DEFAULTS = {"ln.wave": 1, "gemm.group_m": 6, "gemm.large": 7}      # shipped values of the keys an arm may set (restored after the arm)
 ARMS = [a for a in os.environ.get("ARMS", "base;modtable=0").split(";") if a]
 STEPS = int(os.environ.get("STEPS", "12"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
+CLK = os.environ.get("CLK", "0") == "1"
 FLUX_DEV = dict(patch_size=1, in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128, num_attention_heads=24,
                 joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
 
@@ -49,6 +52,8 @@ def main():
         sched.set_begin_index(0)
         lat = lat0
         torch.cuda.synchronize()
+        if CLK:
+            lib.clk_enable(True)
         t0 = time.perf_counter()
         if table:
             model.begin_schedule(torch.stack([t.expand(1).to(lat.dtype) / 1000 for t in ts]), guidance, pooled)
@@ -60,18 +65,25 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         model.end_schedule()
-        return 1e3 * dt / STEPS, lat
+        ghz = None
+        if CLK:
+            ghz = lib.clk_read()["ghz"]
+            lib.clk_enable(False)
+        return 1e3 * dt / STEPS, lat, ghz
 
     run(True)
     res = {a: [] for a in ARMS}
-    finals = {}
+    finals, clk = {}, {}
     for r in range(ROUNDS):
         for arm in ARMS:
-            table, envs, keys = True, {}, []
+            table, envs, keys, attrs = True, {}, [], {}
             for sw in ([] if arm == "base" else arm.split(",")):
                 k, v = sw.split("=", 1)
                 if k == "modtable":
                     table = v != "0"
+                elif k.startswith("attr:"):
+                    attrs[k[5:]] = getattr(model, k[5:])
+                    setattr(model, k[5:], type(attrs[k[5:]])(int(v)))
                 elif k.startswith("env:"):
                     envs[k[4:]] = os.environ.get(k[4:])
                     os.environ[k[4:]] = v
@@ -79,18 +91,22 @@ def main():
                     assert k in DEFAULTS, f"add the shipped value of {k} to DEFAULTS"
                     lib.tune_set(k, int(v))
                     keys.append(k)
-            ms, lat = run(table)
+            ms, lat, ghz = run(table)
             for k in keys:
                 lib.tune_set(k, DEFAULTS[k])
+            for k, v in attrs.items():
+                setattr(model, k, v)
             for k, v in envs.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             res[arm].append(ms)
             finals.setdefault(arm, lat.clone())
-            print(json.dumps({"round": r, "arm": arm, "ms_per_step": ms}), flush=True)
+            clk.setdefault(arm, []).append(ghz)
+            print(json.dumps({"round": r, "arm": arm, "ms_per_step": ms, "gemm_clock_ghz": ghz}), flush=True)
     base = finals[ARMS[0]]
     print(json.dumps({"steps": STEPS, "rounds": ROUNDS,
                       "median_ms": {a: statistics.median(v) for a, v in res.items()},
                       "min_ms": {a: min(v) for a, v in res.items()},
+                      "gemm_clock_ghz": {a: (statistics.median(v) if CLK else None) for a, v in clk.items()},
                       "final_latents_equal_to_first_arm": {a: bool(torch.equal(base, f)) for a, f in finals.items()}}), flush=True)
 
 

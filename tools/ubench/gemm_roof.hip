@@ -1,0 +1,153 @@
+// Microbenchmark: the roof of the shipped GEMM tile (256x256x64, 8 waves = 2 per SIMD, v_mfma_f32_16x16x32_bf16) as a STALL-FREE
+// stream of its own instruction mix — no barriers, no dependent waits — so that what is left is the matrix pipe, the LDS port, the
+// LDS-DMA / fabric path and the chip's power budget (DVFS).  Per "K-tile" and wave, exactly what gemm_bf16_kernel<CFG_256P16> issues:
+//   64 MFMA 16x16x32 over 128 accumulator registers, 24 ds_read_b128 fragment reads (conflict-free, the kernel's swizzle),
+//   8 global_load_lds_dwordx4 pieces (1 KiB each).
+// Fragments flow LDS -> registers -> MFMA one phase later (two register sets), so operand toggling is that of random data.
+// MODE 0 MFMA only (register-resident random operands)          -> the matrix-pipe power roof
+// MODE 1 + fragment reads                                        -> + LDS port
+// MODE 2 + LDS-DMA from a source every workgroup shares (2 MiB: L2-resident)
+// MODE 3 + LDS-DMA from per-workgroup private regions (streams from MALL / HBM)
+// Output per mode: TFLOP/s, effective shader clock (s_memtime cycles / s_memrealtime 100 MHz ticks), cycles per K-tile.
+// Build: hipcc --offload-arch=gfx950 -O3 -o gemm_roof gemm_roof.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ inline unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
+__device__ inline float rnd(unsigned& s) { return ((int)(lcg(s) >> 8) - (1 << 23)) * (1.0f / (1 << 23)); }
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k(const char* src, size_t region, float* out, unsigned long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 128 KiB: [0, 64K) the tile image the fragments are read from,
+                                                                   // [64K, 128K) the LDS-DMA destination (the "other buffer")
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, l15 = lane & 15, g4 = lane >> 4;
+    unsigned seed = tid * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = tid; i < 65536 / 16; i += 512) {
+        bf16x8 v;
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)rnd(seed);
+        *(bf16x8*)(smem + i * 16) = v;
+    }
+    __syncthreads();
+    // the kernel's fragment addresses: row r of a 128-byte-pitch image, 16-byte chunk (c ^ ((r >> 1) & 7))
+    const int sw = (l15 >> 1) & 7;
+    const int ch[2] = {((0 + g4) ^ sw) << 4, ((4 + g4) ^ sw) << 4};
+    // one base per (operand, k-step); the 16-row tile index is an immediate offset (t * 2048)
+    const char* pa[2] = {smem + (wm * 128 + l15) * 128 + ch[0], smem + (wm * 128 + l15) * 128 + ch[1]};
+    const char* pw[2] = {smem + 32768 + (wn * 64 + l15) * 128 + ch[0], smem + 32768 + (wn * 64 + l15) * 128 + ch[1]};
+    bf16x8 fa[2][8], fw[2][4];          // two fragment sets: one feeds this phase's MFMAs, the other is being loaded
+    for (int s = 0; s < 2; ++s) {
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) fa[s][i][j] = (__bf16)rnd(seed);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 8; ++j) fw[s][i][j] = (__bf16)rnd(seed);
+    }
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* gsrc = src + (MODE == 3 ? (size_t)blockIdx.x * region : 0) + (size_t)wave * 1024 + (lane >> 3) * 128 + (lane & 7) * 16;
+    size_t goff = 0;
+    const size_t gmask = region - 1;    // region is a power of two >= 64 KiB
+    char* ddst = smem + 65536 + wave * 1024;
+
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {           // 4 phases x 16 MFMA = one K-tile
+            const int cur = ph & 1, nxt = cur ^ 1;
+            asm volatile("" ::: "memory");          // the image never changes in MODE 1: keep the reads inside the loop
+            if (MODE >= 1) {                        // 6 of the 24 reads per phase, consumed by the NEXT phase's MFMAs (other register set)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fa[nxt][((ph >> 1) & 1) * 4 + j] = *(const bf16x8*)(pa[(ph >> 1) & 1] + ((ph * 4 + j) & 7) * 2048);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fw[nxt][((ph >> 1) & 1) * 2 + j] = *(const bf16x8*)(pw[(ph >> 1) & 1] + ((ph * 2 + j) & 3) * 2048);
+            }
+            if (MODE >= 2) {                        // 2 of the 8 pieces per phase
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (goff & gmask)),
+                                                     (__attribute__((address_space(3))) void*)(ddst + ((ph * 2 + j) & 7) * 8192), 16, 0, 0);
+                    goff += 8192;                  // 8 waves x 1 KiB per piece index
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // loads / pieces first, then the MFMA block (the kernel's segment order)
+#pragma unroll
+            for (int m = 0; m < 16; ++m)            // (ks, u, t) order of the kernel: 2 x 2 x 4
+                acc[ph * 8 + (m & 7)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][m >> 2], fa[cur][(m & 3) + 4 * ((m >> 3) & 1)],
+                                                                              acc[ph * 8 + (m & 7)], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        atomicAdd(clk, c1 - c0);
+        atomicAdd(clk + 1, r1 - r0);
+    }
+    float s = 0;
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int MODE>
+void run(const char* name, const char* src, size_t region, float* out, unsigned long long* clk, int secs_hint) {
+    const int blocks = 256, iters = 6000;
+    auto kern = k<MODE>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(clk, 0, 16);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 131072, 0, src, region, out, clk, iters / 4);   // warm
+        hipMemset(clk, 0, 16);
+        hipEventRecord(e0);
+        for (int l = 0; l < secs_hint; ++l) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 131072, 0, src, region, out, clk, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2];
+        hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        const double flops = 2.0 * 16 * 16 * 32 * 64.0 * iters * 8 * blocks * secs_hint;
+        const double ghz = 0.1 * (double)h[0] / (double)h[1];
+        printf("{\"mode\": %d, \"what\": \"%s\", \"tflops\": %.1f, \"ms\": %.2f, \"clock_ghz\": %.3f, \"cycles_per_ktile\": %.0f, "
+               "\"matrix_pipe_busy\": %.3f}\n",
+               MODE, name, flops / (ms * 1e-3) * 1e-12, ms, ghz, (double)h[0] / ((double)blocks * secs_hint * iters),
+               2048.0 / ((double)h[0] / ((double)blocks * secs_hint * iters)));
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 8;    // back-to-back launches per measurement (sustained load)
+    float* out;
+    unsigned long long* clk;
+    char* src;
+    const size_t region = 8u << 20;                        // per-workgroup private region of MODE 3 (8 MiB x 256 = 2 GiB)
+    hipMalloc(&out, 4);
+    hipMalloc(&clk, 16);
+    hipMalloc(&src, region * 256);
+    // random bf16 source
+    {
+        std::vector<unsigned short> h(region / 2);
+        unsigned s = 1;
+        for (auto& v : h) {
+            s = s * 1664525u + 1013904223u;
+            v = (unsigned short)(((s >> 9) & 0x7fff) % 0x3f80 | ((s >> 3) & 0x8000));   // |x| < 1
+        }
+        for (int i = 0; i < 256; ++i) hipMemcpy(src + (size_t)i * region, h.data(), region, hipMemcpyHostToDevice);
+    }
+    run<0>("MFMA only, register-resident random operands", src, 2u << 20, out, clk, launches);
+    run<1>("+ 24 fragment reads per 64 MFMA (operands from LDS)", src, 2u << 20, out, clk, launches);
+    run<2>("+ 8 LDS-DMA pieces per 64 MFMA, shared 2 MiB source (L2)", src, 2u << 20, out, clk, launches);
+    run<3>("+ 8 LDS-DMA pieces per 64 MFMA, private 8 MiB regions (MALL/HBM)", src, region, out, clk, launches);
+    return 0;
+}
