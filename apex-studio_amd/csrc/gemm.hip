@@ -19,6 +19,8 @@
 //                  denoise step runs at the chip's power limit, and at equal matrix-pipe occupancy the
 //                  16x16x32 form sustains 2.03 GHz against 1.79 GHz for 32x32x16 (tools/ubench/
 //                  mfma_power.hip); in the Flux step it is 8 % faster per GEMM, 6.5 % per step.
+//   9 CFG_256R   : free-running ring on v_mfma_f32_16x16x32_bf16 (round 4): 32-deep sub-tiles in a four-slot LDS ring, fragments
+//                  read one step ahead into a second register set, two barriers per K-tile — see the SCHED 7 branch.
 //   6 CFG_256W   : 4 waves (2x2) of 128x128, one wave per SIMD, accumulators in AGPRs, LDS-DMA through
 //                  buffer_load with scalar piece offsets.  17 % fewer cycles than CFG_256P and faster in
 //                  an isolated loop, but not in the step: the chip answers the denser instruction
@@ -39,6 +41,11 @@
 
 namespace {
 
+// Ablation build of the ring schedule (tools/gemm_ring_ablate.sh; WRONG results, timing only): bit 1 no barriers, 2 no vmcnt waits,
+// 4 no LDS-DMA pieces, 8 no fragment reads.  0 in every shipped library.
+#ifndef APEXMI_GEMM_ABLATE
+#define APEXMI_GEMM_ABLATE 0
+#endif
 constexpr int BK = 64;
 constexpr int GROUP_M = 6;   // tiles tall per group: an XCD's 32 concurrent tiles as ~6 x 5.3 (squarer than 8 x 4: fewer panel fetches per
                              // tile; interleaved A/B, profiles/r03_ab_gemm_group_m.log: Flux -0.4 %, Qwen -1.1 %, Wan -0.6 % vs 8)
@@ -86,14 +93,15 @@ struct GemmGroup {
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-    // 0 plain double buffer | 1 ping-pong phases, 32x32x16 | 4 one wave per SIMD, rotated pipeline | 5 ping-pong, 16x16x32
+    // 0 plain double buffer | 1 ping-pong phases, 32x32x16 | 4 one wave per SIMD, rotated pipeline | 5 ping-pong, 16x16x32 |
+    // 7 free-running ring, 16x16x32
     static constexpr int SCHED = SCHED_;
     static constexpr bool PP = SCHED_ == 1;
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
     static constexpr int STAGE = A_BYTES + W_BYTES;
-    static constexpr int LDS = 2 * STAGE;
+    static constexpr int LDS = SCHED_ == 8 ? 5 * 32768 : 2 * STAGE;   // SCHED 8: five-slot ring (160 KiB, the whole LDS of a CU)
     static constexpr int A_LD = BM * 8 / NT, W_LD = BN * 8 / NT;  // glds per thread per K-tile
     static constexpr int OCC = (LDS <= 80 * 1024 && NT == 256) ? 2 : (NT == 512 ? 2 : 1);  // waves per EU for launch_bounds
 };
@@ -103,6 +111,8 @@ using CFG_128E = Cfg<128, 128, 2, 4, 0>;   // 128x128 block on EIGHT waves (64x3
 using CFG_256P = Cfg<256, 256, 2, 4, 1>;
 using CFG_256W = Cfg<256, 256, 2, 2, 4>;
 using CFG_256P16 = Cfg<256, 256, 2, 4, 5>;
+using CFG_256R = Cfg<256, 256, 2, 4, 7>;     // free-running ring schedule (round 4), `gemm.large = 9`: four slots, pieces 3 sub-tiles ahead
+using CFG_256R5 = Cfg<256, 256, 2, 4, 8>;    // the same with five slots, pieces 4 sub-tiles ahead (`gemm.large = 10`)
 
 // activation of the bias epilogue: 1 gelu(tanh), 2 gelu(erf, torch nn.GELU() default), 3 silu
 APEXMI_DEVICE float act_f(float x, int mode) {
@@ -541,8 +551,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f32x4_t acc16[4][8];  // SCHED 5 only: [16-column n-tile][16-row m-tile]
-    if constexpr (CFG::SCHED == 5) {
+    f32x4_t acc16[4][8];  // SCHED 5 / 7 only: [16-column n-tile][16-row m-tile]
+    if constexpr (CFG::SCHED == 5 || CFG::SCHED >= 7) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -707,6 +717,179 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         }
         period(kt, std::false_type{}, std::false_type{});
 #undef W4_FENCE
+    } else if constexpr (CFG::SCHED >= 7) {
+        // ---- free-running ring on v_mfma_f32_16x16x32_bf16 (round 4) ----
+        // tools/ubench/gemm_roof.hip: the tile's own instruction mix as a stall-free stream (64 MFMA + 24 fragment reads + 8 LDS-DMA
+        // pieces per wave and 64-deep K-tile, fragments read one phase ahead into a second register set, no barrier) keeps the
+        // matrix pipe 93 % busy and is POWER-bound at 1.57 PF (clock 1.62 GHz), where the ping-pong schedule runs at 2.05 GHz with
+        // the pipe 50 % busy: its eight barrier intervals per K-tile each end in an exposed fragment-read latency.  This schedule
+        // is that stream plus the synchronisation a real tile needs and nothing else:
+        //   * the K-tile is cut into 32-deep SUB-TILES (one MFMA k-step); LDS is a ring of four 32 KiB slots
+        //     [A 256 rows x 64 B | W 256 rows x 64 B], chunk swizzle c ^ ((row >> 2) & 3) (64-byte pitch: four rows per bank row;
+        //     a 16-row fragment read covers all 64 banks exactly once per 16-lane group);
+        //   * step s: fragment reads of sub-tile s + 1 into the OTHER register set and the wave's four LDS-DMA pieces of sub-tile
+        //     s + 3 (s + 4 with five slots) in one barrier interval, the 32 MFMAs of sub-tile s in the next: four barriers per 64-deep
+        //     K-tile instead of eight, and nothing waits for a read it has just issued (RAW / WAR argument at RING_STEP below).
+        // Same k order per accumulator as SCHED 5 (32-deep k-steps ascending): results are bit-identical to it.
+        const int l15 = lane & 15, g4 = lane >> 4;
+        const int swz = (g4 ^ (l15 >> 2)) << 4;
+        const int rd_a = (wm * 128 + l15) * 64 + swz;          // + t * 1024 (16-row tile) + slot * 32768
+        const int rd_w = 16384 + (wn * 64 + l15) * 64 + swz;   // + u * 1024
+        // LDS-DMA sources: a wave-uniform base per operand (SGPR pair, advanced by the k offset) + a 32-bit per-lane offset, so
+        // that a piece costs one VGPR, not a 64-bit pointer (the two fragment register sets leave no room for those)
+        const char* base_a = (const char*)(P.A + (int64_t)m0 * P.lda);
+        const char* base_w = (const char*)(P.W + (int64_t)n0 * P.ldw);
+        unsigned off[4];
+        int dst[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pc = wave + 8 * j;                        // 1 KiB piece = 16 rows x 64 B
+            const int row = pc * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            off[j] = (unsigned)((min(m0 + row, M - 1) - m0) * (int)P.lda * 2 + c * 16);
+            off[2 + j] = (unsigned)((min(n0 + row, N - 1) - n0) * (int)P.ldw * 2 + c * 16);
+            dst[j] = pc * 1024;
+            dst[2 + j] = 16384 + pc * 1024;
+        }
+        constexpr int RD_ = CFG::SCHED == 8 ? 4 : 3;           // pieces go out RD_ sub-tiles ahead into a ring of RD_ + 1 slots
+        constexpr int NSLOT = RD_ + 1;
+        auto dma = [&](int st, int slot) {
+            char* base = smem + slot * 32768;
+            const char* ka = base_a + (int64_t)st * 64;
+            const char* kw = base_w + (int64_t)st * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(ka + off[j], base + dst[j]);
+#pragma unroll
+            for (int j = 2; j < 4; ++j) glds16(kw + off[j], base + dst[j]);
+        };
+        // Fragment reads as inline asm: beside an LDS-DMA in flight the compiler's wait-count pass guards every LDS consumer with
+        // lgkmcnt(0) (a flat-class instruction with an LDS side is "pending flat" to it), which here would wait for the twelve reads
+        // just issued for the NEXT step.  The asm reads are invisible to that pass; `frag_wait<N>` is the counted wait, and it names
+        // every register of the set it releases as read-write, so no consumer can be scheduled above it (§5.7 form (ii)).
+        bf16x8 fa[2][8], fw[2][4];
+#define RING_DSR(dstreg, addr, offs) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dstreg) : "v"(addr), "i"(offs) : "memory")
+        // (macros, not generic lambdas: clang rejects an asm operand that names a captured array inside a generic lambda)
+#define RING_RD(slotidx, set)                              \
+    do {                                                   \
+        const int slot_ = (slotidx) * 32768;               \
+        const int aw_ = slot_ + rd_w, aa_ = slot_ + rd_a;  \
+        RING_DSR(fw[set][0], aw_, 0);                      \
+        RING_DSR(fw[set][1], aw_, 1024);                   \
+        RING_DSR(fw[set][2], aw_, 2048);                   \
+        RING_DSR(fw[set][3], aw_, 3072);                   \
+        RING_DSR(fa[set][0], aa_, 0);                      \
+        RING_DSR(fa[set][1], aa_, 1024);                   \
+        RING_DSR(fa[set][2], aa_, 2048);                   \
+        RING_DSR(fa[set][3], aa_, 3072);                   \
+        RING_DSR(fa[set][4], aa_, 4096);                   \
+        RING_DSR(fa[set][5], aa_, 5120);                   \
+        RING_DSR(fa[set][6], aa_, 6144);                   \
+        RING_DSR(fa[set][7], aa_, 7168);                   \
+    } while (0)
+#define RING_WAIT(n, set)                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                 \
+                 : "+v"(fw[set][0]), "+v"(fw[set][1]), "+v"(fw[set][2]), "+v"(fw[set][3]), "+v"(fa[set][0]), "+v"(fa[set][1]), \
+                   "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fa[set][4]), "+v"(fa[set][5]), "+v"(fa[set][6]), "+v"(fa[set][7]) \
+                 :                                                                                                           \
+                 : "memory")
+#define RING_MMA(set)                                                                                                      \
+    do {                                                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) _Pragma("unroll") for (int t = 0; t < 8; ++t) acc16[u][t] =          \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][u], fa[set][t], acc16[u][t], 0, 0, 0);                         \
+        __builtin_amdgcn_s_setprio(0);                                                                                     \
+    } while (0)
+#define RING_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // One step: fragment reads of sub-tile st + 1 into the other set | the wave's pieces of sub-tile st + 3 | counted wait for
+        // THIS step's fragments (read a step ago; the 12 newer reads fly on) | 32 MFMAs | vmcnt: own pieces of sub-tile st + 2
+        // landed, the four of st + 3 stay in flight across the barrier | barrier.  RD / DMA are literals: the last steps have
+        // nothing left to read / stage.
+#define RING_VM(n)                                                                       \
+    do {                                                                                 \
+        if (!(APEXMI_GEMM_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
+    } while (0)
+#define RING_BAR()                                                      \
+    do {                                                                \
+        if (!(APEXMI_GEMM_ABLATE & 1)) __builtin_amdgcn_s_barrier();    \
+    } while (0)
+        // One step of a wave = two barrier intervals: ISSUE (fragment reads of sub-tile st + 1 into the other set, the wave's pieces of
+        // sub-tile st + RD_, the counted vmcnt) | barrier | MMA (32 MFMAs on this step's set, then lgkmcnt(0): the reads issued in
+        // ISSUE have had the whole MFMA segment to land) | barrier.  The M-halves run ONE INTERVAL APART (waves w and w + 4 share a
+        // SIMD): while one wave of a SIMD is in its MFMA segment the other is in its issue segment, whose cost — an LDS-DMA piece
+        // blocks the issuing wave for 60-180 cycles, measured — is then covered by the partner's MFMAs; the lock-step form of this
+        // ring (profiles/r04_gemm_ring_lockstep_*.log) had both waves of a SIMD issuing at the same time and was 8-13 % slower
+        // than the ping-pong schedule.  Nothing in ISSUE waits for what it has just issued.
+        //   RAW: sub-tile st + 2 is first read in interval 2 st + 2 (M-half 0's ISSUE of step st + 1); every wave has waited for
+        //        its pieces of it at the end of its own ISSUE of step st (intervals 2 st / 2 st + 1), before a barrier.
+        //   WAR: pieces of sub-tile st + RD_ overwrite sub-tile st - 1, whose last reads (M-half 1, ISSUE of step st - 2, interval
+        //        2 st - 3) were retired by the lgkmcnt(0) that ends that wave's MMA of step st - 2 (interval 2 st - 2).
+#define RING_STEP(st_, set, RD, DMA)                                        \
+    do {                                                                    \
+        RING_FENCE();                                                       \
+        if (RD && !(APEXMI_GEMM_ABLATE & 8)) RING_RD(s_rd, (set) ^ 1);      \
+        RING_FENCE();                                                       \
+        if (DMA && !(APEXMI_GEMM_ABLATE & 4)) dma((st_) + RD_, s_dma);      \
+        RING_FENCE();                                                       \
+        if (DMA) {                                                          \
+            if (RD_ == 3) RING_VM(4);                                       \
+            else RING_VM(8);                                                \
+        } else {                                                            \
+            RING_VM(0);                                                     \
+        }                                                                   \
+        RING_FENCE();                                                       \
+        RING_BAR();                                                         \
+        RING_FENCE();                                                       \
+        RING_MMA(set);                                                      \
+        if (RD) RING_WAIT(0, (set) ^ 1);                                    \
+        RING_FENCE();                                                       \
+        RING_BAR();                                                         \
+        RING_FENCE();                                                       \
+        s_rd = s_rd + 1 == NSLOT ? 0 : s_rd + 1;                            \
+        s_dma = s_dma + 1 == NSLOT ? 0 : s_dma + 1;                         \
+    } while (0)
+        const int ns = nkt * 2;                                // sub-tiles (K % 64 == 0: always even, >= 2)
+        // prologue: the first RD_ sub-tiles go out, 0 and 1 must have landed before the first reads
+#pragma unroll
+        for (int i = 0; i < RD_; ++i)
+            if (i < ns) dma(i, i);
+        if (ns >= 4 && RD_ == 4) RING_VM(8);
+        else if (ns >= 3) RING_VM(4);
+        else RING_VM(0);
+        RING_FENCE();
+        __builtin_amdgcn_s_barrier();
+        RING_FENCE();
+        RING_RD(0, 0);
+        RING_WAIT(0, 0);
+        RING_FENCE();
+        if (wm == 1) RING_BAR();                               // M-half 1 runs one interval behind M-half 0
+        RING_FENCE();
+        int s_rd = 1, s_dma = RD_ % NSLOT;                     // slots of sub-tile st + 1 / st + RD_ at step st
+        int st = 0;
+        for (; st + 1 + RD_ < ns; st += 2) {                   // both steps of the pair read ahead and stage ahead: no branch inside
+            RING_STEP(st, 0, true, true);
+            RING_STEP(st + 1, 1, true, true);
+        }
+        // the last one or two pairs, straight-line (a loop with variant branches here costs the allocator 400+ spills): after the
+        // branch-free loop 2 or 4 steps remain; with 4, only the three-ahead ring still has a piece to issue (sub-tile ns - 1)
+        if (st + 4 <= ns) {
+            if constexpr (RD_ == 3) RING_STEP(st, 0, true, true);
+            else RING_STEP(st, 0, true, false);
+            RING_STEP(st + 1, 1, true, false);
+            st += 2;
+        }
+        RING_STEP(st, 0, true, false);
+        RING_STEP(st + 1, 1, false, false);
+        RING_FENCE();
+        if (wm == 0) RING_BAR();                               // balance the barrier count of the two halves
+        RING_FENCE();
+#undef RING_VM
+#undef RING_BAR
+#undef RING_STEP
+#undef RING_MMA
+#undef RING_RD
+#undef RING_FENCE
+#undef RING_DSR
+#undef RING_WAIT
     } else if constexpr (CFG::SCHED == 5) {
         // ---- ping-pong schedule on v_mfma_f32_16x16x32_bf16 ----
         // Same phases, regions and waits as SCHED 1; the quadrant (64 rows x 32 columns x K 64) is 16 MFMAs
@@ -976,7 +1159,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
     }
 
     // ---- epilogue ----
-    if constexpr (CFG::SCHED == 5) {
+    if constexpr (CFG::SCHED == 5 || CFG::SCHED >= 7) {
         if constexpr (EPI == APEXMI_EPI_BIAS) {
             if (P.qkv) {                                // block-uniform
                 qkv_epilogue16(acc16, P, G.qs, M, m0, n0, wave, wm, wn, lane, smem);
@@ -1081,7 +1264,7 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         // tiles on a 577 us launch), so the tail problem goes out as its own 128x128-tiled launch (192 quarter-size
         // tiles, under one round of the two-workgroups-per-CU kernel).  Round 3: with the eight-wave 128x128 tiling the same holds
         // for Flux's FF-up (3 x 256 image tiles + 96 text tiles): g_tail_max 64 -> 96.
-        if (cfg == 7 && g_tail_split && G.count >= 2 && G.batch == 1) {
+        if ((cfg == 7 || cfg == 9 || cfg == 10) && g_tail_split && G.count >= 2 && G.batch == 1) {
             int64_t lead = 0;
             for (int i = 0; i + 1 < G.count; ++i)
                 lead += (int64_t)((Ms[i] + 255) / 256) * ((G.p[i].N + 255) / 256);
@@ -1092,7 +1275,10 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
                 T.count = 1;
                 T.p[0] = G.p[li];
                 G.count = li;
-                if (int rc = launch_cfg<CFG_256P16, EPI>(G, Ms, stream)) return rc;
+                if (int rc = (cfg == 9    ? launch_cfg<CFG_256R, EPI>(G, Ms, stream)
+                              : cfg == 10 ? launch_cfg<CFG_256R5, EPI>(G, Ms, stream)
+                                          : launch_cfg<CFG_256P16, EPI>(G, Ms, stream)))
+                    return rc;
                 // the tail launch is under one workgroup per CU, i.e. a latency chain per K-tile whose length is the LDS-DMA
                 // pieces a wave issues (~150 cycles each): eight waves per 128x128 tile issue 4 per K-tile, four waves 8
                 if (g_tail_split == 2) return launch_cfg<CFG_128E, EPI>(T, Ms + li, stream);
@@ -1106,6 +1292,8 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         case 8: return launch_cfg<CFG_128E, EPI>(G, Ms, stream);
         case 6: return launch_cfg<CFG_256W, EPI>(G, Ms, stream);
         case 7: return launch_cfg<CFG_256P16, EPI>(G, Ms, stream);
+        case 9: return launch_cfg<CFG_256R, EPI>(G, Ms, stream);
+        case 10: return launch_cfg<CFG_256R5, EPI>(G, Ms, stream);
         default:
             return launch_cfg<CFG_256P, EPI>(G, Ms, stream);
     }
@@ -1231,7 +1419,8 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
 }
 
 extern "C" int apexmi_gemm_qkv_fusable(int64_t m_total, int n_max, int K) {
-    return (g_force_cfg == 0 || g_force_cfg == 7) && g_large_cfg == 7 && m_total >= 1024 && n_max >= 1024 && K >= 256 && K % BK == 0;
+    return (g_force_cfg == 0 || g_force_cfg == 7 || g_force_cfg == 9 || g_force_cfg == 10) &&
+           (g_large_cfg == 7 || g_large_cfg == 9 || g_large_cfg == 10) && m_total >= 1024 && n_max >= 1024 && K >= 256 && K % BK == 0;
 }
 
 extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, const int64_t* lda, const void* const* W,
@@ -1285,6 +1474,8 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
     APEXMI_REQUIRE(apexmi_gemm_qkv_fusable(mtot, nmax, K),
                    "gemm_bf16_grouped_qkv: needs the 256x256 v_mfma_f32_16x16x32 tiling (gemm.config / gemm.large = 7, >= 1024 rows)");
     ApexmiProfScope prof(0, stream, flops, bytes);
+    if (g_large_cfg == 9 || g_force_cfg == 9) return launch_cfg<CFG_256R, APEXMI_EPI_BIAS>(G, M, stream);
+    if (g_large_cfg == 10 || g_force_cfg == 10) return launch_cfg<CFG_256R5, APEXMI_EPI_BIAS>(G, M, stream);
     return launch_cfg<CFG_256P16, APEXMI_EPI_BIAS>(G, M, stream);
 }
 

@@ -2,8 +2,10 @@
 (`apps/api/src/engine/hunyuanvideo15/t2v.py:107-361`): latents [B, 32, F, H/16, W/16], the transformer input is
 `cat([latents, cond_latents (zeros), mask (zeros)], dim=1)` (65 channels, :20-42, :238-241), the timestep goes in as
 `t.expand(B).to(latents.dtype)` on the 0-1000 scale (:243-245), manual CFG with optional std rescale (:248-306),
-FlowMatch-Euler step, progress protocol 0.45 -> [0.50, 0.90] -> decode.  Prompt embeddings (MLLM + ByT5, with their
-masks) are inputs: the text encoders are outside this backend's scope.
+FlowMatch-Euler step, progress protocol 0.45 -> [0.50, 0.90] -> decode.  Prompts: either the four embedding tensors, or token
+ids through the engine's own text encoders — the MLLM (Qwen2.5-VL, third-from-last hidden state, the 108 template tokens
+dropped) and the glyph ByT5 (a T5-v1.1 encoder over the quoted text, 256 tokens; zeros when the prompt quotes nothing) —
+as `encode_prompt` does in the reference (`shared/__init__.py:145-283, 344-437`); tokenizers stay CPU `transformers` objects.
 
 `HunyuanVideo15I2VEngine` mirrors `engine/hunyuanvideo15/i2v.py:14-407`: the first frame is VAE-encoded (posterior mode,
 normalised; `_get_image_latents`, shared/__init__.py:285-299 -> BaseEngine.vae_encode, base_engine.py:2061-2165), the
@@ -33,8 +35,15 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
 
     def __init__(self, transformer, vae=None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
                  vae_scale_factor_temporal: int = 4, vae_scale_factor_spatial: int = 16,
-                 vision_num_semantic_tokens: int = 729, vision_states_dim: int = 1152, decode_fn=None):
+                 vision_num_semantic_tokens: int = 729, vision_states_dim: int = 1152, decode_fn=None,
+                 text_encoder=None, text_encoder_2=None, tokenizer_max_length: int = 1000, tokenizer_2_max_length: int = 256,
+                 prompt_template_encode_start_idx: int = 108):
         self.transformer = transformer
+        # MLLM (Qwen2.5-VL class, text only) and glyph ByT5 (T5EncoderModel with the ByT5 config), manifest names
+        # `text_encoder` / `text_encoder_2`; lengths and the template crop as the reference engine sets them (shared/__init__.py:40-60)
+        self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2
+        self.tokenizer_max_length, self.tokenizer_2_max_length = tokenizer_max_length, tokenizer_2_max_length
+        self.prompt_template_encode_start_idx = prompt_template_encode_start_idx
         self.vae = vae
         self.decode_fn = decode_fn
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(shift=7.0)
@@ -47,6 +56,73 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
     @property
     def device(self):
         return self.transformer.device
+
+    # ---- prompts -----------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _get_mllm_prompt_embeds(self, input_ids, attention_mask, num_hidden_layers_to_skip: int = 2, crop_start=None):
+        """`_get_mllm_prompt_embeds` (shared/__init__.py:145-232) from the tokenizer's output: `apply_chat_template(system message +
+        prompt, padding="max_length", max_length=tokenizer_max_length + crop_start)` ids and mask -> hidden state
+        `-(num_hidden_layers_to_skip + 1)` of the MLLM, the `crop_start` template tokens dropped, mask as int64."""
+        if self.text_encoder is None:
+            raise RuntimeError("HunyuanVideo15 engine: prompts need a text_encoder (Qwen2.5-VL); or pass prompt_embeds*")
+        crop = self.prompt_template_encode_start_idx if crop_start is None else crop_start
+        dev = self.device
+        ids, mask = input_ids.to(dev), attention_mask.to(dev)
+        hidden = self.text_encoder(input_ids=ids, attention_mask=mask, output_hidden_states=True).hidden_states[
+            -(num_hidden_layers_to_skip + 1)]
+        if crop:
+            hidden, mask = hidden[:, crop:], mask[:, crop:]
+        return hidden.to(self.transformer.dtype), mask.to(torch.int64)
+
+    @torch.no_grad()
+    def _get_byt5_prompt_embeds(self, glyph_ids, batch: int):
+        """`_get_byt5_prompt_embeds` (shared/__init__.py:234-283): the ByT5 encoding of the prompt's quoted ("glyph") text, padded
+        to `tokenizer_2_max_length` with its mask; a prompt that quotes nothing gets zeros and an all-zero mask (`glyph_ids`
+        None, or None at that sample's place in a list)."""
+        from .prompt import TextEncoder, split_ids
+        dev, dt, L = self.device, self.transformer.dtype, self.tokenizer_2_max_length
+        per = glyph_ids if isinstance(glyph_ids, list) else [glyph_ids] * batch if glyph_ids is None else None
+        if per is None:                                   # one (ids, mask) pair for the whole batch
+            ids, mask = split_ids(glyph_ids)
+            per = [(ids[b:b + 1], None if mask is None else mask[b:b + 1]) for b in range(ids.shape[0])]
+        embs, masks = [], []
+        for g in per:
+            if g is None:
+                if self.text_encoder_2 is None:
+                    d_model = self.transformer.config.text_embed_2_dim
+                else:
+                    d_model = next(p for n, p in self.text_encoder_2.named_parameters() if n.endswith("shared.weight")).shape[1]
+                embs.append(torch.zeros(1, L, d_model, device=dev, dtype=dt))
+                masks.append(torch.zeros(1, L, device=dev, dtype=torch.int64))
+                continue
+            if self.text_encoder_2 is None:
+                raise RuntimeError("HunyuanVideo15 engine: glyph text needs a text_encoder_2 (ByT5); or pass prompt_embeds_2")
+            ids, mask = split_ids(g)
+            enc = self.text_encoder_2 if isinstance(self.text_encoder_2, TextEncoder) else TextEncoder(self.text_encoder_2)
+            e, m = enc.encode(input_ids=ids, attention_mask=mask, max_sequence_length=L, pad_to_max_length=True,
+                              use_attention_mask=True, return_attention_mask=True, output_type="hidden_states",
+                              pad_with_zero=False)
+            embs.append(e.to(dev, dt))
+            masks.append(m.to(dev))
+        return torch.cat(embs, dim=0), torch.cat(masks, dim=0)
+
+    def encode_prompt(self, prompt_ids, prompt_2_ids=None, num_videos_per_prompt: int = 1):
+        """`encode_prompt` (shared/__init__.py:344-437) from token ids: `prompt_ids` = (input_ids, attention_mask) of the MLLM chat
+        template, `prompt_2_ids` = (input_ids, attention_mask) of the glyph text for ByT5, a per-sample list of those / None, or
+        None (no quoted text).  Returns (prompt_embeds, prompt_embeds_mask, prompt_embeds_2, prompt_embeds_mask_2), repeated
+        `num_videos_per_prompt` times and cast as the reference casts them (masks included)."""
+        from .prompt import split_ids
+        ids, mask = split_ids(prompt_ids)
+        if mask is None:
+            mask = torch.ones_like(ids)
+        pe, pm = self._get_mllm_prompt_embeds(ids, mask)
+        pe2, pm2 = self._get_byt5_prompt_embeds(prompt_2_ids, pe.shape[0])
+        B, n, dt = pe.shape[0], num_videos_per_prompt, self.transformer.dtype
+
+        def rep(e, m):
+            L = e.shape[1]
+            return (e.repeat(1, n, 1).view(B * n, L, -1).to(dt), m.repeat(1, n).view(B * n, L).to(dt))
+        return (*rep(pe, pm), *rep(pe2, pm2))
 
     def vae_decode(self, latents: torch.Tensor) -> torch.Tensor:
         """BaseEngine.vae_decode (engine/base_engine.py:2030-2059) after t2v.py:350 `vae.enable_tiling()`: denormalise,
@@ -93,14 +169,27 @@ class HunyuanVideo15T2VEngine(EngineLoraMixin):
         return latents
 
     @torch.no_grad()
-    def run(self, prompt_embeds, prompt_embeds_mask, prompt_embeds_2, prompt_embeds_mask_2,
+    def run(self, prompt_embeds=None, prompt_embeds_mask=None, prompt_embeds_2=None, prompt_embeds_mask_2=None,
             negative_prompt_embeds=None, negative_prompt_embeds_mask=None, negative_prompt_embeds_2=None,
             negative_prompt_embeds_mask_2=None, height: int = 480, width: int = 832, num_frames: int = 121,
             num_inference_steps: int = 50, guidance_scale: float = 6.0, guidance_rescale: float = 0.0, sigmas=None,
             seed: Optional[int] = None, generator: Optional[torch.Generator] = None, latents=None,
             return_latents: bool = False, progress_callback=None, output_type: Optional[str] = None, image=None,
-            image_embeds=None, use_light_vae: bool = False, **_ignored):
+            image_embeds=None, use_light_vae: bool = False, prompt_ids=None, prompt_2_ids=None, negative_prompt_ids=None,
+            negative_prompt_2_ids=None, num_videos_per_prompt: int = 1, **_ignored):
+        """`engine.run(prompt=…, …)` (t2v.py:60-160) from the point where the CPU tokenizers have run: `prompt_ids` (+ optional
+        `prompt_2_ids` glyph text, `negative_prompt_ids`, `negative_prompt_2_ids`) go through the MLLM and ByT5 here; or pass the
+        four `prompt_embeds*` tensors (and their negative counterparts)."""
         dev, dt = self.device, self.transformer.dtype
+        if prompt_embeds is None:
+            if prompt_ids is None:
+                raise ValueError("run() needs prompt_ids (token ids of the MLLM chat template) or prompt_embeds*")
+            _emit(progress_callback, 0.05, "Encoding prompt")
+            prompt_embeds, prompt_embeds_mask, prompt_embeds_2, prompt_embeds_mask_2 = self.encode_prompt(
+                prompt_ids, prompt_2_ids, num_videos_per_prompt)
+            if negative_prompt_ids is not None and guidance_scale > 1.0:
+                (negative_prompt_embeds, negative_prompt_embeds_mask, negative_prompt_embeds_2,
+                 negative_prompt_embeds_mask_2) = self.encode_prompt(negative_prompt_ids, negative_prompt_2_ids, num_videos_per_prompt)
         B = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
         if guidance_scale > 1.0 and negative_prompt_embeds is None and _ignored.get("negative_prompt") is not None:

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libapex_mi355.so")
+# APEX_MI355_LIB: load another build of the library (the ablation builds of tools/gemm_ring_ablate.sh); default = the in-tree one
+LIB_PATH = os.environ.get("APEX_MI355_LIB") or os.path.join(_PKG_DIR, "libapex_mi355.so")
 
 _lib = None
 

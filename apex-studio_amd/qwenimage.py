@@ -104,6 +104,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
+        self._sched = None               # modulation table of the clip in flight (begin_schedule)
         self.batch_streams = 2           # images of a batch on side-by-side HIP streams (forward); 1 = sequential
         self._bstreams: List[Any] = []
 
@@ -171,6 +172,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
     def pack(self):
         if self._packed:
             return
+        self._sched = None
         dev, dt = self.device, self.dtype
         if dev.type != "cuda" or dt != torch.bfloat16:
             raise _l.ApexMIError(f"qwenimage.mi355 needs bf16 weights on a ROCm device (got {dt} on {dev}); "
@@ -244,7 +246,40 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         return t
 
     @torch.no_grad()
-    def _forward_one(self, hidden_states, text, timestep, shapes):
+    def begin_schedule(self, timesteps):
+        """Every block's img_mod / txt_mod vectors and norm_out's, for EVERY step of a clip, from one pass over the stacked
+        projection weights (6.8 GB for the 60-block model) instead of one weight-streaming GEMV per step (flux.py
+        `begin_schedule`; here the conditioning vector depends on the timestep alone, so the conditional and the unconditional
+        pass of true CFG share a row).  `timesteps`: [n] or [n, B], the values `forward(timestep=…)` will receive (already
+        / 1000).  Rows are bit-identical to the per-step launches; `forward(attention_kwargs={"modulation_step": i})` reads
+        row i, any other call computes its own vectors as before."""
+        self.pack()
+        n = int(timesteps.shape[0])
+        ts = timesteps.to(self.device).reshape(n, -1)
+        B = ts.shape[1]
+        te = self.time_text_embed.timestep_embedder
+        t = ts.to(self.storage_dtype).float().reshape(-1)
+        h = ops.gemv(te.linear_1.weight, ops.timestep_embedding(t, 256, scale=1000.0), te.linear_1.bias, post="silu")
+        temb = ops.gemv(te.linear_2.weight, h, te.linear_2.bias)
+        self._sched = SimpleNamespace(table=ops.gemv(self._mod_w, temb, self._mod_b, pre_silu=True), temb=temb, n=n, B=B)
+        return self
+
+    def end_schedule(self):
+        self._sched = None
+        return self
+
+    def _sched_row(self, kw, b):
+        sc = self._sched
+        if sc is None or not kw or kw.get("modulation_step") is None:
+            return None
+        i = int(kw["modulation_step"])
+        if not (0 <= i < sc.n):
+            return None
+        r = i * sc.B + min(b, sc.B - 1)       # a [n] schedule serves every image of the batch
+        return sc.table[r:r + 1]
+
+    @torch.no_grad()
+    def _forward_one(self, hidden_states, text, timestep, shapes, mod_row=None):
         cfg = self.config
         dim, H = self.inner_dim, cfg.num_attention_heads
         s_img, s_txt = hidden_states.shape[0], text.shape[0]
@@ -259,28 +294,31 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.ln_modulate(text, gamma=self.txt_norm.weight, out=ws.TXTN, eps=1e-6, rms=True)
         ops.gemm(ws.TXTN, self.txt_in.weight, self.txt_in.bias, out=Xt)
 
-        te = self.time_text_embed.timestep_embedder
-        # `timestep.to(hidden_states.dtype)`, model.py:905: bf16 in production, f32 in the verification mode
-        t = timestep.to(self.storage_dtype).float().reshape(1)
-        tp = ops.timestep_embedding(t, 256, scale=1000.0)
-        h = ops.gemv(te.linear_1.weight, tp, te.linear_1.bias, post="silu")
-        ops.gemv(te.linear_2.weight, h, te.linear_2.bias, out=ws.TEMB)
-
-        n_first = self._mod_first
-        ops.gemv(self._mod_w[:n_first], ws.TEMB, self._mod_b[:n_first], out=ws.MOD[:, :n_first], pre_silu=True)
         mod_ready = None
-        if n_first < self._mod_total:   # the other blocks' modulation streams on a side stream under block 0
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                ops.gemv(self._mod_w[n_first:], ws.TEMB, self._mod_b[n_first:], out=ws.MOD[:, n_first:],
-                         pre_silu=True)
-                mod_ready = torch.cuda.Event()
-                mod_ready.record(self._side)
+        MOD = mod_row
+        if MOD is None:
+            MOD = ws.MOD
+            te = self.time_text_embed.timestep_embedder
+            # `timestep.to(hidden_states.dtype)`, model.py:905: bf16 in production, f32 in the verification mode
+            t = timestep.to(self.storage_dtype).float().reshape(1)
+            tp = ops.timestep_embedding(t, 256, scale=1000.0)
+            h = ops.gemv(te.linear_1.weight, tp, te.linear_1.bias, post="silu")
+            ops.gemv(te.linear_2.weight, h, te.linear_2.bias, out=ws.TEMB)
+
+            n_first = self._mod_first
+            ops.gemv(self._mod_w[:n_first], ws.TEMB, self._mod_b[:n_first], out=ws.MOD[:, :n_first], pre_silu=True)
+            if n_first < self._mod_total:   # the other blocks' modulation streams on a side stream under block 0
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    ops.gemv(self._mod_w[n_first:], ws.TEMB, self._mod_b[n_first:], out=ws.MOD[:, n_first:],
+                             pre_silu=True)
+                    mod_ready = torch.cuda.Event()
+                    mod_ready.record(self._side)
         rope = self._rope_table(shapes, s_txt)
 
         q_in, k_in, v_in = QKV[:, :dim], QKV[:, dim:2 * dim], QKV[:, 2 * dim:]
@@ -296,8 +334,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
                 mod_ready = None
             a = blk.attn
             base = i * 12 * dim
-            mi = lambda j: ws.MOD[0, base + j * dim: base + (j + 1) * dim]              # noqa: E731
-            mt = lambda j: ws.MOD[0, base + (6 + j) * dim: base + (7 + j) * dim]        # noqa: E731
+            mi = lambda j: MOD[0, base + j * dim: base + (j + 1) * dim]              # noqa: E731
+            mt = lambda j: MOD[0, base + (6 + j) * dim: base + (7 + j) * dim]        # noqa: E731
             # chunk order: shift1, scale1, gate1 | shift2, scale2, gate2
             ops.ln_modulate(X, mi(1), mi(0), out=XN, split=s_txt, scale2=mt(1), shift2=mt(0))
             if fuse:
@@ -325,7 +363,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             torch.cuda.current_stream().wait_event(mod_ready)
         o = len(self.transformer_blocks) * 12 * dim
         # AdaLayerNormContinuous: scale first, then shift
-        ops.ln_modulate(Xi, ws.MOD[0, o:o + dim], ws.MOD[0, o + dim:o + 2 * dim], out=XNi)
+        ops.ln_modulate(Xi, MOD[0, o:o + dim], MOD[0, o + dim:o + 2 * dim], out=XNi)
         return ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias)
 
     @ops.on_model_device
@@ -345,7 +383,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
                 isinstance(img_shapes[0][0], (list, tuple)) else img_shapes
 
         def one(b):
-            return self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes_of(b))
+            return self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes_of(b),
+                                     mod_row=self._sched_row(attention_kwargs, b))
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda or any(shapes_of(b) != shapes_of(0) for b in range(1, B)):

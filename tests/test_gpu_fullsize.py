@@ -252,6 +252,59 @@ def test_flux_1024_full_depth_two_steps_and_last_block_vs_oracle(host_threads):
     assert _rel(x_out, ref16) < 1e-3 and e_like < 6e-3 and e_true < 2 * e_emul + 2e-3
 
 
+def test_qwen_edit_1024_full_depth_two_steps_and_last_block_vs_oracle(host_threads):
+    """BASELINE config 3 at FULL depth inside the GPU tier: QwenImage-Edit-2509, 60 blocks, d 3072 = 24 x 128,
+    1024^2 target + one 1024^2 condition image (S_img 8192) + 256 text tokens (S 8448).  Two sampler steps through the EditPlus
+    engine — finite, deterministic — and the LAST block of a forward (60 deep, i.e. on activations only this depth produces)
+    against the oracle's `QwenImageTransformerBlock` fed the HIP path's own input activations and conditioning vector
+    (reference transformer/qwenimage/base/model.py:851-993; block :545-700), every one of the 8448 rows."""
+    from apex_studio_amd import ops
+    from apex_studio_amd.engine_qwenimage import QwenImageEditPlusEngine
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from oracle import qwenimage as OQ
+    L = 60
+    m = QwenImageTransformer2DModel(num_layers=L, device=DEV, dtype=BF).init_synthetic(5)
+    assert m.inner_dim == 3072 and m.config.joint_attention_dim == 3584
+    enc, cond = _randn((1, 256, 3584), 41), _randn((1, 4096, 64), 42)
+    eng = QwenImageEditPlusEngine(m)
+    kw = dict(prompt_embeds=enc, image_latents=cond, image_shapes=[(1024, 1024)], height=1024, width=1024, num_inference_steps=2,
+              seed=7, return_latents=True)
+    lat = eng.run(**kw)
+    assert lat.shape == (1, 4096, 64) and torch.isfinite(lat.float()).all() and float(lat.float().std()) > 0.1
+    assert torch.equal(eng.run(**kw), lat), "two full-depth steps must be deterministic"
+    # one forward with the residual stream captured before the last block; ln_modulate calls: the text RMS norm, then 2 per block,
+    # then norm_out
+    idx_last = 1 + 2 * (L - 1)
+    taken, n, spy, orig = _snapshots(ops, m, {idx_last: "x_in"})
+    ops.ln_modulate = spy
+    shapes = [(1, 64, 64), (1, 64, 64)]
+    try:
+        x = torch.cat([_randn((1, 4096, 64), 43), cond], dim=1)
+        m(hidden_states=x, encoder_hidden_states=enc, encoder_hidden_states_mask=torch.ones(1, 256, device=DEV),
+          timestep=torch.tensor([0.5], device=DEV), img_shapes=[shapes], txt_seq_lens=[256], return_dict=False)
+    finally:
+        ops.ln_modulate = orig
+    assert n[0] == 1 + 2 * L + 1
+    torch.cuda.synchronize()
+    ws = next(iter(m._ws.values()))
+    x_in, x_out = taken["x_in"].float().cpu(), ws.X.float().cpu()        # X after the loop = output of the last block
+    assert x_in.shape == (8448, 3072)
+    temb = ws.TEMB.float().cpu()
+    blk = OQ.QwenImageTransformerBlock(3072, 24, 128).eval()
+    blk.load_state_dict({k: v.float().cpu() for k, v in m.transformer_blocks[-1].state_dict().items()}, strict=True)
+    rope = OQ.qwen_rope_table(OQ.qwen_rope_positions(shapes, 256), (16, 56, 56))
+    with torch.no_grad():
+        t16, i16 = blk(x_in[None, 256:], x_in[None, :256], temb, rope, OL.BF16_STORAGE)
+        t32, i32 = blk(x_in[None, 256:], x_in[None, :256], temb, rope, OL.FP32)
+    ref16, ref32 = torch.cat([t16, i16], dim=1)[0], torch.cat([t32, i32], dim=1)[0]
+    d_hip, d16, d32 = x_out - x_in, ref16 - x_in, ref32 - x_in
+    e_like, e_true, e_emul = _rel(d_hip, d16), _rel(d_hip, d32), _rel(d16, d32)
+    print(f"[full depth] qwen-image-edit 1024^2 + 1 condition image, block 60 of 60 at S 8448: block contribution vs the oracle fed the "
+          f"HIP activations: rel L2 {e_like:.2e} (bf16-storage policy), {e_true:.2e} vs fp32 (the emulation itself: {e_emul:.2e}); "
+          f"output rows {_rel(x_out, ref16):.2e}")
+    assert _rel(x_out, ref16) < 1e-3 and e_like < 6e-3 and e_true < 2 * e_emul + 2e-3
+
+
 def test_wan_block_at_75600_tokens_vs_oracle_rows(host_threads):
     """BASELINE config 4's sequence inside the GPU tier: one full-width Wan block (d 5120, 40 heads, ffn 13824) over the 75 600
     tokens of a 720p x 81-frame clip + 512 text tokens.  256 query rows spread over the sequence are recomputed by the oracle

@@ -137,3 +137,63 @@ def test_qwen_edit_ids_and_pixels_to_frames(golden_dir):
         assert np.array_equal(frames, eng.run(prompt_inputs=inputs, **kw))
     other = dict(inputs, pixel_values=inputs["pixel_values"] * 0.5)
     assert not np.array_equal(frames, eng.run(prompt_inputs=other, **kw)), "the condition image must reach the prompt embedding"
+
+
+def test_hunyuan15_ids_to_frames(golden_dir):
+    """HunyuanVideo-1.5 `run(prompt_ids=…, prompt_2_ids=…)`: the MLLM (Qwen2.5-VL class, hidden state -3, the
+    template tokens cropped) and the glyph ByT5 (T5-v1.1 encoder, 256-token padding with its mask) run inside the engine as
+    `encode_prompt` does in the reference (R/src/engine/hunyuanvideo15/shared/__init__.py:145-283, 344-437); a prompt without
+    quoted text gets zero glyph embeddings with an all-zero mask.  Compared with the stage-by-stage chain, byte for byte."""
+    from apex_studio_amd import text_encoders as TE
+    from apex_studio_amd.engine_hunyuan15 import HunyuanVideo15T2VEngine
+    from apex_studio_amd.hunyuan15 import HunyuanVideo15Transformer3DModel
+    from apex_studio_amd.prompt import TextEncoder
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    from oracle import hunyuan15 as OH
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as OVae
+    from tests.test_gpu_qwen_vl import _models
+    g = torch.load(os.path.join(golden_dir, "qwen2_5_vl.pt"), weights_only=False)
+    _, vl = _models(g)
+    d_txt = g["text_config"]["hidden_size"]
+    byt5 = _init(TE.T5EncoderModel(dict(vocab_size=384, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2), device=DEV), 7)
+    cfg = dict(in_channels=65, out_channels=32, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+               num_refiner_layers=1, text_embed_dim=d_txt, text_embed_2_dim=128, image_embed_dim=64)
+    m = HunyuanVideo15Transformer3DModel(**cfg, device=DEV, dtype=BF)
+    m.load_state_dict({k: v.to(BF) for k, v in synthetic_state_dict(OH.HunyuanVideo15Transformer3DModel(**cfg), 21).items()}, strict=True)
+    vcfg = dict(in_channels=3, out_channels=3, latent_channels=32, block_out_channels=(32, 64, 64, 128, 128),
+                layers_per_block=1, spatial_compression_ratio=16, temporal_compression_ratio=4)
+    vae = AutoencoderKLHunyuanVideo15(**vcfg, device=DEV, dtype=BF)
+    vae.load_state_dict({k: v.to(BF) for k, v in vae_synthetic_state_dict(OVae(**vcfg), 23).items()}, strict=True)
+    crop, L2 = 6, 24
+    eng = HunyuanVideo15T2VEngine(m, vae=vae, vision_num_semantic_tokens=3, vision_states_dim=64, text_encoder=vl,
+                                  text_encoder_2=byt5, tokenizer_2_max_length=L2, prompt_template_encode_start_idx=crop)
+    t = g["text"]
+    ids, mask = t["ids"][:1], t["mask"][:1]
+    nids, nmask = t["ids"][1:2] if t["ids"].shape[0] > 1 else (ids + 1) % 50, t["mask"][1:2] if t["ids"].shape[0] > 1 else mask
+    gen = torch.Generator().manual_seed(8)
+    gids = torch.randint(3, 380, (1, L2), generator=gen)
+    gmask = torch.ones(1, L2, dtype=torch.long)
+    gmask[0, 15:] = 0
+    kw = dict(height=96, width=128, num_frames=5, num_inference_steps=2, guidance_scale=3.0, seed=14, output_type="np")
+    frames = eng.run(prompt_ids=(ids, mask), prompt_2_ids=(gids, gmask), negative_prompt_ids=(nids, nmask), **kw)
+    _frames_ok(frames, (1, 5, 96, 128, 3))
+    # stage by stage
+    hs = vl(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), output_hidden_states=True).hidden_states
+    pe, pm = hs[-3][:, crop:].to(BF), mask[:, crop:].to(DEV)
+    pe2, pm2 = TextEncoder(byt5).encode(input_ids=gids, attention_mask=gmask, max_sequence_length=L2, pad_to_max_length=True,
+                                        use_attention_mask=True, return_attention_mask=True, pad_with_zero=False)
+    got = eng.encode_prompt((ids, mask), (gids, gmask))
+    assert got[0].shape == (1, ids.shape[1] - crop, d_txt) and torch.equal(got[0], pe) and torch.equal(got[1].cpu(), pm.to(BF).cpu())
+    assert got[2].shape == (1, L2, 128) and torch.equal(got[2], pe2.to(DEV, BF)) and torch.equal(got[3].cpu(), pm2.to(BF))
+    nhs = vl(input_ids=nids.to(DEV), attention_mask=nmask.to(DEV), output_hidden_states=True).hidden_states
+    zeros2, zmask2 = torch.zeros(1, L2, 128, device=DEV, dtype=BF), torch.zeros(1, L2, device=DEV)
+    manual = eng.run(prompt_embeds=pe, prompt_embeds_mask=pm, prompt_embeds_2=pe2.to(DEV, BF), prompt_embeds_mask_2=pm2.to(DEV),
+                     negative_prompt_embeds=nhs[-3][:, crop:].to(BF), negative_prompt_embeds_mask=nmask[:, crop:].to(DEV),
+                     negative_prompt_embeds_2=zeros2, negative_prompt_embeds_mask_2=zmask2, **kw)
+    assert np.array_equal(frames, manual)
+    # no quoted text: zero glyph embeddings, all-zero mask (shared/__init__.py:252-262); and the glyph text must matter
+    no_glyph = eng.encode_prompt((ids, mask), None)
+    assert float(no_glyph[2].abs().sum()) == 0.0 and float(no_glyph[3].abs().sum()) == 0.0 and no_glyph[2].shape == (1, L2, 128)
+    assert not np.array_equal(frames, eng.run(prompt_ids=(ids, mask), prompt_2_ids=None, negative_prompt_ids=(nids, nmask), **kw))
+    with torch.inference_mode():                       # as the host's UniversalEngine.run calls it
+        assert np.array_equal(frames, eng.run(prompt_ids=(ids, mask), prompt_2_ids=(gids, gmask), negative_prompt_ids=(nids, nmask), **kw))

@@ -63,6 +63,40 @@ def test_qwen_forward_matches_oracle(name):
         assert torch.equal(after[k].float().cpu(), sd[k]), k
 
 
+def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors():
+    """`begin_schedule`: every step's img_mod / txt_mod / norm_out vectors from one multi-row pass over the stacked projection
+    weights; each row equals the block the per-step GEMVs write, a forward that reads the table equals the one that computes its
+    own (B = 2, batch streams), and calls outside the schedule fall back to the per-step path."""
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    cfg, shapes, s_txt = CONFIGS["mid"]
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(OQ.QwenImageTransformer2DModel(**cfg), 11).items()},
+                      strict=True)
+    n_img = sum(f * h * w for f, h, w in shapes)
+    B, n = 2, 4
+    kw = dict(hidden_states=seeded((B, n_img, 64), 51).to(DEV).to(torch.bfloat16),
+              encoder_hidden_states=seeded((B, s_txt, cfg["joint_attention_dim"]), 52).to(DEV).to(torch.bfloat16),
+              encoder_hidden_states_mask=torch.ones(B, s_txt, device=DEV), img_shapes=[shapes] * B, txt_seq_lens=[s_txt] * B,
+              return_dict=False)
+    ts = torch.linspace(1.0, 0.25, n, device=DEV).to(torch.bfloat16)
+    plain, mods = [], []
+    for i in range(n):
+        plain.append(m(timestep=ts[i].expand(B), **kw)[0].clone())
+        one = {k: (v[:1] if torch.is_tensor(v) else v[:1]) for k, v in kw.items() if k != "return_dict"}
+        m(timestep=ts[i].expand(1), return_dict=False, **one)
+        torch.cuda.synchronize()
+        mods.append(m._ws[(s_txt, n_img, torch.cuda.current_stream().cuda_stream)].MOD.clone())
+    m.begin_schedule(ts)
+    assert m._sched.table.shape == (n, m._mod_total)
+    for i in range(n):
+        assert torch.equal(m._sched.table[i:i + 1], mods[i]), i
+        assert torch.equal(m(timestep=ts[i].expand(B), attention_kwargs={"modulation_step": i}, **kw)[0], plain[i]), i
+    assert torch.equal(m(timestep=ts[1].expand(B), **kw)[0], plain[1])                                             # no index
+    assert torch.equal(m(timestep=ts[2].expand(B), attention_kwargs={"modulation_step": 7}, **kw)[0], plain[2])    # out of range
+    m.end_schedule()
+    assert torch.equal(m(timestep=ts[3].expand(B), attention_kwargs={"modulation_step": 0}, **kw)[0], plain[3])
+
+
 def test_qwen_matches_reference_wiring_golden(golden_dir):
     g = torch.load(os.path.join(golden_dir, "qwen_hybrid.pt"), weights_only=False)
     orc = OQ.QwenImageTransformer2DModel(**g["config"])

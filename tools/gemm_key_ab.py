@@ -43,7 +43,8 @@ def main():
         outs = []
         for v in VALS:
             lib.tune_set(KEY, v)
-            lib.tune_set("gemm.config", 7)
+            if KEY != "gemm.config":
+                lib.tune_set("gemm.config", 7)
             first = None
             for _ in range(6):
                 o = res.clone()
@@ -56,6 +57,8 @@ def main():
             outs.append(first)
         same[f"{M}x{N}x{K}:{epi}"] = all(bool(torch.equal(outs[0], o)) for o in outs[1:])
     lib.tune_set("gemm.config", 0)
+    if KEY == "gemm.config":          # timing below: the auto path with the tiling chosen by gemm.large
+        globals()["KEY"] = "gemm.large"
     lib.tune_set(KEY, VALS[0])
     print(json.dumps({"key": KEY, "values": VALS, "bit_identical_across_values": same}), flush=True)
     shapes = [("qkv_mlp_single", 4608, 21504, 3072, "bias"), ("proj_out_single", 4608, 3072, 15360, "gate_res"),

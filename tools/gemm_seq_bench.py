@@ -58,7 +58,14 @@ def blaslt():
 
 
 res = {}
-for name, cfg in (("cfg7", 7), ("cfg3", 3), ("cfg6", 6)) if not os.environ.get("SEQ_TUNE") else ():
+if os.environ.get("SEQ_ONLY"):          # SEQ_ONLY="7,9": just these tilings, no vendor run (ablation builds)
+    for cfg in (int(v) for v in os.environ["SEQ_ONLY"].split(",")):
+        lib.tune_set("gemm.large", cfg)
+        ms = run(ours)
+        res[f"cfg{cfg}"] = {"ms_per_step": round(ms, 2), "tflops": round(flops / ms / 1e9, 1)}
+    print(json.dumps({"flux_gemm_sequence_tflop": round(flops / 1e12, 2), **res}))
+    sys.exit(0)
+for name, cfg in (("cfg7", 7), ("cfg9_ring", 9), ("cfg10_ring5", 10), ("cfg7_b", 7), ("cfg9_ring_b", 9), ("cfg10_ring5_b", 10)) if not os.environ.get("SEQ_TUNE") else ():
     lib.tune_set("gemm.large", cfg)
     ms = run(ours)
     res[name] = {"ms_per_step": round(ms, 2), "tflops": round(flops / ms / 1e9, 1)}
