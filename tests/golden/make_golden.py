@@ -411,7 +411,7 @@ def gen_vae_hunyuan15():
     torch.save(dict(config=TINY_VAE_HY15, seed=17, z_shape=(1, 32, 3, 10, 14), z_seed=71,
                     untiled=untiled.to(torch.bfloat16), tiled=tiled.to(torch.bfloat16),
                     untiled_f32_sample=untiled[0, :, :, ::8, ::8].clone(), tiled_f32_sample=tiled[0, :, :, ::8, ::8].clone(),
-                    keys=sorted(sd.keys())), os.path.join(OUT, "vae_hunyuan15.pt"))
+                    keys=sorted(k for k in sd if k.startswith("decoder."))), os.path.join(OUT, "vae_hunyuan15.pt"))
     print("vae_hunyuan15.pt", tuple(untiled.shape), float(untiled.abs().mean()), float((tiled - untiled).abs().max()))
 
 
