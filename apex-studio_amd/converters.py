@@ -486,15 +486,135 @@ class FluxKeyConverter(KeyConverter):
         return super().convert(sd)          # NB: the shared pipeline runs WITHOUT model_keys here, as the reference's does
 
 
+class Hunyuan15KeyConverter(KeyConverter):
+    """Original HunyuanVideo-1.5 keys (Tencent release, Comfy-Org repackaging, lightx2v LoRAs keyed on it) -> the diffusers-style
+    keys of `HunyuanVideo15Transformer3DModel` (reference `HunyuanVideo15TransformerConverter`, transformer_converters.py:899-1110):
+    the rename table, then the fused `*_attn_qkv` / `*_attn.qkv` / refiner `self_attn_qkv` tensors split into q / k / v — base
+    weights, biases and LoRA-up factors by thirds along the fused dimension, LoRA-down factors / `.alpha` / scalar fp8 scales
+    shared by the three."""
+    _QKV = (("img_attn_qkv", ("attn.to_q", "attn.to_k", "attn.to_v")), ("img_attn.qkv", ("attn.to_q", "attn.to_k", "attn.to_v")),
+            ("txt_attn_qkv", ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj")),
+            ("txt_attn.qkv", ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj")))
+
+    def __init__(self):
+        super().__init__()
+        ref = "txt_in.individual_token_refiner.blocks."
+        dst = "context_embedder.token_refiner.refiner_blocks."
+        self.rename = {
+            "double_blocks": "transformer_blocks",
+            "txt_in.t_embedder.in_layer": "context_embedder.time_text_embed.timestep_embedder.linear_1",
+            "txt_in.t_embedder.out_layer": "context_embedder.time_text_embed.timestep_embedder.linear_2",
+            "txt_in.c_embedder.in_layer": "context_embedder.time_text_embed.text_embedder.linear_1",
+            "txt_in.c_embedder.out_layer": "context_embedder.time_text_embed.text_embedder.linear_2",
+            ref + "*.self_attn.proj": dst + "*.attn.to_out.0",
+            ref + "*.mlp.0": dst + "*.ff.net.0.proj",
+            ref + "*.mlp.2": dst + "*.ff.net.2",
+            "time_in.in_layer": "time_embed.timestep_embedder.linear_1",
+            "time_in.out_layer": "time_embed.timestep_embedder.linear_2",
+            "byt5_in.fc1": "context_embedder_2.linear_1",
+            "byt5_in.fc2": "context_embedder_2.linear_2",
+            "byt5_in.fc3": "context_embedder_2.linear_3",
+            "byt5_in.layernorm": "context_embedder_2.norm",
+            "cond_type_embedding": "cond_type_embed",
+            "time_in.mlp.0": "time_embed.timestep_embedder.linear_1",
+            "time_in.mlp.2": "time_embed.timestep_embedder.linear_2",
+            "time_r_in.mlp.0": "time_embed.timestep_embedder_r.linear_1",
+            "time_r_in.mlp.2": "time_embed.timestep_embedder_r.linear_2",
+            "final_layer.linear": "proj_out",
+            "final_layer.adaLN_modulation.1": "norm_out.linear",
+            "img_in.proj": "x_embedder.proj",
+            "vision_in.proj.0": "image_embedder.norm_in",
+            "vision_in.proj.1": "image_embedder.linear_1",
+            "vision_in.proj.3": "image_embedder.linear_2",
+            "vision_in.proj.4": "image_embedder.norm_out",
+            "txt_in.c_embedder.linear_1": "context_embedder.time_text_embed.text_embedder.linear_1",
+            "txt_in.c_embedder.linear_2": "context_embedder.time_text_embed.text_embedder.linear_2",
+            "txt_in.input_embedder": "context_embedder.proj_in",
+            "txt_in.t_embedder.mlp.0": "context_embedder.time_text_embed.timestep_embedder.linear_1",
+            "txt_in.t_embedder.mlp.2": "context_embedder.time_text_embed.timestep_embedder.linear_2",
+            ref + "*.adaLN_modulation.1": dst + "*.norm_out.linear",
+            ref + "*.norm1": dst + "*.norm1",
+            ref + "*.norm2": dst + "*.norm2",
+            ref + "*.mlp.fc1": dst + "*.ff.net.0.proj",
+            ref + "*.mlp.fc2": dst + "*.ff.net.2",
+            ref + "*.self_attn_proj": dst + "*.attn.to_out.0",
+            ref: dst,
+            ".img_attn_k.": ".attn.to_k.", ".img_attn_k_norm.": ".attn.norm_k.",
+            ".img_attn_q.": ".attn.to_q.", ".img_attn_q_norm.": ".attn.norm_q.",
+            ".img_attn_v.": ".attn.to_v.", ".img_attn_proj.": ".attn.to_out.0.",
+            ".txt_attn_k.": ".attn.add_k_proj.", ".txt_attn_k_norm.": ".attn.norm_added_k.",
+            ".txt_attn_q.": ".attn.add_q_proj.", ".txt_attn_q_norm.": ".attn.norm_added_q.",
+            ".txt_attn_v.": ".attn.add_v_proj.", ".txt_attn_proj.": ".attn.to_add_out.",
+            ".txt_mlp.fc1": ".ff_context.net.0.proj", ".txt_mlp.fc2": ".ff_context.net.2",
+            ".img_mlp.fc1": ".ff.net.0.proj", ".img_mlp.fc2": ".ff.net.2",
+            ".img_mod.linear": ".norm1.linear", ".txt_mod.linear": ".norm1_context.linear",
+            ".img_attn.proj": ".attn.to_out.0", ".txt_attn.proj": ".attn.to_add_out",
+            ".img_mod.lin.": ".norm1.linear.", ".txt_mod.lin.": ".norm1_context.linear.",
+            ".img_mlp.0": ".ff.net.0.proj", ".img_mlp.2": ".ff.net.2",
+            ".txt_mlp.0": ".ff_context.net.0.proj", ".txt_mlp.2": ".ff_context.net.2",
+        }
+        self.post = {"double_blocks": self._blocks, "transformer_blocks": self._blocks,
+                     "self_attn_qkv": self._refiner_qkv, "self_attn.qkv": self._refiner_qkv}
+
+    @staticmethod
+    def _shared(key: str) -> bool:          # LoRA "down" factors and alphas belong to q, k and v alike
+        return ".lora_down" in key or ".lora_A" in key or key.endswith(".alpha")
+
+    @staticmethod
+    def _thirds(key: str, t):
+        shape = tuple(t.shape)
+        dim = 0 if len(shape) != 2 or shape[0] > shape[1] else 1          # `get_chunk_dim`
+        if shape[dim] % 3:
+            raise ValueError(f"Expected QKV fused dim divisible by 3 for key='{key}', shape={shape}, chunk_dim={dim}")
+        if dim == 0:
+            return rows3(t)
+        if isinstance(t, Src):
+            raise ValueError(f"{key}: a column split of a streamed tensor is not representable")
+        return list(torch.chunk(t, 3, dim=1))
+
+    def _write(self, key: str, sd: Dict[str, Any], src: str, names: Tuple[str, str, str]) -> None:
+        t = sd.pop(key)
+        numel = 1
+        for n in tuple(t.shape):
+            numel *= n
+        if self._shared(key) or len(tuple(t.shape)) == 0 or numel == 1:
+            parts = (t, t, t)
+        else:
+            parts = self._thirds(key, t)
+        for name, part in zip(names, parts):
+            sd[key.replace(src, name).replace("double_blocks", "transformer_blocks")] = part
+
+    def _blocks(self, key: str, sd: Dict[str, Any]) -> None:
+        for src, names in self._QKV:
+            if src in key and key in sd:
+                self._write(key, sd, src, names)
+
+    def _refiner_qkv(self, key: str, sd: Dict[str, Any]) -> None:
+        if key not in sd:
+            return
+        src = "self_attn_qkv" if "self_attn_qkv" in key else "self_attn.qkv"
+        t = sd.pop(key)
+        parts = (t, t, t) if self._shared(key) else rows3(t)
+        for name, part in zip(("attn.to_q", "attn.to_k", "attn.to_v"), parts):
+            sd[key.replace(src, name)] = part
+
+
 def get_transformer_converter(model_base: str) -> KeyConverter:
     """`get_transformer_converter` (R/src/converters/convert.py:71-122) for the families on the hot path; registry keys of
     this backend ("wan.mi355" ...) select the same tables as the reference's ("wan.base" ...)."""
-    family = model_base.split(".")[0]
+    # Only the bases whose tables are ported: the reference has DIFFERENT converters for wan.vace / s2v / animate / multitalk /
+    # ovi / flashvsr ... (convert.py:71-122); sending those through the wan.base table would silently mis-rename them.
+    family, _, variant = model_base.partition(".")
+    if variant not in ("", "base", "mi355"):
+        raise NotImplementedError(f"key converter for model base {model_base!r} is not ported (have: wan / flux / hunyuanvideo15 "
+                                  ".base; qwenimage files are diffusers-keyed)")
     if family == "wan":
         return WanKeyConverter()
     if family == "flux":
         return FluxKeyConverter()
-    return NoOpKeyConverter()          # qwenimage / hunyuanvideo15 files of the manifests are diffusers-keyed
+    if family == "hunyuanvideo15":
+        return Hunyuan15KeyConverter()
+    return NoOpKeyConverter()          # qwenimage files of the manifests are diffusers-keyed
 
 
 # ---- LoRA state dicts -----------------------------------------------------------------------------------------------------

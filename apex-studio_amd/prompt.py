@@ -34,6 +34,21 @@ def split_ids(ids: Ids) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     return ids, None
 
 
+def prompt_clean(text: str, lower_case: bool = False) -> str:
+    """`TextEncoder.prompt_clean` (R/src/text_encoder/text_encoder.py:117-131): ftfy repair (when the package is present — it is
+    a pure-Python text fixer with no effect on clean ASCII), HTML entities unescaped twice, whitespace runs collapsed, stripped."""
+    import html
+    import re
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    text = re.sub(r"\s+", " ", text).strip()
+    return text.lower() if lower_case else text
+
+
 class TextEncoder:
     """`TextEncoder(model, tokenizer=None).encode(...)`: argument names and semantics of the reference's wrapper."""
 
@@ -51,7 +66,11 @@ class TextEncoder:
                num_videos_per_prompt: int = 1, dtype: Optional[torch.dtype] = None, device=None,
                add_special_tokens: Optional[bool] = True, return_attention_mask: bool = False, use_attention_mask: bool = False,
                pad_with_zero: bool = True, output_type: str = "hidden_states", hidden_states_idx: int = -1,
-               reshape_prompt_embeds: bool = True):
+               reshape_prompt_embeds: bool = True, clean_text: bool = True, lower_case: bool = False,
+               use_position_ids: bool = False, use_token_type_ids: bool = False, arrange_attention_mask: bool = False):
+        if use_position_ids or use_token_type_ids or arrange_attention_mask:
+            raise NotImplementedError("TextEncoder.encode: use_position_ids / use_token_type_ids / arrange_attention_mask are not "
+                                      "implemented (no encoder on the hot path's manifests sets them)")
         if input_ids is None:
             if text is None:
                 raise ValueError("encode() needs `text` (with a tokenizer) or `input_ids`")
@@ -59,6 +78,8 @@ class TextEncoder:
                 raise RuntimeError("encode(text=...) needs a tokenizer: pass one to TextEncoder(model, tokenizer), or pass "
                                    "input_ids / attention_mask (tokenisers stay `transformers` objects on the CPU)")
             text = [text] if isinstance(text, str) else list(text)
+            if clean_text:                                  # the reference's default (text_encoder.py:210-211)
+                text = [prompt_clean(t, lower_case=lower_case) for t in text]
             kw = dict(padding="max_length" if pad_to_max_length else "longest", max_length=max_sequence_length, truncation=True,
                       return_tensors="pt", return_attention_mask=True)
             if add_special_tokens is not None:

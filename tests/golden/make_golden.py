@@ -947,7 +947,7 @@ def gen_leaf_pins():
     print("leaf_pins.pt", sorted(out))
 
 
-from tests.golden.make_golden_specs import flux_original_spec, wan_original_spec  # noqa: E402
+from tests.golden.make_golden_specs import flux_original_spec, hunyuan15_original_spec, wan_original_spec  # noqa: E402
 
 
 def gen_convert():
@@ -1060,7 +1060,29 @@ def gen_convert():
         kw[m + ".lora_up.weight"] = (o, r)
         kw[m + ".alpha"] = ()
     run("wan_kohya_lora", lora_pipeline(tc.WanTransformerConverter), kw, 3400, wan_keys)
-    torch.save(dict(cases=cases, wan_cfg=wan_cfg, flux_cfg=flux_cfg), os.path.join(OUT, "convert_keys.pt"))
+    # 5. HunyuanVideo-1.5 (round 4; HunyuanVideo15TransformerConverter, transformer_converters.py:899-1110): an original-format
+    #    checkpoint (fused img / txt / refiner qkv), the already-converted layout, and a lightx2v-style LoRA keyed on the
+    #    original names (fused-qkv down factor + alpha shared by q, k, v; up factor split in thirds)
+    from oracle import hunyuan15 as OH
+    hy_cfg = dict(in_channels=65, out_channels=32, num_attention_heads=1, attention_head_dim=128, num_layers=2, num_refiner_layers=1,
+                  text_embed_dim=64, text_embed_2_dim=96, image_embed_dim=48)
+    hy_model = OH.HunyuanVideo15Transformer3DModel(**hy_cfg)
+    hy_keys = sorted(hy_model.state_dict().keys())
+    hy = lambda sd, mk: tc.HunyuanVideo15TransformerConverter().convert(sd, mk)        # noqa: E731
+    run("hy15_original", hy, hunyuan15_original_spec(), 4000, hy_keys)
+    run("hy15_original_no_model_keys", hy, hunyuan15_original_spec(), 4000, None)
+    run("hy15_wrapped", hy, hunyuan15_original_spec(), 4100, hy_keys, prefix="model.diffusion_model.")
+    run("hy15_already_converted", hy, {k: tuple(v.shape) for k, v in hy_model.state_dict().items()}, 4200, hy_keys)
+    hl = {}
+    for m, (o, i_) in (("double_blocks.0.img_attn_qkv", (384, 128)), ("double_blocks.1.txt_attn_qkv", (384, 128)),
+                       ("double_blocks.0.img_attn_proj", (128, 128)), ("double_blocks.1.img_mlp.fc1", (512, 128)),
+                       ("double_blocks.1.txt_mlp.fc2", (128, 512)), ("double_blocks.0.img_mod.linear", (768, 128)),
+                       ("txt_in.individual_token_refiner.blocks.0.self_attn_qkv", (384, 128)), ("final_layer.linear", (32, 128))):
+        hl[f"diffusion_model.{m}.lora_down.weight"] = (r, i_)
+        hl[f"diffusion_model.{m}.lora_up.weight"] = (o, r)
+        hl[f"diffusion_model.{m}.alpha"] = ()
+    run("hy15_original_key_lora", lora_pipeline(tc.HunyuanVideo15TransformerConverter), hl, 4300, hy_keys)
+    torch.save(dict(cases=cases, wan_cfg=wan_cfg, flux_cfg=flux_cfg, hy_cfg=hy_cfg), os.path.join(OUT, "convert_keys.pt"))
 
 
 def gen_leaf_pins2():

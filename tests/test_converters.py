@@ -30,12 +30,15 @@ def _inputs(c):
 
 
 CHECKPOINT_CASES = ["wan_original", "wan_original_no_model_keys", "wan_fp8_wrapped", "wan_fp8_kijai", "wan_already_converted",
-                    "flux_bfl", "flux_bfl_no_model_keys", "flux_partial_shard", "flux_already_converted"]
-LORA_CASES = ["wan_lightx2v_lora", "flux_bfl_lora_peft_keys", "flux_bfl_lora_base_keys", "flux_kohya_lora", "wan_kohya_lora"]
+                    "flux_bfl", "flux_bfl_no_model_keys", "flux_partial_shard", "flux_already_converted",
+                    "hy15_original", "hy15_original_no_model_keys", "hy15_wrapped", "hy15_already_converted"]
+LORA_CASES = ["wan_lightx2v_lora", "flux_bfl_lora_peft_keys", "flux_bfl_lora_base_keys", "flux_kohya_lora", "wan_kohya_lora",
+              "hy15_original_key_lora"]
 
 
 def _conv(name):
-    return CV.get_transformer_converter("wan.base" if name.startswith("wan") else "flux.base")
+    return CV.get_transformer_converter("wan.base" if name.startswith("wan") else "hunyuanvideo15.base" if name.startswith("hy15")
+                                        else "flux.base")
 
 
 def _same(out, want, name):
@@ -76,7 +79,8 @@ def test_lora_pipeline_matches_the_reference(gold, name):
     prefix strip."""
     c = gold["cases"][name]
     sd = _inputs(c)
-    out = LR.convert_lora_state_dict(sd, "wan.base" if name.startswith("wan") else "flux.base", c["model_keys"])
+    base = "wan.base" if name.startswith("wan") else "hunyuanvideo15.base" if name.startswith("hy15") else "flux.base"
+    out = LR.convert_lora_state_dict(sd, base, c["model_keys"])
     _same(out, c["out"], name)
     assert all(torch.equal(sd[k], _inputs(c)[k]) for k in sd), "the caller's state dict must not be modified"
 
@@ -95,6 +99,11 @@ def test_registry_keys_pick_the_tables():
     assert isinstance(CV.get_transformer_converter("wan.mi355"), CV.WanKeyConverter)
     assert isinstance(CV.get_transformer_converter("flux.base"), CV.FluxKeyConverter)
     assert isinstance(CV.get_transformer_converter("qwenimage.base"), CV.NoOpKeyConverter)
+    assert isinstance(CV.get_transformer_converter("hunyuanvideo15.base"), CV.Hunyuan15KeyConverter)
+    assert isinstance(CV.get_transformer_converter(""), CV.NoOpKeyConverter)
+    for other in ("wan.vace", "wan.s2v", "wan.animate", "flux.kontext"):      # the reference has other tables for these: not ported
+        with pytest.raises(NotImplementedError):
+            CV.get_transformer_converter(other)
     assert CV.kohya_unflatten("lora_unet_double_blocks_0_img_attn_qkv".replace("lora_unet", "unet")) == "unet.double_blocks.0.img_attn.qkv"
     assert CV.kohya_unflatten("unet_time_in_linear_1") == "unet.time.in.linear_1"
 

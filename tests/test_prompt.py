@@ -57,6 +57,14 @@ def test_encode_pooled_and_argument_errors():
         te.encode(input_ids=torch.tensor([[1]]), output_type="text_embeds")
     tok = lambda text, **kw: SimpleNamespace(input_ids=torch.tensor([[len(t), 1] for t in text]), attention_mask=torch.ones(len(text), 2, dtype=torch.long))  # noqa: E731
     assert TextEncoder(_FakeEncoder(), tokenizer=tok).encode(["ab", "abcd"], max_sequence_length=2).shape == (2, 2, 4)
+    # the reference's default `clean_text=True` (text_encoder.py:117-131, 210-211): entities unescaped twice, whitespace collapsed
+    from apex_studio_amd.prompt import prompt_clean
+    assert prompt_clean("  a &amp;amp; b \n\t c  ") == "a & b c" and prompt_clean("A  B", lower_case=True) == "a b"
+    te2 = TextEncoder(_FakeEncoder(), tokenizer=tok)
+    assert float(te2.encode(["  ab   cd "], max_sequence_length=2, pad_with_zero=False)[0, 0, 0]) == 5.0          # "ab cd"
+    assert float(te2.encode(["  ab   cd "], max_sequence_length=2, pad_with_zero=False, clean_text=False)[0, 0, 0]) == 10.0
+    with pytest.raises(NotImplementedError):
+        te.encode(input_ids=torch.tensor([[1]]), use_position_ids=True)
     ids, mask = split_ids({"input_ids": torch.ones(1, 2), "attention_mask": torch.zeros(1, 2)})
     assert mask is not None and split_ids(torch.ones(1, 2))[1] is None and split_ids((ids, mask))[1] is mask
 
