@@ -310,7 +310,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         # one workspace per (shape, HIP stream): two clips may run through one resident model on two streams
         key = (s_txt, s_img, torch.cuda.current_stream().cuda_stream)
         ws = self._ws.get(key)
-        if ws is not None:
+        if ws is not None and ws.shipped == ops.shipped_verification():
             return ws
         dev, dim = self.device, self.inner_dim
         H = self.config.num_attention_heads
@@ -325,7 +325,13 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             VT=torch.zeros(1, H, 128, skp, **bf), CAT=torch.empty(S, dim + mlp, **bf),
             FFH=torch.empty(S, mlp, **bf), MOD=torch.empty(1, self._mod_total, **f32),
             TEMB=torch.empty(1, dim, **f32), OUT=torch.empty(s_img, self.proj_out.out_features, **bf),
+            shipped=ops.shipped_verification(),
         )
+        if ws.shipped and self.storage_dtype == torch.float32:
+            # verification through the shipped kernels (ops.verify_through_shipped_kernels): the fused QKV epilogue and the flash
+            # attention kernel exchange q / k / v^T in bf16, as in production
+            b16 = dict(device=dev, dtype=torch.bfloat16)
+            ws.Qb, ws.Kb, ws.VTb = torch.empty(1, H, S, 128, **b16), torch.empty(1, H, S, 128, **b16), torch.zeros(1, H, 128, skp, **b16)
         self._ws = {k: v for k, v in self._ws.items() if k[:2] == key[:2]}  # one shape resident at a time
         self._ws[key] = ws
         return ws
@@ -488,13 +494,19 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         overlap = os.environ.get("APEX_FLUX_OVERLAP") == "1"
         # fused q/k/v preparation (apexmi_gemm_bf16_grouped_qkv): bit-identical to the two-pass path; `fuse_qkv = False` keeps
         # the [S, 3 dim] projection as a storage point (tests/stage_parity.py reads it)
-        fuse = self.fuse_qkv and self.storage_dtype == torch.bfloat16 and self.transformer_blocks is not None
+        mixed = self.storage_dtype == torch.float32 and ops.shipped_verification()
+        fuse = self.fuse_qkv and (self.storage_dtype == torch.bfloat16 or mixed) and self.transformer_blocks is not None
         fuse_d = fuse and len(self.transformer_blocks) > 0 and ops.qkv_fusable(
             [XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H)
         fuse_s = fuse and len(self.single_transformer_blocks) > 0 and ops.qkv_fusable(
             [XN, XN], [self.single_transformer_blocks[0]._wqkv, self.single_transformer_blocks[0].proj_mlp.weight], [0, 0], H)
         if overlap and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+        if mixed:        # the fused launches and the flash kernel behind them exchange bf16 q / k / v^T (ws.Qb ..), as in production
+            qkv_d = (ws.Qb, ws.Kb, ws.VTb) if fuse_d else (ws.Q, ws.K, ws.VT)
+            qkv_s = (ws.Qb, ws.Kb, ws.VTb) if fuse_s else (ws.Q, ws.K, ws.VT)
+        else:
+            qkv_d = qkv_s = (ws.Q, ws.K, ws.VT)
 
         def join_mod():
             nonlocal mod_ready
@@ -507,6 +519,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 join_mod()
             nblk += 1
             a = blk.attn
+            Qp, Kp, VT = qkv_d
             mi = lambda j: self._mod(MOD, ("d", i, "img"), j)  # noqa: E731
             mt = lambda j: self._mod(MOD, ("d", i, "txt"), j)  # noqa: E731
             # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -540,6 +553,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 join_mod()
             nblk += 1
             a = blk.attn
+            Qp, Kp, VT = qkv_s
             ms = lambda j: self._mod(MOD, ("s", i), j)  # noqa: E731  (shift, scale, gate)
             ops.ln_modulate(X, ms(1), ms(0), out=XN)
             if overlap:

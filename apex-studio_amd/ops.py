@@ -6,7 +6,7 @@ libapex_mi355.so.  Every wrapper refuses CPU tensors: the product path has no fa
 from __future__ import annotations
 
 import math
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
@@ -71,6 +71,24 @@ def clear_verification_caches() -> None:
     _w3_bytes = 0
 
 
+# ---- verification through the SHIPPED kernels ------------------------------------------------------------
+# The f32-storage mode replaces three kernel families by float-capable stand-ins (generic attention, the 128x128 convolution,
+# the two-pass q/k/v preparation).  With this switch on, float activations still flow everywhere else, but those three points run
+# the kernels production launches — the flash attention kernels, the slab / conv-shaped convolution tiles (with their fused norm
+# epilogue), the fused QKV epilogue — on the bf16 ROUNDING of their float operands, and their bf16 results are widened back to
+# float: the chain error then contains exactly those kernels' own storage roundings and nothing else of the bf16 path.
+_shipped_verify = False
+
+
+def verify_through_shipped_kernels(on: bool = True) -> None:
+    global _shipped_verify
+    _shipped_verify = bool(on)
+
+
+def shipped_verification() -> bool:
+    return _shipped_verify
+
+
 def tensor_version(t: torch.Tensor):
     """`t._version`, or None for an inference tensor (created under `torch.inference_mode()`, as everything inside the
     reference's `UniversalEngine.run` is — `R/src/engine/registry.py:196`): those do not track a version counter and
@@ -96,6 +114,62 @@ def _w3(w: torch.Tensor) -> torch.Tensor:
     return hit[1]
 
 
+# ---- fp8-scaled weights RESIDENT in HBM (reference FPScaledLinear, R/src/quantize/scaled_layer.py:390-552) --------------
+class Fp8Weight:
+    """A Linear weight kept as the checkpoint stores it — float8 (e4m3fn / e5m2) [N, K] + `scale_weight` (one value, or one per
+    row) — and dequantised PER CALL into a per-stream bf16 scratch right before the GEMM that reads it, as the reference's
+    `FPScaledLinear.forward` does (`_scale_and_cast_weight`, scaled_layer.py:496-549: `weight.to(bf16) * scale.to(bf16)`, then a
+    bf16 matmul).  Same dequantisation kernel as the load-time path (`apexmi_dequant_fp8_scaled`, every code point pinned by
+    tests/golden/fp_scaled.pt), so a forward is bit-identical to dequantise-at-load; the model holds half the weight bytes."""
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor):
+        if q.dtype not in (torch.float8_e4m3fn, torch.float8_e5m2) or q.dim() != 2:
+            raise TypeError(f"Fp8Weight: expected a 2-D float8 tensor, got {q.dtype} {tuple(q.shape)}")
+        self.q = q.contiguous()
+        s = scale.to(q.device).to(torch.bfloat16).reshape(-1).contiguous()
+        if s.numel() not in (1, q.shape[0]):
+            raise ValueError(f"Fp8Weight: scale has {s.numel()} values for {q.shape[0]} rows")
+        self.scale = s
+        self.shape = q.shape
+        self.device = q.device
+
+    @classmethod
+    def cat(cls, parts: Sequence["Fp8Weight"]) -> "Fp8Weight":
+        """Rows of several weights stacked (a fused q | k | v projection): per-tensor scales become per-row vectors."""
+        if len({p.q.dtype for p in parts}) != 1 or len({p.shape[1] for p in parts}) != 1:
+            raise ValueError("Fp8Weight.cat: parts must share the fp8 format and the input width")
+        q = torch.cat([p.q.view(torch.uint8) for p in parts], dim=0).view(parts[0].q.dtype)
+        s = torch.cat([p.scale if p.scale.numel() == p.shape[0] else p.scale.expand(p.shape[0]) for p in parts])
+        return cls(q, s)
+
+    def nbytes(self) -> int:
+        return self.q.numel() + 2 * self.scale.numel()
+
+    def dequant(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return dequant_fp8_scaled(self.q, self.scale, out=out)
+
+
+_fp8_scratch: dict = {}
+
+
+def _bf16_weight(w, float_acts: bool = False):
+    """`w` as the bf16 [N, K] operand of a GEMM launched next on the current stream: the tensor itself, or — for an Fp8Weight / a
+    parameter carrying one (`param._fp8`, weights.load_checkpoint_into(keep_fp8=True)) — its dequantisation into the stream's
+    scratch.  Stream order makes the reuse safe: the next dequantisation is queued behind the GEMM that read the last one."""
+    f8 = w if isinstance(w, Fp8Weight) else getattr(w, "_fp8", None)
+    if f8 is None:
+        return w
+    if float_acts:           # verification mode caches on (data_ptr, version): never hand it a recycled buffer
+        return f8.dequant()
+    key = (f8.device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _fp8_scratch.get(key)
+    n = f8.shape[0] * f8.shape[1]
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=torch.bfloat16, device=f8.device)
+        _fp8_scratch[key] = buf
+    return f8.dequant(out=buf[:n].view(f8.shape[0], f8.shape[1]))
+
+
 _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES,
         "gelu_erf": _l.EPI_BIAS_GELU_ERF, "silu": _l.EPI_BIAS_SILU, "quick_gelu": _l.EPI_BIAS_QUICK_GELU}
 
@@ -106,6 +180,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  2-D operands, last dim contiguous; a / out / residual bf16, or float32
     in the f32-storage verification mode (w and bias stay bf16)."""
     _req_act(a, "gemm.a")
+    w = _bf16_weight(w, a.dtype == torch.float32)
     _req(w, torch.bfloat16, "gemm.w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
@@ -146,6 +221,9 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
     K = w_list[0].shape[1]
     epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
     act = a_list[0].dtype
+    # resident fp8 weights: the problems of one launch need their dequantised operands side by side, so each gets its own tensor
+    w_list = [w.dequant() if isinstance(w, Fp8Weight) else w._fp8.dequant() if getattr(w, "_fp8", None) is not None else w
+              for w in w_list]
     for a, w, o in zip(a_list, w_list, out_list):
         _req_act(a, "gemm_grouped.a")
         _req(a, act, "gemm_grouped.a")
@@ -188,7 +266,7 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
 
 def qkv_fusable(a_list, w_list, row0, H: int) -> bool:
     """Would gemm_grouped_qkv() take this launch?  (bf16 storage, an even head count, the 256x256 16x16x32 tiling.)"""
-    if any(a.dtype != torch.bfloat16 for a in a_list) or H % 2:
+    if H % 2 or any(a.dtype != torch.bfloat16 and not (_shipped_verify and a.dtype == torch.float32) for a in a_list):
         return False
     return bool(_l.load().apexmi_gemm_qkv_fusable(sum(a.shape[0] for a in a_list), max(w.shape[0] for w in w_list),
                                                   w_list[0].shape[1]))
@@ -204,6 +282,20 @@ def gemm_grouped_qkv(a_list, w_list, bias_list, out_list, epilogue, is_qkv, norm
     n = len(a_list)
     K = w_list[0].shape[1]
     epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
+    if _shipped_verify and any(a.dtype == torch.float32 for a in a_list):
+        # verification through the shipped kernels: the fused problems take the bf16 rounding of their float operand (the value
+        # production stores there) and leave bf16 q / k / v^T; problems that ride along (the single block's MLP-up) keep the
+        # float path, as their own launch
+        none_ = [None] * n
+        bl, nq_, nk_ = bias_list or none_, norm_q or none_, norm_k or none_
+        keep = [i for i in range(n) if is_qkv[i]]
+        for i in range(n):
+            if not is_qkv[i]:
+                gemm(a_list[i], w_list[i], bl[i], out=out_list[i], epilogue=epis[i])
+        sel = lambda lst: [lst[i] for i in keep]          # noqa: E731
+        return gemm_grouped_qkv([to_bf16(a.contiguous()) if a.dtype == torch.float32 else a for a in sel(a_list)], sel(w_list),
+                                sel(bl), [None] * len(keep), sel(epis), [1] * len(keep), sel(nq_), sel(nk_), sel(list(row0)), H, eps,
+                                rope, qo, ko, vt)
     for a, w, o, f in zip(a_list, w_list, out_list, is_qkv):
         _req(a, torch.bfloat16, "gemm_grouped_qkv.a")
         _req(w, torch.bfloat16, "gemm_grouped_qkv.w")
@@ -383,6 +475,14 @@ def attention_prepared(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: 
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _l.load()
+    if _shipped_verify and (q.dtype == torch.float32 or out.dtype == torch.float32):
+        # verification through the shipped flash kernels: bf16 roundings of q / k / v^T in (or the fused epilogue's bf16
+        # outputs as they are), the kernel's bf16 result widened into the float buffer
+        qb, kb, vb = (to_bf16(t_) if t_.dtype == torch.float32 else t_ for t_ in (q, k, vt))
+        ob = torch.empty((B, Sq, H, D), dtype=torch.bfloat16, device=q.device)
+        attention_prepared(qb, kb, vb, ob, Sk, scale)
+        out.copy_(ob)
+        return out
     if q.dtype == torch.float32:     # f32-storage verification mode: f32 arithmetic, no bf16 probabilities
         for t_ in (k, vt, out):
             _req(t_, torch.float32, "attention operand")
@@ -828,6 +928,17 @@ def conv3d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     T, H, W, cin = x.shape
     cout, kpad = w_packed.shape
     Ho, Wo = (2 * H, 2 * W) if upsample2x else (H, W)
+    if x.dtype == torch.float32 and _shipped_verify and not (clip_frames and clip_frames != T):
+        # verification through the shipped convolution tiles (slab / conv-shaped / 128x128, whichever production picks for this
+        # shape): bf16 rounding of the float input, the kernel's bf16 result widened; the residual is added in float
+        y = to_f32(conv3d_cl(to_bf16(x), w_packed, bias, ksize, replicate=replicate, independent_frames=independent_frames,
+                             upsample2x=upsample2x))
+        if residual is not None:
+            y = add(y, residual)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
     if x.dtype == torch.float32:
         assert not (replicate and independent_frames) and not (replicate and upsample2x)
         if clip_frames and clip_frames != T:
@@ -925,7 +1036,14 @@ def conv3d_cl_norm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch
     _req_act(x, "conv3d_cl_norm.x")
     _req(gamma, torch.bfloat16, "conv3d_cl_norm.gamma")
     cout, kpad = w_packed.shape
-    # (float activations — the verification mode — always take the two-launch form: same values, no fused tile)
+    if (x.dtype == torch.float32 and _shipped_verify and gamma.numel() == cout and conv3d_cl_norm_fusable(x, cout, upsample2x)):
+        # verification through the shipped FUSED tile: conv + bias (+ bf16-rounded residual, as production holds it) + RMS norm
+        # (+ SiLU) in one epilogue on the bf16 rounding of the float input; both results widened
+        y, yn = conv3d_cl_norm(to_bf16(x), w_packed, bias, ksize, gamma, silu=silu,
+                               residual=None if residual is None else to_bf16(residual), want_raw=want_raw,
+                               upsample2x=upsample2x, independent_frames=independent_frames)
+        return (None if y is None else to_f32(y)), to_f32(yn)
+    # (float activations — the verification mode — otherwise take the two-launch form: same values, no fused tile)
     if x.dtype == torch.float32 or gamma.numel() != cout or not conv3d_cl_norm_fusable(x, cout, upsample2x):
         if gamma.numel() != cout:
             # the RMS norm divides by sqrt(channel count): a gamma shorter than the packed Cout (a Cout that is not a multiple

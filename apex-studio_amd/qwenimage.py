@@ -205,7 +205,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
     def _workspace(self, s_txt: int, s_img: int):
         key = (s_txt, s_img, torch.cuda.current_stream().cuda_stream)   # per stream: the images of a batch run side by side
         ws = self._ws.get(key)
-        if ws is not None:
+        if ws is not None and ws.shipped == ops.shipped_verification():
             return ws
         dev, dim, H = self.device, self.inner_dim, self.config.num_attention_heads
         S = s_txt + s_img
@@ -217,7 +217,11 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             Q=torch.empty(1, H, S, 128, **bf), K=torch.empty(1, H, S, 128, **bf),
             VT=torch.zeros(1, H, 128, skp, **bf), ATT=torch.empty(S, dim, **bf),
             FFH=torch.empty(S, 4 * dim, **bf), TXTN=torch.empty(s_txt, self.config.joint_attention_dim, **bf),
-            MOD=torch.empty(1, self._mod_total, **f32), TEMB=torch.empty(1, dim, **f32))
+            MOD=torch.empty(1, self._mod_total, **f32), TEMB=torch.empty(1, dim, **f32), shipped=ops.shipped_verification())
+        if ws.shipped and self.storage_dtype == torch.float32:     # verification through the shipped kernels (flux.py `_workspace`)
+            b16 = dict(device=dev, dtype=torch.bfloat16)
+            ws.Qb, ws.Kb, ws.VTb = torch.empty(1, H, S, 128, **b16), torch.empty(1, H, S, 128, **b16), torch.zeros(1, H, 128, skp, **b16)
+        self._ws.pop(key, None)
         # a few workspaces stay resident (the images of a batch on two streams; the cond / uncond passes of true CFG with their own
         # text lengths, engine_qwenimage.py): the oldest goes when a fifth shows up
         while len(self._ws) >= 4:
@@ -325,9 +329,11 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         att_v = ATT.unflatten(-1, (H, 128)).unsqueeze(0)
         # fused q/k/v preparation (apexmi_gemm_bf16_grouped_qkv) where the launch allows it: bf16 storage, 8-aligned streams,
         # >= 1024 rows; `fuse_qkv = False` keeps the [S, 3 dim] projection as a storage point (tests/stage_parity.py)
-        fuse = (getattr(self, "fuse_qkv", True) and getattr(self, "storage_dtype", torch.bfloat16) == torch.bfloat16
+        mixed = self.storage_dtype == torch.float32 and ops.shipped_verification()
+        fuse = (getattr(self, "fuse_qkv", True) and (getattr(self, "storage_dtype", torch.bfloat16) == torch.bfloat16 or mixed)
                 and len(self.transformer_blocks) > 0 and tuple(rope.shape) == (2, S, 128)
                 and ops.qkv_fusable([XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H))
+        Qp, Kp, VTp = (ws.Qb, ws.Kb, ws.VTb) if (mixed and fuse) else (ws.Q, ws.K, ws.VT)
         for i, blk in enumerate(self.transformer_blocks):
             if i == 1 and mod_ready is not None:
                 torch.cuda.current_stream().wait_event(mod_ready)
@@ -342,14 +348,14 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
                 # q/k norm + RoPE + [H, S, D] layout and V^T leave the QKV GEMM's epilogue (bit-identical to the two passes)
                 ops.gemm_grouped_qkv([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [None, None], "bias",
                                      [1, 1], [a.norm_q.weight, a.norm_added_q.weight], [a.norm_k.weight, a.norm_added_k.weight],
-                                     [s_txt, 0], H, 1e-6, rope, ws.Q[0], ws.K[0], ws.VT[0])
+                                     [s_txt, 0], H, 1e-6, rope, Qp[0], Kp[0], VTp[0])
             else:
                 ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c],
                                  [QKV[s_txt:], QKV[:s_txt]])
-                ops.qkv_prepare(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], wq=a.norm_q.weight,
+                ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VTp[0], wq=a.norm_q.weight,
                                 wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
                                 split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
-            ops.attention_prepared(ws.Q, ws.K, ws.VT, att_v, S)
+            ops.attention_prepared(Qp, Kp, VTp, att_v, S)
             ops.gemm_grouped([ATT[s_txt:], ATT[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
                              [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",
                              gate_list=[mi(2), mt(2)], residual_list=[Xi, Xt])

@@ -196,6 +196,9 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
     def pack(self):
         if self._packed:
             return
+        if getattr(self, "_fp8_bytes", 0):
+            raise _l.ApexMIError("wan.mi355: the block weights are resident fp8 (keep_fp8 load) and their bf16 storage is gone; "
+                                 "moving / re-packing such a model is not supported — construct and load again")
         dev, dt = self.device, self.dtype
         if dev.type != "cuda" or dt != torch.bfloat16:
             raise _l.ApexMIError(f"wan.mi355 needs bf16 weights on a ROCm device (got {dt} on {dev}); "
@@ -215,6 +218,47 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         self._ones = torch.ones(dim, device=dev, dtype=torch.float32)
         self._packed = True
         self._weights_changed()
+
+    # ---- fp8-scaled expert weights resident in HBM -------------------------------------------------------------
+    @staticmethod
+    def _fp8_resident_key(key: str) -> bool:
+        """Which fp8-scaled checkpoint tensors `weights.load_checkpoint_into(keep_fp8=True)` keeps as float8 + scale: the
+        Linear weights of the blocks (attention projections and FFN: 99 % of an expert's bytes).  The embedders feed GEMVs and the
+        modulation tables are f32 copies: those stay dequantised."""
+        return key.startswith("blocks.") and key.endswith(".weight") and ".norm" not in key
+
+    @torch.no_grad()
+    def _fp8_adopt(self):
+        """After a keep_fp8 load: fused projections become fused `ops.Fp8Weight`s (per-row scales), every adopted parameter's bf16
+        storage is released.  The blocks' GEMMs then dequantise per call (`ops._bf16_weight`)."""
+        self.pack()
+        dev, dt = self.device, self.dtype
+
+        def fused(parts):
+            f8 = [getattr(p, "_fp8", None) for p in parts]
+            if all(f is None for f in f8):
+                return None
+            if any(f is None for f in f8):
+                raise _l.ApexMIError("wan.mi355 keep_fp8: a fused projection mixes fp8-scaled and plain weights")
+            return ops.Fp8Weight.cat(f8)
+        n = 0
+        for blk in self.blocks:
+            a1, a2 = blk.attn1, blk.attn2
+            for name, parts in (("_wqkv", [a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]), ("_wkv2", [a2.to_k.weight, a2.to_v.weight])):
+                f = fused(parts)
+                if f is not None:
+                    setattr(blk, name, f)
+                    for p in parts:
+                        del p._fp8           # the fused record is the one that is read; the parts' views of the bf16 buffer go
+                        p.data = torch.empty(0, device=dev, dtype=dt)
+                    n += f.nbytes()
+            for p in (a1.to_out[0].weight, a2.to_q.weight, a2.to_out[0].weight, blk.ffn.net[0].proj.weight, blk.ffn.net[2].weight):
+                if getattr(p, "_fp8", None) is not None:
+                    p.data = torch.empty(0, device=dev, dtype=dt)
+                    n += p._fp8.nbytes()
+        self._fp8_bytes = n
+        torch.cuda.empty_cache()
+        return self
 
     @torch.no_grad()
     def _weights_changed(self):

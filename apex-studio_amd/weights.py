@@ -63,7 +63,7 @@ def remap_key(key: str, key_map: Optional[Dict[str, str]]) -> str:
 
 @torch.no_grad()
 def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: Optional[Dict[str, str]] = None,
-                         strict: bool = False, converter="auto") -> Tuple[List[str], List[str]]:
+                         strict: bool = False, converter="auto", keep_fp8: bool = False) -> Tuple[List[str], List[str]]:
     """Stream `files` into `model` (already on the GPU, bf16).  Returns (missing_keys, unexpected_keys) like
     `load_state_dict(strict=False)`; `strict=True` raises on either.  Shapes must match exactly, except that a
     0-d / 1-element `scale_weight` may pair with any weight (scaled_layer.py:444-493).
@@ -71,8 +71,16 @@ def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: 
     `converter`: the checkpoint key converter the files go through per file, as the reference's loader does
     (loader_mixin.py:473 `converter.convert(state_dict, model_keys)`): "auto" = the table of the model's family
     (`model._converter_base`; original-format Wan / BFL-Flux files are renamed and split on the fly, diffusers-keyed files
-    pass through the converter's own already-converted test), None = keys are taken as they are, or a converters.KeyConverter."""
+    pass through the converter's own already-converted test), None = keys are taken as they are, or a converters.KeyConverter.
+
+    `keep_fp8`: fp8-scaled weights the model can hold RESIDENT (`model._fp8_resident_key(key)`: the block Linears of
+    `wan.mi355`) stay float8 + scale in HBM — `ops.Fp8Weight`, dequantised per call as the reference's FPScaledLinear does
+    (scaled_layer.py:390-552) — instead of being dequantised once into the bf16 parameter; the parameter's bf16 storage is
+    released (`model._fp8_adopt()`).  Forwards are bit-identical to the dequantise-at-load path; half the weight bytes."""
     from . import ops
+    resident = getattr(model, "_fp8_resident_key", None) if keep_fp8 else None
+    if keep_fp8 and resident is None:
+        raise NotImplementedError(f"{type(model).__name__} has no resident-fp8 weight mode (keep_fp8=True): wan.mi355 has")
     targets: Dict[str, torch.Tensor] = dict(model.named_parameters())
     targets.update({k: v for k, v in model.named_buffers() if k not in targets})
     if any(not t.is_cuda for t in targets.values()):
@@ -104,8 +112,11 @@ def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: 
             if dst.dtype != torch.bfloat16:
                 raise TypeError(f"{key}: fp8-scaled weights load into bf16 parameters, not {dst.dtype}")
             q = src.view(torch.uint8).to(dst.device, non_blocking=True).view(src.dtype)
-            out2d = dst.data.view(dst.shape[0], -1) if dst.dim() != 2 else dst.data
-            ops.dequant_fp8_scaled(q, scales[prefix](), out=out2d)
+            if resident is not None and dst.dim() == 2 and resident(key):
+                dst._fp8 = ops.Fp8Weight(q, scales[prefix]())            # adopted after the loop (model._fp8_adopt)
+            else:
+                out2d = dst.data.view(dst.shape[0], -1) if dst.dim() != 2 else dst.data
+                ops.dequant_fp8_scaled(q, scales[prefix](), out=out2d)
         else:
             if prefix is not None and prefix in scales:
                 # the reference raises here too (`physical_dtype in (torch.uint8)`, scaled_layer.py:525)
@@ -117,6 +128,8 @@ def load_checkpoint_into(model: torch.nn.Module, files: Sequence[str], key_map: 
         hook = getattr(m, "_weights_changed", None)
         if callable(hook):
             hook()
+    if resident is not None:
+        model._fp8_adopt()
     missing = [k for k in targets if k not in seen]
     if strict and (missing or unexpected):
         raise RuntimeError(f"load_checkpoint_into: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "

@@ -536,3 +536,140 @@ def test_qwen_edit_chain_pixels_to_frames_f32_storage():
     assert _rel(lat_c, image_latents) <= TOL
     _frames("qwen-edit pixels -> encode -> 2 true-CFG steps -> decode", (lat_hip, dec_hip, frames_hip),
             (lat, dec, video_to_uint8_frames(dec.unsqueeze(2))[:, 0]))
+
+
+# ---- the same chains THROUGH THE SHIPPED KERNELS ---------------------------------------------------------------
+# `ops.verify_through_shipped_kernels(True)`: activations stay float everywhere, but the three kernel families the f32-storage mode
+# replaces by float-capable stand-ins — flash attention, the slab / conv-shaped convolution tiles with their fused norm epilogue, the
+# fused QKV epilogue — run as production launches them, on the bf16 rounding of their float operands.  What the chain then differs
+# from the fp32 oracle by is exactly those kernels' own storage roundings; the bar below is the measured one, stated.
+class _Spy:
+    """counts calls of C-ABI entry points by wrapping them on the loaded library object"""
+
+    def __init__(self, names):
+        from apex_studio_amd import lib as L
+        self.lib, self.names, self.count, self.orig = L.load(), names, {n: 0 for n in names}, {}
+
+    def __enter__(self):
+        for n in self.names:
+            fn = getattr(self.lib, n)
+            self.orig[n] = fn
+
+            def wrap(*a, _n=n, _fn=fn):
+                self.count[_n] += 1
+                return _fn(*a)
+            setattr(self.lib, n, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.orig.items():
+            setattr(self.lib, n, fn)
+
+
+@pytest.fixture
+def shipped_kernels():
+    from apex_studio_amd import ops
+    ops.verify_through_shipped_kernels(True)
+    yield ops
+    ops.verify_through_shipped_kernels(False)
+
+
+MIXED_TOL_TRANSFORMER = 4e-3     # measured 1.3e-3 .. 2.5e-3: q / k / v^T, P and the attention output are bf16 inside the shipped kernels
+MIXED_TOL_VAE = 8e-3             # measured 3e-3 .. 5e-3: every convolution's input and output pass through bf16
+
+
+def test_flux_forward_through_shipped_flash_and_fused_qkv(shipped_kernels):
+    """Flux at a size where production's launches run (1024 image + 72 text tokens, 4 heads: the 256x256 GEMM tiling with the fused
+    q/k/v epilogue, the 8-wave flash kernel), float storage, vs the fp32 oracle; the generic f32 attention kernel and the two-pass
+    q/k/v preparation must NOT be what ran."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg = dict(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=4,
+               joint_attention_dim=256, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 9)
+    orc.load_state_dict(sd, strict=True)
+    inp = dict(hidden_states=seeded((1, 1024, 64), 4), encoder_hidden_states=seeded((1, 72, 256), 5), pooled_projections=seeded((1, 64), 3),
+               timestep=torch.tensor([0.7183]), guidance=torch.tensor([4.0]), img_ids=OF.latent_image_ids(32, 32), txt_ids=torch.zeros(72, 3))
+    args = (inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"], inp["img_ids"],
+            inp["txt_ids"], inp["guidance"])
+    ref32, ref16 = orc(*args), orc(*args, policy=OL.BF16_STORAGE)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    names = ["apexmi_attn_fwd_prepared_f32", "apexmi_attn_fwd_prepared_ws", "apexmi_gemm_bf16_grouped_qkv", "apexmi_qkv_prepare_f32"]
+    names = [n for n in names if hasattr(_Spy([]).lib, n)]
+    with _Spy(names) as spy:
+        out = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0]
+        torch.cuda.synchronize()
+    assert out.dtype == F32 and next(iter(m._ws.values())).X.dtype == F32
+    assert spy.count["apexmi_attn_fwd_prepared_ws"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv"] == 2, spy.count
+    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 0 and spy.count.get("apexmi_qkv_prepare_f32", 0) == 0, spy.count
+    e, e16 = _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[shipped-kernel verification] flux 1096 tokens, float storage, shipped flash + fused QKV epilogue: rel L2 {e:.2e} vs the fp32 "
+          f"oracle (the all-bf16 emulation: {e16:.2e}; pure f32-storage mode: <= 8e-7)")
+    assert e <= MIXED_TOL_TRANSFORMER and e < e16
+    # the switch off again: the float stand-ins run, the literal bar holds
+    shipped_kernels.verify_through_shipped_kernels(False)
+    with _Spy(names) as spy:
+        out2 = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0]
+    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv"] == 0 and _rel(out2, ref32) <= TOL
+
+
+@pytest.mark.parametrize("name", ["mid"])
+def test_wan_and_qwen_forward_through_shipped_flash(name, shipped_kernels):
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    from apex_studio_amd.wan import WanTransformer3DModel
+    cfg, shapes, s_txt = QWEN_CONFIGS[name]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, 11)
+    orc.load_state_dict(sd, strict=True)
+    n_img = sum(f * h * w for f, h, w in shapes)
+    x, txt, t = seeded((1, n_img, 64), 51), seeded((1, s_txt, cfg["joint_attention_dim"]), 52), torch.tensor([0.5173])
+    ref32 = orc(x, txt, t, shapes)
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    with _Spy(["apexmi_attn_fwd_prepared_f32", "apexmi_attn_fwd_prepared_ws"]) as spy:
+        out = m(hidden_states=x.to(DEV), encoder_hidden_states=txt.to(DEV), encoder_hidden_states_mask=torch.ones(1, s_txt, device=DEV),
+                timestep=t.to(DEV), img_shapes=[shapes], txt_seq_lens=[s_txt], return_dict=False)[0]
+    e = _rel(out, ref32)
+    print(f"[shipped-kernel verification] qwen {name}: rel L2 {e:.2e} vs the fp32 oracle; attention launches {spy.count}")
+    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 0 and spy.count["apexmi_attn_fwd_prepared_ws"] == cfg["num_layers"]
+    assert out.dtype == F32 and e <= MIXED_TOL_TRANSFORMER
+    wcfg, wshape, ws_txt = WAN_CONFIGS[name]
+    worc = OW.WanTransformer3DModel(**wcfg).eval()
+    wsd = synthetic_state_dict(worc, 13)
+    worc.load_state_dict(wsd, strict=True)
+    xv, tv, tt = seeded(wshape, 61), seeded((1, ws_txt, wcfg["text_dim"]), 62), torch.tensor([417.3])
+    wref = worc(xv, tt, tv)
+    wm = WanTransformer3DModel(**wcfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    wm.load_state_dict({k: v.to(BF) for k, v in wsd.items()}, strict=True)
+    with _Spy(["apexmi_attn_fwd_prepared_f32", "apexmi_attn_fwd_prepared_ws"]) as spy:
+        wout = wm(hidden_states=xv.to(DEV), timestep=tt.to(DEV), encoder_hidden_states=tv.to(DEV), return_dict=False)[0]
+    e = _rel(wout, wref)
+    print(f"[shipped-kernel verification] wan {name}: rel L2 {e:.2e} vs the fp32 oracle; attention launches {spy.count}")
+    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 0 and spy.count["apexmi_attn_fwd_prepared_ws"] >= wcfg["num_layers"]
+    assert e <= MIXED_TOL_TRANSFORMER
+
+
+def test_wan_vae_decode_through_shipped_convolution_tiles(shipped_kernels, host_threads):
+    """A Wan VAE wide enough for production's direct-convolution (slab) kernels and their fused norm epilogue (base_dim 96: the
+    96- and 192-channel stages over >= 64 Ki positions), float storage, untiled decode of 2 latent frames at 16 x 16 vs the fp32
+    oracle; the 128x128 f32 verification kernel must carry only what production also gives to the 128x128 tiling."""
+    from oracle.vae_wan import AutoencoderKLWanDecoder
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    cfg = dict(base_dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1, temperal_downsample=[False, True, True])
+    vae = AutoencoderKLWan(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    vsd = vae_synthetic_state_dict(vae, 29)
+    vae.load_state_dict({k: v.to(BF) for k, v in vsd.items()}, strict=True)
+    vdec = AutoencoderKLWanDecoder(**cfg, latents_mean=list(vae.config.latents_mean), latents_std=list(vae.config.latents_std)).eval()
+    vdec.load_state_dict({k: v for k, v in vsd.items() if k.startswith(("decoder.", "post_quant_conv."))}, strict=True)
+    z = seeded((1, 16, 2, 16, 16), 64)                       # -> 5 frames of 128 x 128: 81 920 positions in the last stage
+    ref32, ref16 = vdec.decode(z), vdec.decode(z, policy=OL.BF16_STORAGE)
+    with _Spy(["apexmi_conv3d_cl_f32", "apexmi_conv3d_cl", "apexmi_conv3d_cl_norm", "apexmi_conv3d_cl_up2"]) as spy:
+        out = vae.decode(z.to(DEV), return_dict=False)[0]
+        torch.cuda.synchronize()
+    e, e16 = _rel(out, ref32), _rel(ref16, ref32)
+    print(f"[shipped-kernel verification] wan vae (base 96) decode, float storage through the shipped convolution tiles: rel L2 {e:.2e} "
+          f"vs the fp32 oracle (all-bf16 emulation {e16:.2e}); launches {spy.count}")
+    assert out.dtype == F32 and out.shape == ref32.shape
+    assert spy.count["apexmi_conv3d_cl_norm"] > 0 and spy.count["apexmi_conv3d_cl"] + spy.count["apexmi_conv3d_cl_up2"] > 0
+    assert e <= MIXED_TOL_VAE

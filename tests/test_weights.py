@@ -127,7 +127,7 @@ def test_streaming_loader_into_packed_flux(tmp_path):
 
 
 # ---------------------------------------------------------------- original-format files (round 3)
-def _original_files(tmp_path):
+def _original_files(tmp_path, fp8_all_block_linears=False):
     """An ORIGINAL-format Wan file whose attention projections are fp8-scaled (the Kijai layout: `blocks.N.self_attn.q.weight`
     in float8_e4m3fn + `blocks.N.self_attn.q.scale_weight` + a `scaled_fp8` marker) and a BFL-format Flux file, written as
     safetensors; returns (paths, the state dicts as real tensors, model configs)."""
@@ -141,7 +141,8 @@ def _original_files(tmp_path):
                     num_attention_heads=1, joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True,
                     axes_dims_rope=(16, 56, 56))
     wan = {k: v.to(torch.bfloat16) for k, v in spec_tensors(wan_original_spec(dim=128, ffn=256, text_dim=64, freq=256), 5000).items()}
-    for k in [k for k in wan if ".self_attn." in k and k.endswith(".weight") and wan[k].dim() == 2]:
+    pick = (lambda k: k.startswith("blocks.")) if fp8_all_block_linears else (lambda k: ".self_attn." in k)
+    for k in [k for k in wan if pick(k) and k.endswith(".weight") and wan[k].dim() == 2]:
         w = wan[k].float()
         s = (w.abs().max() / 448.0).reshape(())
         wan[k] = (w / s).to(torch.float8_e4m3fn)
@@ -197,6 +198,48 @@ def test_original_format_checkpoints_load_into_the_packed_models(tmp_path):
             if v.dtype in weights.FP8_DTYPES:
                 v = OW.dequant(v, want[k[:-len("weight")] + "scale_weight"])
             assert torch.equal(got[k].cpu(), v.to(torch.bfloat16)), k
+
+
+@pytest.mark.gpu
+def test_fp8_scaled_expert_stays_fp8_in_hbm_and_matches_dequant_at_load(tmp_path):
+    """SURVEY.md §8f-2, second half: a Kijai-keyed fp8-scaled Wan file loaded with `keep_fp8=True` keeps every
+    block Linear as float8 + scale on the device (`ops.Fp8Weight`, fused q|k|v with per-row scales) and dequantises per call, as the
+    reference's FPScaledLinear does (scaled_layer.py:390-552); no bf16 copy of those weights exists in the model, and the forward
+    equals the dequantise-at-load model's bit for bit."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import ops, weights
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from tests.golden.seeded import seeded
+    (pw, _), (wan, _), (wan_cfg, _), _ = _original_files(tmp_path, fp8_all_block_linears=True)
+    n_fp8 = sum(v.numel() for k, v in wan.items() if v.dtype == torch.float8_e4m3fn and v.dim() == 2)
+    a = WanTransformer3DModel(**wan_cfg, device=DEV, dtype=torch.bfloat16)
+    assert weights.load_checkpoint_into(a, [pw]) == ([], [])
+    b = WanTransformer3DModel(**wan_cfg, device=DEV, dtype=torch.bfloat16)
+    assert weights.load_checkpoint_into(b, [pw], keep_fp8=True) == ([], [])
+    # what is resident: fp8 bytes (+ 2 per scale), and NO bf16 storage behind the block Linears
+    lin = [p for n, p in b.named_parameters() if n.startswith("blocks.") and n.endswith(".weight") and p.dim() <= 2
+           and ".norm" not in n and "scale_shift" not in n]
+    assert lin and all(p.numel() == 0 for p in lin), [tuple(p.shape) for p in lin if p.numel()][:4]
+    assert isinstance(b.blocks[0]._wqkv, ops.Fp8Weight) and b.blocks[0]._wqkv.scale.numel() == 3 * 128
+    assert n_fp8 <= b._fp8_bytes <= n_fp8 + 8192          # + 2 bytes per scale value
+    bf16_bytes_a = sum(p.numel() * 2 for n, p in a.named_parameters() if n.startswith("blocks."))
+    bf16_bytes_b = sum(p.numel() * 2 for n, p in b.named_parameters() if n.startswith("blocks.")) + b._fp8_bytes
+    assert bf16_bytes_b < 0.56 * bf16_bytes_a
+    x, txt, t = seeded((1, 16, 3, 16, 24), 41).to(DEV), seeded((1, 20, 64), 42).to(DEV), torch.tensor([537.0], device=DEV)
+    outs = []
+    for m in (a, b, b):
+        outs.append(m(hidden_states=x.to(torch.bfloat16), timestep=t, encoder_hidden_states=txt.to(torch.bfloat16), return_dict=False)[0].clone())
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    with pytest.raises(apex_studio_amd.lib.ApexMIError):
+        b._packed = False
+        b.pack()
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    with pytest.raises(NotImplementedError):
+        weights.load_checkpoint_into(FluxTransformer2DModel(patch_size=1, in_channels=64, num_layers=1, num_single_layers=1,
+                                                            attention_head_dim=128, num_attention_heads=1, joint_attention_dim=128,
+                                                            pooled_projection_dim=64, device=DEV), [pw], keep_fp8=True)
 
 
 @pytest.mark.gpu

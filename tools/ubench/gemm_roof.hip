@@ -8,6 +8,11 @@
 // MODE 1 + fragment reads                                        -> + LDS port
 // MODE 2 + LDS-DMA from a source every workgroup shares (2 MiB: L2-resident)
 // MODE 3 + LDS-DMA from per-workgroup private regions (streams from MALL / HBM)
+// MODE 4 + LDS-DMA with the REAL addressing of the Flux single block's QKV+MLP GEMM (M 4608, N 21504, K 3072, row-major operands:
+//          a piece = 8 rows x 128 B, 6 KiB row stride; tiles walked per XCD in 6-tall groups as the kernel does, 32 concurrent
+//          tiles per XCD sharing panels through its L2)
+// MODE 5   the same tile walk with both operands PACKED tile-major (a piece = 1 KiB contiguous, the 32 pieces of a tile's K-tile
+//          adjacent): what pre-packing the weights / writing the activations in tile order would buy
 // Output per mode: TFLOP/s, effective shader clock (s_memtime cycles / s_memrealtime 100 MHz ticks), cycles per K-tile.
 // Build: hipcc --offload-arch=gfx950 -O3 -o gemm_roof gemm_roof.hip
 #include <hip/hip_runtime.h>
@@ -51,6 +56,10 @@ __global__ __launch_bounds__(512, 1) void k(const char* src, size_t region, floa
     f32x4 acc[32];
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const char* gsrc = src + (MODE == 3 ? (size_t)blockIdx.x * region : 0) + (size_t)wave * 1024 + (lane >> 3) * 128 + (lane & 7) * 16;
+    // MODE 4 / 5: A [4608 x 3072] at src, W [21504 x 3072] at src + 32 MiB; 18 x 84 tiles of 256 x 256, 48 K-tiles each
+    constexpr int NM = 18, NN = 84, NKT = 48, TILES = NM * NN;
+    const char* abase = src;
+    const char* wbase = src + (32u << 20);
     size_t goff = 0;
     const size_t gmask = region - 1;    // region is a power of two >= 64 KiB
     char* ddst = smem + 65536 + wave * 1024;
@@ -70,7 +79,24 @@ __global__ __launch_bounds__(512, 1) void k(const char* src, size_t region, floa
                 for (int j = 0; j < 2; ++j)
                     fw[nxt][((ph >> 1) & 1) * 2 + j] = *(const bf16x8*)(pw[(ph >> 1) & 1] + ((ph * 2 + j) & 3) * 2048);
             }
-            if (MODE >= 2) {                        // 2 of the 8 pieces per phase
+            if (MODE >= 4) {                        // 2 of the 8 pieces per phase: pieces 0..3 of this wave = activation rows, 4..7 = weight rows
+                const int kt = it % NKT, round = it / NKT;
+                int sidx = (int)(blockIdx.x & 7) * (TILES / 8) + (int)(blockIdx.x >> 3) + 32 * round;
+                sidx %= TILES;
+                const int width = 6 * NN, first_m = (sidx / width) * 6, pm = first_m + (sidx % width) % 6, pn = (sidx % width) / 6;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pj = ph * 2 + j;                                  // 0..7
+                    const int piece = (pj & 3) * 8 + wave;                      // 0..31: 8 rows each
+                    const char* base = pj < 4 ? abase : wbase;
+                    const int tile = pj < 4 ? pm : pn;
+                    const char* g;
+                    if (MODE == 4) g = base + ((size_t)(tile * 256 + piece * 8 + (lane >> 3)) * 6144) + kt * 128 + (lane & 7) * 16;
+                    else g = base + ((size_t)((tile * NKT + kt) * 32 + piece) * 1024) + lane * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(ddst + (pj & 7) * 8192), 16, 0, 0);
+                }
+            } else if (MODE >= 2) {                 // 2 of the 8 pieces per phase
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (goff & gmask)),
@@ -149,5 +175,7 @@ int main(int argc, char** argv) {
     run<1>("+ 24 fragment reads per 64 MFMA (operands from LDS)", src, 2u << 20, out, clk, launches);
     run<2>("+ 8 LDS-DMA pieces per 64 MFMA, shared 2 MiB source (L2)", src, 2u << 20, out, clk, launches);
     run<3>("+ 8 LDS-DMA pieces per 64 MFMA, private 8 MiB regions (MALL/HBM)", src, region, out, clk, launches);
+    run<4>("+ 8 LDS-DMA pieces per 64 MFMA, the QKV+MLP GEMM's row-major addressing (8 rows x 128 B pieces)", src, region, out, clk, launches);
+    run<5>("+ 8 LDS-DMA pieces per 64 MFMA, the same tile walk on tile-major packed operands (1 KiB contiguous pieces)", src, region, out, clk, launches);
     return 0;
 }
