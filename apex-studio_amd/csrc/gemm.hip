@@ -88,6 +88,9 @@ struct GemmGroup {
     // reference ticks (s_memrealtime) its K-loop took to clk[0] / clk[1]: sum(cycles) / sum(ticks) x 100 MHz = the effective
     // shader clock WHILE this kernel runs inside the real step (the number the "power-bound" argument of DESIGN.md rests on)
     unsigned long long* clk;
+    // EXPERIMENT (tune key gemm.wpacked, tools/gemm_wpacked_ab.py): every W operand of the launch is TILE-MAJOR packed —
+    // [N / 256][K / 64][256 rows][64] — so that an LDS-DMA piece (8 rows x 128 B) is 1 KiB contiguous; SCHED 5 only
+    int wpacked;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -957,23 +960,29 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
                 const int ra0 = (q < 8 ? q * 8 : 128 + (q - 8) * 8) + reg * 64;
                 const int rw0 = (q >> 2) * 64 + reg * 32 + (q & 3) * 8;
                 const int ra = ra0 + (lane >> 3), rw = rw0 + (lane >> 3);
-                ra_src[reg][j] = (const char*)(P.A + (int64_t)min(m0 + ra, M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) * 8));
-                rw_src[reg][j] = (const char*)(P.W + (int64_t)min(n0 + rw, N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) * 8));
+                ra_src[reg][j] = (G.wpacked & 2)
+                    ? (const char*)(P.A + ((int64_t)pm * nkt * 256 + ra) * 64 + (((lane & 7) ^ ((ra >> 1) & 7)) * 8))
+                    : (const char*)(P.A + (int64_t)min(m0 + ra, M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) * 8));
+                rw_src[reg][j] = (G.wpacked & 1)
+                    ? (const char*)(P.W + ((int64_t)pn * nkt * 256 + rw) * 64 + (((lane & 7) ^ ((rw >> 1) & 7)) * 8))
+                    : (const char*)(P.W + (int64_t)min(n0 + rw, N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) * 8));
                 ra_row[reg][j] = ra0;
                 rw_row[reg][j] = rw0;
             }
+        const int64_t w_kstep = (G.wpacked & 1) ? 256 * 128 : BK * 2;     // bytes between consecutive K-tiles of a W / A row
+        const int64_t a_kstep = (G.wpacked & 2) ? 256 * 128 : BK * 2;
         auto stage_a = [&](int buf, int kt, int reg) {
             char* base = smem + buf * CFG::STAGE;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                glds16(ra_src[reg][j] + (int64_t)kt * (BK * 2), base + ra_row[reg][j] * 128);
+                glds16(ra_src[reg][j] + (int64_t)kt * a_kstep, base + ra_row[reg][j] * 128);
             }
         };
         auto stage_w = [&](int buf, int kt, int reg) {
             char* base = smem + buf * CFG::STAGE + CFG::A_BYTES;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                glds16(rw_src[reg][j] + (int64_t)kt * (BK * 2), base + rw_row[reg][j] * 128);
+                glds16(rw_src[reg][j] + (int64_t)kt * w_kstep, base + rw_row[reg][j] * 128);
             }
         };
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -1218,6 +1227,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
+int g_wpacked = 0;    // experiment: W operands are tile-major packed (see GemmGroup::wpacked)
 int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x256 tiles) that goes out as its own launch (96 = the text
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
@@ -1239,6 +1249,7 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     G.total = t;
     G.group_m = g_group_m;
     G.clk = apexmi_clk_ptr();
+    G.wpacked = (CFG::SCHED == 5) ? g_wpacked : 0;
     hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t, G.batch), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }
@@ -1500,6 +1511,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.group_m")) g_group_m = value > 0 ? value : GROUP_M;
     else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
+    else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
     else return 1;
     return 0;
 }

@@ -574,8 +574,10 @@ def shipped_kernels():
     ops.verify_through_shipped_kernels(False)
 
 
-MIXED_TOL_TRANSFORMER = 4e-3     # measured 1.3e-3 .. 2.5e-3: q / k / v^T, P and the attention output are bf16 inside the shipped kernels
-MIXED_TOL_VAE = 8e-3             # measured 3e-3 .. 5e-3: every convolution's input and output pass through bf16
+MIXED_TOL_TRANSFORMER = TOL      # north_star's 1e-3, literally: measured 1.5e-4 (Wan, Qwen) .. 3.4e-4 (Flux) with q / k / v^T, P and the
+                                 # attention output bf16 inside the shipped kernels
+MIXED_TOL_VAE = 1.2e-2           # measured 7.2e-3 (the all-bf16 emulation: 8.0e-3): EVERY convolution's input and output pass through
+                                 # bf16 here, i.e. this is the production VAE's own rounding chain — the bar of tests/test_gpu_end_to_end.py
 
 
 def test_flux_forward_through_shipped_flash_and_fused_qkv(shipped_kernels):
