@@ -27,6 +27,8 @@ def _hipcc() -> str:
 
 
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("APEXMI_GEMM_STREAMK", "0") not in ("", "0"):
+    FLAGS.append("-DAPEXMI_GEMM_STREAMK=1")     # experiment build: the persistent stream-K GEMM launch (gemm.hip; not shipped: slower)
 if os.environ.get("APEXMI_DEBUG", "0") not in ("", "0"):
     FLAGS.append("-DAPEXMI_DEBUG")     # experiment knobs of tools/conv_prof.py / conv_ablate.py (apexmi_tune_set "conv.dbg", "conv.prof_*")
 

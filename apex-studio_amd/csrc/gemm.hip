@@ -37,7 +37,10 @@
 #include "common.h"
 
 #include <cstring>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -45,6 +48,13 @@ namespace {
 // 4 no LDS-DMA pieces, 8 no fragment reads.  0 in every shipped library.
 #ifndef APEXMI_GEMM_ABLATE
 #define APEXMI_GEMM_ABLATE 0
+#endif
+// Stream-K launches (round 4 experiment, profiles/r04_gemm_streamk_ab.log): compiled in only with -DAPEXMI_GEMM_STREAMK=1
+// (APEXMI_GEMM_STREAMK=1 python -m apex_studio_amd.build).  Correct and deterministic, but 6 .. 40 % SLOWER than the tile launch:
+// the persistent workgroups lose the dispatcher's dynamic load balancing (+8 us per tile even without a split tile) and a split
+// tile's hand-over costs ~15 us.  The shipped library does not contain the persistent path (its kernel allocates scratch).
+#ifndef APEXMI_GEMM_STREAMK
+#define APEXMI_GEMM_STREAMK 0
 #endif
 constexpr int BK = 64;
 constexpr int GROUP_M = 6;   // tiles tall per group: an XCD's 32 concurrent tiles as ~6 x 5.3 (squarer than 8 x 4: fewer panel fetches per
@@ -91,6 +101,19 @@ struct GemmGroup {
     // EXPERIMENT (tune key gemm.wpacked, tools/gemm_wpacked_ab.py): every W operand of the launch is TILE-MAJOR packed —
     // [N / 256][K / 64][256 rows][64] — so that an LDS-DMA piece (8 rows x 128 B) is 1 KiB contiguous; SCHED 5 only
     int wpacked;
+    // stream-K (round 4; SCHED 5 launches whose last round of 256 tiles is part-filled, `gemm.streamk`): the launch is 256
+    // PERSISTENT workgroups; the sk_r tiles past the last full round are cut along K into 256 equal unit ranges (see
+    // gemm_bf16_kernel), partial sums travel through sk_slab (256 KiB of f32 per workgroup) guarded by sk_flag
+    int sk_r, sk_tfull;
+    float* sk_slab;
+    unsigned* sk_flag;
+};
+// what a call of gemm_tile() does with its accumulators
+enum { TILE_FULL = 0, TILE_WRITER = 1, TILE_OWNER = 2 };
+struct SkCtx {
+    int mode, kt0, kt1;          // K-tile range [kt0, kt1) of this call
+    int cu;                      // this workgroup's slot: WRITER stores slab[cu] and raises flag[cu]
+    int nparts;                  // OWNER: adds slab[cu - 1] .. slab[cu - nparts] (the workgroups holding the tile's earlier K-tiles)
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int SCHED_>
@@ -497,18 +520,20 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
 }
 
 template <typename CFG, int EPI>
-__global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const GemmGroup G) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s, const SkCtx& sk) {
     constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
 
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    // opaque per call: the persistent (stream-K) launch calls this in a loop, and everything derived from the lane id in the
+    // epilogue would otherwise be hoisted out of that loop and held across the K-loop (+40 VGPRs: 160-220 spilled dwords)
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- tile id -> problem, (pm, pn): XCD-contiguous, grouped GROUP_M tall ----
-    int s = xcd_remap(blockIdx.x, G.total);
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUPS; ++i)
@@ -559,9 +584,15 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) {
+                acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                // opaque: inside the persistent (stream-K) item loop the allocator otherwise fails to keep the accumulators in place
+                // across the K-loop's back edge and copies all 128 registers once per K-tile (64 v_mov_b64: +50 % time)
+                asm volatile("" : "+v"(acc16[i][j]));
+            }
     }
-    const int nkt = G.K / BK;
+    const int nkt_all = G.K / BK;
+    const int nkt = (CFG::SCHED == 5) ? sk.kt1 - sk.kt0 : nkt_all;    // K-tiles of THIS call (stream-K segments: SCHED 5 only)
     unsigned long long clk_c0 = 0, clk_r0 = 0;
     if (G.clk != nullptr) {          // kernel-uniform
         clk_c0 = __builtin_readcyclecounter();
@@ -961,16 +992,25 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
                 const int rw0 = (q >> 2) * 64 + reg * 32 + (q & 3) * 8;
                 const int ra = ra0 + (lane >> 3), rw = rw0 + (lane >> 3);
                 ra_src[reg][j] = (G.wpacked & 2)
-                    ? (const char*)(P.A + ((int64_t)pm * nkt * 256 + ra) * 64 + (((lane & 7) ^ ((ra >> 1) & 7)) * 8))
+                    ? (const char*)(P.A + ((int64_t)pm * nkt_all * 256 + ra) * 64 + (((lane & 7) ^ ((ra >> 1) & 7)) * 8))
                     : (const char*)(P.A + (int64_t)min(m0 + ra, M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) * 8));
                 rw_src[reg][j] = (G.wpacked & 1)
-                    ? (const char*)(P.W + ((int64_t)pn * nkt * 256 + rw) * 64 + (((lane & 7) ^ ((rw >> 1) & 7)) * 8))
+                    ? (const char*)(P.W + ((int64_t)pn * nkt_all * 256 + rw) * 64 + (((lane & 7) ^ ((rw >> 1) & 7)) * 8))
                     : (const char*)(P.W + (int64_t)min(n0 + rw, N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) * 8));
                 ra_row[reg][j] = ra0;
                 rw_row[reg][j] = rw0;
             }
         const int64_t w_kstep = (G.wpacked & 1) ? 256 * 128 : BK * 2;     // bytes between consecutive K-tiles of a W / A row
         const int64_t a_kstep = (G.wpacked & 2) ? 256 * 128 : BK * 2;
+        if (sk.kt0) {                                       // a stream-K segment starts inside the tile's K range
+#pragma unroll
+            for (int reg = 0; reg < 2; ++reg)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ra_src[reg][j] += (int64_t)sk.kt0 * a_kstep;
+                    rw_src[reg][j] += (int64_t)sk.kt0 * w_kstep;
+                }
+        }
         auto stage_a = [&](int buf, int kt, int reg) {
             char* base = smem + buf * CFG::STAGE;
 #pragma unroll
@@ -1167,6 +1207,50 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
         }
     }
 
+    // ---- stream-K hand-over (SCHED 5): partial sums in accumulator order, 16 bytes per lane, fully coalesced ----
+    // CDNA guide §6 Guideline 16, the fence-free form: write-through (sc1) slab stores -> every wave vmcnt(0) -> workgroup barrier
+    // -> ONE lane raises the flag (relaxed, agent scope); the owner polls relaxed, then reads the slab with sc1 loads.  No
+    // release / acquire fence: an agent-scope release writes the XCD's whole L2 back (every dirty output line of the launch) and
+    // cost ~20 us per hand-over here.  Slab addressing through a buffer descriptor: one VGPR offset (16 * tid) + a scalar offset per
+    // 8 KiB row, instead of thirty-two 64-bit address pairs (which the allocator spilled the accumulators for).
+    if constexpr (CFG::SCHED == 5 && APEXMI_GEMM_STREAMK) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+        if (sk.mode == TILE_WRITER) {
+            auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(G.sk_slab + (size_t)sk.cu * 65536), 0, 262144, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc16[i][j]), rs, tid * 16, (i * 8 + j) * 8192, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(G.sk_flag + sk.cu, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (sk.mode == TILE_OWNER) {
+            if (tid == 0)
+                for (int p = 1; p <= sk.nparts; ++p)
+                    while (__hip_atomic_load(G.sk_flag + sk.cu - p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+            // fixed order: own K range + the range before it + the one before that (deterministic, launch to launch)
+            for (int p = 1; p <= sk.nparts; ++p) {
+                auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(G.sk_slab + (size_t)(sk.cu - p) * 65536), 0, 262144, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {           // eight 16-byte loads in flight at a time (the accumulators hold 128 VGPRs)
+                    u32x4_ v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (i * 8 + j) * 8192, 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc16[i][j] += __builtin_bit_cast(f32x4_t, v[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            if (tid == 0)            // every slab has exactly one reader: lower its flag for the next launch on this stream
+                for (int p = 1; p <= sk.nparts; ++p) __hip_atomic_store(G.sk_flag + sk.cu - p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
     // ---- epilogue ----
     if constexpr (CFG::SCHED == 5 || CFG::SCHED >= 7) {
         if constexpr (EPI == APEXMI_EPI_BIAS) {
@@ -1195,6 +1279,94 @@ __global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const Gemm
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt)
         store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
+}
+
+// The launch.  Normally one workgroup per tile.  STREAM-K (G.sk_r > 0, SCHED 5): 256 persistent workgroups, 32 per XCD.
+// Launches whose tile count is not a multiple of the 256 CUs end in a part-filled round — 216 tiles (attention-out, FF-down,
+// the single block's proj_out: 42 % of the Flux step's GEMM flops) leave 40 CUs idle for the whole launch, 648 tiles (QKV of a
+// double block) run a third round at 53 % — and the live clock probe shows the GEMM is NOT power-bound (2.05 GHz), so those idle
+// CUs are lost time, not clock given back.  Here the sk_r tiles past the last full round are shared out by K: XCD x takes
+// r_x = sk_r / 8 (+1) of them, its 32 workgroups cut the r_x * nkt K-tiles into 32 equal unit ranges.  A workgroup's range is
+// [tail of a tile begun by the workgroup before it | whole tiles | head of a tile the next workgroup finishes]:
+//   * the HEAD (a tile whose last K-tiles lie in a higher workgroup) is computed FIRST and leaves as an f32 slab + flag (WRITER);
+//   * then whole tiles of the range and the workgroup's tiles of the full rounds (ordinary epilogue);
+//   * the TAIL (the tile's last K-tiles are here) is computed LAST, adds the slabs of the one or two workgroups before it, and runs
+//     the epilogue (OWNER).
+// An owner only ever waits for workgroups with a LOWER block id on its own XCD (dispatched before it, slab written at the start of
+// their work), so the hand-over is deadlock-free whatever else shares the chip, slabs stay in the XCD's L2, and the f32 sum order
+// (own range, then the ranges before it) is fixed: results are deterministic; they differ from the one-workgroup-per-tile launch
+// by f32 summation order only.
+template <typename CFG, int EPI>
+__global__ __launch_bounds__(CFG::NT, CFG::OCC) void gemm_bf16_kernel(const GemmGroup G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = G.K / BK;
+    SkCtx sk{TILE_FULL, 0, nkt, 0, 0};
+    if constexpr (CFG::SCHED != 5) {
+        gemm_tile<CFG, EPI>(G, smem, xcd_remap(blockIdx.x, G.total), sk);
+    } else {
+        if (!APEXMI_GEMM_STREAMK || (G.sk_r <= 0 && G.sk_tfull <= 0)) {
+            gemm_tile<CFG, EPI>(G, smem, xcd_remap(blockIdx.x, G.total), sk);
+            return;
+        }
+        // The work list of this workgroup is RE-DERIVED from (block id, item index) at the top of every iteration, behind an opaque
+        // copy of the block id: a dozen scalars kept live across the K-loop instead cost SGPR spills into VGPR lanes and, with
+        // them, VGPR spills inside the K-loop (whose scratch loads would also break the counted vmcnt waits).
+        for (int it = 0;; ++it) {
+            int bid = blockIdx.x;
+            asm volatile("" : "+s"(bid));
+            const int x = bid & 7, i = bid >> 3;                                // XCD, workgroup within it (dispatch order)
+            const int rx = G.sk_r / 8 + (x < G.sk_r % 8 ? 1 : 0);               // remainder tiles of this XCD ...
+            const int r0 = G.sk_tfull + x * (G.sk_r / 8) + min(x, G.sk_r % 8);  // ... starting at this sequence index
+            const int64_t units = (int64_t)rx * nkt;
+            auto ustart = [&](int w) { return (int)((units * w) / 32); };
+            const int u0 = ustart(i), u1 = ustart(i + 1);
+            int j0 = 0, j1 = -1;                                                // first / last remainder tile the range touches
+            if (u1 > u0) {
+                j0 = u0 / nkt;
+                j1 = (u1 - 1) / nkt;
+            }
+            // in order: [head -> WRITER] [whole tiles of the range] [its tiles of the full rounds] [tail -> OWNER]
+            const bool has_head = u1 > u0 && u1 < (j1 + 1) * nkt;               // the range's LAST tile is finished by a higher workgroup
+            const bool has_tail = u1 > u0 && u0 > j0 * nkt && !(has_head && j0 == j1);   // its FIRST tile was begun by lower ones
+            const int w_lo = j0 + ((u1 > u0 && u0 > j0 * nkt) ? 1 : 0);         // whole tiles of the range: [w_lo, w_hi]
+            const int w_hi = j1 - (has_head ? 1 : 0);
+            const int n_whole = max(w_hi - w_lo + 1, 0);
+            const int per_xcd = G.sk_tfull / 8;
+            const int n_full = per_xcd > i ? (per_xcd - i + 31) / 32 : 0;
+            const int n_items = (has_head ? 1 : 0) + n_whole + n_full + (has_tail ? 1 : 0);
+            if (it >= n_items) break;
+            int k = it, tile;
+            sk.mode = TILE_FULL;
+            sk.kt0 = 0;
+            sk.kt1 = nkt;
+            sk.nparts = 0;
+            sk.cu = x * 32 + i;
+            if (has_head && k == 0) {
+                sk.mode = TILE_WRITER;
+                sk.kt0 = max(u0, j1 * nkt) - j1 * nkt;
+                sk.kt1 = u1 - j1 * nkt;
+                tile = r0 + j1;
+            } else {
+                k -= has_head ? 1 : 0;
+                if (k < n_whole) {
+                    tile = r0 + w_lo + k;
+                } else if (k < n_whole + n_full) {
+                    tile = x * per_xcd + i + 32 * (k - n_whole);
+                } else {
+                    sk.mode = TILE_OWNER;
+                    sk.kt0 = u0 - j0 * nkt;
+                    sk.kt1 = min(u1, (j0 + 1) * nkt) - j0 * nkt;
+                    for (int w = i - 1; w >= 0 && sk.nparts < 3; --w) {         // workgroups holding K-tiles [0, kt0) of tile j0
+                        if (ustart(w + 1) <= j0 * nkt) break;
+                        ++sk.nparts;
+                    }
+                    tile = r0 + j0;
+                }
+            }
+            if (it) __syncthreads();            // the staging LDS (and the QKV epilogue's scratch) of the previous item is free
+            gemm_tile<CFG, EPI>(G, smem, tile, sk);
+        }
+    }
 }
 
 // ---- exact bf16 split of an f32 operand (f32-storage verification mode) ------------------------------------------
@@ -1232,6 +1404,35 @@ int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x2
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
+// stream-K workspace: 256 slabs of 256 x 256 f32 + 256 flags per (device, stream) — launches on different streams may overlap and
+// must not share slabs; allocated (and the flags zeroed) at the first stream-K launch on that stream, kept for the process
+int g_streamk = 1;    // tune key gemm.streamk (APEXMI_GEMM_STREAMK builds only): 0 off | 1 launches with 88..232 tiles in their last round | 2 persistent always
+struct SkWorkspace {
+    float* slab;
+    unsigned* flag;
+};
+static int sk_workspace(hipStream_t stream, SkWorkspace* out) {
+    static std::mutex mu;
+    static std::vector<std::tuple<int, hipStream_t, SkWorkspace>> all;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : all)
+        if (std::get<0>(e) == dev && std::get<1>(e) == stream) {
+            *out = std::get<2>(e);
+            return 0;
+        }
+    SkWorkspace w{nullptr, nullptr};
+    if (hipMalloc((void**)&w.slab, (size_t)256 * 65536 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&w.flag, 256 * sizeof(unsigned)) != hipSuccess || hipMemset(w.flag, 0, 256 * sizeof(unsigned)) != hipSuccess) {
+        apexmi_set_error("gemm_bf16: stream-K workspace allocation failed");
+        return 1;
+    }
+    all.emplace_back(dev, stream, w);
+    *out = w;
+    return 0;
+}
+
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     static uint64_t attr_set = 0;
@@ -1250,6 +1451,26 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     G.group_m = g_group_m;
     G.clk = apexmi_clk_ptr();
     G.wpacked = (CFG::SCHED == 5) ? g_wpacked : 0;
+    G.sk_r = 0;
+    G.sk_tfull = 0;
+    G.sk_slab = nullptr;
+    G.sk_flag = nullptr;
+    if constexpr (CFG::SCHED == 5 && APEXMI_GEMM_STREAMK) {
+        // stream-K when the last round of 256 tiles is part-filled enough to matter and full enough that a tile is shared by at
+        // most four workgroups (the owner adds at most three slabs): 11..29 remainder tiles per XCD
+        const int r = t % 256;
+        const bool forced = g_streamk == 2 && G.batch == 1 && t >= 256 && (r == 0 || (r >= 88 && r <= 232));   // experiment: persistent always
+        if (forced || (g_streamk && G.batch == 1 && r >= 88 && r <= 232 && G.K / BK >= 8)) {
+            SkWorkspace w;
+            if (sk_workspace(stream, &w)) return 1;
+            G.sk_r = r;
+            G.sk_tfull = t - r;
+            G.sk_slab = w.slab;
+            G.sk_flag = w.flag;
+            hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(256, 1), dim3(CFG::NT), CFG::LDS, stream, G);
+            return apexmi_check_launch("gemm_bf16");
+        }
+    }
     hipLaunchKernelGGL((gemm_bf16_kernel<CFG, EPI>), dim3(t, G.batch), dim3(CFG::NT), CFG::LDS, stream, G);
     return apexmi_check_launch("gemm_bf16");
 }
@@ -1512,6 +1733,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
     else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
+    else if (!strcmp(key, "gemm.streamk")) g_streamk = value;
     else return 1;
     return 0;
 }
