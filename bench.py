@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip (28 steps + decode) timing")
     ap.add_argument("--no-mod-table", action="store_true",
-                    help="A/B: per-step AdaLN GEMVs instead of the per-clip modulation table (flux)")
+                    help="A/B: per-step AdaLN GEMVs instead of the per-clip modulation table (flux, qwen)")
     ap.add_argument("--clip", action="store_true", help="wan: also time a whole 30-step clip + decode")
     ap.add_argument("--queue-wan-steps", type=int, default=30)
     ap.add_argument("--no-shared-weights", action="store_true",
@@ -335,13 +335,25 @@ def build_qwen(args, dev, rank, total):
 
     ts_box = {"ts": reset(total)}
 
+    sched_box = {"i0": None}
+
+    def begin(i0, i1):
+        """`QwenImageEditPlusEngine.base_denoise` entering its loop: the modulation table of steps [i0, i1) (inside the timed region)."""
+        if args.no_mod_table or i1 <= i0:
+            sched_box["i0"] = None
+            return
+        model.begin_schedule(torch.stack([t.expand(1).to(latents.dtype) / 1000 for t in ts_box["ts"][i0:i1]]))
+        sched_box["i0"] = i0
+
     def step(i, lat):
         t = ts_box["ts"][i]
         x = torch.cat([lat, cond], dim=1)
+        akw = None if sched_box["i0"] is None else {"modulation_step": i - sched_box["i0"]}
         v = model(hidden_states=x, encoder_hidden_states=enc, encoder_hidden_states_mask=None,
                   timestep=t.expand(1).to(lat.dtype) / 1000, img_shapes=shapes, txt_seq_lens=[256],
-                  return_dict=False)[0][:, :4096]
+                  attention_kwargs=akw, return_dict=False)[0][:, :4096]
         return sched.step(v, t, lat, return_dict=False)[0]
+    step.begin = begin
 
     label = ("qwenimage-edit-2509 1024x1024 + one 1024x1024 condition image, denoise step (60 MM-DiT blocks, "
              "S_img 8192 + S_txt 256, B=1) + FlowMatch-Euler step")

@@ -11,7 +11,7 @@ W=${WORKLOAD:-flux}                 # flux | qwen
 OUT=$R/gpurun_out/pmc_gemm_$W
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=$([ "$W" = flux ] && echo r03_pmc_gemm || echo r03_pmc_gemm_$W)
+TAG=$([ "$W" = flux ] && echo ${ROUND:-r04}_pmc_gemm || echo ${ROUND:-r04}_pmc_gemm_$W)
 export TAG W
 CMD="python $R/bench.py --workload $W --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
 T=${PROF_TIMEOUT:-420}
