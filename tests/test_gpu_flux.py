@@ -242,6 +242,45 @@ def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors(B):
     assert torch.equal(m(return_dict=False, timestep=ts[4].expand(B), joint_attention_kwargs={"modulation_step": 0}, **g)[0], plain[4])
 
 
+def test_engine_loop_with_true_cfg_reads_two_modulation_tables():
+    """`FluxT2IEngine.base_denoise` with a negative prompt (true CFG): the engine schedules one table per pooled vector (conditional /
+    unconditional) before the loop; the latents must equal the same loop driven through a transformer WITHOUT the hook (the per-step
+    GEMVs), bit for bit."""
+    from apex_studio_amd.engine_flux import FluxT2IEngine
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["mid"]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 7).items()}, strict=True)
+
+    class NoHook:                       # what the reference's own transformer class looks like to the engine
+        config, device, dtype = m.config, m.device, m.dtype
+
+        def __call__(self, *a, **k):
+            assert "joint_attention_kwargs" not in k
+            return m(*a, **k)
+
+        def cache_context(self, name):
+            return m.cache_context(name)
+    inp = _inputs(cfg, hw, s_txt)
+    d = lambda t: t.to(DEV).to(torch.bfloat16)                                                                  # noqa: E731
+    lat = d(seeded((1, hw[0] * hw[1], cfg["in_channels"]), 61))
+    pe, ne = d(inp["encoder_hidden_states"]), d(seeded((1, s_txt, cfg["joint_attention_dim"]), 62))
+    pp, npool = d(inp["pooled_projections"]), d(seeded((1, cfg["pooled_projection_dim"]), 63))
+    outs = []
+    for tr in (m, NoHook()):
+        eng = FluxT2IEngine(tr)
+        ts = eng.scheduler.set_timesteps(sigmas=torch.linspace(1.0, 0.25, 4).tolist(), mu=0.8, device=DEV)
+        eng.scheduler.set_begin_index(0)
+        outs.append(eng.base_denoise(latents=lat, timesteps=ts, guidance=torch.tensor([3.5], device=DEV), prompt_embeds=pe,
+                                     pooled_prompt_embeds=pp, text_ids=inp["txt_ids"].to(DEV), latent_ids=inp["img_ids"].to(DEV),
+                                     negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npool,
+                                     negative_text_ids=inp["txt_ids"].to(DEV), true_cfg_scale=2.5, use_cfg_guidance=True).clone())
+        if tr is m:
+            assert m._sched == {}, "the engine must release the tables when the loop ends"
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 def test_forward_under_inference_mode_matches_no_grad():
     """The host drives the model inside `@torch.inference_mode()` (R/src/engine/registry.py:196): ids built there are inference
     tensors, which carry no `_version` — the rotary-table cache must not read it.  Same bits as under no_grad,
