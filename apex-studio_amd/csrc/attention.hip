@@ -883,6 +883,61 @@ __global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __r
     }
 }
 
+// ---- f32-storage verification form of the text encoders' attention (apexmi_attn_fwd_bias_f32): one workgroup per (query row,
+// head), float q / k / v / out, f32 arithmetic throughout (no bf16 probabilities), the same score / mask rules as
+// softmax_bias_rows_kernel: p = softmax(q.k * scale + bias[h, row, :]) over the kept keys (key-padding mask, causal limit,
+// segment ids), grouped-query key heads.  Scores of the row live in LDS (Sk floats).  Not a performance path.
+__global__ __launch_bounds__(256) void attn_bias_rows_f32_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                                 int64_t ldk, const float* __restrict__ v, int64_t ldv,
+                                                                 float* __restrict__ out, int64_t ldo, int H, int Hkv, int Sq, int Sk,
+                                                                 int D, float scale, const float* __restrict__ bias,
+                                                                 const uint8_t* __restrict__ keep, const int* __restrict__ seg,
+                                                                 int causal) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    float* sc = (float*)smem_;                 // [Sk]
+    float* qs = sc + Sk;                        // [D]
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, h = blockIdx.y, hk = h / (H / Hkv);
+    for (int d = tid; d < D; d += 256) qs[d] = q[(int64_t)row * ldq + h * D + d];
+    __syncthreads();
+    const int lim = causal ? min(Sk, row + 1) : Sk;
+    const int myseg = seg ? seg[row] : 0;
+    const float* br = bias ? bias + ((int64_t)h * Sq + row) * Sk : nullptr;
+    float mx = -1.0e30f;
+    for (int c = tid; c < Sk; c += 256) {
+        float s = -1.0e30f;
+        if (c < lim && !(keep && !keep[c]) && !(seg && seg[c] != myseg)) {
+            const float* kr = k + (int64_t)c * ldk + hk * D;
+            float acc = 0.0f;
+            for (int d = 0; d < D; ++d) acc = fmaf(qs[d], kr[d], acc);
+            s = acc * scale + (br ? br[c] : 0.0f);
+        }
+        sc[c] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int c = tid; c < Sk; c += 256) {
+        const float e = sc[c] > -1.0e29f ? expf(sc[c] - mx) : 0.0f;
+        sc[c] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float tot = red[4] + red[5] + red[6] + red[7];
+    const float inv = tot > 0.0f ? 1.0f / tot : 0.0f;
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.0f;
+        for (int c = 0; c < Sk; ++c) acc = fmaf(sc[c], v[(int64_t)c * ldv + hk * D + d], acc);
+        out[(int64_t)row * ldo + h * D + d] = acc * inv;
+    }
+}
+
 // ---- generic fallback: any D <= 256, bf16 / f16 / f32, strided views; one workgroup per query row.
 // Exists so the operator survives the reference's backend verification probe
 // (B,H,S,D = 1,2,8,64 fp16; attention/functions.py:1999-2251) and odd head sizes (VAE C = 384 is
@@ -1324,6 +1379,19 @@ extern "C" int apexmi_gemm_bf16_batched(const void* A, int64_t lda, int64_t stri
                                         int N, int K, int epilogue, apexmi_stream_t stream);
 
 extern "C" size_t apexmi_attn_bias_workspace_bytes(int H, int Sq, int Sk, int D) { return attn_bias_bytes(H, Sq, Sk, D); }
+
+extern "C" int apexmi_attn_fwd_bias_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                                        int64_t ldo, int H, int Hkv, int Sq, int Sk, int D, float scale, const float* bias,
+                                        const uint8_t* keep, const int* seg, int causal, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(q && k && v && out, "attn_fwd_bias_f32: null operand");
+    APEXMI_REQUIRE(H > 0 && Hkv > 0 && H % Hkv == 0 && Sq > 0 && Sk > 0 && D > 0, "attn_fwd_bias_f32: bad shape");
+    const size_t lds = (size_t)(Sk + D) * sizeof(float);
+    APEXMI_REQUIRE(lds <= 64 * 1024, "attn_fwd_bias_f32: Sk=%d exceeds the verification kernel's LDS row (16 K keys)", Sk);
+    hipLaunchKernelGGL(attn_bias_rows_f32_kernel, dim3(Sq, H), dim3(256), lds, stream, q, ldq, k, ldk, v, ldv, out, ldo, H, Hkv, Sq, Sk,
+                       D, scale, bias, keep, seg, causal);
+    return apexmi_check_launch("attn_fwd_bias_f32");
+}
 
 extern "C" int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                     void* out, int64_t ldo, int H, int Hkv, int Sq, int Sk, int D, float softmax_scale,

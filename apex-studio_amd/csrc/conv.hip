@@ -1538,10 +1538,16 @@ __global__ __launch_bounds__(256) void tanh_clamp_kernel(const bf16_t* __restric
     *(u32x4*)(y + idx * 8) = pack8(v);
 }
 
+// f32-storage verification mode: the same function without the bf16 rounding
+__global__ __launch_bounds__(256) void tanh_clamp_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float inv) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) y[idx] = 3.0f * tanhf(x[idx] * inv * (1.0f / 3.0f));
+}
+
 // TAEHV output (tae/model.py:318-333): clamp to [lo, hi], pixel-shuffle by r (channel c r^2 + i r + j -> pixel
 // (h r + i, w r + j) of image channel c) and drop the first t0 frames: x [T, H, W, Cs] -> y [C, T - t0, H r, W r]
-template <int R>
-__global__ __launch_bounds__(256) void pixel_shuffle_clamp_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int T,
+template <int R, typename TS = bf16_t>
+__global__ __launch_bounds__(256) void pixel_shuffle_clamp_kernel(const TS* __restrict__ x, TS* __restrict__ y, int T,
                                                                   int H, int W, int Cs, int C, int t0, float lo, float hi) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n = (int64_t)C * (T - t0) * H * W;
@@ -1552,14 +1558,14 @@ __global__ __launch_bounds__(256) void pixel_shuffle_clamp_kernel(const bf16_t* 
     r /= H;
     const int t = (int)(r % (T - t0));
     const int c = (int)(r / (T - t0));
-    const bf16_t* src = x + ((((int64_t)(t + t0) * H + h) * W + w) * Cs + c * (R * R));
-    bf16_t* dst = y + (((int64_t)c * (T - t0) + t) * (H * R) + (int64_t)h * R) * ((int64_t)W * R) + (int64_t)w * R;
+    const TS* src = x + ((((int64_t)(t + t0) * H + h) * W + w) * Cs + c * (R * R));
+    TS* dst = y + (((int64_t)c * (T - t0) + t) * (H * R) + (int64_t)h * R) * ((int64_t)W * R) + (int64_t)w * R;
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const float v = fminf(fmaxf(bf16_to_f32(src[i * R + j]), lo), hi);
-            dst[(int64_t)i * W * R + j] = f32_to_bf16(v);
+            const float v = fminf(fmaxf(load1<TS>(src + i * R + j), lo), hi);
+            store1<TS>(dst + (int64_t)i * W * R + j, v);
         }
 }
 
@@ -2002,21 +2008,42 @@ extern "C" int apexmi_tanh_clamp(const void* x, void* y, int64_t n, float inv_sc
     return apexmi_check_launch("tanh_clamp");
 }
 
-extern "C" int apexmi_pixel_shuffle_clamp(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo,
-                                          float hi, apexmi_stream_t stream_) {
+template <typename TS>
+static int pixel_shuffle_clamp_impl(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo, float hi,
+                                    apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APEXMI_REQUIRE(x && y && T > 0 && H > 0 && W > 0 && C > 0 && t0 >= 0 && t0 < T, "pixel_shuffle_clamp: bad arguments");
     APEXMI_REQUIRE((r == 1 || r == 2) && Cs >= C * r * r, "pixel_shuffle_clamp: patch %d / channel stride %d unsupported", r, Cs);
     const int64_t n = (int64_t)C * (T - t0) * H * W;
-    ApexmiProfScope prof(5, stream, 0.0, 4.0 * (double)n * r * r);
+    ApexmiProfScope prof(5, stream, 0.0, 2.0 * sizeof(TS) * (double)n * r * r);
     const dim3 grid((unsigned)((n + 255) / 256));
     if (r == 2)
-        hipLaunchKernelGGL(pixel_shuffle_clamp_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, T, H, W, Cs,
+        hipLaunchKernelGGL((pixel_shuffle_clamp_kernel<2, TS>), grid, dim3(256), 0, stream, (const TS*)x, (TS*)y, T, H, W, Cs,
                            C, t0, lo, hi);
     else
-        hipLaunchKernelGGL(pixel_shuffle_clamp_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, T, H, W, Cs,
+        hipLaunchKernelGGL((pixel_shuffle_clamp_kernel<1, TS>), grid, dim3(256), 0, stream, (const TS*)x, (TS*)y, T, H, W, Cs,
                            C, t0, lo, hi);
     return apexmi_check_launch("pixel_shuffle_clamp");
+}
+
+extern "C" int apexmi_pixel_shuffle_clamp(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo,
+                                          float hi, apexmi_stream_t stream) {
+    return pixel_shuffle_clamp_impl<bf16_t>(x, y, T, H, W, Cs, C, r, t0, lo, hi, stream);
+}
+
+// f32-storage verification mode
+extern "C" int apexmi_pixel_shuffle_clamp_f32(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo,
+                                              float hi, apexmi_stream_t stream) {
+    return pixel_shuffle_clamp_impl<float>(x, y, T, H, W, Cs, C, r, t0, lo, hi, stream);
+}
+
+extern "C" int apexmi_tanh_clamp_f32(const void* x, void* y, int64_t n, float inv_scale, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && y && n > 0, "tanh_clamp_f32: n=%lld must be positive", (long long)n);
+    ApexmiProfScope prof(5, stream, 0.0, 8.0 * (double)n);
+    hipLaunchKernelGGL(tanh_clamp_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)x, (float*)y, n,
+                       inv_scale);
+    return apexmi_check_launch("tanh_clamp_f32");
 }
 
 template <typename TS>

@@ -837,6 +837,26 @@ __global__ __launch_bounds__(256) void mul_bf16_kernel(const bf16_t* __restrict_
     *(u32x4*)(out + i * 8) = pack8(x);
 }
 
+// f32-storage verification forms of the two above (text encoders): float out, the sum / product unrounded
+__global__ __launch_bounds__(256) void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                      int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const bf16_t* __restrict__ table, int64_t ldt, const int64_t* __restrict__ ids,
+                                                              int64_t vocab, const bf16_t* __restrict__ pos, int64_t ldp, int period,
+                                                              float* __restrict__ out, int64_t ldo, int64_t rows, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float v = bf16_to_f32(table[id * ldt + c]);
+    if (pos) v += bf16_to_f32(pos[(r % period) * ldp + c]);
+    out[r * ldo + c] = v;
+}
+
 // out[r, :] = table[ids[r], :] (+ pos[r % period, :]): nn.Embedding lookups of the text encoders (token embedding;
 // CLIPTextEmbeddings adds the learned position embedding of the row's position)
 __global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const bf16_t* __restrict__ table, int64_t ldt,
@@ -881,7 +901,8 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const bf16_t* __restri
 // (apply_rotary_pos_emb_vision / apply_multimodal_rotary_pos_emb, modeling_qwen2_5_vl.py), in place on a packed
 // projection [rows, heads * head_stride] whose heads rotate their first D columns (the vision tower's 80-wide heads
 // live in 128-wide slots).  f32 arithmetic, one rounding to bf16.
-__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int heads,
+template <typename TS>
+__global__ __launch_bounds__(256) void rope_half_kernel(TS* __restrict__ x, int64_t ldx, int64_t rows, int heads,
                                                         int head_stride, int D, const float* __restrict__ cs,
                                                         const float* __restrict__ sn) {
     const int half = D >> 1;
@@ -890,12 +911,12 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
     const int c = (int)(i % half);
     const int h = (int)((i / half) % heads);
     const int64_t r = i / ((int64_t)half * heads);
-    bf16_t* p = x + r * ldx + (int64_t)h * head_stride;
-    const float a = bf16_to_f32(p[c]), b = bf16_to_f32(p[c + half]);
+    TS* p = x + r * ldx + (int64_t)h * head_stride;
+    const float a = load1<TS>(p + c), b = load1<TS>(p + c + half);
     const float* cr = cs + r * D;
     const float* sr = sn + r * D;
-    p[c] = f32_to_bf16(a * cr[c] - b * sr[c]);
-    p[c + half] = f32_to_bf16(b * cr[c + half] + a * sr[c + half]);
+    store1<TS>(p + c, a * cr[c] - b * sr[c]);
+    store1<TS>(p + c + half, b * cr[c + half] + a * sr[c + half]);
 }
 
 // frames[t, y, x, c] = uint8(round(clamp(v * 0.5 + 0.5, 0, 1) * 255)) for v = video[c, t, y, x] (any strides): the
@@ -1281,14 +1302,14 @@ extern "C" int apexmi_add_rowvec_f32(const void* x, int64_t ldx, const void* v, 
     return apexmi_check_launch("add_rowvec_f32");
 }
 
-__global__ __launch_bounds__(256) void group_mean_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
-                                                              int64_t n, int gs) {
+template <typename TS>
+__global__ __launch_bounds__(256) void group_mean_kernel(const TS* __restrict__ x, TS* __restrict__ out, int64_t n, int gs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one output element: position * C + channel
     if (i >= n) return;
-    const bf16_t* p = x + i * gs;
+    const TS* p = x + i * gs;
     float s = 0.0f;
-    for (int g = 0; g < gs; ++g) s += bf16_to_f32(p[g]);
-    out[i] = f32_to_bf16(s / (float)gs);
+    for (int g = 0; g < gs; ++g) s += load1<TS>(p + g);
+    store1<TS>(out + i, s / (float)gs);
 }
 
 extern "C" int apexmi_group_mean_bf16(const void* x, void* out, int64_t P, int C, int gs, apexmi_stream_t stream_) {
@@ -1296,9 +1317,19 @@ extern "C" int apexmi_group_mean_bf16(const void* x, void* out, int64_t P, int C
     APEXMI_REQUIRE(x && out && P > 0 && C > 0 && gs >= 1 && gs <= 64, "group_mean_bf16: bad arguments (gs=%d)", gs);
     const int64_t n = P * C;
     ApexmiProfScope prof(5, stream, 0.0, 2.0 * n * (gs + 1));
-    hipLaunchKernelGGL(group_mean_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+    hipLaunchKernelGGL(group_mean_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        (bf16_t*)out, n, gs);
     return apexmi_check_launch("group_mean_bf16");
+}
+
+// f32-storage verification mode
+extern "C" int apexmi_group_mean_f32(const void* x, void* out, int64_t P, int C, int gs, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && out && P > 0 && C > 0 && gs >= 1 && gs <= 64, "group_mean_f32: bad arguments (gs=%d)", gs);
+    const int64_t n = P * C;
+    hipLaunchKernelGGL(group_mean_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)x,
+                       (float*)out, n, gs);
+    return apexmi_check_launch("group_mean_f32");
 }
 
 extern "C" int apexmi_add_bf16(const void* a, const void* b, void* out, int64_t n, apexmi_stream_t stream_) {
@@ -1329,9 +1360,21 @@ extern "C" int apexmi_rope_half(void* x, int64_t ldx, int64_t rows, int heads, i
     APEXMI_REQUIRE(D > 0 && D % 2 == 0 && D <= head_stride, "rope_half: D=%d must be even and <= head_stride=%d", D, head_stride);
     const int64_t n = rows * heads * (D / 2);
     ApexmiProfScope prof(4, stream, 0.0, 4.0 * (double)rows * heads * D);
-    hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ldx, rows, heads,
+    hipLaunchKernelGGL(rope_half_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ldx, rows, heads,
                        head_stride, D, cos_, sin_);
     return apexmi_check_launch("rope_half");
+}
+
+// f32-storage verification mode
+extern "C" int apexmi_rope_half_f32(void* x, int64_t ldx, int64_t rows, int heads, int head_stride, int D, const float* cos_,
+                                    const float* sin_, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(x && cos_ && sin_ && rows > 0 && heads > 0, "rope_half_f32: bad arguments");
+    APEXMI_REQUIRE(D > 0 && D % 2 == 0 && D <= head_stride, "rope_half_f32: D=%d must be even and <= head_stride=%d", D, head_stride);
+    const int64_t n = rows * heads * (D / 2);
+    hipLaunchKernelGGL(rope_half_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (float*)x, ldx, rows, heads,
+                       head_stride, D, cos_, sin_);
+    return apexmi_check_launch("rope_half_f32");
 }
 
 extern "C" int apexmi_frames_to_u8(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h,
@@ -1366,6 +1409,23 @@ extern "C" int apexmi_mul_bf16(const void* a, const void* b, void* out, int64_t 
     hipLaunchKernelGGL(mul_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)out, n / 8);
     return apexmi_check_launch("mul_bf16");
+}
+
+extern "C" int apexmi_mul_f32(const float* a, const float* b, float* out, int64_t n, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(a && b && out && n > 0, "mul_f32: bad arguments");
+    hipLaunchKernelGGL(mul_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+    return apexmi_check_launch("mul_f32");
+}
+
+extern "C" int apexmi_gather_rows_f32(const void* table, int64_t ldt, int64_t vocab, const int64_t* ids, const void* pos, int64_t ldp,
+                                      int period, float* out, int64_t ldo, int64_t rows, int C, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(table && ids && out && rows > 0 && vocab > 0 && C > 0 && (!pos || period > 0), "gather_rows_f32: bad arguments");
+    const int64_t n = rows * C;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)table, ldt, ids,
+                       vocab, (const bf16_t*)pos, ldp, pos ? period : 1, out, ldo, rows, C);
+    return apexmi_check_launch("gather_rows_f32");
 }
 
 extern "C" int apexmi_gather_rows_bf16(const void* table, int64_t ldt, int64_t vocab, const int64_t* ids, const void* pos,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "apexmi_attn_fwd_bias": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp, C.c_size_t, vp]),
     "apexmi_rope_half": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "apexmi_rope_half_f32": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "apexmi_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "apexmi_gemv": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
                               C.c_int, C.c_int, vp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "apexmi_add_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "apexmi_add_f32": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "apexmi_group_mean_bf16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "apexmi_group_mean_f32": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_rmsnorm_cl": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "apexmi_upsample2x_cl": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "apexmi_time_interleave_cl": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp]),
@@ -85,6 +87,8 @@ SIGNATURES = {
     "apexmi_conv3d_cl_tstrided": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 12 + [vp]),
     "apexmi_tanh_clamp": (C.c_int, [vp, vp, C.c_int64, C.c_float, vp]),
     "apexmi_pixel_shuffle_clamp": (C.c_int, [vp, vp] + [C.c_int] * 7 + [C.c_float, C.c_float, vp]),
+    "apexmi_tanh_clamp_f32": (C.c_int, [vp, vp, C.c_int64, C.c_float, vp]),
+    "apexmi_pixel_shuffle_clamp_f32": (C.c_int, [vp, vp] + [C.c_int] * 7 + [C.c_float, C.c_float, vp]),
     "apexmi_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "apexmi_groupnorm_cl": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, vp,
                                       C.c_size_t, vp]),
@@ -99,6 +103,11 @@ SIGNATURES = {
     "apexmi_frames_to_u8": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       vp, vp]),
     "apexmi_mul_bf16": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "apexmi_mul_f32": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "apexmi_gather_rows_f32": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int, vp, C.c_int64,
+                                         C.c_int64, C.c_int, vp]),
+    "apexmi_attn_fwd_bias_f32": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, C.c_int, vp]),
     "apexmi_gather_rows_bf16": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int, vp, C.c_int64,
                                           C.c_int64, C.c_int, vp]),
     "apexmi_relpos_bias": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),

@@ -583,15 +583,15 @@ def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     """Text-encoder self-attention over packed projections: q [Sq, H*D], k, v [Sk, Hkv*D] bf16 (row-strided views of a
     fused QKV buffer welcome), bias f32 [H, Sq, Sk] (T5 relative-position bias), keep uint8 [Sk] (0 = padded key), seg
     int32 [S] (block-diagonal attention: segment id per token).  Returns [Sq, H*D]."""
-    _req(q, torch.bfloat16, "attention_bias.q")
-    _req(k, torch.bfloat16, "attention_bias.k")
-    _req(v, torch.bfloat16, "attention_bias.v")
+    _req_act(q, "attention_bias.q")
+    _req(k, q.dtype, "attention_bias.k")
+    _req(v, q.dtype, "attention_bias.v")
     assert q.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
     Sq, inner = q.shape
     Sk = k.shape[0]
     D = inner // heads
     if out is None:
-        out = torch.empty((Sq, inner), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((Sq, inner), dtype=q.dtype, device=q.device)
     if bias is not None:
         _req(bias, torch.float32, "attention_bias.bias")
         assert bias.is_contiguous() and bias.shape == (heads, Sq, Sk)
@@ -604,6 +604,13 @@ def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     hkv = heads if kv_heads is None else int(kv_heads)
     assert k.shape[1] == hkv * D and v.shape[1] == hkv * D
     lib = _l.load()
+    if q.dtype == torch.float32:           # f32-storage verification mode: one f32 pass per (row, head), no bf16 probabilities
+        _req(out, torch.float32, "attention_bias.out")
+        rc = lib.apexmi_attn_fwd_bias_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                          out.data_ptr(), out.stride(0), heads, hkv, Sq, Sk, D, float(softmax_scale), _ptr(bias),
+                                          _ptr(keep), _ptr(seg), 1 if causal else 0, _stream())
+        _l.check(rc, "attn_fwd_bias_f32")
+        return out
     need = lib.apexmi_attn_bias_workspace_bytes(heads, Sq, Sk, D)
     key = (q.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
@@ -620,12 +627,12 @@ def attention_bias(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
 def rope_half_(x: torch.Tensor, heads: int, head_stride: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """In place: every head of x [rows, >= heads * head_stride] (bf16, row-strided view welcome) rotates its first D =
     cos.shape[1] columns, x <- x cos + rotate_half(x) sin with f32 tables [rows, D]."""
-    _req(x, torch.bfloat16, "rope_half.x")
+    _req_act(x, "rope_half.x")
     _req(cos, torch.float32, "rope_half.cos")
     _req(sin, torch.float32, "rope_half.sin")
     assert x.dim() == 2 and x.stride(1) == 1 and cos.shape == sin.shape == (x.shape[0], cos.shape[1])
     assert cos.is_contiguous() and sin.is_contiguous() and x.shape[1] >= heads * head_stride
-    _l.check(_l.load().apexmi_rope_half(x.data_ptr(), x.stride(0), x.shape[0], heads, head_stride, cos.shape[1],
+    _l.check(_fn("apexmi_rope_half", x)(x.data_ptr(), x.stride(0), x.shape[0], heads, head_stride, cos.shape[1],
                                         cos.data_ptr(), sin.data_ptr(), _stream()), "rope_half")
     return x
 
@@ -642,18 +649,26 @@ def relpos_bias(weight: torch.Tensor, bucket: torch.Tensor, Sq: int, Sk: int) ->
     return out
 
 
-def gather_rows(table: torch.Tensor, ids: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """table[ids] (+ pos[row % len(pos)]): bf16 [vocab, C], ids int64 [rows] on the device -> [rows, C]."""
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, pos: Optional[torch.Tensor] = None,
+                out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """table[ids] (+ pos[row % len(pos)]): bf16 [vocab, C], ids int64 [rows] on the device -> [rows, C] (`out_dtype` float32: the
+    f32-storage verification mode, the position sum unrounded)."""
     _req(table, torch.bfloat16, "gather_rows.table")
     _req(ids, torch.int64, "gather_rows.ids")
     assert table.dim() == 2 and table.stride(1) == 1 and ids.dim() == 1 and ids.is_contiguous()
     rows, Cc = ids.numel(), table.shape[1]
-    out = torch.empty((rows, Cc), dtype=torch.bfloat16, device=table.device)
+    out = torch.empty((rows, Cc), dtype=out_dtype, device=table.device)
     period = 1
     if pos is not None:
         _req(pos, torch.bfloat16, "gather_rows.pos")
         assert pos.dim() == 2 and pos.stride(1) == 1 and pos.shape[1] == Cc
         period = pos.shape[0]
+    if out_dtype == torch.float32:
+        rc = _l.load().apexmi_gather_rows_f32(table.data_ptr(), table.stride(0), table.shape[0], ids.data_ptr(), _ptr(pos),
+                                              pos.stride(0) if pos is not None else 0, period, out.data_ptr(), out.stride(0),
+                                              rows, Cc, _stream())
+        _l.check(rc, "gather_rows_f32")
+        return out
     rc = _l.load().apexmi_gather_rows_bf16(table.data_ptr(), table.stride(0), table.shape[0], ids.data_ptr(), _ptr(pos),
                                            pos.stride(0) if pos is not None else 0, period, out.data_ptr(), out.stride(0),
                                            rows, Cc, _stream())
@@ -674,12 +689,15 @@ def frames_to_u8(video: torch.Tensor) -> torch.Tensor:
 
 
 def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = a * b for contiguous bf16 tensors of equal shape (numel a multiple of 8)."""
-    _req(a, torch.bfloat16, "mul.a")
-    _req(b, torch.bfloat16, "mul.b")
+    """out = a * b for contiguous bf16 tensors of equal shape (numel a multiple of 8); float tensors in the f32-storage mode."""
+    _req_act(a, "mul.a")
+    _req(b, a.dtype, "mul.b")
     assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty_like(a)
+    if a.dtype == torch.float32:
+        _l.check(_l.load().apexmi_mul_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mul_f32")
+        return out
     _l.check(_l.load().apexmi_mul_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mul_bf16")
     return out
 
@@ -697,13 +715,15 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 def group_mean(x: torch.Tensor, out_channels: int) -> torch.Tensor:
-    """Mean over consecutive channel groups of a channels-last tensor: [..., C * gs] -> [..., C] (bf16, f32 sum)."""
-    _req(x, torch.bfloat16, "group_mean.x")
+    """Mean over consecutive channel groups of a channels-last tensor: [..., C * gs] -> [..., C] (f32 sum; bf16, or float in the
+    f32-storage mode)."""
+    _req_act(x, "group_mean.x")
     assert x.is_contiguous() and x.shape[-1] % out_channels == 0
     gs = x.shape[-1] // out_channels
     out = torch.empty(*x.shape[:-1], out_channels, dtype=x.dtype, device=x.device)
     P = x.numel() // x.shape[-1]
-    _l.check(_l.load().apexmi_group_mean_bf16(x.data_ptr(), out.data_ptr(), P, out_channels, gs, _stream()), "group_mean_bf16")
+    fn = getattr(_l.load(), "apexmi_group_mean_f32" if x.dtype == torch.float32 else "apexmi_group_mean_bf16")
+    _l.check(fn(x.data_ptr(), out.data_ptr(), P, out_channels, gs, _stream()), "group_mean")
     return out
 
 
@@ -1004,21 +1024,21 @@ def conv3d_cl_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.
 
 def tanh_clamp(x: torch.Tensor, inv_scale: float = 1.0) -> torch.Tensor:
     """3 tanh(x * inv_scale / 3) (TAEHV `Clamp`, reference vae/tae/model.py:24-26)."""
-    _req(x, torch.bfloat16, "tanh_clamp.x")
-    assert x.is_contiguous() and x.numel() % 8 == 0
+    _req_act(x, "tanh_clamp.x")
+    assert x.is_contiguous() and (x.dtype == torch.float32 or x.numel() % 8 == 0)
     out = torch.empty_like(x)
-    _l.check(_l.load().apexmi_tanh_clamp(x.data_ptr(), out.data_ptr(), x.numel(), float(inv_scale), _stream()), "tanh_clamp")
+    _l.check(_fn("apexmi_tanh_clamp", x)(x.data_ptr(), out.data_ptr(), x.numel(), float(inv_scale), _stream()), "tanh_clamp")
     return out
 
 
 def pixel_shuffle_clamp(x: torch.Tensor, channels: int, r: int, trim: int = 0, lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
     """x [T, H, W, Cs] channels-last -> [channels, T - trim, H r, W r]: clamp, F.pixel_shuffle(r), drop `trim` leading frames
     (reference vae/tae/model.py:318-333)."""
-    _req(x, torch.bfloat16, "pixel_shuffle_clamp.x")
+    _req_act(x, "pixel_shuffle_clamp.x")
     assert x.dim() == 4 and x.is_contiguous()
     T, H, W, cs = x.shape
-    out = torch.empty((channels, T - trim, H * r, W * r), dtype=torch.bfloat16, device=x.device)
-    _l.check(_l.load().apexmi_pixel_shuffle_clamp(x.data_ptr(), out.data_ptr(), T, H, W, cs, channels, r, trim, float(lo),
+    out = torch.empty((channels, T - trim, H * r, W * r), dtype=x.dtype, device=x.device)
+    _l.check(_fn("apexmi_pixel_shuffle_clamp", x)(x.data_ptr(), out.data_ptr(), T, H, W, cs, channels, r, trim, float(lo),
                                                   float(hi), _stream()), "pixel_shuffle_clamp")
     return out
 

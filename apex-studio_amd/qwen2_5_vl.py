@@ -238,8 +238,8 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
         grid = [[int(x) for x in g] for g in (image_grid_thw.tolist() if torch.is_tensor(image_grid_thw) else image_grid_thw)]
         wp, k, kp = self._patch_weight()
         S = pixel_values.shape[0]
-        px = torch.zeros(S, kp, dtype=torch.bfloat16, device=dev)
-        px[:, :k] = pixel_values.to(dev, torch.bfloat16)
+        px = torch.zeros(S, kp, dtype=self.storage_dtype, device=dev)
+        px[:, :k] = pixel_values.to(dev, self.storage_dtype)
         unit = v.spatial_merge_size ** 2
         widx, seg_win = vision_window_index(grid, v.spatial_merge_size, v.window_size, v.patch_size)
         widx_d = widx.to(dev)
@@ -295,7 +295,7 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
         ids = input_ids.to(dev, torch.int64).reshape(-1).contiguous()
         if int(ids.min()) < 0 or int(ids.max()) >= c.vocab_size:
             raise IndexError("input_ids out of range for the embedding table")
-        x = ops.gather_rows(lm.embed_tokens.weight.data, ids)
+        x = ops.gather_rows(lm.embed_tokens.weight.data, ids, out_dtype=self.storage_dtype)
         grid = None
         if pixel_values is not None:
             grid = [[int(v) for v in g] for g in image_grid_thw.tolist()]
@@ -317,7 +317,7 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
             at = layer.self_attn
             wqkv, bqkv = self._qkv(id(at), (at.q_proj, at.k_proj, at.v_proj))
             qkv = ops.gemm(ops.ln_modulate(x, gamma=layer.input_layernorm.weight.data, rms=True, eps=c.rms_norm_eps), wqkv, bqkv)
-            a = torch.empty((B * S, nq), dtype=torch.bfloat16, device=dev)
+            a = torch.empty((B * S, nq), dtype=x.dtype, device=dev)
             for b in range(B):
                 r = slice(b * S, (b + 1) * S)
                 ops.rope_half_(qkv[r, :nq + nkv], H + Hkv, hd, *tables[b])

@@ -73,6 +73,17 @@ class _Base(nn.Module):
 
     _from_config = from_config
 
+    storage_dtype = torch.bfloat16
+
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """Verification mode (flux.py `set_storage_dtype`): float32 keeps every activation between the kernels in f32 (GEMMs through
+        the exact bf16 split, attention through the f32 row kernel) so the bf16-weight encoder can be compared with the fp32
+        reference at ~1e-6 per element instead of the bf16 rounding floor.  Weights stay bf16.  Not a production path."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("storage dtype is bfloat16 (production) or float32 (verification)")
+        self.storage_dtype = dtype
+        return self
+
     def _first(self):
         return next(self.parameters())
 
@@ -201,7 +212,7 @@ class T5EncoderModel(_Base):
         keep = None
         if attention_mask is not None:
             keep = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()
-        x = ops.gather_rows(self.shared.weight.data, ids)
+        x = ops.gather_rows(self.shared.weight.data, ids, out_dtype=self.storage_dtype)
         ones = self._ones(c.d_model)
         hidden, bias = [], None
         for blk in self.encoder.block:
@@ -213,7 +224,7 @@ class T5EncoderModel(_Base):
                 bias = self._bias(att, S)
             wqkv, _ = self._qkv(id(att), (att.q, att.k, att.v))
             qkv = ops.gemm(ops.ln_modulate(x, gamma=sa.layer_norm.weight.data, rms=True, eps=eps), wqkv)
-            a = torch.empty((B * S, inner), dtype=torch.bfloat16, device=x.device)
+            a = torch.empty((B * S, inner), dtype=x.dtype, device=x.device)
             for b in range(B):
                 r = slice(b * S, (b + 1) * S)
                 ops.attention_bias(qkv[r, :inner], qkv[r, inner:2 * inner], qkv[r, 2 * inner:], H, 1.0, bias=bias,
@@ -296,7 +307,7 @@ class CLIPTextModel(_Base):
         if attention_mask is not None:
             keep = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()
         x = ops.gather_rows(tm.embeddings.token_embedding.weight.data, ids,
-                            pos=tm.embeddings.position_embedding.weight.data[:S])
+                            pos=tm.embeddings.position_embedding.weight.data[:S], out_dtype=self.storage_dtype)
         ones = self._ones(d)
         act = "quick_gelu" if c.hidden_act == "quick_gelu" else "gelu_erf"
         hidden = [x.view(B, S, d)] if output_hidden_states else []
@@ -305,7 +316,7 @@ class CLIPTextModel(_Base):
             wqkv, bqkv = self._qkv(id(at), (at.q_proj, at.k_proj, at.v_proj))
             h = ops.ln_modulate(x, gamma=layer.layer_norm1.weight.data, beta=layer.layer_norm1.bias.data, eps=eps)
             qkv = ops.gemm(h, wqkv, bqkv)
-            a = torch.empty((B * S, d), dtype=torch.bfloat16, device=x.device)
+            a = torch.empty((B * S, d), dtype=x.dtype, device=x.device)
             for b in range(B):
                 r = slice(b * S, (b + 1) * S)
                 ops.attention_bias(qkv[r, :d], qkv[r, d:2 * d], qkv[r, 2 * d:], H, (d // H) ** -0.5,

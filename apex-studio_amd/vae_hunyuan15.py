@@ -271,10 +271,11 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         self.light_vae = light_vae
 
     def set_storage_dtype(self, dtype: torch.dtype):
-        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE of the DECODER: every
-        activation float, the library's `_f32` entry points (the convolutions on the exact three-way bf16 split), and the
-        frame-causal mid-block attention as one f32 attention call per frame over the keys of the frames up to it — the same
-        softmax, without the bf16 probabilities of the materialised production path.  Weights stay bf16; encode stays bf16."""
+        """torch.bfloat16 (production) or torch.float32: the f32-STORAGE VERIFICATION MODE of the decoder AND the encoder
+        (DESIGN.md §1.2): every activation float, the library's `_f32` entry points (the convolutions on the exact three-way bf16
+        split), and the frame-causal mid-block attention as one f32 attention call per frame over the keys of the frames up to
+        it — the same softmax, without the bf16 probabilities of the materialised production path.  Weights stay bf16; the
+        encoder's moments come back float."""
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
         self.storage_dtype = dtype
@@ -432,8 +433,8 @@ class AutoencoderKLHunyuanVideo15(nn.Module):
         Cc, T, H, W = x.shape
         if (T - 1) % self.temporal_compression_ratio:
             raise ValueError(f"hunyuanvideo15 VAE encodes 1 + {self.temporal_compression_ratio} k frames, got {T}")
-        xc = torch.zeros(T, H, W, 8, dtype=torch.bfloat16, device=x.device)
-        xc[..., :Cc] = x.to(torch.bfloat16).permute(1, 2, 3, 0)
+        xc = torch.zeros(T, H, W, 8, dtype=self.storage_dtype, device=x.device)
+        xc[..., :Cc] = x.to(self.storage_dtype).permute(1, 2, 3, 0)
         tsh, tsw = self.tile_sample_min_height, self.tile_sample_min_width
         if not (self.use_tiling and (W > tsw or H > tsh)):
             out = self._encode_tile(xc)

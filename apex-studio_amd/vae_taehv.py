@@ -104,6 +104,16 @@ class TAEHV(nn.Module):
             self.load_state_dict(self.patch_tgrow_layers(_read_checkpoint(checkpoint_path)))
 
     # ---- state ------------------------------------------------------------------------------------------------------
+    storage_dtype = torch.bfloat16
+
+    def set_storage_dtype(self, dtype: torch.dtype):
+        """torch.bfloat16 (production) or torch.float32: the f32-storage verification mode — activations float,
+        the `_f32` entry points (convolutions on the exact bf16 split).  Weights stay bf16."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"activation storage must be bfloat16 or float32, got {dtype}")
+        self.storage_dtype = dtype
+        return self
+
     @property
     def dtype(self):
         return self.decoder[1].weight.dtype
@@ -179,7 +189,7 @@ class TAEHV(nn.Module):
     def _decode_clip(self, z: torch.Tensor, inv_scale: float, trim: int) -> torch.Tensor:
         """z [C, T, H, W] -> [3, T', H', W'] bf16."""
         d = self.decoder
-        x = z.to(self.device, torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+        x = z.to(self.device, self.storage_dtype).permute(1, 2, 3, 0).contiguous()
         x = ops.tanh_clamp(x, inv_scale)
         x = self._conv(d[1], x, True)
         i = 3
@@ -210,8 +220,8 @@ class TAEHV(nn.Module):
         """x [T, 3 p^2, h, w] (pixel-unshuffled, T a multiple of 4) -> [T / 4, latent, h / 8, w / 8] bf16."""
         e = self.encoder
         T, C, H, W = x.shape
-        xc = torch.zeros((T, H, W, (C + 7) // 8 * 8), dtype=torch.bfloat16, device=self.device)
-        xc[..., :C] = x.to(self.device, torch.bfloat16).permute(0, 2, 3, 1)
+        xc = torch.zeros((T, H, W, (C + 7) // 8 * 8), dtype=self.storage_dtype, device=self.device)
+        xc[..., :C] = x.to(self.device, self.storage_dtype).permute(0, 2, 3, 1)
         x = self._conv(e[0], xc, True)
         i = 2
         for _ in range(3):

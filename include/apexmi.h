@@ -528,6 +528,23 @@ int apexmi_crossfade_f32(const void* a, void* b, int64_t outer, int E, int64_t i
                          int64_t b_so, int64_t b_se, apexmi_stream_t stream);
 int apexmi_frames_to_u8_f32(const void* video, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
                             int C, int T, int H, int W, void* out, apexmi_stream_t stream);
+/* Text encoders in the f32-storage mode (round 4): the attention of apexmi_attn_fwd_bias with float q / k / v / out (row strides in
+ * floats; bias f32 [H, Sq, Sk], keep uint8 [Sk], seg int32 [S], causal, grouped-query key heads; f32 arithmetic, no bf16
+ * probabilities), the gated-MLP product and the embedding lookup (bf16 tables, float out, the position sum unrounded). */
+int apexmi_attn_fwd_bias_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                             int64_t ldo, int H, int Hkv, int Sq, int Sk, int D, float scale, const float* bias,
+                             const uint8_t* keep, const int* seg, int causal, apexmi_stream_t stream);
+int apexmi_mul_f32(const float* a, const float* b, float* out, int64_t n, apexmi_stream_t stream);
+int apexmi_gather_rows_f32(const void* table, int64_t ldt, int64_t vocab, const int64_t* ids, const void* pos, int64_t ldp,
+                           int period, float* out, int64_t ldo, int64_t rows, int C, apexmi_stream_t stream);
+/* apexmi_rope_half / apexmi_group_mean_bf16 / apexmi_tanh_clamp / apexmi_pixel_shuffle_clamp on float activations (HunyuanVideo-1.5 VAE encoder and
+ * TAEHV in the verification mode; any n > 0). */
+int apexmi_rope_half_f32(void* x, int64_t ldx, int64_t rows, int heads, int head_stride, int D, const float* cos_, const float* sin_,
+                         apexmi_stream_t stream);
+int apexmi_group_mean_f32(const void* x, void* out, int64_t P, int C, int gs, apexmi_stream_t stream);
+int apexmi_tanh_clamp_f32(const void* x, void* y, int64_t n, float inv_scale, apexmi_stream_t stream);
+int apexmi_pixel_shuffle_clamp_f32(const void* x, void* y, int T, int H, int W, int Cs, int C, int r, int t0, float lo, float hi,
+                                   apexmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Built-in kernel timer (HIP events on the launch stream) used by bench.py's roofline leg.

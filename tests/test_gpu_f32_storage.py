@@ -675,3 +675,106 @@ def test_wan_vae_decode_through_shipped_convolution_tiles(shipped_kernels, host_
     assert out.dtype == F32 and out.shape == ref32.shape
     assert spy.count["apexmi_conv3d_cl_norm"] > 0 and spy.count["apexmi_conv3d_cl"] + spy.count["apexmi_conv3d_cl_up2"] > 0
     assert e <= MIXED_TOL_VAE
+
+
+# ---- round 4: the remaining model classes in the verification mode (VERDICT r3 "missing" #5) -----------------------------------------
+def test_hunyuan15_vae_encode_f32_storage(golden_dir):
+    """HunyuanVideo-1.5 VAE ENCODE (the i2v condition path: replicate-padded causal convolutions, DCAE pixel-unshuffle down-samplers
+    with the grouped-mean shortcut and the first-frame rule, frame-causal mid-block attention; untiled and tiled + cross-faded) in
+    float storage against the fp32 oracle, which `vae_hunyuan15_encode.pt` pins to the reference class."""
+    import os
+    from oracle.vae_hunyuan15 import AutoencoderKLHunyuanVideo15 as Orc
+    from apex_studio_amd.vae_hunyuan15 import AutoencoderKLHunyuanVideo15
+    g = torch.load(os.path.join(golden_dir, "vae_hunyuan15_encode.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = Orc(**cfg).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    vae = AutoencoderKLHunyuanVideo15(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    vae.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    for name in ("image", "clip", "tiled"):
+        c = g[name]
+        x = seeded(c["shape"], c["seed"]).clamp(-1, 1)          # the float pixels the reference ran (float storage takes them as is)
+        kw = {}
+        if name == "tiled":
+            vae.enable_tiling(tile_sample_min_height=c["tile"], tile_sample_min_width=c["tile"],
+                              tile_latent_min_height=c["tile"] // 16, tile_latent_min_width=c["tile"] // 16)
+            orc.enable_tiling()
+            kw = dict(tile_sample_min=c["tile"])
+        post = vae.encode(x.to(DEV), return_dict=False)[0]
+        assert post.parameters.dtype == F32
+        _report(f"hunyuan15 vae encode {name}", post.parameters, orc.encode(x, **kw), orc.encode(x, policy=OL.BF16_STORAGE, **kw))
+        # against the reference class's own moments (committed fixture): the same bar
+        assert _rel(post.parameters, c["moments"]) <= TOL
+
+
+def test_taehv_decode_and_encode_f32_storage(golden_dir):
+    """TAEHV (the light VAE of HunyuanVideo-1.5 and the Wan preview decoder): tanh clamp, MemBlocks as causal kT = 2 convolutions
+    with the leaky-ReLU epilogue, TGrow / TPool, folded up-samples, pixel shuffle + clamp; decode and encode in float storage
+    against the fp32 oracle and the reference's own fp32 outputs (vae_taehv.pt / vae_taehv_encode.pt)."""
+    import os
+    from apex_studio_amd.vae_taehv import TAEHV, AutoencoderKLHunyuanVideo15Light
+    from oracle.vae_taehv import AutoencoderKLHunyuanVideo15Light as OrcLight, TAEHVEncoder
+    g = torch.load(os.path.join(golden_dir, "vae_taehv.pt"), weights_only=False)
+    orc = OrcLight(scaling_factor=g["scaling_factor"]).eval()
+    sd = vae_synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    hip = AutoencoderKLHunyuanVideo15Light(scaling_factor=g["scaling_factor"], device=DEV)
+    hip.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    hip.taehv.set_storage_dtype(F32)
+    for name in ("clip", "frame"):
+        c = g[name]
+        z = seeded(c["shape"], c["seed"]) * c["scale"]            # the float latents the reference ran
+        out = hip.decode(z.to(DEV))
+        assert out.dtype == F32
+        with torch.no_grad():
+            _report(f"taehv decode {name}", out[0], orc.decode(z), orc.decode(z, OL.BF16_STORAGE))
+        assert _rel(out[0], c["sequential"]) <= TOL               # the reference classes' output
+    ge = torch.load(os.path.join(golden_dir, "vae_taehv_encode.pt"), weights_only=False)
+    oe = TAEHVEncoder().eval()
+    sde = vae_synthetic_state_dict(oe, ge["seed"])
+    oe.load_state_dict(sde, strict=True)
+    enc = TAEHV(checkpoint_path=None, model_type="hy15", latent_channels=32, patch_size=2, device=DEV).set_storage_dtype(F32)
+    enc.load_state_dict({k: v.to(BF) for k, v in sde.items()}, strict=False)
+    for name in ("clip9", "clip4"):
+        c = ge[name]
+        x = (seeded(c["shape"], c["seed"]) * 0.25 + 0.5).clamp(0, 1)
+        out = enc.encode_video(x.to(DEV))
+        assert out.dtype == F32
+        with torch.no_grad():
+            _report(f"taehv encode {name}", out, oe.encode_video(x), oe.encode_video(x, OL.BF16_STORAGE))
+        assert _rel(out, c["latents"]) <= TOL
+
+
+def test_qwen2_5_vl_f32_storage(golden_dir):
+    """Qwen2.5-VL (QwenImage-Edit's and HunyuanVideo-1.5's prompt encoder): text-only padded batch, the vision tower (windowed /
+    full block-diagonal attention, 80-wide heads in 128-wide slots, rotate-half RoPE, patch merger) and a prompt with two images,
+    float storage against the fp32 oracle with the same bf16 weights."""
+    import os
+    from oracle import qwen2_5_vl as OQV
+    from apex_studio_amd.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration as Hip
+    from tests.golden.seeded import text_encoder_state_dict
+    g = torch.load(os.path.join(golden_dir, "qwen2_5_vl.pt"), weights_only=False)
+    orc = OQV.Qwen2_5_VLForConditionalGeneration(**g["text_config"], mrope_section=(16, 24, 24), image_token_id=g["image_token_id"],
+                                                 vision_config=g["vision_config"]).eval()
+    sd = text_encoder_state_dict(orc, g["seed"], 52, "norm")
+    sd = {k: _bf(v) for k, v in sd.items()}                       # the norm gains of this draw are not bf16 values: round both sides
+    orc.load_state_dict(sd, strict=True)
+    cfg = dict(text_config={**g["text_config"], "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}},
+               vision_config=g["vision_config"], image_token_id=g["image_token_id"])
+    hip = Hip(cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
+    hip.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    t = g["text"]
+    out = hip(input_ids=t["ids"].to(DEV), attention_mask=t["mask"].to(DEV), output_hidden_states=True)
+    real = t["mask"].bool()
+    assert out.hidden_states[-1].dtype == F32
+    ref = orc(t["ids"], attention_mask=t["mask"])
+    _report("qwen2.5-vl text", out.hidden_states[-1].cpu()[real], ref.hidden_states[-1][real])
+    im = g["image"]
+    px = _bf(im["pixel_values"])
+    vis = hip.get_image_features(px.to(DEV), im["grid"])
+    _report("qwen2.5-vl vision tower", vis, orc.model.visual(px, im["grid"]))
+    out = hip(input_ids=im["ids"].to(DEV), attention_mask=im["mask"].to(DEV), pixel_values=px.to(DEV), image_grid_thw=im["grid"],
+              output_hidden_states=True)
+    ref = orc(im["ids"], attention_mask=im["mask"], pixel_values=px, image_grid_thw=im["grid"])
+    _report("qwen2.5-vl text + 2 images", out.hidden_states[-1], ref.hidden_states[-1])

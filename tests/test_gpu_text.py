@@ -213,3 +213,104 @@ def test_t5_byt5_like_geometry_matches_oracle():
     e_like, e_true, e_emul = _rel(got[real], ref16[real]), _rel(got[real], ref32[real]), _rel(ref16[real], ref32[real])
     print(f"[t5 byt5-like] hip vs bf16-storage oracle {e_like:.3e}; vs fp32 {e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
     assert e_like < 2e-2 and e_true < 2 * e_emul + 2e-3
+
+
+# ---- f32-storage verification mode: the encoders against the fp32 oracle without the bf16 storage floor -------
+def _rel64(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("H,S,D,mode", [(2, 21, 64, "bias"), (64, 512, 64, "bias_keep"), (12, 77, 64, "causal_keep"),
+                                        (4, 200, 128, "plain")])
+def test_attention_bias_f32_storage(H, S, D, mode):
+    from apex_studio_amd import ops
+    inner = H * D
+    qkv = seeded((S, 3 * inner), 11).to(DEV)
+    bias = seeded((H, S, S), 12).to(DEV) if "bias" in mode else None
+    keep = None
+    if "keep" in mode:
+        keep = torch.ones(S, dtype=torch.uint8, device=DEV)
+        keep[S - S // 3:] = 0
+    causal = "causal" in mode
+    scale = 1.0 if "bias" in mode else D ** -0.5
+    out = ops.attention_bias(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], H, scale, bias=bias, keep=keep,
+                             causal=causal)
+    assert out.dtype == torch.float32
+    q, k, v = (t.double().view(S, H, D).transpose(0, 1) for t in (qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]))
+    sc = q @ k.transpose(1, 2) * scale
+    if bias is not None:
+        sc = sc + bias.double()
+    m = torch.ones(S, S, dtype=torch.bool, device=DEV)
+    if causal:
+        m = m.tril()
+    if keep is not None:
+        m = m & keep.bool()[None, :]
+    ref = (torch.softmax(sc.masked_fill(~m, float("-inf")), dim=-1) @ v).transpose(0, 1).reshape(S, inner)
+    e = _rel64(out, ref)
+    print(f"[f32 attention_bias {mode} H{H} S{S} D{D}] rel {e:.2e}")
+    assert e < 2e-6, e
+
+
+def test_text_elementwise_ops_f32_storage():
+    from apex_studio_amd import ops
+    a, b = seeded((37, 256), 21), seeded((37, 256), 22)
+    assert torch.equal(ops.mul(a.to(DEV), b.to(DEV)).cpu(), a * b)
+    table, pos = _bf(seeded((100, 128), 23)), _bf(seeded((19, 128), 24))
+    ids = torch.randint(0, 100, (38,), generator=torch.Generator().manual_seed(3))
+    got = ops.gather_rows(table.to(DEV), ids.to(DEV), out_dtype=torch.float32)
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), table[ids].float())
+    got = ops.gather_rows(table.to(DEV), ids.to(DEV), pos=pos.to(DEV), out_dtype=torch.float32).cpu()
+    assert torch.equal(got, table[ids].float() + pos.float().repeat(2, 1))
+
+
+def _bf_sd(sd):
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", ["t5", "umt5"])
+def test_t5_encoder_f32_storage_matches_fp32_oracle(golden_dir, name):
+    """Same bf16 weights on both sides, activations in f32 on the device: what is left is summation order (the production test
+    above can only hold the bf16 chain to the bf16 floor)."""
+    from apex_studio_amd import text_encoders as TE
+    g = torch.load(os.path.join(golden_dir, "text_encoders.pt"), weights_only=False)
+    c, cfg = g[name], g["t5_config"]
+    orc = OT.T5EncoderModel(**cfg, per_layer_bias=(name == "umt5")).eval()
+    sd = _bf_sd(text_encoder_state_dict(orc, c["seed"], 24, "layer_norm.weight"))
+    sd.pop("encoder.embed_tokens.weight")
+    orc.load_state_dict(sd, strict=False)
+    hip = _load_hip(TE.UMT5EncoderModel if name == "umt5" else TE.T5EncoderModel, cfg, sd).set_storage_dtype(torch.float32)
+    ids, mask = g["t5_ids"], g["t5_mask"]
+    for m in (None, mask):
+        out = hip(input_ids=ids.to(DEV), attention_mask=None if m is None else m.to(DEV), output_hidden_states=True)
+        assert out.last_hidden_state.dtype == torch.float32
+        ref = orc(ids, attention_mask=m)
+        real = torch.ones_like(mask).bool() if m is None else m.bool()
+        e = _rel64(out.last_hidden_state.cpu()[real], ref.last_hidden_state[real])
+        e_h = max(_rel64(a.cpu()[real], b[real]) for a, b in zip(out.hidden_states, ref.hidden_states))
+        print(f"[{name} f32 storage masked={m is not None}] last {e:.2e}; worst hidden state {e_h:.2e}")
+        assert e < 1e-4 and e_h < 1e-4, (e, e_h)
+    # the switch goes back: production output is what it was
+    hip.set_storage_dtype(torch.bfloat16)
+    assert hip(input_ids=ids.to(DEV)).last_hidden_state.dtype == torch.bfloat16
+
+
+def test_clip_text_f32_storage_matches_fp32_oracle(golden_dir):
+    from apex_studio_amd import text_encoders as TE
+    g = torch.load(os.path.join(golden_dir, "text_encoders.pt"), weights_only=False)
+    c, cfg = g["clip"], g["clip_config"]
+    orc = OT.CLIPTextModel(**cfg).eval()
+    sd = _bf_sd(text_encoder_state_dict(orc, c["seed"], 30, "layer_norm"))
+    orc.load_state_dict(sd, strict=True)
+    hip = TE.CLIPTextModel(cfg, device=DEV, dtype=torch.bfloat16).set_storage_dtype(torch.float32)
+    hip.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    ids, mask = g["clip_ids"], g["clip_mask"]
+    for m in (None, mask):
+        out = hip(input_ids=ids.to(DEV), attention_mask=None if m is None else m.to(DEV), output_hidden_states=True)
+        ref = orc(ids, attention_mask=m)
+        real = torch.ones_like(mask).bool() if m is None else m.bool()
+        e = _rel64(out.last_hidden_state.cpu()[real], ref.last_hidden_state[real])
+        e_p = _rel64(out.pooler_output, ref.pooler_output)
+        e_h = max(_rel64(a.cpu()[real], b[real]) for a, b in zip(out.hidden_states, ref.hidden_states))
+        print(f"[clip f32 storage masked={m is not None}] last {e:.2e}; pooled {e_p:.2e}; worst hidden state {e_h:.2e}")
+        assert e < 1e-4 and e_p < 1e-4 and e_h < 1e-4, (e, e_p, e_h)
