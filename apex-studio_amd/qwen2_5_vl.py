@@ -286,8 +286,10 @@ class Qwen2_5_VLForConditionalGeneration(_Base):
     @ops.on_model_device
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
-                output_hidden_states=False, return_dict=True, **_):
+                output_hidden_states=False, return_dict=True, pixel_values_videos=None, video_grid_thw=None, **_):
         self._check(input_ids)
+        if pixel_values_videos is not None or video_grid_thw is not None:
+            raise NotImplementedError("qwen2.5-vl (mi355): video inputs are not built (no engine of the reference passes them)")
         c, lm, dev = self.config, self.model.language_model, self.device
         B, S = input_ids.shape
         ids_cpu = input_ids.detach().cpu()

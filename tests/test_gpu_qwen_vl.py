@@ -121,3 +121,5 @@ def test_qwen2_5_vl_matches_transformers_and_oracle(golden_dir):
     assert len(out.hidden_states) == im["n_hidden"] and e_like < 2e-2 and e_ref < 2 * e_emul + 2e-3
     with pytest.raises(ValueError):
         hip(input_ids=im["ids"][:, :-20].to(DEV), pixel_values=im["pixel_values"].to(DEV), image_grid_thw=im["grid"])
+    with pytest.raises(NotImplementedError):     # video inputs: refused, not silently ignored
+        hip(input_ids=im["ids"].to(DEV), pixel_values_videos=im["pixel_values"].to(DEV), video_grid_thw=im["grid"])
