@@ -176,15 +176,19 @@ APEXMI_DEVICE float wave_max(float x) {
 }
 
 APEXMI_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-APEXMI_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+// x * sigmoid(z) with z pre-scaled by log2(e): one v_exp_f32 and one v_rcp_f32 (1 ulp each) instead of expf + an IEEE division
+// (v_div_scale / v_div_fmas / v_div_fixup + Newton steps: ~12 instructions).  The activations sit in GEMM epilogues that run with
+// every matrix pipe idle — tools/gemm_tile_trace.py priced the old tanh-form GELU at 14 us per 256 x 256 tile (30 VALU instructions
+// a value), a fifth of a K = 3072 tile's K-loop.  x -> -inf: exp2 = inf, rcp = 0, result -0; x -> +inf: result x.
+APEXMI_DEVICE float x_sigmoid_log2(float x, float z_log2) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z_log2));
+}
+APEXMI_DEVICE float silu_f(float x) { return x_sigmoid_log2(x, 1.4426950408889634f * x); }
+// gelu(approximate="tanh") = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3); 0.5 (1 + tanh(u)) = sigmoid(2u) exactly, which
+// also has no cancellation for negative x (the 1 - 2 / (e + 1) form loses the result's leading bits there)
 APEXMI_DEVICE float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2 / (exp(2u) + 1); clamp keeps exp finite
-    float e = __expf(fminf(2.0f * u, 80.0f));
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+    const float a = 2.0f * 0.7978845608028654f * 1.4426950408889634f, b = a * 0.044715f;
+    return x_sigmoid_log2(x, x * fmaf(b, x * x, a));
 }
 
 // async 16-byte global -> LDS copy: LDS destination is wave-uniform `lds` + lane*16

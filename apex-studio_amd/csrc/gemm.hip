@@ -56,6 +56,16 @@ namespace {
 #ifndef APEXMI_GEMM_STREAMK
 #define APEXMI_GEMM_STREAMK 0
 #endif
+// Per-workgroup timeline of the shipped schedule (tools/gemm_tile_trace.py, profiles/r04_gemm_tile_trace.log): compiled in only with
+// -DAPEXMI_GEMM_TRACE=1 into a side library; tune keys "gemm.trace_lo" / "gemm.trace_hi" = halves of a device pointer to 8 u64 per
+// workgroup: {HW_ID, XCC_ID, t_entry, t_loop_begin, t_loop_end, t_stores_issued, t_stores_acknowledged} in s_memrealtime ticks (10 ns).
+#ifndef APEXMI_GEMM_TRACE
+#define APEXMI_GEMM_TRACE 0
+#endif
+// A/B of the 256 x 256 tile's output stores: 1 = non-temporal (streaming) stores.  Not shipped unless measured (see the trace log).
+#ifndef APEXMI_GEMM_STORE_NT
+#define APEXMI_GEMM_STORE_NT 0
+#endif
 constexpr int BK = 64;
 constexpr int GROUP_M = 6;   // tiles tall per group: an XCD's 32 concurrent tiles as ~6 x 5.3 (squarer than 8 x 4: fewer panel fetches per
                              // tile; interleaved A/B, profiles/r03_ab_gemm_group_m.log: Flux -0.4 %, Qwen -1.1 %, Wan -0.6 % vs 8)
@@ -98,6 +108,9 @@ struct GemmGroup {
     // reference ticks (s_memrealtime) its K-loop took to clk[0] / clk[1]: sum(cycles) / sum(ticks) x 100 MHz = the effective
     // shader clock WHILE this kernel runs inside the real step (the number the "power-bound" argument of DESIGN.md rests on)
     unsigned long long* clk;
+#if APEXMI_GEMM_TRACE
+    unsigned long long* trace;
+#endif
     // EXPERIMENT (tune key gemm.wpacked, tools/gemm_wpacked_ab.py): every W operand of the launch is TILE-MAJOR packed —
     // [N / 256][K / 64][256 rows][64] — so that an LDS-DMA piece (8 rows x 128 B) is 1 KiB contiguous; SCHED 5 only
     int wpacked;
@@ -144,9 +157,25 @@ using CFG_256R5 = Cfg<256, 256, 2, 4, 8>;    // the same with five slots, pieces
 APEXMI_DEVICE float act_f(float x, int mode) {
     if (mode == 1) return gelu_tanh_f(x);
     if (mode == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    if (mode == 4) return x / (1.0f + __expf(-1.702f * x));   // quick_gelu (CLIP text MLP)
+    if (mode == 4) return x_sigmoid_log2(x, (1.702f * 1.4426950408889634f) * x);   // quick_gelu (CLIP text MLP)
     return silu_f(x);
 }
+// the same with the mode known at compile time.  The epilogues dispatch on the (block-uniform) mode ONCE, outside their loops
+// (APEXMI_ACT_DISPATCH): with act_f(x, P.gelu) per element hipcc emitted a four-way scalar branch chain around every one of a lane's
+// 128 values (1577 branches in the 256 x 256 kernel), so no two values' exp / rcp chains ever overlapped.
+template <int ACT>
+APEXMI_DEVICE float act_c(float x) {
+    if constexpr (ACT == 0) return x;
+    else return act_f(x, ACT);
+}
+#define APEXMI_ACT_DISPATCH(mode, ...)                                    \
+    switch (mode) {                                                       \
+        case 1: { constexpr int ACT = 1; __VA_ARGS__; } break;            \
+        case 2: { constexpr int ACT = 2; __VA_ARGS__; } break;            \
+        case 3: { constexpr int ACT = 3; __VA_ARGS__; } break;            \
+        case 4: { constexpr int ACT = 4; __VA_ARGS__; } break;            \
+        default: { constexpr int ACT = 0; __VA_ARGS__; } break;           \
+    }
 inline int act_mode(int epilogue) {
     return epilogue == APEXMI_EPI_BIAS_GELU ? 1 : epilogue == APEXMI_EPI_BIAS_GELU_ERF ? 2 : epilogue == APEXMI_EPI_BIAS_SILU ? 3 : epilogue == APEXMI_EPI_BIAS_QUICK_GELU ? 4 : 0;
 }
@@ -169,7 +198,7 @@ APEXMI_DEVICE void swap_pair(u32x2& a, u32x2& b) {
 // of one per 8-byte group (C may alias R, so the compiler cannot hoist loads above stores itself).
 // Accumulator layout: lane holds C[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3; pairs of groups are
 // exchanged with the other half-wave into 8 consecutive columns -> 16-byte accesses.
-template <int EPI, int TM>
+template <int EPI, int TM, int ACT = 0>
 APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, int N, const int (&m)[TM],
                                int nbase, int hi) {
     float bs[4][4];
@@ -202,7 +231,7 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o[j] = acc[mt][4 * g + j] + bs[g][j];
-                        if (EPI == APEXMI_EPI_BIAS_F32 && P.gelu) o[j] = act_f(o[j], P.gelu);
+                        o[j] = act_c<ACT>(o[j]);
                     }
                     if (EPI == EPI_GATE_RES_F32) {
                         const f32x4 r = *(const f32x4*)(Rf + (int64_t)m[mt] * P.ldr + n);
@@ -236,7 +265,7 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[q][j] = acc[mt][4 * (g0 + q) + j] + bs[g0 + q][j];
-                    if (EPI == APEXMI_EPI_BIAS && P.gelu) v[q][j] = act_f(v[q][j], P.gelu);  // block-uniform
+                    v[q][j] = act_c<ACT>(v[q][j]);
                 }
             if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
                 u32x2 ra = {rr[mt][pr][0], rr[mt][pr][1]}, rb = {rr[mt][pr][2], rr[mt][pr][3]};
@@ -275,7 +304,7 @@ APEXMI_DEVICE void swap16(uint32_t& a, uint32_t& b) {
 // c = lane & 15) holds C[m = mtile*16 + c][n = nbase + 16 t + 4 g + (0..3)] for t = 0 (x), 1 (y).  One
 // v_permlane16_swap per dword pair turns that into 8 consecutive columns per lane, starting at
 // nbase + 16 (g & 1) + 8 (g >> 1), so stores and residual loads are 16 bytes wide.
-template <int EPI, int MT>
+template <int EPI, int MT, int ACT = 0>
 APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], const GemmProblem& P, int N,
                                 const int (&m)[MT], int nbase, int g) {
     float bs[2][4];
@@ -305,7 +334,7 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o[j] = a[j] + bs[t][j];
-                        if (EPI == APEXMI_EPI_BIAS_F32 && P.gelu) o[j] = act_f(o[j], P.gelu);
+                        o[j] = act_c<ACT>(o[j]);
                     }
                     if (EPI == EPI_GATE_RES_F32) {
                         const f32x4 r = *(const f32x4*)(Rf + (int64_t)m[mt] * P.ldr + n);
@@ -331,10 +360,8 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         for (int j = 0; j < 4; ++j) {
             v[0][j] = x[mt][j] + bs[0][j];
             v[1][j] = y[mt][j] + bs[1][j];
-            if (EPI == APEXMI_EPI_BIAS && P.gelu) {
-                v[0][j] = act_f(v[0][j], P.gelu);
-                v[1][j] = act_f(v[1][j], P.gelu);
-            }
+            v[0][j] = act_c<ACT>(v[0][j]);
+            v[1][j] = act_c<ACT>(v[1][j]);
         }
         if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
             uint32_t r0 = rr[mt][0], r1 = rr[mt][1], r2 = rr[mt][2], r3 = rr[mt][3];
@@ -355,7 +382,11 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         swap16(x1, y1);
         if (m[mt] >= 0 && nst < N) {
             const u32x4 o = {x0, x1, y0, y1};
+#if APEXMI_GEMM_STORE_NT
+            __builtin_nontemporal_store(o, (u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst));
+#else
             *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;
+#endif
         }
     }
 }
@@ -519,10 +550,39 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
     }
 }
 
+#if APEXMI_GEMM_TRACE
+#define APEXMI_TRACE_END()                                                                                   \
+    do {                                                                                                     \
+        if (G.trace != nullptr) {                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            const unsigned long long t_st = __builtin_amdgcn_s_memrealtime();                                \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+            const unsigned long long t_ack = __builtin_amdgcn_s_memrealtime();                               \
+            if (tid == 0) {                                                                                  \
+                unsigned long long* o = G.trace + (size_t)blockIdx.x * 8;                                    \
+                o[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  /* HW_REG_HW_ID */             \
+                o[1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); /* HW_REG_XCC_ID */            \
+                o[2] = tr_in;                                                                                \
+                o[3] = tr_l0;                                                                                \
+                o[4] = tr_l1;                                                                                \
+                o[5] = t_st;                                                                                 \
+                o[6] = t_ack;                                                                                \
+                o[7] = (unsigned long long)s;                                                                \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+#else
+#define APEXMI_TRACE_END() do { } while (0)
+#endif
+
 template <typename CFG, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s, const SkCtx& sk) {
     constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
 
+#if APEXMI_GEMM_TRACE
+    unsigned long long tr_in = 0, tr_l0 = 0, tr_l1 = 0;
+    if (G.trace != nullptr) tr_in = __builtin_amdgcn_s_memrealtime();
+#endif
     int tid_ = threadIdx.x;
     // opaque per call: the persistent (stream-K) launch calls this in a loop, and everything derived from the lane id in the
     // epilogue would otherwise be hoisted out of that loop and held across the K-loop (+40 VGPRs: 160-220 spilled dwords)
@@ -598,6 +658,9 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         clk_c0 = __builtin_readcyclecounter();
         clk_r0 = __builtin_amdgcn_s_memrealtime();
     }
+#if APEXMI_GEMM_TRACE
+    if (G.trace != nullptr) tr_l0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * CFG::STAGE + wave * 1024;
@@ -1199,6 +1262,13 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
 #undef PP_BAR
     }
 
+#if APEXMI_GEMM_TRACE
+    if (G.trace != nullptr) {
+        __builtin_amdgcn_sched_barrier(0);
+        tr_l1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     if (G.clk != nullptr) {
         const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
@@ -1256,6 +1326,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         if constexpr (EPI == APEXMI_EPI_BIAS) {
             if (P.qkv) {                                // block-uniform
                 qkv_epilogue16(acc16, P, G.qs, M, m0, n0, wave, wm, wn, lane, smem);
+                APEXMI_TRACE_END();
                 return;
             }
         }
@@ -1265,9 +1336,10 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
             mrow16[mt] = m0 + wm * 128 + mt * 16 + (lane & 15);
             if (mrow16[mt] >= M) mrow16[mt] = -1;
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            store_slab16<EPI, 8>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, lane >> 4);
+        APEXMI_ACT_DISPATCH((EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_F32) ? P.gelu : 0,
+                            _Pragma("unroll") for (int p = 0; p < 2; ++p)
+                                store_slab16<EPI, 8, ACT>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, lane >> 4));
+        APEXMI_TRACE_END();
         return;
     }
     int mrow[TM];
@@ -1276,9 +1348,9 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         mrow[mt] = m0 + wm * (BM / CFG::WM) + mt * 32 + l31;
         if (mrow[mt] >= M) mrow[mt] = -1;  // lane stays alive for the cross-lane exchange, stores nothing
     }
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt)
-        store_ntile<EPI, TM>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi);
+    APEXMI_ACT_DISPATCH((EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_F32) ? P.gelu : 0,
+                        _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)
+                            store_ntile<EPI, TM, ACT>(acc[nt], P, N, mrow, n0 + wn * (BN / CFG::WN) + nt * 32, hi));
 }
 
 // The launch.  Normally one workgroup per tile.  STREAM-K (G.sk_r > 0, SCHED 5): 256 persistent workgroups, 32 per XCD.
@@ -1397,6 +1469,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
+#if APEXMI_GEMM_TRACE
+uintptr_t g_gemm_trace = 0;
+#endif
 int g_large_cfg = 7;  // tiling the auto path picks for large problems (tune key gemm.large)
 int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
 int g_wpacked = 0;    // experiment: W operands are tile-major packed (see GemmGroup::wpacked)
@@ -1450,6 +1525,9 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
     G.total = t;
     G.group_m = g_group_m;
     G.clk = apexmi_clk_ptr();
+#if APEXMI_GEMM_TRACE
+    G.trace = (unsigned long long*)g_gemm_trace;
+#endif
     G.wpacked = (CFG::SCHED == 5) ? g_wpacked : 0;
     G.sk_r = 0;
     G.sk_tfull = 0;
@@ -1733,6 +1811,10 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
     else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
+#if APEXMI_GEMM_TRACE
+    else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
+    else if (!strcmp(key, "gemm.trace_hi")) g_gemm_trace = (g_gemm_trace & (uintptr_t)0xffffffffu) | ((uintptr_t)(uint32_t)value << 32);
+#endif
     else if (!strcmp(key, "gemm.streamk")) g_streamk = value;
     else return 1;
     return 0;
