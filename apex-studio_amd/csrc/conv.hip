@@ -186,7 +186,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
         }
     }
 
-    // ---- epilogue: bias (+ residual) -> bf16, lane holds out[m][n .. n+3] per group ----
+    // ---- epilogue: bias (+ residual) -> bf16, lane holds out[m][n .. n+3] per group.  Bias once per column group, every residual
+    // load issued before the first store (out may alias res: the compiler cannot hoist them itself) ----
+    float bsf[2][4][4], rsf[2][2][4][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsf[nt][g][j] = 0.0f;
+            if (a.bias != nullptr) load4<bf16_t>(a.bias + min(n0 + wn * 64 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4), bsf[nt][g]);
+        }
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rsf[mt][nt][g][j] = 0.0f;
+                if (has_res) {
+                    const int m = min(m0 + wm * 64 + mt * 32 + l31, M - 1);
+                    load4<TO>((const TO*)a.res + (int64_t)m * a.Cout + min(n0 + wn * 64 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4), rsf[mt][nt][g]);
+                }
+            }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + wm * 64 + mt * 32 + l31;
@@ -198,21 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
                 if (m >= M || n >= a.Cout) continue;
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * g + j];
-                if (a.bias != nullptr) {
-                    float b[4];
-                    load4<bf16_t>(a.bias + n, b);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += b[j];
-                }
-                if (a.res != nullptr) {
-                    float r[4];
-                    load4<TO>((const TO*)a.res + (int64_t)m * a.Cout + n, r);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += r[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], a.act, a.act_slope);
+                for (int j = 0; j < 4; ++j) v[j] = conv_act(acc[nt][mt][4 * g + j] + bsf[nt][g][j] + rsf[mt][nt][g][j], a.act, a.act_slope);
                 store4<TO>((TO*)a.out + (int64_t)m * a.Cout + n, v);
             }
     }
@@ -270,40 +280,62 @@ APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const
         }
         return;
     }
+    // Loads first, all of them, then arithmetic and stores: out may alias res, so hipcc cannot move a residual load above an earlier
+    // store itself, and with the loads inside the (mt, nt, pr) loops every iteration paid its own memory round trip (and re-read the
+    // same bias for every m-tile) while the matrix pipe of the CU sat idle.  Bias stays packed (two dwords per 4-column group).
+    const int nb0 = n0 + wn * (NT * 32);
+    u32x2 bsp[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsp[nt][g] = u32x2{0u, 0u};
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bsp[nt][g] = *(const u32x2*)(a.bias + min(nb0 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4));
+    }
+    u32x4 rr[MT][NT][2];
+    const bool has_res = a.res != nullptr;
+    if (has_res) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    rr[mt][nt][pr] = *(const u32x4*)(a.res + (int64_t)max(mrow[mt], 0) * a.Cout +
+                                                     max(min(nb0 + nt * 32 + 8 * (2 * pr + hi), a.Cout - 8), 0));
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         ssq[mt] = 0.0f;
         const int m = mrow[mt];
-        const int64_t mrow_b = (int64_t)max(m, 0) * a.Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const int nb = n0 + wn * (NT * 32) + nt * 32;
+                const int nb = nb0 + nt * 32;
                 const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
                 if (nb + 16 * pr >= a.Cout) continue;             // wave-uniform; lanes past Cout inside the pair store nothing
                 u32x2 ra = {0u, 0u}, rb = {0u, 0u};
-                if (a.res != nullptr) {
-                    const u32x4 rr = *(const u32x4*)(a.res + mrow_b + min(nst, a.Cout - 8));
-                    ra = u32x2{rr[0], rr[1]};
-                    rb = u32x2{rr[2], rr[3]};
+                if (has_res) {
+                    ra = u32x2{rr[mt][nt][pr][0], rr[mt][nt][pr][1]};
+                    rb = u32x2{rr[mt][nt][pr][2], rr[mt][nt][pr][3]};
                     swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
                 }
                 u32x2 o[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int g = 2 * pr + q;
-                    const int n = min(nb + 8 * g + 4 * hi, a.Cout - 4);
                     float v[4];
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
-                    if (a.bias != nullptr) {
-                        const u32x2 b = *(const u32x2*)(a.bias + n);
-                        v[0] += bf16_lo(b[0]);
-                        v[1] += bf16_hi(b[0]);
-                        v[2] += bf16_lo(b[1]);
-                        v[3] += bf16_hi(b[1]);
-                    }
+                    const u32x2 b = bsp[nt][g];
+                    v[0] += bf16_lo(b[0]);
+                    v[1] += bf16_hi(b[0]);
+                    v[2] += bf16_lo(b[1]);
+                    v[3] += bf16_hi(b[1]);
                     const u32x2 r2 = q ? rb : ra;
                     v[0] += bf16_lo(r2[0]);
                     v[1] += bf16_hi(r2[0]);
@@ -350,35 +382,44 @@ APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const
             }
         }
         const float root_c = sqrtf((float)a.Cout);
+        u32x2 gmp[NT][4];                      // gamma, packed, once per channel group (it was re-read for every m-tile)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow[mt];
-            const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int g = 0; g < 4; ++g) gmp[nt][g] = *(const u32x2*)(a.norm_gamma + min(nb0 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4));
+        auto second = [&](auto SILU) {         // the SiLU switch is block-uniform: decided once, not per 4-column group
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int nb = n0 + wn * (NT * 32) + nt * 32;
-                    const int nst = nb + 8 * (2 * pr + hi);
-                    if (nb + 16 * pr >= a.Cout) continue;
-                    u32x2 o[2];
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow[mt];
+                const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int g = 2 * pr + q;
-                        const u32x2 gm = *(const u32x2*)(a.norm_gamma + min(nb + 8 * g + 4 * hi, a.Cout - 4));
-                        float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
-                                      acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
-                        if (a.norm_silu) {
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int nb = nb0 + nt * 32;
+                        const int nst = nb + 8 * (2 * pr + hi);
+                        if (nb + 16 * pr >= a.Cout) continue;
+                        u32x2 o[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * pr + q;
+                            const u32x2 gm = gmp[nt][g];
+                            float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
+                                          acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
+                            if constexpr (decltype(SILU)::value) {
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
+                            }
+                            o[q][0] = pack_bf16(y[0], y[1]);
+                            o[q][1] = pack_bf16(y[2], y[3]);
                         }
-                        o[q][0] = pack_bf16(y[0], y[1]);
-                        o[q][1] = pack_bf16(y[2], y[3]);
+                        swap_pair(o[0], o[1]);
+                        if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
                     }
-                    swap_pair(o[0], o[1]);
-                    if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
-                }
-        }
+            }
+        };
+        if (a.norm_silu) second(std::true_type{});
+        else second(std::false_type{});
     }
 }
 
