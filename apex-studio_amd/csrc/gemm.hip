@@ -62,10 +62,6 @@ namespace {
 #ifndef APEXMI_GEMM_TRACE
 #define APEXMI_GEMM_TRACE 0
 #endif
-// A/B of the 256 x 256 tile's output stores: 1 = non-temporal (streaming) stores.  Not shipped unless measured (see the trace log).
-#ifndef APEXMI_GEMM_STORE_NT
-#define APEXMI_GEMM_STORE_NT 0
-#endif
 constexpr int BK = 64;
 constexpr int GROUP_M = 6;   // tiles tall per group: an XCD's 32 concurrent tiles as ~6 x 5.3 (squarer than 8 x 4: fewer panel fetches per
                              // tile; interleaved A/B, profiles/r03_ab_gemm_group_m.log: Flux -0.4 %, Qwen -1.1 %, Wan -0.6 % vs 8)
@@ -306,7 +302,7 @@ APEXMI_DEVICE void swap16(uint32_t& a, uint32_t& b) {
 // nbase + 16 (g & 1) + 8 (g >> 1), so stores and residual loads are 16 bytes wide.
 template <int EPI, int MT, int ACT = 0>
 APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], const GemmProblem& P, int N,
-                                const int (&m)[MT], int nbase, int g) {
+                                const int (&m)[MT], int nbase, int g, const u32x4* rr_pre = nullptr) {
     float bs[2][4];
     f32x4 gt[2];
 #pragma unroll
@@ -351,7 +347,7 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
     if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            rr[mt] = *(const u32x4*)(P.R + (int64_t)max(m[mt], 0) * P.ldr + min(nst, N - 8));
+            rr[mt] = rr_pre ? rr_pre[mt] : *(const u32x4*)(P.R + (int64_t)max(m[mt], 0) * P.ldr + min(nst, N - 8));
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -382,11 +378,7 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
         swap16(x1, y1);
         if (m[mt] >= 0 && nst < N) {
             const u32x4 o = {x0, x1, y0, y1};
-#if APEXMI_GEMM_STORE_NT
-            __builtin_nontemporal_store(o, (u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst));
-#else
-            *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;
-#endif
+            *(u32x4*)(P.C + (int64_t)m[mt] * P.ldc + nst) = o;     // (non-temporal stores: no difference, profiles/r04_gemm_tile_trace_*)
         }
     }
 }
@@ -1336,9 +1328,27 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
             mrow16[mt] = m0 + wm * 128 + mt * 16 + (lane & 15);
             if (mrow16[mt] >= M) mrow16[mt] = -1;
         }
-        APEXMI_ACT_DISPATCH((EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_F32) ? P.gelu : 0,
-                            _Pragma("unroll") for (int p = 0; p < 2; ++p)
-                                store_slab16<EPI, 8, ACT>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, lane >> 4));
+        if constexpr (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+            // the residual rows of BOTH 32-column slabs before the first store: C may alias R, so hipcc keeps slab 1's loads behind
+            // slab 0's stores, a second memory round trip with every matrix pipe idle (gemm_tile_trace: 6.3-8 us against 3-4 us
+            // for the other epilogues)
+            u32x4 rr2[2][8];
+            const int g = lane >> 4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int nst = n0 + wn * 64 + p * 32 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+                    rr2[p][mt] = *(const u32x4*)(P.R + (int64_t)max(mrow16[mt], 0) * P.ldr + min(nst, N - 8));
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                store_slab16<EPI, 8, 0>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, g, rr2[p]);
+        } else {
+            APEXMI_ACT_DISPATCH((EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_F32) ? P.gelu : 0,
+                                _Pragma("unroll") for (int p = 0; p < 2; ++p)
+                                    store_slab16<EPI, 8, ACT>(acc16[2 * p], acc16[2 * p + 1], P, N, mrow16, n0 + wn * 64 + p * 32, lane >> 4));
+        }
         APEXMI_TRACE_END();
         return;
     }

@@ -8,7 +8,7 @@ if [ "${1:-build}" = "build" ]; then
   mkdir -p $BIN
   for v in trace:0; do
     n=${v%%:*}; nt=${v##*:}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DAPEXMI_GEMM_TRACE=1 -DAPEXMI_GEMM_STORE_NT=$nt -c $ROOT/apex-studio_amd/csrc/gemm.hip -o $BIN/gemm_$n.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DAPEXMI_GEMM_TRACE=1 -c $ROOT/apex-studio_amd/csrc/gemm.hip -o $BIN/gemm_$n.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $BIN/libapex_$n.so $ROOT/apex-studio_amd/csrc/runtime.o $BIN/gemm_$n.o \
       $ROOT/apex-studio_amd/csrc/attention.o $ROOT/apex-studio_amd/csrc/elementwise.o $ROOT/apex-studio_amd/csrc/conv.o && rm $BIN/gemm_$n.o
   done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic + MFMA-pipe occupancy of the attention kernels in the Wan step (dominant kernel of `bench.py --workload
 # wan`): separate rocprofv3 --pmc passes (kernel-trace only beside the counters) over ONE expert forward.  Writes
-# gpurun_out/pmc_wan/r03_pmc_attn_wan.json (copy to profiles/) with the sha256 of csrc/attention.hip the binary was built
+# gpurun_out/pmc_wan/${ROUND:-r04}_pmc_attn_wan.json (copy to profiles/) with the sha256 of csrc/attention.hip the binary was built
 # from — bench.py reports `roofline.traffic` from it only while that hash still matches.
 set -u
 R=$GRAFT_REPO_ROOT
@@ -49,7 +49,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in s and "GRBM_GUI_ACTIVE" in w:
     res["mfma_pipe_busy_fraction"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (w["GRBM_GUI_ACTIVE"] / 8 * 1024)
     if s.get("SQ_LDS_IDX_ACTIVE"):
         res["lds_bank_conflict_share"] = s.get("SQ_LDS_BANK_CONFLICT", 0.0) / s["SQ_LDS_IDX_ACTIVE"]
-json.dump(res, open(out + "r03_pmc_attn_wan.json", "w"), indent=1)
+json.dump(res, open(out + os.environ.get("ROUND", "r04") + "_pmc_attn_wan.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
