@@ -53,6 +53,9 @@ namespace {
 // (APEXMI_GEMM_STREAMK=1 python -m apex_studio_amd.build).  Correct and deterministic, but 6 .. 40 % SLOWER than the tile launch:
 // the persistent workgroups lose the dispatcher's dynamic load balancing (+8 us per tile even without a split tile) and a split
 // tile's hand-over costs ~15 us.  The shipped library does not contain the persistent path (its kernel allocates scratch).
+// Those figures are from the commit that built it (git log -S APEXMI_GEMM_STREAMK); since the epilogue rewrite later in round 4
+// (one instantiation per activation mode, both residual slabs pre-loaded) the persistent item loop spills 64-191 VGPRs and runs at
+// half the tile launch's rate (profiles/r04_gemm_persistent_probe_b.log) — the build flag is kept for the record, not maintained.
 #ifndef APEXMI_GEMM_STREAMK
 #define APEXMI_GEMM_STREAMK 0
 #endif
