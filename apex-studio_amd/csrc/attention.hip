@@ -20,6 +20,18 @@
 // its L2 copy of K / V^T.
 #include "common.h"
 
+// Per-workgroup timeline of the shipped flash kernel (tools/attn_tile_trace.py): compiled in only with -DAPEXMI_ATTN_TRACE=1 into a side
+// library; the host reads a device pointer from the environment variable APEXMI_ATTN_TRACE_PTR (hex) at every launch.  8 u64 per
+// workgroup: {HW_ID, XCC_ID, t_entry, t_loop_begin, t_loop_end, t_stores_issued, t_stores_acknowledged, tile} (s_memrealtime, 10 ns).
+#ifndef APEXMI_ATTN_TRACE
+#define APEXMI_ATTN_TRACE 0
+#endif
+#if APEXMI_ATTN_TRACE
+#include <stdlib.h>
+__device__ unsigned long long* d_attn_trace = nullptr;
+#endif
+
+
 #include <cstdint>
 
 namespace {
@@ -253,6 +265,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     int64_t o_ss, int64_t o_sh, float scale_log2e, int s_base, int nsplit, float* __restrict__ opart,
     float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if APEXMI_ATTN_TRACE
+    unsigned long long* const trace = d_attn_trace;
+    unsigned long long tr_in = 0, tr_l0 = 0, tr_l1 = 0;
+    if (trace) tr_in = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -380,6 +397,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     int slot = 0;              // LDS stage of tile t
     if (late) C4_BAR();        // second half runs one cluster behind
     if ((PRIO & 4) && late) __builtin_amdgcn_s_setprio(1);   // the younger half loses every age arbitration otherwise
+#if APEXMI_ATTN_TRACE
+    if (trace) tr_l0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < nt; ++t) {
         const char* Ks = smem + (NS == 2 ? (t & 1) : slot) * ATT_STAGE;
         const char* Vs = Ks + K_TILE_BYTES;
@@ -502,6 +522,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     if (!late) C4_BAR();       // balance the barrier count of the two halves
 #undef C4_BAR
 #undef C4_LGKM_BAR
+#if APEXMI_ATTN_TRACE
+    if (trace) {
+        __builtin_amdgcn_sched_barrier(0);
+        tr_l1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 
     // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
     const float l_tot = sum_xor32(l_run);
@@ -537,6 +564,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
                 *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
             }
     }
+#if APEXMI_ATTN_TRACE
+    if (trace) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t_st = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_ack = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = trace + (size_t)blockIdx.x * 8;
+            o[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            o[1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+            o[2] = tr_in;
+            o[3] = tr_l0;
+            o[4] = tr_l1;
+            o[5] = t_st;
+            o[6] = t_ack;
+            o[7] = (unsigned long long)s;
+        }
+    }
+#endif
 }
 
 
@@ -1174,6 +1220,13 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
         const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
         if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
         const int main_wgs = total - tail;
+#if APEXMI_ATTN_TRACE
+        {
+            const char* e = getenv("APEXMI_ATTN_TRACE_PTR");
+            unsigned long long* p = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_attn_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, stream);
+        }
+#endif
         hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), c4_lds, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
                            o_strides[2], c, 0, 1, (float*)nullptr, (float*)nullptr);

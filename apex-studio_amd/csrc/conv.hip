@@ -18,6 +18,45 @@
 // Weights are pre-packed [Cout, Kpad] (tap-major, ci-minor).  128x128x64 tile, 4 waves, 2 workgroups/CU.
 #include "common.h"
 
+// Per-workgroup timeline of the direct-convolution kernels (tools/conv_tile_trace.py): compiled in only with -DAPEXMI_CONV_TRACE=1 into
+// a side library; the host reads a device pointer from APEXMI_CONV_TRACE_PTR (hex) at every slab launch.  8 u64 per workgroup:
+// {HW_ID, XCC_ID, t_entry, t_loop_begin, t_loop_end, t_stores_issued, t_stores_acknowledged, 0} (s_memrealtime, 10 ns).
+#ifndef APEXMI_CONV_TRACE
+#define APEXMI_CONV_TRACE 0
+#endif
+#if APEXMI_CONV_TRACE
+#include <stdlib.h>
+__device__ unsigned long long* d_conv_trace = nullptr;
+#define CONV_TRACE_DECL() unsigned long long* const trace_ = d_conv_trace; unsigned long long tr_in = 0, tr_l0 = 0, tr_l1 = 0; \
+    if (trace_) tr_in = __builtin_amdgcn_s_memrealtime()
+#define CONV_TRACE_AT(x) do { if (trace_) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define CONV_TRACE_END()                                                                                     \
+    do {                                                                                                     \
+        if (trace_) {                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            const unsigned long long t_st = __builtin_amdgcn_s_memrealtime();                                \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+            const unsigned long long t_ack = __builtin_amdgcn_s_memrealtime();                               \
+            if (threadIdx.x == 0) {                                                                          \
+                unsigned long long* o = trace_ + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;          \
+                o[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                                 \
+                o[1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);                                \
+                o[2] = tr_in; o[3] = tr_l0; o[4] = tr_l1; o[5] = t_st; o[6] = t_ack;                         \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+static void conv_trace_arm(hipStream_t stream) {
+    const char* e = getenv("APEXMI_CONV_TRACE_PTR");
+    unsigned long long* p = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_conv_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, stream);
+}
+#else
+#define CONV_TRACE_DECL() do { } while (0)
+#define CONV_TRACE_AT(x) do { } while (0)
+#define CONV_TRACE_END() do { } while (0)
+#endif
+
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -785,6 +824,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     constexpr int SLABB = NPJ * 8192;
     constexpr int WCH = NT * 32 * PITCH, WP = WCH / 1024;   // weight chunk: NT * 32 rows x PITCH bytes
     constexpr int WLD = (WP + 3) / 4;                    // weight pieces per issuing wave (waves 0..3)
+    CONV_TRACE_DECL();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -903,6 +943,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     w_chunk_next();
 
     int ph = 0, sp = 0, slot = 0;
+    CONV_TRACE_AT(tr_l0);
     for (int it = 0; it < nchunks; ++it) {
         if (loader) {
             // the slab of this phase was issued during the previous phase (or the prologue): wait for it once, at the phase's
@@ -968,6 +1009,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         }
     }
 
+    CONV_TRACE_AT(tr_l1);
     int mrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -975,6 +1017,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         mrow[m] = (y < a.H && x < a.W) ? (t * a.H + y) * a.W + x : -1;
     }
     conv_epilogue<MT, NT, 1, NORM>(a, acc, mrow, n0, wave, 0, l31, hi, smem);
+    CONV_TRACE_END();
 }
 
 // Register-prefetch form of the slab kernel (shipped, conv.pp = 1).  Same slab / weight-chunk images, same (temporal tap ->
@@ -1006,6 +1049,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     constexpr int WCH = WROWS * PITCH, WP = WCH / 1024;       // weight chunk bytes / pieces
     constexpr int WLN = (WP + NW - 1) / NW;                   // weight pieces per wave and chunk
     static_assert(NPJ <= 16 && WLN <= 5 && SPT <= 3, "piece tables");
+    CONV_TRACE_DECL();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1275,10 +1319,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
             advance_phase();
         }
     };
+    CONV_TRACE_AT(tr_l0);
     for (int it = 0; it < nchunks; it += 2) {
         interval(std::integral_constant<int, 0>{}, it);
         if (it + 1 < nchunks) interval(std::integral_constant<int, 1>{}, it + 1);
     }
+    CONV_TRACE_AT(tr_l1);
 
 #undef STAMP
     if (prof && lane == 0) {
@@ -1296,6 +1342,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
         mrow[m] = (y < a.H && x < a.W) ? (t * a.H + y) * a.W + x : -1;
     }
     conv_epilogue<MT, NT, WNW, NORM>(a, acc, mrow, n0, wr, wn, l31, hi, smem);
+    CONV_TRACE_END();
 }
 
 using CV_N32 = ConvCfg<8, 1, 2, 1>;    // 512 x 32
@@ -1333,6 +1380,9 @@ int launch_slab_inst(const ConvArgs& a, hipStream_t stream) {
     APEXMI_SET_ATTR_ONCE(attr,
         (void)hipFuncSetAttribute((const void*)conv3d_slab_kernel<NT, MT, NORM, SLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int gx = a.T * ((a.H + 8 * MT - 1) / (8 * MT)) * ((a.W + 31) / 32), gy = (a.Cout + NT * 32 - 1) / (NT * 32);
+#if APEXMI_CONV_TRACE
+    conv_trace_arm(stream);
+#endif
     hipLaunchKernelGGL((conv3d_slab_kernel<NT, MT, NORM, SLW>), dim3(gx, gy), dim3(512), LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab)");
 }
@@ -1347,6 +1397,9 @@ int launch_slabp_inst(const ConvArgs& a, hipStream_t stream) {
     APEXMI_SET_ATTR_ONCE(attr, (void)hipFuncSetAttribute((const void*)conv3d_slabp_kernel<NT, MT, WNW, NORM, SLW, NW>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int gx = a.T * ((a.H + TH - 1) / TH) * ((a.W + 31) / 32), gy = (a.Cout + WROWS - 1) / WROWS;
+#if APEXMI_CONV_TRACE
+    conv_trace_arm(stream);
+#endif
     hipLaunchKernelGGL((conv3d_slabp_kernel<NT, MT, WNW, NORM, SLW, NW>), dim3(gx, gy), dim3(NW * 64), LDS, stream, a);
     return apexmi_check_launch("conv3d_cl (slab, prefetch)");
 }
