@@ -26,6 +26,11 @@
 #ifndef APEXMI_ATTN_TRACE
 #define APEXMI_ATTN_TRACE 0
 #endif
+// Timing-only ablation of the shipped kernel's softmax cluster (WRONG results; side library only, tools/attn_ablate.sh):
+// bit 0: exp2 replaced by a move; bit 1: no row-max (the max pass and its cross-lane exchange skipped); bit 2: no V^T fragment reads
+#ifndef APEXMI_ATTN_ABLATE
+#define APEXMI_ATTN_ABLATE 0
+#endif
 #if APEXMI_ATTN_TRACE
 #include <stdlib.h>
 __device__ unsigned long long* d_attn_trace = nullptr;
@@ -429,11 +434,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
         C4_BAR();
         // ---- C3: V^T fragments -> the same registers, softmax beside the reads ----
+        if (!(APEXMI_ATTN_ABLATE & 4)) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                kv[kk * 4 + dt] = *(const bf16x8*)(Vs + v_off[dt] + (((kk * 2 + hi) ^ v_sw[dt]) << 4));
+                for (int dt = 0; dt < 4; ++dt)
+                    kv[kk * 4 + dt] = *(const bf16x8*)(Vs + v_off[dt] + (((kk * 2 + hi) ^ v_sw[dt]) << 4));
+        }
         if (t == nt - 1 && (Sk & (KV - 1)) != 0) {   // mask keys past Sk (wave-uniform branch)
             const int kv0 = t * KV;
 #pragma unroll
@@ -447,11 +454,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         }
         {
             float mx = sacc[0][0];
+            if (!(APEXMI_ATTN_ABLATE & 2)) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
-            mx = max_xor32(mx) * scale_log2e;
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+                mx = max_xor32(mx) * scale_log2e;
+            }
             if (__any(mx > m_run + DEFER)) {
                 const float m_new = ceilf(fmaxf(m_run, mx));   // integer: see the note above DEFER
                 const float alpha = fast_exp2(m_run - m_new);
@@ -473,8 +482,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 x = {sacc[kt][r], sacc[kt][r + 1]};
                         x = __builtin_elementwise_fma(x, c2, nm2);
-                        x[0] = fast_exp2(x[0]);
-                        x[1] = fast_exp2(x[1]);
+                        if (!(APEXMI_ATTN_ABLATE & 1)) {
+                            x[0] = fast_exp2(x[0]);
+                            x[1] = fast_exp2(x[1]);
+                        }
                         sacc[kt][r] = x[0];
                         sacc[kt][r + 1] = x[1];
                         ps2 += x;
