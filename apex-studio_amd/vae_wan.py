@@ -349,7 +349,7 @@ class AutoencoderKLWan(nn.Module):
         return ops.conv3d_cl_norm(x, w, b, k, gamma, silu=silu, residual=residual, want_raw=want_raw, upsample2x=upsample2x,
                                   independent_frames=self._indep and k[0] > 1)
 
-    def _res(self, blk: _Res, x, xn=None, next_norm=None):
+    def _res(self, blk: _Res, x, xn=None, next_norm=None, want_raw=True):
         """WanResidualBlock (reference vae/wan/model.py:389-441).  `xn` = silu(norm1(x)) when the producer of x already
         made it; `next_norm` = (gamma, silu) of the norm that will read this block's output.  conv1's output is read by
         norm2 only, so it is never stored: conv1 writes silu(norm2(.)) directly.  Returns (out, normed out or None)."""
@@ -359,7 +359,9 @@ class AutoencoderKLWan(nn.Module):
         _, n2 = self._conv_norm(blk.conv1, xn, self._gamma(blk.norm2), silu=True, want_raw=False)
         if next_norm is None:
             return self._conv(blk.conv2, n2, residual=h), None
-        return self._conv_norm(blk.conv2, n2, next_norm[0], silu=next_norm[1], residual=h)
+        # want_raw=False (the decoder's LAST block): only norm_out reads this output, so the raw tensor — 1 GB per full-resolution
+        # tile — is never stored
+        return self._conv_norm(blk.conv2, n2, next_norm[0], silu=next_norm[1], residual=h, want_raw=want_raw)
 
     def _attn(self, blk: _Attn, x, n=None):
         T, H, W, Cc = x.shape
@@ -410,7 +412,7 @@ class AutoencoderKLWan(nn.Module):
             else:
                 nn_ = None                          # a resampler reads the raw tensor
             if isinstance(m, _Res):
-                x, xn = self._res(m, x, xn, next_norm=nn_)
+                x, xn = self._res(m, x, xn, next_norm=nn_, want_raw=nxt is not None)
             else:
                 x, xn = self._resample(m, x, next_norm=nn_)
         return self._conv(d.conv_out, xn)
