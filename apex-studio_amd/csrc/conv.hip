@@ -884,29 +884,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         const int n = L / CPP, sl = L - n * CPP;
         wsrc[i] = (const char*)(a.w + (int64_t)min(n0 + n, a.Cout - 1) * a.Kpad + (slab_swz<SLW>(sl, n) * 8));
     }
-    const int nchunks = nph * 9;
-    // chunk cursor (the chunk to ISSUE next): ring slot, spatial tap, slice, temporal tap -> byte offset into a weight row
-    int c_slot = 0, c_sp = 0, c_sl = 0;
-    int c_step = 0;                                            // temporal step of the issue cursor (-> tap through slab_tap_of_step)
-    int64_t c_tap_off = (int64_t)(kt_first + slab_tap_of_step(0, t, nk, a.torder)) * 9 * a.Cin * 2;   // (temporal tap * 9) * Cin * 2 bytes
-    auto w_chunk_next = [&]() {
-        const int64_t kbase = c_tap_off + (int64_t)c_sp * (a.Cin * 2) + c_sl * PITCH;
-        char* dst = smem + 2 * SLABB + c_slot * WCH;
-        if (!loader) {
+    // A phase = (temporal tap, channel slice) = nine chunks, one per spatial tap, UNROLLED below: the tap (dy, dx), the weight-ring
+    // slot (9 = 0 mod 3: chunk sp of every phase sits in slot sp % 3), which chunks carry slab pieces and the issue cursor's tap are
+    // compile-time constants, so what is left per chunk is the work itself (round 3 counted 105 SALU + 58 VALU instructions and 15
+    // branches of bookkeeping per chunk beside 18 MFMAs).  Same order of loads, waits, reads and MFMAs as before: same bits.
+    auto w_issue = [&](int slot_, int64_t kbase) {       // the weight chunk at byte offset kbase of every row -> ring slot slot_
+        char* dst = smem + 2 * SLABB + slot_ * WCH;
 #pragma unroll
-            for (int i = 0; i < WLD; ++i)
-                if ((i + 1) * 4 <= WP || i * 4 + wave < WP) glds16(wsrc[i] + kbase, dst + (i * 4 + wave) * 1024);   // wave-uniform
-        }
-        c_slot = c_slot == 2 ? 0 : c_slot + 1;
-        if (++c_sp == 9) {
-            c_sp = 0;
-            if (++c_sl == S) {
-                c_sl = 0;
-                ++c_step;
-                c_tap_off = (int64_t)(kt_first + slab_tap_of_step(min(c_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2;
-            }
+        for (int i = 0; i < WLD; ++i)
+            if ((i + 1) * 4 <= WP || i * 4 + wave < WP) glds16(wsrc[i] + kbase, dst + (i * 4 + wave) * 1024);   // wave-uniform
+    };
+    int w_sl = 0, w_step = 0;                             // (slice, temporal step) of the phase AFTER the current one
+    auto w_phase_base = [&]() -> int64_t {
+        return (int64_t)(kt_first + slab_tap_of_step(min(w_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2 + w_sl * PITCH;
+    };
+    int64_t wk_cur = w_phase_base();
+    auto w_phase_advance = [&]() {
+        if (++w_sl == S) {
+            w_sl = 0;
+            ++w_step;
         }
     };
+    w_phase_advance();
+    int64_t wk_next = w_phase_base();
     int nw = 0;                                        // this wave's loads per weight chunk (0 for the slab loaders)
 #pragma unroll
     for (int i = 0; i < WLD; ++i) nw += (!loader && ((i + 1) * 4 <= WP || i * 4 + wave < WP)) ? 1 : 0;
@@ -939,74 +939,93 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
         }
     };
     advance_phase();
-    w_chunk_next();
-    w_chunk_next();
+    if (!loader) {
+        w_issue(0, wk_cur);
+        w_issue(1, wk_cur + (int64_t)(a.Cin * 2));
+    }
+    auto wait_weights = [&](bool last) {               // at most this wave's pieces of the NEXT chunk may still be in flight
+        switch (last ? 0 : nw) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+    };
+    int pa0[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pa0[m] = (MT * wave + m) * SC + l31;
+    int wrow_off[NT];                                  // byte offset of this lane's weight row of n-tile nt inside a chunk image
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow_off[nt] = (nt * 32 + l31) * PITCH;
 
-    int ph = 0, sp = 0, slot = 0;
     CONV_TRACE_AT(tr_l0);
-    for (int it = 0; it < nchunks; ++it) {
-        if (loader) {
-            // the slab of this phase was issued during the previous phase (or the prologue): wait for it once, at the phase's
-            // first chunk; its pieces had a whole phase to land
-            if (sp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            // loads of this wave issued after chunk `it`: chunk it + 1
-            const int k = it + 1 < nchunks ? nw : 0;
-            switch (k) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            }
-        }
-        // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int dy = sp / 3, dx = sp - dy * 3;
+    for (int ph = 0; ph < nph; ++ph) {
         const char* Sb = smem + (ph & 1) * SLABB;
-        const char* Ws = smem + 2 * SLABB + slot * WCH;
-        slot = slot == 2 ? 0 : slot + 1;
-        int pa[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) pa[m] = (MT * wave + m + dy) * SC + (l31 + dx);
-        // order inside a chunk: all fragment reads -> this wave's DMA issues (their ~150 cycles apiece hide the LDS latency)
-        // -> the MFMAs, which then drain underneath the next chunk's wait / barrier / reads
-        bf16x8 af[KS][MT], wf[KS][NT];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * PITCH + (slab_swz<SLW>(2 * ks + hi, pa[m]) << 4));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nt * 32 + l31;
-                wf[ks][nt] = *(const bf16x8*)(Ws + n * PITCH + (slab_swz<SLW>(2 * ks + hi, n) << 4));
+        const bool last_ph = ph + 1 == nph;
+        auto chunk = [&](auto SPC) {
+            constexpr int sp = decltype(SPC)::value;
+            constexpr int dy = sp / 3, dx = sp - dy * 3;
+            if (loader) {
+                // the slab of this phase was issued during the previous phase (or the prologue): wait for it once, at the phase's
+                // first chunk; its pieces had a whole phase to land
+                if constexpr (sp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                wait_weights(sp == 8 && last_ph);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (loader) {     // next phase's slab: two pieces per chunk over the first NPJ chunks of this phase
-            if (ph + 1 < nph && sp < NPJ) {
-                slab_piece((ph + 1) & 1, np_off, 2 * sp);
-                slab_piece((ph + 1) & 1, np_off, 2 * sp + 1);
+            // a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. waits for the prefetches too
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const char* Ws = smem + 2 * SLABB + (sp % 3) * WCH;
+            int pa[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) pa[m] = pa0[m] + (dy * SC + dx);
+            // order inside a chunk: all fragment reads -> this wave's DMA issues (their ~150 cycles apiece hide the LDS latency)
+            // -> the MFMAs, which then drain underneath the next chunk's wait / barrier / reads
+            bf16x8 af[KS][MT], wf[KS][NT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * PITCH + (slab_swz<SLW>(2 * ks + hi, pa[m]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[ks][nt] = *(const bf16x8*)(Ws + wrow_off[nt] + (slab_swz<SLW>(2 * ks + hi, nt * 32 + l31) << 4));
             }
-        } else if (it + 2 < nchunks) {
-            w_chunk_next();
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (loader) {     // next phase's slab: two pieces per chunk over the first NPJ chunks of this phase
+                if constexpr (sp < NPJ) {
+                    if (!last_ph) {
+                        slab_piece((ph + 1) & 1, np_off, 2 * sp);
+                        slab_piece((ph + 1) & 1, np_off, 2 * sp + 1);
+                    }
+                }
+            } else if (!(last_ph && sp >= 7)) {         // the chunk two ahead: spatial tap (sp + 2) % 9 of this phase or of the next
+                w_issue((sp + 2) % 3, (sp < 7 ? wk_cur : wk_next) + (int64_t)((sp + 2) % 9) * (a.Cin * 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nt], af[ks][m], acc[nt][m], 0, 0, 0);
-        if (++sp == 9) {
-            sp = 0;
-            ++ph;
-            advance_phase();
-        }
+                    for (int m = 0; m < MT; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nt], af[ks][m], acc[nt][m], 0, 0, 0);
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        chunk(std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 5>{});
+        chunk(std::integral_constant<int, 6>{});
+        chunk(std::integral_constant<int, 7>{});
+        chunk(std::integral_constant<int, 8>{});
+        advance_phase();
+        wk_cur = wk_next;
+        w_phase_advance();
+        wk_next = w_phase_base();
     }
 
     CONV_TRACE_AT(tr_l1);
