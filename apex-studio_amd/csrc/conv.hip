@@ -957,9 +957,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
     int pa0[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) pa0[m] = (MT * wave + m) * SC + l31;
-    int wrow_off[NT];                                  // byte offset of this lane's weight row of n-tile nt inside a chunk image
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wrow_off[nt] = (nt * 32 + l31) * PITCH;
 
     CONV_TRACE_AT(tr_l0);
     for (int ph = 0; ph < nph; ++ph) {
@@ -981,6 +978,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             const char* Ws = smem + 2 * SLABB + (sp % 3) * WCH;
             int pa[MT];
+            // (with a compile-time tap the fragment offsets of all nine taps are loop-invariant and hipcc hoists them out of the phase
+            // loop: up to 256 VGPRs, no spill in any instantiation, and measured FASTER than recomputing them per chunk — HunyuanVideo-1.5
+            // decode 2265 vs 2294 ms; the prefetch kernel below, which has no registers to spare, keeps them opaque instead)
+            const int lrow = l31;
 #pragma unroll
             for (int m = 0; m < MT; ++m) pa[m] = pa0[m] + (dy * SC + dx);
             // order inside a chunk: all fragment reads -> this wave's DMA issues (their ~150 cycles apiece hide the LDS latency)
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_slab_kernel(const ConvArgs a) {
                 for (int m = 0; m < MT; ++m) af[ks][m] = *(const bf16x8*)(Sb + pa[m] * PITCH + (slab_swz<SLW>(2 * ks + hi, pa[m]) << 4));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    wf[ks][nt] = *(const bf16x8*)(Ws + wrow_off[nt] + (slab_swz<SLW>(2 * ks + hi, nt * 32 + l31) << 4));
+                    wf[ks][nt] = *(const bf16x8*)(Ws + (nt * 32 + lrow) * PITCH + (slab_swz<SLW>(2 * ks + hi, nt * 32 + lrow) << 4));
             }
             __builtin_amdgcn_sched_barrier(0);
             if (loader) {     // next phase's slab: two pieces per chunk over the first NPJ chunks of this phase
@@ -1131,37 +1132,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)(smem + buf * SLABB + (j * NW + wave) * 1024), 16,
                                                  (int)o, 0, 0, 0);
     };
-    // issue cursor over weight chunks
-    int c_slot = 0, c_sp = 0, c_sl = 0;
-    int c_step = 0;
-    int c_tap_off = (kt_first + slab_tap_of_step(0, t, nk, a.torder)) * 9 * a.Cin * 2;
-    auto w_piece = [&](auto I) -> int {                         // piece i of the chunk under the cursor; 1 if this wave has it
+    // Weight chunks: byte offset of a PHASE's (temporal tap, slice) inside a weight row; the nine spatial taps of the phase follow at
+    // Cin * 2 bytes each.  wk_cur = the phase whose MFMAs run, wk_next = the one after it.
+    int w_sl = 0, w_step = 0;
+    auto w_phase_base = [&]() -> int {
+        return (kt_first + slab_tap_of_step(min(w_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2 + w_sl * PITCH;
+    };
+    auto w_phase_advance = [&]() {
+        if (++w_sl == S) {
+            w_sl = 0;
+            ++w_step;
+        }
+    };
+    int wk_cur = w_phase_base();
+    w_phase_advance();
+    int wk_next = w_phase_base();
+    auto w_piece = [&](auto I, int slot_, int kbase) -> int {   // piece i of the chunk at kbase -> ring slot slot_; 1 if this wave has it
         constexpr int i = decltype(I)::value;
         if (i * NW + wave >= WP || (a.dbg & 1)) return 0;
-        const int kbase = c_tap_off + c_sp * (a.Cin * 2) + c_sl * PITCH;
-        char* dst = smem + 2 * SLABB + c_slot * WCH;
+        char* dst = smem + 2 * SLABB + slot_ * WCH;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (i * NW + wave) * 1024), 16, wvoff[i], kbase, 0,
                                                  0);
         return 1;
     };
-    auto w_advance = [&]() {
-        c_slot = (c_slot + 1) & 3;
-        if (++c_sp == 9) {
-            c_sp = 0;
-            if (++c_sl == S) {
-                c_sl = 0;
-                ++c_step;
-                c_tap_off = (kt_first + slab_tap_of_step(min(c_step, nk - 1), t, nk, a.torder)) * 9 * a.Cin * 2;
-            }
-        }
-    };
-    auto w_chunk_all = [&]() {
-        (void)w_piece(std::integral_constant<int, 0>{});
-        if constexpr (WLN > 1) (void)w_piece(std::integral_constant<int, 1>{});
-        if constexpr (WLN > 2) (void)w_piece(std::integral_constant<int, 2>{});
-        if constexpr (WLN > 3) (void)w_piece(std::integral_constant<int, 3>{});
-        if constexpr (WLN > 4) (void)w_piece(std::integral_constant<int, 4>{});
-        w_advance();
+    auto w_chunk_all = [&](int slot_, int kbase) {
+        (void)w_piece(std::integral_constant<int, 0>{}, slot_, kbase);
+        if constexpr (WLN > 1) (void)w_piece(std::integral_constant<int, 1>{}, slot_, kbase);
+        if constexpr (WLN > 2) (void)w_piece(std::integral_constant<int, 2>{}, slot_, kbase);
+        if constexpr (WLN > 3) (void)w_piece(std::integral_constant<int, 3>{}, slot_, kbase);
+        if constexpr (WLN > 4) (void)w_piece(std::integral_constant<int, 4>{}, slot_, kbase);
     };
 
     f32x16 acc[NT][MT];
@@ -1191,43 +1190,48 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     for (int j = 0; j < NPJ; ++j)
         if (j * NW + wave < NSP) slab_piece(0, np_off, soff[j], j);
     advance_phase();
-    w_chunk_all();
-    if (nchunks > 1) w_chunk_all();
-    if (nchunks > 2) w_chunk_all();
+    w_chunk_all(0, wk_cur);                                   // chunks 0, 1, 2 of phase 0 (a phase has nine: they exist)
+    w_chunk_all(1, wk_cur + a.Cin * 2);
+    w_chunk_all(2, wk_cur + 2 * a.Cin * 2);
 
-    // ---- fragment reads: cursor (phase parity, spatial tap, ring slot) of the chunk to READ next
-    int r_buf = 0, r_sp = 0, r_slot = 0;
+    // ---- fragment reads ----
     const int wrow = wn * (NT * 32) + l31;                     // this lane's first weight row inside the chunk
     bf16x8 af[2][KS][MT], wf[2][KS][NT];
     constexpr int NR = KS * (MT + NT), NM = KS * NT * MT;      // fragment reads / MFMAs per chunk
     const char* rbase[MT + NT];                                // LDS row addresses of the chunk being read
     int rkey[MT + NT];                                         // ... and their swizzle keys (position / weight row)
-    auto read_setup = [&]() {
-        const int dy = r_sp / 3, dx = r_sp - dy * 3;
-        const char* Sb = smem + r_buf * SLABB;
-        const char* Ws = smem + 2 * SLABB + r_slot * WCH;
+    int pa0[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pa0[m] = (MT * wr + m) * SC + l31;
+    // address arithmetic of the reads of the chunk with spatial tap SPR in slab buffer buf_ and weight-ring slot slot_
+    auto read_setup = [&](auto SPR, int buf_, int slot_) {
+        constexpr int spr = decltype(SPR)::value;
+        constexpr int dy = spr / 3, dx = spr - dy * 3;
+        const char* Sb = smem + buf_ * SLABB;
+        const char* Ws = smem + 2 * SLABB + slot_ * WCH;
+        // opaque copies: with the tap a compile-time constant everything derived from the lane's position is loop-invariant, and
+        // hipcc hoists nine taps' worth of swizzled offsets out of the chunk loop (+60 VGPRs: spills inside the loop)
+        int w0 = wrow;
+        asm volatile("" : "+v"(w0));
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            rkey[m] = (MT * wr + m + dy) * SC + (l31 + dx);
+            int p0 = pa0[m];
+            asm volatile("" : "+v"(p0));
+            rkey[m] = p0 + (dy * SC + dx);
             rbase[m] = Sb + rkey[m] * PITCH;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            rkey[MT + nt] = wrow + nt * 32;
+            rkey[MT + nt] = w0 + nt * 32;
             rbase[MT + nt] = Ws + rkey[MT + nt] * PITCH;
-        }
-        r_slot = (r_slot + 1) & 3;
-        if (++r_sp == 9) {
-            r_sp = 0;
-            r_buf ^= 1;
         }
     };
     auto read_one = [&](auto SET, auto R) {                   // read r of the chunk: k-step r / (MT + NT), operand r % (MT + NT)
-        constexpr int s = decltype(SET)::value, r = decltype(R)::value;
+        constexpr int s_ = decltype(SET)::value, r = decltype(R)::value;
         constexpr int ks = r / (MT + NT), o = r % (MT + NT);
         const bf16x8 v = *(const bf16x8*)(rbase[o] + (slab_swz<SLW>(2 * ks + hi, rkey[o]) << 4));
-        if constexpr (o < MT) af[s][ks][o] = v;
-        else wf[s][ks][o - MT] = v;
+        if constexpr (o < MT) af[s_][ks][o] = v;
+        else wf[s_][ks][o - MT] = v;
     };
     auto read_range = [&](auto SET, auto LO, auto HI, auto&& self) {
         constexpr int lo = decltype(LO)::value, hi_ = decltype(HI)::value;
@@ -1239,71 +1243,89 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    read_setup();
+    read_setup(std::integral_constant<int, 0>{}, 0, 0);
     read_range(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NR>{}, read_range);
     // (the builtin, not inline asm: the compiler's own waitcnt bookkeeping must SEE that no fragment read is pending at the
     // top of an interval — otherwise it guards the first MFMA with lgkmcnt(0), i.e. waits for the prefetch just issued)
     __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0)
 
-    int ph = 0, sp = 0;                                        // the chunk whose MFMAs run in this interval
-    // One interval = the NM MFMAs of chunk `it` with everything else issued in their shadow: after MFMA i, the wave issues
-    // its share of chunk it + 1's fragment reads (into the other register set; past the last chunk they read stale LDS,
-    // unused) and, at slots that differ between the two waves of a SIMD, one DMA piece.  An MFMA holds the pipe for 32
-    // cycles and the wave for ~4: the instructions between two MFMAs cost nothing as long as they fit that shadow.
+    // One interval = the NM MFMAs of a chunk with everything else issued in their shadow: after MFMA i, the wave issues its share of
+    // the NEXT chunk's fragment reads (into the other register set; past the last chunk they read stale LDS, unused) and, at slots
+    // that differ between the two waves of a SIMD, one DMA piece.  Round 4: the interval is instantiated per (spatial tap, register
+    // set) — eighteen chunks = two phases per trip of the loop — so which slot carries which piece, the next chunk's tap and the
+    // issue cursor's tap are compile-time; what stays run-time is the ring slot, the slab buffer parity and the end-of-clip guards.
+    // Before, that bookkeeping was ~226 scalar instructions and ~39 branches per interval beside 18 MFMAs: 14 issues per MFMA gap
+    // where ~5 fit (MI355X_MICROARCH.md, per-instruction constants).
     constexpr int DSTR = NM >= 16 ? 2 : 1;                     // MFMA slots between two DMA pieces
-    const int dbase = late ? NM / 2 : 1;                       // first DMA slot of this wave
-    auto slot = [&](auto SET, auto I, int it, int& issued) {
-        constexpr int s = decltype(SET)::value, i = decltype(I)::value;
-        constexpr int ks = i / (NT * MT), nt = (i / MT) % NT, m = i % MT;
-        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][ks][nt], af[s][ks][m], acc[nt][m], 0, 0, 0);
-        if constexpr (i == 0) read_setup();                   // address arithmetic of chunk it + 1: under the first MFMA
-        else read_range(std::integral_constant<int, s ^ 1>{}, std::integral_constant<int, (i - 1) * NR / (NM - 1)>{},
-                        std::integral_constant<int, i * NR / (NM - 1)>{}, read_range);
-        // DMA piece d of this interval (weights of chunk it + 3 first, then the next slab's share of this tap) at slot dbase + DSTR d
-#pragma unroll
-        for (int d = 0; d < WLN + SPT; ++d) {
-            constexpr bool may_early = true;
-            if ((i - 1) % DSTR == 0 || (i - NM / 2) % DSTR == 0) {
-                if (i == dbase + DSTR * d) {
-                    if (d < WLN) {
-                        if (it + 3 < nchunks) {
-                            if (d == 0) issued += w_piece(std::integral_constant<int, 0>{});
-                            if (d == 1) { if constexpr (WLN > 1) issued += w_piece(std::integral_constant<int, 1>{}); }
-                            if (d == 2) { if constexpr (WLN > 2) issued += w_piece(std::integral_constant<int, 2>{}); }
-                            if (d == 3) { if constexpr (WLN > 3) issued += w_piece(std::integral_constant<int, 3>{}); }
-                            if (d == 4) { if constexpr (WLN > 4) issued += w_piece(std::integral_constant<int, 4>{}); }
-                            if (d == WLN - 1) w_advance();
-                        }
-                    } else if (ph + 1 < nph && sp < 7 && !(a.dbg & 2)) {
-#pragma unroll
-                        for (int j = 0; j < NPJ; ++j)
-                            if (j % SPT == d - WLN && j * 7 / NPJ == sp && j * NW + wave < NSP) {
-                                slab_piece((ph + 1) & 1, np_off, soff[j], j);
-                                ++issued;
-                            }
-                    }
-                }
-            }
-            (void)may_early;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto slots = [&](auto SET, auto I, int it, int& issued, auto&& self) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (i < NM) {
-            slot(SET, I, it, issued);
-            self(SET, std::integral_constant<int, i + 1>{}, it, issued, self);
-        }
-    };
+    // per-interval cycle stamps (tools/conv_prof.py): debug builds only — in the shipped kernel they were six uniform branches and a
+    // dozen live SGPRs per interval
+#ifdef APEXMI_DEBUG
     const bool prof = a.prof != nullptr && blockIdx.x == 300 && blockIdx.y == 0;
     unsigned long long pf_issue = 0, pf_vm = 0, pf_lgkm = 0, pf_bar = 0, pf_t3 = 0;
 #define STAMP(x) do { if (prof) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-    auto interval = [&](auto SET, int it) {
+#else
+#define STAMP(x) do { } while (0)
+#endif
+    int ph = 0;                                                // phase of the chunk whose MFMAs run
+    // DMA piece d of the interval of spatial tap SP: weights of the chunk three ahead first, then the next slab's share of this tap
+    auto dma_piece = [&](auto SP, auto D, int it, int& issued) {
+        constexpr int sp = decltype(SP)::value, d = decltype(D)::value;
+        if constexpr (d < WLN) {
+            if (!(ph + 1 == nph && sp >= 6)) {                 // chunk it + 3 exists
+                const int kb = (sp < 6 ? wk_cur : wk_next) + ((sp + 3) % 9) * (a.Cin * 2);
+                issued += w_piece(std::integral_constant<int, d>{}, (it + 3) & 3, kb);
+            }
+        } else if constexpr (sp < 7) {
+            if (ph + 1 < nph && !(a.dbg & 2)) {
+#pragma unroll
+                for (int j = 0; j < NPJ; ++j)
+                    if (j % SPT == d - WLN && j * 7 / NPJ == sp && j * NW + wave < NSP) {
+                        slab_piece((ph + 1) & 1, np_off, soff[j], j);
+                        ++issued;
+                    }
+            }
+        }
+    };
+    auto dma_at = [&](auto SP, auto I, auto D, int it, int& issued, auto&& self) {   // pieces whose slot is MFMA i (early / late half)
+        constexpr int i = decltype(I)::value, d = decltype(D)::value;
+        if constexpr (d < WLN + SPT) {
+            if constexpr (i == 1 + DSTR * d) {
+                if (!late) dma_piece(SP, D, it, issued);
+            }
+            if constexpr (NW == 8 && i == NM / 2 + DSTR * d) {
+                if (late) dma_piece(SP, D, it, issued);
+            }
+            self(SP, I, std::integral_constant<int, d + 1>{}, it, issued, self);
+        }
+    };
+    auto slots = [&](auto SET, auto SP, auto I, int it, int& issued, auto&& self) {
+        constexpr int s_ = decltype(SET)::value, sp = decltype(SP)::value, i = decltype(I)::value;
+        if constexpr (i < NM) {
+            constexpr int ks = i / (NT * MT), nt = (i / MT) % NT, m = i % MT;
+            acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s_][ks][nt], af[s_][ks][m], acc[nt][m], 0, 0, 0);
+            if constexpr (i == 0) {
+                // address arithmetic of chunk it + 1 under the first MFMA: its tap is compile-time, its slab buffer is the next
+                // phase's after tap 8
+                read_setup(std::integral_constant<int, (sp + 1) % 9>{}, (sp == 8 ? ph + 1 : ph) & 1, (it + 1) & 3);
+            } else {
+                read_range(std::integral_constant<int, s_ ^ 1>{}, std::integral_constant<int, (i - 1) * NR / (NM - 1)>{},
+                           std::integral_constant<int, i * NR / (NM - 1)>{}, read_range);
+            }
+            dma_at(SP, I, std::integral_constant<int, 0>{}, it, issued, dma_at);
+            __builtin_amdgcn_sched_barrier(0);
+            self(SET, SP, std::integral_constant<int, i + 1>{}, it, issued, self);
+        }
+    };
+    auto interval = [&](auto IDX, int it) {
+        constexpr int idx = decltype(IDX)::value;
+        constexpr int sp = idx % 9;
+#ifdef APEXMI_DEBUG
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#endif
         STAMP(t0);
         __builtin_amdgcn_sched_barrier(0);
         int issued = 0;
-        slots(SET, std::integral_constant<int, 0>{}, it, issued, slots);
+        slots(std::integral_constant<int, idx & 1>{}, std::integral_constant<int, sp>{}, std::integral_constant<int, 0>{}, it, issued, slots);
         STAMP(t1);
         switch (issued) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -1318,6 +1340,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
         }
         STAMP(t2);
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the prefetched set (long complete by now)
+#ifdef APEXMI_DEBUG
         if (prof) {
             if (it > 0) pf_bar += t0 - pf_t3;
             pf_issue += t1 - t0;
@@ -1329,23 +1352,39 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
             pf_lgkm += t3 - t2;
             pf_t3 = t3;
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (++sp == 9) {
-            sp = 0;
+        if constexpr (sp == 8) {
             ++ph;
             advance_phase();
+            wk_cur = wk_next;
+            w_phase_advance();
+            wk_next = w_phase_base();
         }
     };
+    auto phase9 = [&](auto BASE, int it) {                     // the nine intervals of one phase; BASE = 0 / 9: register-set parity
+        constexpr int b0 = decltype(BASE)::value;
+        interval(std::integral_constant<int, b0 + 0>{}, it + 0);
+        interval(std::integral_constant<int, b0 + 1>{}, it + 1);
+        interval(std::integral_constant<int, b0 + 2>{}, it + 2);
+        interval(std::integral_constant<int, b0 + 3>{}, it + 3);
+        interval(std::integral_constant<int, b0 + 4>{}, it + 4);
+        interval(std::integral_constant<int, b0 + 5>{}, it + 5);
+        interval(std::integral_constant<int, b0 + 6>{}, it + 6);
+        interval(std::integral_constant<int, b0 + 7>{}, it + 7);
+        interval(std::integral_constant<int, b0 + 8>{}, it + 8);
+    };
     CONV_TRACE_AT(tr_l0);
-    for (int it = 0; it < nchunks; it += 2) {
-        interval(std::integral_constant<int, 0>{}, it);
-        if (it + 1 < nchunks) interval(std::integral_constant<int, 1>{}, it + 1);
+    for (int it = 0; it < nchunks; it += 18) {
+        phase9(std::integral_constant<int, 0>{}, it);
+        if (it + 9 < nchunks) phase9(std::integral_constant<int, 9>{}, it + 9);
     }
     CONV_TRACE_AT(tr_l1);
 
 #undef STAMP
+#ifdef APEXMI_DEBUG
     if (prof && lane == 0) {
         unsigned long long* o = a.prof + wave * 8;
         o[0] = pf_bar;
@@ -1354,6 +1393,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
         o[3] = pf_lgkm;
         o[5] = (unsigned long long)nchunks;
     }
+#endif
     int mrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
