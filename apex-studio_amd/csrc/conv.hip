@@ -1147,9 +1147,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
     int wk_cur = w_phase_base();
     w_phase_advance();
     int wk_next = w_phase_base();
+    // which weight pieces (bit i: piece i NW + wave exists) and which slab pieces (bit j) this wave carries, and whether it is of the
+    // early half: plain scalar integers tested with one compare each (as `bool`s combined with && they became lane masks that hipcc
+    // rebuilt through v_cndmask / v_cmp at every piece of every interval)
+    int wmask_ = 0, smask_ = 0;
+#pragma unroll
+    for (int i = 0; i < WLN; ++i) wmask_ |= (i * NW + wave < WP) ? (1 << i) : 0;
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) smask_ |= (j * NW + wave < NSP) ? (1 << j) : 0;
+#ifdef APEXMI_DEBUG
+    if (a.dbg & 1) wmask_ = 0;        // conv.dbg: timing-only ablation of the DMA (tools/conv_ablate.py)
+    if (a.dbg & 2) smask_ = 0;
+#endif
+    const int wmask = __builtin_amdgcn_readfirstlane(wmask_), smask = __builtin_amdgcn_readfirstlane(smask_);
+    const int early_i = __builtin_amdgcn_readfirstlane(late ? 0 : 1);
     auto w_piece = [&](auto I, int slot_, int kbase) -> int {   // piece i of the chunk at kbase -> ring slot slot_; 1 if this wave has it
         constexpr int i = decltype(I)::value;
-        if (i * NW + wave >= WP || (a.dbg & 1)) return 0;
+        if (!(wmask & (1 << i))) return 0;
         char* dst = smem + 2 * SLABB + slot_ * WCH;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (i * NW + wave) * 1024), 16, wvoff[i], kbase, 0,
                                                  0);
@@ -1276,12 +1290,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
                 issued += w_piece(std::integral_constant<int, d>{}, (it + 3) & 3, kb);
             }
         } else if constexpr (sp < 7) {
-            if (ph + 1 < nph && !(a.dbg & 2)) {
+            if (ph + 1 < nph) {
 #pragma unroll
                 for (int j = 0; j < NPJ; ++j)
-                    if (j % SPT == d - WLN && j * 7 / NPJ == sp && j * NW + wave < NSP) {
-                        slab_piece((ph + 1) & 1, np_off, soff[j], j);
-                        ++issued;
+                    if (j % SPT == d - WLN && j * 7 / NPJ == sp) {
+                        if (smask & (1 << j)) {
+                            slab_piece((ph + 1) & 1, np_off, soff[j], j);
+                            ++issued;
+                        }
                     }
             }
         }
@@ -1290,10 +1306,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv3d_slabp_kernel(
         constexpr int i = decltype(I)::value, d = decltype(D)::value;
         if constexpr (d < WLN + SPT) {
             if constexpr (i == 1 + DSTR * d) {
-                if (!late) dma_piece(SP, D, it, issued);
+                if (early_i) dma_piece(SP, D, it, issued);
             }
             if constexpr (NW == 8 && i == NM / 2 + DSTR * d) {
-                if (late) dma_piece(SP, D, it, issued);
+                if (!early_i) dma_piece(SP, D, it, issued);
             }
             self(SP, I, std::integral_constant<int, d + 1>{}, it, issued, self);
         }
