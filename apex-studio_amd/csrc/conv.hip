@@ -159,31 +159,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
 
     const int nkt = a.Kext / BK;
 
+    // Source of channel 0 of piece i's CURRENT tap (nullptr: the tap falls into the padding and reads the zero line).  It changes only
+    // when the lane's 64-channel chunk wraps into the next tap — every Cin / 64 K-tiles — so the tap decode, the bounds tests and the
+    // 64-bit address arithmetic (~40 VALU instructions a piece, four pieces per 16 MFMAs: the kernel was VALU-bound) run once per
+    // tap instead of once per K-tile; in between a piece costs one add.
+    auto tap_base = [&](int i) -> const bf16_t* {
+        if (a_tap[i] >= a.ntaps) return nullptr;
+        const int o = tap_off[a_tap[i]];
+        const int ti = pos_t[i] + (int)(int8_t)(o & 0xff);
+        const int yi = pos_y[i] + (int)(int8_t)((o >> 8) & 0xff);
+        const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
+        if (a.replicate) {   // HunyuanVideo15CausalConv3d: F.pad(..., mode="replicate") == clamped coordinates
+            const int tc = max(ti, pos_lo[i]), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
+            return a.in + ((int64_t)(tc * a.Hin + (yc >> a.up)) * a.Win + (xc >> a.up)) * a.Cin;
+        }
+        if (ti >= pos_lo[i] && ti < a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+            return a.in + ((int64_t)(ti * a.Hin + (yi >> a.up)) * a.Win + (xi >> a.up)) * a.Cin;
+        return nullptr;
+    };
+    const bf16_t* tbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tbase[i] = tap_base(i);
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16_t* src = a.zeros;
-            if (a_tap[i] < a.ntaps) {
-                const int o = tap_off[a_tap[i]];
-                const int ti = pos_t[i] + (int)(int8_t)(o & 0xff);
-                const int yi = pos_y[i] + (int)(int8_t)((o >> 8) & 0xff);
-                const int xi = pos_x[i] + (int)(int8_t)((o >> 16) & 0xff);
-                if (a.replicate) {   // HunyuanVideo15CausalConv3d: F.pad(..., mode="replicate") == clamped coordinates
-                    const int tc = max(ti, pos_lo[i]), yc = min(max(yi, 0), a.H - 1), xc = min(max(xi, 0), a.W - 1);
-                    src = a.in + ((int64_t)(tc * a.Hin + (yc >> a.up)) * a.Win + (xc >> a.up)) * a.Cin + a_ci[i];
-                } else if (ti >= pos_lo[i] && ti < a.T && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) {
-                    src = a.in + ((int64_t)(ti * a.Hin + (yi >> a.up)) * a.Win + (xi >> a.up)) * a.Cin + a_ci[i];
-                }
-            }
+            const bf16_t* src = tbase[i] != nullptr ? tbase[i] + a_ci[i] : a.zeros;
             glds16(src, base + i * 4096);
             // advance this lane's chunk by one K-tile (64 channels)
+            const int tap_was = a_tap[i];
             a_tap[i] += a.q64;
             a_ci[i] += a.r64;
             if (a_ci[i] >= a.Cin) {
                 a_ci[i] -= a.Cin;
                 a_tap[i] += 1;
             }
+            if (a_tap[i] != tap_was) tbase[i] = tap_base(i);
         }
         const int64_t koff = (int64_t)kt * (BK * 2);
 #pragma unroll
