@@ -282,8 +282,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(const ConvArgs a) {
 // of the [positions, Cout] matrix) of this lane's row in m-tile mt or -1, wave (wm, wn) of a WMW x WNW wave grid, n0 = first
 // output channel of the workgroup tile ------------------------------------------------------------------------------------
 template <int MT, int NT, int WNW, int NORM>
-APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const int (&mrow)[MT], int n0, int wm, int wn,
+APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const int (&mrow_)[MT], int n0, int wm, int wn,
                                  int l31, int hi, char* smem) {
+    // Opaque copies of everything lane-derived: the epilogue's addresses are pure functions of the lane and the kernel arguments, so
+    // hipcc computes them at kernel entry and carries them — a dozen 64-bit values — across the chunk loop, where the slab kernels
+    // have no register to spare (spills).  The volatile statements keep their order against the loop's own (waits), i.e. stay here.
+    int mrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        mrow[mt] = mrow_[mt];
+        asm volatile("" : "+v"(mrow[mt]));
+    }
+    asm volatile("" : "+v"(l31), "+v"(hi));
     // ---- epilogue: bias (+ residual) -> bf16.  A lane holds out[m][nbase + 8 g + 4 hi + (0..3)], g = 0..3, per 32-column
     // tile; pairs of groups are exchanged with the other half-wave (v_permlane32_swap) into 8 CONSECUTIVE columns, so
     // residual loads and stores are 16 bytes per lane (the GEMM's epilogue trick).
@@ -333,143 +343,186 @@ APEXMI_DEVICE void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], const
     // Loads first, all of them, then arithmetic and stores: out may alias res, so hipcc cannot move a residual load above an earlier
     // store itself, and with the loads inside the (mt, nt, pr) loops every iteration paid its own memory round trip (and re-read the
     // same bias for every m-tile) while the matrix pipe of the CU sat idle.  Bias stays packed (two dwords per 4-column group).
+    // FULL (every 32-column n-tile of the wave lies inside Cout — all the layers of the shipped decoders): no column clamps or
+    // guards, and one 64-bit row base per m-tile with compile-time column offsets; before, every 16-byte access rebuilt its address
+    // with a 64-bit multiply-add behind a clamp and a lane-mask branch (~200 of the epilogue's instructions per lane).
     const int nb0 = n0 + wn * (NT * 32);
-    u32x2 bsp[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bsp[nt][g] = u32x2{0u, 0u};
-    if (a.bias != nullptr) {
+    auto body = [&](auto FULL_) {
+        constexpr bool FULL = decltype(FULL_)::value;
+        const int cg = nb0 + 4 * hi;                        // this lane's first column of a 4-column group (+ 8 g + 32 nt)
+        const int cs = nb0 + 8 * hi;                        // ... of an 8-column store / residual segment (+ 16 pr + 32 nt)
+        auto gcol = [&](int nt, int g) { return FULL ? cg + nt * 32 + 8 * g : min(cg + nt * 32 + 8 * g, a.Cout - 4); };
+        u32x2 bsp[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bsp[nt][g] = *(const u32x2*)(a.bias + min(nb0 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4));
-    }
-    u32x4 rr[MT][NT][2];
-    const bool has_res = a.res != nullptr;
-    if (has_res) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int g = 0; g < 4; ++g) bsp[nt][g] = u32x2{0u, 0u};
+        if (a.bias != nullptr) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
-                    rr[mt][nt][pr] = *(const u32x4*)(a.res + (int64_t)max(mrow[mt], 0) * a.Cout +
-                                                     max(min(nb0 + nt * 32 + 8 * (2 * pr + hi), a.Cout - 8), 0));
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        ssq[mt] = 0.0f;
-        const int m = mrow[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int nb = nb0 + nt * 32;
-                const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
-                if (nb + 16 * pr >= a.Cout) continue;             // wave-uniform; lanes past Cout inside the pair store nothing
-                u32x2 ra = {0u, 0u}, rb = {0u, 0u};
-                if (has_res) {
-                    ra = u32x2{rr[mt][nt][pr][0], rr[mt][nt][pr][1]};
-                    rb = u32x2{rr[mt][nt][pr][2], rr[mt][nt][pr][3]};
-                    swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
-                }
-                u32x2 o[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * pr + q;
-                    float v[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
-                    const u32x2 b = bsp[nt][g];
-                    v[0] += bf16_lo(b[0]);
-                    v[1] += bf16_hi(b[0]);
-                    v[2] += bf16_lo(b[1]);
-                    v[3] += bf16_hi(b[1]);
-                    const u32x2 r2 = q ? rb : ra;
-                    v[0] += bf16_lo(r2[0]);
-                    v[1] += bf16_hi(r2[0]);
-                    v[2] += bf16_lo(r2[1]);
-                    v[3] += bf16_hi(r2[1]);
-                    if (!NORM) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
-                    }
-                    o[q][0] = pack_bf16(v[0], v[1]);
-                    o[q][1] = pack_bf16(v[2], v[3]);
-                    if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
-                        const float r0 = bf16_lo(o[q][0]), r1 = bf16_hi(o[q][0]), r2f = bf16_lo(o[q][1]), r3 = bf16_hi(o[q][1]);
-                        acc[nt][mt][4 * g + 0] = r0;
-                        acc[nt][mt][4 * g + 1] = r1;
-                        acc[nt][mt][4 * g + 2] = r2f;
-                        acc[nt][mt][4 * g + 3] = r3;
-                        if (nb + 8 * g + 4 * hi < a.Cout) ssq[mt] += r0 * r0 + r1 * r1 + r2f * r2f + r3 * r3;
-                    }
-                }
-                if (!NORM || a.out != nullptr) {
-                    swap_pair(o[0], o[1]);
-                    if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
-                }
-            }
-    }
-    if constexpr (NORM) {
-        // a row's channels: this lane's groups + those of lane ^ 32, and (WNW > 1) the other waves of the row through LDS
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ssq[mt] = sum_xor32(ssq[mt]);
-        if constexpr (WNW > 1) {
-            float* red = (float*)smem;          // the staging buffers are free: every wave is past its last fragment read
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                if (hi == 0) red[(wm * (MT * 32) + mt * 32 + l31) * WNW + wn] = ssq[mt];
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float t = 0.0f;
-#pragma unroll
-                for (int w = 0; w < WNW; ++w) t += red[(wm * (MT * 32) + mt * 32 + l31) * WNW + w];
-                ssq[mt] = t;
-            }
+                for (int g = 0; g < 4; ++g) bsp[nt][g] = *(const u32x2*)(a.bias + gcol(nt, g));
         }
-        const float root_c = sqrtf((float)a.Cout);
-        u32x2 gmp[NT][4];                      // gamma, packed, once per channel group (it was re-read for every m-tile)
+        int64_t rowb[MT];                                   // element offset of this lane's first store column in row mrow[mt]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt) rowb[mt] = (int64_t)max(mrow[mt], 0) * a.Cout + cs;
+        // residual rows: all m-tiles up front (one m-tile at a time costs the fused-norm epilogue a second round trip, +2.3 us)
+        constexpr int RMT = MT;
+        u32x4 rr[RMT][NT][2];
+        const bool has_res = a.res != nullptr;
+        auto load_res = [&](int mt, int slot) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gmp[nt][g] = *(const u32x2*)(a.norm_gamma + min(nb0 + nt * 32 + 8 * g + 4 * hi, a.Cout - 4));
-        auto second = [&](auto SILU) {         // the SiLU switch is block-uniform: decided once, not per 4-column group
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mrow[mt];
-                const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const int nb = nb0 + nt * 32;
-                        const int nst = nb + 8 * (2 * pr + hi);
-                        if (nb + 16 * pr >= a.Cout) continue;
-                        u32x2 o[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int g = 2 * pr + q;
-                            const u32x2 gm = gmp[nt][g];
-                            float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
-                                          acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
-                            if constexpr (decltype(SILU)::value) {
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
-                            }
-                            o[q][0] = pack_bf16(y[0], y[1]);
-                            o[q][1] = pack_bf16(y[2], y[3]);
-                        }
-                        swap_pair(o[0], o[1]);
-                        if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
-                    }
-            }
+                for (int pr = 0; pr < 2; ++pr) {
+                    if constexpr (FULL) rr[slot][nt][pr] = *(const u32x4*)(a.res + rowb[mt] + (nt * 32 + 16 * pr));
+                    else rr[slot][nt][pr] = *(const u32x4*)(a.res + (int64_t)max(mrow[mt], 0) * a.Cout + max(min(cs + nt * 32 + 16 * pr, a.Cout - 8), 0));
+                }
         };
-        if (a.norm_silu) second(std::true_type{});
-        else second(std::false_type{});
+        if (has_res) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) load_res(mt, mt);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ssq[mt] = 0.0f;
+            const int m = mrow[mt];
+            const int rs = mt;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int nb = nb0 + nt * 32;
+                    const int nst = nb + 8 * (2 * pr + hi);           // first of the 8 columns this lane loads / stores
+                    if constexpr (!FULL) {
+                        if (nb + 16 * pr >= a.Cout) continue;         // wave-uniform; lanes past Cout inside the pair store nothing
+                    }
+                    u32x2 ra = {0u, 0u}, rb = {0u, 0u};
+                    if (has_res) {
+                        ra = u32x2{rr[rs][nt][pr][0], rr[rs][nt][pr][1]};
+                        rb = u32x2{rr[rs][nt][pr][2], rr[rs][nt][pr][3]};
+                        swap_pair(ra, rb);                            // 16-byte row segment -> accumulator layout
+                    }
+                    u32x2 o[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * pr + q;
+                        float v[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = acc[nt][mt][4 * g + jj];
+                        const u32x2 b = bsp[nt][g];
+                        v[0] += bf16_lo(b[0]);
+                        v[1] += bf16_hi(b[0]);
+                        v[2] += bf16_lo(b[1]);
+                        v[3] += bf16_hi(b[1]);
+                        const u32x2 r2 = q ? rb : ra;
+                        v[0] += bf16_lo(r2[0]);
+                        v[1] += bf16_hi(r2[0]);
+                        v[2] += bf16_lo(r2[1]);
+                        v[3] += bf16_hi(r2[1]);
+                        if (!NORM) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) v[jj] = conv_act(v[jj], a.act, a.act_slope);
+                        }
+                        o[q][0] = pack_bf16(v[0], v[1]);
+                        o[q][1] = pack_bf16(v[2], v[3]);
+                        if (NORM) {   // the norm is taken over the STORED (bf16) values, as the separate pass reads them back
+                            const float r0 = bf16_lo(o[q][0]), r1 = bf16_hi(o[q][0]), r2f = bf16_lo(o[q][1]), r3 = bf16_hi(o[q][1]);
+                            acc[nt][mt][4 * g + 0] = r0;
+                            acc[nt][mt][4 * g + 1] = r1;
+                            acc[nt][mt][4 * g + 2] = r2f;
+                            acc[nt][mt][4 * g + 3] = r3;
+                            if (FULL || nb + 8 * g + 4 * hi < a.Cout) ssq[mt] += r0 * r0 + r1 * r1 + r2f * r2f + r3 * r3;
+                        }
+                    }
+                    if (!NORM || a.out != nullptr) {
+                        swap_pair(o[0], o[1]);
+                        const u32x4 ov = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                        if constexpr (FULL) {
+                            if (m >= 0) *(u32x4*)(a.out + rowb[mt] + (nt * 32 + 16 * pr)) = ov;
+                        } else {
+                            if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out + (int64_t)m * a.Cout + nst) = ov;
+                        }
+                    }
+                    // (without the guards' basic-block boundaries the scheduler overlaps all twelve segments of a lane and spills)
+                    if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if constexpr (NORM) {
+            // a row's channels: this lane's groups + those of lane ^ 32, and (WNW > 1) the other waves of the row through LDS
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ssq[mt] = sum_xor32(ssq[mt]);
+            if constexpr (WNW > 1) {
+                float* red = (float*)smem;          // the staging buffers are free: every wave is past its last fragment read
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (hi == 0) red[(wm * (MT * 32) + mt * 32 + l31) * WNW + wn] = ssq[mt];
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < WNW; ++w) t += red[(wm * (MT * 32) + mt * 32 + l31) * WNW + w];
+                    ssq[mt] = t;
+                }
+            }
+            const float root_c = sqrtf((float)a.Cout);
+            u32x2 gmp[NT][4];                      // gamma, packed, once per channel group (it was re-read for every m-tile)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gmp[nt][g] = *(const u32x2*)(a.norm_gamma + gcol(nt, g));
+            auto second = [&](auto SILU) {         // the SiLU switch is block-uniform: decided once, not per 4-column group
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mrow[mt];
+                    const float scale = root_c / fmaxf(sqrtf(ssq[mt]), 1e-12f);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int nb = nb0 + nt * 32;
+                            const int nst = nb + 8 * (2 * pr + hi);
+                            if constexpr (!FULL) {
+                                if (nb + 16 * pr >= a.Cout) continue;
+                            }
+                            u32x2 o[2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int g = 2 * pr + q;
+                                const u32x2 gm = gmp[nt][g];
+                                float y[4] = {acc[nt][mt][4 * g + 0] * scale * bf16_lo(gm[0]), acc[nt][mt][4 * g + 1] * scale * bf16_hi(gm[0]),
+                                              acc[nt][mt][4 * g + 2] * scale * bf16_lo(gm[1]), acc[nt][mt][4 * g + 3] * scale * bf16_hi(gm[1])};
+                                if constexpr (decltype(SILU)::value) {
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj) y[jj] = silu_f(y[jj]);
+                                }
+                                o[q][0] = pack_bf16(y[0], y[1]);
+                                o[q][1] = pack_bf16(y[2], y[3]);
+                            }
+                            swap_pair(o[0], o[1]);
+                            const u32x4 ov = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+                            if constexpr (FULL) {
+                                if (m >= 0) *(u32x4*)(a.out_norm + rowb[mt] + (nt * 32 + 16 * pr)) = ov;
+                            } else {
+                                if (m >= 0 && nst < a.Cout) *(u32x4*)(a.out_norm + (int64_t)m * a.Cout + nst) = ov;
+                            }
+                            if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            };
+            if (a.norm_silu) second(std::true_type{});
+            else second(std::false_type{});
+        }
+    };
+    // (the fused-norm instantiations keep the guarded path: their FULL form compiled to 256 VGPRs + ~30 spilled values inside the
+    // epilogue and measured 6-7 us SLOWER per workgroup, profiles/r04_conv_tile_trace_c.log)
+    if constexpr (NORM) {
+        body(std::false_type{});
+    } else {
+        if ((a.Cout & 31) == 0 && nb0 + NT * 32 <= a.Cout) body(std::true_type{});
+        else body(std::false_type{});
     }
 }
 
