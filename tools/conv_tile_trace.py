@@ -66,3 +66,4 @@ run("96 -> 96, 3x3x3, plain (slab kernel)", 21, 256, 256, 96, 96, False, False)
 run("192 -> 192, 3x3x3, fused norm (prefetch kernel)", 21, 128, 128, 192, 192, True, True)
 run("192 -> 192, 3x3x3, plain + residual (prefetch kernel)", 21, 128, 128, 192, 192, False, True)
 run("384 -> 384, 3x3x3, plain (prefetch kernel, 2 N tiles)", 11, 64, 64, 384, 384, False, False)
+run("96 -> 3 (+1 pad), 3x3x3, conv_out (slab kernel, narrow epilogue)", 21, 256, 256, 96, 3, False, False)
