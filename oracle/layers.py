@@ -15,8 +15,9 @@ GELU-tanh, RMSNorm, get_1d_rotary_pos_embed, apply_rotary_emb (both sequence dim
 order, formula), the chunk orders of the Zero / ZeroSingle forms, and the [scale, shift] order of
 AdaLayerNormContinuous (through the reference's checkpoint converter).  Also pinned by reference-run fixtures: the
 attention operator (reference `sdpa`), the in-tree efficiency ops, and the reference's own Flux / Wan / Qwen block
-wiring executed on top of these leaves.  Left "parity unpinned" (no copy in the tree): FP32LayerNorm (torch's
-layer_norm in f32), the CombinedTimestep*Embeddings containers (sums of pinned parts), `LinearActivation`.
+wiring executed on top of these leaves; FP32LayerNorm is pinned to torch's own `F.layer_norm` in f32 and to the written-out
+float64 definition (tests/test_oracle_leaf_pins.py::test_fp32_layernorm_is_torch_layer_norm_in_f32).  Left "parity unpinned"
+(no copy in the tree): the CombinedTimestep*Embeddings containers (sums of pinned parts), `LinearActivation`.
 
 `emulate_bf16`: the GPU path stores activations in bf16 between kernels and accumulates in f32.
 `Policy.r(x)` rounds to bf16 at exactly those storage points so a like-for-like comparison is

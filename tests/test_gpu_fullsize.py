@@ -305,6 +305,35 @@ def test_qwen_edit_1024_full_depth_two_steps_and_last_block_vs_oracle(host_threa
     assert _rel(x_out, ref16) < 1e-3 and e_like < 6e-3 and e_true < 2 * e_emul + 2e-3
 
 
+def _wan_block_rows_vs_oracle(m, blk_index, x_in, ws, rows, grid=(21, 45, 80)):
+    """The oracle's `WanTransformerBlock` (reference transformer/wan/base/model.py:1020-1333) on `rows` of the sequence, fed the HIP
+    path's input activations `x_in` [S, dim] (keys / values from every token; queries, projections and the FFN for the sampled
+    rows) and the HIP path's own time projection and text context."""
+    from oracle import wan as OWn
+    S, dim = x_in.shape
+    H = m.config.num_attention_heads
+    blk = OWn.WanTransformerBlock(dim, m.config.ffn_dim, H).eval()
+    blk.load_state_dict({k: v.float().cpu() for k, v in m.blocks[blk_index].state_dict().items()}, strict=True)
+    temb6 = ws.TPROJ.float().cpu().view(1, 6, dim)
+    ctx = ws.CTX.float().cpu()[None]
+    cos, sin = OWn.wan_rope_table(grid, 128)
+    pol = OL.BF16_STORAGE
+    with torch.no_grad():
+        sh, sc, gt, csh, csc, cgt = (blk.scale_shift_table + temb6).chunk(6, dim=1)
+        n_all = pol.r(blk.norm1(x_in[None]) * (1 + sc) + sh)                                  # [1, S, dim]
+        a = blk.attn1
+        k = pol.r(a.norm_k(pol.r(a.to_k(n_all)))).unflatten(2, (H, -1)).transpose(1, 2)
+        v = pol.r(a.to_v(n_all)).unflatten(2, (H, -1)).transpose(1, 2)
+        q = pol.r(a.norm_q(pol.r(a.to_q(n_all[:, rows])))).unflatten(2, (H, -1)).transpose(1, 2)
+        k = pol.r(OWn.apply_wan_rope(k, cos, sin))
+        q = pol.r(OWn.apply_wan_rope(q, cos[rows], sin[rows]))
+        o = pol.r(OL.sdpa(q, k, v, policy=pol).transpose(1, 2).flatten(2, 3))
+        xr = pol.r(x_in[None, rows] + a.to_out[0](o) * gt)
+        xr = pol.r(xr + blk.attn2(pol.r(blk.norm2(xr)), ctx, None, pol))
+        nr = pol.r(blk.norm3(xr) * (1 + csc) + csh)
+        return pol.r(xr + blk.ffn.net[2](pol.r(blk.ffn.net[0](nr))) * cgt)[0]
+
+
 def test_wan_block_at_75600_tokens_vs_oracle_rows(host_threads):
     """BASELINE config 4's sequence inside the GPU tier: one full-width Wan block (d 5120, 40 heads, ffn 13824) over the 75 600
     tokens of a 720p x 81-frame clip + 512 text tokens.  256 query rows spread over the sequence are recomputed by the oracle
@@ -331,35 +360,64 @@ def test_wan_block_at_75600_tokens_vs_oracle_rows(host_threads):
         ops.ln_modulate = orig
     assert n[0] == n_calls and out.shape == x.shape and torch.isfinite(out.float()).all()
     ws = next(iter(m._ws.values()))
-    S, dim, H = 75600, 5120, 40
+    S, dim = 75600, 5120
     x_in, x_out = taken["x_in"].float().cpu(), taken["x_out"].float().cpu()
     assert x_in.shape == (S, dim)
-    blk = OWn.WanTransformerBlock(dim, 13824, H).eval()
-    blk.load_state_dict({k: v.float().cpu() for k, v in m.blocks[0].state_dict().items()}, strict=True)
-    temb6 = ws.TPROJ.float().cpu().view(1, 6, dim)
-    ctx = ws.CTX.float().cpu()[None]
-    cos, sin = OWn.wan_rope_table((21, 45, 80), 128)
     rows = (torch.arange(256) * 295 + 11)
     assert int(rows.max()) < S
-    pol = OL.BF16_STORAGE
-    with torch.no_grad():
-        sh, sc, gt, csh, csc, cgt = (blk.scale_shift_table + temb6).chunk(6, dim=1)
-        n_all = pol.r(blk.norm1(x_in[None]) * (1 + sc) + sh)                                  # [1, S, dim]
-        a = blk.attn1
-        k = pol.r(a.norm_k(pol.r(a.to_k(n_all)))).unflatten(2, (H, -1)).transpose(1, 2)
-        v = pol.r(a.to_v(n_all)).unflatten(2, (H, -1)).transpose(1, 2)
-        q = pol.r(a.norm_q(pol.r(a.to_q(n_all[:, rows])))).unflatten(2, (H, -1)).transpose(1, 2)
-        k = pol.r(OWn.apply_wan_rope(k, cos, sin))
-        q = pol.r(OWn.apply_wan_rope(q, cos[rows], sin[rows]))
-        o = pol.r(OL.sdpa(q, k, v, policy=pol).transpose(1, 2).flatten(2, 3))
-        xr = pol.r(x_in[None, rows] + a.to_out[0](o) * gt)
-        xr = pol.r(xr + blk.attn2(pol.r(blk.norm2(xr)), ctx, None, pol))
-        nr = pol.r(blk.norm3(xr) * (1 + csc) + csh)
-        ref = pol.r(xr + blk.ffn.net[2](pol.r(blk.ffn.net[0](nr))) * cgt)[0]
+    ref = _wan_block_rows_vs_oracle(m, 0, x_in, ws, rows)
     got = x_out[rows]
     e_rows, e_delta = _rel(got, ref), _rel(got - x_in[rows], ref - x_in[rows])
     print(f"[full length] wan block at S 75 600 (d 5120): 256 sampled rows vs the oracle fed the HIP activations: rel L2 {e_rows:.2e} "
           f"on the rows, {e_delta:.2e} on the block's contribution")
     # block 0's input is the patch embedding (small), so the rows ARE the block's contribution: seven storage points deep,
     # free-running inside the block — the bf16 noise floor (tests/stage_parity.py), not the per-kernel 5e-4
+    assert e_rows < 6e-3 and e_delta < 6e-3
+
+
+def test_wan_720p_full_depth_two_experts_two_steps_and_last_block_vs_oracle(host_threads):
+    """BASELINE config 4 at FULL depth inside the GPU tier: Wan-2.2 A14B, both 40-block experts resident
+    (2 x 14 B parameters), 720p x 81 frames = 75 600 tokens + 512 text tokens, two UniPC steps through `WanT2VEngine.run` that
+    cross the t >= 875 boundary (reference engine/wan/shared/__init__.py:478-608: step 1 on the high-noise expert, step 2 on the
+    low-noise one) — finite, deterministic, each expert called exactly once per run — and the LAST block of the low-noise
+    expert's forward (40 deep, i.e. on activations only this depth produces) against the oracle's `WanTransformerBlock`
+    (reference transformer/wan/base/model.py:1020-1333; forward :1684-1891) fed the HIP path's own input activations, on 256
+    sampled rows with keys / values from all 75 600 tokens."""
+    from apex_studio_amd import ops
+    from apex_studio_amd.engine_wan import WanT2VEngine
+    from apex_studio_amd.wan import WanTransformer3DModel
+    L = 40
+    hi = WanTransformer3DModel(num_layers=L, device=DEV, dtype=BF).init_synthetic(2)
+    lo = WanTransformer3DModel(num_layers=L, device=DEV, dtype=BF).init_synthetic(3)
+    assert hi.inner_dim == 5120 and hi.config.ffn_dim == 13824 and len(lo.blocks) == L
+    calls = {"hi": [], "lo": []}
+    for name, mod in (("hi", hi), ("lo", lo)):
+        mod.register_forward_pre_hook(lambda _m, _a, kw, name=name: calls[name].append(float(kw["timestep"][0])), with_kwargs=True)
+    eng = WanT2VEngine(hi, lo, vae=None)
+    enc = _randn((1, 512, 4096), 51)
+    kw = dict(prompt_embeds=enc, height=720, width=1280, duration=81, num_inference_steps=2, seed=9, return_latents=True)
+    lat = eng.run(**kw)
+    assert lat.shape == (1, 16, 21, 90, 160) and torch.isfinite(lat).all() and float(lat.std()) > 0.1
+    assert len(calls["hi"]) == 1 and len(calls["lo"]) == 1 and calls["hi"][0] >= 875 > calls["lo"][0], calls
+    assert torch.equal(eng.run(**kw), lat), "two full-depth steps over both experts must be deterministic"
+    # one forward of the low-noise expert with the residual stream captured before its last block and before norm_out;
+    # ln_modulate calls on the shipped (fused q/k) path: norm1, norm2, cross k-norm, norm3 per block, then norm_out
+    assert lo.fuse_qkv
+    taken, n, spy, orig = _snapshots(ops, lo, {4 * (L - 1): "x_in", 4 * L: "x_out"})
+    ops.ln_modulate = spy
+    try:
+        out = lo(hidden_states=_randn((1, 16, 21, 90, 160), 52), timestep=torch.tensor([500.0], device=DEV),
+                 encoder_hidden_states=enc, return_dict=False)[0]
+    finally:
+        ops.ln_modulate = orig
+    assert n[0] == 4 * L + 1 and torch.isfinite(out.float()).all()
+    ws = next(iter(lo._ws.values()))
+    x_in, x_out = taken["x_in"].float().cpu(), taken["x_out"].float().cpu()
+    assert x_in.shape == (75600, 5120)
+    rows = (torch.arange(256) * 295 + 11)
+    ref = _wan_block_rows_vs_oracle(lo, L - 1, x_in, ws, rows)
+    got = x_out[rows]
+    e_rows, e_delta = _rel(got, ref), _rel(got - x_in[rows], ref - x_in[rows])
+    print(f"[full depth] wan 720p x 81f, block 40 of 40 at S 75 600: 256 sampled rows vs the oracle fed the HIP activations: rel L2 "
+          f"{e_rows:.2e} on the rows, {e_delta:.2e} on the block's contribution; expert timesteps {calls}")
     assert e_rows < 6e-3 and e_delta < 6e-3

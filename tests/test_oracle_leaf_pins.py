@@ -244,3 +244,30 @@ def test_flux_vae_decoder_topology_is_the_ldm_decoder(pins2):
         assert out.shape == c["out"].shape
         rel = float((out - c["out"]).norm() / c["out"].norm())
         assert rel < 1e-5, (c["tag"], rel)
+
+
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp32_layernorm_is_torch_layer_norm_in_f32(affine, dtype):
+    """`FP32LayerNorm` (diffusers.models.normalization, un-vendored; used by the reference's Wan blocks, transformer/wan/base
+    /model.py norm1 / norm2 / norm3 / norm_out, and restated for MLX at mlx/modules/layers.py:7-17) is by definition
+    `F.layer_norm(x.float(), shape, weight.float(), bias.float(), eps).to(x.dtype)`: pinned against torch's own layer_norm in
+    f32 and against the written-out definition in float64 — the statistics are NOT taken in the storage dtype."""
+    import torch.nn.functional as F
+    dim, eps = 192, 1e-6
+    ln = OL.FP32LayerNorm(dim, eps, elementwise_affine=affine)
+    if affine:
+        ln.weight.data = (1 + 0.1 * seeded((dim,), 3)).to(dtype)
+        ln.bias.data = (0.05 * seeded((dim,), 4)).to(dtype)
+    x = (seeded((2, 37, dim), 5) * 3 + 0.7).to(dtype)
+    got = ln(x)
+    w, b = (ln.weight.float(), ln.bias.float()) if affine else (None, None)
+    assert got.dtype == dtype and torch.equal(got, F.layer_norm(x.float(), (dim,), w, b, eps).to(dtype))
+    xd = x.double()
+    ref = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + eps)
+    if affine:
+        ref = ref * w.double() + b.double()
+    _close(got.float(), ref.to(dtype).float(), 2e-6 if dtype == torch.float32 else 8e-3)
+    if dtype == torch.bfloat16:        # statistics in the storage dtype would differ: this is what "FP32" buys
+        naive = F.layer_norm(x, (dim,), ln.weight if affine else None, ln.bias if affine else None, eps)
+        assert (got.float() - ref.float()).abs().max() <= (naive.float() - ref.float()).abs().max() + 1e-6
