@@ -113,10 +113,10 @@ class FluxT2IEngine(EngineLoraMixin):
         # The sampler's timesteps are known here: every step's AdaLN modulation vectors in one pass over the stacked projection
         # weights instead of one 6.4 GB GEMV per step (`begin_schedule`, bit-identical rows); a transformer without the hook (the
         # reference's own class behind this engine) just runs as before.
-        scheduled = hasattr(self.transformer, "begin_schedule") and n > 0
-        if scheduled:
+        scheduled = None          # this clip's schedule handle: two clips through one resident model never share a table
+        if hasattr(self.transformer, "begin_schedule") and n > 0:
             B = latents.shape[0]
-            self.transformer.begin_schedule(
+            scheduled = self.transformer.begin_schedule(
                 torch.stack([t.expand(B).to(latents.dtype) / 1000 for t in timesteps]), guidance,
                 [pooled_prompt_embeds] + ([negative_pooled_prompt_embeds] if use_cfg_guidance else []))
         try:
@@ -125,8 +125,8 @@ class FluxT2IEngine(EngineLoraMixin):
                                          use_cfg_guidance, render_on_step, render_on_step_callback, render_on_step_interval,
                                          denoise_progress_callback, preview_hw, scheduled)
         finally:
-            if scheduled:
-                self.transformer.end_schedule()
+            if scheduled is not None:
+                self.transformer.end_schedule(scheduled)
         _emit(denoise_progress_callback, 1.0, "Denoise finished")
         return latents
 
@@ -137,7 +137,7 @@ class FluxT2IEngine(EngineLoraMixin):
         n = len(timesteps)
         for i, t in enumerate(timesteps):
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
-            jkw = {"joint_attention_kwargs": {"modulation_step": i}} if scheduled else {}
+            jkw = {"joint_attention_kwargs": {"modulation_step": i, "modulation_schedule": scheduled}} if scheduled is not None else {}
             with self.transformer.cache_context("cond"):
                 noise_pred = self.transformer(
                     hidden_states=latents, timestep=timestep / 1000, guidance=guidance,

@@ -115,16 +115,16 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             self.transformer.pack()          # on the calling stream, before any forward forks off onto the side stream
         # every step's modulation vectors from one pass over the projection weights (qwenimage.py `begin_schedule`); built on the
         # calling stream before any forward forks off; a transformer without the hook runs as before
-        scheduled = hasattr(self.transformer, "begin_schedule") and n > 0
-        if scheduled:
-            self.transformer.begin_schedule(torch.stack([t.expand(latents.shape[0]).to(latents.dtype) / 1000 for t in timesteps]))
+        scheduled = None          # this clip's schedule handle (schedule.py): never shared with another clip in flight
+        if hasattr(self.transformer, "begin_schedule") and n > 0:
+            scheduled = self.transformer.begin_schedule(torch.stack([t.expand(latents.shape[0]).to(latents.dtype) / 1000 for t in timesteps]))
         try:
             return self._denoise_loop(latents, timesteps, prompt_embeds, img_shapes, image_latents, negative_prompt_embeds,
                                       true_cfg_scale, use_cfg_guidance, denoise_progress_callback, render_on_step,
                                       render_on_step_callback, render_on_step_interval, preview_hw, scheduled)
         finally:
-            if scheduled:
-                self.transformer.end_schedule()
+            if scheduled is not None:
+                self.transformer.end_schedule(scheduled)
 
     def _denoise_loop(self, latents, timesteps, prompt_embeds, img_shapes, image_latents, negative_prompt_embeds, true_cfg_scale,
                       use_cfg_guidance, denoise_progress_callback, render_on_step, render_on_step_callback, render_on_step_interval,
@@ -136,8 +136,8 @@ class QwenImageEditPlusEngine(EngineLoraMixin):
             x = latents if image_latents is None else torch.cat([latents, image_latents], dim=1)
             kw = dict(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states_mask=None,
                       img_shapes=img_shapes, return_dict=False)
-            if scheduled:
-                kw["attention_kwargs"] = {"modulation_step": i}
+            if scheduled is not None:
+                kw["attention_kwargs"] = {"modulation_step": i, "modulation_schedule": scheduled}
             cfg = use_cfg_guidance and negative_prompt_embeds is not None
             side = None
             if cfg and self.cfg_streams and x.is_cuda:

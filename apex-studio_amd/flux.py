@@ -34,6 +34,7 @@ import torch.nn as nn
 
 from .lora import LoraAdapterMixin  # noqa: E402
 from . import lib as _l
+from .schedule import ModulationSchedule, ScheduleRegistry
 from . import ops
 
 
@@ -182,7 +183,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         self._ws: Dict[Any, Any] = {}
         self._side = None
         self._rope_cache = None
-        self._sched: Dict[Any, Any] = {}  # modulation tables of the clip in flight (begin_schedule), keyed by the pooled tensor
+        self._scheds = ScheduleRegistry()  # modulation schedules of the clips in flight (begin_schedule), one handle per clip
         self.batch_streams = 2           # images of a batch run side by side on HIP streams (see forward); 1 = sequential
         self._bstreams: List[Any] = []
         self.storage_dtype = torch.bfloat16
@@ -257,7 +258,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
     def pack(self):
         if self._packed:
             return
-        self._sched = {}
+        self._scheds.clear()
         dev, dt = self.device, self.dtype
         if dev.type != "cuda" or dt != torch.bfloat16:
             raise _l.ApexMIError(f"flux.mi355 needs bf16 weights on a ROCm device (got {dt} on {dev}); "
@@ -370,12 +371,15 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
 
         `timesteps`: [n] or [n, B], the values `forward(timestep=…)` will receive (i.e. already / 1000); `guidance`: [B] or
         None; `pooled_projections`: one [B, P] tensor or a list of them (conditional / unconditional pass of true CFG).
-        `forward(..., joint_attention_kwargs={"modulation_step": i})` with one of these pooled tensors then reads row i of
-        its table; any other call computes its vectors as before.  `end_schedule()` frees the tables (n·B × 4.2 MB each)."""
+        `begin_schedule` returns the clip's HANDLE (schedule.ModulationSchedule).  `forward(..., joint_attention_kwargs=
+        {"modulation_step": i, "modulation_schedule": handle})` with one of these pooled tensors then reads row i of its table;
+        any other call computes its vectors as before.  Without a handle the call is served only while exactly one schedule is
+        live on the model (two clips through one resident model on two streams must pass theirs).  `end_schedule(handle)` frees
+        the tables (n·B × 4.2 MB each) and raises if a scheduled step was called with another timestep / guidance."""
         self.pack()
-        self._sched = {}
         n = int(timesteps.shape[0])
         pls = pooled_projections if isinstance(pooled_projections, (list, tuple)) else [pooled_projections]
+        sched = None
         for pooled in pls:
             if pooled is None:
                 continue
@@ -388,24 +392,26 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             g = None if guidance is None else guidance.to(self.device).reshape(1, -1).expand(n, B)
             cond = self._cond_rows(ts.reshape(-1), None if g is None else g.reshape(-1),
                                    pooled.unsqueeze(0).expand(n, B, pooled.shape[-1]).reshape(n * B, -1))
-            table = ops.gemv(self._mod_w, cond, self._mod_b, pre_silu=True)              # [n B, mod_total] f32
-            self._sched[(pooled.data_ptr(), tuple(pooled.shape))] = SimpleNamespace(table=table, n=n, B=B, pooled=pooled)
+            if sched is None:
+                sched = ModulationSchedule(n, B, ts, None if g is None else g[0])
+                sched.pooled = []
+            elif B != sched.B:
+                raise ValueError("begin_schedule: the pooled tensors of one clip must share a batch size")
+            sched.tables[(pooled.data_ptr(), tuple(pooled.shape))] = ops.gemv(self._mod_w, cond, self._mod_b, pre_silu=True)  # [n B, mod_total] f32
+            sched.pooled.append(pooled)           # keeps the key's storage alive for the clip
+        return None if sched is None else self._scheds.add(sched)
+
+    def end_schedule(self, handle=None):
+        self._scheds.end(handle)
         return self
 
-    def end_schedule(self):
-        self._sched = {}
-        return self
-
-    def _sched_row(self, pooled_projections, jkw, b):
-        """[1, mod_total] view of the table row for (step, image b), or None when this call is not part of the scheduled clip."""
-        if not self._sched or not jkw or jkw.get("modulation_step") is None:
+    def _sched_row(self, pooled_projections, jkw, b, timestep=None, guidance=None):
+        """[1, mod_total] view of the table row for (step, image b), or None when this call is not part of a scheduled clip."""
+        sc = self._scheds.find(jkw)
+        if sc is None:
             return None
-        sc = self._sched.get((pooled_projections.data_ptr(), tuple(pooled_projections.shape)))
-        i = int(jkw["modulation_step"])
-        if sc is None or not (0 <= i < sc.n) or b >= sc.B:
-            return None
-        r = i * sc.B + b
-        return sc.table[r:r + 1]
+        return sc.row((pooled_projections.data_ptr(), tuple(pooled_projections.shape)), int(jkw["modulation_step"]), b,
+                      timestep, guidance)
 
     def _embed_t(self, emb: _TimestepEmbedding, proj: torch.Tensor, out: torch.Tensor, accum: bool):
         h = ops.gemv(emb.linear_1.weight, proj, emb.linear_1.bias, post="silu")
@@ -617,7 +623,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             return self._forward_one(
                 hs[b].contiguous(), enc[b].contiguous(), pooled_projections[b], timestep[b:b + 1],
                 img_ids, txt_ids, None if guidance is None else guidance[b:b + 1],
-                mod_row=self._sched_row(pooled_projections, joint_attention_kwargs, b))
+                mod_row=self._sched_row(pooled_projections, joint_attention_kwargs, b, timestep[b:b + 1],
+                                        None if guidance is None else guidance[b:b + 1]))
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda:

@@ -29,6 +29,7 @@ import torch.nn as nn
 from .lora import LoraAdapterMixin  # noqa: E402
 from . import lib as _l
 from . import ops
+from .schedule import ModulationSchedule, ScheduleRegistry
 from .flux import _Config, _Linear, _Norm, _FF, _AdaNorm, _TimestepEmbedding, _repoint
 
 
@@ -104,7 +105,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         self.fuse_qkv = os.environ.get("APEX_FUSE_QKV", "1") != "0"
         self._rope: Dict[Any, torch.Tensor] = {}
         self._side = None
-        self._sched = None               # modulation table of the clip in flight (begin_schedule)
+        self._scheds = ScheduleRegistry()  # modulation schedules of the clips in flight (begin_schedule), one handle per clip
         self.batch_streams = 2           # images of a batch on side-by-side HIP streams (forward); 1 = sequential
         self._bstreams: List[Any] = []
 
@@ -172,7 +173,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
     def pack(self):
         if self._packed:
             return
-        self._sched = None
+        self._scheds.clear()
         dev, dt = self.device, self.dtype
         if dev.type != "cuda" or dt != torch.bfloat16:
             raise _l.ApexMIError(f"qwenimage.mi355 needs bf16 weights on a ROCm device (got {dt} on {dev}); "
@@ -255,8 +256,10 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         projection weights (6.8 GB for the 60-block model) instead of one weight-streaming GEMV per step (flux.py
         `begin_schedule`; here the conditioning vector depends on the timestep alone, so the conditional and the unconditional
         pass of true CFG share a row).  `timesteps`: [n] or [n, B], the values `forward(timestep=…)` will receive (already
-        / 1000).  Rows are bit-identical to the per-step launches; `forward(attention_kwargs={"modulation_step": i})` reads
-        row i, any other call computes its own vectors as before."""
+        / 1000).  Rows are bit-identical to the per-step launches.  Returns the clip's HANDLE (schedule.ModulationSchedule):
+        `forward(attention_kwargs={"modulation_step": i, "modulation_schedule": handle})` reads row i of THAT clip's table; a call
+        without a handle is served only while exactly one schedule is live on the model, any other call computes its own vectors
+        as before.  `end_schedule(handle)` frees the table and raises if a scheduled step ran with another timestep."""
         self.pack()
         n = int(timesteps.shape[0])
         ts = timesteps.to(self.device).reshape(n, -1)
@@ -265,22 +268,20 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         t = ts.to(self.storage_dtype).float().reshape(-1)
         h = ops.gemv(te.linear_1.weight, ops.timestep_embedding(t, 256, scale=1000.0), te.linear_1.bias, post="silu")
         temb = ops.gemv(te.linear_2.weight, h, te.linear_2.bias)
-        self._sched = SimpleNamespace(table=ops.gemv(self._mod_w, temb, self._mod_b, pre_silu=True), temb=temb, n=n, B=B)
+        sched = ModulationSchedule(n, B, ts)
+        sched.tables["mod"] = ops.gemv(self._mod_w, temb, self._mod_b, pre_silu=True)
+        sched.table, sched.temb = sched.tables["mod"], temb
+        return self._scheds.add(sched)
+
+    def end_schedule(self, handle=None):
+        self._scheds.end(handle)
         return self
 
-    def end_schedule(self):
-        self._sched = None
-        return self
-
-    def _sched_row(self, kw, b):
-        sc = self._sched
-        if sc is None or not kw or kw.get("modulation_step") is None:
+    def _sched_row(self, kw, b, timestep=None):
+        sc = self._scheds.find(kw)
+        if sc is None:
             return None
-        i = int(kw["modulation_step"])
-        if not (0 <= i < sc.n):
-            return None
-        r = i * sc.B + min(b, sc.B - 1)       # a [n] schedule serves every image of the batch
-        return sc.table[r:r + 1]
+        return sc.row("mod", int(kw["modulation_step"]), b, timestep, clamp_b=True)   # an [n] schedule serves every image of the batch
 
     @torch.no_grad()
     def _forward_one(self, hidden_states, text, timestep, shapes, mod_row=None):
@@ -390,7 +391,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
 
         def one(b):
             return self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes_of(b),
-                                     mod_row=self._sched_row(attention_kwargs, b))
+                                     mod_row=self._sched_row(attention_kwargs, b, timestep[b:b + 1]))
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda or any(shapes_of(b) != shapes_of(0) for b in range(1, B)):

@@ -13,6 +13,8 @@ in HBM before the timed region.  After the timed steps one whole clip (28 steps 
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Other single-GPU BASELINE configs (not the default bench line):
+  --workload flux512 Flux-Dev 512^2 (config 1's geometry, S 1024 + 512, full depth) on the GPU: the small-shape line that
+                     prices the host launch path (`host_enqueue_ms_per_step`)
   --workload qwen    QwenImage-Edit-2509 1024^2 + one 1024^2 condition image (config 3), steps/s
   --workload wan     Wan-2.2 A14B 720p x 81 frames, one expert forward + UniPC step (config 4), steps/s;
                      with --clip also 30 steps with the expert switch + tiled 3-D VAE decode (minutes)
@@ -55,7 +57,9 @@ FLUX_DEV = dict(patch_size=1, in_channels=64, num_layers=19, num_single_layers=3
                 guidance_embeds=True, axes_dims_rope=(16, 56, 56))
 S_IMG, S_TXT = 4096, 512
 # algorithmic FLOPs of one step: 2MNK per GEMM + 4 H Sq Sk D per attention
-STEP_TFLOP = {"flux": 74.36, "qwen": 167.4, "wan": 6520.0, "hunyuan": 1394.9}
+# flux512 (config 1's geometry on the GPU: S 1024 + 512): every GEMM is linear in S (59.506 x 1536 / 4608 = 19.835), attention
+# 4 x 24 x 1536^2 x 128 x 57 = 1.652
+STEP_TFLOP = {"flux": 74.36, "flux512": 21.49, "qwen": 167.4, "wan": 6520.0, "hunyuan": 1394.9}
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -64,7 +68,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["flux", "qwen", "wan", "hunyuan", "queue"], default="flux")
+    ap.add_argument("--workload", choices=["flux", "flux512", "qwen", "wan", "hunyuan", "queue"], default="flux")
     ap.add_argument("--layers", type=str, default="", help="debug: 'D,S' block counts (invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -82,18 +86,42 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline():
+def cpu_info():
+    """What the host cores ARE (BASELINE.md §3 asks for model, socket count and core count next to the CPU number)."""
+    model, phys, cores, logical = "unknown", set(), set(), 0
+    try:
+        pid = "0"
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+                phys.add(v)
+            elif k == "core id":
+                cores.add((pid, v))
+    except OSError:
+        pass
+    return {"cpu_model": model, "sockets": max(len(phys), 1), "physical_cores": len(cores) or None,
+            "logical_cpus": logical or (os.cpu_count() or 1)}
+
+
+def cpu_baseline(s_img=None, side=64):
     """Oracle on host cores: one double + one single block at full width and sequence, fp32."""
     from oracle import flux as OF
     from oracle import layers as OL
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
     dim, H = 3072, 24
+    S_IMG = s_img or globals()["S_IMG"]
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, S_IMG, dim, generator=g)
     ctx = torch.randn(1, S_TXT, dim, generator=g)
     temb = torch.randn(1, dim, generator=g)
-    ids = torch.cat((torch.zeros(S_TXT, 3), OF.latent_image_ids(64, 64)), dim=0)
+    ids = torch.cat((torch.zeros(S_TXT, 3), OF.latent_image_ids(side, side)), dim=0)
     rope = OF.flux_pos_embed(ids, (16, 56, 56))
     dbl = OF.FluxTransformerBlock(dim, H, 128).eval()
     sgl = OF.FluxSingleTransformerBlock(dim, H, 128).eval()
@@ -105,16 +133,16 @@ def cpu_baseline():
         t2 = time.perf_counter()
     t_step = 19 * (t1 - t0) + 38 * (t2 - t1)
     return {
-        "value": 1.0 / t_step, "unit": "steps/s", "cores": ncores, "kind": "port",
+        "value": 1.0 / t_step, "unit": "steps/s", "cores": ncores, "kind": "port", **cpu_info(),
         "sample": (f"oracle fp32 (PyTorch CPU restatement of the reference path), 1 double block "
-                   f"({t1 - t0:.2f} s) + 1 single block ({t2 - t1:.2f} s) at full width 3072 / S=4608, "
+                   f"({t1 - t0:.2f} s) + 1 single block ({t2 - t1:.2f} s) at full width 3072 / S={S_IMG + S_TXT}, "
                    f"extrapolated x19 / x38; embedders and final layer (<0.1% of FLOPs) excluded"),
     }
 
 
 def _cpu_rate(flops, seconds, step_tflop, cores, sample):
     rate = flops / seconds                                    # algorithmic FLOP/s the host cores sustain on the sample
-    return {"value": rate / (step_tflop * 1e12), "unit": "steps/s", "cores": cores, "kind": "port", "sample": sample}
+    return {"value": rate / (step_tflop * 1e12), "unit": "steps/s", "cores": cores, "kind": "port", **cpu_info(), "sample": sample}
 
 
 def cpu_baseline_qwen():
@@ -163,7 +191,24 @@ def cpu_baseline_wan():
                      f"{STEP_TFLOP['wan']} TFLOP per expert forward")
 
 
-def wan_half(dev):
+def pmc_traffic(src_file, suffix):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc summary (tools/gpu_pmc*.sh; separate passes, cannot run inside
+    this process): used ONLY if it was taken from the kernel source this binary was built from (sha256 recorded next to it);
+    otherwise null — never a stale constant.  Returns (bytes per launch, source file, the record)."""
+    import glob
+    import hashlib
+    if not suffix:
+        return None, None, None
+    with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
+        src_hash = hashlib.sha256(f.read()).hexdigest()
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{suffix}")), reverse=True):
+        rec = json.load(open(pmc))
+        if rec.get("source_sha256") == src_hash:
+            return rec.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(pmc), rec
+    return None, None, None
+
+
+def wan_half(dev, cpu=True):
     """The other half of BASELINE.json's metric on the default line: Wan-2.2 A14B 720p x 81 frames (config 4), one
     expert, 1 warm-up + 2 timed [forward + UniPC step], then the tiled 3-D VAE decode (1 warm-up + 1 timed)."""
     from apex_studio_amd import lib
@@ -209,14 +254,30 @@ def wan_half(dev):
         torch.cuda.synchronize()
         dec = time.perf_counter() - t0
     tf = STEP_TFLOP["wan"]
-    return {"workload": "wan-2.2-a14b text-to-video 720p x 81 frames: one expert forward (40 blocks, S 75600 + 512 text "
-                        "tokens, B=1, no CFG) + UniPC step; tiled 3-D VAE decode to [1,3,81,720,1280]",
-            "steps_timed": 2, "ms_per_step": 1e3 * dt, "steps_per_sec": 1.0 / dt, "step_tflop": tf,
-            "model_tflops": tf / dt, "mfma_utilisation_step": tf / dt / PEAK_BF16_TFLOPS,
-            "attention": {"tflops": att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] else None,
-                          "ms_per_step": att["ms"] / 2, "launches_per_step": att["launches"] / 2},
-            "decode_s": dec, "sec_per_clip_30_steps": 30 * dt + dec, "video": list(video.shape),
-            "finite": finite and bool(torch.isfinite(video.float()).all().item())}
+    ach = att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] else None
+    traffic, traffic_src, rec = pmc_traffic("attention.hip", "pmc_attn_wan.json")
+    alg = (rec or {}).get("algorithmic_bytes_per_launch")
+    roof = {"bound": "mfma", "kernel": "attn_fwd_d128_c4_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_BF16_TFLOPS if ach else None, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (traffic / alg) if traffic and alg else None,
+            "avg_launch_us": 1e3 * att["ms"] / att["launches"] if att["launches"] else None,
+            "launches_per_step": att["launches"] / 2, "algorithmic_tflop_per_step": att["flops"] / 2 / 1e12,
+            "note": "the dominant kernel of the Wan step (72 % of it): achieved = 4 H Sq Sk D flops of its launches / their summed "
+                    "HIP-event durations over the 2 timed steps (events on the launch stream); traffic = HBM bytes per launch from "
+                    "the hash-matched rocprofv3 --pmc pass, mean over 40 self-attention (S 75600) + 40 cross-attention (512 keys) "
+                    "launches"}
+    out = {"workload": "wan-2.2-a14b text-to-video 720p x 81 frames: one expert forward (40 blocks, S 75600 + 512 text "
+                       "tokens, B=1, no CFG) + UniPC step; tiled 3-D VAE decode to [1,3,81,720,1280]",
+           "steps_timed": 2, "ms_per_step": 1e3 * dt, "steps_per_sec": 1.0 / dt, "step_tflop": tf,
+           "model_tflops": tf / dt, "mfma_utilisation_step": tf / dt / PEAK_BF16_TFLOPS,
+           "attention": {"tflops": ach, "ms_per_step": att["ms"] / 2, "launches_per_step": att["launches"] / 2},
+           "roofline": roof, "decode_s": dec, "sec_per_clip_30_steps": 30 * dt + dec, "video": list(video.shape),
+           "finite": finite and bool(torch.isfinite(video.float()).all().item())}
+    del vae, video, z
+    torch.cuda.empty_cache()
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_wan()
+    return out
 
 
 def synth_vae_init(vae, seed):
@@ -241,6 +302,8 @@ def build_flux(args, dev, rank, total):
     if args.layers:
         d, s = (int(v) for v in args.layers.split(","))
         cfg.update(num_layers=d, num_single_layers=s)
+    small = args.workload == "flux512"
+    S_IMG, side, px, clip_steps = (1024, 32, 512, 4) if small else (4096, 64, 1024, 28)
     model = FluxTransformer2DModel(**cfg, device=dev, dtype=torch.bfloat16).init_synthetic(seed=1234 + rank)
     model.pack()
     g = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -248,7 +311,7 @@ def build_flux(args, dev, rank, total):
     gs = torch.Generator(device=dev).manual_seed(7)
     enc = torch.randn(1, S_TXT, 4096, generator=gs, device=dev).to(torch.bfloat16)
     pooled = torch.randn(1, 768, generator=gs, device=dev).to(torch.bfloat16)
-    img_ids = latent_image_ids(64, 64).to(dev)
+    img_ids = latent_image_ids(side, side).to(dev)
     txt_ids = torch.zeros(S_TXT, 3, device=dev)
     guidance = torch.full([1], 3.5, device=dev, dtype=torch.float32)
     sched = FlowMatchEulerDiscreteScheduler.flux_dev()
@@ -267,16 +330,19 @@ def build_flux(args, dev, rank, total):
         """What `FluxT2IEngine.base_denoise` does when it enters its loop (engine_flux.py): steps [i0, i1) of the current
         timesteps are one clip whose AdaLN modulation vectors are computed in one pass over the projection weights.  The
         timed region calls this itself, so the table's cost sits INSIDE the measured time (charged to its first step)."""
+        if sched_box.get("h") is not None:
+            model.end_schedule(sched_box["h"])          # the previous clip is over (also: its rows matched its timesteps)
+            sched_box["h"] = None
         if args.no_mod_table or i1 <= i0:
             sched_box["i0"] = None
             return
         ts = ts_box["ts"][i0:i1]
-        model.begin_schedule(torch.stack([t.expand(1).to(latents.dtype) / 1000 for t in ts]), guidance, pooled)
+        sched_box["h"] = model.begin_schedule(torch.stack([t.expand(1).to(latents.dtype) / 1000 for t in ts]), guidance, pooled)
         sched_box["i0"] = i0
 
     def step(i, lat):
         t = ts_box["ts"][i]
-        jkw = None if sched_box["i0"] is None else {"modulation_step": i - sched_box["i0"]}
+        jkw = None if sched_box["i0"] is None else {"modulation_step": i - sched_box["i0"], "modulation_schedule": sched_box["h"]}
         v = model(hidden_states=lat, timestep=t.expand(1).to(lat.dtype) / 1000, guidance=guidance,
                   pooled_projections=pooled, encoder_hidden_states=enc, txt_ids=txt_ids, img_ids=img_ids,
                   joint_attention_kwargs=jkw, return_dict=False)[0]
@@ -284,29 +350,29 @@ def build_flux(args, dev, rank, total):
     step.begin = begin
 
     def clip():
-        """One whole clip: 28 steps + unpack + 2-D VAE decode (engine/flux/t2i.py:251-255)."""
+        """One whole clip: 28 (flux512: 4) steps + unpack + 2-D VAE decode (engine/flux/t2i.py:251-255)."""
         from apex_studio_amd.engine_flux import unpack_latents
         from apex_studio_amd.vae_flux import AutoencoderKL
         vae = synth_vae_init(AutoencoderKL(device=dev, dtype=torch.bfloat16), 5)
         lat = torch.randn(1, S_IMG, 64, generator=g, device=dev).to(torch.bfloat16)
         for rep in range(2):        # first pass warms the VAE's packed weights
-            ts_box["ts"] = reset(28)
+            ts_box["ts"] = reset(clip_steps)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             x = lat
-            begin(0, 28)
-            for i in range(28):
+            begin(0, clip_steps)
+            for i in range(clip_steps):
                 x = step(i, x)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            z = vae.denormalize_latents(unpack_latents(x, 1024, 1024, 8))
+            z = vae.denormalize_latents(unpack_latents(x, px, px, 8))
             img = vae.decode(z, return_dict=False)[0]
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-        return {"sec_per_clip": t2 - t0, "denoise_s": t1 - t0, "decode_s": t2 - t1, "steps": 28,
+        return {"sec_per_clip": t2 - t0, "denoise_s": t1 - t0, "decode_s": t2 - t1, "steps": clip_steps,
                 "image": list(img.shape), "finite": bool(torch.isfinite(img.float()).all().item())}
 
-    label = ("flux-dev-1024x1024 denoise step (19 double + 38 single MM-DiT blocks, S_img 4096 + S_txt 512, "
+    label = (f"flux-dev-{px}x{px} denoise step (19 double + 38 single MM-DiT blocks, S_img {S_IMG} + S_txt 512, "
              "B=1, no CFG) + FlowMatch-Euler step") if not args.layers else \
         f"DEBUG reduced depth {args.layers} (not a valid result)"
     return step, latents, reset, [enc, pooled], clip, label
@@ -339,16 +405,19 @@ def build_qwen(args, dev, rank, total):
 
     def begin(i0, i1):
         """`QwenImageEditPlusEngine.base_denoise` entering its loop: the modulation table of steps [i0, i1) (inside the timed region)."""
+        if sched_box.get("h") is not None:
+            model.end_schedule(sched_box["h"])
+            sched_box["h"] = None
         if args.no_mod_table or i1 <= i0:
             sched_box["i0"] = None
             return
-        model.begin_schedule(torch.stack([t.expand(1).to(latents.dtype) / 1000 for t in ts_box["ts"][i0:i1]]))
+        sched_box["h"] = model.begin_schedule(torch.stack([t.expand(1).to(latents.dtype) / 1000 for t in ts_box["ts"][i0:i1]]))
         sched_box["i0"] = i0
 
     def step(i, lat):
         t = ts_box["ts"][i]
         x = torch.cat([lat, cond], dim=1)
-        akw = None if sched_box["i0"] is None else {"modulation_step": i - sched_box["i0"]}
+        akw = None if sched_box["i0"] is None else {"modulation_step": i - sched_box["i0"], "modulation_schedule": sched_box["h"]}
         v = model(hidden_states=x, encoder_hidden_states=enc, encoder_hidden_states_mask=None,
                   timestep=t.expand(1).to(lat.dtype) / 1000, img_shapes=shapes, txt_seq_lens=[256],
                   attention_kwargs=akw, return_dict=False)[0][:, :4096]
@@ -627,7 +696,7 @@ def main():
         return
 
     total = args.warmup + args.steps
-    build = {"flux": build_flux, "qwen": build_qwen, "wan": build_wan, "hunyuan": build_hunyuan}[args.workload]
+    build = {"flux": build_flux, "flux512": build_flux, "qwen": build_qwen, "wan": build_wan, "hunyuan": build_hunyuan}[args.workload]
     step, latents, reset, shared_inputs, clip_fn, label = build(args, dev, rank, total)
 
     bcast = None
@@ -646,6 +715,7 @@ def main():
     begin(args.warmup, total)                             # INSIDE the timed region: the K timed steps are one clip
     for i in range(args.warmup, total):
         latents = step(i, latents)
+    enqueued = time.perf_counter() - t0                   # host side done: every launch of the K steps is in the queue
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -673,7 +743,12 @@ def main():
                 "world": world, "rccl_ranks": world if distributed else 1,
                 "model_tflops_per_gpu": (tf_ / (ms * 1e-3)) if full_ else None,
                 "mfma_utilisation_step": (tf_ / (ms * 1e-3) / PEAK_BF16_TFLOPS) if full_ else None,
-                "finite": finite, "broadcast": b or None, **({"debug_shared_gpu": True} if share_gpu else {})}
+                "finite": finite, "broadcast": b or None, **({"debug_shared_gpu": True} if share_gpu else {}),
+                # the Python + ctypes launch path, priced: wall time of the K-step loop up to its last
+                # enqueue, no sync inside.  The host is ahead of the GPU when this is well below ms_per_step; where the two
+                # meet, the HIP queue's back-pressure is what the host waited on and the number is an upper bound.
+                "host_enqueue_ms_per_step": 1e3 * enqueued / args.steps,
+                "gpu_to_host_enqueue_ratio": elapsed / enqueued if enqueued > 0 else None}
 
     # The ONE exchange step of the queue — shared text-encoder / VAE weights from rank 0, scatter + all-gather per 1 GiB
     # bucket, every rank then encodes the same ids with ITS copy and the results are compared bit for bit — runs AFTER the
@@ -740,19 +815,9 @@ def main():
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pmc*.sh), which cannot run
         # inside this process: the committed summary is used ONLY if it was taken from the kernel source this binary
         # was built from (sha256 recorded next to it); otherwise null — never a stale constant.
-        traffic, traffic_src = None, None
-        import glob
-        import hashlib
-        src_file = "gemm.hip" if dom == "gemm" else "attention.hip"
         suffix = {("gemm", "flux"): "pmc_gemm.json", ("gemm", "qwen"): "pmc_gemm_qwen.json",
                   ("attention", "wan"): "pmc_attn_wan.json"}.get((dom, args.workload))
-        with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
-            src_hash = hashlib.sha256(f.read()).hexdigest()
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{suffix}")), reverse=True) if suffix else []:
-            rec = json.load(open(pmc))
-            if rec.get("source_sha256") == src_hash:
-                traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
-                break
+        traffic, traffic_src, pmc_rec = pmc_traffic("gemm.hip" if dom == "gemm" else "attention.hip", suffix)
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_c4_kernel",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
@@ -760,7 +825,12 @@ def main():
                     "algorithmic_tflop_per_step": gk["flops"] / nprof / 1e12,
                     "note": "achieved = algorithmic flops / summed HIP-event durations of the kernel's launches over "
                             f"{nprof} extra event-instrumented steps; the per-class times in `kernels` come from that pass, "
-                            "include the event overhead and are NOT additive to ms_per_step"}
+                            "include the event overhead and are NOT additive to ms_per_step; `traffic` = HBM bytes PER LAUNCH "
+                            "(mean over the kernel's launches) from the separate rocprofv3 --pmc pass named in traffic_source, "
+                            "used only when that record's source hash equals this binary's kernel source"
+                            + (f"; that pass ran `{pmc_rec.get('command')}`" + (" - a DEPTH-REDUCED run of the same launches: "
+                               "per launch it is the full-depth figure, per step it is not" if "--layers" in str(pmc_rec.get("command")) else "")
+                               if pmc_rec else "")}
         # The power roof the fraction has to be read against: the chip clocks to its power budget (DVFS), so the nominal
         # 2.5 PF (2.4 GHz) is not on offer while this kernel runs.  Measured live, un-instrumented steps, no profiler: every
         # GEMM workgroup stamps its K-loop with s_memtime (shader cycles) and s_memrealtime (100 MHz) — apexmi_clk_*.
@@ -789,12 +859,13 @@ def main():
         out = core_line()
         out.update({"sec_per_clip": clip["sec_per_clip"] if clip else None, "clip": clip, "roofline": roofline,
                     "kernels": kernels})
-        if not args.no_cpu_baseline and args.gpus == 1 and args.workload in ("flux", "qwen", "wan"):
-            out["cpu_baseline"] = {"flux": cpu_baseline, "qwen": cpu_baseline_qwen, "wan": cpu_baseline_wan}[args.workload]()
+        if not args.no_cpu_baseline and args.gpus == 1 and args.workload in ("flux", "flux512", "qwen", "wan"):
+            out["cpu_baseline"] = {"flux": cpu_baseline, "flux512": lambda: cpu_baseline(1024, 32), "qwen": cpu_baseline_qwen,
+                                   "wan": cpu_baseline_wan}[args.workload]()
         if args.workload == "flux" and args.gpus == 1 and full and not args.no_wan:
             del step, latents, clip_fn
             torch.cuda.empty_cache()
-            out["wan"] = wan_half(dev)
+            out["wan"] = wan_half(dev, cpu=not args.no_cpu_baseline)
     _flush_c_stdio()           # RCCL's version banner sits in C stdio: get it out BEFORE the result line
     if rank == 0:
         print(json.dumps(out), flush=True)    # the ONE JSON line, last on stdout

@@ -226,11 +226,11 @@ def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors(B):
         m(return_dict=False, timestep=ts[i].expand(1), **{k: (v[:1] if k not in ("img_ids", "txt_ids") else v) for k, v in g.items()})
         torch.cuda.synchronize()
         mods.append(m._ws[(s_txt, hw[0] * hw[1], torch.cuda.current_stream().cuda_stream)].MOD.clone())
-    m.begin_schedule(ts, g["guidance"], g["pooled_projections"])
-    (sc,) = m._sched.values()
-    assert sc.table.shape == (n * B, m._mod_total)
+    h = m.begin_schedule(ts, g["guidance"], g["pooled_projections"])
+    (table,) = h.tables.values()
+    assert table.shape == (n * B, m._mod_total) and len(m._scheds) == 1
     for i in range(n):
-        assert torch.equal(sc.table[i * B:i * B + 1], mods[i]), i
+        assert torch.equal(table[i * B:i * B + 1], mods[i]), i
         out = m(return_dict=False, timestep=ts[i].expand(B), joint_attention_kwargs={"modulation_step": i}, **g)[0]
         assert torch.equal(out, plain[i]), i
     # not part of the clip: another pooled tensor / no index / index out of range -> per-step path, same bits
@@ -238,8 +238,55 @@ def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors(B):
     assert torch.equal(m(return_dict=False, timestep=ts[1].expand(B), joint_attention_kwargs={"modulation_step": 3}, **other)[0], plain[1])
     assert torch.equal(m(return_dict=False, timestep=ts[2].expand(B), **g)[0], plain[2])
     assert torch.equal(m(return_dict=False, timestep=ts[2].expand(B), joint_attention_kwargs={"modulation_step": 9}, **g)[0], plain[2])
-    m.end_schedule()
+    m.end_schedule(h)                                    # also the mismatch check: every scheduled call above matched its row
+    assert len(m._scheds) == 0 and not h.live
     assert torch.equal(m(return_dict=False, timestep=ts[4].expand(B), joint_attention_kwargs={"modulation_step": 0}, **g)[0], plain[4])
+    assert torch.equal(m(return_dict=False, timestep=ts[4].expand(B),
+                         joint_attention_kwargs={"modulation_step": 0, "modulation_schedule": h}, **g)[0], plain[4])   # stale handle
+
+
+def test_two_clips_in_flight_read_their_own_schedule():
+    """two clips through ONE resident model — SAME pooled tensor (shared prompt embeddings), different
+    timesteps, the second clip's schedule built and consumed on another HIP stream.  Each clip's handle selects its own table
+    (bit-identical to the per-step path); a call WITHOUT a handle while two schedules are live computes its own vectors instead
+    of guessing; ending one clip leaves the other's table alone; a scheduled step handed a timestep that is not its row's is
+    reported when the clip ends."""
+    from apex_studio_amd import lib
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["mid"]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(m, 7).items()}, strict=True)
+    n = 3
+    ts_a = torch.linspace(1.0, 0.5, n, device=DEV).to(torch.bfloat16)
+    ts_b = torch.linspace(0.9, 0.1, n, device=DEV).to(torch.bfloat16)
+    g = dict(hidden_states=seeded((1, hw[0] * hw[1], cfg["in_channels"]), 41).to(DEV).to(torch.bfloat16),
+             encoder_hidden_states=seeded((1, s_txt, cfg["joint_attention_dim"]), 42).to(DEV).to(torch.bfloat16),
+             pooled_projections=seeded((1, cfg["pooled_projection_dim"]), 43).to(DEV).to(torch.bfloat16),
+             guidance=torch.tensor([4.0], device=DEV), img_ids=OF.latent_image_ids(*hw).to(DEV), txt_ids=torch.zeros(s_txt, 3, device=DEV))
+    fwd = lambda t, **jk: m(return_dict=False, timestep=t.expand(1), joint_attention_kwargs=jk or None, **g)[0].clone()   # noqa: E731
+    plain_a, plain_b = [fwd(t) for t in ts_a], [fwd(t) for t in ts_b]
+    torch.cuda.synchronize()
+    ha = m.begin_schedule(ts_a, g["guidance"], g["pooled_projections"])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hb = m.begin_schedule(ts_b, g["guidance"], g["pooled_projections"])     # same pooled tensor: the old key collided here
+    assert len(m._scheds) == 2 and ha.id != hb.id and hb.stream == side.cuda_stream
+    for i in range(n):
+        assert torch.equal(fwd(ts_b[i], modulation_step=i, modulation_schedule=hb), plain_b[i]), i    # main stream waits on hb.ready
+        with torch.cuda.stream(side):
+            out = fwd(ts_a[i], modulation_step=i, modulation_schedule=ha)                                # side stream waits on ha.ready
+        side.synchronize()
+        assert torch.equal(out, plain_a[i]), i
+        assert torch.equal(fwd(ts_a[i], modulation_step=i), plain_a[i]), "no handle + two live schedules -> per-step path"
+    m.end_schedule(hb)
+    assert len(m._scheds) == 1 and ha.live and not hb.live
+    assert torch.equal(fwd(ts_a[1], modulation_step=1), plain_a[1])              # one live schedule again: served from ha
+    # a row read with ANOTHER timestep: wrong modulation by construction -> loud at the end of the clip
+    wrong = fwd(ts_a[0], modulation_step=2, modulation_schedule=ha)
+    assert not torch.equal(wrong, plain_a[0])
+    with pytest.raises(lib.ApexMIError, match="different from the row"):
+        m.end_schedule(ha)
+    assert len(m._scheds) == 0
 
 
 def test_engine_loop_with_true_cfg_reads_two_modulation_tables():
@@ -276,7 +323,7 @@ def test_engine_loop_with_true_cfg_reads_two_modulation_tables():
                                      negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npool,
                                      negative_text_ids=inp["txt_ids"].to(DEV), true_cfg_scale=2.5, use_cfg_guidance=True).clone())
         if tr is m:
-            assert m._sched == {}, "the engine must release the tables when the loop ends"
+            assert len(m._scheds) == 0, "the engine must release the tables when the loop ends"
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
 

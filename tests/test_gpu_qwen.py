@@ -86,15 +86,29 @@ def test_scheduled_modulation_table_is_bit_identical_to_per_step_vectors():
         m(timestep=ts[i].expand(1), return_dict=False, **one)
         torch.cuda.synchronize()
         mods.append(m._ws[(s_txt, n_img, torch.cuda.current_stream().cuda_stream)].MOD.clone())
-    m.begin_schedule(ts)
-    assert m._sched.table.shape == (n, m._mod_total)
+    h = m.begin_schedule(ts)
+    assert h.table.shape == (n, m._mod_total) and len(m._scheds) == 1
     for i in range(n):
-        assert torch.equal(m._sched.table[i:i + 1], mods[i]), i
+        assert torch.equal(h.table[i:i + 1], mods[i]), i
         assert torch.equal(m(timestep=ts[i].expand(B), attention_kwargs={"modulation_step": i}, **kw)[0], plain[i]), i
     assert torch.equal(m(timestep=ts[1].expand(B), **kw)[0], plain[1])                                             # no index
     assert torch.equal(m(timestep=ts[2].expand(B), attention_kwargs={"modulation_step": 7}, **kw)[0], plain[2])    # out of range
-    m.end_schedule()
+    # a second clip with OTHER timesteps in flight (the table used to be model-global): the handle selects the
+    # clip's own rows; without a handle and two live schedules the forward computes its own vectors
+    h2 = m.begin_schedule(ts.flip(0))
+    assert torch.equal(m(timestep=ts[0].expand(B), attention_kwargs={"modulation_step": n - 1, "modulation_schedule": h2}, **kw)[0], plain[0])
+    assert torch.equal(m(timestep=ts[0].expand(B), attention_kwargs={"modulation_step": 0, "modulation_schedule": h}, **kw)[0], plain[0])
+    assert torch.equal(m(timestep=ts[1].expand(B), attention_kwargs={"modulation_step": 0}, **kw)[0], plain[1])
+    m.end_schedule(h2)
+    m.end_schedule(h)
+    assert len(m._scheds) == 0
     assert torch.equal(m(timestep=ts[3].expand(B), attention_kwargs={"modulation_step": 0}, **kw)[0], plain[3])
+    # a scheduled step called with a timestep that is not its row's is reported when the clip ends
+    from apex_studio_amd import lib
+    h3 = m.begin_schedule(ts)
+    m(timestep=ts[2].expand(B), attention_kwargs={"modulation_step": 0, "modulation_schedule": h3}, **kw)
+    with pytest.raises(lib.ApexMIError, match="different from the row"):
+        m.end_schedule(h3)
 
 
 def test_qwen_matches_reference_wiring_golden(golden_dir):
