@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--no-mod-table", action="store_true",
                     help="A/B: per-step AdaLN GEMVs instead of the per-clip modulation table (flux, qwen)")
     ap.add_argument("--clip", action="store_true", help="wan: also time a whole 30-step clip + decode")
+    ap.add_argument("--fp8", action="store_true",
+                    help="wan: block Linear weights RESIDENT as float8_e4m3fn + per-tensor scale_weight (the layout the Wan-2.2 manifest's "
+                         "default files ship, R/manifest/video/wan-2.2-a14b-text-to-video-1.0.0.v1.yml:108-116), dequantised per call")
     ap.add_argument("--queue-wan-steps", type=int, default=30)
     ap.add_argument("--no-shared-weights", action="store_true",
                     help="N>1: broadcast only the prompt embeddings, not the text-encoder/VAE weights")
@@ -429,11 +432,27 @@ def build_qwen(args, dev, rank, total):
     return step, latents, reset, [enc], None, label
 
 
+@torch.no_grad()
+def fp8_quantise_blocks(model):
+    """Synthetic stand-in for a keep_fp8 load (weights.load_checkpoint_into(keep_fp8=True)): every block Linear weight becomes
+    float8_e4m3fn + one `scale_weight` = amax / 448 (the fp8-scaled checkpoint layout, R/src/quantize/scaled_layer.py:390-552),
+    then `_fp8_adopt()` fuses the projections' records and releases the bf16 storage."""
+    from apex_studio_amd import ops
+    for name, p in model.named_parameters():
+        if model._fp8_resident_key(name) and p.dim() == 2:
+            scale = (p.data.abs().amax().float() / 448.0).clamp_min(1e-12)
+            q = (p.data.float() / scale).to(torch.float8_e4m3fn)
+            p._fp8 = ops.Fp8Weight(q, scale.reshape(1))
+    return model._fp8_adopt()
+
+
 def build_wan(args, dev, rank, total):
     from apex_studio_amd.wan import WanTransformer3DModel
     from apex_studio_amd.schedulers import UniPCMultistepScheduler
     model = WanTransformer3DModel(device=dev, dtype=torch.bfloat16).init_synthetic(seed=999 + rank)
     model.pack()
+    if args.fp8:
+        fp8_quantise_blocks(model)
     g = torch.Generator(device=dev).manual_seed(300 + rank)
     latents = torch.randn(1, 16, 21, 90, 160, generator=g, device=dev)
     enc = torch.randn(1, 512, 4096, generator=torch.Generator(device=dev).manual_seed(9), device=dev).to(torch.bfloat16)
@@ -465,7 +484,8 @@ def build_wan(args, dev, rank, total):
                 "finite": bool(torch.isfinite(video.float()).all().item())}
 
     label = ("wan-2.2-a14b text-to-video 720p x 81 frames, one expert forward (40 blocks, S 75600 + 512 text, B=1, "
-             "no CFG) + UniPC step")
+             "no CFG) + UniPC step") + (f"; block weights resident fp8-scaled ({model._fp8_bytes / 2**30:.1f} GiB), dequantised per call"
+                                        if args.fp8 else "")
     return step, latents, reset, [enc], (clip if args.clip else None), label
 
 
