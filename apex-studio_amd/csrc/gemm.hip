@@ -1481,6 +1481,251 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     store8<bf16_t>(o + 2 * (int64_t)K, lo);
 }
 
+// ---- 288 x 192 tile: the EXACT-FILL tiling (round 5) --------------------------------------------------------
+// The Flux single block's proj_out (M 4608 joint rows, N 3072, K 15360: 28 % of the step's GEMM flops) is 18 x 12 = 216 tiles of
+// 256 x 256 on 256 CUs: one round with 40 CUs idle.  As 288 x 192 it is 16 x 16 = 256 tiles, one FULL round of tiles that carry
+// 0.84 of a 256 x 256 tile's work.  Same machine as the shipped schedule (SCHED 5): 8 waves (2 x 4), v_mfma_f32_16x16x32_bf16,
+// 16-byte LDS-DMA pieces into a double-buffered image with the (row >> 1) & 7 chunk swizzle, the two M-halves of the block one
+// barrier apart so that every SIMD has one wave in its MFMA segment and one in its LDS / DMA segment.  What differs:
+//   * a wave owns 144 x 48 = 9 x 3 accumulator tiles (108 VGPRs); a K-tile is THREE phases (m-groups of 3 tiles x all 3 n-tiles:
+//     18 MFMAs each); the weight fragments (6 reads) are read once per K-tile in phase 0, 6 activation-fragment reads per phase:
+//     24 ds_read_b128 per 54 MFMAs (shipped: 24 per 64);
+//   * a K-tile is 60 pieces of 8 rows (36 activation + 24 weight) = 7.5 per wave: issued as 8 per wave, the last four of the
+//     phase-0 class being duplicates of its first four (same bytes to the same LDS address), so that every wave's counted
+//     vmcnt waits are the same: pieces j = 0..4 of a wave are what the NEXT K-tile's phase 0 reads (all weight rows + m-group 0),
+//     j = 5, 6 complete m-group 1, j = 7 m-group 2; issued 3 + 3 + 2 over the three phases of the current K-tile;
+//   * the third n-tile of a wave has no partner for the 8-consecutive-columns exchange: 8-byte epilogue accesses for that third.
+// Every output element is accumulated over K in the same order as on the 256 x 256 tiling (K-tiles in sequence, two 32-deep
+// MFMAs each), so results are BIT-IDENTICAL to it (tests/test_gpu_ops.py::test_gemm_x288_tiling_is_bit_identical).
+constexpr int XBM = 288, XBN = 192;
+constexpr int X_A_BYTES = XBM * BK * 2, X_W_BYTES = XBN * BK * 2, X_STAGE = X_A_BYTES + X_W_BYTES, X_LDS = 2 * X_STAGE;
+
+// one 16-column n-tile of a wave (accumulator layout: lane (g, c) holds C[m = 16 mt + c][nb + 4 g + (0..3)]): 8-byte accesses
+template <int EPI, int MT, int ACT = 0>
+APEXMI_DEVICE void store_single16(const f32x4_t (&x)[MT], const GemmProblem& P, int N, const int (&m)[MT], int nb, int g,
+                                  const u32x2* rr_pre) {
+    const int nl = min(nb + 4 * g, N - 4);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias != nullptr) {
+        const u32x2 b = *(const u32x2*)(P.bias + nl);
+        bs[0] = bf16_lo(b[0]);
+        bs[1] = bf16_hi(b[0]);
+        bs[2] = bf16_lo(b[1]);
+        bs[3] = bf16_hi(b[1]);
+    }
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == APEXMI_EPI_BIAS_GATE_RES) gt = *(const f32x4*)(P.gate + nl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_c<ACT>(x[mt][j] + bs[j]);
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+            const u32x2 r = rr_pre[mt];
+            v[0] = bf16_lo(r[0]) + gt[0] * v[0];
+            v[1] = bf16_hi(r[0]) + gt[1] * v[1];
+            v[2] = bf16_lo(r[1]) + gt[2] * v[2];
+            v[3] = bf16_hi(r[1]) + gt[3] * v[3];
+        }
+        if (m[mt] >= 0 && nb + 4 * g < N)
+            *(u32x2*)(P.C + (int64_t)m[mt] * P.ldc + nb + 4 * g) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_x288_kernel(const GemmGroup G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;      // waves w and w + 4 share a SIMD: same column strip, the other M-half
+
+    // ---- tile id -> problem, (pm, pn): XCD-contiguous, grouped group_m tall (as gemm_tile) ----
+    int s = xcd_remap(blockIdx.x, G.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUPS; ++i)
+        if (i < G.count && s >= G.p[i].tile0) gi = i;
+    const GemmProblem P = G.p[gi];
+    s -= P.tile0;
+    const int nn = P.nn, N = P.N, M = P.M;
+    const int GM = G.group_m;
+    const int width = GM * nn;
+    const int first_m = (s / width) * GM;
+    const int gsz = min(P.nm - first_m, GM);
+    const int pm = first_m + (s % width) % gsz;
+    const int pn = (s % width) / gsz;
+    const int m0 = pm * XBM, n0 = pn * XBN;
+
+    // ---- the wave's 8 LDS-DMA pieces of a K-tile (8 rows x 128 B each), in need order ----
+    const char* src[8];
+    int dst[8];                                   // byte offset of the piece inside a stage (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int row0;
+        bool isw = false;
+        if (j < 3) {                              // all 192 weight rows
+            isw = true;
+            row0 = (j * 8 + wave) * 8;
+        } else if (j < 5) {                       // m-group 0 of both halves (rows 0..47, 144..191) + four duplicates
+            const int q = (j - 3) * 8 + wave;
+            row0 = q < 6 ? q * 8 : q < 12 ? 144 + (q - 6) * 8 : (q - 12) * 8;
+        } else {                                  // m-group 1 (rows 48..95, 192..239), then m-group 2 (96..143, 240..287)
+            const int q = (j - 5) * 8 + wave;
+            row0 = q < 6 ? 48 + q * 8 : q < 12 ? 192 + (q - 6) * 8 : q < 18 ? 96 + (q - 12) * 8 : 240 + (q - 18) * 8;
+        }
+        const int row = row0 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        src[j] = isw ? (const char*)(P.W + (int64_t)min(n0 + row, N - 1) * P.ldw + c * 8)
+                     : (const char*)(P.A + (int64_t)min(m0 + row, M - 1) * P.lda + c * 8);
+        dst[j] = (isw ? X_A_BYTES : 0) + row0 * 128;
+    }
+    auto stage = [&](int buf, int kt, int j) { glds16(src[j] + (int64_t)kt * (BK * 2), smem + buf * X_STAGE + dst[j]); };
+
+    f32x4_t acc[3][9];                            // [16-column n-tile][16-row m-tile]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = G.K / BK;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (G.clk != nullptr) {
+        clk_c0 = __builtin_readcyclecounter();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // fragment reads: lane (l15, g4) reads row (tile base + l15), 16-byte chunk (4 ks + g4) ^ swizzle
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int sw16 = (l15 >> 1) & 7;
+    const int a_base = (wm * 144 + l15) * 128, w_base = X_A_BYTES + (wn * 48 + l15) * 128;
+    const int ch16[2] = {((0 + g4) ^ sw16) << 4, ((4 + g4) ^ sw16) << 4};
+    bf16x8 af[3][2], wf[3][2];
+    auto rd_a = [&](const char* St, int grp) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[t][ks] = *(const bf16x8*)(St + a_base + (grp * 3 + t) * 2048 + ch16[ks]);
+    };
+    auto rd_w = [&](const char* St) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *(const bf16x8*)(St + w_base + t * 2048 + ch16[ks]);
+    };
+    auto mma = [&](int grp) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    acc[nt][grp * 3 + t] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], af[t][ks], acc[nt][grp * 3 + t], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define X_SYNC()                                                                    \
+    do {                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        __builtin_amdgcn_s_barrier();                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#define X_BAR()                                \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#define X_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#pragma unroll
+    for (int j = 0; j < 8; ++j) stage(0, 0, j);
+    X_VMCNT(0);
+    X_BAR();
+    if (wm == 1) X_BAR();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* St = smem + (kt & 1) * X_STAGE;
+        const bool more = kt + 1 < nkt;
+        const int nb = (kt + 1) & 1;
+        // phase 0: m-group 0.  A wave's waits cover what the NEXT phase reads (the partner half passes this barrier before it reads)
+        rd_w(St);
+        rd_a(St, 0);
+        if (more) {
+            stage(nb, kt + 1, 0);
+            stage(nb, kt + 1, 1);
+            stage(nb, kt + 1, 2);
+            X_VMCNT(4);                           // in flight at most: j = 7 of this K-tile + the three just issued -> m-group 1 landed
+        } else {
+            X_VMCNT(1);
+        }
+        X_SYNC();
+        mma(0);
+        X_BAR();
+        // phase 1: m-group 1
+        rd_a(St, 1);
+        if (more) {
+            stage(nb, kt + 1, 3);
+            stage(nb, kt + 1, 4);
+            stage(nb, kt + 1, 5);
+            X_VMCNT(6);                           // the six pieces of the next K-tile only -> m-group 2 landed
+        } else {
+            X_VMCNT(0);
+        }
+        X_SYNC();
+        mma(1);
+        X_BAR();
+        // phase 2: m-group 2
+        rd_a(St, 2);
+        if (more) {
+            stage(nb, kt + 1, 6);
+            stage(nb, kt + 1, 7);
+            X_VMCNT(3);                           // j = 5, 6, 7 of the next K-tile may fly: its weights and m-group 0 landed
+        }
+        X_SYNC();
+        mma(2);
+        X_BAR();
+    }
+    if (wm == 0) X_BAR();                         // balance the barrier count of the two halves
+#undef X_VMCNT
+#undef X_SYNC
+#undef X_BAR
+
+    if (G.clk != nullptr) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(G.clk, c1 - clk_c0);
+            atomicAdd(G.clk + 1, r1 - clk_r0);
+        }
+    }
+
+    // ---- epilogue: a 32-column slab (n-tiles 0, 1: 16-byte accesses) + the single n-tile 2 (8-byte accesses) ----
+    int mrow[9];
+#pragma unroll
+    for (int mt = 0; mt < 9; ++mt) {
+        mrow[mt] = m0 + wm * 144 + mt * 16 + l15;
+        if (mrow[mt] >= M) mrow[mt] = -1;
+    }
+    const int nbase = n0 + wn * 48;
+    if constexpr (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+        // every residual row before the first store (C may alias R: the compiler cannot move loads above stores itself)
+        u32x4 rr[9];
+        u32x2 r1[9];
+        const int nst = nbase + 16 * (g4 & 1) + 8 * (g4 >> 1);
+#pragma unroll
+        for (int mt = 0; mt < 9; ++mt) {
+            const bf16_t* row = P.R + (int64_t)max(mrow[mt], 0) * P.ldr;
+            rr[mt] = *(const u32x4*)(row + min(nst, N - 8));
+            r1[mt] = *(const u32x2*)(row + min(nbase + 32 + 4 * g4, N - 4));
+        }
+        store_slab16<EPI, 9, 0>(acc[0], acc[1], P, N, mrow, nbase, g4, rr);
+        store_single16<EPI, 9, 0>(acc[2], P, N, mrow, nbase + 32, g4, r1);
+    } else {
+        APEXMI_ACT_DISPATCH(P.gelu, store_slab16<EPI, 9, ACT>(acc[0], acc[1], P, N, mrow, nbase, g4);
+                            store_single16<EPI, 9, ACT>(acc[2], P, N, mrow, nbase + 32, g4, nullptr));
+    }
+}
+
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 #if APEXMI_GEMM_TRACE
 uintptr_t g_gemm_trace = 0;
@@ -1490,6 +1735,7 @@ int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
 int g_wpacked = 0;    // experiment: W operands are tile-major packed (see GemmGroup::wpacked)
 int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x256 tiles) that goes out as its own launch (96 = the text
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
+int g_x288 = 1;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never | 1 where it saves a round's worth of work | 2 always (A/B, tests)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
 // stream-K workspace: 256 slabs of 256 x 256 f32 + 256 flags per (device, stream) — launches on different streams may overlap and
@@ -1567,8 +1813,63 @@ int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
 }
 
 template <int EPI>
+int launch_x288(GemmGroup& G, const int* Ms, hipStream_t stream) {
+    static uint64_t attr_set = 0;
+    APEXMI_SET_ATTR_ONCE(attr_set,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_x288_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS));
+    int t = 0;
+    for (int i = 0; i < G.count; ++i) {
+        G.p[i].M = Ms[i];
+        G.p[i].nm = (Ms[i] + XBM - 1) / XBM;
+        G.p[i].nn = (G.p[i].N + XBN - 1) / XBN;
+        G.p[i].tile0 = t;
+        t += G.p[i].nm * G.p[i].nn;
+    }
+    G.total = t;
+    G.group_m = g_group_m;
+    G.clk = apexmi_clk_ptr();
+    G.wpacked = 0;
+    G.sk_r = G.sk_tfull = 0;
+    G.sk_slab = nullptr;
+    G.sk_flag = nullptr;
+    hipLaunchKernelGGL((gemm_bf16_x288_kernel<EPI>), dim3(t, 1), dim3(512), X_LDS, stream, G);
+    return apexmi_check_launch("gemm_bf16 (288x192)");
+}
+
+// Does the 288 x 192 tiling finish this launch in less tile-work than 256 x 256?  Cost = rounds of 256 concurrent tiles x work per
+// tile (a 288 x 192 tile stages 11 % more bytes per flop: priced at +4 %); it has to win by 5 %.
+inline bool x288_pays(const GemmGroup& G, const int* Ms) {
+    int64_t t256 = 0, t288 = 0;
+    for (int i = 0; i < G.count; ++i) {
+        if (G.p[i].qkv) return false;            // the fused q/k/v epilogue is written for 256-column tiles (two heads)
+        t256 += (int64_t)((Ms[i] + 255) / 256) * ((G.p[i].N + 255) / 256);
+        t288 += (int64_t)((Ms[i] + XBM - 1) / XBM) * ((G.p[i].N + XBN - 1) / XBN);
+    }
+    const double c256 = (double)((t256 + 255) / 256) * 65536.0;
+    const double c288 = (double)((t288 + 255) / 256) * (XBM * XBN) * 1.04;
+    return c288 < 0.95 * c256;
+}
+
+// bf16-epilogue launches only (the float-I/O classes of the verification mode stay on 256 x 256; their sums are the same anyway)
+inline bool use_x288(const GemmGroup& G, const int* Ms) {
+    if (g_x288 == 0 || G.batch != 1 || G.K % BK != 0 || !(g_force_cfg == 0 || g_force_cfg == 7) || g_large_cfg != 7) return false;
+    int64_t mtot = 0;
+    int nmax = 0;
+    for (int i = 0; i < G.count; ++i) {
+        if (G.p[i].qkv) return false;
+        mtot += Ms[i];
+        nmax = G.p[i].N > nmax ? G.p[i].N : nmax;
+    }
+    if (g_x288 == 2) return true;
+    return G.K >= 256 && mtot >= 1024 && nmax >= 1024 && x288_pays(G, Ms);
+}
+
+template <int EPI>
 int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     int cfg = g_force_cfg;
+    if constexpr (EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_GATE_RES) {
+        if (use_x288(G, Ms)) return launch_x288<EPI>(G, Ms, stream);
+    }
     if (cfg == 0) {
         int64_t mtot = 0;
         int nmax = 0;
@@ -1741,6 +2042,16 @@ extern "C" int apexmi_gemm_bf16_grouped(int count, const void* const* A, const i
     return launch_group(G, M, kind, stream);
 }
 
+extern "C" int apexmi_gemm_uses_x288(int M, int N, int K) {
+    GemmGroup G;
+    memset(&G, 0, sizeof(G));
+    G.count = 1;
+    G.K = K;
+    G.batch = 1;
+    G.p[0].N = N;
+    return (M > 0 && N > 0 && K > 0 && use_x288(G, &M)) ? 1 : 0;
+}
+
 extern "C" int apexmi_gemm_qkv_fusable(int64_t m_total, int n_max, int K) {
     return (g_force_cfg == 0 || g_force_cfg == 7 || g_force_cfg == 9 || g_force_cfg == 10) &&
            (g_large_cfg == 7 || g_large_cfg == 9 || g_large_cfg == 10) && m_total >= 1024 && n_max >= 1024 && K >= 256 && K % BK == 0;
@@ -1824,6 +2135,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.large")) g_large_cfg = value;
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
     else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
+    else if (!strcmp(key, "gemm.x288")) g_x288 = value;
 #if APEXMI_GEMM_TRACE
     else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
     else if (!strcmp(key, "gemm.trace_hi")) g_gemm_trace = (g_gemm_trace & (uintptr_t)0xffffffffu) | ((uintptr_t)(uint32_t)value << 32);

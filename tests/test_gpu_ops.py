@@ -725,3 +725,86 @@ def test_attention_backend_key_padding_masks():
         ab.hip_mfma(q, k, v, attn_mask=torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device="cuda"))
     with pytest.raises(ApexMIError):
         ab.hip_mfma(q, k, v, attn_mask=torch.zeros(B, Sk, dtype=torch.bool, device="cuda"))
+
+
+# ---- the 288 x 192 exact-fill tiling (round 5, gemm.hip gemm_bf16_x288_kernel) --------------------------------------------------
+@pytest.fixture
+def gemm_x288():
+    from apex_studio_amd import lib
+    yield lambda v: lib.tune_set("gemm.x288", v)
+    lib.tune_set("gemm.x288", 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 15360), (4608, 3072, 256), (288, 192, 64), (289, 200, 128), (1000, 1040, 320),
+                                   (75, 3072, 1024), (2000, 8, 64)])
+def test_gemm_x288_tiling_is_bit_identical(M, N, K, gemm_x288):
+    """Every output element is summed over K in the same order on both tilings (K-tiles in sequence, two 32-deep MFMAs each),
+    so the 288 x 192 tiling must reproduce the shipped 256 x 256 launch BIT FOR BIT — every epilogue, ragged edges in M and N,
+    in place on the residual — and match the fp32 reference."""
+    ops = _ops()
+    a, w, b = _bf(seeded((M, K), 1)).to(DEV), _bf(seeded((N, K), 2, scale=K ** -0.5)).to(DEV), _bf(seeded((N,), 3)).to(DEV)
+    gate, r = seeded((N,), 4).to(DEV), _bf(seeded((M, N), 5)).to(DEV)
+    got = {}
+    for mode in (0, 2):
+        gemm_x288(mode)
+        x = r.clone()
+        ops.gemm(a, w, b, out=x, epilogue="gate_res", gate=gate, residual=x)
+        strided = torch.zeros(M, N + 24, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, w, None, out=strided[:, 16:16 + N], epilogue="silu")
+        got[mode] = (ops.gemm(a, w, b), ops.gemm(a, w, b, epilogue="gelu"), x, strided)
+    for u, v, what in zip(got[0], got[2], ("bias", "gelu", "gate_res in place", "silu into a strided view, no bias")):
+        assert torch.equal(u, v), f"288x192 differs from 256x256: {what} at {(M, N, K)}"
+    ref = a.float() @ w.float().T + b.float()
+    _check(got[2][0], ref, 3e-3, "x288 bias")
+    _check(got[2][2], r.float() + gate * ref, 3e-3, "x288 gate_res")
+    assert torch.equal(got[2][3][:, :16].cpu(), torch.zeros(M, 16, dtype=torch.bfloat16)) and \
+        torch.equal(got[2][3][:, 16 + N:].cpu(), torch.zeros(M, 8, dtype=torch.bfloat16)), "stores outside the view"
+
+
+def test_gemm_x288_grouped_and_race_screen(gemm_x288):
+    """Two problems (different M, N and activation) in one 288 x 192 launch, and a deep-K problem repeated: a staging / barrier
+    race (the counted vmcnt waits behind the duplicated pieces) shows up as run-to-run differences."""
+    ops = _ops()
+    K, Mi, Mt = 512, 700, 80
+    ai, at = _bf(seeded((Mi, K), 1)).to(DEV), _bf(seeded((Mt, K), 2)).to(DEV)
+    wi, wt = _bf(seeded((768, K), 3, scale=K ** -0.5)).to(DEV), _bf(seeded((1000, K), 4, scale=K ** -0.5)).to(DEV)
+    bi, bt = _bf(seeded((768,), 5)).to(DEV), _bf(seeded((1000,), 6)).to(DEV)
+    outs = {}
+    for mode in (0, 2):
+        gemm_x288(mode)
+        oi, ot = torch.zeros(Mi, 768, dtype=torch.bfloat16, device=DEV), torch.zeros(Mt, 1000, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_grouped([ai, at], [wi, wt], [bi, bt], [oi, ot], epilogue=["bias", "gelu"])
+        outs[mode] = (oi, ot)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    _check(outs[2][1], torch.nn.functional.gelu(at.float() @ wt.float().T + bt.float(), approximate="tanh"), 3e-3, "x288 grouped gelu")
+    gemm_x288(2)
+    a = _bf(seeded((1152, 4096), 11)).to(DEV)
+    w = _bf(seeded((2048, 4096), 12, scale=4096 ** -0.5)).to(DEV)
+    first = ops.gemm(a, w)
+    _check(first, a.float() @ w.float().T, 3e-3, "x288 deep-K")
+    for _ in range(10):
+        assert torch.equal(ops.gemm(a, w), first), "non-deterministic result: LDS staging race"
+
+
+def test_gemm_x288_is_what_the_flux_proj_out_launch_runs():
+    """The auto rule (`gemm.x288 = 1`): the single block's proj_out (4608 x 3072 x 15360: 216 tiles of 256 x 256 = one round
+    with 40 CUs idle) goes out as 16 x 16 = 256 tiles of 288 x 192; launches that already fill their rounds (FF-up, QKV + MLP,
+    Wan's 23-round launches) stay on the 256 x 256 tiling; the result is the same bits either way."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    L = lib.load()
+    assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 1
+    assert L.apexmi_gemm_uses_x288(4096, 12288, 3072) == 0       # FF-up, image stream: 3 exact rounds already
+    assert L.apexmi_gemm_uses_x288(4608, 21504, 3072) == 0       # QKV + MLP-up: 5.9 rounds
+    assert L.apexmi_gemm_uses_x288(75600, 5120, 5120) == 0       # Wan: 23.1 rounds
+    assert L.apexmi_gemm_uses_x288(512, 3072, 3072) == 0         # under 1024 rows: the 128 x 128 tiling's business
+    a = _bf(seeded((4608, 15360), 1)).to(DEV)
+    w = _bf(seeded((3072, 15360), 2, scale=15360 ** -0.5)).to(DEV)
+    auto = ops.gemm(a, w)
+    lib.tune_set("gemm.x288", 0)
+    try:
+        assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 0
+        off = ops.gemm(a, w)
+    finally:
+        lib.tune_set("gemm.x288", 1)
+    assert torch.equal(auto, off)
