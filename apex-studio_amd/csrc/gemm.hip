@@ -1497,6 +1497,16 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 //   * the third n-tile of a wave has no partner for the 8-consecutive-columns exchange: 8-byte epilogue accesses for that third.
 // Every output element is accumulated over K in the same order as on the 256 x 256 tiling (K-tiles in sequence, two 32-deep
 // MFMAs each), so results are BIT-IDENTICAL to it (tests/test_gpu_ops.py::test_gemm_x288_tiling_is_bit_identical).
+//
+// MEASURED (profiles/r05_gemm_x288_ab.log, r05_gemm_fill_probe.log) AND NOT SHIPPED (`gemm.x288` = 0): proj_out 351 us against
+// 339 us on 256 x 256 (-3.5 %), every other part-filled shape -0.1 .. -7 %, the Flux step 67.6 against 66.9 ms.  The premise —
+// "40 idle CUs are lost time" — is wrong for this kernel: a K-tile of a 256 x 256 workgroup takes 1.23 us while <= 128 CUs hold a
+// tile, 1.34 us at 192, 1.43 us at 224 and 1.53 us at 256 (the same curve for 288 x 192: 1.23 -> 1.42 us), i.e. the chip delivers
+// ~11 TB/s of L2 -> LDS staging in aggregate however many CUs ask for it, and a K-tile never takes less than ~1.23 us on a CU
+// although its MFMAs need 1.0 us (0.84 us here).  Filling the last 40 CUs therefore slows the other 216 down by what the 40 add,
+// and a tile that stages 11 % more bytes per flop loses.  The only lever left on this term is FEWER staged bytes per flop
+// (a 384 x 256 tile: 192 accumulator registers of 256; fp8 weight pieces: profiles/r05_gemm_roof_fp8.log).
+// Kept as a selectable tiling (`gemm.x288` = 1 | 2) for the record and for the A/B tools.
 constexpr int XBM = 288, XBN = 192;
 constexpr int X_A_BYTES = XBM * BK * 2, X_W_BYTES = XBN * BK * 2, X_STAGE = X_A_BYTES + X_W_BYTES, X_LDS = 2 * X_STAGE;
 
@@ -1735,7 +1745,8 @@ int g_force_cfg = 0;  // 0 auto, else the tiling number of the header comment
 int g_wpacked = 0;    // experiment: W operands are tile-major packed (see GemmGroup::wpacked)
 int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x256 tiles) that goes out as its own launch (96 = the text
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
-int g_x288 = 1;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never | 1 where it saves a round's worth of work | 2 always (A/B, tests)
+int g_x288 = 0;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never (SHIPPED: it measured slower, see the kernel's header) |
+                      // 1 where it saves a round's worth of tile-work | 2 always (A/B, tests)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
 // stream-K workspace: 256 slabs of 256 x 256 f32 + 256 flags per (device, stream) — launches on different streams may overlap and

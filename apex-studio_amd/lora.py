@@ -183,9 +183,10 @@ class LoraAdapterMixin:
             raise ValueError("no LoRA tensors found in the state dict")
         for m, d in mods.items():                      # validate before touching anything
             w = self._lora_param(m, "weight")
-            if tuple(d["B"].shape[:1]) + tuple(d["A"].shape[1:]) != tuple(w.shape):
+            wshape = getattr(w, "_fp8_shape", None) or tuple(w.shape)      # a resident-fp8 parameter has no bf16 storage (wan.py)
+            if tuple(d["B"].shape[:1]) + tuple(d["A"].shape[1:]) != tuple(wshape):
                 raise ValueError(f"adapter '{adapter_name}', module '{m}': delta {d['B'].shape[0]}x{d['A'].shape[1]} "
-                                 f"does not fit weight {tuple(w.shape)}")
+                                 f"does not fit weight {tuple(wshape)}")
         ads[adapter_name] = mods
         self._lora_scales[adapter_name] = 1.0 if activate else 0.0
         if activate:

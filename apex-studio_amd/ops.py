@@ -6,7 +6,7 @@ libapex_mi355.so.  Every wrapper refuses CPU tensors: the product path has no fa
 from __future__ import annotations
 
 import math
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -132,6 +132,13 @@ class Fp8Weight:
         self.scale = s
         self.shape = q.shape
         self.device = q.device
+        # which model Linears the rows belong to: [(module path, first row, rows)] (set by the model that adopts the record)
+        self.parts: List[Tuple[str, int, int]] = []
+        # RUN-TIME LoRA on a weight whose bf16 form does not exist (set_lora): lora_A [Rp, K] = the active adapters' down factors
+        # stacked along the rank (zero rows up to a multiple of 64), lora_B [N, Rp] = their up factors x scale, placed on the rows
+        # of their part (block-diagonal for a fused projection)
+        self.lora_A: Optional[torch.Tensor] = None
+        self.lora_B: Optional[torch.Tensor] = None
 
     @classmethod
     def cat(cls, parts: Sequence["Fp8Weight"]) -> "Fp8Weight":
@@ -140,7 +147,41 @@ class Fp8Weight:
             raise ValueError("Fp8Weight.cat: parts must share the fp8 format and the input width")
         q = torch.cat([p.q.view(torch.uint8) for p in parts], dim=0).view(parts[0].q.dtype)
         s = torch.cat([p.scale if p.scale.numel() == p.shape[0] else p.scale.expand(p.shape[0]) for p in parts])
-        return cls(q, s)
+        out = cls(q, s)
+        r0 = 0
+        for p in parts:
+            out.parts += [(m, r0 + a, n) for m, a, n in p.parts]
+            r0 += p.shape[0]
+        return out
+
+    @torch.no_grad()
+    def set_lora(self, adapters: Sequence[Tuple[str, torch.Tensor, torch.Tensor, float]]) -> int:
+        """`adapters`: (module path, A [r, K], B [rows of that part, r], scale) of every ACTIVE adapter touching this record.
+        The reference keeps fp8-scaled base weights and runs `base(x) + scale * B(A(x))` per Linear at run time (PEFT layers
+        around FPScaledLinear, R/src/lora/manager.py:454-606); gemm() below does the same as ONE extra skinny GEMM and a K
+        extended by the padded rank (see _gemm_fp8_lora).  Returns the padded rank (0 = no adapter left)."""
+        if not adapters:
+            self.lora_A = self.lora_B = None
+            return 0
+        N, K = self.shape
+        row_of = {m: (a, n) for m, a, n in self.parts}
+        R = sum(int(a.shape[0]) for _, a, _, _ in adapters)
+        Rp = (R + 63) // 64 * 64
+        A = torch.zeros((Rp, K), dtype=torch.float32, device=self.device)
+        B = torch.zeros((N, Rp), dtype=torch.float32, device=self.device)
+        c = 0
+        for m, a, b, sc in adapters:
+            if m not in row_of:
+                raise KeyError(f"Fp8Weight.set_lora: '{m}' is not a part of this record ({[p[0] for p in self.parts]})")
+            r0, n = row_of[m]
+            r = int(a.shape[0])
+            if tuple(a.shape) != (r, K) or tuple(b.shape) != (n, r):
+                raise ValueError(f"LoRA factors {tuple(b.shape)} x {tuple(a.shape)} do not fit the {n} x {K} weight of '{m}'")
+            A[c:c + r] = a.to(self.device, torch.float32)
+            B[r0:r0 + n, c:c + r] = b.to(self.device, torch.float32) * float(sc)
+            c += r
+        self.lora_A, self.lora_B = A.to(torch.bfloat16), B.to(torch.bfloat16)
+        return Rp
 
     def nbytes(self) -> int:
         return self.q.numel() + 2 * self.scale.numel()
@@ -152,6 +193,44 @@ class Fp8Weight:
 _fp8_scratch: dict = {}
 
 
+def _fp8_of(w):
+    return w if isinstance(w, Fp8Weight) else getattr(w, "_fp8", None)
+
+
+def _scratch(dev, n: int) -> torch.Tensor:
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    buf = _fp8_scratch.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        _fp8_scratch[key] = buf
+    return buf
+
+
+def _gemm_fp8_lora(a, f8: "Fp8Weight", bias, out, epilogue, gate, residual, lora_buf):
+    """epi(a W^T + (a A^T) B'^T + bias) for a resident-fp8 weight W with run-time LoRA factors, as TWO launches:
+         t = a A^T                      [M, Rp] bf16 — the reference's `lora_A(x)` output, rounded as it is there — written into
+                                        the columns right behind `a` in its padded buffer (`lora_buf`: same rows, >= K + Rp wide);
+         out = epi([a | t] [W | B']^T)  one GEMM over K + Rp: W dequantised into the per-stream scratch with row stride K + Rp
+                                        (the kernel of the load-time path), B' = scale x B copied behind it.
+    The adapter term is accumulated in f32 with the base product and rounded ONCE, under any epilogue (GELU included) — at least as
+    accurate as the reference's bf16 `result + lora_B(lora_A(x)) * scaling`.  Cost: Rp / K more K-tiles (1.25 % at rank 64 on
+    d = 5120) + the skinny GEMM; no pass over the [M, N] output."""
+    M, K = a.shape
+    N = f8.shape[0]
+    Rp = f8.lora_A.shape[0]
+    if a.dtype != torch.bfloat16:
+        raise NotImplementedError("run-time LoRA on resident-fp8 weights exists for bf16 activation storage only")
+    if lora_buf is None or lora_buf.data_ptr() != a.data_ptr() or lora_buf.stride(0) != a.stride(0) or lora_buf.shape[1] < K + Rp \
+            or lora_buf.shape[0] != M:
+        raise _l.ApexMIError(f"gemm: the weight carries run-time LoRA factors (rank {Rp} padded) and needs `lora_buf` = the activation "
+                             f"buffer of `a` with >= {K + Rp} columns (got {None if lora_buf is None else tuple(lora_buf.shape)})")
+    gemm(a, f8.lora_A, None, out=lora_buf[:, K:K + Rp])
+    w2 = _scratch(f8.device, N * (K + Rp))[:N * (K + Rp)].view(N, K + Rp)
+    f8.dequant(out=w2[:, :K])
+    w2[:, K:].copy_(f8.lora_B)
+    return gemm(lora_buf[:, :K + Rp], w2, bias, out=out, epilogue=epilogue, gate=gate, residual=residual)
+
+
 def _bf16_weight(w, float_acts: bool = False):
     """`w` as the bf16 [N, K] operand of a GEMM launched next on the current stream: the tensor itself, or — for an Fp8Weight / a
     parameter carrying one (`param._fp8`, weights.load_checkpoint_into(keep_fp8=True)) — its dequantisation into the stream's
@@ -159,15 +238,12 @@ def _bf16_weight(w, float_acts: bool = False):
     f8 = w if isinstance(w, Fp8Weight) else getattr(w, "_fp8", None)
     if f8 is None:
         return w
+    if f8.lora_A is not None:
+        raise _l.ApexMIError("this resident-fp8 weight carries run-time LoRA factors: only gemm(..., lora_buf=) applies them")
     if float_acts:           # verification mode caches on (data_ptr, version): never hand it a recycled buffer
         return f8.dequant()
-    key = (f8.device.index, torch.cuda.current_stream().cuda_stream)
-    buf = _fp8_scratch.get(key)
     n = f8.shape[0] * f8.shape[1]
-    if buf is None or buf.numel() < n:
-        buf = torch.empty(n, dtype=torch.bfloat16, device=f8.device)
-        _fp8_scratch[key] = buf
-    return f8.dequant(out=buf[:n].view(f8.shape[0], f8.shape[1]))
+    return f8.dequant(out=_scratch(f8.device, n)[:n].view(f8.shape[0], f8.shape[1]))
 
 
 _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_GATE_RES,
@@ -176,10 +252,15 @@ _EPI = {"bias": _l.EPI_BIAS, "gelu": _l.EPI_BIAS_GELU, "gate_res": _l.EPI_BIAS_G
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, epilogue: str = "bias",
-         gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+         gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         lora_buf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  2-D operands, last dim contiguous; a / out / residual bf16, or float32
-    in the f32-storage verification mode (w and bias stay bf16)."""
+    in the f32-storage verification mode (w and bias stay bf16).  `lora_buf`: see _gemm_fp8_lora (ignored unless `w` is a
+    resident-fp8 weight with run-time LoRA factors)."""
     _req_act(a, "gemm.a")
+    f8 = _fp8_of(w)
+    if f8 is not None and f8.lora_A is not None:
+        return _gemm_fp8_lora(a, f8, bias, out, epilogue, gate, residual, lora_buf)
     w = _bf16_weight(w, a.dtype == torch.float32)
     _req(w, torch.bfloat16, "gemm.w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1

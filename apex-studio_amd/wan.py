@@ -234,6 +234,13 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         self.pack()
         dev, dt = self.device, self.dtype
 
+        names = {id(p): k[:-len(".weight")] for k, p in self.named_parameters() if k.endswith(".weight")}
+        for p in self.parameters():            # every record knows which Linear its rows are (run-time LoRA addresses them by name)
+            f = getattr(p, "_fp8", None)
+            if f is not None:
+                f.parts = [(names[id(p)], 0, int(f.shape[0]))]
+                p._fp8_shape = tuple(f.shape)
+
         def fused(parts):
             f8 = [getattr(p, "_fp8", None) for p in parts]
             if all(f is None for f in f8):
@@ -242,6 +249,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
                 raise _l.ApexMIError("wan.mi355 keep_fp8: a fused projection mixes fp8-scaled and plain weights")
             return ops.Fp8Weight.cat(f8)
         n = 0
+        self._fp8_records = {}                 # module path -> the record holding its rows
         for blk in self.blocks:
             a1, a2 = blk.attn1, blk.attn2
             for name, parts in (("_wqkv", [a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]), ("_wkv2", [a2.to_k.weight, a2.to_v.weight])):
@@ -252,13 +260,46 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
                         del p._fp8           # the fused record is the one that is read; the parts' views of the bf16 buffer go
                         p.data = torch.empty(0, device=dev, dtype=dt)
                     n += f.nbytes()
+                    self._fp8_records.update({m: f for m, _, _ in f.parts})
             for p in (a1.to_out[0].weight, a2.to_q.weight, a2.to_out[0].weight, blk.ffn.net[0].proj.weight, blk.ffn.net[2].weight):
                 if getattr(p, "_fp8", None) is not None:
                     p.data = torch.empty(0, device=dev, dtype=dt)
                     n += p._fp8.nbytes()
+                    self._fp8_records[p._fp8.parts[0][0]] = p._fp8
         self._fp8_bytes = n
         torch.cuda.empty_cache()
         return self
+
+    # ---- LoRA on resident-fp8 weights: applied at RUN TIME, as the reference does (R/src/lora/manager.py:454-606 around
+    # FPScaledLinear) — there is no bf16 weight to merge into.  Modules whose weights are ordinary bf16 parameters still merge.
+    @torch.no_grad()
+    def _lora_remerge(self, modules):
+        recs = getattr(self, "_fp8_records", None) or {}
+        modules = set(modules)
+        resident = {m for m in modules if m in recs}
+        if resident:
+            for m in resident:
+                if any("bias" in d[m] for d in self._lora_adapters.values() if m in d):
+                    raise NotImplementedError(f"wan.mi355: a lora_B.bias on the resident-fp8 Linear '{m}' is not supported")
+            touched = {id(recs[m]): recs[m] for m in resident}
+            pad = 0
+            for rec in touched.values():
+                act = [(m, d[m]["A"], d[m]["B"], self._lora_scales[n]) for m, _, _ in rec.parts
+                       for n, d in self._lora_adapters.items()
+                       if m in d and self._lora_scales[n] != 0.0 and self._lora_enabled]
+                rec.set_lora(act)
+            for rec in {id(r): r for r in recs.values()}.values():
+                pad = max(pad, 0 if rec.lora_A is None else int(rec.lora_A.shape[0]))
+            if pad != getattr(self, "_lora_pad", 0):
+                self._lora_pad = pad         # the activation buffers grow by this many columns (see _workspace)
+                self._ws = {}
+        super()._lora_remerge(modules - resident)
+
+    def state_dict(self, *a, **k):
+        if getattr(self, "_fp8_bytes", 0):
+            raise _l.ApexMIError("wan.mi355: this model was loaded with keep_fp8=True — its block weights live as float8 + scale "
+                                 "records (inference only); it has no bf16 state dict to save.  Load without keep_fp8 to serialise.")
+        return super().state_dict(*a, **k)
 
     @torch.no_grad()
     def _weights_changed(self):
@@ -282,11 +323,16 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         tkp = (s_txt + 63) // 64 * 64
         bf = dict(device=dev, dtype=self.storage_dtype)     # activation buffers
         f32 = dict(device=dev, dtype=torch.float32)
+        # run-time LoRA on resident-fp8 weights (ops._gemm_fp8_lora): the buffers a Linear READS carry `pad` spare columns behind
+        # their rows for the adapters' rank-space activations; pad = 0 (no such adapter) is the plain layout
+        pad = int(getattr(self, "_lora_pad", 0))
+        XNf, ATTf = torch.empty(S, dim + pad, **bf), torch.empty(S, dim + pad, **bf)
+        FFHf, CTXf = torch.empty(S, ffn + pad, **bf), torch.empty(s_txt, dim + pad, **bf)
         ws = SimpleNamespace(
-            X=torch.empty(S, dim, **bf), XN=torch.empty(S, dim, **bf), QKV=torch.empty(S, 3 * dim, **bf),
+            X=torch.empty(S, dim, **bf), XN=XNf[:, :dim], QKV=torch.empty(S, 3 * dim, **bf),
             Q=torch.empty(1, H, S, 128, **bf), K=torch.empty(1, H, S, 128, **bf),
-            VT=torch.zeros(1, H, 128, skp, **bf), ATT=torch.empty(S, dim, **bf), FFH=torch.empty(S, ffn, **bf),
-            CTX=torch.empty(s_txt, dim, **bf), CTXH=torch.empty(s_txt, dim, **bf),
+            VT=torch.zeros(1, H, 128, skp, **bf), ATT=ATTf[:, :dim], FFH=FFHf[:, :ffn],
+            CTX=CTXf[:, :dim], CTXH=torch.empty(s_txt, dim, **bf), XNf=XNf, ATTf=ATTf, FFHf=FFHf, CTXf=CTXf,
             KV2=torch.empty(s_txt, 2 * dim, **bf), K2=torch.empty(1, H, s_txt, 128, **bf),
             VT2=torch.zeros(1, H, 128, tkp, **bf),
             MOD=torch.empty(max(len(self.blocks), 1), 6 * dim, **f32), MOD2=torch.empty(1, 2 * dim, **f32),
@@ -350,7 +396,7 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
             m = lambda j: ws.MOD[i, j * dim:(j + 1) * dim]  # noqa: E731 shift, scale, gate, c_shift, c_scale, c_gate
             # 1. self attention
             ops.ln_modulate(X, m(1), m(0), out=XN, eps=eps)
-            ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV)
+            ops.gemm(XN, blk._wqkv, blk._bqkv, out=QKV, lora_buf=ws.XNf)
             if fuse:       # across-heads RMSNorm of q and k + RoPE + layout + V^T in one read of the projection
                 ops.qk_rms_rope_rows(q_in, k_in, v_in, H, ws.Q[0], ws.K[0], ws.VT[0], wq=a1.norm_q.weight, wk=a1.norm_k.weight,
                                      eps=eps, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
@@ -361,31 +407,31 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
                                 rope_mode=_l.ROPE_INTERLEAVED)
             ops.attention_prepared(ws.Q, ws.K, ws.VT, att_v, S)
             ops.gemm(ATT, a1.to_out[0].weight, a1.to_out[0].bias, out=X, epilogue="gate_res", gate=m(2),
-                     residual=X)
+                     residual=X, lora_buf=ws.ATTf)
             # 2. cross attention over the text tokens (no RoPE, ungated residual)
             if isinstance(blk.norm2, _AffineNorm):
                 ops.ln_modulate(X, gamma=blk.norm2.weight, beta=blk.norm2.bias, out=XN, eps=eps)
                 src = XN
             else:
                 src = X
-            ops.gemm(src, a2.to_q.weight, a2.to_q.bias, out=q_in)
+            ops.gemm(src, a2.to_q.weight, a2.to_q.bias, out=q_in, lora_buf=ws.XNf if src is XN else None)
             if fuse:
                 ops.qk_rms_rope_rows(q_in, None, None, H, ws.Q[0], None, None, wq=a2.norm_q.weight, eps=eps)
             else:
                 ops.ln_modulate(q_in, gamma=a2.norm_q.weight, out=q_in, eps=eps, rms=True)
-            ops.gemm(ws.CTX, blk._wkv2, blk._bkv2, out=ws.KV2)
+            ops.gemm(ws.CTX, blk._wkv2, blk._bkv2, out=ws.KV2, lora_buf=ws.CTXf)
             ops.ln_modulate(ws.KV2[:, :dim], gamma=a2.norm_k.weight, out=ws.KV2[:, :dim], eps=eps, rms=True)
             if not fuse:
                 ops.qkv_prepare(q_in, None, None, H, ws.Q[0], None, None)
             ops.qkv_prepare(ws.KV2[:, :dim], None, ws.KV2[:, dim:], H, ws.K2[0], None, ws.VT2[0])
             ops.attention_prepared(ws.Q, ws.K2, ws.VT2, att_v, s_txt)
             ops.gemm(ATT, a2.to_out[0].weight, a2.to_out[0].bias, out=X, epilogue="gate_res", gate=self._ones,
-                     residual=X)
+                     residual=X, lora_buf=ws.ATTf)
             # 3. feed-forward
             ops.ln_modulate(X, m(4), m(3), out=XN, eps=eps)
-            ops.gemm(XN, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, out=FFH, epilogue="gelu")
+            ops.gemm(XN, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, out=FFH, epilogue="gelu", lora_buf=ws.XNf)
             ops.gemm(FFH, blk.ffn.net[2].weight, blk.ffn.net[2].bias, out=X, epilogue="gate_res", gate=m(5),
-                     residual=X)
+                     residual=X, lora_buf=ws.FFHf)
 
         # (scale_shift_table + temb).chunk(2): shift first, then scale (model.py:1849-1856)
         ops.ln_modulate(X, ws.MOD2[0, dim:], ws.MOD2[0, :dim], out=XN, eps=eps)

@@ -130,7 +130,8 @@ int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, con
  * (round 5): launches whose 256 x 256 tiles leave a round of the 256 CUs part-filled and whose 288 x 192 tiles do not — the
  * Flux single block's proj_out, `nn.Linear(dim + mlp_hidden, dim)` at R/src/transformer/flux/base/model.py:195-227: 4608 x 3072 x
  * 15360 is 216 tiles of 256 x 256 (40 CUs idle) but 16 x 16 = 256 tiles of 288 x 192.  Results are bit-identical on both tilings
- * (same K order per output element); tune key "gemm.x288": 0 never, 1 this rule (default), 2 always. */
+ * (same K order per output element); tune key "gemm.x288": 0 never (the shipped default: the tiling measured 3.5 % SLOWER on
+ * that launch — a K-tile's time grows with the number of busy CUs, so idle CUs are not lost time; gemm.hip), 1 this rule, 2 always. */
 int apexmi_gemm_uses_x288(int M, int N, int K);
 
 /* Up to 4 problems that share K in ONE launch (per-problem M, N and epilogue; gate/residual

@@ -732,7 +732,7 @@ def test_attention_backend_key_padding_masks():
 def gemm_x288():
     from apex_studio_amd import lib
     yield lambda v: lib.tune_set("gemm.x288", v)
-    lib.tune_set("gemm.x288", 1)
+    lib.tune_set("gemm.x288", 0)
 
 
 @pytest.mark.parametrize("M,N,K", [(4608, 3072, 15360), (4608, 3072, 256), (288, 192, 64), (289, 200, 128), (1000, 1040, 320),
@@ -786,25 +786,26 @@ def test_gemm_x288_grouped_and_race_screen(gemm_x288):
         assert torch.equal(ops.gemm(a, w), first), "non-deterministic result: LDS staging race"
 
 
-def test_gemm_x288_is_what_the_flux_proj_out_launch_runs():
-    """The auto rule (`gemm.x288 = 1`): the single block's proj_out (4608 x 3072 x 15360: 216 tiles of 256 x 256 = one round
-    with 40 CUs idle) goes out as 16 x 16 = 256 tiles of 288 x 192; launches that already fill their rounds (FF-up, QKV + MLP,
-    Wan's 23-round launches) stay on the 256 x 256 tiling; the result is the same bits either way."""
+def test_gemm_x288_auto_rule_and_shipped_default():
+    """`gemm.x288`: 0 (SHIPPED — the exact-fill tiling measured 3.5 % slower on the very launch it was built for,
+    profiles/r05_gemm_x288_ab.log) never uses it; 1 applies the rounds x tile-work rule: the single block's proj_out
+    (4608 x 3072 x 15360: 216 tiles of 256 x 256, or 16 x 16 = 256 of 288 x 192) yes; launches that already fill their rounds
+    (FF-up image stream, QKV + MLP, Wan's 23-round launches) no.  The result is the same bits either way."""
     from apex_studio_amd import lib
     ops = _ops()
     L = lib.load()
-    assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 1
-    assert L.apexmi_gemm_uses_x288(4096, 12288, 3072) == 0       # FF-up, image stream: 3 exact rounds already
-    assert L.apexmi_gemm_uses_x288(4608, 21504, 3072) == 0       # QKV + MLP-up: 5.9 rounds
-    assert L.apexmi_gemm_uses_x288(75600, 5120, 5120) == 0       # Wan: 23.1 rounds
-    assert L.apexmi_gemm_uses_x288(512, 3072, 3072) == 0         # under 1024 rows: the 128 x 128 tiling's business
+    assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 0, "shipped default: off"
     a = _bf(seeded((4608, 15360), 1)).to(DEV)
     w = _bf(seeded((3072, 15360), 2, scale=15360 ** -0.5)).to(DEV)
-    auto = ops.gemm(a, w)
-    lib.tune_set("gemm.x288", 0)
+    off = ops.gemm(a, w)
+    lib.tune_set("gemm.x288", 1)
     try:
-        assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 0
-        off = ops.gemm(a, w)
+        assert L.apexmi_gemm_uses_x288(4608, 3072, 15360) == 1
+        assert L.apexmi_gemm_uses_x288(4096, 12288, 3072) == 0       # FF-up, image stream: 3 exact rounds already
+        assert L.apexmi_gemm_uses_x288(4608, 21504, 3072) == 0       # QKV + MLP-up: 5.9 rounds
+        assert L.apexmi_gemm_uses_x288(75600, 5120, 5120) == 0       # Wan: 23.1 rounds
+        assert L.apexmi_gemm_uses_x288(512, 3072, 3072) == 0         # under 1024 rows: the 128 x 128 tiling's business
+        auto = ops.gemm(a, w)
     finally:
-        lib.tune_set("gemm.x288", 1)
+        lib.tune_set("gemm.x288", 0)
     assert torch.equal(auto, off)

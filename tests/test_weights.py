@@ -279,3 +279,82 @@ def test_lightx2v_keyed_lora_merges_like_its_peft_twin():
     assert len(changed) == 12 and all(".attn" in k or ".ffn" in k for k in changed), changed
     for k in twins[0]:
         assert torch.equal(twins[0][k], twins[1][k]), k
+
+
+@pytest.mark.gpu
+def test_fp8_resident_expert_runs_a_lightx2v_keyed_lora_at_run_time(tmp_path):
+    """the Wan-2.2 manifest ships fp8-scaled experts AND auto-applies lightning LoRAs
+    (R/manifest/video/wan-2.2-a14b-text-to-video-1.0.0.v1.yml:39-51, :108-116); the reference serves that pair at run time,
+    `base(x) + scale * B(A(x))` around FPScaledLinear (R/src/lora/manager.py:454-606, R/src/quantize/scaled_layer.py:496-549).
+    A keep_fp8 model has no bf16 weight to merge into: its block Linears get the adapters' factors attached to their fp8
+    records and `ops.gemm` applies them as one skinny GEMM + a K extended by the padded rank.  Checked against the oracle run
+    on dequantised + merged f32 weights, against the dequantise-at-load model (which merges), through a scale change, and
+    back to the plain fp8 forward bit for bit."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import lib, lora, ops, weights
+    from apex_studio_amd.wan import WanTransformer3DModel
+    from oracle import layers as OL, lora as OLR, wan as OWan
+    from tests.golden.seeded import seeded, spec_tensors
+    (pw, _), _, (cfg, _), _ = _original_files(tmp_path, fp8_all_block_linears=True)
+    a = WanTransformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    assert weights.load_checkpoint_into(a, [pw]) == ([], [])
+    b = WanTransformer3DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    assert weights.load_checkpoint_into(b, [pw], keep_fp8=True) == ([], [])
+    base_sd = {k: v.float().cpu() for k, v in a.state_dict().items()}
+    with pytest.raises(lib.ApexMIError, match="keep_fp8"):
+        b.state_dict()
+    r, spec = 4, {}
+    for i in range(2):
+        for at, n in (("self_attn", "q"), ("self_attn", "o"), ("cross_attn", "q"), ("cross_attn", "k"), ("cross_attn", "v")):
+            m = f"diffusion_model.blocks.{i}.{at}.{n}"
+            spec.update({m + ".lora_down.weight": (r, 128), m + ".lora_up.weight": (128, r), m + ".alpha": ()})
+        spec.update({f"diffusion_model.blocks.{i}.ffn.0.lora_down.weight": (r, 128), f"diffusion_model.blocks.{i}.ffn.0.lora_up.weight": (256, r),
+                     f"diffusion_model.blocks.{i}.ffn.2.lora_down.weight": (r, 256), f"diffusion_model.blocks.{i}.ffn.2.lora_up.weight": (128, r),
+                     f"diffusion_model.blocks.{i}.cross_attn.k.diff_b": (128,)})
+    raw = {k: (v * 0.3 if v.dim() == 2 else v) for k, v in spec_tensors(spec, 3100).items()}
+    x, txt, t = seeded((1, 16, 3, 16, 24), 41).to(torch.bfloat16), seeded((1, 20, 64), 42).to(torch.bfloat16), torch.tensor([537.0])
+
+    def fwd(m):
+        out = m(hidden_states=x.to(DEV), timestep=t.to(DEV), encoder_hidden_states=txt.to(DEV), return_dict=False)[0]
+        torch.cuda.synchronize()
+        return out.float().cpu()
+    plain = fwd(b)
+    assert torch.equal(plain, fwd(a))
+    a.load_lora_adapter({k: v.clone() for k, v in raw.items()}, adapter_name="lx")
+    b.load_lora_adapter({k: v.clone() for k, v in raw.items()}, adapter_name="lx")
+    assert b._lora_pad == 64 and b._fp8_bytes > 0
+    rec = b.blocks[0]._wkv2                                   # fused k | v record: two adapters, block-diagonal up factors
+    assert isinstance(rec, ops.Fp8Weight) and rec.lora_A.shape == (64, 128) and rec.lora_B.shape == (256, 64)
+    assert float(rec.lora_B[:128, r:].abs().max()) == 0 and float(rec.lora_B[128:, :r].abs().max()) == 0
+    assert float(rec.lora_A[2 * r:].abs().max()) == 0 and b.blocks[0]._wqkv.lora_A is not None
+    mods = lora.split_modules(lora.convert_lora_state_dict(raw, "wan.base", list(base_sd)))
+    assert len(mods) == 14 and "blocks.1.ffn.net.2" in mods
+
+    def oracle(scale):
+        orc = OWan.WanTransformer3DModel(**cfg).eval()
+        sd = dict(base_sd)
+        for m, d in mods.items():
+            sd[m + ".weight"] = OLR.merged_weight(sd[m + ".weight"], [(d["A"].float(), d["B"].float(), scale)])
+        orc.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            return orc(x.float(), t, txt.float(), policy=OL.BF16_STORAGE), orc(x.float(), t, txt.float())
+    rel = lambda u, v: float((u - v).norm() / v.norm())          # noqa: E731
+    for scale in (1.0, 0.5):
+        if scale != 1.0:
+            a.set_adapters("lx", scale)
+            b.set_adapters("lx", scale)
+        ref16, ref32 = oracle(scale)
+        got_b, got_a = fwd(b), fwd(a)
+        e_like, e_true, e_emul = rel(got_b, ref16), rel(got_b, ref32), rel(ref16, ref32)
+        print(f"[fp8 + run-time LoRA, scale {scale}] vs the bf16-storage oracle {e_like:.2e}, vs fp32 {e_true:.2e} (emulation "
+              f"{e_emul:.2e}); vs the dequantise-at-load model with MERGED weights {rel(got_b, got_a):.2e}; LoRA changed the output "
+              f"by {rel(got_b, plain):.2e}")
+        assert rel(got_b, plain) > 2e-2, "the adapter must matter for this test to mean anything"
+        assert e_like < 6e-3 and e_true < 2 * e_emul + 2e-3 and rel(got_b, got_a) < 6e-3
+        assert torch.equal(fwd(b), got_b), "deterministic"
+    b.disable_lora()
+    assert b._lora_pad == 0 and b.blocks[0]._wkv2.lora_A is None
+    assert torch.equal(fwd(b), plain), "without adapters the resident-fp8 forward is the plain one again, bit for bit"
+    b.enable_lora()
+    b.delete_adapters("lx")
+    assert torch.equal(fwd(b), plain) and b._lora_pad == 0

@@ -51,7 +51,7 @@ for M, N, K, epi in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             res[m].append(e0.elapsed_time(e1) / REPS * 1e3)
-    lib.tune_set("gemm.x288", 1)
+    lib.tune_set("gemm.x288", 0)
     fl = 2.0 * M * N * K
     med = {m: statistics.median(v) for m, v in res.items()}
     print(json.dumps({"shape": [M, N, K], "epilogue": epi, "auto_rule_picks_x288": bool(uses),
