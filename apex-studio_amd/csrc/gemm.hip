@@ -1747,6 +1747,7 @@ int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x2
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_x288 = 0;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never (SHIPPED: it measured slower, see the kernel's header) |
                       // 1 where it saves a round's worth of tile-work | 2 always (A/B, tests)
+int g_small_max = 112; // tune key gemm.small_max: launches of at most this many 256 x 256 tiles go out on the 128 x 128 tiling (0: never)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
 // stream-K workspace: 256 slabs of 256 x 256 f32 + 256 flags per (device, stream) — launches on different streams may overlap and
@@ -1890,6 +1891,21 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         }
         // large problems: 256x256 tiles, one per CU per round; otherwise the 128x128 tiling
         cfg = (mtot >= 1024 && nmax >= 1024 && G.K >= 256) ? g_large_cfg : 1;
+        // A launch that covers well under half of the CUs with 256 x 256 tiles (the 512^2 geometry: proj_out 1536 x 3072 = 72 tiles,
+        // FF-down 48 + 24) runs its K-loop on a few CUs at the per-CU floor of ~1.23 us per K-tile while the rest idle; four times
+        // as many 128 x 128 tiles (two workgroups per CU) finish sooner until ~118 tiles (profiles/r05_gemm_small_ab.log: 72 tiles
+        // K 15360 295 -> 213 us, 48 tiles K 12288 237 -> 160 us, 96 tiles 238 -> 192 us; 144 tiles 236 vs 342 us: stays).  Launches
+        // Gate / residual launches only (attention-out, FF-down, proj_out — the part-filled ones of the MM-DiT blocks): the
+        // bias-class projections keep the tiling whose sums the fused q/k/v epilogue reproduces bit for bit.
+        if (EPI == APEXMI_EPI_BIAS_GATE_RES && cfg == 7 && G.batch == 1 && g_small_max > 0) {
+            int64_t t256 = 0;
+            bool any_qkv = false;
+            for (int i = 0; i < G.count; ++i) {
+                t256 += (int64_t)((Ms[i] + 255) / 256) * ((G.p[i].N + 255) / 256);
+                any_qkv |= G.p[i].qkv != 0;
+            }
+            if (!any_qkv && t256 <= g_small_max) cfg = 1;
+        }
         // with a 24 KiB row stride (K = 12288, the MLP down-projection) the one-wave-per-SIMD kernel loses
         // 17-23 % to channel aliasing that the ping-pong schedules do not see
         if (cfg == 6 && G.K % 12288 == 0) cfg = 7;
@@ -2147,6 +2163,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.config")) g_force_cfg = value;
     else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
     else if (!strcmp(key, "gemm.x288")) g_x288 = value;
+    else if (!strcmp(key, "gemm.small_max")) g_small_max = value;
 #if APEXMI_GEMM_TRACE
     else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
     else if (!strcmp(key, "gemm.trace_hi")) g_gemm_trace = (g_gemm_trace & (uintptr_t)0xffffffffu) | ((uintptr_t)(uint32_t)value << 32);

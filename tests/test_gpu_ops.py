@@ -809,3 +809,26 @@ def test_gemm_x288_auto_rule_and_shipped_default():
     finally:
         lib.tune_set("gemm.x288", 0)
     assert torch.equal(auto, off)
+
+
+def test_gemm_small_gate_res_launches_use_the_128_tiling():
+    """`gemm.small_max` (round 5): a gate / residual launch of at most 112 tiles of 256 x 256 (the 512^2 geometry's proj_out,
+    attention-out, FF-down) goes out as 128 x 128 tiles; same result as the forced 256 x 256 launch to f32 summation order,
+    both within the usual bar of the fp32 reference; 144 tiles and more stay on 256 x 256 (bit-identical to forcing it)."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    for (M, N, K), small in (((1536, 3072, 1024), True), ((3072, 3072, 512), False)):
+        a, w, b = _bf(seeded((M, K), 1)).to(DEV), _bf(seeded((N, K), 2, scale=K ** -0.5)).to(DEV), _bf(seeded((N,), 3)).to(DEV)
+        gate, r = seeded((N,), 4).to(DEV), _bf(seeded((M, N), 5)).to(DEV)
+        ref = r.float() + gate * (a.float() @ w.float().T + b.float())
+        auto = ops.gemm(a, w, b, epilogue="gate_res", gate=gate, residual=r)
+        lib.tune_set("gemm.small_max", 0)
+        try:
+            big = ops.gemm(a, w, b, epilogue="gate_res", gate=gate, residual=r)
+        finally:
+            lib.tune_set("gemm.small_max", 112)
+        _check(auto, ref, 3e-3, f"small rule {M}x{N}")
+        _check(big, ref, 3e-3, f"256x256 {M}x{N}")
+        assert torch.equal(auto, big) != small or _rel(auto, big) < 1e-3, "the rule must (not) have changed the tiling"
+        if not small:
+            assert torch.equal(auto, big)

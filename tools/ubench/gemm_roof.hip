@@ -13,6 +13,12 @@
 //          tiles per XCD sharing panels through its L2)
 // MODE 5   the same tile walk with both operands PACKED tile-major (a piece = 1 KiB contiguous, the 32 pieces of a tile's K-tile
 //          adjacent): what pre-packing the weights / writing the activations in tile order would buy
+// MODE 6   MODE 4 with the WEIGHT operand staged as fp8 (the in-loop form of the fp8-scaled Wan experts,
+//          R/src/quantize/scaled_layer.py:496-549): a weight piece = 16 rows x 64 B, 2 per wave and K-tile instead of 4 (48 KiB staged
+//          per K-tile instead of 64), weight fragments read as ds_read_b64 and converted in registers — v_cvt_pk_f32_fp8 x 4,
+//          v_pk_mul_f32 x 4 (x the row's scale), v_cvt_pk_bf16_f32 x 4 per fragment: bit-identical to weight.to(bf16) * scale —
+//          feeding the same MFMAs
+// MODE 7   MODE 6 without the conversion arithmetic (raw bytes reinterpreted): what the staging alone buys
 // Output per mode: TFLOP/s, effective shader clock (s_memtime cycles / s_memrealtime 100 MHz ticks), cycles per K-tile.
 // Build: hipcc --offload-arch=gfx950 -O3 -o gemm_roof gemm_roof.hip
 #include <hip/hip_runtime.h>
@@ -55,6 +61,9 @@ __global__ __launch_bounds__(512, 1) void k(const char* src, size_t region, floa
     }
     f32x4 acc[32];
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    const float ws_ = 0.5f + 0.001f * (float)(lane & 15);     // the lane's row scale (one weight row per lane of a fragment)
+    const f32x2_ wscale = {ws_, ws_};
     const char* gsrc = src + (MODE == 3 ? (size_t)blockIdx.x * region : 0) + (size_t)wave * 1024 + (lane >> 3) * 128 + (lane & 7) * 16;
     // MODE 4 / 5: A [4608 x 3072] at src, W [21504 x 3072] at src + 32 MiB; 18 x 84 tiles of 256 x 256, 48 K-tiles each
     constexpr int NM = 18, NN = 84, NKT = 48, TILES = NM * NN;
@@ -76,10 +85,55 @@ __global__ __launch_bounds__(512, 1) void k(const char* src, size_t region, floa
                 for (int j = 0; j < 4; ++j)
                     fa[nxt][((ph >> 1) & 1) * 4 + j] = *(const bf16x8*)(pa[(ph >> 1) & 1] + ((ph * 4 + j) & 7) * 2048);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    fw[nxt][((ph >> 1) & 1) * 2 + j] = *(const bf16x8*)(pw[(ph >> 1) & 1] + ((ph * 2 + j) & 3) * 2048);
+                for (int j = 0; j < 2; ++j) {
+                    if (MODE >= 6) {                // fp8 weight image: 64-byte rows, the lane's 8 values = one ds_read_b64
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        typedef __attribute__((ext_vector_type(2))) float f32x2;
+                        // row r of the fp8 image at r * 64; 8-byte chunk (4 ks + g4) ^ (((r >> 2) & 3) << 1): the 32 lanes of a ds_read_b64
+                        // group (16 rows x 2 chunks) then cover 32 distinct bank pairs — conflict-free
+                        const u32x2 raw = *(const u32x2*)(smem + 32768 + (wn * 64 + ((ph * 2 + j) & 3) * 16 + l15) * 64 +
+                                                          ((((((ph >> 1) & 1) * 4) + g4) ^ (((l15 >> 2) & 3) << 1)) << 3));
+                        bf16x8 o;
+                        if (MODE == 6) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[h], false);
+                                f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[h], true);
+                                lo = lo * wscale;
+                                hi = hi * wscale;
+                                o[4 * h + 0] = (__bf16)lo[0];
+                                o[4 * h + 1] = (__bf16)lo[1];
+                                o[4 * h + 2] = (__bf16)hi[0];
+                                o[4 * h + 3] = (__bf16)hi[1];
+                            }
+                        } else {
+                            u32x4 z = {raw[0], raw[1], raw[0] ^ 0x01010101u, raw[1] ^ 0x02020202u};
+                            o = __builtin_bit_cast(bf16x8, z);
+                        }
+                        fw[nxt][((ph >> 1) & 1) * 2 + j] = o;
+                    } else {
+                        fw[nxt][((ph >> 1) & 1) * 2 + j] = *(const bf16x8*)(pw[(ph >> 1) & 1] + ((ph * 2 + j) & 3) * 2048);
+                    }
+                }
             }
-            if (MODE >= 4) {                        // 2 of the 8 pieces per phase: pieces 0..3 of this wave = activation rows, 4..7 = weight rows
+            if (MODE >= 6) {                        // 6 pieces per K-tile: 4 activation (bf16, 8 rows x 128 B), 2 weight (fp8, 16 rows x 64 B)
+                const int kt = it % NKT, round = it / NKT;
+                int sidx = (int)(blockIdx.x & 7) * (TILES / 8) + (int)(blockIdx.x >> 3) + 32 * round;
+                sidx %= TILES;
+                const int width = 6 * NN, first_m = (sidx / width) * 6, pm = first_m + (sidx % width) % 6, pn = (sidx % width) / 6;
+                {
+                    const int piece = ph * 8 + wave;                            // 0..31
+                    const char* g = abase + ((size_t)(pm * 256 + piece * 8 + (lane >> 3)) * 6144) + kt * 128 + (lane & 7) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(ddst + ph * 8192), 16, 0, 0);
+                }
+                if ((ph & 1) == 0) {
+                    const int piece = (ph >> 1) * 8 + wave;                     // 0..15: 16 rows of 64 B each
+                    const char* g = wbase + ((size_t)(pn * 256 + piece * 16 + (lane >> 2)) * 3072) + kt * 64 + (lane & 3) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(ddst + 32768 + (ph >> 1) * 8192), 16, 0, 0);
+                }
+            } else if (MODE >= 4) {                 // 2 of the 8 pieces per phase: pieces 0..3 of this wave = activation rows, 4..7 = weight rows
                 const int kt = it % NKT, round = it / NKT;
                 int sidx = (int)(blockIdx.x & 7) * (TILES / 8) + (int)(blockIdx.x >> 3) + 32 * round;
                 sidx %= TILES;
@@ -177,5 +231,10 @@ int main(int argc, char** argv) {
     run<3>("+ 8 LDS-DMA pieces per 64 MFMA, private 8 MiB regions (MALL/HBM)", src, region, out, clk, launches);
     run<4>("+ 8 LDS-DMA pieces per 64 MFMA, the QKV+MLP GEMM's row-major addressing (8 rows x 128 B pieces)", src, region, out, clk, launches);
     run<5>("+ 8 LDS-DMA pieces per 64 MFMA, the same tile walk on tile-major packed operands (1 KiB contiguous pieces)", src, region, out, clk, launches);
+    run<4>("(again) row-major bf16 operands, 8 pieces per 64 MFMA", src, region, out, clk, launches);
+    run<6>("fp8 WEIGHT pieces (6 pieces per 64 MFMA: 48 KiB per K-tile), fragments converted in registers (cvt + x scale + bf16 round)", src, region, out, clk, launches);
+    run<7>("fp8 WEIGHT pieces, NO conversion arithmetic (staging effect alone)", src, region, out, clk, launches);
+    run<4>("(again) row-major bf16 operands, 8 pieces per 64 MFMA", src, region, out, clk, launches);
+    run<6>("(again) fp8 WEIGHT pieces + in-register conversion", src, region, out, clk, launches);
     return 0;
 }
