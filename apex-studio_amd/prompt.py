@@ -34,6 +34,9 @@ def split_ids(ids: Ids) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     return ids, None
 
 
+_ftfy_warned = False
+
+
 def prompt_clean(text: str, lower_case: bool = False) -> str:
     """`TextEncoder.prompt_clean` (R/src/text_encoder/text_encoder.py:117-131): ftfy repair (when the package is present — it is
     a pure-Python text fixer with no effect on clean ASCII), HTML entities unescaped twice, whitespace runs collapsed, stripped."""
@@ -43,7 +46,15 @@ def prompt_clean(text: str, lower_case: bool = False) -> str:
         import ftfy
         text = ftfy.fix_text(text)
     except ImportError:
-        pass
+        # ftfy only ever changes non-ASCII text (mojibake, odd quotes, full-width forms): there the reference would have tokenised a
+        # repaired string, so say so once instead of silently diverging; clean ASCII prompts are untouched either way
+        global _ftfy_warned
+        if not _ftfy_warned and not text.isascii():
+            import warnings
+            warnings.warn("apex_studio_amd.prompt: the `ftfy` package is not installed; the reference repairs non-ASCII prompt text "
+                          "with ftfy.fix_text before tokenising (R/src/text_encoder/text_encoder.py:117-131) — this prompt contains "
+                          "non-ASCII characters and is tokenised unrepaired", RuntimeWarning, stacklevel=2)
+            _ftfy_warned = True
     text = html.unescape(html.unescape(text)).strip()
     text = re.sub(r"\s+", " ", text).strip()
     return text.lower() if lower_case else text

@@ -117,3 +117,29 @@ def test_engines_encode_prompt_ids_before_the_loop():
     with pytest.raises(ValueError, match="per tokenizer"):
         FluxT2IEngine(SimpleNamespace(config=SimpleNamespace(in_channels=64), device=torch.device("cpu"), dtype=torch.float32),
                       text_encoder=_FakeEncoder(), text_encoder_2=_FakeEncoder()).encode_prompt(prompt_ids=ids)
+
+
+def test_prompt_clean_entities_whitespace_and_the_ftfy_notice():
+    """`prompt_clean` (R/src/text_encoder/text_encoder.py:117-131): HTML entities unescaped twice, whitespace runs collapsed,
+    stripped; ftfy is absent in this image — ASCII prompts are unaffected by that, a non-ASCII prompt gets ONE warning that the
+    reference would have repaired it before tokenising."""
+    import warnings
+    from apex_studio_amd import prompt as P
+    assert P.prompt_clean("  a &amp;amp; b \n\t c&lt;d  ") == "a & b c<d"
+    assert P.prompt_clean("Hello  World", lower_case=True) == "hello world"
+    try:
+        import ftfy  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    P._ftfy_warned = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        P.prompt_clean("plain ascii prompt")
+        assert not w
+        out = P.prompt_clean("cafÃ© au lait")
+        P.prompt_clean("naïve again")
+    if have:
+        assert out == "café au lait" and not w
+    else:
+        assert out == "cafÃ© au lait" and len(w) == 1 and "ftfy" in str(w[0].message)
