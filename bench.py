@@ -112,12 +112,35 @@ def cpu_info():
             "logical_cpus": logical or (os.cpu_count() or 1)}
 
 
+def best_threads(fn, budget_s=25.0):
+    """The thread count the CPU baseline runs at: all logical CPUs is NOT the fastest on a 2-socket SMT host (oversubscribed
+    oneDNN / OpenMP teams: the 256-thread run of r4 was several times slower than 64 threads).  `fn()` = one bounded piece of
+    the workload; tried at {physical cores, half of them, a quarter, logical CPUs} until the budget is spent; returns
+    (threads, {threads: seconds})."""
+    info = cpu_info()
+    logical = os.cpu_count() or 1
+    phys = info["physical_cores"] or logical
+    cands = []
+    for c in (phys, max(phys // 2, 1), max(phys // 4, 1), logical):
+        if 1 <= c <= logical and c not in cands:
+            cands.append(c)
+    seen, t_start = {}, time.perf_counter()
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
+        fn()
+        seen[c] = time.perf_counter() - t0
+        if time.perf_counter() - t_start > budget_s:
+            break
+    best = min(seen, key=seen.get)
+    torch.set_num_threads(best)
+    return best, seen
+
+
 def cpu_baseline(s_img=None, side=64):
     """Oracle on host cores: one double + one single block at full width and sequence, fp32."""
     from oracle import flux as OF
     from oracle import layers as OL
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     dim, H = 3072, 24
     S_IMG = s_img or globals()["S_IMG"]
     g = torch.Generator().manual_seed(0)
@@ -129,6 +152,7 @@ def cpu_baseline(s_img=None, side=64):
     dbl = OF.FluxTransformerBlock(dim, H, 128).eval()
     sgl = OF.FluxSingleTransformerBlock(dim, H, 128).eval()
     with torch.no_grad():
+        ncores, sweep = best_threads(lambda: sgl(x, ctx, temb, rope, OL.FP32))
         t0 = time.perf_counter()
         dbl(x, ctx, temb, rope, OL.FP32)
         t1 = time.perf_counter()
@@ -139,7 +163,8 @@ def cpu_baseline(s_img=None, side=64):
         "value": 1.0 / t_step, "unit": "steps/s", "cores": ncores, "kind": "port", **cpu_info(),
         "sample": (f"oracle fp32 (PyTorch CPU restatement of the reference path), 1 double block "
                    f"({t1 - t0:.2f} s) + 1 single block ({t2 - t1:.2f} s) at full width 3072 / S={S_IMG + S_TXT}, "
-                   f"extrapolated x19 / x38; embedders and final layer (<0.1% of FLOPs) excluded"),
+                   f"extrapolated x19 / x38; embedders and final layer (<0.1% of FLOPs) excluded; torch threads = {ncores}, the "
+                   f"fastest of the single-block sweep {({k: round(v, 2) for k, v in sweep.items()})} s"),
     }
 
 
@@ -152,30 +177,26 @@ def cpu_baseline_qwen():
     """Oracle QwenImage block (fp32) at full width on a shortened sequence, scaled to the step by algorithmic FLOPs."""
     from oracle import qwenimage as OQ
     from oracle import layers as OL
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     dim, H, s_img, s_txt = 3072, 24, 4096, 256
     g = torch.Generator().manual_seed(0)
     blk = OQ.QwenImageTransformerBlock(dim, H, 128).eval()
     img, txt, temb = torch.randn(1, s_img, dim, generator=g), torch.randn(1, s_txt, dim, generator=g), torch.randn(1, dim, generator=g)
     rope = OQ.qwen_rope_table(OQ.qwen_rope_positions([(1, 64, 64)], s_txt), (16, 56, 56))
     with torch.no_grad():
-        t0 = time.perf_counter()
-        blk(img, txt, temb, rope, OL.FP32)
-        dt = time.perf_counter() - t0
+        ncores, sweep = best_threads(lambda: blk(img, txt, temb, rope, OL.FP32))
+        dt = sweep[ncores]
     S = s_img + s_txt
     flops = 2.0 * S * 12 * dim * dim + 4.0 * S * S * dim
     return _cpu_rate(flops, dt, STEP_TFLOP["qwen"], ncores,
                      f"oracle fp32 QwenImage block at full width 3072, S = {s_img} + {s_txt} tokens ({dt:.2f} s, "
-                     f"{flops / 1e12:.2f} TFLOP); steps/s = sustained FLOP/s / {STEP_TFLOP['qwen']} TFLOP per step")
+                     f"{flops / 1e12:.2f} TFLOP); steps/s = sustained FLOP/s / {STEP_TFLOP['qwen']} TFLOP per step; torch threads = {ncores}, the "
+                     f"fastest of {({k: round(v, 2) for k, v in sweep.items()})} s")
 
 
 def cpu_baseline_wan():
     """Oracle Wan block (fp32) at full width on a shortened clip, scaled to the step by algorithmic FLOPs."""
     from oracle import wan as OW
     from oracle import layers as OL
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     dim, H, ffn, s_txt, grid = 5120, 40, 13824, 512, (3, 30, 52)
     S = grid[0] * grid[1] * grid[2]
     g = torch.Generator().manual_seed(0)
@@ -184,14 +205,14 @@ def cpu_baseline_wan():
     temb6 = torch.randn(1, 6, dim, generator=g)
     rope = OW.wan_rope_table(grid, 128)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        blk(x, ctx, temb6, rope, OL.FP32)
-        dt = time.perf_counter() - t0
+        ncores, sweep = best_threads(lambda: blk(x, ctx, temb6, rope, OL.FP32))
+        dt = sweep[ncores]
     flops = 2.0 * S * (6 * dim * dim + 2 * dim * ffn) + 2.0 * s_txt * 2 * dim * dim + 4.0 * S * S * dim + 4.0 * S * s_txt * dim
     return _cpu_rate(flops, dt, STEP_TFLOP["wan"], ncores,
                      f"oracle fp32 Wan block at full width 5120 / ffn 13824 on a {grid} latent grid (S = {S}) + {s_txt} "
                      f"text tokens ({dt:.2f} s, {flops / 1e12:.2f} TFLOP); steps/s = sustained FLOP/s / "
-                     f"{STEP_TFLOP['wan']} TFLOP per expert forward")
+                     f"{STEP_TFLOP['wan']} TFLOP per expert forward; torch threads = {ncores}, the fastest of "
+                     f"{({k: round(v, 2) for k, v in sweep.items()})} s")
 
 
 def pmc_traffic(src_file, suffix):
