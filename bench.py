@@ -114,14 +114,14 @@ def cpu_info():
 
 def best_threads(fn, budget_s=25.0):
     """The thread count the CPU baseline runs at: all logical CPUs is NOT the fastest on a 2-socket SMT host (oversubscribed
-    oneDNN / OpenMP teams: the 256-thread run of r4 was several times slower than 64 threads).  `fn()` = one bounded piece of
-    the workload; tried at {physical cores, half of them, a quarter, logical CPUs} until the budget is spent; returns
+    oneDNN / OpenMP teams: the 256-thread run of r4 was 5-6 x slower than 32 threads on 2 x EPYC 9575F).  `fn()` = one bounded piece
+    of the workload; tried at {1/4, 1/8, 1/2, all of the physical cores, logical CPUs} until the budget is spent; returns
     (threads, {threads: seconds})."""
     info = cpu_info()
     logical = os.cpu_count() or 1
     phys = info["physical_cores"] or logical
     cands = []
-    for c in (phys, max(phys // 2, 1), max(phys // 4, 1), logical):
+    for c in (max(phys // 4, 1), max(phys // 8, 1), max(phys // 2, 1), phys, logical):
         if 1 <= c <= logical and c not in cands:
             cands.append(c)
     seen, t_start = {}, time.perf_counter()
