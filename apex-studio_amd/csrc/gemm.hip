@@ -1736,6 +1736,231 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x288_kernel(const GemmGroup 
     }
 }
 
+// ---- 384 x 256 tile: FEWER STAGED BYTES PER FLOP (round 5) ----------------------------------------------------------------------
+// The shipped 256 x 256 launch is bound by L2 -> LDS staging, not by its MFMAs (see the 288 x 192 kernel's header: a K-tile takes
+// 1.23 us on a lightly loaded chip and 1.53 us with all 256 CUs busy, ~11 TB/s in aggregate, while its MFMAs need 1.0 us), and the
+// time per flop of the two tilings measured so far is proportional to their staged bytes per flop (1.10 x for 1.11 x).  A 384 x 256
+// tile stages (384 + 256) x 128 B per 2 x 384 x 256 x 64 flops: 0.833 of the 256 x 256 tile's bytes per flop.  What it costs:
+//   * 192 accumulator registers per lane (8 waves of 192 x 64 = 12 x 4 tiles of 16 x 16) of the 256 a wave has at two waves per
+//     SIMD, so everything else is lean: fragments single-buffered per k-step (6 activation + 4 weight reads feed 24 MFMAs), the
+//     LDS-DMA pieces addressed through two buffer descriptors with ONE per-lane offset each (a wave only takes pieces of its own
+//     row parity, so the source swizzle is the same for all of them) and scalar piece / K offsets; rows past M / N fall outside
+//     the descriptor's range and read as zero (no clamping);
+//   * the whole LDS of a CU: 2 x (48 + 32) KiB.
+// Schedule: the ping-pong of the shipped kernel — the two M-halves of the block one barrier apart, every SIMD with one wave in its
+// MFMA segment and one in its LDS / DMA segment — with four phases per K-tile = (k-step, m-half): 24 MFMAs each; a wave's 10 pieces
+// of the NEXT K-tile go out 3 + 3 + 2 + 2 over the phases: 4 weight + 3 activation pieces of m-half 0 first (what the next phase 0
+// reads), then the 3 of m-half 1 (phase 1), behind counted vmcnt(3) waits.
+// Same K order per output element as the other tilings: results are BIT-IDENTICAL to the 256 x 256 launch.
+constexpr int YBM = 384, YBN = 256;
+constexpr int Y_A_BYTES = YBM * BK * 2, Y_W_BYTES = YBN * BK * 2, Y_STAGE = Y_A_BYTES + Y_W_BYTES, Y_LDS = 2 * Y_STAGE;
+
+template <int EPI, int DIST = 1>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;      // waves w and w + 4 share a SIMD: same column strip, the other M-half
+
+    int s = xcd_remap(blockIdx.x, G.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUPS; ++i)
+        if (i < G.count && s >= G.p[i].tile0) gi = i;
+    const GemmProblem P = G.p[gi];
+    s -= P.tile0;
+    const int nn = P.nn, N = P.N, M = P.M;
+    const int GM = G.group_m;
+    const int width = GM * nn;
+    const int first_m = (s / width) * GM;
+    const int gsz = min(P.nm - first_m, GM);
+    const int pm = first_m + (s % width) % gsz;
+    const int pn = (s % width) / gsz;
+    const int m0 = pm * YBM, n0 = pn * YBN;
+
+    // ---- LDS-DMA: two buffer descriptors, one per-lane offset each, scalar piece offsets ----
+    const int rows_a = min(M - m0, YBM), rows_w = min(N - n0, YBN);
+    auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (int64_t)m0 * P.lda), 0,
+                                                    (int)(((int64_t)(rows_a - 1) * P.lda + G.K) * 2), 0x00020000);
+    auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (int64_t)n0 * P.ldw), 0,
+                                                    (int)(((int64_t)(rows_w - 1) * P.ldw + G.K) * 2), 0x00020000);
+    // a wave takes pieces (8 rows each) of ONE parity: (row >> 1) & 7 = 4 (piece & 1) + (lane >> 4) for every one of them
+    const int par = wave & 1, widx = wave >> 1;
+    const int sw_src = ((lane & 7) ^ (4 * par + (lane >> 4))) * 16;
+    const int voff_a = (lane >> 3) * (int)P.lda * 2 + sw_src;
+    const int voff_w = (lane >> 3) * (int)P.ldw * 2 + sw_src;
+    const int lda8 = (int)P.lda * 16, ldw8 = (int)P.ldw * 16;         // bytes per 8-row piece step
+    // piece j of the wave: 0..3 weight pieces, 4..6 activation pieces of m-half 0 (rows 0..95 and 192..287), 7..9 of m-half 1
+    auto piece_of = [&](int j) -> int {
+        if (j < 4) return 2 * (4 * j + widx) + par;
+        const int e = 3 * widx + (j < 7 ? j - 4 : j - 7);            // 0..11 within the parity's list
+        return (e < 6 ? 0 : 24) + (j < 7 ? 0 : 12) + 2 * (e % 6) + par;
+    };
+    auto stage = [&](int buf, int kt, int j) {
+        const int pc = piece_of(j);
+        char* dst = smem + buf * Y_STAGE + (j < 4 ? Y_A_BYTES : 0) + pc * 1024;
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)dst, 16, voff_w, pc * ldw8 + kt * (BK * 2), 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)dst, 16, voff_a, pc * lda8 + kt * (BK * 2), 0, 0);
+    };
+
+    f32x4_t acc[4][12];                           // [16-column n-tile][16-row m-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = G.K / BK;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (G.clk != nullptr) {
+        clk_c0 = __builtin_readcyclecounter();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int sw16 = (l15 >> 1) & 7;
+    const int a_base = (wm * 192 + l15) * 128, w_base = Y_A_BYTES + (wn * 64 + l15) * 128;
+    const int ch16[2] = {((0 + g4) ^ sw16) << 4, ((4 + g4) ^ sw16) << 4};
+    bf16x8 af[6], wf[4];
+    auto rd_a = [&](const char* St, int h, int ks) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) af[t] = *(const bf16x8*)(St + a_base + (h * 6 + t) * 2048 + ch16[ks]);
+    };
+    auto rd_w = [&](const char* St, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *(const bf16x8*)(St + w_base + t * 2048 + ch16[ks]);
+    };
+    auto mma = [&](int h) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[nt][h * 6 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[nt][h * 6 + t], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define Y_SYNC()                                                                    \
+    do {                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        __builtin_amdgcn_s_barrier();                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#define Y_BAR()                                \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#define Y_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#pragma unroll
+    for (int j = 0; j < 10; ++j) stage(0, 0, j);
+    Y_VMCNT(0);
+    Y_BAR();
+    if (wm == 1) Y_BAR();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* St = smem + (kt & 1) * Y_STAGE;
+        const bool more = kt + 1 < nkt;
+        const int nb = (kt + 1) & 1;
+        // The wave's 10 pieces of the next K-tile go out over the four phases as 2 + 3 + 2 + 3 (DIST 1: the phases that read 10
+        // fragments issue two pieces, those that read 6 issue three) or 3 + 3 + 2 + 2 (DIST 0).  A wave's wait covers what the NEXT
+        // phase reads: phase 0 -> m-half 1 of THIS K-tile (its pieces 7..9, issued during the previous K-tile), phase 3 -> the
+        // weights and m-half 0 of the next one (pieces 0..6: 7..9 may fly).
+        // phase 0: k-step 0, m-half 0
+        rd_w(St, 0);
+        rd_a(St, 0, 0);
+        if (more) {
+            stage(nb, kt + 1, 0);
+            stage(nb, kt + 1, 1);
+            if (DIST == 0) {
+                stage(nb, kt + 1, 2);
+                Y_VMCNT(3);
+            } else {
+                Y_VMCNT(2);
+            }
+        } else {
+            Y_VMCNT(0);
+        }
+        Y_SYNC();
+        mma(0);
+        Y_BAR();
+        // phase 1: k-step 0, m-half 1
+        rd_a(St, 1, 0);
+        if (more) {
+            if (DIST != 0) stage(nb, kt + 1, 2);
+            stage(nb, kt + 1, 3);
+            stage(nb, kt + 1, 4);
+            if (DIST == 0) stage(nb, kt + 1, 5);
+        }
+        Y_SYNC();
+        mma(1);
+        Y_BAR();
+        // phase 2: k-step 1, m-half 0
+        rd_w(St, 1);
+        rd_a(St, 0, 1);
+        if (more) {
+            if (DIST != 0) stage(nb, kt + 1, 5);
+            stage(nb, kt + 1, 6);
+            if (DIST == 0) stage(nb, kt + 1, 7);
+        }
+        Y_SYNC();
+        mma(0);
+        Y_BAR();
+        // phase 3: k-step 1, m-half 1
+        rd_a(St, 1, 1);
+        if (more) {
+            if (DIST != 0) stage(nb, kt + 1, 7);
+            stage(nb, kt + 1, 8);
+            stage(nb, kt + 1, 9);
+            Y_VMCNT(3);
+        }
+        Y_SYNC();
+        mma(1);
+        Y_BAR();
+    }
+    if (wm == 0) Y_BAR();
+#undef Y_VMCNT
+#undef Y_SYNC
+#undef Y_BAR
+
+    if (G.clk != nullptr) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(G.clk, c1 - clk_c0);
+            atomicAdd(G.clk + 1, r1 - clk_r0);
+        }
+    }
+
+    // ---- epilogue: per 32-column slab and a few m-tiles at a time (the accumulators leave 64 registers for everything else) ----
+    constexpr int MTC = EPI == APEXMI_EPI_BIAS_GATE_RES ? 3 : 6;      // m-tiles per call (gate / residual also holds the residual rows)
+#pragma unroll
+    for (int h = 0; h < 12 / MTC; ++h) {
+        int mrow[MTC];
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+            mrow[mt] = m0 + wm * 192 + (h * MTC + mt) * 16 + l15;
+            if (mrow[mt] >= M) mrow[mt] = -1;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int nbase = n0 + wn * 64 + p * 32;
+            const f32x4_t(&x)[MTC] = *(const f32x4_t(*)[MTC]) & acc[2 * p][h * MTC];
+            const f32x4_t(&y)[MTC] = *(const f32x4_t(*)[MTC]) & acc[2 * p + 1][h * MTC];
+            if constexpr (EPI == APEXMI_EPI_BIAS_GATE_RES) {
+                u32x4 rr[MTC];
+                const int nst = nbase + 16 * (g4 & 1) + 8 * (g4 >> 1);
+#pragma unroll
+                for (int mt = 0; mt < MTC; ++mt) rr[mt] = *(const u32x4*)(P.R + (int64_t)max(mrow[mt], 0) * P.ldr + min(nst, N - 8));
+                store_slab16<EPI, MTC, 0>(x, y, P, N, mrow, nbase, g4, rr);
+            } else {
+                APEXMI_ACT_DISPATCH(P.gelu, store_slab16<EPI, MTC, ACT>(x, y, P, N, mrow, nbase, g4));
+            }
+        }
+    }
+}
+
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 #if APEXMI_GEMM_TRACE
 uintptr_t g_gemm_trace = 0;
@@ -1747,6 +1972,8 @@ int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x2
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_x288 = 0;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never (SHIPPED: it measured slower, see the kernel's header) |
                       // 1 where it saves a round's worth of tile-work | 2 always (A/B, tests)
+int g_x384_dist = -1; // tune key gemm.x384_dist: how a wave's 10 pieces are spread over the 4 phases (0: 3+3+2+2, 1: 2+3+2+3, -1: by launch size)
+int g_x384 = 1;       // tune key gemm.x384: the 384 x 256 tiling — 0 never | 1 where its staged bytes win (x384_pays; SHIPPED) | 2 always (A/B, tests)
 int g_small_max = 112; // tune key gemm.small_max: launches of at most this many 256 x 256 tiles go out on the 128 x 128 tiling (0: never)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
 
@@ -1848,6 +2075,33 @@ int launch_x288(GemmGroup& G, const int* Ms, hipStream_t stream) {
     return apexmi_check_launch("gemm_bf16 (288x192)");
 }
 
+template <int EPI>
+int launch_x384(GemmGroup& G, const int* Ms, hipStream_t stream) {
+    static uint64_t attr_set = 0;
+    APEXMI_SET_ATTR_ONCE(attr_set,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS));
+    int t = 0;
+    for (int i = 0; i < G.count; ++i) {
+        G.p[i].M = Ms[i];
+        G.p[i].nm = (Ms[i] + YBM - 1) / YBM;
+        G.p[i].nn = (G.p[i].N + YBN - 1) / YBN;
+        G.p[i].tile0 = t;
+        t += G.p[i].nm * G.p[i].nn;
+    }
+    G.total = t;
+    G.group_m = g_group_m;
+    G.clk = apexmi_clk_ptr();
+    G.wpacked = 0;
+    G.sk_r = G.sk_tfull = 0;
+    G.sk_slab = nullptr;
+    G.sk_flag = nullptr;
+    const int dist = g_x384_dist >= 0 ? g_x384_dist : (t >= 2048 ? 0 : 1);     // measured: 3+3+2+2 +1 % on Wan's launches, 2+3+2+3 +1..2 % on Flux's
+    if (dist == 0) hipLaunchKernelGGL((gemm_bf16_x384_kernel<EPI, 0>), dim3(t, 1), dim3(512), Y_LDS, stream, G);
+    else hipLaunchKernelGGL((gemm_bf16_x384_kernel<EPI, 1>), dim3(t, 1), dim3(512), Y_LDS, stream, G);
+    return apexmi_check_launch("gemm_bf16 (384x256)");
+}
+
 // Does the 288 x 192 tiling finish this launch in less tile-work than 256 x 256?  Cost = rounds of 256 concurrent tiles x work per
 // tile (a 288 x 192 tile stages 11 % more bytes per flop: priced at +4 %); it has to win by 5 %.
 inline bool x288_pays(const GemmGroup& G, const int* Ms) {
@@ -1876,11 +2130,34 @@ inline bool use_x288(const GemmGroup& G, const int* Ms) {
     return G.K >= 256 && mtot >= 1024 && nmax >= 1024 && x288_pays(G, Ms);
 }
 
+// The 384 x 256 tiling pays where the launch is bound by the chip's aggregate staging rate — several FULL rounds of tiles — and
+// loses where tiles are few (a K-tile costs a CU 1.78 us at best against 1.23 us): every problem's row tiles nearly full (<= 1.5 %
+// of padding rows), at least three rounds of 256 tiles, and a last round that is full, mostly full, or one of many
+// (profiles/r05_gemm_x384_ab*.log: 4608 x 21504 +8..10 %, 4608 x 9216 +9..10 %, Wan's 75 600-row launches +3..7 %; 2.25 rounds -3 %,
+// part-filled single rounds -22 %).
+inline bool x384_pays(const GemmGroup& G, const int* Ms) {
+    int64_t t = 0;
+    for (int i = 0; i < G.count; ++i) {
+        const int64_t nm = (Ms[i] + YBM - 1) / YBM;
+        if ((nm * YBM - Ms[i]) * 200 > 3 * (int64_t)Ms[i]) return false;
+        t += nm * ((G.p[i].N + YBN - 1) / YBN);
+    }
+    const int64_t rem = t % 256;
+    return t >= 3 * 256 && (rem == 0 || rem >= 154 || t >= 8 * 256);
+}
+inline bool use_x384(const GemmGroup& G, const int* Ms) {
+    if (g_x384 == 0 || G.batch != 1 || G.K % BK != 0 || !(g_force_cfg == 0 || g_force_cfg == 7) || g_large_cfg != 7) return false;
+    for (int i = 0; i < G.count; ++i)
+        if (G.p[i].qkv || G.p[i].lda > (1 << 26) || G.p[i].ldw > (1 << 26)) return false;
+    return g_x384 == 2 || x384_pays(G, Ms);
+}
+
 template <int EPI>
 int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
     int cfg = g_force_cfg;
     if constexpr (EPI == APEXMI_EPI_BIAS || EPI == APEXMI_EPI_BIAS_GATE_RES) {
         if (use_x288(G, Ms)) return launch_x288<EPI>(G, Ms, stream);
+        if (use_x384(G, Ms)) return launch_x384<EPI>(G, Ms, stream);
     }
     if (cfg == 0) {
         int64_t mtot = 0;
@@ -2164,6 +2441,8 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.wpacked")) g_wpacked = value;
     else if (!strcmp(key, "gemm.x288")) g_x288 = value;
     else if (!strcmp(key, "gemm.small_max")) g_small_max = value;
+    else if (!strcmp(key, "gemm.x384")) g_x384 = value;
+    else if (!strcmp(key, "gemm.x384_dist")) g_x384_dist = value;
 #if APEXMI_GEMM_TRACE
     else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
     else if (!strcmp(key, "gemm.trace_hi")) g_gemm_trace = (g_gemm_trace & (uintptr_t)0xffffffffu) | ((uintptr_t)(uint32_t)value << 32);

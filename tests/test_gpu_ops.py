@@ -873,3 +873,63 @@ def test_gemm_epilogue_activations_on_every_bf16_code_point(epi):
     worst = float((err / bound).max())
     print(f"[{epi}] float output of the verification mode: max error / (1e-6 |y| [+ 5e-7 |x| where |y| < 1e-3 |x|]) = {worst:.3f}")
     assert worst <= 1.0, worst
+
+
+# ---- the 384 x 256 tiling (round 5, gemm.hip gemm_bf16_x384_kernel) ---------------------------------------------------------------
+@pytest.fixture
+def gemm_x384():
+    from apex_studio_amd import lib
+    yield lambda v: lib.tune_set("gemm.x384", v)
+    lib.tune_set("gemm.x384", 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 3072, 3072), (384, 256, 64), (385, 264, 128), (1000, 1040, 320), (75, 3072, 1024),
+                                   (2000, 8, 64), (768, 512, 15360)])
+def test_gemm_x384_tiling_is_bit_identical(M, N, K, gemm_x384):
+    """Same K order per output element as the 256 x 256 launch: the 384 x 256 tiling (192 accumulators, buffer-descriptor
+    LDS-DMA with rows past M / N reading as zero) must reproduce it BIT FOR BIT — every epilogue, ragged edges, in place on the
+    residual, strided output — and match the fp32 reference."""
+    ops = _ops()
+    a, w, b = _bf(seeded((M, K), 1)).to(DEV), _bf(seeded((N, K), 2, scale=K ** -0.5)).to(DEV), _bf(seeded((N,), 3)).to(DEV)
+    gate, r = seeded((N,), 4).to(DEV), _bf(seeded((M, N), 5)).to(DEV)
+    got = {}
+    for mode in (0, 2):
+        gemm_x384(mode)
+        x = r.clone()
+        ops.gemm(a, w, b, out=x, epilogue="gate_res", gate=gate, residual=x)
+        strided = torch.zeros(M, N + 24, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, w, None, out=strided[:, 16:16 + N], epilogue="silu")
+        got[mode] = (ops.gemm(a, w, b), ops.gemm(a, w, b, epilogue="gelu"), x, strided)
+    for u, v, what in zip(got[0], got[2], ("bias", "gelu", "gate_res in place", "silu into a strided view, no bias")):
+        assert torch.equal(u, v), f"384x256 differs from 256x256: {what} at {(M, N, K)}"
+    ref = a.float() @ w.float().T + b.float()
+    _check(got[2][0], ref, 3e-3, "x384 bias")
+    _check(got[2][2], r.float() + gate * ref, 3e-3, "x384 gate_res")
+    assert torch.equal(got[2][3][:, :16].cpu(), torch.zeros(M, 16, dtype=torch.bfloat16)) and \
+        torch.equal(got[2][3][:, 16 + N:].cpu(), torch.zeros(M, 8, dtype=torch.bfloat16)), "stores outside the view"
+
+
+def test_gemm_x384_grouped_strided_operands_and_race_screen(gemm_x384):
+    """Two problems in one 384 x 256 launch; activations read through a strided view (the single block's CAT buffer); a deep-K
+    problem repeated (a race behind the counted vmcnt waits shows up as run-to-run differences)."""
+    ops = _ops()
+    K, Mi, Mt = 512, 700, 80
+    big = _bf(seeded((Mi + Mt, K + 64), 1)).to(DEV)
+    ai, at = big[Mt:, 32:32 + K], big[:Mt, 32:32 + K]
+    wi, wt = _bf(seeded((768, K), 3, scale=K ** -0.5)).to(DEV), _bf(seeded((1000, K), 4, scale=K ** -0.5)).to(DEV)
+    bi, bt = _bf(seeded((768,), 5)).to(DEV), _bf(seeded((1000,), 6)).to(DEV)
+    outs = {}
+    for mode in (0, 2):
+        gemm_x384(mode)
+        oi, ot = torch.zeros(Mi, 768, dtype=torch.bfloat16, device=DEV), torch.zeros(Mt, 1000, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_grouped([ai, at], [wi, wt], [bi, bt], [oi, ot], epilogue=["bias", "gelu"])
+        outs[mode] = (oi, ot)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    _check(outs[2][1], torch.nn.functional.gelu(at.float() @ wt.float().T + bt.float(), approximate="tanh"), 3e-3, "x384 grouped gelu")
+    gemm_x384(2)
+    a = _bf(seeded((1152, 4096), 11)).to(DEV)
+    w = _bf(seeded((2048, 4096), 12, scale=4096 ** -0.5)).to(DEV)
+    first = ops.gemm(a, w)
+    _check(first, a.float() @ w.float().T, 3e-3, "x384 deep-K")
+    for _ in range(10):
+        assert torch.equal(ops.gemm(a, w), first), "non-deterministic result: LDS staging race"

@@ -17,8 +17,11 @@ from apex_studio_amd import lib, ops  # noqa: E402
 DEV = "cuda"
 K = int(os.environ.get("K", "12288"))
 X288 = os.environ.get("X288", "0") == "1"
-BM, BN = (288, 192) if X288 else (256, 256)
+X384 = os.environ.get("X384", "0") == "1"          # the 384 x 256 tiling (DIST=0|1: its piece distribution)
+BM, BN = (288, 192) if X288 else (384, 256) if X384 else (256, 256)
 lib.tune_set("gemm.x288", 2 if X288 else 0)
+lib.tune_set("gemm.x384", 2 if X384 else 0)
+lib.tune_set("gemm.x384_dist", int(os.environ.get("DIST", "1")))
 g = torch.Generator(device=DEV).manual_seed(0)
 for nm, nn in [(2, 8), (4, 8), (8, 8), (8, 12), (8, 16), (12, 16), (14, 16), (16, 13), (16, 14), (16, 15), (16, 16), (16, 17), (16, 20), (16, 24), (16, 32)]:
     M, N = BM * nm, BN * nn
@@ -47,3 +50,4 @@ for nm, nn in [(2, 8), (4, 8), (8, 8), (8, 12), (8, 16), (12, 16), (14, 16), (16
                       "tflops": round(2.0 * M * N * K / us / 1e6, 1)}), flush=True)
     del ws
 lib.tune_set("gemm.x288", 0)
+lib.tune_set("gemm.x384", 1)

@@ -20,6 +20,9 @@ DEFAULT = ("4608,3072,15360,gate_res;4096,3072,12288,gate_res;4096,3072,3072,gat
 SHAPES = [s.split(",") for s in os.environ.get("SHAPES", DEFAULT).split(";") if s]
 ROUNDS, REPS = int(os.environ.get("ROUNDS", "5")), int(os.environ.get("REPS", "38"))
 ARMS = [int(v) for v in os.environ.get("ARMS", "0,2").split(",")]
+for _kv in filter(None, os.environ.get("TUNE", "").split(",")):      # extra keys for the whole run, e.g. TUNE=gemm.x384_dist=0
+    lib.tune_set(_kv.split("=")[0], int(_kv.split("=")[1]))
+KEY = os.environ.get("KEY", "gemm.x288")        # KEY=gemm.x384: the 384 x 256 tiling
 g = torch.Generator(device=DEV).manual_seed(0)
 for M, N, K, epi in SHAPES:
     M, N, K = int(M), int(N), int(K)
@@ -40,7 +43,7 @@ for M, N, K, epi in SHAPES:
     res, outs = {m: [] for m in ARMS}, {}
     for r in range(ROUNDS):
         for m in ARMS:
-            lib.tune_set("gemm.x288", m)
+            lib.tune_set(KEY, m)
             launch(0)
             outs.setdefault(m, out.clone())
             torch.cuda.synchronize()
@@ -51,10 +54,10 @@ for M, N, K, epi in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             res[m].append(e0.elapsed_time(e1) / REPS * 1e3)
-    lib.tune_set("gemm.x288", 0)
+    lib.tune_set(KEY, 1 if KEY == "gemm.x384" else 0)
     fl = 2.0 * M * N * K
     med = {m: statistics.median(v) for m, v in res.items()}
-    print(json.dumps({"shape": [M, N, K], "epilogue": epi, "auto_rule_picks_x288": bool(uses),
+    print(json.dumps({"shape": [M, N, K], "epilogue": epi, "key": KEY, "auto_rule_picks_x288": bool(uses),
                       "us": {str(m): round(v, 1) for m, v in med.items()},
                       "tflops": {str(m): round(fl / v / 1e6, 1) for m, v in med.items()},
                       "x288_speedup": round(med[ARMS[0]] / med[ARMS[-1]], 4),
