@@ -398,7 +398,10 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
 //          sequence positions per lane, 128-byte runs per d-row of [H, 128, Skp].
 // Rows >= M are not stored; the zero padding of V^T beyond S_out is the caller's (the workspace is allocated zeroed).  A stream
 // whose row range is not 8-aligned takes an element-wise (still coalesced) V^T store; q / k rows have no alignment to keep.
-APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, const QkvShared& Q, int M, int m0, int n0,
+// MT = 16-row m-tiles per wave, WROWS = rows per M-half of the block: <8, 128> on the 256 x 256 tiling, <12, 192> on the 384 x 256 one
+// (round 5), whose V^T tile (384 x 256 bf16 = 192 KiB) does not fit the LDS and goes out in two passes, one per M-half.
+template <int MT = 8, int WROWS = 128>
+APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P, const QkvShared& Q, int M, int m0, int n0,
                                   int wave, int wm, int wn, int lane, char* smem) {
     const int g = lane >> 4, c = lane & 15;
     const int which = n0 / Q.inner;                    // 0 q, 1 k, 2 v: block-uniform
@@ -429,80 +432,93 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
     const int cw = 16 * (g & 1) + 8 * (g >> 1);        // first of the lane's 8 columns inside a 32-column slab
     __syncthreads();                                    // every wave is out of the main loop's fragment reads
     if (which == 2) {
-        // ---- V^T: tile[r][d] (256 x 256 bf16), row r rotated by ((r >> 3) + 4 (r & 7)) sixteen-byte chunks
+        // ---- V^T: tile[r][d] (ROWS x 256 bf16), row r rotated by ((r >> 3) + 4 (r & 7)) sixteen-byte chunks
+        constexpr int NPASS = (2 * WROWS * 512 > 160 * 1024) ? 2 : 1;         // M-halves staged together, or one after the other
+        constexpr int ROWS = NPASS == 1 ? 2 * WROWS : WROWS;
         bf16_t* tile = (bf16_t*)smem;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            load_bias(p);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                const int r = wm * 128 + mt * 16 + c;
-                const int dch = (wn * 64 + p * 32 + cw) >> 3;
-                *(u32x4*)(tile + r * 256 + (((dch + (r >> 3) + 4 * (r & 7)) & 31) << 3)) = rounded(p, mt);
-            }
-        }
-        __syncthreads();
         const int tid = wave * 64 + lane;
-        if (((P.row0 | M) & 7) != 0) {
-            // a stream that does not start (or end) on an 8-position boundary of the joint sequence (prompt lengths are what they
-            // are): 16-byte stores would be misaligned, so one element per lane, a wave = 64 consecutive positions of one d-row
-            // (a contiguous 128-byte run) — 8 x the store instructions of the aligned form, the same bytes
-            for (int i = 0; i < 128; ++i) {
-                const int idx = i * 512 + tid;
-                const int r = idx & 255, d = idx >> 8;
-                const bf16_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
-                const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
-                if (m0 + r < M) Q.vt[((int64_t)h * 128 + dd) * Q.Skp + P.row0 + m0 + r] = e;
-            }
-            return;
-        }
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int idx = i * 512 + tid;
-            const int sc = idx & 7, d = (idx >> 3) & 255, sc_hi = idx >> 11;     // 8 lanes = 8 consecutive position chunks of one d
-            const int s8 = (sc_hi * 8 + sc) * 8;                                // first of the 8 positions (tile row)
-            uint32_t w[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = s8 + j;
-                const uint32_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
-                if (j & 1) w[j >> 1] |= e << 16;
-                else w[j >> 1] = e;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (NPASS == 2 && pass == 1) __syncthreads();                      // the first half's readers are done with the tile
+            if (NPASS == 1 || wm == pass) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    load_bias(p);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int r = (NPASS == 1 ? wm * WROWS : 0) + mt * 16 + c;
+                        const int dch = (wn * 64 + p * 32 + cw) >> 3;
+                        *(u32x4*)(tile + r * 256 + (((dch + (r >> 3) + 4 * (r & 7)) & 31) << 3)) = rounded(p, mt);
+                    }
+                }
             }
-            const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
-            if (m0 + s8 < M)
-                *(u32x4*)(Q.vt + ((int64_t)h * 128 + dd) * Q.Skp + P.row0 + m0 + s8) = u32x4{w[0], w[1], w[2], w[3]};
+            __syncthreads();
+            const int mp = m0 + (NPASS == 1 ? 0 : pass * WROWS);               // first output row of this pass
+            if (((P.row0 | M) & 7) != 0) {
+                // a stream that does not start (or end) on an 8-position boundary of the joint sequence (prompt lengths are what they
+                // are): 16-byte stores would be misaligned, so one element per lane, a wave = 64 consecutive positions of one d-row
+                // (a contiguous 128-byte run) — 8 x the store instructions of the aligned form, the same bytes
+                for (int i = 0; i < ROWS / 2; ++i) {
+                    const int idx = i * 512 + tid;
+                    const int r = idx % ROWS, d = idx / ROWS;
+                    const bf16_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
+                    const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
+                    if (mp + r < M) Q.vt[((int64_t)h * 128 + dd) * Q.Skp + P.row0 + mp + r] = e;
+                }
+                continue;
+            }
+#pragma unroll 4
+            for (int i = 0; i < ROWS / 16; ++i) {
+                const int idx = i * 512 + tid;
+                const int sc = idx & 7, d = (idx >> 3) & 255, sc_hi = idx >> 11;     // 8 lanes = 8 consecutive position chunks of one d
+                const int s8 = (sc_hi * 8 + sc) * 8;                                // first of the 8 positions (tile row)
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = s8 + j;
+                    const uint32_t e = tile[r * 256 + ((((d >> 3) + (r >> 3) + 4 * (r & 7)) & 31) << 3) + (d & 7)];
+                    if (j & 1) w[j >> 1] |= e << 16;
+                    else w[j >> 1] = e;
+                }
+                const int h = (ncol0 + d) >> 7, dd = (ncol0 + d) & 127;
+                if (mp + s8 < M)
+                    *(u32x4*)(Q.vt + ((int64_t)h * 128 + dd) * Q.Skp + P.row0 + mp + s8) = u32x4{w[0], w[1], w[2], w[3]};
+            }
         }
         return;
     }
     // ---- q / k: RMS norm over the head, rotation, [H, S_out, 128]
-    float* red = (float*)smem;                          // [8 waves][16 = slab x m-tile][64 lanes]
+    float* red = (float*)smem;                          // [8 waves][2 MT = slab x m-tile][64 lanes]
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         load_bias(p);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             float x[8];
             unpack8(rounded(p, mt), x);
             float sq = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) sq += x[j] * x[j];
-            red[(wave * 16 + p * 8 + mt) * 64 + lane] = sq;
+            red[(wave * 2 * MT + p * MT + mt) * 64 + lane] = sq;
         }
     }
     __syncthreads();
     const bf16_t* nw = which ? P.nk : P.nq;
     const int h = (ncol0 >> 7) + (wn >> 1);
     bf16_t* dst_base = (which ? Q.ko : Q.qo) + (int64_t)h * Q.S_out * 128;
-    float rinv[8];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const float a0 = red[(wave * 16 + mt) * 64 + lane] + red[((wave ^ 1) * 16 + mt) * 64 + lane];          // chunk ^ 8: the partner wave
-        const float a1 = red[(wave * 16 + 8 + mt) * 64 + lane] + red[((wave ^ 1) * 16 + 8 + mt) * 64 + lane];
+    auto rinv_of = [&](int mt) -> float {
+        const float a0 = red[(wave * 2 * MT + mt) * 64 + lane] + red[((wave ^ 1) * 2 * MT + mt) * 64 + lane];          // chunk ^ 8: the partner wave
+        const float a1 = red[(wave * 2 * MT + MT + mt) * 64 + lane] + red[((wave ^ 1) * 2 * MT + MT + mt) * 64 + lane];
         float sq = a0 + a1;                                                              // chunk ^ 4: the other slab
         sq += __shfl_xor(sq, 16, 64);                                                    // chunk ^ 2
         sq += __shfl_xor(sq, 32, 64);                                                    // chunk ^ 1
-        rinv[mt] = rsqrtf(sq * (1.0f / 128) + Q.eps);
+        return rsqrtf(sq * (1.0f / 128) + Q.eps);
+    };
+    // 256 x 256 tiling: the 8 factors once, in registers; 384 x 256 (192 accumulators): recomputed per (slab, m-tile) from the LDS sums
+    float rinv[MT > 8 ? 1 : MT];
+    if constexpr (MT <= 8) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) rinv[mt] = rinv_of(mt);
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -511,14 +527,15 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
         float wv[8];
         if (nw != nullptr) unpack8(*(const u32x4*)(nw + d), wv);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wm * 128 + mt * 16 + c;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * WROWS + mt * 16 + c;
             const int srow = P.row0 + min(m, M - 1);
             float x[8], y[8];
             unpack8(rounded(p, mt), x);
             if (nw != nullptr) {
+                const float ri = MT > 8 ? rinv_of(mt) : rinv[MT > 8 ? 0 : mt];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = x[j] * rinv[mt] * wv[j];
+                for (int j = 0; j < 8; ++j) x[j] = x[j] * ri * wv[j];
             }
             const float* cp = Q.rope + (int64_t)srow * 128 + d;
             const float* sp = Q.rope + (int64_t)Q.S_out * 128 + (int64_t)srow * 128 + d;
@@ -540,7 +557,8 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][8], const GemmProblem& P, 
             if (m < M)
                 *(u32x4*)(dst_base + (int64_t)srow * 128 + d) =
                     u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
-            if (mt & 1) __builtin_amdgcn_sched_barrier(0);   // two rows' table loads in flight at a time, not sixteen (registers)
+            // rows' table loads in flight at a time: two on the 256 x 256 tiling, ONE where 192 accumulators leave 64 registers
+            if (MT > 8 || (mt & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -1755,7 +1773,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x288_kernel(const GemmGroup 
 constexpr int YBM = 384, YBN = 256;
 constexpr int Y_A_BYTES = YBM * BK * 2, Y_W_BYTES = YBN * BK * 2, Y_STAGE = Y_A_BYTES + Y_W_BYTES, Y_LDS = 2 * Y_STAGE;
 
-template <int EPI, int DIST = 1>
+template <int EPI, int DIST = 1, int QKV = 0>      // QKV = 1: launches that carry a fused q/k/v problem (their own instantiation: its epilogue
+                                                   // spills a few registers, which the plain launches must not pay for)
 __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1933,6 +1952,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         }
     }
 
+    if constexpr (EPI == APEXMI_EPI_BIAS && QKV == 1) {
+        if (P.qkv) {                                   // block-uniform: the fused q / k / v preparation (two passes for V^T)
+            qkv_epilogue16<12, 192>(acc, P, G.qs, M, m0, n0, wave, wm, wn, lane, smem);
+            return;
+        }
+    }
     // ---- epilogue: per 32-column slab and a few m-tiles at a time (the accumulators leave 64 registers for everything else) ----
     constexpr int MTC = EPI == APEXMI_EPI_BIAS_GATE_RES ? 3 : 6;      // m-tiles per call (gate / residual also holds the residual rows)
 #pragma unroll
@@ -1973,6 +1998,7 @@ int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x2
 int g_x288 = 0;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never (SHIPPED: it measured slower, see the kernel's header) |
                       // 1 where it saves a round's worth of tile-work | 2 always (A/B, tests)
 int g_x384_dist = -1; // tune key gemm.x384_dist: how a wave's 10 pieces are spread over the 4 phases (0: 3+3+2+2, 1: 2+3+2+3, -1: by launch size)
+int g_x384_qkv = 1;   // tune key gemm.x384_qkv: launches with the fused q/k/v epilogue may use the 384 x 256 tiling too (A/B)
 int g_x384 = 1;       // tune key gemm.x384: the 384 x 256 tiling — 0 never | 1 where its staged bytes win (x384_pays; SHIPPED) | 2 always (A/B, tests)
 int g_small_max = 112; // tune key gemm.small_max: launches of at most this many 256 x 256 tiles go out on the 128 x 128 tiling (0: never)
 int g_tail_split = 2; // tune key gemm.tail: a small last problem of a grouped launch goes out on the 128x128 tiling (1: four waves, 2: eight)
@@ -2080,7 +2106,9 @@ int launch_x384(GemmGroup& G, const int* Ms, hipStream_t stream) {
     static uint64_t attr_set = 0;
     APEXMI_SET_ATTR_ONCE(attr_set,
         (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS));
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS);
+        if constexpr (EPI == APEXMI_EPI_BIAS)
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_x384_kernel<EPI, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS));
     int t = 0;
     for (int i = 0; i < G.count; ++i) {
         G.p[i].M = Ms[i];
@@ -2096,6 +2124,14 @@ int launch_x384(GemmGroup& G, const int* Ms, hipStream_t stream) {
     G.sk_r = G.sk_tfull = 0;
     G.sk_slab = nullptr;
     G.sk_flag = nullptr;
+    bool any_qkv = false;
+    for (int i = 0; i < G.count; ++i) any_qkv |= G.p[i].qkv != 0;
+    if constexpr (EPI == APEXMI_EPI_BIAS) {
+        if (any_qkv) {
+            hipLaunchKernelGGL((gemm_bf16_x384_kernel<EPI, 1, 1>), dim3(t, 1), dim3(512), Y_LDS, stream, G);
+            return apexmi_check_launch("gemm_bf16 (384x256, fused q/k/v)");
+        }
+    }
     const int dist = g_x384_dist >= 0 ? g_x384_dist : (t >= 2048 ? 0 : 1);     // measured: 3+3+2+2 +1 % on Wan's launches, 2+3+2+3 +1..2 % on Flux's
     if (dist == 0) hipLaunchKernelGGL((gemm_bf16_x384_kernel<EPI, 0>), dim3(t, 1), dim3(512), Y_LDS, stream, G);
     else hipLaunchKernelGGL((gemm_bf16_x384_kernel<EPI, 1>), dim3(t, 1), dim3(512), Y_LDS, stream, G);
@@ -2412,6 +2448,9 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
     APEXMI_REQUIRE(apexmi_gemm_qkv_fusable(mtot, nmax, K),
                    "gemm_bf16_grouped_qkv: needs the 256x256 v_mfma_f32_16x16x32 tiling (gemm.config / gemm.large = 7, >= 1024 rows)");
     ApexmiProfScope prof(0, stream, flops, bytes);
+    // the single block's QKV + MLP-up launch (M 4608 = 12 x 384: 1008 tiles of 384 x 256 = 3.9 rounds instead of 1512 = 5.9)
+    if (g_x384 && g_x384_qkv && g_large_cfg == 7 && (g_force_cfg == 0 || g_force_cfg == 7) && (g_x384 == 2 || x384_pays(G, M)))
+        return launch_x384<APEXMI_EPI_BIAS>(G, M, stream);
     if (g_large_cfg == 9 || g_force_cfg == 9) return launch_cfg<CFG_256R, APEXMI_EPI_BIAS>(G, M, stream);
     if (g_large_cfg == 10 || g_force_cfg == 10) return launch_cfg<CFG_256R5, APEXMI_EPI_BIAS>(G, M, stream);
     return launch_cfg<CFG_256P16, APEXMI_EPI_BIAS>(G, M, stream);
@@ -2443,6 +2482,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.small_max")) g_small_max = value;
     else if (!strcmp(key, "gemm.x384")) g_x384 = value;
     else if (!strcmp(key, "gemm.x384_dist")) g_x384_dist = value;
+    else if (!strcmp(key, "gemm.x384_qkv")) g_x384_qkv = value;
 #if APEXMI_GEMM_TRACE
     else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
     else if (!strcmp(key, "gemm.trace_hi")) g_gemm_trace = (g_gemm_trace & (uintptr_t)0xffffffffu) | ((uintptr_t)(uint32_t)value << 32);

@@ -23,8 +23,27 @@ def _rope(S, seed):
     return torch.stack([cos, sin]).contiguous().float()
 
 
+@pytest.fixture
+def x384():
+    """`gemm.x384`: 1 = the shipped rule, 2 = every launch on the 384 x 256 tiling, 0 = never; restored to 1."""
+    from apex_studio_amd import lib as _l
+    yield lambda v: _l.tune_set("gemm.x384", v)
+    _l.tune_set("gemm.x384", 1)
+
+
 @pytest.mark.parametrize("m_img,m_txt", [(1280, 256), (1096, 72), (1024, 0), (1091, 77), (1100, 3)])
 def test_joint_streams_bit_identical_to_two_pass(m_img, m_txt):
+    _joint_streams(m_img, m_txt)
+
+
+@pytest.mark.parametrize("m_img,m_txt", [(1280, 256), (1152, 0), (1091, 77), (1100, 3), (700, 400)])
+def test_joint_streams_on_the_384_tiling(m_img, m_txt, x384):
+    """The same on the 384 x 256 tiling (round 5: `qkv_epilogue16<12, 192>`, V^T in two passes through the LDS): forced for the
+    fused launch, with the two-pass reference left on the shipped 256 x 256 / 128 x 128 kernels."""
+    _joint_streams(m_img, m_txt, x384)
+
+
+def _joint_streams(m_img, m_txt, x384=None):
     from apex_studio_amd import lib as _l, ops
     H, K = 4, 512
     inner, S = H * 128, m_img + m_txt
@@ -49,8 +68,12 @@ def test_joint_streams_bit_identical_to_two_pass(m_img, m_txt):
     assert ops.qkv_fusable(xs, ws, row0, H)
     q1, k1 = (torch.full((H, S, 128), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     vt1 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
+    if x384 is not None:
+        x384(2)
     ops.gemm_grouped_qkv(xs, ws, bs, [None] * len(xs), "bias", [1] * len(xs), nq[:len(xs)], nk[:len(xs)], row0, H, 1e-6, rope,
                          q1, k1, vt1)
+    if x384 is not None:
+        x384(1)
     torch.cuda.synchronize()
     assert torch.equal(q1, q0), int((q1 != q0).sum())
     assert torch.equal(k1, k0), int((k1 != k0).sum())
@@ -58,8 +81,26 @@ def test_joint_streams_bit_identical_to_two_pass(m_img, m_txt):
 
 
 def test_single_block_launch_with_mlp_up_bit_identical():
+    _single_block(4, 512, 1160, 2048)
+
+
+def test_single_block_launch_on_the_384_tiling(x384):
+    _single_block(4, 512, 1160, 2048, x384)
+
+
+def test_flux_single_block_shape_takes_the_384_tiling_and_is_bit_identical(x384):
+    """The real launch: M 4608 = 12 x 384, QKV (N 9216, 24 heads) + MLP-up (N 12288, GELU), K 3072 — 1008 tiles of 384 x 256 under the
+    shipped rule (`gemm.x384` = 1) — against the two-pass path, and against the same fused launch kept on 256 x 256."""
+    a = _single_block(24, 3072, 4608, 12288)
+    x384(0)
+    b = _single_block(24, 3072, 4608, 12288)
+    x384(1)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def _single_block(H, K, S, mlp, x384=None):
     from apex_studio_amd import lib as _l, ops
-    H, K, S, mlp = 4, 512, 1160, 2048
     inner = H * 128
     skp = (S + 63) // 64 * 64
     x = _rand((S, K), 21)
@@ -77,10 +118,15 @@ def test_single_block_launch_with_mlp_up_bit_identical():
     q1, k1 = (torch.empty(H, S, 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     vt1 = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
     up1 = torch.empty(S, mlp, device=DEV, dtype=torch.bfloat16)
+    if x384 is not None:
+        x384(2)
     ops.gemm_grouped_qkv([x, x], [wqkv, wmlp], [bqkv, bmlp], [None, up1], ["bias", "gelu"], [1, 0], [nq, None], [nk, None], [0, 0],
                          H, 1e-6, rope, q1, k1, vt1)
+    if x384 is not None:
+        x384(1)
     torch.cuda.synchronize()
     assert torch.equal(up1, up0) and torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(vt1, vt0)
+    return q1, k1, vt1, up1
 
 
 def test_refused_when_the_tiling_has_no_fused_epilogue():

@@ -27,7 +27,7 @@ from apex_studio_amd.flux import FluxTransformer2DModel  # noqa: E402
 from apex_studio_amd.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
 
 DEV = "cuda"
-DEFAULTS = {"ln.wave": 1, "gemm.group_m": 6, "gemm.large": 7, "gemm.tail": 2, "gemm.tail_max": 96, "gemm.x288": 0, "gemm.x384": 1, "gemm.small_max": 112}      # shipped values of the keys an arm may set (restored after the arm)
+DEFAULTS = {"ln.wave": 1, "gemm.group_m": 6, "gemm.large": 7, "gemm.tail": 2, "gemm.tail_max": 96, "gemm.x288": 0, "gemm.x384": 1, "gemm.x384_qkv": 1, "gemm.small_max": 112}      # shipped values of the keys an arm may set (restored after the arm)
 ARMS = [a for a in os.environ.get("ARMS", "base;modtable=0").split(";") if a]
 STEPS = int(os.environ.get("STEPS", "12"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
