@@ -11,7 +11,7 @@ W=${WORKLOAD:-flux}                 # flux | qwen
 OUT=$R/gpurun_out/pmc_gemm_$W
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=$([ "$W" = flux ] && echo ${ROUND:-r04}_pmc_gemm || echo ${ROUND:-r04}_pmc_gemm_$W)
+TAG=$([ "$W" = flux ] && echo ${ROUND:-r05}_pmc_gemm || echo ${ROUND:-r05}_pmc_gemm_$W)
 export TAG W
 CMD="python $R/bench.py --workload $W --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
 T=${PROF_TIMEOUT:-420}
@@ -23,21 +23,25 @@ python - <<'PY'
 import csv, glob, hashlib, json, os
 root = os.environ["GRAFT_REPO_ROOT"]
 out = root + "/gpurun_out/pmc_gemm_" + os.environ["W"] + "/"
+def big(name):          # the large-tile GEMM launches of the step: the shipped 256 x 256 ping-pong kernel and (round 5) the 384 x 256 one
+    return ("gemm_bf16_kernel" in name and "Cfg<256, 256, 2, 4, 5>" in name) or "gemm_bf16_x384_kernel" in name
+
+
 def means(sub, pick):
     vals, durs = {}, []
     for f in glob.glob(out + sub + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if pick in r["Kernel_Name"] and "Cfg<256, 256, 2, 4, 5>" in r["Kernel_Name"]:
+            if big(r["Kernel_Name"]):
                 vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for f in glob.glob(out + sub + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if pick in r["Kernel_Name"] and "Cfg<256, 256, 2, 4, 5>" in r["Kernel_Name"]:
+            if big(r["Kernel_Name"]):
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return {k: sum(v) / len(v) for k, v in vals.items()}, (len(durs), sum(durs) / max(len(durs), 1))
 f, (n, ns_f) = means("fetch", "gemm_bf16_kernel")
 w, _ = means("write", "gemm_bf16_kernel")
 s, _ = means("sq", "gemm_bf16_kernel")
-res = {"kernel": "gemm_bf16_kernel<Cfg<256,256,2,4,5>> (ping-pong, v_mfma_f32_16x16x32_bf16), all epilogues",
+res = {"kernel": "gemm_bf16_kernel<Cfg<256,256,2,4,5>> (ping-pong, v_mfma_f32_16x16x32_bf16) + gemm_bf16_x384_kernel (384 x 256 tiles), all epilogues",
        "command": "python bench.py --workload %s --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan" % os.environ["W"],
        "source_sha256": hashlib.sha256(open(root + "/apex-studio_amd/csrc/gemm.hip", "rb").read()).hexdigest(),
        "dispatches": n, "avg_duration_ns_under_pmc": ns_f}
