@@ -69,12 +69,33 @@ class WanT2VEngine(EngineLoraMixin):
                     guidance_scale: Union[float, List[float]] = 5.0, boundary_timestep=None,
                     use_cfg_guidance: bool = True, transformer_dtype=None, render_on_step: bool = False,
                     render_on_step_callback=None, render_on_step_interval: int = 3,
-                    denoise_progress_callback=None):
+                    denoise_progress_callback=None, easy_cache_thresh: float = 0.0, easy_cache_ret_steps: int = 10):
+        """`easy_cache_thresh` > 0: EasyCache step skipping (R/src/engine/wan/shared/__init__.py:372-381, :435-444, :502-504) — the
+        reference enables it, with a state reset, on an expert when that expert is loaded; both experts are resident here, so it is
+        enabled (and reset) each time the selected expert CHANGES, and switched off when the loop ends."""
         _emit(denoise_progress_callback, 0.0, "Starting denoise")
+        try:
+            return self._moe_loop(latents, timesteps, prompt_embeds, negative_prompt_embeds, guidance_scale, boundary_timestep,
+                                  use_cfg_guidance, transformer_dtype, render_on_step, render_on_step_callback, render_on_step_interval,
+                                  denoise_progress_callback, easy_cache_thresh, easy_cache_ret_steps)
+        finally:
+            if easy_cache_thresh > 0.0:
+                for tr in {id(self.high_noise_transformer): self.high_noise_transformer,
+                           id(self.low_noise_transformer): self.low_noise_transformer}.values():
+                    if hasattr(tr, "disable_easy_cache"):
+                        tr.disable_easy_cache()
+
+    def _moe_loop(self, latents, timesteps, prompt_embeds, negative_prompt_embeds, guidance_scale, boundary_timestep, use_cfg_guidance,
+                  transformer_dtype, render_on_step, render_on_step_callback, render_on_step_interval, denoise_progress_callback,
+                  easy_cache_thresh, easy_cache_ret_steps):
         n = len(timesteps)
+        current = None
         for i, t in enumerate(timesteps):
             timestep = t.expand(latents.shape[0])
             transformer = self._select_dual_noise_transformer(t, boundary_timestep)
+            if easy_cache_thresh > 0.0 and transformer is not current and hasattr(transformer, "enable_easy_cache"):
+                transformer.enable_easy_cache(n, easy_cache_thresh, easy_cache_ret_steps, should_reset_global_cache=True)
+            current = transformer
             x = latents.to(transformer_dtype or compute_dtype(transformer))
             scale = self._select_dual_noise_guidance_scale(t, boundary_timestep, guidance_scale)
             noise_pred = transformer(hidden_states=x, timestep=timestep, encoder_hidden_states=prompt_embeds,
@@ -111,7 +132,7 @@ class WanT2VEngine(EngineLoraMixin):
             return_latents: bool = False, progress_callback=None, render_on_step: bool = False,
             render_on_step_callback=None, render_on_step_interval: int = 3, output_type: Optional[str] = None,
             prompt=None, negative_prompt=None, prompt_ids=None, negative_prompt_ids=None, num_videos: int = 1,
-            text_encoder_kwargs=None, **_ignored):
+            text_encoder_kwargs=None, easy_cache_thresh: float = 0.0, easy_cache_ret_steps: int = 10, **_ignored):
         """`engine.run(prompt=..., negative_prompt=..., ...)` (R/src/engine/wan/t2v.py:12-247): prompts as strings (text
         encoder with a tokenizer) or token ids `(input_ids, attention_mask)`, or pre-computed embeddings."""
         dev = self.device
@@ -151,7 +172,8 @@ class WanT2VEngine(EngineLoraMixin):
                                    boundary_timestep=boundary, use_cfg_guidance=cfg,
                                    render_on_step=render_on_step, render_on_step_callback=render_on_step_callback,
                                    render_on_step_interval=render_on_step_interval,
-                                   denoise_progress_callback=mapped)
+                                   denoise_progress_callback=mapped, easy_cache_thresh=easy_cache_thresh,
+                                   easy_cache_ret_steps=easy_cache_ret_steps)
         if return_latents or self.vae is None:
             _emit(progress_callback, 1.0, "Returning latents")
             return latents

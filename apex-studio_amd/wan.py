@@ -159,8 +159,21 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
     def set_chunk_feed_forward(self, *a, **k):
         return None
 
-    def enable_easy_cache(self, *a, **k):
-        raise NotImplementedError("wan.mi355: EasyCache step skipping is not implemented")
+    def enable_easy_cache(self, num_steps: int, thresh: float, ret_steps: int = 10, should_reset_global_cache: bool = True):
+        """The reference's EasyCache switch (R/src/transformer/wan/base/model.py:1645-1672): from now on `forward` serves
+        conditional / unconditional call pairs from the cache while the accumulated predicted change stays under `thresh`
+        (easycache.py).  `should_reset_global_cache=False` keeps the running state (the reference's state is global)."""
+        from .easycache import EasyCache
+        if should_reset_global_cache or getattr(self, "_easy_cache", None) is None:
+            self._easy_cache = EasyCache(num_steps, thresh, ret_steps)
+        else:
+            ec = self._easy_cache
+            ec.num_steps, ec.thresh, ec.ret_steps = int(num_steps) * 2, float(thresh), int(ret_steps) * 2
+        return self
+
+    def disable_easy_cache(self):
+        self._easy_cache = None
+        return self
 
     def _apply(self, fn, *a, **k):
         self._packed = False
@@ -451,9 +464,15 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
             raise NotImplementedError("wan.mi355: per-token timesteps are not supported")
         self.pack()
         enc = encoder_hidden_states.to(self.storage_dtype)
-        outs = [self._forward_one(hidden_states[b], timestep[b:b + 1], enc[b].contiguous())
-                for b in range(hidden_states.shape[0])]
-        out = torch.stack(outs, dim=0).to(hidden_states.dtype)
+
+        def run():
+            return torch.stack([self._forward_one(hidden_states[b], timestep[b:b + 1], enc[b].contiguous())
+                                for b in range(hidden_states.shape[0])], dim=0)
+        ec = getattr(self, "_easy_cache", None)
+        if ec is not None:       # EasyCache: this call may be served from the cache; float32 out, as the reference returns
+            out = ec(hidden_states, self.config.out_channels, run)
+        else:
+            out = run().to(hidden_states.dtype)
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)

@@ -18,6 +18,8 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
   hunyuan15_hybrid.pt   the reference's OWN HunyuanVideo15Transformer3DModel / block / attention processor / token refiner
                         (transformer/hunyuanvideo15/base/model.py) on a tiny config, t2v and i2v token orders, leaves
                         from oracle.layers: pins the wiring of oracle.hunyuan15.
+  wan_easycache.pt      the reference's EasyCache forward (transformer/wan/base/model.py:202-520) on the tiny reference Wan model driven
+                        like a CFG sampler: which calls run / are served from the cache, every output — pins oracle.easycache.
   flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
   fp_scaled.pt          reference fp8_activation_dequant / FPScaledLinear._scale_and_cast_weight
                         (quantize/scaled_layer.py:154-167, :496-549) on seeded float8_e4m3fn / e5m2 weights with
@@ -274,6 +276,47 @@ def gen_wan_hybrid():
     torch.save(dict(config=TINY_WAN, seed=9, inputs=inp, out=out.float(), keys=sorted(sd.keys())),
                os.path.join(OUT, "wan_hybrid.pt"))
     print("wan_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
+
+
+def gen_wan_easycache():
+    """The reference's EasyCache forward (`easycache_forward_`, transformer/wan/base/model.py:202-520, enabled by
+    `enable_easy_cache(num_steps, thresh, ret_steps)` :1645-1672) on the tiny Wan model, float64, driven like a CFG sampler:
+    per step one conditional (even call) and one unconditional (odd call) forward on the same latent, then an Euler-like
+    update small enough that the input-change predictor skips some pairs.  Saved: every call's output and whether the blocks
+    ran — pins oracle.easycache and, through it, `wan.mi355`'s `enable_easy_cache`."""
+    import src.transformer.wan.base.model as RM
+    from oracle.wan import WanTransformer3DModel as OracleWan
+    ref = RM.WanTransformer3DModel(**TINY_WAN, rope_max_seq_len=64).eval()
+    sd = synthetic_state_dict(OracleWan(**TINY_WAN), 9)
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.double()
+    ran = []
+    blk0 = ref.blocks[0]
+    orig_fwd = blk0.forward
+    blk0.forward = lambda *a, **k: (ran.append(1), orig_fwd(*a, **k))[1]
+    n, ret_steps, thresh, dt, g = 10, 2, 1.0, 0.02, 3.0
+    x = seeded((1, 16, 3, 8, 12), 41).double()
+    txt_c, txt_u = seeded((1, 20, 64), 42).double(), seeded((1, 20, 64), 43).double()
+    ts = [float(t) for t in torch.linspace(900.0, 100.0, n)]
+    ref.enable_easy_cache(n, thresh, ret_steps, should_reset_global_cache=True)
+    outs, computed = [], []
+    with torch.no_grad():
+        for i in range(n):
+            pair = []
+            for txt in (txt_c, txt_u):
+                k0 = len(ran)
+                o = ref(hidden_states=x, timestep=torch.tensor([ts[i]], dtype=torch.float64), encoder_hidden_states=txt, return_dict=False)[0]
+                computed.append(len(ran) > k0)
+                outs.append(o.float().clone())
+                pair.append(o.double())
+            x = x - dt * (pair[1] + g * (pair[0] - pair[1]))
+    ref.disable_easy_cache()
+    assert any(computed[2 * ret_steps:]) and not all(computed), computed
+    torch.save(dict(config=TINY_WAN, seed=9, n=n, ret_steps=ret_steps, thresh=thresh, dt=dt, guidance=g, timesteps=ts,
+                    x_seed=41, txt_seeds=(42, 43), outs=outs, computed=computed, x_final=x.float()),
+               os.path.join(OUT, "wan_easycache.pt"))
+    print("wan_easycache.pt", "computed:", "".join("C" if c else "-" for c in computed))
+
 
 
 TINY_QWEN = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=2, attention_head_dim=128,
@@ -1157,11 +1200,11 @@ def gen_leaf_pins2():
 
 
 # Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
-FIXTURES = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "wan_easycache", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
             "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
             "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
 # the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
-FAST = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+FAST = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "wan_easycache", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
         "convert"]
 
 

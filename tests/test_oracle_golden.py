@@ -365,4 +365,34 @@ def test_fixture_recipe_reproduces_the_committed_files():
                        capture_output=True, text=True, timeout=600, cwd=root)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
-    assert "21 generators -> 21 files compared, 0 mismatches" in r.stdout, tail
+    assert "22 generators -> 22 files compared, 0 mismatches" in r.stdout, tail
+
+
+def test_easycache_restatement_matches_the_reference_function(golden_dir):
+    """oracle.easycache (the step-skipping rule of the reference's `easycache_forward_`, transformer/wan/base/model.py:202-520)
+    around the oracle Wan model (fp32) against the reference function itself run on the reference model
+    (float64, tests/golden/wan_easycache.pt): the same calls are computed / served from the cache, every output to 5e-5."""
+    from oracle import wan as OW
+    from oracle.easycache import EasyCacheState, easycache_forward
+    g = _load(golden_dir, "wan_easycache.pt")
+    m = OW.WanTransformer3DModel(**g["config"]).eval()
+    m.load_state_dict(synthetic_state_dict(m, g["seed"]), strict=True)
+    x = seeded((1, 16, 3, 8, 12), g["x_seed"])
+    txts = [seeded((1, 20, 64), s) for s in g["txt_seeds"]]
+    st = EasyCacheState(g["n"], g["thresh"], g["ret_steps"])
+    computed, k = [], 0
+    with torch.no_grad():
+        for i in range(g["n"]):
+            pair = []
+            for txt in txts:
+                t = torch.tensor([g["timesteps"][i]])
+                out, did = easycache_forward(st, lambda: m(x, t, txt), x, g["config"]["out_channels"])
+                computed.append(did)
+                ref = g["outs"][k]
+                rel = float((out - ref).norm() / ref.norm())
+                assert out.dtype == torch.float32 and rel < 5e-5, (k, rel)
+                pair.append(out)
+                k += 1
+            x = x - g["dt"] * (pair[1] + g["guidance"] * (pair[0] - pair[1]))
+    assert computed == g["computed"] and not all(computed), "".join("C" if c else "-" for c in computed)
+    assert float((x.float() - g["x_final"]).norm() / g["x_final"].norm()) < 5e-5
