@@ -2184,7 +2184,8 @@ inline bool x384_pays(const GemmGroup& G, const int* Ms) {
 inline bool use_x384(const GemmGroup& G, const int* Ms) {
     if (g_x384 == 0 || G.batch != 1 || G.K % BK != 0 || !(g_force_cfg == 0 || g_force_cfg == 7) || g_large_cfg != 7) return false;
     for (int i = 0; i < G.count; ++i)
-        if (G.p[i].qkv || G.p[i].lda > (1 << 26) || G.p[i].ldw > (1 << 26)) return false;
+        // (the kernel's piece offsets are 32-bit: 384 rows x leading dimension x 2 bytes must stay below 2^31)
+        if (G.p[i].qkv || G.p[i].lda > (1 << 21) || G.p[i].ldw > (1 << 21)) return false;
     return g_x384 == 2 || x384_pays(G, Ms);
 }
 
@@ -2449,7 +2450,9 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
                    "gemm_bf16_grouped_qkv: needs the 256x256 v_mfma_f32_16x16x32 tiling (gemm.config / gemm.large = 7, >= 1024 rows)");
     ApexmiProfScope prof(0, stream, flops, bytes);
     // the single block's QKV + MLP-up launch (M 4608 = 12 x 384: 1008 tiles of 384 x 256 = 3.9 rounds instead of 1512 = 5.9)
-    if (g_x384 && g_x384_qkv && g_large_cfg == 7 && (g_force_cfg == 0 || g_force_cfg == 7) && (g_x384 == 2 || x384_pays(G, M)))
+    bool ld_ok = true;
+    for (int i = 0; i < count; ++i) ld_ok &= lda[i] <= (1 << 21) && ldw[i] <= (1 << 21);
+    if (g_x384 && g_x384_qkv && ld_ok && g_large_cfg == 7 && (g_force_cfg == 0 || g_force_cfg == 7) && (g_x384 == 2 || x384_pays(G, M)))
         return launch_x384<APEXMI_EPI_BIAS>(G, M, stream);
     if (g_large_cfg == 9 || g_force_cfg == 9) return launch_cfg<CFG_256R, APEXMI_EPI_BIAS>(G, M, stream);
     if (g_large_cfg == 10 || g_force_cfg == 10) return launch_cfg<CFG_256R5, APEXMI_EPI_BIAS>(G, M, stream);
