@@ -471,7 +471,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
 
     @torch.no_grad()
     def _forward_one(self, hidden_states, encoder_hidden_states, pooled, timestep, img_ids, txt_ids,
-                     guidance, mod_row=None):
+                     guidance, mod_row=None, cn_d=None, cn_s=None):
         cfg = self.config
         dim, H = self.inner_dim, cfg.num_attention_heads
         s_img, s_txt = hidden_states.shape[0], encoder_hidden_states.shape[0]
@@ -553,6 +553,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             ops.gemm_grouped([FFH[s_txt:], FFH[:s_txt]], [ff[2].weight, ffc[2].weight],
                              [ff[2].bias, ffc[2].bias], [Xi, Xt], epilogue="gate_res",
                              gate_list=[mi(5), mt(5)], residual_list=[Xi, Xt])
+            if cn_d is not None:
+                ops.add(Xi, cn_d[i], out=Xi)
 
         for i, blk in enumerate(self.single_transformer_blocks):
             if nblk == 1:
@@ -591,6 +593,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 torch.cuda.current_stream().wait_event(mlp_done)
             ops.gemm(CAT, blk.proj_out.weight, blk.proj_out.bias, out=X, epilogue="gate_res", gate=ms(2),
                      residual=X)
+            if cn_s is not None:
+                ops.add(Xi, cn_s[i], out=Xi)
 
         join_mod()
         # AdaLayerNormContinuous: scale first, then shift
@@ -607,8 +611,21 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 guidance: torch.Tensor = None, joint_attention_kwargs: Optional[Dict[str, Any]] = None,
                 controlnet_block_samples=None, controlnet_single_block_samples=None,
                 return_dict: bool = True, controlnet_blocks_repeat: bool = False):
-        if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
-            raise NotImplementedError("flux.mi355: controlnet residuals are outside the hot-path scope")
+        # ControlNet residuals (reference model.py:594-612, :631-640): per-block tensors [B, S_img, dim] added to the image stream
+        # after the block — sample index = block // ceil(blocks / samples), or block % samples with `controlnet_blocks_repeat`
+        # (double blocks only).  The ControlNet that produces them is not part of this path.
+        def _cn(samples, nblocks, repeat):
+            if samples is None:
+                return None
+            n = len(samples)
+            if n == 0:
+                return None
+            step = -(-nblocks // n)
+            idx = [(i % n if repeat else i // step) for i in range(nblocks)]
+            ss = [smp.to(self.device, self.storage_dtype).contiguous() for smp in samples]
+            return [ss[j] for j in idx]
+        cn_d = _cn(controlnet_block_samples, len(self.transformer_blocks), controlnet_blocks_repeat)
+        cn_s = _cn(controlnet_single_block_samples, len(self.single_transformer_blocks), False)
         if joint_attention_kwargs and "ip_adapter_image_embeds" in joint_attention_kwargs:
             raise NotImplementedError("flux.mi355: IP-adapter is outside the hot-path scope")
         self.pack()
@@ -624,7 +641,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 hs[b].contiguous(), enc[b].contiguous(), pooled_projections[b], timestep[b:b + 1],
                 img_ids, txt_ids, None if guidance is None else guidance[b:b + 1],
                 mod_row=self._sched_row(pooled_projections, joint_attention_kwargs, b, timestep[b:b + 1],
-                                        None if guidance is None else guidance[b:b + 1]))
+                                        None if guidance is None else guidance[b:b + 1]),
+                cn_d=None if cn_d is None else [t[b] for t in cn_d], cn_s=None if cn_s is None else [t[b] for t in cn_s])
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda:

@@ -156,7 +156,8 @@ class FluxTransformer2DModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids,
-                txt_ids, guidance=None, policy: Policy = FP32):
+                txt_ids, guidance=None, policy: Policy = FP32, controlnet_block_samples=None,
+                controlnet_single_block_samples=None, controlnet_blocks_repeat: bool = False):
         pol = policy
         x = pol.r(self.x_embedder(hidden_states))
         # reference: `timestep.to(hidden_states.dtype) * 1000` (model.py:535-537) — with bf16 hidden
@@ -170,10 +171,20 @@ class FluxTransformer2DModel(nn.Module):
             temb = self.time_text_embed(timestep, pooled_projections)
         ctx = pol.r(self.context_embedder(encoder_hidden_states))
         rope = flux_pos_embed(torch.cat((txt_ids, img_ids), dim=0), self.axes_dims_rope)
-        for blk in self.transformer_blocks:
+        # ControlNet residuals on the image stream after every block (reference model.py:594-612, :631-640): sample index =
+        # block // ceil(blocks / samples), or block % samples with `controlnet_blocks_repeat` (double blocks only)
+        import math
+        for i, blk in enumerate(self.transformer_blocks):
             ctx, x = blk(x, ctx, temb, rope, pol)
-        for blk in self.single_transformer_blocks:
+            if controlnet_block_samples is not None:
+                n = len(controlnet_block_samples)
+                j = i % n if controlnet_blocks_repeat else i // int(math.ceil(len(self.transformer_blocks) / n))
+                x = pol.r(x + controlnet_block_samples[j])
+        for i, blk in enumerate(self.single_transformer_blocks):
             ctx, x = blk(x, ctx, temb, rope, pol)
+            if controlnet_single_block_samples is not None:
+                n = len(controlnet_single_block_samples)
+                x = pol.r(x + controlnet_single_block_samples[i // int(math.ceil(len(self.single_transformer_blocks) / n))])
         x = pol.r(self.norm_out(x, temb))
         return pol.r(self.proj_out(x))
 

@@ -18,6 +18,8 @@ executed; only inputs and outputs (tensors) are saved.  What each fixture pins:
   hunyuan15_hybrid.pt   the reference's OWN HunyuanVideo15Transformer3DModel / block / attention processor / token refiner
                         (transformer/hunyuanvideo15/base/model.py) on a tiny config, t2v and i2v token orders, leaves
                         from oracle.layers: pins the wiring of oracle.hunyuan15.
+  flux_controlnet.pt    the reference Flux model fed ControlNet residual samples (interval and repeat placement) — pins oracle.flux's
+                        and the HIP model's `controlnet_block_samples` / `controlnet_single_block_samples` inputs.
   wan_easycache.pt      the reference's EasyCache forward (transformer/wan/base/model.py:202-520) on the tiny reference Wan model driven
                         like a CFG sampler: which calls run / are served from the cache, every output — pins oracle.easycache.
   flux_scheduler.pt     oracle FlowMatch-Euler trajectory (restatement only; diffusers absent).
@@ -249,6 +251,32 @@ def gen_flux_hybrid():
     torch.save(dict(config=TINY_FLUX, seed=7, inputs=inp, out=out, keys=sorted(sd.keys())),
                os.path.join(OUT, "flux_hybrid.pt"))
     print("flux_hybrid.pt", tuple(out.shape), float(out.abs().mean()), missing)
+
+
+def gen_flux_controlnet():
+    """The reference FluxTransformer2DModel fed ControlNet residuals (`controlnet_block_samples` / `controlnet_single_block_samples`,
+    `controlnet_blocks_repeat`; transformer/flux/base/model.py:594-640): a 3 + 3-block model with 2 double samples (interval
+    ceil(3 / 2) = 2, or index mod 2 with `controlnet_blocks_repeat`) and 2 single samples — pins the residual placement of
+    oracle.flux and the HIP model."""
+    from src.transformer.flux.base.model import FluxTransformer2DModel as RefFlux
+    cfg = dict(TINY_FLUX, num_layers=3, num_single_layers=3)
+    ref = RefFlux(**cfg).eval()
+    sd = synthetic_state_dict(ref, 17)
+    ref.load_state_dict(sd, strict=True)
+    inp = tiny_flux_inputs()
+    n_img, dim = inp["hidden_states"].shape[1], cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    cd = [seeded((1, n_img, dim), 70 + i) * 0.5 for i in range(2)]
+    cs = [seeded((1, n_img, dim), 80 + i) * 0.5 for i in range(2)]
+    outs = {}
+    with torch.no_grad():
+        for name, kw in (("interval", dict(controlnet_block_samples=cd, controlnet_single_block_samples=cs)),
+                         ("repeat", dict(controlnet_block_samples=cd, controlnet_blocks_repeat=True)),
+                         ("none", dict())):
+            outs[name] = ref(return_dict=False, **dict(inp), **kw)[0]
+    assert float((outs["interval"] - outs["none"]).abs().max()) > 1e-3 and float((outs["repeat"] - outs["interval"]).abs().max()) > 1e-3
+    torch.save(dict(config=cfg, seed=17, inputs=inp, double_seeds=(70, 71), single_seeds=(80, 81), scale=0.5, out=outs,
+                    keys=sorted(sd.keys())), os.path.join(OUT, "flux_controlnet.pt"))
+    print("flux_controlnet.pt", {k: float(v.abs().mean()) for k, v in outs.items()})
 
 
 TINY_WAN = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=16,
@@ -1200,11 +1228,11 @@ def gen_leaf_pins2():
 
 
 # Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
-FIXTURES = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "wan_easycache", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
             "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
             "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
 # the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
-FAST = ["attention", "efficiency", "flux_hybrid", "wan_hybrid", "wan_easycache", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
         "convert"]
 
 

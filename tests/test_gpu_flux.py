@@ -387,3 +387,46 @@ def test_batch_of_images_on_streams_is_bit_identical_to_the_sequential_walk():
                 assert torch.equal(one[0], first[b])
     assert torch.isfinite(outs[2].float()).all() and torch.equal(outs[1], outs[2])
     assert not torch.equal(outs[2][0], outs[2][1])
+
+
+def test_controlnet_residual_inputs_match_the_reference_run(golden_dir):
+    """`controlnet_block_samples` / `controlnet_single_block_samples` / `controlnet_blocks_repeat` (reference
+    transformer/flux/base/model.py:594-640): residuals added to the image stream after each block.  `flux_controlnet.pt` is the
+    reference model's own output (3 + 3 blocks, 2 + 2 samples, interval and repeat placement): the float-storage mode directly
+    against it (1e-4), production bf16 against the oracle's bf16 policy (the usual free-running bar)."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    g = torch.load(os.path.join(golden_dir, "flux_controlnet.pt"), weights_only=False)
+    cfg = g["config"]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    inp = g["inputs"]
+    n_img, dim = inp["hidden_states"].shape[1], orc.inner_dim
+    cd = [seeded((1, n_img, dim), s) * g["scale"] for s in g["double_seeds"]]
+    cs = [seeded((1, n_img, dim), s) * g["scale"] for s in g["single_seeds"]]
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    modes = (("interval", dict(controlnet_block_samples=cd, controlnet_single_block_samples=cs)),
+             ("repeat", dict(controlnet_block_samples=cd, controlnet_blocks_repeat=True)))
+    m.set_storage_dtype(torch.float32)
+    for name, kw in modes:
+        out = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()},
+                **{k: ([t.to(DEV) for t in v] if isinstance(v, list) else v) for k, v in kw.items()})[0].cpu()
+        rel = _rel(out, g["out"][name])
+        print(f"[controlnet {name}] float-storage mode vs the reference run: rel L2 {rel:.2e}")
+        assert rel < 1e-4, (name, rel)
+    m.set_storage_dtype(torch.bfloat16)
+    rin = {k: (v.to(torch.bfloat16).float() if k in ("hidden_states", "encoder_hidden_states", "pooled_projections") else v)
+           for k, v in inp.items()}
+    args = (rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"], rin["img_ids"],
+            rin["txt_ids"], rin["guidance"])
+    for name, kw in modes:
+        kb = {k: ([t.to(torch.bfloat16).float() for t in v] if isinstance(v, list) else v) for k, v in kw.items()}
+        ref16 = orc(*args, policy=OL.BF16_STORAGE, **kb)
+        gin = {k: (v.to(DEV).to(torch.bfloat16) if k in ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV))
+               for k, v in inp.items()}
+        out = m(return_dict=False, **gin, **{k: ([t.to(DEV).to(torch.bfloat16) for t in v] if isinstance(v, list) else v)
+                                             for k, v in kw.items()})[0].float().cpu()
+        assert _rel(out, ref16) < 6e-3, (name, _rel(out, ref16))
+    plain = m(return_dict=False, **gin)[0].float().cpu()
+    assert _rel(plain, g["out"]["none"]) < 3e-2 and _rel(plain, out) > 1e-3

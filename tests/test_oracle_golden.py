@@ -63,6 +63,26 @@ def test_flux_wiring_matches_reference_blocks(golden_dir):
     assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
 
 
+def test_flux_controlnet_residual_placement_matches_reference(golden_dir):
+    """`controlnet_block_samples` / `controlnet_single_block_samples` / `controlnet_blocks_repeat` of the reference Flux forward
+    (transformer/flux/base/model.py:594-640) — 3 + 3 blocks, 2 + 2 samples: oracle.flux vs the reference run."""
+    g = _load(golden_dir, "flux_controlnet.pt")
+    model = OF.FluxTransformer2DModel(**g["config"]).eval()
+    assert sorted(model.state_dict().keys()) == g["keys"]
+    model.load_state_dict(synthetic_state_dict(model, g["seed"]), strict=True)
+    inp = g["inputs"]
+    n_img, dim = inp["hidden_states"].shape[1], model.inner_dim
+    cd = [seeded((1, n_img, dim), s) * g["scale"] for s in g["double_seeds"]]
+    cs = [seeded((1, n_img, dim), s) * g["scale"] for s in g["single_seeds"]]
+    args = (inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"], inp["img_ids"],
+            inp["txt_ids"], inp["guidance"])
+    for name, kw in (("interval", dict(controlnet_block_samples=cd, controlnet_single_block_samples=cs)),
+                     ("repeat", dict(controlnet_block_samples=cd, controlnet_blocks_repeat=True)), ("none", {})):
+        out = model(*args, **kw)
+        rel = float((out - g["out"][name]).norm() / g["out"][name].norm())
+        assert rel < 1e-5, (name, rel)
+
+
 def test_bf16_storage_policy_is_close_to_fp32(golden_dir):
     g = _load(golden_dir, "flux_hybrid.pt")
     model = OF.FluxTransformer2DModel(**g["config"]).eval()
@@ -365,7 +385,7 @@ def test_fixture_recipe_reproduces_the_committed_files():
                        capture_output=True, text=True, timeout=600, cwd=root)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
-    assert "22 generators -> 22 files compared, 0 mismatches" in r.stdout, tail
+    assert "23 generators -> 23 files compared, 0 mismatches" in r.stdout, tail
 
 
 def test_easycache_restatement_matches_the_reference_function(golden_dir):
