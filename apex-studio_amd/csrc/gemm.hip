@@ -1997,6 +1997,7 @@ int g_tail_max = 96;   // tune key gemm.tail_max: largest tail problem (in 256x2
                        // stream of Flux's FF-up, 512 x 12288: 864 tiles = 3.4 rounds as one launch; 71.5 -> 70.9 ms per step split)
 int g_x288 = 0;       // tune key gemm.x288: the 288 x 192 exact-fill tiling — 0 never (SHIPPED: it measured slower, see the kernel's header) |
                       // 1 where it saves a round's worth of tile-work | 2 always (A/B, tests)
+int g_x384_group_m = 3; // tune key gemm.x384_group_m: tile-group height of the 384 x 256 launches
 int g_x384_dist = -1; // tune key gemm.x384_dist: how a wave's 10 pieces are spread over the 4 phases (0: 3+3+2+2, 1: 2+3+2+3, -1: by launch size)
 int g_x384_qkv = 1;   // tune key gemm.x384_qkv: launches with the fused q/k/v epilogue may use the 384 x 256 tiling too (A/B)
 int g_x384 = 1;       // tune key gemm.x384: the 384 x 256 tiling — 0 never | 1 where its staged bytes win (x384_pays; SHIPPED) | 2 always (A/B, tests)
@@ -2118,7 +2119,9 @@ int launch_x384(GemmGroup& G, const int* Ms, hipStream_t stream) {
         t += G.p[i].nm * G.p[i].nn;
     }
     G.total = t;
-    G.group_m = g_group_m;
+    // tile groups 3 tall: an XCD's 32 concurrent tiles as 3 x 10.7 = 1152 activation rows x 2730 weight rows per K-slice (6 tall: 2304 x
+    // 1365) — on the 75 600-row launches +2..4 % (profiles/r05_gemm_x384_group_m.log), the same on the 12-row-tile Flux launch
+    G.group_m = g_x384_group_m;
     G.clk = apexmi_clk_ptr();
     G.wpacked = 0;
     G.sk_r = G.sk_tfull = 0;
@@ -2485,6 +2488,7 @@ int apexmi_set_gemm_key(const char* key, int value) {
     else if (!strcmp(key, "gemm.small_max")) g_small_max = value;
     else if (!strcmp(key, "gemm.x384")) g_x384 = value;
     else if (!strcmp(key, "gemm.x384_dist")) g_x384_dist = value;
+    else if (!strcmp(key, "gemm.x384_group_m")) g_x384_group_m = value > 0 ? value : 3;
     else if (!strcmp(key, "gemm.x384_qkv")) g_x384_qkv = value;
 #if APEXMI_GEMM_TRACE
     else if (!strcmp(key, "gemm.trace_lo")) g_gemm_trace = (g_gemm_trace & ~(uintptr_t)0xffffffffu) | (uint32_t)value;
