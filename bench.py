@@ -894,6 +894,7 @@ def main():
         # GEMM workgroup stamps its K-loop with s_memtime (shader cycles) and s_memrealtime (100 MHz) — apexmi_clk_*.
         if dom == "gemm":
             nclk = min(5, args.steps)
+            reset(total)                      # the scheduler's step index: the roofline pass above consumed some of the timesteps
             begin(0, nclk)
             lat = latents
             lib.clk_enable(True)
