@@ -180,8 +180,10 @@ def test_flux_forward_identical_with_and_without_the_fusion():
     assert torch.equal(a, b)
 
 
-def test_fused_epilogue_race_screen():
-    """The fused epilogue reuses the GEMM's staging LDS (cross-wave sums, the V tile) right after the main loop, whose two
+@pytest.mark.parametrize("tiling", [256, 384])
+def test_fused_epilogue_race_screen(tiling, x384):
+    """(tiling 384: the same screen on the 384 x 256 tiling — its V^T leaves in two LDS passes, one per M-half.)
+    The fused epilogue reuses the GEMM's staging LDS (cross-wave sums, the V tile) right after the main loop, whose two
     M-halves run a barrier apart: 60 back-to-back launches at a Flux-like shape (K deep enough for the ping-pong to be in steady
     state, unaligned text stream) must all give the same bits."""
     from apex_studio_amd import ops
@@ -197,6 +199,7 @@ def test_fused_epilogue_race_screen():
     nk = [_rand((128,), 39) * 0.2 + 1, _rand((128,), 40) * 0.2 + 1]
     rope = _rope(S, 41)
     ref = None
+    x384(2 if tiling == 384 else 0)
     for it in range(60):
         q, k = (torch.full((H, S, 128), 3.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
         vt = torch.zeros(H, 128, skp, device=DEV, dtype=torch.bfloat16)
@@ -206,6 +209,7 @@ def test_fused_epilogue_race_screen():
             ref = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(cur, ref)), it
+    x384(1)
     assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[2].float()).all()
 
 
