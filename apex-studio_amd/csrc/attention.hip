@@ -263,13 +263,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_kernel(
 // (bf16) and the log2-sum-exp of its rows, attn_combine_kernel merges them.
 // NS = LDS stages of the K / V^T tiles: 2 (shipped: tile t + 1 is staged during tile t and waited for three clusters later) or 3
 // (tile t + 2 staged during tile t: a whole tile more of slack for loads that miss L2 — `attn.stages`, A/B).
-template <int NW, int PRIO, int NS = 2>
+// XV = experiment bits (`attn.xv`, A/B; 0 = shipped).  Bits 0-1 (DMA): the cluster a wave issues the next tile's LDS-DMA pieces from:
+// 0 = C1 beside the K fragment reads, 1 = C2, one piece after every fourth QK^T MFMA, 2 = C3 right after the V^T fragment reads are
+// issued, 3 = C3 behind the softmax (three stages only: the late half would wait for its own pieces at once otherwise).  Bit 2: the
+// row sum of P is taken in the issue gaps of the wave's own P V MFMAs (C4) as four independent partial sums, instead of one
+// dependent 16-deep v_pk_add_f32 chain that LLVM sinks BEHIND those MFMAs (~270 cycles of C4, tools/attn_cluster_trace.py);
+// bit 3: so are the bf16 conversions of key groups 1..3; bit 4: and their exponentials (needs bit 3).  Bit 5: the row sum stays in
+// C3 as four independent packed partial sums (pinned there).  Bit 6: C3's softmax with scalar f32 VALU only (inline asm keeps the SLP
+// vectoriser from re-packing it), eight partial sums pinned in C3.
+template <int NW, int PRIO, int NS = 2, int XV = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int H, int Sq, int Sk_all, int Skp, int nqb, int total, int64_t o_sb,
     int64_t o_ss, int64_t o_sh, float scale_log2e, int s_base, int nsplit, float* __restrict__ opart,
     float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DMA = XV & 3;
+    constexpr bool GAPS = (XV & 4) != 0;               // row sums (+ bit 3: bf16 pairs, + bit 4: exponentials) in C4's MFMA gaps
+    constexpr int CVT_C3 = (XV & 8) ? 1 : 4;           // key groups converted to bf16 in C3
+    constexpr int EXP_C3 = (XV & 16) ? 1 : 4;          // key groups exponentiated in C3
+    static_assert(!(XV & 16) || (XV & 8), "attn.xv bit 4 needs bit 3");
 #if APEXMI_ATTN_TRACE
     unsigned long long* const trace = d_attn_trace;
     unsigned long long tr_in = 0, tr_l0 = 0, tr_l1 = 0;
@@ -328,18 +341,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         }
     }
 
-    auto stage = [&](int buf, int t) {
+    const int nt = (Sk + KV - 1) / KV;
+    constexpr bool ALLP = (16 % NW) == 0;   // every wave owns LD whole pieces: no wave-uniform guard (and no branch) in the loop
+    auto stage_piece = [&](int buf, int t, int j) {   // j < LD: K piece j; j >= LD: V^T piece j - LD
         char* base = smem + buf * ATT_STAGE + wave * 1024;
         const int kv0 = t * KV;
-#pragma unroll
-        for (int i = 0; i < LD; ++i)
-            if (i * NW + wave < 16) {  // wave-uniform
+        if (j < LD) {
+            const int i = j;
+            if (ALLP || i * NW + wave < 16) {  // wave-uniform
                 const int key = min(kv0 + k_key[i], Sk - 1);
                 glds16(Kp + (int64_t)key * HD + k_c[i], base + i * (NW * 1024));
             }
+        } else {
+            const int i = j - LD;
+            if (ALLP || i * NW + wave < 16) glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * (NW * 1024));
+        }
+    };
+    auto stage = [&](int buf, int t) {
 #pragma unroll
-        for (int i = 0; i < LD; ++i)
-            if (i * NW + wave < 16) glds16(v_src[i] + (int64_t)kv0 * 2, base + K_TILE_BYTES + i * (NW * 1024));
+        for (int j = 0; j < 2 * LD; ++j) stage_piece(buf, t, j);
+    };
+    auto stage_next = [&](int t, int slot) {   // the loop's prefetch: tile t + 1 (two stages) or t + 2 (three)
+        if (NS == 2) {
+            if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        } else if (t + 2 < nt) {
+            stage(slot == 0 ? 2 : slot - 1, t + 2);             // (slot + 2) % 3: the stage tile t - 1 was read from
+        }
     };
 
     // LDS read offsets
@@ -375,7 +402,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     // Waves 4..7 run one cluster behind waves 0..3, so on every SIMD one wave is in a matrix cluster while its partner
     // is in a load cluster: the fragment reads (-15 % when interleaved with the MFMAs they feed, profiles/
     // r01_attention_notes.md) and the softmax run in the partner's matrix time.
-    const int nt = (Sk + KV - 1) / KV;
     const bool late = wave >= NW / 2;
     bf16x8 kv[16];
     f32x16 sacc[2];
@@ -391,6 +417,40 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
         C4_BAR();                                                \
     } while (0)
+    // cluster-level stamps (-DAPEXMI_ATTN_TRACE=2, tools/attn_cluster_trace.py): waves 0 and NW/2 stamp s_memtime (core cycles) right
+    // after every barrier and right before the cluster's closing wait, for the tiles TRW0 .. TRW0 + 7, into 1 KiB of LDS behind the
+    // stages; the pair of a cluster is written at the start of the next one (its SMEM returns ride out the barrier wait)
+#if APEXMI_ATTN_TRACE >= 2
+    constexpr int TRW0 = 16;
+    unsigned long long ts_a = 0, ts_b = 0, ts_m = 0, ts_n = 0;
+    char* const tr_lds = smem + NS * ATT_STAGE;
+    const bool tr_wave = trace && (wave == 0 || wave == NW / 2);
+#define TR_START() do { if (tr_wave) asm volatile("s_memtime %0" : "=s"(ts_a)); } while (0)
+#define TR_END()   do { if (tr_wave) asm volatile("s_memtime %0" : "=s"(ts_b)); } while (0)
+#define TR_MID()   do { if (tr_wave) asm volatile("s_memtime %0" : "=s"(ts_m)); } while (0)
+#define TR_MID2(v) do { if (tr_wave) asm volatile("s_memtime %0" : "=s"(ts_n), "+v"(v)); else asm volatile("" : "+v"(v)); } while (0)
+#define TR_END_DEP(v) do { if (tr_wave) asm volatile("s_memtime %0" : "=s"(ts_b), "+v"(v)); else asm volatile("" : "+v"(v)); } while (0)
+#define TR_FLUSH(tt, c)                                                                                      \
+    do {                                                                                                     \
+        if (tr_wave && (tt) >= TRW0 && (tt) < TRW0 + 8) {                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts_a), "+s"(ts_b), "+s"(ts_m), "+s"(ts_n)::"memory"); \
+            if (lane == 0) {                                                                                 \
+                unsigned long long* d = (unsigned long long*)(tr_lds) + ((late ? 32 : 0) + ((tt) - TRW0) * 4 + (c)) * 4; \
+                d[0] = ts_a;                                                                                 \
+                d[1] = ts_b;                                                                                 \
+                d[2] = ts_m;                                                                                 \
+                d[3] = ts_n;                                                                                 \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+#else
+#define TR_START() do {} while (0)
+#define TR_END() do {} while (0)
+#define TR_MID() do {} while (0)
+#define TR_MID2(v) do {} while (0)
+#define TR_END_DEP(v) do {} while (0)
+#define TR_FLUSH(tt, c) do {} while (0)
+#endif
     stage(0, 0);
     if (NS == 3 && nt > 1) {
         stage(1, 1);
@@ -408,18 +468,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
     for (int t = 0; t < nt; ++t) {
         const char* Ks = smem + (NS == 2 ? (t & 1) : slot) * ATT_STAGE;
         const char* Vs = Ks + K_TILE_BYTES;
+        TR_FLUSH(t - 1, 3);
+        TR_START();
         // ---- C1: K fragments -> registers; LDS-DMA of the next tile (its stage was last read two clusters ago) ----
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
                 kv[ks * 2 + kt] = *(const bf16x8*)(Ks + k_off[kt] + (((ks * 2 + hi) ^ k_sw[kt]) << 4));
-        if (NS == 2) {
-            if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        } else if (t + 2 < nt) {
-            stage(slot == 0 ? 2 : slot - 1, t + 2);             // (slot + 2) % 3: the stage tile t - 1 was read from
-        }
+        TR_MID();
+        if (DMA == 0) stage_next(t, slot);
+        TR_END();
         C4_LGKM_BAR();
+        TR_FLUSH(t, 0);
+        TR_START();
         // ---- C2: S^T = K Q^T ----
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -429,10 +491,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[ks * 2 + kt], qf[ks], sacc[kt], 0, 0, 0);
+                if (DMA == 1 && kt == 1 && (ks & 1) == 0 && (ks >> 1) < 2 * LD) {   // after MFMAs 2, 6, 10, 14
+                    const int j = ks >> 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (NS == 2) {
+                        if (t + 1 < nt) stage_piece((t + 1) & 1, t + 1, j);
+                    } else if (t + 2 < nt) {
+                        stage_piece(slot == 0 ? 2 : slot - 1, t + 2, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
+        TR_MID();
+        TR_END();
         C4_BAR();
+        TR_FLUSH(t, 1);
+        TR_START();
         // ---- C3: V^T fragments -> the same registers, softmax beside the reads ----
         if (!(APEXMI_ATTN_ABLATE & 4)) {
 #pragma unroll
@@ -440,6 +517,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     kv[kk * 4 + dt] = *(const bf16x8*)(Vs + v_off[dt] + (((kk * 2 + hi) ^ v_sw[dt]) << 4));
+        }
+        TR_MID();
+        if (DMA == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_next(t, slot);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (t == nt - 1 && (Sk & (KV - 1)) != 0) {   // mask keys past Sk (wave-uniform branch)
             const int kv0 = t * KV;
@@ -455,11 +538,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         {
             float mx = sacc[0][0];
             if (!(APEXMI_ATTN_ABLATE & 2)) {
+                if (XV & 128) {   // four independent chains instead of one 16-deep v_max3 chain (max is exact: same result)
+                    float m4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        m4[c] = sacc[c >> 1][8 * (c & 1)];
+#pragma unroll
+                        for (int j = 1; j < 8; ++j) m4[c] = fmaxf(m4[c], sacc[c >> 1][8 * (c & 1) + j]);
+                    }
+                    mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+                } else {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+                }
                 mx = max_xor32(mx) * scale_log2e;
+                TR_MID2(mx);
             }
             if (__any(mx > m_run + DEFER)) {
                 const float m_new = ceilf(fmaxf(m_run, mx));   // integer: see the note above DEFER
@@ -471,10 +566,81 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             }
+            if (GAPS) {
+                // `attn.xv` bit 2: the tail of the softmax runs in the gaps of this wave's OWN P V MFMAs (C4): here only the
+                // scaled differences (packed fma), and the exponentials + bf16 conversion of the key groups C4 does not take
+                const f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+                const float nm = -m_run;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 x = {sacc[kt][r], sacc[kt][r + 1]};
+                        if (XV & 64) {   // scalar fma (inline asm: the SLP vectoriser would re-pack it)
+                            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x[0]) : "v"(sacc[kt][r]), "s"(scale_log2e), "v"(nm));
+                            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x[1]) : "v"(sacc[kt][r + 1]), "s"(scale_log2e), "v"(nm));
+                        } else {
+                            x = __builtin_elementwise_fma(x, c2, nm2);
+                        }
+                        if (kt * 2 + (r >> 3) < EXP_C3) {
+                            x[0] = fast_exp2(x[0]);
+                            x[1] = fast_exp2(x[1]);
+                        }
+                        sacc[kt][r] = x[0];
+                        sacc[kt][r + 1] = x[1];
+                    }
+#pragma unroll
+                for (int kk = 0; kk < CVT_C3; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[kk][j] = (__bf16)sacc[kk >> 1][8 * (kk & 1) + j];
+            } else {
             if (PRIO & 2) {
                 // packed f32 math: one v_pk_fma_f32 / v_pk_add_f32 per PAIR of scores (the accumulator registers of an
                 // MFMA are consecutive, so the pairs are already aligned) — 32 fewer VALU issues per tile and wave
                 const f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+                if (XV & 64) {
+                    // no packed f32 at all (a v_pk_* beside the partner's MFMAs waits ~30 cycles, tools/attn_cluster_trace.py):
+                    // scalar fma / exp / add, eight independent partial sums, pinned to this cluster
+                    float pq[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    const float nm = -m_run;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 8) {   // batches of eight: no instruction waits for the one before it
+                            float z[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z[j]) : "v"(sacc[kt][r0 + j]), "s"(scale_log2e), "v"(nm));
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) z[j] = fast_exp2(z[j]);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                sacc[kt][r0 + j] = z[j];
+                                asm("v_add_f32 %0, %1, %2" : "=v"(pq[j]) : "v"(pq[j]), "v"(z[j]));
+                            }
+                        }
+                    l_run += ((pq[0] + pq[1]) + (pq[2] + pq[3])) + ((pq[4] + pq[5]) + (pq[6] + pq[7]));
+                    asm volatile("" : "+v"(l_run));
+                } else if (XV & 32) {
+                    // row sum as FOUR independent packed partial sums, pinned to this cluster: the single 16-deep dependent
+                    // chain of v_pk_add_f32 that LLVM otherwise sinks behind the P V MFMAs costs C4 ~270 cycles
+                    f32x2 pq[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            f32x2 x = {sacc[kt][r], sacc[kt][r + 1]};
+                            x = __builtin_elementwise_fma(x, c2, nm2);
+                            x[0] = fast_exp2(x[0]);
+                            x[1] = fast_exp2(x[1]);
+                            sacc[kt][r] = x[0];
+                            sacc[kt][r + 1] = x[1];
+                            pq[(r >> 1) & 3] += x;
+                        }
+                    const f32x2 pt = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+                    l_run += pt[0] + pt[1];
+                    asm volatile("" : "+v"(l_run));
+                } else {
                 f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -491,6 +657,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
                         ps2 += x;
                     }
                 l_run += ps2[0] + ps2[1];
+                }
             } else {
                 float psum = 0.0f;
 #pragma unroll
@@ -507,6 +674,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[kk][j] = (__bf16)sacc[kk >> 1][8 * (kk & 1) + j];
+            }
+        }
+        if (DMA == 3) {
+            static_assert(DMA != 3 || NS == 3, "attn.xv & 3 == 3 needs three stages");
+            __builtin_amdgcn_sched_barrier(0);
+            stage_next(t, slot);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // this wave's LDS-DMA pieces of tile t+1 must have landed before the barrier that opens the first cluster
         // reading them: the early half's C1(t+1) follows ITS C4(t) and the late half's C3(t) in the same slot
@@ -514,25 +688,81 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
             if (NS == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t + 1; t + 2's pieces may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        TR_END_DEP(pf[CVT_C3 - 1]);
         C4_LGKM_BAR();
+        TR_FLUSH(t, 2);
+        TR_START();
         // ---- C4: O^T += V^T P^T ----
         if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
+        if (GAPS) {
+            // key group g = 8 keys = the B operand of k-step g.  While the four MFMAs of k-step kk are in the pipe, this wave's
+            // issue slots take pair dt of group kk + 1: (its two exponentials,) (its bf16 pair,) and its two terms of the row sum
+            // (four partial sums: no add waits for the one before it); group 0's terms ride with k-step 3
+            float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#define PV_SLOT(kk, dt)                                                                                              \
+    do {                                                                                                             \
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[(kk) * 4 + (dt)], pf[kk], oacc[dt], 0, 0, 0);          \
+        constexpr int gq = (kk) < 3 ? (kk) + 1 : 0;                                                                  \
+        constexpr int ix = 8 * (gq & 1) + 2 * (dt);                                                                  \
+        float a = sacc[gq >> 1][ix], b = sacc[gq >> 1][ix + 1];                                                      \
+        if ((kk) < 3 && gq >= EXP_C3) {                                                                              \
+            a = fast_exp2(a);                                                                                        \
+            b = fast_exp2(b);                                                                                        \
+        }                                                                                                            \
+        if ((kk) < 3 && gq >= CVT_C3) {                                                                              \
+            pf[gq][2 * (dt)] = (__bf16)a;                                                                            \
+            pf[gq][2 * (dt) + 1] = (__bf16)b;                                                                        \
+        }                                                                                                            \
+        ps[2 * ((dt) & 1)] += a;                                                                                     \
+        ps[2 * ((dt) & 1) + 1] += b;                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(                                                                        \
+            0x002, 2 + (((kk) < 3 && gq >= EXP_C3) ? 2 : 0) + (((kk) < 3 && gq >= CVT_C3) ? 1 : 0), 0);              \
+    } while (0)
+#define PV_STEP(kk) do { PV_SLOT(kk, 0); PV_SLOT(kk, 1); PV_SLOT(kk, 2); PV_SLOT(kk, 3); } while (0)
+            PV_STEP(0);
+            PV_STEP(1);
+            PV_STEP(2);
+            PV_STEP(3);
+#undef PV_STEP
+#undef PV_SLOT
+            // LLVM sinks a value to its use: without the pins the sixteen adds leave this block (and the MFMA gaps) again
+            asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]));
+            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv[kk * 4 + dt], pf[kk], oacc[dt], 0, 0, 0);
+        }
         if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
+        TR_MID();
         if (!late) {
             if (NS == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        TR_END();
         C4_BAR();
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
+    TR_FLUSH(nt - 1, 3);
     if (!late) C4_BAR();       // balance the barrier count of the two halves
+#if APEXMI_ATTN_TRACE >= 2
+    if (trace) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        C4_BAR();
+        if (tid < 256) trace[(size_t)blockIdx.x * 264 + 8 + tid] = ((const unsigned long long*)tr_lds)[tid];
+    }
+#endif
 #undef C4_BAR
 #undef C4_LGKM_BAR
+#undef TR_START
+#undef TR_END
+#undef TR_MID
+#undef TR_MID2
+#undef TR_END_DEP
+#undef TR_FLUSH
 #if APEXMI_ATTN_TRACE
     if (trace) {
         __builtin_amdgcn_sched_barrier(0);
@@ -582,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_ack = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned long long* o = trace + (size_t)blockIdx.x * 8;
+            unsigned long long* o = trace + (size_t)blockIdx.x * (APEXMI_ATTN_TRACE >= 2 ? 264 : 8);
             o[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
             o[1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
             o[2] = tr_in;
@@ -1148,6 +1378,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
 int g_attn_stages = 2;  // apexmi_tune_set("attn.stages", 2/3): LDS stages of the shipped 4-cluster kernel
+int g_attn_xv = 0;      // apexmi_tune_set("attn.xv", 0..7): experiment bits of the 4-cluster kernel (its comment)
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
 // (measured with the limit raised to 3/4 of a round: the Flux launch, 256 + 176 workgroups, gets 13 % SLOWER, 0.281 vs
@@ -1222,11 +1453,44 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
             attn_fwd_d128_c4_kernel<8, 6>, attn_fwd_d128_c4_kernel<8, 7>};
         auto c4 = c4_tab[var];
         const bool s3 = g_attn_stages == 3 && var == 2;          // the 3-stage form exists for the shipped variant only
-        if (s3) c4 = attn_fwd_d128_c4_kernel<8, 2, 3>;
-        const int c4_lds = (s3 ? 3 : 2) * ATT_STAGE;
-        static uint64_t c4_attr[9] = {};
-        APEXMI_SET_ATTR_ONCE(c4_attr[s3 ? 8 : var],
-            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, c4_lds));
+        int attr_slot = var;
+        if (var == 2 && (s3 || g_attn_xv)) {                      // stage count x experiment bits, shipped softmax variant only
+            void (*x)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, int, int64_t, int64_t,
+                      int64_t, float, int, int, float*, float*) = nullptr;
+            switch (g_attn_xv + (s3 ? 100 : 0)) {
+                case 0: x = attn_fwd_d128_c4_kernel<8, 2, 2, 0>; break;
+                case 1: x = attn_fwd_d128_c4_kernel<8, 2, 2, 1>; break;
+                case 2: x = attn_fwd_d128_c4_kernel<8, 2, 2, 2>; break;
+                case 4: x = attn_fwd_d128_c4_kernel<8, 2, 2, 4>; break;
+                case 12: x = attn_fwd_d128_c4_kernel<8, 2, 2, 12>; break;
+                case 28: x = attn_fwd_d128_c4_kernel<8, 2, 2, 28>; break;
+                case 32: x = attn_fwd_d128_c4_kernel<8, 2, 2, 32>; break;
+                case 64: x = attn_fwd_d128_c4_kernel<8, 2, 2, 64>; break;
+                case 92: x = attn_fwd_d128_c4_kernel<8, 2, 2, 92>; break;
+                case 156: x = attn_fwd_d128_c4_kernel<8, 2, 2, 156>; break;
+                case 220: x = attn_fwd_d128_c4_kernel<8, 2, 2, 220>; break;
+                case 128: x = attn_fwd_d128_c4_kernel<8, 2, 2, 128>; break;
+                case 100: x = attn_fwd_d128_c4_kernel<8, 2, 3, 0>; break;
+                case 101: x = attn_fwd_d128_c4_kernel<8, 2, 3, 1>; break;
+                case 102: x = attn_fwd_d128_c4_kernel<8, 2, 3, 2>; break;
+                case 103: x = attn_fwd_d128_c4_kernel<8, 2, 3, 3>; break;
+                default: break;
+            }
+            if (!x) {
+                apexmi_set_error("attn_fwd_prepared: attn.xv=%d with attn.stages=%d is not built", g_attn_xv, s3 ? 3 : 2);
+                return 1;
+            }
+            c4 = x;
+            attr_slot = -1;
+        }
+        const int c4_lds = (s3 ? 3 : 2) * ATT_STAGE + (APEXMI_ATTN_TRACE >= 2 ? 2048 : 0);
+        static uint64_t c4_attr[8] = {};
+        if (attr_slot < 0) {   // experiment arms: set on every call
+            (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, c4_lds);
+        } else {
+            APEXMI_SET_ATTR_ONCE(c4_attr[attr_slot],
+                (void)hipFuncSetAttribute((const void*)c4, hipFuncAttributeMaxDynamicSharedMemorySize, c4_lds));
+        }
         int tail = attn_tail(total, Sk);
         const size_t need = (size_t)tail * ATT_NSPLIT * 256 * (HD * 4 + 8);
         if (tail && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)) tail = 0;
@@ -1279,6 +1543,7 @@ void apexmi_set_attn_waves(int v) { g_attn_waves = v; }
 void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
 void apexmi_set_attn_stages(int v) { g_attn_stages = v; }
+void apexmi_set_attn_xv(int v) { g_attn_xv = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && (int64_t)Sq * Sk >= 256 * 256)

@@ -168,6 +168,7 @@ void apexmi_set_attn_mfma(int v);
 void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
 void apexmi_set_attn_stages(int v);
+void apexmi_set_attn_xv(int v);
 void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 void apexmi_set_conv_v2(int v);
@@ -218,6 +219,9 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         return 0;
     } else if (!strcmp(key, "attn.stages")) {
         apexmi_set_attn_stages(value);
+        return 0;
+    } else if (!strcmp(key, "attn.xv")) {
+        apexmi_set_attn_xv(value);
         return 0;
     } else if (!strcmp(key, "attn.waves")) {
         apexmi_set_attn_waves(value);
