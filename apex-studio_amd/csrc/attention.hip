@@ -827,6 +827,97 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 }
 
 
+// ---- one wave per SIMD, 64 query rows per wave (`attn.w64`) ----------------------------------------------------
+// What the cluster trace of the 4-cluster kernel says (tools/attn_cluster_trace.py, profiles/r05_attn_cluster_trace*.log): with two
+// waves per SIMD the softmax VALU of a load cluster gets almost no issue slots while the partner's MFMA cluster streams, every
+// cluster hand-over costs a barrier, and a KV tile takes ~3800 cycles for 2048 cycles of MFMAs.  This kernel keeps the products, the
+// LDS images and the fragment / score / P lane mapping of that kernel and changes the schedule: 4 waves, ONE per SIMD, each owning
+// two 32-row query blocks (A, B) and the whole 512-register file; every K / V^T fragment read from LDS feeds TWO MFMAs; the softmax
+// of a tile is split over the two 32-MFMA phases of the loop and issued in the wave's OWN MFMA gaps:
+//   phase X(t): S(t+1) = K(t+1) Q^T  (32 MFMAs)  beside  exp2 / row-sum terms / bf16 pairs of tile t
+//   phase Y(t): O^T += V^T(t) P(t)^T (32 MFMAs)  beside  row max / running-max decision / scaling of tile t+1
+// One s_barrier per tile, LDS ring of four stages.  The running max is per ROW here (a row is raised when ITS tile max exceeds it
+// by more than DEFER): with the integer max any choice gives the same result up to f32 summation order (note above DEFER).
+// The loop is ONE asm statement generated by tools/gen_attn_w64.py (register map, instruction placement, wait counts and the
+// MFMA -> VALU hazards are the generator's): hipcc's allocator spilled 160-220 registers on every C++ form of it.
+APEXMI_DEVICE int w64_perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_d128_w64_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float scale_log2e) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int s = xcd_remap(blockIdx.x, total);
+    const int hb = s / nqb, qb = s % nqb;
+    const bf16_t* Qp = Q + (int64_t)hb * Sq * HD;
+    const bf16_t* Kp = K + (int64_t)hb * Sk * HD;
+    const bf16_t* Vp = Vt + (int64_t)hb * HD * Skp;
+    const int nt = __builtin_amdgcn_readfirstlane((Sk + KV - 1) / KV);
+    const int rem = __builtin_amdgcn_readfirstlane(Sk & (KV - 1));
+    const int row_a = qb * 256 + wave * 64 + l31;
+    const bf16_t* qa = Qp + (int64_t)min(row_a, Sq - 1) * HD + hi * 8;
+    const bf16_t* qbp = Qp + (int64_t)min(row_a + 32, Sq - 1) * HD + hi * 8;
+    // LDS-DMA: two raw buffer descriptors (base, stride 0, bytes, flags), one per-lane offset each; K rows past Sk read as zero (their
+    // scores are masked), V^T columns past Sk are the zero padding of the buffer.  K piece i of a wave = image rows 16 i + 4 wave +
+    // (lane >> 4) <- keys 16 i + perm32(4 wave + (lane >> 4)), chunk (lane & 15) ^ row; V^T piece i = rows (d) 32 i + 8 wave +
+    // (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
+    const uint64_t kb = (uint64_t)Kp, vb = (uint64_t)Vp;
+    u32x4 rk = {(uint32_t)kb, (uint32_t)(kb >> 32) & 0xffffu, (uint32_t)(Sk * (HD * 2)), 0x00020000u};
+    u32x4 rv = {(uint32_t)vb, (uint32_t)(vb >> 32) & 0xffffu, (uint32_t)((int64_t)HD * Skp * 2), 0x00020000u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rk[j] = __builtin_amdgcn_readfirstlane(rk[j]);
+        rv[j] = __builtin_amdgcn_readfirstlane(rv[j]);
+    }
+    const int krow0 = 4 * wave + (lane >> 4);
+    const int voff_k = w64_perm32(krow0) * (HD * 2) + (((lane & 15) ^ krow0) << 4);
+    const int vrow0 = 8 * wave + (lane >> 3);
+    const int voff_v = vrow0 * Skp * 2 + (((lane & 7) ^ ((vrow0 >> 1) & 7)) << 4);
+    const int v_piece = __builtin_amdgcn_readfirstlane(32 * Skp * 2);
+    const int wbase = wave * 1024;
+    // fragment reads: K image row l31 (+ 32 kt), chunk (2 ks + hi) ^ (row & 15) = ((hi ^ row) & 15) ^ 2 ks; V^T image row l31 (+ 32 dt),
+    // chunk (2 kk + hi) ^ ((row >> 1) & 7)
+    const int ka = l31 * 256 + (((hi ^ l31) & 15) << 4);
+    const int va = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4);
+
+    f32x16 o0, o1, o2, o3, o4, o5, o6, o7;
+    float la, lb;
+    asm volatile(
+#include "attn_w64_body.inc"
+        : "={a[0:15]}"(o0), "={a[16:31]}"(o1), "={a[32:47]}"(o2), "={a[48:63]}"(o3), "={a[64:79]}"(o4), "={a[80:95]}"(o5),
+          "={a[96:111]}"(o6), "={a[112:127]}"(o7), [la] "=&v"(la), [lb] "=&v"(lb)
+        : [qa] "v"(qa), [qb] "v"(qbp), [ka] "v"(ka), [va] "v"(va), [vk] "v"(voff_k), [vv] "v"(voff_v), [rk] "s"(rk), [rv] "s"(rv),
+          [sc] "s"(scale_log2e), [nt] "s"(nt), [rem] "s"(rem), [vp] "s"(v_piece), [w] "s"(wbase)
+        : "memory", "vcc", "scc",
+#include "attn_w64_clobbers.inc"
+    );
+
+    // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
+    const int b = hb / H, h = hb % H;
+    const f32x16* oo[2][4] = {{&o0, &o1, &o2, &o3}, {&o4, &o5, &o6, &o7}};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float inv = 1.0f / sum_xor32(e ? lb : la);
+        const int qrow = row_a + 32 * e;
+        if (qrow < Sq) {
+            bf16_t* op = O + (int64_t)b * o_sb + (int64_t)qrow * o_ss + (int64_t)h * o_sh;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& x = *oo[e][dt];
+                    u32x2 o;
+                    o[0] = pack_bf16(x[4 * g + 0] * inv, x[4 * g + 1] * inv);
+                    o[1] = pack_bf16(x[4 * g + 2] * inv, x[4 * g + 3] * inv);
+                    *(u32x2*)(op + dt * 32 + g * 8 + hi * 4) = o;
+                }
+        }
+    }
+}
+
 // ---- the same kernel on v_mfma_f32_16x16x32_bf16 -----------------------------------------------
 // The denoise step runs at the chip's power limit; at equal matrix-pipe occupancy the 16x16x32 form
 // sustains ~13 % higher clocks than 32x32x16 (tools/ubench/mfma_power.hip), so it is the faster one.
@@ -1378,6 +1469,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
 int g_attn_stages = 2;  // apexmi_tune_set("attn.stages", 2/3): LDS stages of the shipped 4-cluster kernel
+int g_attn_w64 = 0;     // apexmi_tune_set("attn.w64", 0/1): one wave per SIMD, 64 query rows per wave (attn_fwd_d128_w64_kernel)
 int g_attn_xv = 0;      // apexmi_tune_set("attn.xv", 0..7): experiment bits of the 4-cluster kernel (its comment)
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
@@ -1442,6 +1534,16 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
     const int nqb = (Sq + qbr - 1) / qbr;
     const int total = nqb * H * B;
     const bool m16 = g_attn_mfma == 16;
+    if (nw == 8 && !m16 && g_attn_w64) {
+        auto w64 = attn_fwd_d128_w64_kernel;
+        static uint64_t w64_attr = 0;
+        APEXMI_SET_ATTR_ONCE(w64_attr,
+            (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE));
+        hipLaunchKernelGGL(w64, dim3(total), dim3(256), 4 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total, o_strides[0], o_strides[1],
+                           o_strides[2], c);
+        return apexmi_check_launch("attn_fwd_d128_w64");
+    }
     if (nw == 8 && !m16 && g_attn_c4) {
         // ---- shipped path: 4-cluster kernel; a nearly empty last round is cut into ATT_NSPLIT key ranges ----
         // bit 0: s_setprio around the matrix clusters; bit 1: packed-f32 softmax; bit 2: static priority for waves 4..7
@@ -1544,6 +1646,7 @@ void apexmi_set_attn_mfma(int v) { g_attn_mfma = v; }
 void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
 void apexmi_set_attn_stages(int v) { g_attn_stages = v; }
 void apexmi_set_attn_xv(int v) { g_attn_xv = v; }
+void apexmi_set_attn_w64(int v) { g_attn_w64 = v; }
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && (int64_t)Sq * Sk >= 256 * 256)

@@ -169,6 +169,7 @@ void apexmi_set_ln_wave(int v);
 void apexmi_set_attn_c4(int v);
 void apexmi_set_attn_stages(int v);
 void apexmi_set_attn_xv(int v);
+void apexmi_set_attn_w64(int v);
 void apexmi_set_qk_group(int v);
 void apexmi_set_attn_split(int v);
 void apexmi_set_conv_v2(int v);
@@ -219,6 +220,9 @@ extern "C" int apexmi_tune_set(const char* key, int value) {
         return 0;
     } else if (!strcmp(key, "attn.stages")) {
         apexmi_set_attn_stages(value);
+        return 0;
+    } else if (!strcmp(key, "attn.w64")) {
+        apexmi_set_attn_w64(value);
         return 0;
     } else if (!strcmp(key, "attn.xv")) {
         apexmi_set_attn_xv(value);

@@ -1,0 +1,449 @@
+#!/usr/bin/env python
+"""Generator of the loop of attn_fwd_d128_w64_kernel (apex-studio_amd/csrc/attention.hip): writes
+apex-studio_amd/csrc/attn_w64_body.inc, the body of ONE asm statement with a fixed register map.
+
+Why a generator: the kernel runs one wave per SIMD on (nearly) the whole 512-register file — two 32-row query blocks per wave, two
+score sets, O^T and Q in AGPRs.  hipcc's allocator does not cope (first builds: 164-219 spilled registers, Q fragments reloaded
+from scratch before every MFMA, score sets copied at every join), so the registers are assigned here and every instruction of the
+loop is placed here: the MFMAs of a phase with the softmax VALU, the LDS fragment reads and the LDS-DMA pieces of its gaps.
+
+Schedule (per KV tile t of 64 keys, per wave: query blocks A and B of 32 rows):
+  phase X(t): S(t+1) = K(t+1) Q^T, 32 MFMAs (each K fragment feeds A and B)   | exp2, row-sum terms, bf16 pairs of tile t
+  phase Y(t): O^T += V^T(t) P(t)^T, 32 MFMAs (each V^T fragment feeds A and B) | row max, running-max decision, scaling of tile t+1
+  one s_barrier per tile; LDS ring of four stages (tile t+3 is staged during X(t)).
+Layouts (LDS images, fragment / score / P lane mapping) are those of attn_fwd_d128_c4_kernel.
+
+Register map
+  v[0:63]    score set 0: (block e, key half kt) at 32 e + 16 kt        v[64:127]  score set 1
+  v[128:159] P (bf16): block e, 16-key step kk at 128 + 16 e + 4 kk
+  v[160:175] K fragment ring (2 x 2 fragments)   v[176:207] V^T fragment ring (2 x 4 fragments)
+  v[208:215] row-sum partials (4 per block)  v[216:219] row-max chains  v220/221 m  v222/223 l  v224/225 alpha
+  v[226:235] temporaries  v236 K read base  v237 V^T read base
+  a[0:127]   O^T: block e, d-tile dt at 64 e + 16 dt               a[128:191] Q fragments: 128 + 32 e + 4 ks
+  s[40:63]   scalar temporaries (tile counter, stage offsets, DMA offsets)
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "apex-studio_amd", "csrc", "attn_w64_body.inc")
+NEG_BIG = "0xf149f2ca"      # -1.0e30f
+DEFER = "0x40c00000"        # 6.0f
+
+
+def vr(base, n=1):
+    return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=1):
+    return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
+
+
+def S(st, e, kt):
+    return st * 64 + e * 32 + kt * 16
+
+
+def Sreg(st, v):            # value v = 0..63: block v >> 5, (kt, r) = ((v >> 4) & 1, v & 15)
+    return S(st, v >> 5, (v >> 4) & 1) + (v & 15)
+
+
+def P(e, kk):
+    return 128 + e * 16 + kk * 4
+
+
+def KF(r, kt):
+    return 160 + r * 8 + kt * 4
+
+
+def VF(r, dt):
+    return 176 + r * 16 + dt * 4
+
+
+def PS(e, i):
+    return 208 + e * 4 + i
+
+
+def MX(e, kt):
+    return 216 + e * 2 + kt
+
+
+M_, L_, AL_ = (lambda e: 220 + e), (lambda e: 222 + e), (lambda e: 224 + e)
+T = [226 + i for i in range(10)]
+KB, VB = 236, 237
+
+
+def O(e, dt):
+    return e * 64 + dt * 16
+
+
+def Q(e, ks):
+    return 128 + e * 32 + ks * 4
+
+
+class Emit:
+    def __init__(self):
+        self.lines = []
+        self.lds = []          # destination base registers of outstanding ds_reads, issue order
+        self.label_n = 0
+
+    def i(self, s):
+        self.lines.append(s)
+
+    def label(self, stem):
+        self.label_n += 1
+        return f".Lw64_{stem}_{self.label_n}_%="
+
+    def ds_read(self, dst, addr, off):
+        self.i(f"ds_read_b128 {vr(dst, 4)}, {vr(addr)} offset:{off}")
+        self.lds.append(dst)
+
+    def need(self, dst):
+        """wait until the ds_read into `dst` has returned (LDS returns in order)"""
+        if dst in self.lds:
+            k = self.lds.index(dst)
+            after = len(self.lds) - 1 - k
+            self.i(f"s_waitcnt lgkmcnt({after})")
+            self.lds = self.lds[k + 1:]
+
+    def lds_flush(self):
+        if self.lds:
+            self.i("s_waitcnt lgkmcnt(0)")
+            self.lds = []
+
+
+def mfma(em, dst, a, b, c, dst_a=False, b_a=False):
+    d = ar(dst, 16) if dst_a else vr(dst, 16)
+    bb = ar(b, 4) if b_a else vr(b, 4)
+    cc = "0" if c is None else d
+    em.i(f"v_mfma_f32_32x32x16_bf16 {d}, {vr(a, 4)}, {bb}, {cc}")
+
+
+def drain(em, n=2):
+    for _ in range(n):
+        em.i("s_nop 15")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def sm1_ops(ns, with_fin):
+    """phase-Y filler queue: (l += row-sum partials of the tile just exponentiated), row max of set ns, decision, scaling"""
+    q = []
+    if with_fin:
+        for e in range(2):
+            q.append(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
+            q.append(f"v_add_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(PS(e, 3))}")
+        for e in range(2):
+            q.append(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 2))}")
+        for e in range(2):
+            q.append(f"v_add_f32 {vr(L_(e))}, {vr(L_(e))}, {vr(PS(e, 0))}")
+    # four max chains, round robin
+    chains = []
+    for e in range(2):
+        for kt in range(2):
+            b = S(ns, e, kt)
+            ops = [f"v_max3_f32 {vr(MX(e, kt))}, {vr(b)}, {vr(b + 1)}, {vr(b + 2)}"]
+            for j in range(6):
+                ops.append(f"v_max3_f32 {vr(MX(e, kt))}, {vr(MX(e, kt))}, {vr(b + 3 + 2 * j)}, {vr(b + 4 + 2 * j)}")
+            ops.append(f"v_max_f32 {vr(MX(e, kt))}, {vr(MX(e, kt))}, {vr(b + 15)}")
+            chains.append(ops)
+    for j in range(8):
+        for c in chains:
+            q.append(c[j])
+    # decisions, the two blocks interleaved (temporaries T[0..3] for A, T[4..7] for B)
+    dec = []
+    for e in range(2):
+        t0, t1, t2, t3 = T[4 * e:4 * e + 4]
+        dec.append([
+            f"v_max_f32 {vr(MX(e, 0))}, {vr(MX(e, 0))}, {vr(MX(e, 1))}",
+            f"v_mov_b32 {vr(t0)}, {vr(MX(e, 0))}",
+            "s_nop 1",
+            f"v_permlane32_swap_b32 {vr(t0)}, {vr(MX(e, 0))}",
+            f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(MX(e, 0))}",
+            f"v_mul_f32 {vr(t0)}, %[sc], {vr(t0)}",                      # m1 = tile max, scaled
+            f"v_add_f32 {vr(t1)}, {DEFER}, {vr(M_(e))}",
+            f"v_max_f32 {vr(t2)}, {vr(M_(e))}, {vr(t0)}",
+            f"v_cmp_gt_f32 s[{50 + 2 * e}:{51 + 2 * e}], {vr(t0)}, {vr(t1)}",   # not vcc: the two blocks' chains interleave
+            f"v_ceil_f32 {vr(t2)}, {vr(t2)}",
+            f"v_cndmask_b32 {vr(t2)}, {vr(M_(e))}, {vr(t2)}, s[{50 + 2 * e}:{51 + 2 * e}]",       # m_new
+            f"v_sub_f32 {vr(t3)}, {vr(M_(e))}, {vr(t2)}",
+            f"v_mov_b32 {vr(M_(e))}, {vr(t2)}",
+            f"v_exp_f32 {vr(AL_(e))}, {vr(t3)}",
+            "s_nop 0",
+            f"v_mul_f32 {vr(L_(e))}, {vr(L_(e))}, {vr(AL_(e))}",
+        ])
+    for j in range(len(dec[0])):
+        q.append(dec[0][j])
+        q.append(dec[1][j])
+    for e in range(2):
+        for w in range(32):
+            r = Sreg(ns, e * 32 + w)
+            q.append(f"v_fma_f32 {vr(r)}, {vr(r)}, %[sc], -{vr(M_(e))}")
+    return q
+
+
+def sm2_ops(st):
+    """phase-X filler queue: exp2 of set st in place, row-sum partial terms, bf16 pairs; the uses trail the exponentials by a pair"""
+    q = [f"v_mov_b32 {vr(PS(e, i))}, 0" for e in range(2) for i in range(4)]
+
+    def use(v):
+        e, w = v >> 5, v & 31
+        return [f"v_add_f32 {vr(PS(e, v & 3))}, {vr(PS(e, v & 3))}, {vr(Sreg(st, v))}",
+                f"v_add_f32 {vr(PS(e, (v + 1) & 3))}, {vr(PS(e, (v + 1) & 3))}, {vr(Sreg(st, v + 1))}",
+                f"v_cvt_pk_bf16_f32 {vr(P(e, w >> 3) + ((w & 7) >> 1))}, {vr(Sreg(st, v))}, {vr(Sreg(st, v + 1))}"]
+    for v in range(0, 64, 2):
+        q.append(f"v_exp_f32 {vr(Sreg(st, v))}, {vr(Sreg(st, v))}")
+        q.append(f"v_exp_f32 {vr(Sreg(st, v + 1))}, {vr(Sreg(st, v + 1))}")
+        if v >= 2:
+            q += use(v - 2)
+    q.append("s_nop 0")
+    q += use(62)
+    return q
+
+
+def spread(q, nslots, first_extra=0):
+    """split queue q over nslots gaps as evenly as possible; `first_extra` ops go before the first MFMA"""
+    pre, rest = q[:first_extra], q[first_extra:]
+    out = [[] for _ in range(nslots)]
+    for k, op in enumerate(rest):
+        out[k * nslots // len(rest)].append(op)
+    return pre, out
+
+
+def dma_piece(em, j):
+    """LDS-DMA piece j (0..3 K, 4..7 V^T) of tile t + 3: s44 = LDS base of the stage + wave, s45 / s46 = K / V^T tile offsets"""
+    if j < 4:
+        em.i(f"s_add_i32 m0, s44, {j * 4096}")
+        em.i(f"s_add_i32 s47, s45, {j * 4096}")
+        em.i("buffer_load_dwordx4 %[vk], %[rk], s47 offen lds")
+    else:
+        em.i(f"s_add_i32 m0, s44, {16384 + (j - 4) * 4096}")
+        if j == 4:
+            em.i("s_mov_b32 s48, s46")
+        else:
+            em.i("s_add_i32 s48, s48, %[vp]")
+        em.i("buffer_load_dwordx4 %[vv], %[rv], s48 offen lds")
+
+
+def stage_regs(em):
+    """scalars of tile t = s40"""
+    em.i("s_add_i32 s41, s40, 1")
+    em.i("s_and_b32 s41, s41, 3")
+    em.i("s_lshl_b32 s42, s41, 15")                 # K read stage of tile t + 1
+    em.i("s_and_b32 s41, s40, 3")
+    em.i("s_lshl_b32 s43, s41, 15")
+    em.i("s_add_i32 s43, s43, 16384")               # V^T read stage of tile t
+    em.i("s_add_i32 s41, s40, 3")
+    em.i("s_lshl_b32 s45, s41, 14")                 # K bytes of tile t + 3
+    em.i("s_lshl_b32 s46, s41, 7")                  # V^T bytes of tile t + 3
+    em.i("s_and_b32 s41, s41, 3")
+    em.i("s_lshl_b32 s44, s41, 15")
+    em.i("s_add_i32 s44, s44, %[w]")                # DMA stage of tile t + 3 (+ this wave's piece)
+
+
+def mask_block(em, st):
+    """keys >= Sk of the last tile -> -1e30 (set st); %[rem] = Sk % 64 != 0.  T[0] = 8 hi, T[1] = -1e30"""
+    em.i(f"v_mbcnt_lo_u32_b32 {vr(T[0])}, -1, 0")
+    em.i(f"v_mbcnt_hi_u32_b32 {vr(T[0])}, -1, {vr(T[0])}")
+    em.i(f"v_lshrrev_b32 {vr(T[0])}, 2, {vr(T[0])}")
+    em.i(f"v_and_b32 {vr(T[0])}, 8, {vr(T[0])}")
+    em.i(f"v_mov_b32 {vr(T[1])}, {NEG_BIG}")
+    for e in range(2):
+        for kt in range(2):
+            for r in range(16):
+                a, bb = r >> 2, r & 3
+                kc = kt * 32 + 16 * (a >> 1) + 4 * (a & 1) + bb
+                em.i(f"s_sub_i32 s47, %[rem], {kc}")
+                em.i(f"v_cmp_le_i32 vcc, s47, {vr(T[0])}")            # rem - kc <= 8 hi  <=>  key >= rem
+                reg = S(st, e, kt) + r
+                em.i(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(T[1])}, vcc")
+
+
+def rescale_block(em):
+    """O^T *= alpha for a block whose running max rose (rare): through VGPR temporaries"""
+    for e in range(2):
+        skip = em.label("nors")
+        em.i(f"v_cmp_neq_f32 vcc, 1.0, {vr(AL_(e))}")
+        em.i(f"s_cbranch_vccz {skip}")
+        drain(em, 4)
+        for k in range(0, 64, 4):
+            for u in range(4):
+                em.i(f"v_accvgpr_read_b32 {vr(T[u])}, {ar(e * 64 + k + u)}")
+            em.i("s_nop 0")
+            for u in range(4):
+                em.i(f"v_mul_f32 {vr(T[u])}, {vr(T[u])}, {vr(AL_(e))}")
+            em.i("s_nop 0")
+            for u in range(4):
+                em.i(f"v_accvgpr_write_b32 {ar(e * 64 + k + u)}, {vr(T[u])}")
+        em.i("s_nop 7")
+        em.i(f"{skip}:")
+
+
+def tile(em, par, more, dma):
+    st, ns = par, par ^ 1
+    # ---------------- phase X ----------------
+    q = sm2_ops(st)
+    pre, gaps = spread(q, 32, first_extra=10)
+    if more:
+        em.i(f"v_add_u32 {vr(KB)}, s42, %[ka]")
+        em.ds_read(KF(0, 0), KB, 0)
+        em.ds_read(KF(0, 1), KB, 8192)
+    for op in pre:
+        em.i(op)
+    for ks in range(8):
+        if more and ks + 1 < 8:
+            em.i(f"v_xor_b32 {vr(T[8])}, {(ks + 1) << 5}, {vr(KB)}")
+            em.ds_read(KF((ks + 1) & 1, 0), T[8], 0)
+            em.ds_read(KF((ks + 1) & 1, 1), T[8], 8192)
+        for qq in range(4):
+            e, kt, slot = qq >> 1, qq & 1, ks * 4 + qq
+            if more:
+                em.need(KF(ks & 1, kt))
+                mfma(em, S(ns, e, kt), KF(ks & 1, kt), Q(e, ks), None if ks == 0 else 1, b_a=True)
+            for op in gaps[slot]:
+                em.i(op)
+            if dma and (slot & 3) == 1:
+                dma_piece(em, slot >> 2)
+    # V^T fragments of the first step of phase Y: issued here so their latency rides under the tail of phase X
+    em.i(f"v_add_u32 {vr(VB)}, s43, %[va]")
+    for dt in range(4):
+        em.ds_read(VF(0, dt), VB, dt * 4096)
+    if more:
+        drain(em)                                    # S(t+1) is read by VALU from here on
+        lm = em.label("nomask")
+        em.i("s_add_i32 s47, s40, 2")
+        em.i("s_cmp_lg_u32 s47, %[nt]")              # tile t + 1 is the last one ...
+        em.i(f"s_cbranch_scc1 {lm}")
+        em.i("s_cmp_eq_u32 %[rem], 0")               # ... and ragged
+        em.i(f"s_cbranch_scc1 {lm}")
+        mask_block(em, ns)
+        em.i(f"{lm}:")
+    # ---------------- phase Y ----------------
+    q = sm1_ops(ns, with_fin=True) if more else sm1_ops(ns, with_fin=True)[:8]
+    _, gaps = spread(q, 32)
+    for kk in range(4):
+        if kk + 1 < 4:
+            em.i(f"v_xor_b32 {vr(T[9])}, {(kk + 1) << 5}, {vr(VB)}")
+            for dt in range(4):
+                em.ds_read(VF((kk + 1) & 1, dt), T[9], dt * 4096)
+        for qq in range(8):
+            dt, e, slot = qq >> 1, qq & 1, kk * 8 + qq
+            em.need(VF(kk & 1, dt))
+            mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
+            for op in gaps[slot]:
+                em.i(op)
+    if more:
+        rescale_block(em)
+    em.i("s_waitcnt vmcnt(8)" if dma else "s_waitcnt vmcnt(0)")
+    em.i("s_barrier")
+    em.i("s_add_i32 s40, s40, 1")
+    stage_regs(em)
+
+
+def dispatch(em, par, labels, done):
+    """choose the body of tile s40 with parity par"""
+    em.i(f"{labels[('top', par)]}:")
+    em.i("s_cmp_ge_u32 s40, %[nt]")
+    em.i(f"s_cbranch_scc1 {done}")
+    em.i("s_add_i32 s47, s40, 3")
+    em.i("s_cmp_lt_u32 s47, %[nt]")
+    em.i(f"s_cbranch_scc1 {labels[('f', par)]}")
+    em.i("s_add_i32 s47, s40, 1")
+    em.i("s_cmp_lt_u32 s47, %[nt]")
+    em.i(f"s_cbranch_scc1 {labels[('m', par)]}")
+    em.i(f"s_branch {labels[('l', par)]}")
+
+
+def main():
+    em = Emit()
+    # ---------------- prologue ----------------
+    for e, a in ((0, "%[qa]"), (1, "%[qb]")):
+        for ks in range(8):
+            em.i(f"global_load_dwordx4 {ar(Q(e, ks), 4)}, {a}, off offset:{ks * 32}")
+    for e in range(2):
+        em.i(f"v_mov_b32 {vr(M_(e))}, {NEG_BIG}")
+        em.i(f"v_mov_b32 {vr(L_(e))}, 0")
+        em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")
+    for k in range(128):
+        em.i(f"v_accvgpr_write_b32 {ar(k)}, 0")
+    # tiles 0..2 staged: `stage_regs` computes the scalars for tile s40 + 3
+    for tt in range(3):
+        skip = em.label("nost")
+        em.i(f"s_cmp_le_u32 %[nt], {tt}")
+        em.i(f"s_cbranch_scc1 {skip}")
+        em.i(f"s_mov_b32 s40, {tt - 3}")
+        stage_regs(em)
+        for j in range(8):
+            dma_piece(em, j)
+        em.i(f"{skip}:")
+    l2, l1, lw = em.label("nt2"), em.label("nt1"), em.label("waited")
+    em.i("s_cmp_lt_u32 %[nt], 3")
+    em.i(f"s_cbranch_scc1 {l2}")
+    em.i("s_waitcnt vmcnt(16)")
+    em.i(f"s_branch {lw}")
+    em.i(f"{l2}:")
+    em.i("s_cmp_lt_u32 %[nt], 2")
+    em.i(f"s_cbranch_scc1 {l1}")
+    em.i("s_waitcnt vmcnt(8)")
+    em.i(f"s_branch {lw}")
+    em.i(f"{l1}:")
+    em.i("s_waitcnt vmcnt(0)")
+    em.i(f"{lw}:")
+    em.i("s_barrier")
+    # S(0) into set 0, nothing beside it
+    em.i(f"v_mov_b32 {vr(KB)}, %[ka]")
+    for ks in range(8):
+        em.i(f"v_xor_b32 {vr(T[8])}, {ks << 5}, {vr(KB)}")
+        em.ds_read(KF(0, 0), T[8], 0)
+        em.ds_read(KF(0, 1), T[8], 8192)
+        for e in range(2):
+            for kt in range(2):
+                em.need(KF(0, kt))
+                mfma(em, S(0, e, kt), KF(0, kt), Q(e, ks), None if ks == 0 else 1, b_a=True)
+        em.i("s_nop 7")                               # the fragments are overwritten by the next step's reads
+    drain(em)
+    lm = em.label("nomask0")
+    em.i("s_cmp_lg_u32 %[nt], 1")
+    em.i(f"s_cbranch_scc1 {lm}")
+    em.i("s_cmp_eq_u32 %[rem], 0")
+    em.i(f"s_cbranch_scc1 {lm}")
+    mask_block(em, 0)
+    em.i(f"{lm}:")
+    for op in sm1_ops(0, with_fin=False):
+        em.i(op)
+    l8, lw = em.label("w0"), em.label("waited2")
+    em.i("s_cmp_lt_u32 %[nt], 3")
+    em.i(f"s_cbranch_scc1 {l8}")
+    em.i("s_waitcnt vmcnt(8)")
+    em.i(f"s_branch {lw}")
+    em.i(f"{l8}:")
+    em.i("s_waitcnt vmcnt(0)")
+    em.i(f"{lw}:")
+    em.i("s_barrier")
+    em.i("s_mov_b32 s40, 0")
+    stage_regs(em)
+    # ---------------- tiles ----------------
+    labels = {}
+    for par in range(2):
+        for k in ("top", "f", "m", "l"):
+            labels[(k, par)] = em.label(f"{k}{par}")
+    done = em.label("done")
+    em.i(f"s_branch {labels[('top', 0)]}")
+    for par in range(2):
+        dispatch(em, par, labels, done)
+        for k, more, dma in (("f", True, True), ("m", True, False), ("l", False, False)):
+            em.i(f"{labels[(k, par)]}:")
+            assert not em.lds
+            tile(em, par, more, dma)
+            assert not em.lds
+            em.i(f"s_branch {labels[('top', par ^ 1)]}")
+    em.i(f"{done}:")
+    drain(em)
+    em.i(f"v_mov_b32 %[la], {vr(L_(0))}")
+    em.i(f"v_mov_b32 %[lb], {vr(L_(1))}")
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen_attn_w64.py - do not edit (the generator holds the register map and the schedule)\n")
+        for ln in em.lines:
+            f.write(f'"{ln}\\n\\t"\n')
+    n_mfma = sum("v_mfma" in ln for ln in em.lines)
+    print(f"{OUT}: {len(em.lines)} instructions, {n_mfma} MFMAs")
+
+
+if __name__ == "__main__":
+    main()
