@@ -60,6 +60,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"),
                os.path.join(PKG_DIR, "..", "include", "apexmi.h")]
+    # generated / multi-include pieces of the translation units (attn_w64_body.inc = tools/gen_attn_w64.py, ...)
+    headers += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".inc", ".h")) and f != "common.h")
     objs = []
     jobs = []
     for src in SOURCES:

@@ -17,12 +17,19 @@ Register map
   v[0:63]    score set 0: (block e, key half kt) at 32 e + 16 kt        v[64:127]  score set 1
   v[128:159] P (bf16): block e, 16-key step kk at 128 + 16 e + 4 kk
   v[160:175] K fragment ring (2 x 2 fragments)   v[176:207] V^T fragment ring (2 x 4 fragments)
-  v[208:215] row-sum partials (4 per block)  v[216:219] row-max chains  v220/221 m  v222/223 l  v224/225 alpha
+  v[208:215] row-sum partials (4 per block, carried over the tiles)  v[216:219] row-max chains  v220/222 m  v221/223 alpha
   v[226:235] temporaries  v236 K read base  v237 V^T read base
   a[0:127]   O^T: block e, d-tile dt at 64 e + 16 dt               a[128:191] Q fragments: 128 + 32 e + 4 ks
   s[40:63]   scalar temporaries (tile counter, stage offsets, DMA offsets)
 """
 import os
+import sys
+
+# timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
+OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "drain": 2}   # schedule options (CLI --opt k=v)
+TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
+ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
+       "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "apex-studio_amd", "csrc", "attn_w64_body.inc")
 NEG_BIG = "0xf149f2ca"      # -1.0e30f
@@ -65,7 +72,7 @@ def MX(e, kt):
     return 216 + e * 2 + kt
 
 
-M_, L_, AL_ = (lambda e: 220 + e), (lambda e: 222 + e), (lambda e: 224 + e)
+M_, AL_ = (lambda e: 220 + 2 * e), (lambda e: 221 + 2 * e)     # running max / rescale factor of block e (m on an even register: v_pk_fma_f32)
 T = [226 + i for i in range(10)]
 KB, VB = 236, 237
 
@@ -83,6 +90,7 @@ class Emit:
         self.lines = []
         self.lds = []          # destination base registers of outstanding ds_reads, issue order
         self.label_n = 0
+        self.in_loop = False
 
     def i(self, s):
         self.lines.append(s)
@@ -92,6 +100,8 @@ class Emit:
         return f".Lw64_{stem}_{self.label_n}_%="
 
     def ds_read(self, dst, addr, off):
+        if not ABL["reads"]:
+            return
         self.i(f"ds_read_b128 {vr(dst, 4)}, {vr(addr)} offset:{off}")
         self.lds.append(dst)
 
@@ -110,6 +120,8 @@ class Emit:
 
 
 def mfma(em, dst, a, b, c, dst_a=False, b_a=False):
+    if not ABL["mfma"]:
+        return
     d = ar(dst, 16) if dst_a else vr(dst, 16)
     bb = ar(b, 4) if b_a else vr(b, 4)
     cc = "0" if c is None else d
@@ -117,23 +129,16 @@ def mfma(em, dst, a, b, c, dst_a=False, b_a=False):
 
 
 def drain(em, n=2):
+    if not ABL["drain"]:
+        return
     for _ in range(n):
         em.i("s_nop 15")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-def sm1_ops(ns, with_fin):
-    """phase-Y filler queue: (l += row-sum partials of the tile just exponentiated), row max of set ns, decision, scaling"""
+def sm1_ops(ns):
+    """row max of set ns, running-max decision (the row-sum partials take the rescale factor here), scaled differences"""
     q = []
-    if with_fin:
-        for e in range(2):
-            q.append(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
-            q.append(f"v_add_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(PS(e, 3))}")
-        for e in range(2):
-            q.append(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 2))}")
-        for e in range(2):
-            q.append(f"v_add_f32 {vr(L_(e))}, {vr(L_(e))}, {vr(PS(e, 0))}")
-    # four max chains, round robin
     chains = []
     for e in range(2):
         for kt in range(2):
@@ -146,7 +151,6 @@ def sm1_ops(ns, with_fin):
     for j in range(8):
         for c in chains:
             q.append(c[j])
-    # decisions, the two blocks interleaved (temporaries T[0..3] for A, T[4..7] for B)
     dec = []
     for e in range(2):
         t0, t1, t2, t3 = T[4 * e:4 * e + 4]
@@ -166,27 +170,52 @@ def sm1_ops(ns, with_fin):
             f"v_mov_b32 {vr(M_(e))}, {vr(t2)}",
             f"v_exp_f32 {vr(AL_(e))}, {vr(t3)}",
             "s_nop 0",
-            f"v_mul_f32 {vr(L_(e))}, {vr(L_(e))}, {vr(AL_(e))}",
+            f"v_mul_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(AL_(e))}",
+            f"v_mul_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(AL_(e))}",
+            f"v_mul_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(AL_(e))}",
+            f"v_mul_f32 {vr(PS(e, 3))}, {vr(PS(e, 3))}, {vr(AL_(e))}",
+            f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}",   # does O^T of this block need the factor?
         ])
     for j in range(len(dec[0])):
-        q.append(dec[0][j])
-        q.append(dec[1][j])
+        q.append(dec[0][j] + " ;dec")
+        q.append(dec[1][j] + " ;dec")
     for e in range(2):
-        for w in range(32):
+        for w in range(0, 32, 2):
             r = Sreg(ns, e * 32 + w)
-            q.append(f"v_fma_f32 {vr(r)}, {vr(r)}, %[sc], -{vr(M_(e))}")
+            if OPT["pk_fma"]:
+                q.append(f"v_pk_fma_f32 {vr(r, 2)}, {vr(r, 2)}, s[78:79], {vr(M_(e), 2)} op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+            else:
+                q.append(f"v_fma_f32 {vr(r)}, {vr(r)}, %[sc], -{vr(M_(e))}")
+                q.append(f"v_fma_f32 {vr(r + 1)}, {vr(r + 1)}, %[sc], -{vr(M_(e))}")
     return q
 
 
-def sm2_ops(st):
-    """phase-X filler queue: exp2 of set st in place, row-sum partial terms, bf16 pairs; the uses trail the exponentials by a pair"""
-    q = [f"v_mov_b32 {vr(PS(e, i))}, 0" for e in range(2) for i in range(4)]
+def add_ops(st):
+    """row-sum terms of set st (exponentiated) into the four partial sums of each block"""
+    q = []
+    for v in range(0, 64, 2):
+        e, r = v >> 5, Sreg(st, v)
+        if OPT["pk_add"]:
+            p0 = PS(e, v & 2)
+            q.append(f"v_pk_add_f32 {vr(p0, 2)}, {vr(p0, 2)}, {vr(r, 2)}")
+        else:
+            q.append(f"v_add_f32 {vr(PS(e, v & 3))}, {vr(PS(e, v & 3))}, {vr(r)}")
+            q.append(f"v_add_f32 {vr(PS(e, (v + 1) & 3))}, {vr(PS(e, (v + 1) & 3))}, {vr(r + 1)}")
+    return q
+
+
+def sm2_ops(st, with_adds):
+    """exp2 of set st in place and the bf16 pairs (and the row-sum terms); the uses trail the exponentials by a pair"""
+    q = []
+    adds = add_ops(st)
+    per = len(adds) // 32
 
     def use(v):
         e, w = v >> 5, v & 31
-        return [f"v_add_f32 {vr(PS(e, v & 3))}, {vr(PS(e, v & 3))}, {vr(Sreg(st, v))}",
-                f"v_add_f32 {vr(PS(e, (v + 1) & 3))}, {vr(PS(e, (v + 1) & 3))}, {vr(Sreg(st, v + 1))}",
-                f"v_cvt_pk_bf16_f32 {vr(P(e, w >> 3) + ((w & 7) >> 1))}, {vr(Sreg(st, v))}, {vr(Sreg(st, v + 1))}"]
+        u = [f"v_cvt_pk_bf16_f32 {vr(P(e, w >> 3) + ((w & 7) >> 1))}, {vr(Sreg(st, v))}, {vr(Sreg(st, v + 1))}"]
+        if with_adds:
+            u = adds[(v >> 1) * per:(v >> 1) * per + per] + u
+        return u
     for v in range(0, 64, 2):
         q.append(f"v_exp_f32 {vr(Sreg(st, v))}, {vr(Sreg(st, v))}")
         q.append(f"v_exp_f32 {vr(Sreg(st, v + 1))}, {vr(Sreg(st, v + 1))}")
@@ -197,8 +226,18 @@ def sm2_ops(st):
     return q
 
 
+DROP = {"exp": "v_exp_f32 v", "add": ("v_add_f32", "v_pk_add_f32"), "cvt": "v_cvt_pk", "max": "v_max3", "fma": ("v_fma_f32", "v_pk_fma_f32")}
+
+
 def spread(q, nslots, first_extra=0):
     """split queue q over nslots gaps as evenly as possible; `first_extra` ops go before the first MFMA"""
+    for k, pre in DROP.items():
+        if not ABL[k]:
+            q = [op for op in q if not op.startswith(pre)]   # pre: a prefix or a tuple of prefixes
+    if not ABL["dec"]:
+        q = [op for op in q if not op.endswith(";dec")]
+    if not q:
+        return [], [[] for _ in range(nslots)]
     pre, rest = q[:first_extra], q[first_extra:]
     out = [[] for _ in range(nslots)]
     for k, op in enumerate(rest):
@@ -208,6 +247,8 @@ def spread(q, nslots, first_extra=0):
 
 def dma_piece(em, j):
     """LDS-DMA piece j (0..3 K, 4..7 V^T) of tile t + 3: s44 = LDS base of the stage + wave, s45 / s46 = K / V^T tile offsets"""
+    if not ABL["dma"] and em.in_loop:
+        return
     if j < 4:
         em.i(f"s_add_i32 m0, s44, {j * 4096}")
         em.i(f"s_add_i32 s47, s45, {j * 4096}")
@@ -256,11 +297,12 @@ def mask_block(em, st):
 
 
 def rescale_block(em):
-    """O^T *= alpha for a block whose running max rose (rare): through VGPR temporaries"""
+    """O^T *= alpha for a block whose running max rose (rare): through VGPR temporaries.  s[54:55] / s[56:57]... the decision left
+    `alpha != 1` lane masks in s[54:55] (block A) and s[56:57] (block B): the test at the edge is scalar"""
     for e in range(2):
         skip = em.label("nors")
-        em.i(f"v_cmp_neq_f32 vcc, 1.0, {vr(AL_(e))}")
-        em.i(f"s_cbranch_vccz {skip}")
+        em.i(f"s_cmp_eq_u64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
+        em.i(f"s_cbranch_scc1 {skip}")
         drain(em, 4)
         for k in range(0, 64, 4):
             for u in range(4):
@@ -277,15 +319,20 @@ def rescale_block(em):
 
 def tile(em, par, more, dma):
     st, ns = par, par ^ 1
-    # ---------------- phase X ----------------
-    q = sm2_ops(st)
-    pre, gaps = spread(q, 32, first_extra=10)
+    TS = 80 if TRACE else 0          # trace stamps live in s[80:87]
+    # ---------------- phase X: S(t+1) = K(t+1) Q^T beside exp2 / bf16 pairs (/ row-sum terms) of tile t ----------------
+    em.in_loop = True
+    if TRACE:
+        em.i("s_memtime s[80:81]")
+    q = sm2_ops(st, with_adds=OPT["adds_in"] == "X") if ABL["fill_x"] else []
+    pre, gaps = spread(q, 32, first_extra=6)
     if more:
         em.i(f"v_add_u32 {vr(KB)}, s42, %[ka]")
         em.ds_read(KF(0, 0), KB, 0)
         em.ds_read(KF(0, 1), KB, 8192)
     for op in pre:
         em.i(op)
+    vread_slot = 32 - OPT["vread_early"]
     for ks in range(8):
         if more and ks + 1 < 8:
             em.i(f"v_xor_b32 {vr(T[8])}, {(ks + 1) << 5}, {vr(KB)}")
@@ -294,18 +341,23 @@ def tile(em, par, more, dma):
         for qq in range(4):
             e, kt, slot = qq >> 1, qq & 1, ks * 4 + qq
             if more:
-                em.need(KF(ks & 1, kt))
+                if qq == 0:
+                    em.need(KF(ks & 1, 1))               # one wait per step: the later of its two fragments
                 mfma(em, S(ns, e, kt), KF(ks & 1, kt), Q(e, ks), None if ks == 0 else 1, b_a=True)
             for op in gaps[slot]:
                 em.i(op)
-            if dma and (slot & 3) == 1:
+            if dma and OPT["dma_in"] == "X" and (slot & 3) == 1:
                 dma_piece(em, slot >> 2)
-    # V^T fragments of the first step of phase Y: issued here so their latency rides under the tail of phase X
-    em.i(f"v_add_u32 {vr(VB)}, s43, %[va]")
-    for dt in range(4):
-        em.ds_read(VF(0, dt), VB, dt * 4096)
+            if slot == vread_slot - 1 or (slot == 31 and vread_slot >= 32):
+                # V^T fragments of the first step of phase Y: their latency rides under the tail of phase X (after the K reads of
+                # step 7, which were issued at the top of step 6: the LDS returns in order)
+                em.i(f"v_add_u32 {vr(VB)}, s43, %[va]")
+                for dt in range(4):
+                    em.ds_read(VF(0, dt), VB, dt * 4096)
+    if TRACE:
+        em.i("s_memtime s[82:83]")
     if more:
-        drain(em)                                    # S(t+1) is read by VALU from here on
+        drain(em, OPT["drain"])                      # S(t+1) is read by VALU from here on
         lm = em.label("nomask")
         em.i("s_add_i32 s47, s40, 2")
         em.i("s_cmp_lg_u32 s47, %[nt]")              # tile t + 1 is the last one ...
@@ -314,8 +366,13 @@ def tile(em, par, more, dma):
         em.i(f"s_cbranch_scc1 {lm}")
         mask_block(em, ns)
         em.i(f"{lm}:")
-    # ---------------- phase Y ----------------
-    q = sm1_ops(ns, with_fin=True) if more else sm1_ops(ns, with_fin=True)[:8]
+    # ---------------- phase Y: O^T += V^T(t) P(t)^T beside (row-sum terms of tile t,) max / decision / scaling of tile t+1 ------
+    q = []
+    if ABL["fill_y"]:
+        if OPT["adds_in"] == "Y":
+            q += add_ops(st)
+        if more:
+            q += sm1_ops(ns)
     _, gaps = spread(q, 32)
     for kk in range(4):
         if kk + 1 < 4:
@@ -324,14 +381,34 @@ def tile(em, par, more, dma):
                 em.ds_read(VF((kk + 1) & 1, dt), T[9], dt * 4096)
         for qq in range(8):
             dt, e, slot = qq >> 1, qq & 1, kk * 8 + qq
-            em.need(VF(kk & 1, dt))
+            if qq == 0:
+                em.need(VF(kk & 1, 3))                   # one wait per step
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
             for op in gaps[slot]:
                 em.i(op)
+            if dma and OPT["dma_in"] == "Y" and (slot & 3) == 1:
+                dma_piece(em, slot >> 2)
     if more:
         rescale_block(em)
-    em.i("s_waitcnt vmcnt(8)" if dma else "s_waitcnt vmcnt(0)")
-    em.i("s_barrier")
+    if TRACE:
+        em.i("s_memtime s[84:85]")
+    em.i("s_waitcnt vmcnt(8)" if dma and ABL["dma"] else "s_waitcnt vmcnt(0)")
+    if TRACE:
+        em.i("s_memtime s[86:87]")
+    if ABL["barrier"]:
+        em.i("s_barrier")
+    if TRACE:   # s[64:69] += phase X, phase Y, DMA wait; s[70:71] += barrier + scalar bookkeeping (from the previous tile's last stamp)
+        em.i("s_waitcnt lgkmcnt(0)")
+        for acc, (hi_, lo_) in ((64, (82, 80)), (66, (84, 82)), (68, (86, 84))):
+            em.i(f"s_sub_u32 s76, s{hi_}, s{lo_}")
+            em.i(f"s_subb_u32 s77, s{hi_ + 1}, s{lo_ + 1}")
+            em.i(f"s_add_u32 s{acc}, s{acc}, s76")
+            em.i(f"s_addc_u32 s{acc + 1}, s{acc + 1}, s77")
+        em.i("s_sub_u32 s76, s80, s74")
+        em.i("s_subb_u32 s77, s81, s75")
+        em.i("s_add_u32 s70, s70, s76")
+        em.i("s_addc_u32 s71, s71, s77")
+        em.i("s_mov_b64 s[74:75], s[86:87]")
     em.i("s_add_i32 s40, s40, 1")
     stage_regs(em)
 
@@ -351,6 +428,18 @@ def dispatch(em, par, labels, done):
 
 
 def main():
+    out = OUT
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            out = a[6:]
+        elif a.startswith("--no-"):
+            ABL[a[5:]] = False
+        elif a.startswith("--opt="):
+            k, v = a[6:].split("=")
+            OPT[k] = type(OPT[k])(int(v)) if isinstance(OPT[k], (bool, int)) else v
+        elif a == "--trace":
+            global TRACE
+            TRACE = True
     em = Emit()
     # ---------------- prologue ----------------
     for e, a in ((0, "%[qa]"), (1, "%[qb]")):
@@ -358,8 +447,13 @@ def main():
             em.i(f"global_load_dwordx4 {ar(Q(e, ks), 4)}, {a}, off offset:{ks * 32}")
     for e in range(2):
         em.i(f"v_mov_b32 {vr(M_(e))}, {NEG_BIG}")
-        em.i(f"v_mov_b32 {vr(L_(e))}, 0")
         em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")
+        for i in range(4):
+            em.i(f"v_mov_b32 {vr(PS(e, i))}, 0")
+    em.i("s_mov_b32 s78, %[sc]")                      # {scale, scale} for v_pk_fma_f32
+    em.i("s_mov_b32 s79, %[sc]")
+    for e in range(2):
+        em.i(f"s_mov_b64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
     for k in range(128):
         em.i(f"v_accvgpr_write_b32 {ar(k)}, 0")
     # tiles 0..2 staged: `stage_regs` computes the scalars for tile s40 + 3
@@ -405,8 +499,10 @@ def main():
     em.i(f"s_cbranch_scc1 {lm}")
     mask_block(em, 0)
     em.i(f"{lm}:")
-    for op in sm1_ops(0, with_fin=False):
-        em.i(op)
+    for op in sm1_ops(0):
+        em.i(op.replace(' ;dec', ''))
+    for e in range(2):
+        em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")          # O is still zero: nothing to rescale
     l8, lw = em.label("w0"), em.label("waited2")
     em.i("s_cmp_lt_u32 %[nt], 3")
     em.i(f"s_cbranch_scc1 {l8}")
@@ -418,6 +514,11 @@ def main():
     em.i("s_barrier")
     em.i("s_mov_b32 s40, 0")
     stage_regs(em)
+    if TRACE:
+        for k in range(64, 72, 2):
+            em.i(f"s_mov_b64 s[{k}:{k + 1}], 0")
+        em.i("s_memtime s[74:75]")
+        em.i("s_waitcnt lgkmcnt(0)")
     # ---------------- tiles ----------------
     labels = {}
     for par in range(2):
@@ -435,14 +536,34 @@ def main():
             em.i(f"s_branch {labels[('top', par ^ 1)]}")
     em.i(f"{done}:")
     drain(em)
-    em.i(f"v_mov_b32 %[la], {vr(L_(0))}")
-    em.i(f"v_mov_b32 %[lb], {vr(L_(1))}")
-    with open(OUT, "w") as f:
+    if TRACE:   # lane 0 of every wave: {phase X, phase Y, DMA wait, barrier} cycles summed over the tiles
+        skip = em.label("notrace")
+        em.i("s_cmp_eq_u64 %[tp], 0")
+        em.i(f"s_cbranch_scc1 {skip}")
+        em.i(f"v_mbcnt_lo_u32_b32 {vr(T[0])}, -1, 0")
+        em.i(f"v_mbcnt_hi_u32_b32 {vr(T[0])}, -1, {vr(T[0])}")
+        em.i(f"v_cmp_eq_u32 vcc, 0, {vr(T[0])}")
+        em.i("s_and_saveexec_b64 s[76:77], vcc")
+        em.i(f"v_mov_b32 {vr(T[2])}, 0")
+        for k in range(4):
+            em.i(f"v_mov_b32 {vr(T[0])}, s{64 + 2 * k}")
+            em.i(f"v_mov_b32 {vr(T[1])}, s{65 + 2 * k}")
+            em.i(f"global_store_dwordx2 {vr(T[2])}, {vr(T[0], 2)}, %[tp] offset:{8 * k}")
+            em.i("s_nop 1")
+        em.i("s_waitcnt vmcnt(0)")
+        em.i("s_mov_b64 exec, s[76:77]")
+        em.i(f"{skip}:")
+    for e, o in ((0, "%[la]"), (1, "%[lb]")):
+        em.i(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
+        em.i(f"v_add_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(PS(e, 3))}")
+        em.i("s_nop 0")
+        em.i(f"v_add_f32 {o}, {vr(PS(e, 0))}, {vr(PS(e, 2))}")
+    with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_w64.py - do not edit (the generator holds the register map and the schedule)\n")
         for ln in em.lines:
             f.write(f'"{ln}\\n\\t"\n')
     n_mfma = sum("v_mfma" in ln for ln in em.lines)
-    print(f"{OUT}: {len(em.lines)} instructions, {n_mfma} MFMAs")
+    print(f"{out}: {len(em.lines)} instructions, {n_mfma} MFMAs")
 
 
 if __name__ == "__main__":
