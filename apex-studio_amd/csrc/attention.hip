@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
 int g_attn_stages = 2;  // apexmi_tune_set("attn.stages", 2/3): LDS stages of the shipped 4-cluster kernel
-int g_attn_w64 = 0;     // apexmi_tune_set("attn.w64", 0/1): one wave per SIMD, 64 query rows per wave (attn_fwd_d128_w64_kernel)
+int g_attn_w64 = 1;     // apexmi_tune_set("attn.w64", 0/1): main launch on attn_fwd_d128_w64_kernel (shipped) or on the 4-cluster kernel
 int g_attn_xv = 0;      // apexmi_tune_set("attn.xv", 0..7): experiment bits of the 4-cluster kernel (its comment)
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
@@ -1496,35 +1496,6 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
     const int nqb = (Sq + qbr - 1) / qbr;
     const int total = nqb * H * B;
     const bool m16 = g_attn_mfma == 16;
-    if (nw == 8 && !m16 && g_attn_w64) {
-        auto w64 = attn_fwd_d128_w64_kernel;
-#ifdef APEXMI_ATTN_W64_ABLATE
-        switch (g_attn_w64) {
-            case 2: w64 = attn_fwd_d128_w64_abl1_kernel; break;
-            case 3: w64 = attn_fwd_d128_w64_abl2_kernel; break;
-            case 4: w64 = attn_fwd_d128_w64_abl3_kernel; break;
-            case 5: w64 = attn_fwd_d128_w64_abl4_kernel; break;
-            case 6: w64 = attn_fwd_d128_w64_abl5_kernel; break;
-            case 7: w64 = attn_fwd_d128_w64_abl6_kernel; break;
-            default: break;
-        }
-        (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
-#endif
-#if APEXMI_ATTN_TRACE
-        {
-            const char* e = getenv("APEXMI_ATTN_TRACE_PTR");
-            unsigned long long* p = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
-            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_attn_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, stream);
-        }
-#endif
-        static uint64_t w64_attr = 0;
-        APEXMI_SET_ATTR_ONCE(w64_attr,
-            (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE));
-        hipLaunchKernelGGL(w64, dim3(total), dim3(256), 4 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, total, o_strides[0], o_strides[1],
-                           o_strides[2], c);
-        return apexmi_check_launch("attn_fwd_d128_w64");
-    }
     if (nw == 8 && !m16 && g_attn_c4) {
         // ---- shipped path: 4-cluster kernel; a nearly empty last round is cut into ATT_NSPLIT key ranges ----
         // bit 0: s_setprio around the matrix clusters; bit 1: packed-f32 softmax; bit 2: static priority for waves 4..7
@@ -1585,10 +1556,35 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
             (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_attn_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, stream);
         }
 #endif
+        if (g_attn_w64) {
+            // ---- shipped main launch: one wave per SIMD, 64 query rows per wave (attn_fwd_d128_w64_kernel); the split tail
+            // below stays on the 4-cluster kernel ----
+            auto w64 = attn_fwd_d128_w64_kernel;
+#ifdef APEXMI_ATTN_W64_ABLATE
+            switch (g_attn_w64) {
+                case 2: w64 = attn_fwd_d128_w64_abl1_kernel; break;
+                case 3: w64 = attn_fwd_d128_w64_abl2_kernel; break;
+                case 4: w64 = attn_fwd_d128_w64_abl3_kernel; break;
+                case 5: w64 = attn_fwd_d128_w64_abl4_kernel; break;
+                case 6: w64 = attn_fwd_d128_w64_abl5_kernel; break;
+                case 7: w64 = attn_fwd_d128_w64_abl6_kernel; break;
+                default: break;
+            }
+            (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
+#endif
+            static uint64_t w64_attr = 0;
+            APEXMI_SET_ATTR_ONCE(w64_attr,
+                (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE));
+            hipLaunchKernelGGL(w64, dim3(main_wgs), dim3(256), 4 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
+                               o_strides[2], c);
+            if (int rc = apexmi_check_launch("attn_fwd_d128_w64")) return rc;
+        } else {
         hipLaunchKernelGGL(c4, dim3(main_wgs), dim3(512), c4_lds, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
                            o_strides[2], c, 0, 1, (float*)nullptr, (float*)nullptr);
         if (int rc = apexmi_check_launch("attn_fwd_d128")) return rc;
+        }
         if (tail) {
             float* opart = (float*)workspace;
             float* lse = (float*)((char*)workspace + (size_t)tail * ATT_NSPLIT * 256 * HD * 4);

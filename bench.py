@@ -215,6 +215,23 @@ def cpu_baseline_wan():
                      f"{({k: round(v, 2) for k, v in sweep.items()})} s")
 
 
+def kernel_source_sha256(src_file):
+    """sha256 of a kernel translation unit: the .hip file followed by its generated / multi-include pieces in csrc/ (for
+    attention.hip: attn_*.h, attn_*.inc = the generated loop of the w64 kernel), in sorted order.  tools/gpu_pmc*.sh record the same."""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "apex-studio_amd", "csrc")
+    stem = {"attention.hip": "attn_"}.get(src_file)
+    files = [os.path.join(csrc, src_file)]
+    if stem:
+        files += sorted(glob.glob(os.path.join(csrc, stem + "*.h")) + glob.glob(os.path.join(csrc, stem + "*.inc")))
+    h = hashlib.sha256()
+    for fn in files:
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(src_file, suffix):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc summary (tools/gpu_pmc*.sh; separate passes, cannot run inside
     this process): used ONLY if it was taken from the kernel source this binary was built from (sha256 recorded next to it);
@@ -223,8 +240,7 @@ def pmc_traffic(src_file, suffix):
     import hashlib
     if not suffix:
         return None, None, None
-    with open(os.path.join(ROOT, "apex-studio_amd", "csrc", src_file), "rb") as f:
-        src_hash = hashlib.sha256(f.read()).hexdigest()
+    src_hash = kernel_source_sha256(src_file)
     for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{suffix}")), reverse=True):
         rec = json.load(open(pmc))
         if rec.get("source_sha256") == src_hash:
@@ -281,7 +297,7 @@ def wan_half(dev, cpu=True):
     ach = att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] else None
     traffic, traffic_src, rec = pmc_traffic("attention.hip", "pmc_attn_wan.json")
     alg = (rec or {}).get("algorithmic_bytes_per_launch")
-    roof = {"bound": "mfma", "kernel": "attn_fwd_d128_c4_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    roof = {"bound": "mfma", "kernel": "attn_fwd_d128_w64_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_BF16_TFLOPS if ach else None, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (traffic / alg) if traffic and alg else None,
             "avg_launch_us": 1e3 * att["ms"] / att["launches"] if att["launches"] else None,
@@ -876,7 +892,7 @@ def main():
         suffix = {("gemm", "flux"): "pmc_gemm.json", ("gemm", "qwen"): "pmc_gemm_qwen.json",
                   ("attention", "wan"): "pmc_attn_wan.json"}.get((dom, args.workload))
         traffic, traffic_src, pmc_rec = pmc_traffic("gemm.hip" if dom == "gemm" else "attention.hip", suffix)
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_c4_kernel",
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom == "gemm" else "attn_fwd_d128_w64_kernel",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
                     "launches_per_step": gk["launches"] / nprof,

@@ -548,14 +548,66 @@ def test_attention_four_cluster_variant(shape, c4):
     v = seeded((B, H, Sk, 128), 387, torch.bfloat16)
     lib.tune_set("attn.waves", 8)
     lib.tune_set("attn.c4", c4)
+    lib.tune_set("attn.w64", 0)            # the variants of the 4-cluster kernel itself (the shipped main launch is attn.w64)
     try:
         out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
         out2 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     finally:
         lib.tune_set("attn.waves", 0)
         lib.tune_set("attn.c4", 3)
+        lib.tune_set("attn.w64", 1)
     _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention c4 {shape}", ulp=3.0)
     assert torch.equal(out.cpu(), out2.cpu())
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 2, 256, 128), (1, 2, 256, 192), (1, 2, 256, 320), (1, 1, 64, 40),
+                                   (1, 2, 700, 333), (2, 3, 260, 1000), (1, 4, 1536, 1536), (1, 3, 513, 4097)])
+def test_attention_w64_kernel(shape):
+    """`attn.w64` (shipped main launch): one wave per SIMD, 64 query rows per wave, the loop one generated asm statement
+    (tools/gen_attn_w64.py).  One to five key tiles exercise every tail body of the generated loop (last / one / two more tiles),
+    ragged key counts the masking of the last tile, 513 rows the clamped query rows.  Same bar as the 4-cluster kernel against
+    the oracle, bit-identical repeats (race screen of the LDS ring / barrier choreography), and within one bf16 ulp on a few
+    elements in 1e5 of the 4-cluster kernel (same rounding points, different f32 summation order of the row sums)."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    B, H, Sq, Sk = shape
+    q = seeded((B, H, Sq, 128), 785, torch.bfloat16)
+    k = seeded((B, H, Sk, 128), 786, torch.bfloat16)
+    v = seeded((B, H, Sk, 128), 787, torch.bfloat16)
+    lib.tune_set("attn.waves", 8)
+    try:
+        lib.tune_set("attn.w64", 1)
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+        out2 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+        lib.tune_set("attn.w64", 0)
+        c4 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+    finally:
+        lib.tune_set("attn.waves", 0)
+        lib.tune_set("attn.w64", 1)
+    _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention w64 {shape}", ulp=3.0)
+    assert torch.equal(out.cpu(), out2.cpu())
+    frac = float((out != c4).float().mean())
+    rel = float((out.float() - c4.float()).norm() / c4.float().norm())
+    assert frac < 2e-3 and rel < 2e-4, (shape, frac, rel)
+
+
+def test_attention_w64_running_max_rescale_and_flux_shape():
+    """The w64 kernel's rare paths at full width: a key whose score towers over the running max late in the sequence forces the
+    per-row rescale of O^T (through the AGPR accumulators), and the Flux launch geometry (24 heads x 4608, 432 workgroups)."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    H, S = 24, 4608
+    q = seeded((1, H, S, 128), 811, torch.bfloat16)
+    k = seeded((1, H, S, 128), 812, torch.bfloat16)
+    v = seeded((1, H, S, 128), 813, torch.bfloat16)
+    k[0, :, 3000] = q[0, :, 100] * 4.0          # rows near 100 get a score far above everything seen in the first 46 tiles
+    k[0, :, 4500] = q[0, :, 2000] * 8.0
+    lib.tune_set("attn.w64", 1)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    rows = torch.cat([torch.arange(90, 110), torch.arange(1990, 2010), torch.arange(0, S, 257)])
+    ref = OL.sdpa(q[:, :, rows].float(), k.float(), v.float())
+    _check(out[:, :, rows], ref, 1e-2, "attention w64 rescale", ulp=3.0)
+    assert torch.isfinite(out).all()
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])

@@ -26,7 +26,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "drain": 2}   # schedule options (CLI --opt k=v)
+OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -262,20 +262,35 @@ def dma_piece(em, j):
         em.i("buffer_load_dwordx4 %[vv], %[rv], s48 offen lds")
 
 
-def stage_regs(em):
-    """scalars of tile t = s40"""
-    em.i("s_add_i32 s41, s40, 1")
-    em.i("s_and_b32 s41, s41, 3")
-    em.i("s_lshl_b32 s42, s41, 15")                 # K read stage of tile t + 1
-    em.i("s_and_b32 s41, s40, 3")
-    em.i("s_lshl_b32 s43, s41, 15")
-    em.i("s_add_i32 s43, s43, 16384")               # V^T read stage of tile t
-    em.i("s_add_i32 s41, s40, 3")
-    em.i("s_lshl_b32 s45, s41, 14")                 # K bytes of tile t + 3
-    em.i("s_lshl_b32 s46, s41, 7")                  # V^T bytes of tile t + 3
+def dma_regs(em, tile_expr_add):
+    """scalars of the LDS-DMA of tile s40 + tile_expr_add: s44 = its stage (+ this wave's piece), s45 / s46 = K / V^T byte offsets"""
+    em.i(f"s_add_i32 s41, s40, {tile_expr_add}")
+    em.i("s_lshl_b32 s45, s41, 14")
+    em.i("s_lshl_b32 s46, s41, 7")
     em.i("s_and_b32 s41, s41, 3")
     em.i("s_lshl_b32 s44, s41, 15")
-    em.i("s_add_i32 s44, s44, %[w]")                # DMA stage of tile t + 3 (+ this wave's piece)
+    em.i("s_add_i32 s44, s44, %[w]")
+
+
+def kstage_reg(em, add):
+    """s42 = LDS offset of the K image of tile s40 + add"""
+    em.i(f"s_add_i32 s41, s40, {add}")
+    em.i("s_and_b32 s41, s41, 3")
+    em.i("s_lshl_b32 s42, s41, 15")
+
+
+def vstage_reg(em):
+    """s43 = LDS offset of the V^T image of tile s40"""
+    em.i("s_and_b32 s41, s40, 3")
+    em.i("s_lshl_b32 s43, s41, 15")
+    em.i("s_add_i32 s43, s43, 16384")
+
+
+def k_first_reads(em):
+    """first-step K fragments of the tile whose stage is in s42 (the tile phase X computes next): issued a phase early"""
+    em.i(f"v_add_u32 {vr(KB)}, s42, %[ka]")
+    em.ds_read(KF(0, 0), KB, 0)
+    em.ds_read(KF(0, 1), KB, 8192)
 
 
 def mask_block(em, st):
@@ -317,19 +332,19 @@ def rescale_block(em):
         em.i(f"{skip}:")
 
 
-def tile(em, par, more, dma):
+def tile(em, par, more, more2, dma):
+    """tile t = s40, score set par.  more: tile t+1 exists (phase X computes its scores; its first K fragments are already in flight);
+    more2: tile t+2 exists (its first K fragments are read at the end of phase Y); dma: tile t+3 exists (staged in phase Y)"""
     st, ns = par, par ^ 1
-    TS = 80 if TRACE else 0          # trace stamps live in s[80:87]
     # ---------------- phase X: S(t+1) = K(t+1) Q^T beside exp2 / bf16 pairs (/ row-sum terms) of tile t ----------------
     em.in_loop = True
+    em.lds = [KF(0, 0), KF(0, 1)] if (more and ABL["reads"]) else []
     if TRACE:
         em.i("s_memtime s[80:81]")
     q = sm2_ops(st, with_adds=OPT["adds_in"] == "X") if ABL["fill_x"] else []
-    pre, gaps = spread(q, 32, first_extra=6)
-    if more:
-        em.i(f"v_add_u32 {vr(KB)}, s42, %[ka]")
-        em.ds_read(KF(0, 0), KB, 0)
-        em.ds_read(KF(0, 1), KB, 8192)
+    pre, gaps = spread(q, 32, first_extra=OPT["pre_x"])
+    for k in range(OPT["dummy_x"]):   # experiment: independent VALU ops in the gaps
+        gaps[k * 32 // OPT["dummy_x"]].append(f"v_mov_b32 v{238 + (k & 3)}, 1.0")
     for op in pre:
         em.i(op)
     vread_slot = 32 - OPT["vread_early"]
@@ -346,24 +361,23 @@ def tile(em, par, more, dma):
                 mfma(em, S(ns, e, kt), KF(ks & 1, kt), Q(e, ks), None if ks == 0 else 1, b_a=True)
             for op in gaps[slot]:
                 em.i(op)
-            if dma and OPT["dma_in"] == "X" and (slot & 3) == 1:
-                dma_piece(em, slot >> 2)
-            if slot == vread_slot - 1 or (slot == 31 and vread_slot >= 32):
-                # V^T fragments of the first step of phase Y: their latency rides under the tail of phase X (after the K reads of
-                # step 7, which were issued at the top of step 6: the LDS returns in order)
+            if slot == vread_slot - 1:
+                # V^T fragments of the first step of phase Y: their latency rides under the tail of phase X
                 em.i(f"v_add_u32 {vr(VB)}, s43, %[va]")
                 for dt in range(4):
                     em.ds_read(VF(0, dt), VB, dt * 4096)
     if TRACE:
         em.i("s_memtime s[82:83]")
     if more:
-        drain(em, OPT["drain"])                      # S(t+1) is read by VALU from here on
+        # no drain here: the first VALU reads of S(t+1) (row max) follow the row-sum terms of tile t, ten MFMA gaps into phase Y;
+        # only the (once per workgroup) masking of a ragged last tile reads S(t+1) at once
         lm = em.label("nomask")
         em.i("s_add_i32 s47, s40, 2")
         em.i("s_cmp_lg_u32 s47, %[nt]")              # tile t + 1 is the last one ...
         em.i(f"s_cbranch_scc1 {lm}")
         em.i("s_cmp_eq_u32 %[rem], 0")               # ... and ragged
         em.i(f"s_cbranch_scc1 {lm}")
+        drain(em, 3)
         mask_block(em, ns)
         em.i(f"{lm}:")
     # ---------------- phase Y: O^T += V^T(t) P(t)^T beside (row-sum terms of tile t,) max / decision / scaling of tile t+1 ------
@@ -374,7 +388,24 @@ def tile(em, par, more, dma):
         if more:
             q += sm1_ops(ns)
     _, gaps = spread(q, 32)
+    for k in range(OPT["dummy_y"]):
+        gaps[k * 32 // OPT["dummy_y"]].append(f"v_mov_b32 v{238 + (k & 3)}, 1.0")
     for kk in range(4):
+        if kk == 2:
+            # ---- the tile's one barrier, in the MIDDLE of the phase: tile t + 2 (staged a tile ago) becomes visible, and every
+            # wave has left phase Y(t - 1), whose V^T stage the LDS-DMA of tile t + 3 (below) overwrites.  The MFMAs of steps 0 / 1
+            # are still in the pipe while the waves meet. ----
+            if TRACE:
+                em.i("s_memtime s[84:85]")
+            em.i("s_waitcnt vmcnt(0)")
+            if ABL["barrier"]:
+                em.i("s_barrier")
+            if TRACE:
+                em.i("s_memtime s[86:87]")
+            if dma:
+                dma_regs(em, 3)
+            if more2:
+                kstage_reg(em, 2)
         if kk + 1 < 4:
             em.i(f"v_xor_b32 {vr(T[9])}, {(kk + 1) << 5}, {vr(VB)}")
             for dt in range(4):
@@ -386,44 +417,41 @@ def tile(em, par, more, dma):
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
             for op in gaps[slot]:
                 em.i(op)
-            if dma and OPT["dma_in"] == "Y" and (slot & 3) == 1:
-                dma_piece(em, slot >> 2)
+            if dma and slot >= 16 and (slot & 1) == 1:
+                dma_piece(em, (slot - 16) >> 1)
+            if more2 and slot == 31 - OPT["kread_early"]:
+                k_first_reads(em)                        # first K fragments of tile t + 2, for phase X of the next tile
     if more:
         rescale_block(em)
-    if TRACE:
-        em.i("s_memtime s[84:85]")
-    em.i("s_waitcnt vmcnt(8)" if dma and ABL["dma"] else "s_waitcnt vmcnt(0)")
-    if TRACE:
-        em.i("s_memtime s[86:87]")
-    if ABL["barrier"]:
-        em.i("s_barrier")
-    if TRACE:   # s[64:69] += phase X, phase Y, DMA wait; s[70:71] += barrier + scalar bookkeeping (from the previous tile's last stamp)
-        em.i("s_waitcnt lgkmcnt(0)")
-        for acc, (hi_, lo_) in ((64, (82, 80)), (66, (84, 82)), (68, (86, 84))):
+    em.i("s_add_i32 s40, s40, 1")
+    vstage_reg(em)
+    if TRACE:   # s[64:65] += phase X, s[66:67] += phase Y (both halves), s[68:69] += DMA wait + barrier
+        em.i("s_memtime s[88:89]")
+        em.i("s_waitcnt lgkmcnt(0)")                     # (drains the early K reads too: the next body's counted waits stay valid)
+        for acc, (hi_, lo_) in ((64, (82, 80)), (66, (84, 82)), (68, (86, 84)), (66, (88, 86))):
             em.i(f"s_sub_u32 s76, s{hi_}, s{lo_}")
             em.i(f"s_subb_u32 s77, s{hi_ + 1}, s{lo_ + 1}")
             em.i(f"s_add_u32 s{acc}, s{acc}, s76")
             em.i(f"s_addc_u32 s{acc + 1}, s{acc + 1}, s77")
-        em.i("s_sub_u32 s76, s80, s74")
+        em.i("s_sub_u32 s76, s80, s74")                  # tile edge: from the previous tile's last stamp to this tile's first
         em.i("s_subb_u32 s77, s81, s75")
         em.i("s_add_u32 s70, s70, s76")
         em.i("s_addc_u32 s71, s71, s77")
-        em.i("s_mov_b64 s[74:75], s[86:87]")
-    em.i("s_add_i32 s40, s40, 1")
-    stage_regs(em)
+        em.i("s_mov_b64 s[74:75], s[88:89]")
+    # the scoreboard at the tile edge: the next body assumes exactly the early K reads (or nothing)
+    want = [KF(0, 0), KF(0, 1)] if (more2 and ABL["reads"]) else []
+    assert em.lds == want, (em.lds, want)
 
 
 def dispatch(em, par, labels, done):
-    """choose the body of tile s40 with parity par"""
+    """choose the body of tile s40 with parity par: f = tiles t+1..t+3 exist, m2 = t+1, t+2, m1 = t+1 only, l = last"""
     em.i(f"{labels[('top', par)]}:")
     em.i("s_cmp_ge_u32 s40, %[nt]")
     em.i(f"s_cbranch_scc1 {done}")
-    em.i("s_add_i32 s47, s40, 3")
-    em.i("s_cmp_lt_u32 s47, %[nt]")
-    em.i(f"s_cbranch_scc1 {labels[('f', par)]}")
-    em.i("s_add_i32 s47, s40, 1")
-    em.i("s_cmp_lt_u32 s47, %[nt]")
-    em.i(f"s_cbranch_scc1 {labels[('m', par)]}")
+    for add, k in ((3, "f"), (2, "m2"), (1, "m1")):
+        em.i(f"s_add_i32 s47, s40, {add}")
+        em.i("s_cmp_lt_u32 s47, %[nt]")
+        em.i(f"s_cbranch_scc1 {labels[(k, par)]}")
     em.i(f"s_branch {labels[('l', par)]}")
 
 
@@ -456,13 +484,13 @@ def main():
         em.i(f"s_mov_b64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
     for k in range(128):
         em.i(f"v_accvgpr_write_b32 {ar(k)}, 0")
-    # tiles 0..2 staged: `stage_regs` computes the scalars for tile s40 + 3
+    # tiles 0..2 staged
     for tt in range(3):
         skip = em.label("nost")
         em.i(f"s_cmp_le_u32 %[nt], {tt}")
         em.i(f"s_cbranch_scc1 {skip}")
-        em.i(f"s_mov_b32 s40, {tt - 3}")
-        stage_regs(em)
+        em.i(f"s_mov_b32 s40, {tt}")
+        dma_regs(em, 0)
         for j in range(8):
             dma_piece(em, j)
         em.i(f"{skip}:")
@@ -513,7 +541,14 @@ def main():
     em.i(f"{lw}:")
     em.i("s_barrier")
     em.i("s_mov_b32 s40, 0")
-    stage_regs(em)
+    vstage_reg(em)
+    lk = em.label("nok1")
+    em.i("s_cmp_lt_u32 %[nt], 2")
+    em.i(f"s_cbranch_scc1 {lk}")
+    kstage_reg(em, 1)
+    k_first_reads(em)                                 # first K fragments of tile 1: phase X of tile 0 expects them in flight
+    em.i(f"{lk}:")
+    em.lds = []
     if TRACE:
         for k in range(64, 72, 2):
             em.i(f"s_mov_b64 s[{k}:{k + 1}], 0")
@@ -522,17 +557,16 @@ def main():
     # ---------------- tiles ----------------
     labels = {}
     for par in range(2):
-        for k in ("top", "f", "m", "l"):
+        for k in ("top", "f", "m2", "m1", "l"):
             labels[(k, par)] = em.label(f"{k}{par}")
     done = em.label("done")
     em.i(f"s_branch {labels[('top', 0)]}")
     for par in range(2):
         dispatch(em, par, labels, done)
-        for k, more, dma in (("f", True, True), ("m", True, False), ("l", False, False)):
+        for k, more, more2, dma in (("f", True, True, True), ("m2", True, True, False), ("m1", True, False, False),
+                                    ("l", False, False, False)):
             em.i(f"{labels[(k, par)]}:")
-            assert not em.lds
-            tile(em, par, more, dma)
-            assert not em.lds
+            tile(em, par, more, more2, dma)
             em.i(f"s_branch {labels[('top', par ^ 1)]}")
     em.i(f"{done}:")
     drain(em)

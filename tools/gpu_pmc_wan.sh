@@ -15,8 +15,10 @@ timeout $T rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-fo
 timeout $T rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -o wan -- $CMD > $OUT/sq.log 2>&1; echo "sq $?"
 cd $R
 python - <<'PY'
-import csv, glob, hashlib, json, os
+import csv, glob, hashlib, json, os, sys
 root = os.environ["GRAFT_REPO_ROOT"]
+sys.path.insert(0, root)
+import bench   # kernel_source_sha256: attention.hip + its generated includes, the hash bench.py matches against
 out = root + "/gpurun_out/pmc_wan/"
 def means(sub):
     vals, durs = {}, []
@@ -34,9 +36,9 @@ w, _ = means("write")
 s, _ = means("sq")
 S, H, D, T = 75600, 40, 128, 512
 alg = ((4 * H * S * D * 2) + (2 * H * S * D * 2 + 2 * H * T * D * 2)) / 2      # mean of a self- and a cross-attention launch (q, k, v, o / q, o + 512-key k, v)
-res = {"kernel": "attn_fwd_d128_c4_kernel<8, 2> (self-attention, S 75600) and attn_fwd_d128_kernel<4> (cross-attention, 512 keys)",
+res = {"kernel": "attn_fwd_d128_w64_kernel (self-attention, S 75600) and attn_fwd_d128_kernel<4> (cross-attention, 512 keys)",
        "command": "python bench.py --workload wan --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-clip",
-       "source_sha256": hashlib.sha256(open(root + "/apex-studio_amd/csrc/attention.hip", "rb").read()).hexdigest(),
+       "source_sha256": bench.kernel_source_sha256("attention.hip"),
        "dispatches": n, "avg_duration_ns_under_pmc": ns, "algorithmic_bytes_per_launch": int(alg),
        "note": "mean over the 80 attention launches of one expert forward (40 self-attention S = 75600, 40 cross-attention Sk = 512); "
                "every q-block round of a head streams that head's K and V^T again because 4 MiB of L2 per XCD cannot hold them; "
