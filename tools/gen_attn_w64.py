@@ -91,6 +91,7 @@ class Emit:
         self.lds = []          # destination base registers of outstanding ds_reads, issue order
         self.label_n = 0
         self.in_loop = False
+        self.pending_raise = None
 
     def i(self, s):
         self.lines.append(s)
@@ -136,9 +137,7 @@ def drain(em, n=2):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-def sm1_ops(ns):
-    """row max of set ns, running-max decision (the row-sum partials take the rescale factor here), scaled differences"""
-    q = []
+def max_chain_ops(ns):
     chains = []
     for e in range(2):
         for kt in range(2):
@@ -148,22 +147,27 @@ def sm1_ops(ns):
                 ops.append(f"v_max3_f32 {vr(MX(e, kt))}, {vr(MX(e, kt))}, {vr(b + 3 + 2 * j)}, {vr(b + 4 + 2 * j)}")
             ops.append(f"v_max_f32 {vr(MX(e, kt))}, {vr(MX(e, kt))}, {vr(b + 15)}")
             chains.append(ops)
-    for j in range(8):
-        for c in chains:
-            q.append(c[j])
-    dec = []
-    for e in range(2):
-        t0, t1, t2, t3 = T[4 * e:4 * e + 4]
-        dec.append([
-            f"v_max_f32 {vr(MX(e, 0))}, {vr(MX(e, 0))}, {vr(MX(e, 1))}",
+    return [c[j] for j in range(8) for c in chains]          # four chains, round robin
+
+
+def dec_test_ops(e):
+    """tile max of block e (scaled) in T[4 e]; lanes whose running max must rise in s[50 + 2 e : 51 + 2 e]"""
+    t0, t1 = T[4 * e], T[4 * e + 1]
+    return [f"v_max_f32 {vr(MX(e, 0))}, {vr(MX(e, 0))}, {vr(MX(e, 1))}",
             f"v_mov_b32 {vr(t0)}, {vr(MX(e, 0))}",
             "s_nop 1",
             f"v_permlane32_swap_b32 {vr(t0)}, {vr(MX(e, 0))}",
             f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(MX(e, 0))}",
             f"v_mul_f32 {vr(t0)}, %[sc], {vr(t0)}",                      # m1 = tile max, scaled
             f"v_add_f32 {vr(t1)}, {DEFER}, {vr(M_(e))}",
-            f"v_max_f32 {vr(t2)}, {vr(M_(e))}, {vr(t0)}",
-            f"v_cmp_gt_f32 s[{50 + 2 * e}:{51 + 2 * e}], {vr(t0)}, {vr(t1)}",   # not vcc: the two blocks' chains interleave
+            f"v_cmp_gt_f32 s[{50 + 2 * e}:{51 + 2 * e}], {vr(t0)}, {vr(t1)}"]   # not vcc: the two blocks' chains interleave
+
+
+def dec_raise_ops(e):
+    """the rows of s[50 + 2 e : ...] take the new integer maximum; the row-sum partials take the factor; s[54 + 2 e : ...] = the
+    lanes whose O^T needs it (applied after the phase's MFMAs)"""
+    t0, t2, t3 = T[4 * e], T[4 * e + 2], T[4 * e + 3]
+    return [f"v_max_f32 {vr(t2)}, {vr(M_(e))}, {vr(t0)}",
             f"v_ceil_f32 {vr(t2)}, {vr(t2)}",
             f"v_cndmask_b32 {vr(t2)}, {vr(M_(e))}, {vr(t2)}, s[{50 + 2 * e}:{51 + 2 * e}]",       # m_new
             f"v_sub_f32 {vr(t3)}, {vr(M_(e))}, {vr(t2)}",
@@ -174,11 +178,11 @@ def sm1_ops(ns):
             f"v_mul_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(AL_(e))}",
             f"v_mul_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(AL_(e))}",
             f"v_mul_f32 {vr(PS(e, 3))}, {vr(PS(e, 3))}, {vr(AL_(e))}",
-            f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}",   # does O^T of this block need the factor?
-        ])
-    for j in range(len(dec[0])):
-        q.append(dec[0][j] + " ;dec")
-        q.append(dec[1][j] + " ;dec")
+            f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}"]
+
+
+def scale_ops(ns):
+    q = []
     for e in range(2):
         for w in range(0, 32, 2):
             r = Sreg(ns, e * 32 + w)
@@ -188,6 +192,24 @@ def sm1_ops(ns):
                 q.append(f"v_fma_f32 {vr(r)}, {vr(r)}, %[sc], -{vr(M_(e))}")
                 q.append(f"v_fma_f32 {vr(r + 1)}, {vr(r + 1)}, %[sc], -{vr(M_(e))}")
     return q
+
+
+def sm1_ops(ns, inline_raise):
+    """row max of set ns, the running-max test, (the raise,) the scaled differences.  inline_raise: the raise of both blocks in line
+    (prologue); otherwise the marker @RAISE stands where the loop branches to its out-of-line raise when any row needs one"""
+    q = max_chain_ops(ns)
+    d0, d1 = dec_test_ops(0), dec_test_ops(1)
+    for j in range(len(d0)):
+        q.append(d0[j] + " ;dec")
+        q.append(d1[j] + " ;dec")
+    if inline_raise:
+        r0, r1 = dec_raise_ops(0), dec_raise_ops(1)
+        for j in range(len(r0)):
+            q.append(r0[j])
+            q.append(r1[j])
+    else:
+        q.append("@RAISE")
+    return q + scale_ops(ns)
 
 
 def add_ops(st):
@@ -235,7 +257,7 @@ def spread(q, nslots, first_extra=0):
         if not ABL[k]:
             q = [op for op in q if not op.startswith(pre)]   # pre: a prefix or a tuple of prefixes
     if not ABL["dec"]:
-        q = [op for op in q if not op.endswith(";dec")]
+        q = [op for op in q if not op.endswith(";dec") and op != "@RAISE"]
     if not q:
         return [], [[] for _ in range(nslots)]
     pre, rest = q[:first_extra], q[first_extra:]
@@ -386,8 +408,9 @@ def tile(em, par, more, more2, dma):
         if OPT["adds_in"] == "Y":
             q += add_ops(st)
         if more:
-            q += sm1_ops(ns)
+            q += sm1_ops(ns, inline_raise=False)
     _, gaps = spread(q, 32)
+    raise_lbl, raise_ret = em.label("raise"), em.label("raised")
     for k in range(OPT["dummy_y"]):
         gaps[k * 32 // OPT["dummy_y"]].append(f"v_mov_b32 v{238 + (k & 3)}, 1.0")
     for kk in range(4):
@@ -416,7 +439,16 @@ def tile(em, par, more, more2, dma):
                 em.need(VF(kk & 1, 3))                   # one wait per step
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
             for op in gaps[slot]:
-                em.i(op)
+                if op == "@RAISE":       # any row of either block above its running max + DEFER?  (rare after the first tiles)
+                    em.i("s_or_b64 s[58:59], s[50:51], s[52:53]")
+                    em.i("s_mov_b64 s[54:55], 0")
+                    em.i("s_mov_b64 s[56:57], 0")
+                    em.i("s_cmp_lg_u64 s[58:59], 0")
+                    em.i(f"s_cbranch_scc1 {raise_lbl}")
+                    em.i(f"{raise_ret}:")
+                    have_raise = True
+                else:
+                    em.i(op)
             if dma and slot >= 16 and (slot & 1) == 1:
                 dma_piece(em, (slot - 16) >> 1)
             if more2 and slot == 31 - OPT["kread_early"]:
@@ -425,6 +457,7 @@ def tile(em, par, more, more2, dma):
         rescale_block(em)
     em.i("s_add_i32 s40, s40, 1")
     vstage_reg(em)
+    em.pending_raise = (raise_lbl, raise_ret) if (more and ABL["fill_y"] and ABL["dec"]) else None
     if TRACE:   # s[64:65] += phase X, s[66:67] += phase Y (both halves), s[68:69] += DMA wait + barrier
         em.i("s_memtime s[88:89]")
         em.i("s_waitcnt lgkmcnt(0)")                     # (drains the early K reads too: the next body's counted waits stay valid)
@@ -527,7 +560,7 @@ def main():
     em.i(f"s_cbranch_scc1 {lm}")
     mask_block(em, 0)
     em.i(f"{lm}:")
-    for op in sm1_ops(0):
+    for op in sm1_ops(0, inline_raise=True):
         em.i(op.replace(' ;dec', ''))
     for e in range(2):
         em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")          # O is still zero: nothing to rescale
@@ -568,6 +601,13 @@ def main():
             em.i(f"{labels[(k, par)]}:")
             tile(em, par, more, more2, dma)
             em.i(f"s_branch {labels[('top', par ^ 1)]}")
+            if em.pending_raise:         # out of line: the raise of the running maxima (both blocks; lanes that need none keep theirs)
+                em.i(f"{em.pending_raise[0]}:")
+                r0, r1 = dec_raise_ops(0), dec_raise_ops(1)
+                for j in range(len(r0)):
+                    em.i(r0[j])
+                    em.i(r1[j])
+                em.i(f"s_branch {em.pending_raise[1]}")
     em.i(f"{done}:")
     drain(em)
     if TRACE:   # lane 0 of every wave: {phase X, phase Y, DMA wait, barrier} cycles summed over the tiles
