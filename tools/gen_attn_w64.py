@@ -336,6 +336,9 @@ def mask_block(em, st):
 def rescale_block(em):
     """O^T *= alpha for a block whose running max rose (rare): through VGPR temporaries.  s[54:55] / s[56:57]... the decision left
     `alpha != 1` lane masks in s[54:55] (block A) and s[56:57] (block B): the test at the edge is scalar"""
+    none = em.label("norsall")
+    em.i("s_cmp_eq_u64 s[58:59], 0")                 # no row of either block was raised in this tile (the usual case)
+    em.i(f"s_cbranch_scc1 {none}")
     for e in range(2):
         skip = em.label("nors")
         em.i(f"s_cmp_eq_u64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
@@ -352,6 +355,7 @@ def rescale_block(em):
                 em.i(f"v_accvgpr_write_b32 {ar(e * 64 + k + u)}, {vr(T[u])}")
         em.i("s_nop 7")
         em.i(f"{skip}:")
+    em.i(f"{none}:")
 
 
 def tile(em, par, more, more2, dma):
@@ -390,14 +394,11 @@ def tile(em, par, more, more2, dma):
                     em.ds_read(VF(0, dt), VB, dt * 4096)
     if TRACE:
         em.i("s_memtime s[82:83]")
-    if more:
-        # no drain here: the first VALU reads of S(t+1) (row max) follow the row-sum terms of tile t, ten MFMA gaps into phase Y;
-        # only the (once per workgroup) masking of a ragged last tile reads S(t+1) at once
+    if more and not more2:
+        # tile t + 1 is the last one (this body only): mask its keys past Sk if it is ragged.  No drain anywhere else: the first VALU
+        # reads of S(t+1) (row max) follow the row-sum terms of tile t, ten MFMA gaps into phase Y
         lm = em.label("nomask")
-        em.i("s_add_i32 s47, s40, 2")
-        em.i("s_cmp_lg_u32 s47, %[nt]")              # tile t + 1 is the last one ...
-        em.i(f"s_cbranch_scc1 {lm}")
-        em.i("s_cmp_eq_u32 %[rem], 0")               # ... and ragged
+        em.i("s_cmp_eq_u32 %[rem], 0")
         em.i(f"s_cbranch_scc1 {lm}")
         drain(em, 3)
         mask_block(em, ns)
@@ -600,6 +601,10 @@ def main():
                                     ("l", False, False, False)):
             em.i(f"{labels[(k, par)]}:")
             tile(em, par, more, more2, dma)
+            if k == "f":                 # steady state: straight to the other parity's full body while three more tiles exist
+                em.i("s_add_i32 s47, s40, 3")
+                em.i("s_cmp_lt_u32 s47, %[nt]")
+                em.i(f"s_cbranch_scc1 {labels[('f', par ^ 1)]}")
             em.i(f"s_branch {labels[('top', par ^ 1)]}")
             if em.pending_raise:         # out of line: the raise of the running maxima (both blocks; lanes that need none keep theirs)
                 em.i(f"{em.pending_raise[0]}:")
