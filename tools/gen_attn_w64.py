@@ -18,7 +18,7 @@ Register map
   v[128:159] P (bf16): block e, 16-key step kk at 128 + 16 e + 4 kk
   v[160:175] K fragment ring (2 x 2 fragments)   v[176:207] V^T fragment ring (2 x 4 fragments)
   v[208:215] row-sum partials (4 per block, carried over the tiles)  v[216:219] row-max chains  v220/222 m  v221/223 alpha
-  v[226:235] temporaries  v236 K read base  v237 V^T read base
+  v[226:235] temporaries  v236 K read base  v237 V^T read base  v[238:243] LDS-DMA offsets of pieces 1..3 (K, V^T)
   a[0:127]   O^T: block e, d-tile dt at 64 e + 16 dt               a[128:191] Q fragments: 128 + 32 e + 4 ks
   s[40:63]   scalar temporaries (tile counter, stage offsets, DMA offsets)
 """
@@ -267,21 +267,21 @@ def spread(q, nslots, first_extra=0):
     return pre, out
 
 
-def dma_piece(em, j):
-    """LDS-DMA piece j (0..3 K, 4..7 V^T) of tile t + 3: s44 = LDS base of the stage + wave, s45 / s46 = K / V^T tile offsets"""
+def dma_piece(em, j, part=3):
+    """LDS-DMA piece j (0..3 K, 4..7 V^T) of a tile: s44 = LDS base of its stage (+ this wave's piece), s45 / s46 = its K / V^T byte
+    offsets, v[238:243] = the per-lane offsets of pieces 1..3.  part 1 = the M0 write, 2 = the load (M0 needs one instruction between
+    them: in the loop a gap's fillers stand there), 3 = both with an s_nop"""
     if not ABL["dma"] and em.in_loop:
         return
-    if j < 4:
-        em.i(f"s_add_i32 m0, s44, {j * 4096}")
-        em.i(f"s_add_i32 s47, s45, {j * 4096}")
-        em.i("buffer_load_dwordx4 %[vk], %[rk], s47 offen lds")
-    else:
-        em.i(f"s_add_i32 m0, s44, {16384 + (j - 4) * 4096}")
-        if j == 4:
-            em.i("s_mov_b32 s48, s46")
+    if part & 1:
+        em.i(f"s_add_i32 m0, s44, {j * 4096 if j < 4 else 16384 + (j - 4) * 4096}")
+    if part == 3:
+        em.i("s_nop 0")
+    if part & 2:
+        if j < 4:
+            em.i(f"buffer_load_dwordx4 {'%[vk]' if j == 0 else vr(237 + j)}, %[rk], s45 offen lds")
         else:
-            em.i("s_add_i32 s48, s48, %[vp]")
-        em.i("buffer_load_dwordx4 %[vv], %[rv], s48 offen lds")
+            em.i(f"buffer_load_dwordx4 {'%[vv]' if j == 4 else vr(236 + j)}, %[rv], s46 offen lds")
 
 
 def dma_regs(em, tile_expr_add):
@@ -370,7 +370,7 @@ def tile(em, par, more, more2, dma):
     q = sm2_ops(st, with_adds=OPT["adds_in"] == "X") if ABL["fill_x"] else []
     pre, gaps = spread(q, 32, first_extra=OPT["pre_x"])
     for k in range(OPT["dummy_x"]):   # experiment: independent VALU ops in the gaps
-        gaps[k * 32 // OPT["dummy_x"]].append(f"v_mov_b32 v{238 + (k & 3)}, 1.0")
+        gaps[k * 32 // OPT["dummy_x"]].append(f"v_mov_b32 v{226 + (k & 3)}, 1.0")
     for op in pre:
         em.i(op)
     vread_slot = 32 - OPT["vread_early"]
@@ -413,7 +413,7 @@ def tile(em, par, more, more2, dma):
     _, gaps = spread(q, 32)
     raise_lbl, raise_ret = em.label("raise"), em.label("raised")
     for k in range(OPT["dummy_y"]):
-        gaps[k * 32 // OPT["dummy_y"]].append(f"v_mov_b32 v{238 + (k & 3)}, 1.0")
+        gaps[k * 32 // OPT["dummy_y"]].append(f"v_mov_b32 v{226 + (k & 3)}, 1.0")
     for kk in range(4):
         if kk == 2:
             # ---- the tile's one barrier, in the MIDDLE of the phase: tile t + 2 (staged a tile ago) becomes visible, and every
@@ -439,6 +439,11 @@ def tile(em, par, more, more2, dma):
             if qq == 0:
                 em.need(VF(kk & 1, 3))                   # one wait per step
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
+            piece = dma and slot >= 16 and (slot & 1) == 1
+            if piece:
+                dma_piece(em, (slot - 16) >> 1, part=1)
+                if not gaps[slot]:
+                    em.i("s_nop 0")
             for op in gaps[slot]:
                 if op == "@RAISE":       # any row of either block above its running max + DEFER?  (rare after the first tiles)
                     em.i("s_or_b64 s[58:59], s[50:51], s[52:53]")
@@ -450,8 +455,8 @@ def tile(em, par, more, more2, dma):
                     have_raise = True
                 else:
                     em.i(op)
-            if dma and slot >= 16 and (slot & 1) == 1:
-                dma_piece(em, (slot - 16) >> 1)
+            if piece:
+                dma_piece(em, (slot - 16) >> 1, part=2)
             if more2 and slot == 31 - OPT["kread_early"]:
                 k_first_reads(em)                        # first K fragments of tile t + 2, for phase X of the next tile
     if more:
@@ -512,6 +517,11 @@ def main():
         em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")
         for i in range(4):
             em.i(f"v_mov_b32 {vr(PS(e, i))}, 0")
+    for j in range(1, 4):                             # per-piece LDS-DMA offsets: no scalar offset arithmetic in the loop
+        em.i(f"v_add_u32 {vr(237 + j)}, {j * 4096}, %[vk]")
+    em.i(f"v_add_u32 {vr(241)}, %[vp], %[vv]")
+    em.i(f"v_add_u32 {vr(242)}, %[vp], {vr(241)}")
+    em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(242)}")
     em.i("s_mov_b32 s78, %[sc]")                      # {scale, scale} for v_pk_fma_f32
     em.i("s_mov_b32 s79, %[sc]")
     for e in range(2):
