@@ -26,7 +26,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
+OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -406,10 +406,23 @@ def tile(em, par, more, more2, dma):
     # ---------------- phase Y: O^T += V^T(t) P(t)^T beside (row-sum terms of tile t,) max / decision / scaling of tile t+1 ------
     q = []
     if ABL["fill_y"]:
-        if OPT["adds_in"] == "Y":
-            q += add_ops(st)
-        if more:
-            q += sm1_ops(ns, inline_raise=False)
+        adds = add_ops(st) if OPT["adds_in"] == "Y" else []
+        sm1 = sm1_ops(ns, inline_raise=False) if more else []
+        if OPT["mix_y"] and adds and sm1:
+            # the row-sum terms of tile t (independent adds) between the dependent chains of tile t + 1 (row max, running-max test);
+            # every add stays ahead of the raise, which scales the partial sums INCLUDING tile t
+            k = sm1.index("@RAISE")
+            head, tail = sm1[:k], sm1[k:]
+            lead = 8                                         # a few adds first: S(t+1) was written by the last MFMAs of phase X
+            q += adds[:lead]
+            rest = adds[lead:]
+            for i, op in enumerate(head):
+                q.append(op)
+                lo, hi = i * len(rest) // len(head), (i + 1) * len(rest) // len(head)
+                q += rest[lo:hi]
+            q += tail
+        else:
+            q += adds + sm1
     _, gaps = spread(q, 32)
     raise_lbl, raise_ret = em.label("raise"), em.label("raised")
     for k in range(OPT["dummy_y"]):
