@@ -17,6 +17,7 @@ import apex_studio_amd  # noqa: E402,F401
 from apex_studio_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
+lib.tune_set("attn.w64", 0)   # this tool measures the 4-cluster kernel (the shipped main launch is attn.w64 = 1)
 NAMES = ["C1 K reads (+DMA)", "C2 QK^T", "C3 V reads + softmax", "C4 PV"]
 ARMS = [tuple(int(x) for x in a.split(":")) for a in os.environ.get("ARMS", "2:0,2:4").split(",")]
 g = torch.Generator(device=DEV).manual_seed(0)

@@ -12,6 +12,7 @@ import apex_studio_amd  # noqa: E402,F401
 from apex_studio_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
+lib.tune_set("attn.w64", 0)   # this tool measures the 4-cluster kernel (the shipped main launch is attn.w64 = 1)
 SHAPES = {"flux": (24, 4608), "qwen": (24, 8448), "wan": (40, 75600), "long": (8, 32768)}
 ARMS = [tuple(int(x) for x in a.split(":")) for a in os.environ.get("ARMS", "2:0,2:4").split(",")]
 

@@ -27,6 +27,7 @@ def timeit(fn, iters):
 
 
 DEV = "cuda"
+lib.tune_set("attn.w64", 0)   # this tool measures the 4-cluster kernel (the shipped main launch is attn.w64 = 1)
 for name in os.environ.get("SHAPES", "flux,qwen,wan").split(","):
     H, S = SHAPES[name]
     skp = (S + 63) // 64 * 64

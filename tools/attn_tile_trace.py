@@ -11,9 +11,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import apex_studio_amd  # noqa: E402,F401
-from apex_studio_amd import ops  # noqa: E402
+from apex_studio_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
+lib.tune_set("attn.w64", 0)   # this tool measures the 4-cluster kernel (the shipped main launch is attn.w64 = 1)
 g = torch.Generator(device=DEV).manual_seed(0)
 for name, H, S in (("flux 24 x 4608", 24, 4608), ("qwen-like 24 x 8448", 24, 8448), ("long 8 x 32768", 8, 32768)):
     skp = (S + 63) // 64 * 64
