@@ -17,8 +17,11 @@ Register map
   v[0:63]    score set 0: (block e, key half kt) at 32 e + 16 kt        v[64:127]  score set 1
   v[128:159] P (bf16): block e, 16-key step kk at 128 + 16 e + 4 kk
   v[160:175] K fragment ring (2 x 2 fragments)   v[176:207] V^T fragment ring (2 x 4 fragments)
-  v[208:215] row-sum partials (4 per block, carried over the tiles)  v[216:219] row-max chains  v220/222 m  v221/223 alpha
-  v[226:235] temporaries  v236 K read base  v237 V^T read base  v[238:243] LDS-DMA offsets of pieces 1..3 (K, V^T)
+  v[208:211] row-sum partials (2 per block, carried over the tiles)  v[212:219] K fragment read addresses (one per k-step)
+  v220/222 m  v221/223 alpha  v[226:233] temporaries (row-max chains in 228/229/232/233)  v[234:237] V^T fragment read addresses
+  v[238:243] LDS-DMA offsets of pieces 1..3 (K, V^T)
+LDS: K ring = four 16 KiB stages at 0, V^T ring = four 16 KiB stages at 64 KiB; the loop is unrolled over the four stages, so every
+stage offset is an immediate of the ds_read / an immediate of the M0 write
   a[0:127]   O^T: block e, d-tile dt at 64 e + 16 dt               a[128:191] Q fragments: 128 + 32 e + 4 ks
   s[40:63]   scalar temporaries (tile counter, stage offsets, DMA offsets)
 """
@@ -64,17 +67,24 @@ def VF(r, dt):
     return 176 + r * 16 + dt * 4
 
 
-def PS(e, i):
-    return 208 + e * 4 + i
+def PS(e, i):               # two row-sum partials per block, carried over the tiles
+    return 208 + e * 2 + i
 
 
-def MX(e, kt):
-    return 216 + e * 2 + kt
+def KA(ks):                 # K fragment read address of k-step ks (lane part; the stage is an immediate offset)
+    return 212 + ks
+
+
+def VA(kk):                 # V^T fragment read address of 16-key step kk
+    return 234 + kk
 
 
 M_, AL_ = (lambda e: 220 + 2 * e), (lambda e: 221 + 2 * e)     # running max / rescale factor of block e (m on an even register: v_pk_fma_f32)
-T = [226 + i for i in range(10)]
-KB, VB = 236, 237
+T = [226 + i for i in range(8)]
+
+
+def MX(e, kt):             # row-max chains: the raise's temporaries (dead while the chains run)
+    return T[4 * e + 2 + kt]
 
 
 def O(e, dt):
@@ -176,8 +186,6 @@ def dec_raise_ops(e):
             "s_nop 0",
             f"v_mul_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(AL_(e))}",
             f"v_mul_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(AL_(e))}",
-            f"v_mul_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(AL_(e))}",
-            f"v_mul_f32 {vr(PS(e, 3))}, {vr(PS(e, 3))}, {vr(AL_(e))}",
             f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}"]
 
 
@@ -218,11 +226,10 @@ def add_ops(st):
     for v in range(0, 64, 2):
         e, r = v >> 5, Sreg(st, v)
         if OPT["pk_add"]:
-            p0 = PS(e, v & 2)
-            q.append(f"v_pk_add_f32 {vr(p0, 2)}, {vr(p0, 2)}, {vr(r, 2)}")
+            q.append(f"v_pk_add_f32 {vr(PS(e, 0), 2)}, {vr(PS(e, 0), 2)}, {vr(r, 2)}")
         else:
-            q.append(f"v_add_f32 {vr(PS(e, v & 3))}, {vr(PS(e, v & 3))}, {vr(r)}")
-            q.append(f"v_add_f32 {vr(PS(e, (v + 1) & 3))}, {vr(PS(e, (v + 1) & 3))}, {vr(r + 1)}")
+            q.append(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(r)}")
+            q.append(f"v_add_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(r + 1)}")
     return q
 
 
@@ -267,14 +274,15 @@ def spread(q, nslots, first_extra=0):
     return pre, out
 
 
-def dma_piece(em, j, part=3):
-    """LDS-DMA piece j (0..3 K, 4..7 V^T) of a tile: s44 = LDS base of its stage (+ this wave's piece), s45 / s46 = its K / V^T byte
+def dma_piece(em, j, stage, part=3):
+    """LDS-DMA piece j (0..3 K, 4..7 V^T) of a tile into ring stage `stage` (compile time): s45 / s46 = the tile's K / V^T byte
     offsets, v[238:243] = the per-lane offsets of pieces 1..3.  part 1 = the M0 write, 2 = the load (M0 needs one instruction between
     them: in the loop a gap's fillers stand there), 3 = both with an s_nop"""
     if not ABL["dma"] and em.in_loop:
         return
     if part & 1:
-        em.i(f"s_add_i32 m0, s44, {j * 4096 if j < 4 else 16384 + (j - 4) * 4096}")
+        off = stage * 16384 + (j * 4096 if j < 4 else 65536 + (j - 4) * 4096)
+        em.i(f"s_add_i32 m0, %[w], {off}")
     if part == 3:
         em.i("s_nop 0")
     if part & 2:
@@ -284,35 +292,10 @@ def dma_piece(em, j, part=3):
             em.i(f"buffer_load_dwordx4 {'%[vv]' if j == 4 else vr(236 + j)}, %[rv], s46 offen lds")
 
 
-def dma_regs(em, tile_expr_add):
-    """scalars of the LDS-DMA of tile s40 + tile_expr_add: s44 = its stage (+ this wave's piece), s45 / s46 = K / V^T byte offsets"""
-    em.i(f"s_add_i32 s41, s40, {tile_expr_add}")
-    em.i("s_lshl_b32 s45, s41, 14")
-    em.i("s_lshl_b32 s46, s41, 7")
-    em.i("s_and_b32 s41, s41, 3")
-    em.i("s_lshl_b32 s44, s41, 15")
-    em.i("s_add_i32 s44, s44, %[w]")
-
-
-def kstage_reg(em, add):
-    """s42 = LDS offset of the K image of tile s40 + add"""
-    em.i(f"s_add_i32 s41, s40, {add}")
-    em.i("s_and_b32 s41, s41, 3")
-    em.i("s_lshl_b32 s42, s41, 15")
-
-
-def vstage_reg(em):
-    """s43 = LDS offset of the V^T image of tile s40"""
-    em.i("s_and_b32 s41, s40, 3")
-    em.i("s_lshl_b32 s43, s41, 15")
-    em.i("s_add_i32 s43, s43, 16384")
-
-
-def k_first_reads(em):
-    """first-step K fragments of the tile whose stage is in s42 (the tile phase X computes next): issued a phase early"""
-    em.i(f"v_add_u32 {vr(KB)}, s42, %[ka]")
-    em.ds_read(KF(0, 0), KB, 0)
-    em.ds_read(KF(0, 1), KB, 8192)
+def k_first_reads(em, stage):
+    """first-step K fragments of the tile in K stage `stage` (the tile phase X computes next): issued a phase early"""
+    em.ds_read(KF(0, 0), KA(0), stage * 16384)
+    em.ds_read(KF(0, 1), KA(0), stage * 16384 + 8192)
 
 
 def mask_block(em, st):
@@ -358,10 +341,12 @@ def rescale_block(em):
     em.i(f"{none}:")
 
 
-def tile(em, par, more, more2, dma):
-    """tile t = s40, score set par.  more: tile t+1 exists (phase X computes its scores; its first K fragments are already in flight);
-    more2: tile t+2 exists (its first K fragments are read at the end of phase Y); dma: tile t+3 exists (staged in phase Y)"""
-    st, ns = par, par ^ 1
+def tile(em, sg, more, more2, dma):
+    """tile t = s40 with t % 4 = sg (compile time: ring stages and the score set follow from it).  more: tile t+1 exists (phase X
+    computes its scores; its first K fragments are already in flight); more2: tile t+2 exists (its first K fragments are read at the
+    end of phase Y); dma: tile t+3 exists (staged in phase Y)"""
+    st, ns = sg & 1, (sg & 1) ^ 1
+    kst, vst, k2st, dst = (sg + 1) & 3, sg, (sg + 2) & 3, (sg + 3) & 3      # K stage of t+1, V^T stage of t, K of t+2, DMA of t+3
     # ---------------- phase X: S(t+1) = K(t+1) Q^T beside exp2 / bf16 pairs (/ row-sum terms) of tile t ----------------
     em.in_loop = True
     em.lds = [KF(0, 0), KF(0, 1)] if (more and ABL["reads"]) else []
@@ -376,9 +361,8 @@ def tile(em, par, more, more2, dma):
     vread_slot = 32 - OPT["vread_early"]
     for ks in range(8):
         if more and ks + 1 < 8:
-            em.i(f"v_xor_b32 {vr(T[8])}, {(ks + 1) << 5}, {vr(KB)}")
-            em.ds_read(KF((ks + 1) & 1, 0), T[8], 0)
-            em.ds_read(KF((ks + 1) & 1, 1), T[8], 8192)
+            em.ds_read(KF((ks + 1) & 1, 0), KA(ks + 1), kst * 16384)
+            em.ds_read(KF((ks + 1) & 1, 1), KA(ks + 1), kst * 16384 + 8192)
         for qq in range(4):
             e, kt, slot = qq >> 1, qq & 1, ks * 4 + qq
             if more:
@@ -389,9 +373,8 @@ def tile(em, par, more, more2, dma):
                 em.i(op)
             if slot == vread_slot - 1:
                 # V^T fragments of the first step of phase Y: their latency rides under the tail of phase X
-                em.i(f"v_add_u32 {vr(VB)}, s43, %[va]")
                 for dt in range(4):
-                    em.ds_read(VF(0, dt), VB, dt * 4096)
+                    em.ds_read(VF(0, dt), VA(0), vst * 16384 + dt * 4096)
     if TRACE:
         em.i("s_memtime s[82:83]")
     if more and not more2:
@@ -408,21 +391,7 @@ def tile(em, par, more, more2, dma):
     if ABL["fill_y"]:
         adds = add_ops(st) if OPT["adds_in"] == "Y" else []
         sm1 = sm1_ops(ns, inline_raise=False) if more else []
-        if OPT["mix_y"] and adds and sm1:
-            # the row-sum terms of tile t (independent adds) between the dependent chains of tile t + 1 (row max, running-max test);
-            # every add stays ahead of the raise, which scales the partial sums INCLUDING tile t
-            k = sm1.index("@RAISE")
-            head, tail = sm1[:k], sm1[k:]
-            lead = 8                                         # a few adds first: S(t+1) was written by the last MFMAs of phase X
-            q += adds[:lead]
-            rest = adds[lead:]
-            for i, op in enumerate(head):
-                q.append(op)
-                lo, hi = i * len(rest) // len(head), (i + 1) * len(rest) // len(head)
-                q += rest[lo:hi]
-            q += tail
-        else:
-            q += adds + sm1
+        q += adds + sm1
     _, gaps = spread(q, 32)
     raise_lbl, raise_ret = em.label("raise"), em.label("raised")
     for k in range(OPT["dummy_y"]):
@@ -439,14 +408,9 @@ def tile(em, par, more, more2, dma):
                 em.i("s_barrier")
             if TRACE:
                 em.i("s_memtime s[86:87]")
-            if dma:
-                dma_regs(em, 3)
-            if more2:
-                kstage_reg(em, 2)
         if kk + 1 < 4:
-            em.i(f"v_xor_b32 {vr(T[9])}, {(kk + 1) << 5}, {vr(VB)}")
             for dt in range(4):
-                em.ds_read(VF((kk + 1) & 1, dt), T[9], dt * 4096)
+                em.ds_read(VF((kk + 1) & 1, dt), VA(kk + 1), vst * 16384 + dt * 4096)
         for qq in range(8):
             dt, e, slot = qq >> 1, qq & 1, kk * 8 + qq
             if qq == 0:
@@ -454,7 +418,7 @@ def tile(em, par, more, more2, dma):
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
             piece = dma and slot >= 16 and (slot & 1) == 1
             if piece:
-                dma_piece(em, (slot - 16) >> 1, part=1)
+                dma_piece(em, (slot - 16) >> 1, dst, part=1)
                 if not gaps[slot]:
                     em.i("s_nop 0")
             for op in gaps[slot]:
@@ -465,17 +429,17 @@ def tile(em, par, more, more2, dma):
                     em.i("s_cmp_lg_u64 s[58:59], 0")
                     em.i(f"s_cbranch_scc1 {raise_lbl}")
                     em.i(f"{raise_ret}:")
-                    have_raise = True
                 else:
                     em.i(op)
             if piece:
-                dma_piece(em, (slot - 16) >> 1, part=2)
+                dma_piece(em, (slot - 16) >> 1, dst, part=2)
             if more2 and slot == 31 - OPT["kread_early"]:
-                k_first_reads(em)                        # first K fragments of tile t + 2, for phase X of the next tile
+                k_first_reads(em, k2st)                  # first K fragments of tile t + 2, for phase X of the next tile
     if more:
         rescale_block(em)
     em.i("s_add_i32 s40, s40, 1")
-    vstage_reg(em)
+    em.i("s_add_i32 s45, s45, 16384")                    # K / V^T byte offsets of the tile the NEXT body stages
+    em.i("s_add_i32 s46, s46, 128")
     em.pending_raise = (raise_lbl, raise_ret) if (more and ABL["fill_y"] and ABL["dec"]) else None
     if TRACE:   # s[64:65] += phase X, s[66:67] += phase Y (both halves), s[68:69] += DMA wait + barrier
         em.i("s_memtime s[88:89]")
@@ -495,16 +459,16 @@ def tile(em, par, more, more2, dma):
     assert em.lds == want, (em.lds, want)
 
 
-def dispatch(em, par, labels, done):
-    """choose the body of tile s40 with parity par: f = tiles t+1..t+3 exist, m2 = t+1, t+2, m1 = t+1 only, l = last"""
-    em.i(f"{labels[('top', par)]}:")
+def dispatch(em, sg, labels, done):
+    """choose the body of tile s40 (s40 % 4 = sg): f = tiles t+1..t+3 exist, m2 = t+1, t+2, m1 = t+1 only, l = last"""
+    em.i(f"{labels[('top', sg)]}:")
     em.i("s_cmp_ge_u32 s40, %[nt]")
     em.i(f"s_cbranch_scc1 {done}")
     for add, k in ((3, "f"), (2, "m2"), (1, "m1")):
         em.i(f"s_add_i32 s47, s40, {add}")
         em.i("s_cmp_lt_u32 s47, %[nt]")
-        em.i(f"s_cbranch_scc1 {labels[(k, par)]}")
-    em.i(f"s_branch {labels[('l', par)]}")
+        em.i(f"s_cbranch_scc1 {labels[(k, sg)]}")
+    em.i(f"s_branch {labels[('l', sg)]}")
 
 
 def main():
@@ -528,8 +492,13 @@ def main():
     for e in range(2):
         em.i(f"v_mov_b32 {vr(M_(e))}, {NEG_BIG}")
         em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")
-        for i in range(4):
+        for i in range(2):
             em.i(f"v_mov_b32 {vr(PS(e, i))}, 0")
+    for ks in range(8):                               # fragment read addresses: lane part x k-step, the ring stage is an immediate
+        em.i(f"v_xor_b32 {vr(KA(ks))}, {ks << 5}, %[ka]")
+    for kk in range(4):
+        em.i(f"v_xor_b32 {vr(VA(kk))}, {kk << 5}, %[va]")
+        em.i(f"v_add_u32 {vr(VA(kk))}, 65536, {vr(VA(kk))}")     # the V^T ring starts at 64 KiB
     for j in range(1, 4):                             # per-piece LDS-DMA offsets: no scalar offset arithmetic in the loop
         em.i(f"v_add_u32 {vr(237 + j)}, {j * 4096}, %[vk]")
     em.i(f"v_add_u32 {vr(241)}, %[vp], %[vv]")
@@ -546,10 +515,10 @@ def main():
         skip = em.label("nost")
         em.i(f"s_cmp_le_u32 %[nt], {tt}")
         em.i(f"s_cbranch_scc1 {skip}")
-        em.i(f"s_mov_b32 s40, {tt}")
-        dma_regs(em, 0)
+        em.i(f"s_mov_b32 s45, {tt << 14}")
+        em.i(f"s_mov_b32 s46, {tt << 7}")
         for j in range(8):
-            dma_piece(em, j)
+            dma_piece(em, j, tt)
         em.i(f"{skip}:")
     l2, l1, lw = em.label("nt2"), em.label("nt1"), em.label("waited")
     em.i("s_cmp_lt_u32 %[nt], 3")
@@ -566,11 +535,9 @@ def main():
     em.i(f"{lw}:")
     em.i("s_barrier")
     # S(0) into set 0, nothing beside it
-    em.i(f"v_mov_b32 {vr(KB)}, %[ka]")
     for ks in range(8):
-        em.i(f"v_xor_b32 {vr(T[8])}, {ks << 5}, {vr(KB)}")
-        em.ds_read(KF(0, 0), T[8], 0)
-        em.ds_read(KF(0, 1), T[8], 8192)
+        em.ds_read(KF(0, 0), KA(ks), 0)
+        em.ds_read(KF(0, 1), KA(ks), 8192)
         for e in range(2):
             for kt in range(2):
                 em.need(KF(0, kt))
@@ -598,12 +565,12 @@ def main():
     em.i(f"{lw}:")
     em.i("s_barrier")
     em.i("s_mov_b32 s40, 0")
-    vstage_reg(em)
+    em.i(f"s_mov_b32 s45, {3 << 14}")                 # byte offsets of tile 3, the first one the loop stages
+    em.i(f"s_mov_b32 s46, {3 << 7}")
     lk = em.label("nok1")
     em.i("s_cmp_lt_u32 %[nt], 2")
     em.i(f"s_cbranch_scc1 {lk}")
-    kstage_reg(em, 1)
-    k_first_reads(em)                                 # first K fragments of tile 1: phase X of tile 0 expects them in flight
+    k_first_reads(em, 1)                              # first K fragments of tile 1: phase X of tile 0 expects them in flight
     em.i(f"{lk}:")
     em.lds = []
     if TRACE:
@@ -613,12 +580,12 @@ def main():
         em.i("s_waitcnt lgkmcnt(0)")
     # ---------------- tiles ----------------
     labels = {}
-    for par in range(2):
+    for par in range(4):
         for k in ("top", "f", "m2", "m1", "l"):
             labels[(k, par)] = em.label(f"{k}{par}")
     done = em.label("done")
     em.i(f"s_branch {labels[('top', 0)]}")
-    for par in range(2):
+    for par in range(4):
         dispatch(em, par, labels, done)
         for k, more, more2, dma in (("f", True, True, True), ("m2", True, True, False), ("m1", True, False, False),
                                     ("l", False, False, False)):
@@ -627,8 +594,8 @@ def main():
             if k == "f":                 # steady state: straight to the other parity's full body while three more tiles exist
                 em.i("s_add_i32 s47, s40, 3")
                 em.i("s_cmp_lt_u32 s47, %[nt]")
-                em.i(f"s_cbranch_scc1 {labels[('f', par ^ 1)]}")
-            em.i(f"s_branch {labels[('top', par ^ 1)]}")
+                em.i(f"s_cbranch_scc1 {labels[('f', (par + 1) & 3)]}")
+            em.i(f"s_branch {labels[('top', (par + 1) & 3)]}")
             if em.pending_raise:         # out of line: the raise of the running maxima (both blocks; lanes that need none keep theirs)
                 em.i(f"{em.pending_raise[0]}:")
                 r0, r1 = dec_raise_ops(0), dec_raise_ops(1)
@@ -656,10 +623,7 @@ def main():
         em.i("s_mov_b64 exec, s[76:77]")
         em.i(f"{skip}:")
     for e, o in ((0, "%[la]"), (1, "%[lb]")):
-        em.i(f"v_add_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
-        em.i(f"v_add_f32 {vr(PS(e, 2))}, {vr(PS(e, 2))}, {vr(PS(e, 3))}")
-        em.i("s_nop 0")
-        em.i(f"v_add_f32 {o}, {vr(PS(e, 0))}, {vr(PS(e, 2))}")
+        em.i(f"v_add_f32 {o}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_w64.py - do not edit (the generator holds the register map and the schedule)\n")
         for ln in em.lines:
