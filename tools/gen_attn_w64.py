@@ -102,6 +102,7 @@ class Emit:
         self.label_n = 0
         self.in_loop = False
         self.pending_raise = None
+        self.pending_rescale = None
 
     def i(self, s):
         self.lines.append(s)
@@ -316,12 +317,19 @@ def mask_block(em, st):
                 em.i(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(T[1])}, vcc")
 
 
-def rescale_block(em):
-    """O^T *= alpha for a block whose running max rose (rare): through VGPR temporaries.  s[54:55] / s[56:57]... the decision left
-    `alpha != 1` lane masks in s[54:55] (block A) and s[56:57] (block B): the test at the edge is scalar"""
-    none = em.label("norsall")
-    em.i("s_cmp_eq_u64 s[58:59], 0")                 # no row of either block was raised in this tile (the usual case)
-    em.i(f"s_cbranch_scc1 {none}")
+def rescale_test(em):
+    """hot path: one scalar test; the rescale of O^T itself (rare) is out of line.  Returns (entry, return) labels"""
+    go, back = em.label("rescale"), em.label("rescaled")
+    em.i("s_cmp_lg_u64 s[58:59], 0")                 # some row of either block was raised in this tile
+    em.i(f"s_cbranch_scc1 {go}")
+    em.i(f"{back}:")
+    return go, back
+
+
+def rescale_block(em, go, back):
+    """O^T *= alpha for a block whose running max rose: through VGPR temporaries.  The raise left `alpha != 1` lane masks in
+    s[54:55] (block A) and s[56:57] (block B)"""
+    em.i(f"{go}:")
     for e in range(2):
         skip = em.label("nors")
         em.i(f"s_cmp_eq_u64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
@@ -338,7 +346,7 @@ def rescale_block(em):
                 em.i(f"v_accvgpr_write_b32 {ar(e * 64 + k + u)}, {vr(T[u])}")
         em.i("s_nop 7")
         em.i(f"{skip}:")
-    em.i(f"{none}:")
+    em.i(f"s_branch {back}")
 
 
 def tile(em, sg, more, more2, dma):
@@ -435,8 +443,7 @@ def tile(em, sg, more, more2, dma):
                 dma_piece(em, (slot - 16) >> 1, dst, part=2)
             if more2 and slot == 31 - OPT["kread_early"]:
                 k_first_reads(em, k2st)                  # first K fragments of tile t + 2, for phase X of the next tile
-    if more:
-        rescale_block(em)
+    em.pending_rescale = rescale_test(em) if more else None
     em.i("s_add_i32 s40, s40, 1")
     em.i("s_add_i32 s45, s45, 16384")                    # K / V^T byte offsets of the tile the NEXT body stages
     em.i("s_add_i32 s46, s46, 128")
@@ -584,25 +591,42 @@ def main():
         for k in ("top", "f", "m2", "m1", "l"):
             labels[(k, par)] = em.label(f"{k}{par}")
     done = em.label("done")
+    rare = []                            # (raise labels, rescale labels) of every body: emitted behind the bodies
+
+    def body(k, sg, more, more2, dma):
+        em.i(f"{labels[(k, sg)]}:")
+        tile(em, sg, more, more2, dma)
+        rare.append((em.pending_raise, em.pending_rescale))
+
     em.i(f"s_branch {labels[('top', 0)]}")
-    for par in range(4):
-        dispatch(em, par, labels, done)
-        for k, more, more2, dma in (("f", True, True, True), ("m2", True, True, False), ("m1", True, False, False),
-                                    ("l", False, False, False)):
-            em.i(f"{labels[(k, par)]}:")
-            tile(em, par, more, more2, dma)
-            if k == "f":                 # steady state: straight to the other parity's full body while three more tiles exist
-                em.i("s_add_i32 s47, s40, 3")
-                em.i("s_cmp_lt_u32 s47, %[nt]")
-                em.i(f"s_cbranch_scc1 {labels[('f', (par + 1) & 3)]}")
-            em.i(f"s_branch {labels[('top', (par + 1) & 3)]}")
-            if em.pending_raise:         # out of line: the raise of the running maxima (both blocks; lanes that need none keep theirs)
-                em.i(f"{em.pending_raise[0]}:")
-                r0, r1 = dec_raise_ops(0), dec_raise_ops(1)
-                for j in range(len(r0)):
-                    em.i(r0[j])
-                    em.i(r1[j])
-                em.i(f"s_branch {em.pending_raise[1]}")
+    # steady state: the four full bodies one behind the other, falling through while three more tiles exist
+    for sg in range(4):
+        body("f", sg, True, True, True)
+        em.i("s_add_i32 s47, s40, 3")
+        em.i("s_cmp_lt_u32 s47, %[nt]")
+        if sg < 3:
+            em.i(f"s_cbranch_scc0 {labels[('top', sg + 1)]}")
+        else:
+            em.i(f"s_cbranch_scc1 {labels[('f', 0)]}")
+            em.i(f"s_branch {labels[('top', 0)]}")
+    # the dispatchers and the tail bodies
+    for sg in range(4):
+        dispatch(em, sg, labels, done)
+        for k, more, more2, dma in (("m2", True, True, False), ("m1", True, False, False), ("l", False, False, False)):
+            body(k, sg, more, more2, dma)
+            em.i(f"s_branch {labels[('top', (sg + 1) & 3)]}")
+    # out of line: the raise of the running maxima (both blocks; lanes that need none keep theirs) and the rescale of O^T
+    for pr, ps in rare:
+        if pr:
+            em.i(f"{pr[0]}:")
+            r0, r1 = dec_raise_ops(0), dec_raise_ops(1)
+            for j in range(len(r0)):
+                em.i(r0[j])
+                em.i(r1[j])
+            em.i(f"s_branch {pr[1]}")
+        if ps:
+            rescale_block(em, ps[0], ps[1])
+    em.i(f"s_branch {done}")
     em.i(f"{done}:")
     drain(em)
     if TRACE:   # lane 0 of every wave: {phase X, phase Y, DMA wait, barrier} cycles summed over the tiles
