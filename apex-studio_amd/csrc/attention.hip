@@ -1491,7 +1491,10 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
     // seven-wave workgroups — is 7 % SLOWER than 432 eight-wave ones: 14 waves per CU split 4/4/3/3 over
     // the SIMDs.  `attn.waves` still accepts 4..8.)
     int nw = g_attn_waves;
-    if (nw == 0) nw = (int64_t)((Sq + 255) / 256) * H * B >= 256 ? 8 : 4;
+    // the w64 kernel (one 256-row workgroup per CU) beats 128-row 4-wave workgroups from 144 workgroups up although it leaves CUs
+    // idle (24 x 1536, the 512^2 Flux geometry: 41 vs 52 us; 192: x1.30, 240: x1.21) and loses below (128: x0.96, 96: x0.89) —
+    // tools/attn_small_ab.py, profiles/r05_attn_small_ab.log
+    if (nw == 0) nw = (int64_t)((Sq + 255) / 256) * H * B >= (g_attn_w64 ? 140 : 256) ? 8 : 4;
     const int qbr = nw * 32;
     const int nqb = (Sq + qbr - 1) / qbr;
     const int total = nqb * H * B;
