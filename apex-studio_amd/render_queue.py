@@ -3,8 +3,9 @@
 The reference's only multi-GPU mechanism is data parallelism over JOBS: one long-lived engine-runner
 actor per GPU fed from a FIFO, GPU picked by free VRAM (apps/api/src/api/ray_tasks.py:181-306,
 ray_resources.py:81-111, settings.py:8 MAX_JOBS_PER_GPU=1).  Here that is one process per GPU under
-torch.distributed (backend "nccl" = RCCL over xGMI), a deterministic longest-processing-time
-assignment of clips to ranks, and exactly ONE exchange step: a broadcast of the weights every clip
+torch.distributed (backend "nccl" = RCCL over xGMI), clips PULLED by whichever rank is free (an atomic
+counter in the rendezvous store; a deterministic longest-processing-time split when there is no
+store), and exactly ONE exchange step: a broadcast of the weights every clip
 shares (text encoders, VAE) and of shared prompt embeddings at queue start.  No collective inside a
 denoise step.
 
@@ -149,14 +150,60 @@ def assign_clips(costs: Sequence[float], world: int) -> List[List[int]]:
     return out
 
 
+_queue_epoch = 0          # run_queue calls so far in this process: every rank calls it the same number of times, so the
+                          # store key of a run is the same on all of them without any exchange
+
+
+def _rendezvous_store(group=None):
+    """The key-value store the process group was rendezvoused through (a TCPStore on rank 0's host for `env://` /
+    torchrun), or None.  Only the default group has one we can reach."""
+    if not dist.is_initialized() or group is not None:
+        return None
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+    except Exception:
+        return None
+
+
+def dispatch_order(costs: Sequence[float]) -> List[int]:
+    """Pull order of the dynamic queue: longest clip first (ties by index) — the LPT seed; with a shared counter the
+    i-th pull anywhere gets the i-th entry."""
+    return sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+
+
 def run_queue(clips: Sequence[dict], runner: Callable[[dict], object], costs: Sequence[float] = None,
-              group=None) -> Dict[str, object]:
-    """Each rank renders the clips assigned to it with `runner(clip)`; returns (on every rank) the
-    per-clip seconds, the per-rank busy time and the makespan."""
+              group=None, dynamic: bool = False) -> Dict[str, object]:
+    """Each rank renders clips with `runner(clip)`; returns (on every rank) the per-clip seconds, which rank rendered
+    which clip, the per-rank busy time and the makespan.
+
+    `dynamic=False`: the static longest-processing-time split of `assign_clips` on the caller's `cost` guesses.
+    `dynamic=True`: ranks PULL — the reference picks the GPU per job at submit time and feeds one FIFO per GPU actor
+    (apps/api/src/api/ray_tasks.py:181-306, engine.py:89-122), i.e. a GPU that finishes early takes the next job.  Here
+    a rank that becomes free takes the next index of `dispatch_order(costs)` from an atomic counter in the rendezvous
+    store (`Store.add`, served by rank 0's TCPStore: a request / reply on the host network — no collective, nothing
+    inside a denoise step), so a wrong cost guess, a data-dependent clip (EasyCache skips) or a slow board costs at
+    most one clip of imbalance instead of a rank's whole static share.  Every clip is rendered exactly once; with
+    exact costs and equal boards the pull order reproduces the LPT assignment.  Without a reachable store (world 1,
+    a sub-group) the static split is used."""
+    global _queue_epoch
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     costs = list(costs) if costs is not None else [float(c.get("cost", 1.0)) for c in clips]
-    mine = assign_clips(costs, world)[rank]
+    _queue_epoch += 1
+    store = _rendezvous_store(group) if dynamic and world > 1 else None
+    if store is not None:
+        order, key = dispatch_order(costs), f"apexmi/render_queue/{_queue_epoch}/next"
+
+        def take():
+            while True:
+                n = int(store.add(key, 1)) - 1
+                if n >= len(order):
+                    return
+                yield order[n]
+        mine = take()
+    else:
+        mine = iter(assign_clips(costs, world)[rank])
     if dist.is_initialized():
         dist.barrier(group=group)
     t_start = time.perf_counter()
@@ -173,9 +220,14 @@ def run_queue(clips: Sequence[dict], runner: Callable[[dict], object], costs: Se
         dist.all_gather_object(gathered, {"rank": rank, "times": times, "busy": busy}, group=group)
     else:
         gathered = [{"rank": 0, "times": times, "busy": busy}]
-    clip_seconds = {}
+    clip_seconds, clip_rank = {}, {}
     for g in gathered:
         clip_seconds.update(g["times"])
+        clip_rank.update({i: g["rank"] for i in g["times"]})
+    if sorted(clip_seconds) != list(range(len(clips))) or sum(len(g["times"]) for g in gathered) != len(clips):
+        raise RuntimeError(f"render queue: {len(clips)} clips queued, rendered {sorted(clip_seconds)} "
+                           f"({sum(len(g['times']) for g in gathered)} renders)")
     makespan = max(g["busy"] for g in gathered)
-    return {"clip_seconds": clip_seconds, "busy": [g["busy"] for g in gathered], "makespan": makespan,
+    return {"clip_seconds": clip_seconds, "clip_rank": clip_rank, "busy": [g["busy"] for g in gathered],
+            "makespan": makespan, "dispatch": "dynamic" if store is not None else "static",
             "clips_per_hour": 3600.0 * len(clips) / makespan if makespan > 0 else 0.0}

@@ -566,7 +566,7 @@ def build_hunyuan(args, dev, rank, total):
 
 
 def run_queue(args, dev, rank, world):
-    """config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips, one clip per GPU at a time (LPT assignment)."""
+    """config 5: 4 Flux-1024^2 clips + 4 Wan-720p clips, one clip per GPU at a time (pulled by the free rank; LPT order as the seed)."""
     from apex_studio_amd import render_queue
     from apex_studio_amd.engine_flux import FluxT2IEngine
     from apex_studio_amd.engine_wan import WanT2VEngine
@@ -614,12 +614,12 @@ def run_queue(args, dev, rank, world):
     # (1) the literal config 5: 8 clips, STRONG scaling — bounded by its longest clip once every GPU holds one
     clips = [{"kind": "flux", "seed": i, "cost": 2.5} for i in range(4)] + \
             [{"kind": "wan", "seed": 10 + i, "cost": wan_cost} for i in range(4)]
-    res = render_queue.run_queue(clips, runner)
+    res = render_queue.run_queue(clips, runner, dynamic=True)
     # (2) the same queue DEEPENED with the node (WEAK scaling: one Flux + one Wan clip per GPU) — the regime in which
     # clip-per-GPU sharding can show its N-fold throughput (north_star's >= 7.5x at 8 GPUs)
     weak_clips = [{"kind": "flux", "seed": 100 + i, "cost": 2.5} for i in range(world)] + \
                  [{"kind": "wan", "seed": 200 + i, "cost": wan_cost} for i in range(world)]
-    weak = render_queue.run_queue(weak_clips, runner)
+    weak = render_queue.run_queue(weak_clips, runner, dynamic=True)
     _flush_c_stdio()
     if rank == 0:
         print(json.dumps({
@@ -629,7 +629,8 @@ def run_queue(args, dev, rank, world):
             "config": {"workload": f"8-clip render queue: 4x flux-dev 1024^2 (28 steps + decode) + 4x wan-2.2 "
                                    f"720p x 81f ({args.queue_wan_steps} steps, expert switch, tiled 3D-VAE decode), "
                                    f"one clip per GPU at a time", "parallelism": f"clip-per-gpu x{world}"},
-            "world": world, "makespan_s": res["makespan"], "busy_s": res["busy"],
+            "world": world, "makespan_s": res["makespan"], "busy_s": res["busy"], "dispatch": res["dispatch"],
+            "clip_rank": {str(k): v for k, v in sorted(res["clip_rank"].items())},
             "clip_seconds": {str(k): round(v, 3) for k, v in sorted(res["clip_seconds"].items())},
             "weak_scaling": {"clips": len(weak_clips), "what": "one flux-dev 1024^2 clip + one wan-2.2 720p clip PER GPU",
                              "clips_per_hour": weak["clips_per_hour"], "makespan_s": weak["makespan"],

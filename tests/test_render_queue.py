@@ -173,6 +173,72 @@ def _ragged_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _dynamic_worker(rank, world, port, q, slow_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    # 12 equal-cost clips; the "render" is a seeded function of the clip alone, the slow rank sleeps 5x longer per clip
+    clips = [{"id": i, "cost": 1.0, "seed": 1000 + i} for i in range(12)]
+
+    def make_runner(sink, nap):
+        def run(c):
+            time.sleep(nap * (5.0 if rank == slow_rank else 1.0))
+            sink[c["id"]] = torch.randn(4, generator=torch.Generator().manual_seed(c["seed"]))
+        return run
+    out_s, out_d, out_d2 = {}, {}, {}
+    stat = rq.run_queue(clips, make_runner(out_s, 0.0))                      # static LPT (the fallback), no naps
+    dyn = rq.run_queue(clips, make_runner(out_d, 0.06), dynamic=True)
+    dyn2 = rq.run_queue(clips, make_runner(out_d2, 0.0), dynamic=True)       # a second dynamic run: its own counter key
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"s": out_s, "d": out_d, "d2": out_d2})
+    merged = {k: {} for k in ("s", "d", "d2")}
+    for g in gathered:
+        for k in merged:
+            assert not set(merged[k]) & set(g[k]), "a clip rendered on two ranks"
+            merged[k].update(g[k])
+    same = all(sorted(merged[k]) == list(range(12)) for k in merged) and \
+        all(torch.equal(merged["s"][i], merged["d"][i]) and torch.equal(merged["s"][i], merged["d2"][i]) for i in range(12))
+    per_rank = [sum(1 for r in dyn["clip_rank"].values() if r == j) for j in range(world)]
+    q.put((rank, stat["dispatch"], dyn["dispatch"], dyn2["dispatch"], bool(same), per_rank,
+           [sum(1 for r in stat["clip_rank"].values() if r == j) for j in range(world)], sorted(dyn["clip_seconds"])))
+    dist.destroy_process_group()
+
+
+def _check_dynamic(out, world, slow):
+    for rank, s_kind, d_kind, d2_kind, same, per_rank, per_rank_static, seen in out:
+        assert (s_kind, d_kind, d2_kind) == ("static", "dynamic", "dynamic")
+        assert same, "every clip exactly once, results identical to the static run"
+        assert seen == list(range(12)) and sum(per_rank) == 12
+        assert per_rank_static == [12 // world] * world
+        others = [n for j, n in enumerate(per_rank) if j != slow]
+        assert per_rank[slow] < min(others), (per_rank, "the slow rank must end with fewer clips than any other")
+    assert len({tuple(o[5]) for o in out}) == 1, "every rank reports the same clip -> rank map"
+
+
+def test_dynamic_dispatch_world2_slow_rank_gets_fewer_clips():
+    """`run_queue(dynamic=True)`: ranks pull the next clip from an atomic counter in the rendezvous store
+    (apps/api/src/api/ray_tasks.py:181-306 picks the GPU per job).  A rank whose runner is 5x slower ends with fewer clips,
+    every clip is rendered exactly once, and the rendered results equal the static run's."""
+    _check_dynamic(_run_world(_dynamic_worker, 2, extra=(1,)), 2, 1)
+
+
+def test_dynamic_dispatch_world4():
+    _check_dynamic(_run_world(_dynamic_worker, 4, extra=(2,)), 4, 2)
+
+
+def test_dynamic_dispatch_order_and_world1_fallback():
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    assert rq.dispatch_order([2, 100, 2, 100, 50]) == [1, 3, 4, 0, 2]
+    done = []
+    res = rq.run_queue([{"id": i} for i in range(3)], lambda c: done.append(c["id"]), dynamic=True)
+    assert res["dispatch"] == "static" and sorted(done) == [0, 1, 2] and res["clip_rank"] == {0: 0, 1: 0, 2: 0}
+
+
 def test_broadcast_ragged_sizes_and_layout_mismatch_world4():
     out = _run_world(_ragged_worker, 4)
     assert all(o[1] for o in out) and out[0][2] >= 2
