@@ -2211,7 +2211,7 @@ int launch_epi(GemmGroup& G, const int* Ms, hipStream_t stream) {
         // A launch that covers well under half of the CUs with 256 x 256 tiles (the 512^2 geometry: proj_out 1536 x 3072 = 72 tiles,
         // FF-down 48 + 24) runs its K-loop on a few CUs at the per-CU floor of ~1.23 us per K-tile while the rest idle; four times
         // as many 128 x 128 tiles (two workgroups per CU) finish sooner until ~118 tiles (profiles/r05_gemm_small_ab.log: 72 tiles
-        // K 15360 295 -> 213 us, 48 tiles K 12288 237 -> 160 us, 96 tiles 238 -> 192 us; 144 tiles 236 vs 342 us: stays).  Launches
+        // K 15360 295 -> 213 us, 48 tiles K 12288 237 -> 160 us, 96 tiles 238 -> 192 us; 144 tiles 236 vs 342 us: stays).
         // Gate / residual launches only (attention-out, FF-down, proj_out — the part-filled ones of the MM-DiT blocks): the
         // bias-class projections keep the tiling whose sums the fused q/k/v epilogue reproduces bit for bit.
         if (EPI == APEXMI_EPI_BIAS_GATE_RES && cfg == 7 && G.batch == 1 && g_small_max > 0) {

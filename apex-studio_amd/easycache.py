@@ -5,12 +5,18 @@ the rule of `easycache_forward_` (R/src/transformer/wan/base/model.py:202-520, :
 count) / unconditional (odd); on even calls the input change since the previous even call, scaled by the measured output / input
 change rate K and the previous output's magnitude, is accumulated; while the sum stays under `thresh` the PAIR is served from the
 cache (`raw_input + (last computed output - its input)`), except during the first `ret_steps` pairs and the last pair, which are
-always computed.  The reference keeps this state in module globals shared by whichever transformer is loaded and resets it when it
-enables the cache on a newly loaded expert; here the state belongs to the model instance and `enable_easy_cache(...,
-should_reset_global_cache=True)` resets it, so the engine enables it on an expert each time that expert takes over (engine_wan.py).
+always computed.  The reference keeps this state in module globals shared by whichever transformer is loaded: it resets them when it
+enables the cache on the high-noise expert and does NOT when it enables it on the low-noise expert (`should_reset_global_cache=False`,
+R/src/engine/wan/shared/__init__.py:372-381 vs :435-444), so the call count, K, the accumulated error and the caches carry across the
+expert switch and the last pair of the clip is always computed.  Here the state is an object: `enable_easy_cache(...,
+should_reset_global_cache=True)` makes a fresh one, `share_easy_cache_state(other)` + `enable_easy_cache(..., False)` continues
+another model's (engine_wan.py does that at the switch) — per clip, not per process, so two engines in one process do not collide.
 
-The reductions are a handful of elementwise torch ops over one latent (a few MB) and one host read per conditional call — noise
-beside a 5 s transformer forward; the forward itself is the unchanged HIP path.  Outputs are float32, as the reference returns."""
+Dtypes follow the reference: `raw_input`, the caches and the change statistics stay in the dtypes torch gives them from
+`hidden_states` and the model's output (bf16 in production), only the returned tensor is cast to float32 — the skip decisions
+are then taken on the same rounded statistics as the reference's.  The reductions are a handful of elementwise torch ops over one
+latent (a few MB) and one host read per conditional call — noise beside a 5 s transformer forward; the forward itself is the
+unchanged HIP path."""
 from __future__ import annotations
 
 from typing import Callable, Optional
@@ -29,26 +35,26 @@ class EasyCache:
         self.cnt = 0
         self.accumulated = 0.0
         self.should_calc = True
-        self.k: Optional[float] = None
+        self.k: Optional[torch.Tensor] = None
         self.prev_in_even = self.prev_out_even = self.prev_out_odd = self.prev_prev_in_even = None
         self.cache_even = self.cache_odd = None
         self.computed = []                            # per call: did the transformer run? (diagnostics / tests)
 
     @staticmethod
-    def _mean_abs(t: torch.Tensor) -> float:
-        return float(t.float().abs().mean())
+    def _mean_abs(t: torch.Tensor) -> torch.Tensor:
+        return t.flatten().abs().mean()
 
     @torch.no_grad()
     def __call__(self, hidden_states: torch.Tensor, out_channels: int, forward: Callable[[], torch.Tensor]) -> torch.Tensor:
-        raw_input = hidden_states[:, :out_channels].float().clone()
+        raw_input = hidden_states[:, :out_channels].clone()
         even = self.cnt % 2 == 0
         if even:
             if self.cnt < self.ret_steps or self.cnt >= self.num_steps - 2:
                 self.should_calc, self.accumulated = True, 0.0
             elif self.prev_in_even is not None and self.prev_out_even is not None and self.k is not None:
                 change = self._mean_abs(raw_input - self.prev_in_even)
-                self.accumulated += self.k * (change / self._mean_abs(self.prev_out_even))
-                if self.accumulated < self.thresh:
+                self.accumulated = self.accumulated + self.k * (change / self._mean_abs(self.prev_out_even))
+                if bool(self.accumulated < self.thresh):              # the one host read of a conditional call
                     self.should_calc = False
                 else:
                     self.should_calc, self.accumulated = True, 0.0
@@ -59,8 +65,8 @@ class EasyCache:
         if not self.should_calc and prev_out is not None:
             self.cnt += 1
             self.computed.append(False)
-            return raw_input + cache
-        output = forward().float()
+            return (raw_input + cache).float()
+        output = forward()
         if even:
             if self.prev_out_even is not None and self.prev_prev_in_even is not None:
                 self.k = self._mean_abs(output - self.prev_out_even) / self._mean_abs(self.prev_in_even - self.prev_prev_in_even)
@@ -72,4 +78,4 @@ class EasyCache:
             self.cache_odd = output - raw_input
         self.cnt += 1
         self.computed.append(True)
-        return output
+        return output.float()

@@ -70,9 +70,12 @@ class WanT2VEngine(EngineLoraMixin):
                     use_cfg_guidance: bool = True, transformer_dtype=None, render_on_step: bool = False,
                     render_on_step_callback=None, render_on_step_interval: int = 3,
                     denoise_progress_callback=None, easy_cache_thresh: float = 0.0, easy_cache_ret_steps: int = 10):
-        """`easy_cache_thresh` > 0: EasyCache step skipping (R/src/engine/wan/shared/__init__.py:372-381, :435-444, :502-504) — the
-        reference enables it, with a state reset, on an expert when that expert is loaded; both experts are resident here, so it is
-        enabled (and reset) each time the selected expert CHANGES, and switched off when the loop ends."""
+        """`easy_cache_thresh` > 0: EasyCache step skipping (R/src/engine/wan/shared/__init__.py:372-381, :435-444, :502-504).  The
+        reference enables it on the high-noise expert WITH a reset of its (module-global) state and on the low-noise expert WITHOUT
+        one, so the call count, the rate K, the accumulated error and the caches run on across the expert switch: no second
+        warm-up of `ret_steps` pairs, and the last pair of the clip (`cnt >= 2n - 2`) is always computed.  Both experts are
+        resident here: the first expert of the loop gets a fresh state, every later one continues it
+        (`share_easy_cache_state`), and the cache is switched off when the loop ends."""
         _emit(denoise_progress_callback, 0.0, "Starting denoise")
         try:
             return self._moe_loop(latents, timesteps, prompt_embeds, negative_prompt_embeds, guidance_scale, boundary_timestep,
@@ -94,7 +97,10 @@ class WanT2VEngine(EngineLoraMixin):
             timestep = t.expand(latents.shape[0])
             transformer = self._select_dual_noise_transformer(t, boundary_timestep)
             if easy_cache_thresh > 0.0 and transformer is not current and hasattr(transformer, "enable_easy_cache"):
-                transformer.enable_easy_cache(n, easy_cache_thresh, easy_cache_ret_steps, should_reset_global_cache=True)
+                first = current is None
+                if not first and hasattr(transformer, "share_easy_cache_state"):
+                    transformer.share_easy_cache_state(current)
+                transformer.enable_easy_cache(n, easy_cache_thresh, easy_cache_ret_steps, should_reset_global_cache=first)
             current = transformer
             x = latents.to(transformer_dtype or compute_dtype(transformer))
             scale = self._select_dual_noise_guidance_scale(t, boundary_timestep, guidance_scale)

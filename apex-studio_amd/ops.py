@@ -302,9 +302,22 @@ def gemm_grouped(a_list, w_list, bias_list, out_list, epilogue="bias", gate_list
     K = w_list[0].shape[1]
     epis = [epilogue] * n if isinstance(epilogue, str) else list(epilogue)
     act = a_list[0].dtype
-    # resident fp8 weights: the problems of one launch need their dequantised operands side by side, so each gets its own tensor
-    w_list = [w.dequant() if isinstance(w, Fp8Weight) else w._fp8.dequant() if getattr(w, "_fp8", None) is not None else w
-              for w in w_list]
+    # resident fp8 weights: the problems of one launch need their dequantised operands side by side — carved out of ONE per-stream
+    # scratch (stream order makes the reuse safe, see _bf16_weight); a weight with run-time LoRA factors has no grouped form
+    f8s = [_fp8_of(w) for w in w_list]
+    if any(f is not None for f in f8s):
+        if any(f is not None and f.lora_A is not None for f in f8s):
+            raise _l.ApexMIError("gemm_grouped: a resident-fp8 weight carries run-time LoRA factors: only gemm(..., lora_buf=) applies them")
+        if act == torch.float32:     # verification mode caches on (data_ptr, version): never hand it a recycled buffer
+            w_list = [w if f is None else f.dequant() for w, f in zip(w_list, f8s)]
+        else:
+            sizes = [0 if f is None else (f.shape[0] * f.shape[1] + 7) // 8 * 8 for f in f8s]
+            dev = next(f for f in f8s if f is not None).device
+            buf, off, ws = _scratch(dev, sum(sizes)), 0, []
+            for w, f, n in zip(w_list, f8s, sizes):
+                ws.append(w if f is None else f.dequant(out=buf[off:off + f.shape[0] * f.shape[1]].view(f.shape[0], f.shape[1])))
+                off += n
+            w_list = ws
     for a, w, o in zip(a_list, w_list, out_list):
         _req_act(a, "gemm_grouped.a")
         _req(a, act, "gemm_grouped.a")

@@ -32,7 +32,11 @@ class ModulationSchedule:
         self.timesteps = timesteps.detach().float().reshape(self.n, -1).contiguous()      # [n, B] or [n, 1], as scheduled
         self.guidance = None if guidance is None else guidance.detach().float().reshape(-1).contiguous()
         self.tables: Dict[Any, torch.Tensor] = {}          # key (model-defined) -> [n * B, mod_total] f32
-        self.mismatch = torch.zeros((), dtype=torch.int32, device=self.timesteps.device)
+        # one mismatch counter per (step, image), bumped with a device ATOMIC add (`index_add_`): `row()` is called from concurrent
+        # streams (the images of a batch under batch_streams, the cond / uncond passes under cfg_streams), and a plain `add_` on one
+        # scalar is a read-modify-write that two streams can interleave — a lost increment would let an invalid clip pass
+        self.mismatch = torch.zeros(self.n * self.B, dtype=torch.int32, device=self.timesteps.device)
+        self._slot = torch.arange(self.n * self.B, dtype=torch.int64, device=self.timesteps.device)
         self.ready = None
         self.stream = None
         self._waited = set()
@@ -78,8 +82,9 @@ class ModulationSchedule:
             bad = timestep.detach().float().reshape(-1)[0] != self.timesteps[i, min(b, self.timesteps.shape[1] - 1)]
             if guidance is not None and self.guidance is not None:
                 bad = bad | (guidance.detach().float().reshape(-1)[0] != self.guidance[min(b, self.guidance.numel() - 1)])
-            self.mismatch.add_(bad.to(torch.int32))
         r = i * self.B + b
+        if timestep is not None:
+            self.mismatch.index_add_(0, self._slot[r:r + 1], bad.to(torch.int32).reshape(1))
         return t[r:r + 1]
 
     def release(self, check: bool = True):
@@ -87,8 +92,9 @@ class ModulationSchedule:
         another timestep / guidance produced wrong modulation — that is reported, loudly, not absorbed."""
         self.live = False
         self.tables = {}
-        if check and sys.exc_info()[0] is None and int(self.mismatch.item()) != 0:
-            raise _l.ApexMIError(f"modulation schedule #{self.id}: {int(self.mismatch.item())} scheduled step(s) were called with a "
+        bad = int(self.mismatch.sum().item()) if check and sys.exc_info()[0] is None else 0
+        if bad != 0:
+            raise _l.ApexMIError(f"modulation schedule #{self.id}: {bad} scheduled step(s) were called with a "
                                  "timestep / guidance different from the row they read (begin_schedule's timesteps must be the "
                                  "values forward receives); the clip's output is invalid")
 

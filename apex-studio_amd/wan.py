@@ -171,6 +171,13 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
             ec.num_steps, ec.thresh, ec.ret_steps = int(num_steps) * 2, float(thresh), int(ret_steps) * 2
         return self
 
+    def share_easy_cache_state(self, other):
+        """Continue `other`'s EasyCache state on this model (the reference's state is module-global, so the low-noise expert
+        picks up where the high-noise one stopped: R/src/engine/wan/shared/__init__.py:435-444 enables it with
+        `should_reset_global_cache=False`).  Follow with `enable_easy_cache(..., should_reset_global_cache=False)`."""
+        self._easy_cache = getattr(other, "_easy_cache", None)
+        return self
+
     def disable_easy_cache(self):
         self._easy_cache = None
         return self

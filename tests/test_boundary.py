@@ -48,6 +48,93 @@ def test_backend_registration_and_argument_errors():
     assert {"auto_mi355", "wan_mi355", "qwenimage_mi355", "hunyuanvideo15_mi355"} <= set(vreg.all())
 
 
+REF_REGISTER = "/root/reference/apps/api/src/register/__init__.py"
+
+
+def _reference_register_module():
+    """The reference's own registry module, loaded BY PATH (it has no imports beyond typing / functools).  The reference never
+    travels to the GPU box: there this returns None and the tests that need it skip."""
+    import importlib.util
+    import os
+    if not os.path.exists(REF_REGISTER):
+        return None
+    spec = importlib.util.spec_from_file_location("apex_reference_register", REF_REGISTER)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_backend_registers_into_the_REAL_reference_registry():
+    """The mirror (apex-studio_amd/register.py) is pinned to what it mirrors: `hip_mfma` and the component classes are registered
+    into the reference's real `FunctionRegister` / `ClassRegister` (R/src/register/__init__.py:8-290) and dispatched through
+    `attention_register.call(q, k, v, ..., key=)` exactly as R/src/attention/functions.py:84 / the processors do."""
+    ref = _reference_register_module()
+    if ref is None:
+        pytest.skip("the reference tree is not on this machine (GPU box)")
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import attention_backend as ab
+    from apex_studio_amd import register as mirror
+    from apex_studio_amd.lib import ApexMIError
+    reg = ref.FunctionRegister()
+
+    @reg("sdpa")                                    # what the reference registers first (attention/functions.py:338)
+    def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, softmax_scale=None, **kw):
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p,
+                                                                is_causal=is_causal, scale=softmax_scale)
+    reg.set_default("sdpa")
+    ab.register(reg)
+    assert ab.KEY in reg.all() and reg.get(ab.KEY) is ab.hip_mfma and reg.get_default() == "sdpa"
+    q = torch.randn(1, 2, 8, 64)
+    assert reg.call(q, q, q).shape == q.shape                       # the default backend still serves
+    if not torch.cuda.is_available():
+        assert not reg.is_available(ab.KEY) and ab.KEY not in reg.all_available()
+        with pytest.raises(RuntimeError):
+            reg.call(q, q, q, key=ab.KEY)                           # registered but unavailable: the reference's own error
+        reg.set_availability(ab.KEY, True)                          # forced: the call reaches hip_mfma with the reference's kwargs
+        with pytest.raises(ApexMIError):
+            reg.call(q, q, q, attn_mask=None, dropout_p=0.0, is_causal=True, softmax_scale=None, key=ab.KEY)
+        with pytest.raises(Exception) as ei:                        # CPU tensors: the product path fails loudly, no fallback
+            reg.call(q, q, q, attn_mask=None, dropout_p=0.0, is_causal=False, softmax_scale=None, key=ab.KEY)
+        assert not isinstance(ei.value, (KeyError, TypeError)), ei.value
+    ab.register(reg, set_default=True)                              # overwrite=True: a second registration replaces, no KeyError
+    assert reg.get_default() == ab.KEY
+    vreg = ref.ClassRegister()
+    creg = ab.register_models(ref.ClassRegister(), vreg)
+    assert {"auto_mi355", "wan_mi355", "qwenimage_mi355", "hunyuanvideo15_mi355"} <= set(vreg.all())
+    assert {"flux.mi355", "wan.mi355", "qwenimage.mi355", "hunyuanvideo15.mi355"} <= set(creg.all())
+    # the mirror and the original behave alike on the whole contract (same calls, same results / exception types)
+    def script(R):
+        out = []
+        r = R.FunctionRegister()
+        r("a")(lambda x: x + 1)
+        try:
+            r("a")(lambda x: x)
+        except Exception as e:
+            out.append(type(e).__name__)
+        r("a", overwrite=True)(lambda x: x + 2)
+        r("b", available=False)(lambda x: x)
+        out.append(r.call(1, key="a"))
+        try:
+            r.call(1, key="b")
+        except Exception as e:
+            out.append(type(e).__name__)
+        try:
+            r.get("zzz")
+        except Exception as e:
+            out.append(type(e).__name__)
+        r.set_default("a")
+        out += [r.call(5), r.get_default(), sorted(r.all()), sorted(r.all_available()), r.is_available("b"), r.is_available("zzz")]
+        r.set_availability("b", True)
+        out.append(sorted(r.all_available()))
+
+        @r
+        def named(x):
+            return -x
+        out.append(r.call(3, key="named"))
+        return out
+    assert script(ref) == script(mirror)
+
+
 def test_flux_class_contract_on_meta_device():
     """What LoaderMixin._load_model demands (reference mixins/loader_mixin.py:219-531): from_config under
     empty weights, diffusers-style state-dict keys, load_state_dict(assign=True), .config access."""

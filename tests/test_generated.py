@@ -32,3 +32,31 @@ def test_attn_w64_clobber_list_covers_the_registers_the_loop_names():
     outputs = {f"a{i}" for i in range(128)}
     missing = sorted(r for r in used - clob - outputs)
     assert not missing, missing
+
+
+def test_build_refuses_a_w64_kernel_that_spills():
+    """apex-studio_amd/build.py parses hipcc's kernel-resource-usage remarks of attention.hip and refuses a binary whose
+    hand-register-mapped kernel uses scratch or spills (a compiler upgrade that allocates differently must fail loudly)."""
+    sys.path.insert(0, ROOT)
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import build as b
+    import pytest
+    ok = """./attn_w64_kernel.h:7:1: remark: Function Name: _ZN12_GLOBAL__N_124attn_fwd_d128_w64_kernelEPKtS1_S1_Ptiiiiiilllf [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     TotalSGPRs: 96 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     AGPRs: 196 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+attention.hip:1103:1: remark: Function Name: _ZN12_GLOBAL__N_119softmax_rows_kernelEPKflifPtlii [-Rpass-analysis=kernel-resource-usage]
+attention.hip:1103:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]
+"""
+    res = b.parse_resource_remarks(ok)
+    k = next(x for x in res if "w64" in x)
+    assert res[k]["VGPRs"] == 256 and res[k]["AGPRs"] == 196 and res[k]["ScratchSize"] == 0
+    b.check_no_spill("attention.hip", ok)                     # another kernel's scratch is not its business
+    for field in ("ScratchSize [bytes/lane]: 0", "VGPRs Spill: 0", "SGPRs Spill: 0"):
+        with pytest.raises(RuntimeError, match="must not spill"):
+            b.check_no_spill("attention.hip", ok.replace(field, field[:-1] + "12", 1))
+    with pytest.raises(RuntimeError, match="no resource remark"):
+        b.check_no_spill("attention.hip", "")
