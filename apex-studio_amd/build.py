@@ -116,7 +116,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         err = proc.communicate()[1]          # waits; None unless stderr was piped
         if err:
             rest = [l for l in err.splitlines() if "kernel-resource-usage" not in l and not l.lstrip().startswith(("|", "^"))
-                    and not l.strip()[:1].isdigit()]
+                    and not l.strip()[:1].isdigit() and not l.startswith("In file included from")]
             if rest and verbose:
                 print("\n".join(rest), file=sys.stderr, flush=True)
         if proc.returncode != 0:

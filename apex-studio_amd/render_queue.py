@@ -81,7 +81,7 @@ def broadcast_parameters(modules, src: int = 0, group=None, bucket_bytes: int = 
     derived state (fused / padded / packed copies) is then dropped through the `_weights_changed` hooks.
     Sizes to expect: Flux T5-XXL 9.5 GB + CLIP-L 0.25 GB + VAE 0.17 GB; Wan UMT5-XXL 11.4 GB + VAE 0.5 GB."""
     tensors = shared_tensors(modules)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
+    if not dist.is_initialized() or not tensors:      # an initialised group of ONE rank still goes through the backend below
         return {"bytes": sum(t.numel() * t.element_size() for t in tensors), "seconds": 0.0, "gbps": 0.0,
                 "world": 1, "tensors": len(tensors), "buckets": 0}
     world, rank = dist.get_world_size(group), dist.get_rank(group)

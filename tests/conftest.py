@@ -30,3 +30,17 @@ def host_threads():
     torch.set_num_threads(max(1, min(avail, 64)))
     yield
     torch.set_num_threads(before)
+
+
+def measured(name: str, value: float, bar: float) -> float:
+    """An assert that can fail for a real regression: `bar` is pinned at about twice the value measured on the MI355X (the
+    measured value stands beside each call).  With APEX_RECORD_MEASURED=<file> every call appends {name, value, bar} to that
+    JSON-lines file, so a GPU run prints what the bars should be re-pinned to."""
+    import json
+    value = float(value)
+    path = os.environ.get("APEX_RECORD_MEASURED")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"name": name, "value": value, "bar": bar}) + "\n")
+    assert value < bar, f"{name}: measured {value:.3e} is not under its bar {bar:.1e}"
+    return value

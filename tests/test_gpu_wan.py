@@ -5,6 +5,8 @@ import os
 import pytest
 import torch
 
+from tests.conftest import measured
+
 from oracle import layers as OL
 from oracle import wan as OW
 from tests import stage_parity as SP
@@ -71,7 +73,7 @@ def test_wan_matches_reference_wiring_golden(golden_dir):
     _, out = _hip(g["config"], sd, inp["hidden_states"], inp["timestep"], inp["encoder_hidden_states"])
     rel = _rel(out, g["out"])
     print(f"wan hip bf16 vs reference-wiring f64 golden: rel {rel:.3e}")
-    assert rel < 3e-2, rel
+    measured("wan_hybrid.bf16_vs_reference_run", rel, 3e-2)
 
 
 def test_wan_full_width_one_block_matches_oracle(host_threads):

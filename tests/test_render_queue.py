@@ -3,6 +3,7 @@ backend "nccl" on the GPU box)."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -257,3 +258,45 @@ def test_bench_refuses_to_fake_multi_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+
+
+def _nccl_world1_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import render_queue as rq
+    from apex_studio_amd import text_encoders as TE
+    dev = torch.device("cuda", 0)
+    big = torch.arange(1 << 22, dtype=torch.int32, device=dev)            # 16 MiB: the scatter + all-gather route
+    small = torch.full((7,), 3.0, device=dev)
+    stats = rq.broadcast_shared([big, small], src=0)
+    ok = bool(torch.equal(big.cpu(), torch.arange(1 << 22, dtype=torch.int32)) and torch.equal(small.cpu(), torch.full((7,), 3.0)))
+    t5 = TE.T5EncoderModel(dict(vocab_size=64, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2), device=dev,
+                           dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    want = []
+    for p in t5.parameters():
+        w = torch.randn(p.shape, generator=g).to(p.dtype)
+        p.data.copy_(w)
+        want.append(w)
+    pst = rq.broadcast_parameters([t5], src=0, bucket_bytes=1 << 16)
+    ok = ok and all(torch.equal(p.data.cpu(), w) for p, w in zip(t5.parameters(), want))
+    done = []
+    res = rq.run_queue([{"id": i, "cost": 1.0} for i in range(3)], lambda c: done.append(c["id"]), dynamic=True)
+    q.put((rank, ok, stats["bytes"], stats["world"], pst["buckets"], pst["bytes"], sorted(done), res["dispatch"],
+           dist.get_backend()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_world1_carries_the_exchange_step():
+    """RCCL initialisation and the queue's exchange step inside the GPU suite: backend `nccl` (= RCCL) at world 1 on the one
+    visible MI355X — `broadcast_shared` (plain broadcast and the scatter + all-gather route) and `broadcast_parameters`
+    (layout digest all-gather, bucketed staging) run THROUGH the backend, bytes unchanged.  N > 1 ranks need the 8-GPU node."""
+    (rank, ok, nbytes, world, buckets, pbytes, done, dispatch, backend), = _run_world(_nccl_world1_worker, 1, timeout=600)
+    assert backend == "nccl" and world == 1
+    assert ok and nbytes == (1 << 24) + 28 and buckets > 1 and pbytes > 0
+    assert done == [0, 1, 2] and dispatch == "static"
