@@ -91,7 +91,7 @@ def test_flux_matches_reference_wiring_golden(golden_dir):
     _, out = _run_hip(cfg, sd, g["inputs"])
     rel = _rel(out, g["out"])
     print(f"hip bf16 vs reference-wiring fp32 golden: rel {rel:.3e}")
-    measured("flux_hybrid.bf16_vs_reference_run", rel, 3e-2)
+    measured("flux_hybrid.bf16_vs_reference_run", rel, 1.1e-2)      # measured 5.2e-3 (round 6)
 
 
 def test_state_dict_survives_packing_and_repeat_calls():
@@ -431,5 +431,5 @@ def test_controlnet_residual_inputs_match_the_reference_run(golden_dir):
                                              for k, v in kw.items()})[0].float().cpu()
         assert _rel(out, ref16) < 6e-3, (name, _rel(out, ref16))
     plain = m(return_dict=False, **gin)[0].float().cpu()
-    measured("flux_controlnet.none.bf16_vs_reference_run", _rel(plain, g["out"]["none"]), 3e-2)
+    measured("flux_controlnet.none.bf16_vs_reference_run", _rel(plain, g["out"]["none"]), 1.2e-2)   # measured 6.1e-3
     assert _rel(plain, out) > 1e-3

@@ -90,7 +90,7 @@ def test_hunyuan15_matches_reference_wiring_golden(golden_dir):
                                                                        "patch_size", "patch_size_t")}, sd, inp)
         rel = _rel(out, g["out"][name])
         print(f"hunyuan15 hip bf16 vs reference-wiring f64 golden ({name}): rel {rel:.3e}")
-        measured(f"hunyuan15_hybrid.{name}.bf16_vs_reference_run", rel, 3e-2)
+        measured(f"hunyuan15_hybrid.{name}.bf16_vs_reference_run", rel, 9e-3)       # measured 4.5e-3 / 4.7e-3 (round 6)
 
 
 def test_hunyuan15_all_tokens_valid_and_determinism():
@@ -169,7 +169,7 @@ def test_hunyuan15_meanflow_timestep_r(golden_dir):
         e_like, e_gold = _rel(out, ref16), _rel(out, g["out"][name])
         print(f"[hunyuan15 meanflow {name}] hip vs bf16-storage oracle {e_like:.3e}; vs reference-wiring f64 golden {e_gold:.3e}")
         assert e_like < 6e-3
-        measured(f"hunyuan15_meanflow.{name}.bf16_vs_reference_run", e_gold, 3e-2)
+        measured(f"hunyuan15_meanflow.{name}.bf16_vs_reference_run", e_gold, 9e-3)       # measured 4.4e-3 / 4.3e-3
     plain = HunyuanVideo15Transformer3DModel(**dict(cfg, use_meanflow=False), device=DEV, dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         plain(return_dict=False, timestep_r=g["timestep_r"].to(DEV), **dev)

@@ -268,7 +268,7 @@ def test_rmsnorm_matches_reference_golden(golden_dir):
     out = ops.ln_modulate(x.to(DEV), gamma=_bf(c["weight"]).to(DEV), eps=c["eps"], rms=True)
     # the reference rounds the normalisation factor to bf16 before the multiply (mod.py:31-33)
     assert torch.allclose(out.float().cpu(), c["out"][0].float(), atol=3e-2, rtol=2e-2)
-    measured("efficiency_ops.rmsnorm_bf16.rel_vs_reference_run", _rel(out.cpu(), c["out"][0]), 3e-2)
+    measured("efficiency_ops.rmsnorm_bf16.rel_vs_reference_run", _rel(out.cpu(), c["out"][0]), 7e-3)      # measured 3.3e-3 (round 6)
 
 
 # ------------------------------------------------------------------------------------- qkv_prepare
@@ -397,10 +397,11 @@ def test_attention_reference_goldens(golden_dir):
             # bf16: P is rounded to bf16 before P V (as flash kernels do) -> ~1e-2 rel of |out|max
             _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attn {c['q_shape']}", ulp=3.0)
             assert torch.allclose(out.float().cpu(), c["out"].float(), atol=3e-2, rtol=3e-2)
-            measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.rel_vs_reference_run", _rel(out.cpu(), c["out"]), 3e-2)
-            # like for like: the oracle rounding where the kernel rounds (bf16 P into P V, f32 row sums, bf16 store)
-            measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.like_for_like",
-                     _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 5e-4)
+            measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.rel_vs_reference_run", _rel(out.cpu(), c["out"]), 5e-3)   # measured 2.3e-3
+            if c["q_shape"][-1] == 128:      # the flash kernels (other head sizes run the generic kernel, whose probabilities stay f32)
+                # like for like: the oracle rounding where the kernel rounds (bf16 P into P V, f32 row sums, bf16 store)
+                measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.like_for_like",
+                         _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 5e-4)
 
 
 def test_attention_verification_probe_shape():
@@ -564,8 +565,8 @@ def test_attention_four_cluster_variant(shape, c4):
         lib.tune_set("attn.c4", 3)
         lib.tune_set("attn.w64", 1)
     _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention c4 {shape}", ulp=3.0)
-    measured(f"attention_c4.{shape}.like_for_like",
-             _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 5e-4)
+    measured(f"attention_c4.{shape}.like_for_like",       # measured 1e-8 .. 8.7e-5 (round 6)
+             _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 3e-4)
     assert torch.equal(out.cpu(), out2.cpu())
 
 
@@ -595,8 +596,8 @@ def test_attention_w64_kernel(shape):
         lib.tune_set("attn.w64", 1)
     _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention w64 {shape}", ulp=3.0)
     # the assert that can fail: same inputs, the oracle rounding exactly where the kernel rounds -> the like-for-like bar (5e-4)
-    measured(f"attention_w64.{shape}.like_for_like",
-             _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 5e-4)
+    measured(f"attention_w64.{shape}.like_for_like",      # measured 0 .. 1.1e-4 (round 6)
+             _rel(out.cpu(), OL.sdpa(q.float(), k.float(), v.float(), policy=OL.BF16_STORAGE).to(torch.bfloat16)), 3e-4)
     assert torch.equal(out.cpu(), out2.cpu())
     frac = float((out != c4).float().mean())
     rel = float((out.float() - c4.float()).norm() / c4.float().norm())

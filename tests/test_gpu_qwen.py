@@ -122,7 +122,7 @@ def test_qwen_matches_reference_wiring_golden(golden_dir):
                   inp["img_shapes"][0])
     rel = _rel(out, g["out"])
     print(f"qwen hip bf16 vs reference-wiring fp32 golden: rel {rel:.3e}")
-    measured("qwen_hybrid.bf16_vs_reference_run", rel, 3e-2)
+    measured("qwen_hybrid.bf16_vs_reference_run", rel, 9e-3)       # measured 4.5e-3 (round 6)
 
 
 def test_qwen_full_width_one_block_matches_oracle(host_threads):

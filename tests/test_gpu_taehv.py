@@ -241,5 +241,5 @@ def test_taehv_encoder_matches_reference_output_and_oracle(golden_dir):
         print(f"[taehv encode {name}] hip vs reference fp32 {e_ref:.3e}; vs bf16-storage oracle {e_like:.3e}; vs fp32 oracle "
               f"{e_true:.3e}; emulation vs fp32 {e_emul:.3e}")
         assert e_like < 2e-2 and e_true < 2 * e_emul + 2e-3
-        measured(f"taehv_encode.{name}.bf16_vs_reference_run", e_ref, 3e-2)
+        measured(f"taehv_encode.{name}.bf16_vs_reference_run", e_ref, 1.3e-2)       # measured 6.4e-3 / 6.6e-3 (round 6)
         assert torch.equal(out, hip.encode_video(x.to(DEV)).float().cpu())

@@ -73,7 +73,7 @@ def test_wan_matches_reference_wiring_golden(golden_dir):
     _, out = _hip(g["config"], sd, inp["hidden_states"], inp["timestep"], inp["encoder_hidden_states"])
     rel = _rel(out, g["out"])
     print(f"wan hip bf16 vs reference-wiring f64 golden: rel {rel:.3e}")
-    measured("wan_hybrid.bf16_vs_reference_run", rel, 3e-2)
+    measured("wan_hybrid.bf16_vs_reference_run", rel, 1.0e-2)       # measured 4.8e-3 (round 6)
 
 
 def test_wan_full_width_one_block_matches_oracle(host_threads):
