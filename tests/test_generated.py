@@ -14,6 +14,10 @@ def test_attn_w64_loop_is_what_its_generator_writes(tmp_path):
                    capture_output=True)
     committed = open(os.path.join(ROOT, "apex-studio_amd", "csrc", "attn_w64_body.inc")).read()
     assert out.read_text() == committed
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_w64.py"), f"--out={out}", "--clobbers"], check=True,
+                   capture_output=True)
+    assert (tmp_path / "attn_w64_clobbers.inc").read_text() == \
+        open(os.path.join(ROOT, "apex-studio_amd", "csrc", "attn_w64_clobbers.inc")).read()
 
 
 def test_attn_w64_clobber_list_covers_the_registers_the_loop_names():

@@ -29,7 +29,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
+OPT = {"rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -184,10 +184,11 @@ def dec_raise_ops(e):
             f"v_sub_f32 {vr(t3)}, {vr(M_(e))}, {vr(t2)}",
             f"v_mov_b32 {vr(M_(e))}, {vr(t2)}",
             f"v_exp_f32 {vr(AL_(e))}, {vr(t3)}",
-            "s_nop 0",
-            f"v_mul_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(AL_(e))}",
-            f"v_mul_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(AL_(e))}",
-            f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}"]
+            "s_nop 0"] + \
+        ([] if OPT["rowsum"] == "mfma4" else      # mfma4: the partial sums live in AGPRs and take the factor with O^T (rescale_block)
+         [f"v_mul_f32 {vr(PS(e, 0))}, {vr(PS(e, 0))}, {vr(AL_(e))}",
+          f"v_mul_f32 {vr(PS(e, 1))}, {vr(PS(e, 1))}, {vr(AL_(e))}"]) + \
+        [f"v_cmp_neq_f32 s[{54 + 2 * e}:{55 + 2 * e}], 1.0, {vr(AL_(e))}"]
 
 
 def scale_ops(ns):
@@ -222,8 +223,23 @@ def sm1_ops(ns, inline_raise):
 
 
 def add_ops(st):
-    """row-sum terms of set st (exponentiated) into the four partial sums of each block"""
+    """row-sum terms of set st (exponentiated) into the two partial sums of each block.
+    rowsum = "add": the unrounded f32 exponentials, one v_add_f32 each (64 per tile).
+    rowsum = "dot2c": the PACKED bf16 probabilities of the tile (what multiplies V), two per v_dot2c_f32_bf16 against a {1.0, 1.0}
+    bf16 pair in s79 — 32 issue slots per tile instead of 64, and the normaliser is the sum of exactly the weights of P V
+    (measured, profiles/r06_attn_w64_rowsum_ab.log: no faster — the dot is not a full-rate VALU op).
+    rowsum = "mfma4": no VALU at all — see rowsum_mfma()."""
     q = []
+    if OPT["rowsum"] == "mfma4":
+        return q
+    if OPT["rowsum"] == "dot2c":
+        assert not OPT["pk_fma"], "s79 holds the bf16 ones pair"
+        if OPT["adds_in"] == "X":      # pair order (block-major): sm2_ops places each behind the v_cvt_pk of its pair
+            return [f"v_dot2c_f32_bf16 {vr(PS(e, j & 1))}, s79, {vr(P(e, 0) + j)}" for e in range(2) for j in range(16)]
+        for j in range(16):            # four chains round robin
+            for e in range(2):
+                q.append(f"v_dot2c_f32_bf16 {vr(PS(e, j & 1))}, s79, {vr(P(e, 0) + j)}")
+        return q
     for v in range(0, 64, 2):
         e, r = v >> 5, Sreg(st, v)
         if OPT["pk_add"]:
@@ -244,7 +260,8 @@ def sm2_ops(st, with_adds):
         e, w = v >> 5, v & 31
         u = [f"v_cvt_pk_bf16_f32 {vr(P(e, w >> 3) + ((w & 7) >> 1))}, {vr(Sreg(st, v))}, {vr(Sreg(st, v + 1))}"]
         if with_adds:
-            u = adds[(v >> 1) * per:(v >> 1) * per + per] + u
+            mine = adds[(v >> 1) * per:(v >> 1) * per + per]
+            u = u + mine if OPT["rowsum"] == "dot2c" else mine + u      # dot2c reads the packed pair, the adds the exponentials
         return u
     for v in range(0, 64, 2):
         q.append(f"v_exp_f32 {vr(Sreg(st, v))}, {vr(Sreg(st, v))}")
@@ -256,7 +273,25 @@ def sm2_ops(st, with_adds):
     return q
 
 
-DROP = {"exp": "v_exp_f32 v", "add": ("v_add_f32", "v_pk_add_f32"), "cvt": "v_cvt_pk", "max": "v_max3", "fma": ("v_fma_f32", "v_pk_fma_f32")}
+def SACC(e, h):              # rowsum = "mfma4": two 4-register accumulators per block in the free AGPRs
+    return 192 + 8 * e + 4 * h
+
+
+ONES = 224                   # v[224:225]: the bf16 pair {1.0, 1.0} twice — the all-ones A operand of the 4x4x4 MFMA
+
+
+def rowsum_mfma(em, e, kk, h):
+    """rowsum = "mfma4": the row-sum terms on the matrix pipe.  v_mfma_f32_4x4x4_16b_bf16 is sixteen independent 4x4x4 products;
+    with an all-ones A every lane's four result registers receive the sum of ITS OWN four bf16 B values: one 2-pass MFMA adds four
+    packed probabilities of the lane to its partial row sum — 16 of them per tile (128 matrix-pipe cycles) replace 64 v_add_f32
+    (256 issue cycles).  Half h of the 8-key fragment P(e, kk)."""
+    if not ABL["add"]:
+        return
+    d = ar(SACC(e, h), 4)
+    em.i(f"v_mfma_f32_4x4x4_16b_bf16 {d}, {vr(ONES, 2)}, {vr(P(e, kk) + 2 * h, 2)}, {d}")
+
+
+DROP = {"exp": "v_exp_f32 v", "add": ("v_add_f32", "v_pk_add_f32", "v_dot2c_f32_bf16"), "cvt": "v_cvt_pk", "max": "v_max3", "fma": ("v_fma_f32", "v_pk_fma_f32")}
 
 
 def spread(q, nslots, first_extra=0):
@@ -344,6 +379,15 @@ def rescale_block(em, go, back):
             em.i("s_nop 0")
             for u in range(4):
                 em.i(f"v_accvgpr_write_b32 {ar(e * 64 + k + u)}, {vr(T[u])}")
+        if OPT["rowsum"] == "mfma4":      # the block's partial row sums (register 0 of each accumulator is the one read at the end)
+            for h in range(2):
+                em.i(f"v_accvgpr_read_b32 {vr(T[h])}, {ar(SACC(e, h))}")
+            em.i("s_nop 0")
+            for h in range(2):
+                em.i(f"v_mul_f32 {vr(T[h])}, {vr(T[h])}, {vr(AL_(e))}")
+            em.i("s_nop 0")
+            for h in range(2):
+                em.i(f"v_accvgpr_write_b32 {ar(SACC(e, h))}, {vr(T[h])}")
         em.i("s_nop 7")
         em.i(f"{skip}:")
     em.i(f"s_branch {back}")
@@ -424,6 +468,8 @@ def tile(em, sg, more, more2, dma):
             if qq == 0:
                 em.need(VF(kk & 1, 3))                   # one wait per step
             mfma(em, O(e, dt), VF(kk & 1, dt), P(e, kk), 1, dst_a=True)
+            if OPT["rowsum"] == "mfma4" and OPT["mfma4_pos"] == "start" and (qq & 1) == 1:
+                rowsum_mfma(em, qq >> 2, kk, (qq >> 1) & 1)
             piece = dma and slot >= 16 and (slot & 1) == 1
             if piece:
                 dma_piece(em, (slot - 16) >> 1, dst, part=1)
@@ -441,6 +487,8 @@ def tile(em, sg, more, more2, dma):
                     em.i(op)
             if piece:
                 dma_piece(em, (slot - 16) >> 1, dst, part=2)
+            if OPT["rowsum"] == "mfma4" and OPT["mfma4_pos"] == "end" and (qq & 1) == 1:      # behind the gap's VALU, right in front of the next P V MFMA
+                rowsum_mfma(em, qq >> 2, kk, (qq >> 1) & 1)
             if more2 and slot == 31 - OPT["kread_early"]:
                 k_first_reads(em, k2st)                  # first K fragments of tile t + 2, for phase X of the next tile
     em.pending_rescale = rescale_test(em) if more else None
@@ -512,11 +560,16 @@ def main():
     em.i(f"v_add_u32 {vr(242)}, %[vp], {vr(241)}")
     em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(242)}")
     em.i("s_mov_b32 s78, %[sc]")                      # {scale, scale} for v_pk_fma_f32
-    em.i("s_mov_b32 s79, %[sc]")
+    em.i("s_mov_b32 s79, 0x3f803f80" if OPT["rowsum"] == "dot2c" else "s_mov_b32 s79, %[sc]")     # dot2c: the bf16 pair {1.0, 1.0}
     for e in range(2):
         em.i(f"s_mov_b64 s[{54 + 2 * e}:{55 + 2 * e}], 0")
     for k in range(128):
         em.i(f"v_accvgpr_write_b32 {ar(k)}, 0")
+    if OPT["rowsum"] == "mfma4":
+        for k in range(192, 208):
+            em.i(f"v_accvgpr_write_b32 {ar(k)}, 0")
+        em.i(f"v_mov_b32 {vr(ONES)}, 0x3f803f80")
+        em.i(f"v_mov_b32 {vr(ONES + 1)}, 0x3f803f80")
     # tiles 0..2 staged
     for tt in range(3):
         skip = em.label("nost")
@@ -646,12 +699,24 @@ def main():
         em.i("s_waitcnt vmcnt(0)")
         em.i("s_mov_b64 exec, s[76:77]")
         em.i(f"{skip}:")
+    if OPT["rowsum"] == "mfma4":
+        for e in range(2):
+            for h in range(2):
+                em.i(f"v_accvgpr_read_b32 {vr(PS(e, h))}, {ar(SACC(e, h))}")
+        em.i("s_nop 1")
     for e, o in ((0, "%[la]"), (1, "%[lb]")):
         em.i(f"v_add_f32 {o}, {vr(PS(e, 0))}, {vr(PS(e, 1))}")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_w64.py - do not edit (the generator holds the register map and the schedule)\n")
         for ln in em.lines:
             f.write(f'"{ln}\\n\\t"\n')
+    if out == OUT or "--clobbers" in sys.argv:      # the asm statement's clobber list: the registers this generator's map owns
+        regs = [f"v{i}" for i in range(244)] + [f"a{i}" for i in range(128, 208)] + [f"s{i}" for i in range(40, 90)]
+        with open(os.path.join(os.path.dirname(out), "attn_w64_clobbers.inc"), "w") as f:
+            f.write("// GENERATED by tools/gen_attn_w64.py with attn_w64_body.inc: the registers the asm body owns (v[0:243], a[128:207] — Q and\n"
+                    "// the rowsum accumulators; a[0:127] = O^T are the statement's outputs —, s[40:89])\n")
+            for k in range(0, len(regs), 16):
+                f.write(", ".join(f'"{r}"' for r in regs[k:k + 16]) + (",\n" if k + 16 < len(regs) else "\n"))
     n_mfma = sum("v_mfma" in ln for ln in em.lines)
     print(f"{out}: {len(em.lines)} instructions, {n_mfma} MFMAs")
 
