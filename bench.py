@@ -59,6 +59,8 @@ S_IMG, S_TXT = 4096, 512
 # algorithmic FLOPs of one step: 2MNK per GEMM + 4 H Sq Sk D per attention
 # flux512 (config 1's geometry on the GPU: S 1024 + 512): every GEMM is linear in S (59.506 x 1536 / 4608 = 19.835), attention
 # 4 x 24 x 1536^2 x 128 x 57 = 1.652
+WAN_VAE_ALGORITHMIC_TFLOP = 632.0      # the untiled 720p x 81-frame decode (the reference's tiled execution ~ x1.78)
+WAN_VAE_ALGORITHMIC_BYTES = 0.38e12    # minimal bf16 activation traffic with norm / activation fused
 STEP_TFLOP = {"flux": 74.36, "flux512": 21.49, "qwen": 167.4, "wan": 6520.0, "hunyuan": 1394.9}
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
@@ -112,7 +114,7 @@ def cpu_info():
             "logical_cpus": logical or (os.cpu_count() or 1)}
 
 
-def best_threads(fn, budget_s=25.0):
+def best_threads(fn, budget_s=20.0):
     """The thread count the CPU baseline runs at: all logical CPUs is NOT the fastest on a 2-socket SMT host (oversubscribed
     oneDNN / OpenMP teams: the 256-thread run of r4 was 5-6 x slower than 32 threads on 2 x EPYC 9575F).  `fn()` = one bounded piece
     of the workload; tried at {1/4, 1/8, 1/2, all of the physical cores, logical CPUs} until the budget is spent; returns
@@ -248,6 +250,69 @@ def pmc_traffic(src_file, suffix):
     return None, None, None
 
 
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s peak (~6.3 TB/s achievable)
+
+
+def decode_roofline(prof, seconds, pmc_suffix, algorithmic_tflop, algorithmic_bytes, what):
+    """The VAE decode against both rooflines (north_star: "rocprof counters reporting achieved HBM GB/s and MFMA utilisation" for
+    the VAE).  `prof` = the library's per-class records over ONE timed decode (class `gemm` carries the convolutions: 2 M Cout
+    taps Cin flops and input + weight + output bytes per launch; `attention` the mid-block attention; the rest the norm /
+    upsample / blend passes with their bytes).  executed = what the launches computed (tiled: overlapping tiles recompute their
+    halos, R/src/vae/wan/model.py:1516-1623); algorithmic = the untiled decode.  `traffic` = HBM-side bytes of
+    the whole decode from the hash-matched rocprofv3 --pmc record (tools/gpu_pmc_vae.sh), else null."""
+    ex_flops = sum(v["flops"] for v in prof.values())
+    ex_bytes = sum(v["bytes"] for v in prof.values())
+    kernel_ms = sum(v["ms"] for v in prof.values())
+    traffic, src, rec = None, None, None
+    import glob
+    import hashlib
+    conv_hash = hashlib.sha256(open(os.path.join(ROOT, "apex-studio_amd", "csrc", "conv.hip"), "rb").read()).hexdigest()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{pmc_suffix}")), reverse=True):
+        r = json.load(open(f))
+        if r.get("source_sha256") == conv_hash:
+            traffic, src, rec = r.get("traffic_bytes_per_decode"), "profiles/" + os.path.basename(f), r
+            break
+    ach = ex_flops / seconds / 1e12
+    return {"what": what, "seconds": seconds, "launches": int(sum(v["launches"] for v in prof.values())),
+            "executed_tflop": ex_flops / 1e12, "algorithmic_tflop": algorithmic_tflop,
+            "executed_over_algorithmic": ex_flops / 1e12 / algorithmic_tflop if algorithmic_tflop else None,
+            "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+            "frac_algorithmic": (algorithmic_tflop / seconds / PEAK_BF16_TFLOPS) if algorithmic_tflop else None,
+            "kernel_ms_sum": kernel_ms,
+            "hbm": {"launch_bytes": ex_bytes, "launch_gbps": ex_bytes / seconds / 1e9, "peak_gbps": HBM_PEAK_GBPS,
+                    "frac_launch_bytes": ex_bytes / seconds / 1e9 / HBM_PEAK_GBPS,
+                    "algorithmic_bytes": algorithmic_bytes, "traffic": traffic, "traffic_source": src,
+                    "traffic_gbps": (traffic / seconds / 1e9) if traffic else None,
+                    "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic and algorithmic_bytes else None,
+                    "traffic_over_launch_bytes": (traffic / ex_bytes) if traffic and ex_bytes else None,
+                    "mfma_pipe_busy_conv_kernels": (rec or {}).get("mfma_pipe_busy_fraction_conv_kernels"),
+                    "l2_hit_rate": (rec or {}).get("l2_hit_rate")},
+            "note": "achieved = executed flops of every launch of ONE decode / its wall time (tiles run two at a time on side "
+                    "streams, so the per-launch HIP-event durations in kernel_ms_sum overlap and exceed the wall time); launch_bytes "
+                    "= input + weight + output bytes each launch must move if nothing stayed in cache (intermediates are written "
+                    "and read back once per layer: the un-fused upper bound of useful traffic); traffic = measured HBM-side bytes "
+                    "(2 x FETCH_SIZE + WRITE_SIZE summed over the decode's dispatches) from the hash-matched PMC record"}
+
+
+def timed_decode(fn):
+    """fn() twice (warm, then timed with the library's per-class records on): (output, seconds, records)."""
+    from apex_studio_amd import lib
+    out = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        if rep == 1:
+            lib.prof_reset()
+            lib.prof_enable(True)
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    prof = lib.prof_read()
+    lib.prof_enable(False)
+    lib.prof_reset()
+    return out, dt, prof
+
+
 def wan_half(dev, cpu=True):
     """The other half of BASELINE.json's metric on the default line: Wan-2.2 A14B 720p x 81 frames (config 4), one
     expert, 1 warm-up + 2 timed [forward + UniPC step], then the tiled 3-D VAE decode (1 warm-up + 1 timed)."""
@@ -287,12 +352,17 @@ def wan_half(dev, cpu=True):
     vae = synth_vae_init(AutoencoderKLWan(device=dev, dtype=torch.bfloat16), 6)
     vae.enable_tiling()
     z = vae.denormalize_latents(lat).to(torch.bfloat16)
-    for _ in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        video = vae.decode(z, return_dict=False)[0]
-        torch.cuda.synchronize()
-        dec = time.perf_counter() - t0
+    video, dec, dprof = timed_decode(lambda: vae.decode(z, return_dict=False)[0])
+    # the library's records cost one HIP-event pair per launch; the bare time is taken once more without them
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    video = vae.decode(z, return_dict=False)[0]
+    torch.cuda.synchronize()
+    dec_bare = time.perf_counter() - t0
+    decode = decode_roofline(dprof, dec, "pmc_conv.json", WAN_VAE_ALGORITHMIC_TFLOP, WAN_VAE_ALGORITHMIC_BYTES,
+                             "Wan 3-D VAE, tiled 4 x 7 decode of [1,16,21,90,160] -> [1,3,81,720,1280]")
+    decode["seconds_without_records"] = dec_bare
+    dec = min(dec, dec_bare)
     tf = STEP_TFLOP["wan"]
     ach = att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] else None
     traffic, traffic_src, rec = pmc_traffic("attention.hip", "pmc_attn_wan.json")
@@ -311,7 +381,7 @@ def wan_half(dev, cpu=True):
            "steps_timed": 2, "ms_per_step": 1e3 * dt, "steps_per_sec": 1.0 / dt, "step_tflop": tf,
            "model_tflops": tf / dt, "mfma_utilisation_step": tf / dt / PEAK_BF16_TFLOPS,
            "attention": {"tflops": ach, "ms_per_step": att["ms"] / 2, "launches_per_step": att["launches"] / 2},
-           "roofline": roof, "decode_s": dec, "sec_per_clip_30_steps": 30 * dt + dec, "video": list(video.shape),
+           "roofline": roof, "decode_s": dec, "decode": decode, "sec_per_clip_30_steps": 30 * dt + dec, "video": list(video.shape),
            "finite": finite and bool(torch.isfinite(video.float()).all().item())}
     del vae, video, z
     torch.cuda.empty_cache()
@@ -409,7 +479,14 @@ def build_flux(args, dev, rank, total):
             img = vae.decode(z, return_dict=False)[0]
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-        return {"sec_per_clip": t2 - t0, "denoise_s": t1 - t0, "decode_s": t2 - t1, "steps": clip_steps,
+        # the decode once more under the library's per-class records: its roofline object (the 2-D twin of wan.decode)
+        _, dsec, dprof = timed_decode(lambda: vae.decode(z, return_dict=False)[0])
+        decode = decode_roofline(dprof, dsec, "pmc_conv_flux.json", None, None,
+                                 f"Flux 2-D VAE decode of [1,16,{px // 8},{px // 8}] -> [1,3,{px},{px}] (untiled: executed = algorithmic)")
+        decode["algorithmic_tflop"] = decode["executed_tflop"]
+        decode["executed_over_algorithmic"] = 1.0
+        decode["frac_algorithmic"] = decode["frac"]
+        return {"sec_per_clip": t2 - t0, "denoise_s": t1 - t0, "decode_s": t2 - t1, "decode": decode, "steps": clip_steps,
                 "image": list(img.shape), "finite": bool(torch.isfinite(img.float()).all().item())}
 
     label = (f"flux-dev-{px}x{px} denoise step (19 double + 38 single MM-DiT blocks, S_img {S_IMG} + S_txt 512, "
@@ -898,11 +975,14 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * gk["ms"] / gk["launches"],
                     "launches_per_step": gk["launches"] / nprof,
                     "algorithmic_tflop_per_step": gk["flops"] / nprof / 1e12,
+                    "algorithmic_bytes_per_launch": gk["bytes"] / gk["launches"] if gk["bytes"] else None,
+                    "traffic_over_algorithmic": (traffic * gk["launches"] / gk["bytes"]) if traffic and gk["bytes"] else None,
                     "note": "achieved = algorithmic flops / summed HIP-event durations of the kernel's launches over "
                             f"{nprof} extra event-instrumented steps; the per-class times in `kernels` come from that pass, "
                             "include the event overhead and are NOT additive to ms_per_step; `traffic` = HBM bytes PER LAUNCH "
                             "(mean over the kernel's launches) from the separate rocprofv3 --pmc pass named in traffic_source, "
-                            "used only when that record's source hash equals this binary's kernel source"
+                            "used only when that record's source hash equals this binary's kernel source; algorithmic_bytes_per_launch = "
+                            "activation + weight + output bytes once (mean over the kernel's launches)"
                             + (f"; that pass ran `{pmc_rec.get('command')}`" + (" - a DEPTH-REDUCED run of the same launches: "
                                "per launch it is the full-depth figure, per step it is not" if "--layers" in str(pmc_rec.get("command")) else "")
                                if pmc_rec else "")}
