@@ -879,6 +879,148 @@ def gen_qwen2_5_vl():
     print("qwen2_5_vl", float(a.hidden_states[-1].abs().mean()), float(b.hidden_states[-1].abs().mean()), float(vis.abs().mean()))
 
 
+def extract_method(rel, cls, name, ns):
+    """One METHOD of a reference class compiled as a plain function (by AST) in namespace `ns`: for engine classes whose module
+    cannot be imported here (the engine base pulls diffusers / loguru).  The reference's code is RUN from where it lies."""
+    import ast
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    f = next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    env = dict(ns)
+    exec(compile(ast.Module(body=[f], type_ignores=[]), path, "exec"), env)
+    return env[name]
+
+
+TINY_WAN_I2V = dict(TINY_WAN, in_channels=36)
+
+
+def gen_wan_i2v():
+    """Wan-2.2 A14B image-to-video, the two things the reference adds to the text-to-video path:
+      (a) `WanI2VEngine.run` ITSELF (engine/wan/i2v.py:13-314, compiled from the class by AST and driven with a stand-in `self`:
+          the text encoder, scheduler, latent noise and `denoise` are stubs that carry no arithmetic of this path; the aspect-ratio
+          resize and the frame count are the reference's own `BaseEngine._aspect_ratio_resize` / `_parse_num_frames`, the VAE encode
+          is the reference AutoencoderKLWan on tiny channels through the `vae_encode` recipe base_engine.py:2139-2160): what reaches
+          `denoise` — the 20-channel `latent_condition` = [first-frame mask x 4 | normalised condition latents], the guidance
+          scales and the CFG decision.  `video_processor.preprocess` is diffusers' (absent): stated as x / 127.5 - 1.
+      (b) the reference WanTransformer3DModel with `in_channels` = 36 on cat([latents, latent_condition]), float64."""
+    import types
+    import typing
+    import numpy as np
+    from PIL import Image
+    install_vae_stubs()
+    ref_vae_mod = load_by_path("ref_vae_wan_i2v", "src/vae/wan/model.py")
+    from oracle.vae_wan import AutoencoderKLWanEncoder
+    vae = ref_vae_mod.AutoencoderKLWan(**TINY_VAE).eval()
+    vsd = vae_synthetic_state_dict(AutoencoderKLWanEncoder(**TINY_VAE), 15)
+    vae.load_state_dict(vsd, strict=False)
+    base = extract_defs("src/engine/base_engine.py", [], {})      # (namespace only)
+    ns = dict(torch=torch, np=np, Image=Image, Dict=typing.Dict, Any=typing.Any, Callable=typing.Callable, List=typing.List,
+              Union=typing.Union, Optional=typing.Optional, InputImage=typing.Any,
+              safe_emit_progress=lambda *a, **k: None, make_mapped_progress=lambda cb, a, b: None)
+    run = extract_method("src/engine/wan/i2v.py", "WanI2VEngine", "run", ns)
+    resize = extract_method("src/engine/base_engine.py", "BaseEngine", "_aspect_ratio_resize", ns)
+    parse_frames = extract_method("src/engine/base_engine.py", "BaseEngine", "_parse_num_frames", ns)
+    seen = {}
+
+    class Sched:
+        config = types.SimpleNamespace(num_train_timesteps=1000)
+
+        def set_timesteps(self, n, device=None):
+            self.timesteps = torch.linspace(999.0, 1.0, n)
+
+    class Self:
+        device = torch.device("cpu")
+        text_encoder = types.SimpleNamespace(encode=lambda prompt, device=None, num_videos_per_prompt=1, **kw:
+                                             seeded((num_videos_per_prompt, 20, 64), 42 if prompt == "a cat" else 43))
+        scheduler = Sched()
+        component_dtypes = {"transformer": torch.float32}
+        helpers = {}
+        vae_scale_factor_spatial, vae_scale_factor_temporal = 8, 4
+        video_processor = types.SimpleNamespace(preprocess=lambda img, height, width:
+                                                torch.from_numpy(np.asarray(img).astype(np.float32) / 255.0).permute(2, 0, 1)[None] * 2.0 - 1.0)
+
+        def load_component_by_type(self, *a, **k):
+            pass
+
+        to_device = _offload = load_component_by_type
+
+        def _load_image(self, image):
+            return Image.fromarray(image)
+
+        def _aspect_ratio_resize(self, *a, **k):
+            return resize(self, *a, **k)
+
+        def _parse_num_frames(self, *a, **k):
+            return parse_frames(self, *a, **k)
+
+        def _get_timesteps(self, scheduler, timesteps, timesteps_as_indices, num_inference_steps):
+            return scheduler.timesteps, num_inference_steps
+
+        def load_config_by_type(self, kind):
+            return types.SimpleNamespace(scale_factor_spatial=8, scale_factor_temporal=4, z_dim=16)
+
+        def _get_latents(self, height, width, duration, num_channels_latents, vae_scale_factor_spatial, vae_scale_factor_temporal,
+                         fps, batch_size, seed, dtype, generator):
+            nf = self._parse_num_frames(duration, fps)
+            return seeded((batch_size, num_channels_latents, (nf - 1) // vae_scale_factor_temporal + 1,
+                           height // vae_scale_factor_spatial, width // vae_scale_factor_spatial), 41).to(dtype)
+
+        def vae_encode(self, video, offload=False, dtype=None, normalize_latents_dtype=None):
+            """BaseEngine.vae_encode without its disk cache (base_engine.py:2139-2160)."""
+            seen["video_condition"] = video.clone()
+            vae.enable_tiling(tile_sample_min_height=48, tile_sample_min_width=48, tile_sample_stride_height=32,
+                              tile_sample_stride_width=32)
+            with torch.no_grad():
+                # `encode(video)[0].mode()`: DiagonalGaussianDistribution is diffusers' (absent); its mode is the mean = the first
+                # z_dim channels of what `_encode` returns (vae/wan/model.py:1319-1331)
+                lat = vae._encode(video)[:, :16]
+            return vae.normalize_latents(lat.to(normalize_latents_dtype)).to(dtype)
+
+        def denoise(self, **kw):
+            seen.update({k: kw[k] for k in ("latent_condition", "first_frame_mask", "guidance_scale", "use_cfg_guidance",
+                                            "boundary_timestep", "expand_timesteps")})
+            seen["transformer_kwargs"] = sorted(kw["transformer_kwargs"])
+            seen["latents_shape"] = tuple(kw["latents"].shape)
+            return kw["latents"]
+
+        def vae_decode(self, *a, **k):
+            raise AssertionError("return_latents=True")
+
+    image = (seeded((50, 90, 3), 71) * 60 + 128).clamp(0, 255).to(torch.uint8).numpy()        # 50 x 90 RGB, resized by the engine
+    out = run(Self(), image=image, prompt="a cat", negative_prompt="blurry", duration=9, height=64, width=96, num_inference_steps=4,
+              seed=0, high_noise_guidance_scale=3.5, low_noise_guidance_scale=2.0, boundary_ratio=0.9, return_latents=True)
+    cond = seen["latent_condition"]
+    assert cond.shape[1] == 20 and tuple(out.shape) == seen["latents_shape"]
+    run(Self(), image=image, prompt="a cat", negative_prompt="blurry", duration=9, height=64, width=96, num_inference_steps=4,
+        boundary_ratio=0.9, return_latents=True)                                   # default scales 1.0 / 1.0: no CFG
+    no_cfg = seen["use_cfg_guidance"]
+    # (b) the 36-channel expert on [latents | condition]
+    from src.transformer.wan.base.model import WanTransformer3DModel as RefWan
+    from oracle.wan import WanTransformer3DModel as OracleWan
+    ref = RefWan(**TINY_WAN_I2V, rope_max_seq_len=64).eval()
+    sd = synthetic_state_dict(OracleWan(**TINY_WAN_I2V), 19)
+    assert sorted(sd.keys()) == sorted(ref.state_dict().keys())
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.double()
+    lat = seeded(seen["latents_shape"], 41)
+    x = torch.cat([lat, cond], dim=1)
+    txt = seeded((1, 20, 64), 42)
+    with torch.no_grad():
+        fwd = ref(hidden_states=x.double(), timestep=torch.tensor([950.0], dtype=torch.float64), encoder_hidden_states=txt.double(),
+                  return_dict=False)[0]
+    torch.save(dict(image=torch.from_numpy(image), height=64, width=96, duration=9, vae_config=TINY_VAE, vae_seed=15,
+                    tile=(48, 48, 32, 32), resized=tuple(seen["video_condition"].shape[-2:]),
+                    video_condition_frame0=seen["video_condition"][:, :, 0].clone(),
+                    video_condition_rest_abs_max=float(seen["video_condition"][:, :, 1:].abs().max()),
+                    latent_condition=cond.float(), first_frame_mask=seen["first_frame_mask"].float(),
+                    guidance_scale=[float(g) for g in (3.5, 2.0)], use_cfg_guidance=True, use_cfg_guidance_default_scales=bool(no_cfg),
+                    boundary_timestep=float(900.0), transformer_kwargs=seen["transformer_kwargs"], latents_shape=seen["latents_shape"],
+                    wan_config=TINY_WAN_I2V, wan_seed=19, latents_seed=41, txt_seed=42, timestep=950.0, wan_out=fwd.float()),
+               os.path.join(OUT, "wan_i2v.pt"))
+    print("wan_i2v.pt", tuple(cond.shape), seen["video_condition"].shape, float(cond[:, 4:].abs().mean()), tuple(fwd.shape), no_cfg)
+
+
 # ---- leaf pins: the reference's IN-TREE copies of the diffusers leaves -----------------------------------------------
 def extract_defs(rel, names, ns=None):
     """Execute only the named top-level functions / classes of a reference source file (by AST), in a namespace that
@@ -1228,11 +1370,11 @@ def gen_leaf_pins2():
 
 
 # Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
-FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
             "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
             "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
 # the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
-FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
         "convert"]
 
 
