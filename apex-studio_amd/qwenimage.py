@@ -12,8 +12,10 @@ per-head RMSNorm + RoPE + V^T, joint attention, gate+residual epilogues.  Differ
 every block owns its img_mod / txt_mod projection (all 120 of them are one batched GEMV per step, chunk
 order [shift1, scale1, gate1, shift2, scale2, gate2]); complex RoPE with centred image positions and
 offset text positions (QwenEmbedRope, model.py:187-314); RMSNorm(3584) on the text embeddings.
-`zero_cond_t`, `use_additional_t_cond`, layer-3D RoPE and ControlNet residuals raise
-NotImplementedError (off in the Edit-2509 configuration).
+`zero_cond_t` (the condition images' tokens are modulated by a second conditioning row at t = 0: model.py:640-677, :692-702,
+:912-923, :980-981) and `use_additional_t_cond` (`addition_t_embedding`, :164-182) are served since round 6 (off in the
+Edit-2509 configuration; pinned by tests/golden/qwen_variants.pt); layer-3D RoPE and ControlNet residuals raise
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -62,9 +64,11 @@ class _QwenBlock(nn.Module):
 
 
 class _TimeTextEmbed(nn.Module):
-    def __init__(self, dim: int, **kw):
+    def __init__(self, dim: int, use_additional_t_cond: bool = False, **kw):
         super().__init__()
         self.timestep_embedder = _TimestepEmbedding(256, dim, **kw)
+        if use_additional_t_cond:      # QwenTimestepProjEmbeddings, model.py:164-166: key time_text_embed.addition_t_embedding.weight
+            self.addition_t_embedding = nn.Embedding(2, dim, **kw)
 
 
 class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
@@ -80,8 +84,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         super().__init__()
         if attention_head_dim != 128:
             raise _l.ApexMIError("qwenimage.mi355: attention_head_dim must be 128 (MFMA attention tile)")
-        if zero_cond_t or use_additional_t_cond or use_layer3d_rope:
-            raise NotImplementedError("qwenimage.mi355: zero_cond_t / additional_t_cond / layer3d rope variants")
+        if use_layer3d_rope:
+            raise NotImplementedError("qwenimage.mi355: the layer3d rope variant")
         self.config = _Config(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
                               num_layers=num_layers, attention_head_dim=attention_head_dim,
                               num_attention_heads=num_attention_heads, joint_attention_dim=joint_attention_dim,
@@ -90,7 +94,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         kw = dict(device=device, dtype=dtype)
         self.out_channels = out_channels or in_channels
         self.inner_dim = dim = num_attention_heads * attention_head_dim
-        self.time_text_embed = _TimeTextEmbed(dim, **kw)
+        self.time_text_embed = _TimeTextEmbed(dim, use_additional_t_cond, **kw)
         self.txt_norm = _Norm(joint_attention_dim, **kw)
         self.img_in = _Linear(in_channels, dim, **kw)
         self.txt_in = _Linear(joint_attention_dim, dim, **kw)
@@ -218,7 +222,9 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             Q=torch.empty(1, H, S, 128, **bf), K=torch.empty(1, H, S, 128, **bf),
             VT=torch.zeros(1, H, 128, skp, **bf), ATT=torch.empty(S, dim, **bf),
             FFH=torch.empty(S, 4 * dim, **bf), TXTN=torch.empty(s_txt, self.config.joint_attention_dim, **bf),
-            MOD=torch.empty(1, self._mod_total, **f32), TEMB=torch.empty(1, dim, **f32), shipped=ops.shipped_verification())
+            # zero_cond_t: a second conditioning row (t = 0) for the condition images' tokens
+            MOD=torch.empty(2 if self.config.zero_cond_t else 1, self._mod_total, **f32),
+            TEMB=torch.empty(2 if self.config.zero_cond_t else 1, dim, **f32), shipped=ops.shipped_verification())
         if ws.shipped and self.storage_dtype == torch.float32:     # verification through the shipped kernels (flux.py `_workspace`)
             b16 = dict(device=dev, dtype=torch.bfloat16)
             ws.Qb, ws.Kb, ws.VTb = torch.empty(1, H, S, 128, **b16), torch.empty(1, H, S, 128, **b16), torch.zeros(1, H, 128, skp, **b16)
@@ -284,8 +290,9 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         return sc.row("mod", int(kw["modulation_step"]), b, timestep, clamp_b=True)   # an [n] schedule serves every image of the batch
 
     @torch.no_grad()
-    def _forward_one(self, hidden_states, text, timestep, shapes, mod_row=None):
+    def _forward_one(self, hidden_states, text, timestep, shapes, mod_row=None, addition_t_cond=None):
         cfg = self.config
+        zc = bool(cfg.zero_cond_t)
         dim, H = self.inner_dim, cfg.num_attention_heads
         s_img, s_txt = hidden_states.shape[0], text.shape[0]
         if sum(int(f) * int(h) * int(w) for f, h, w in shapes) != s_img:
@@ -306,9 +313,15 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             te = self.time_text_embed.timestep_embedder
             # `timestep.to(hidden_states.dtype)`, model.py:905: bf16 in production, f32 in the verification mode
             t = timestep.to(self.storage_dtype).float().reshape(1)
+            if zc:                         # `timestep = torch.cat([timestep, timestep * 0])`, model.py:912-913
+                t = torch.cat([t, t * 0])
             tp = ops.timestep_embedding(t, 256, scale=1000.0)
             h = ops.gemv(te.linear_1.weight, tp, te.linear_1.bias, post="silu")
             ops.gemv(te.linear_2.weight, h, te.linear_2.bias, out=ws.TEMB)
+            if cfg.use_additional_t_cond:  # conditioning + addition_t_embedding[addition_t_cond] (both rows), model.py:175-182
+                if addition_t_cond is None:
+                    raise ValueError("When additional_t_cond is True, addition_t_cond must be provided.")
+                ws.TEMB.add_(self.time_text_embed.addition_t_embedding.weight[addition_t_cond.reshape(1).long()].float())
 
             n_first = self._mod_first
             ops.gemv(self._mod_w[:n_first], ws.TEMB, self._mod_b[:n_first], out=ws.MOD[:, :n_first], pre_silu=True)
@@ -335,6 +348,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
                 and len(self.transformer_blocks) > 0 and tuple(rope.shape) == (2, S, 128)
                 and ops.qkv_fusable([XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H))
         Qp, Kp, VTp = (ws.Qb, ws.Kb, ws.VTb) if (mixed and fuse) else (ws.Q, ws.K, ws.VT)
+        # zero_cond_t: the first image (the target) is conditioned on t, the images after it on t = 0 (`modulate_index`, :914-921)
+        n0 = int(shapes[0][0]) * int(shapes[0][1]) * int(shapes[0][2]) if zc else s_img
         for i, blk in enumerate(self.transformer_blocks):
             if i == 1 and mod_ready is not None:
                 torch.cuda.current_stream().wait_event(mod_ready)
@@ -344,6 +359,9 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             mi = lambda j: MOD[0, base + j * dim: base + (j + 1) * dim]              # noqa: E731
             mt = lambda j: MOD[0, base + (6 + j) * dim: base + (7 + j) * dim]        # noqa: E731
             # chunk order: shift1, scale1, gate1 | shift2, scale2, gate2
+            if zc:
+                self._block_zero_cond(blk, ws, MOD, base, s_txt, n0, rope, fuse, Qp, Kp, VTp, q_in, k_in, v_in, att_v, H)
+                continue
             ops.ln_modulate(X, mi(1), mi(0), out=XN, split=s_txt, scale2=mt(1), shift2=mt(0))
             if fuse:
                 # q/k norm + RoPE + [H, S, D] layout and V^T leave the QKV GEMM's epilogue (bit-identical to the two passes)
@@ -373,14 +391,64 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.ln_modulate(Xi, MOD[0, o:o + dim], MOD[0, o + dim:o + 2 * dim], out=XNi)
         return ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias)
 
+    def _block_zero_cond(self, blk, ws, MOD, base, s_txt, n0, rope, fuse, Qp, Kp, VTp, q_in, k_in, v_in, att_v, H):
+        """One block with `zero_cond_t`: the same launches, with the image stream's modulation and gates taken per ROW RANGE —
+        target tokens [s_txt, s_txt + n0) from conditioning row 0 (t), condition-image tokens behind them from row 1 (t = 0); the
+        text stream from row 0 (`_modulate(index)`, model.py:640-677; `txt_mod(temb.chunk(2)[0])`, :692-693).  The LN + modulate
+        pass runs once per range, the gate / residual GEMMs carry the two image ranges as two problems of the grouped launch."""
+        dim = self.inner_dim
+        a = blk.attn
+        X, XN, QKV, ATT, FFH = ws.X, ws.XN, ws.QKV, ws.ATT, ws.FFH
+        S = X.shape[0]
+        c0 = s_txt + n0                                   # first condition-image row
+        Xt, Xi, XNt, XNi = X[:s_txt], X[s_txt:], XN[:s_txt], XN[s_txt:]
+        m0 = lambda j: MOD[0, base + j * dim: base + (j + 1) * dim]                # noqa: E731  image stream, row t
+        m1 = lambda j: MOD[1, base + j * dim: base + (j + 1) * dim]                # noqa: E731  image stream, row t = 0
+        mt = lambda j: MOD[0, base + (6 + j) * dim: base + (7 + j) * dim]          # noqa: E731  text stream, row t
+        rng = [(s_txt, c0), (c0, S), (0, s_txt)] if c0 < S else [(s_txt, S), (0, s_txt)]
+        gates = lambda j: ([m0(j), m1(j), mt(j)] if c0 < S else [m0(j), mt(j)])    # noqa: E731
+
+        def ln(jscale, jshift):
+            ops.ln_modulate(X[:c0], m0(jscale), m0(jshift), out=XN[:c0], split=s_txt, scale2=mt(jscale), shift2=mt(jshift))
+            if c0 < S:
+                ops.ln_modulate(X[c0:], m1(jscale), m1(jshift), out=XN[c0:])
+
+        def gated(src, w_img, b_img, w_txt, b_txt, j):
+            ws_ = [w_img] * (len(rng) - 1) + [w_txt]
+            bs_ = [b_img] * (len(rng) - 1) + [b_txt]
+            ops.gemm_grouped([src[lo:hi] for lo, hi in rng], ws_, bs_, [X[lo:hi] for lo, hi in rng], epilogue="gate_res",
+                             gate_list=gates(j), residual_list=[X[lo:hi] for lo, hi in rng])
+
+        ln(1, 0)
+        if fuse:
+            ops.gemm_grouped_qkv([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [None, None], "bias",
+                                 [1, 1], [a.norm_q.weight, a.norm_added_q.weight], [a.norm_k.weight, a.norm_added_k.weight],
+                                 [s_txt, 0], H, 1e-6, rope, Qp[0], Kp[0], VTp[0])
+        else:
+            ops.gemm_grouped([XNi, XNt], [blk._wqkv, blk._wqkv_c], [blk._bqkv, blk._bqkv_c], [QKV[s_txt:], QKV[:s_txt]])
+            ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VTp[0], wq=a.norm_q.weight, wk=a.norm_k.weight,
+                            wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight, split=s_txt, eps=1e-6, rope=rope,
+                            rope_mode=_l.ROPE_INTERLEAVED)
+        ops.attention_prepared(Qp, Kp, VTp, att_v, S)
+        gated(ATT, a.to_out[0].weight, a.to_out[0].bias, a.to_add_out.weight, a.to_add_out.bias, 2)
+        ln(4, 3)
+        fi, ft = blk.img_mlp.net, blk.txt_mlp.net
+        ops.gemm_grouped([XNi, XNt], [fi[0].proj.weight, ft[0].proj.weight], [fi[0].proj.bias, ft[0].proj.bias],
+                         [FFH[s_txt:], FFH[:s_txt]], epilogue="gelu")
+        gated(FFH, fi[2].weight, fi[2].bias, ft[2].weight, ft[2].bias, 5)
+
     @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                 encoder_hidden_states_mask: torch.Tensor = None, timestep: torch.Tensor = None,
                 img_shapes=None, txt_seq_lens=None, guidance: torch.Tensor = None, attention_kwargs=None,
                 controlnet_block_samples=None, additional_t_cond=None, return_dict: bool = True):
-        if controlnet_block_samples is not None or additional_t_cond is not None:
-            raise NotImplementedError("qwenimage.mi355: controlnet / additional_t_cond are out of scope")
+        if controlnet_block_samples is not None:
+            raise NotImplementedError("qwenimage.mi355: controlnet residuals are out of scope")
+        if self.config.use_additional_t_cond and additional_t_cond is None:
+            raise ValueError("When additional_t_cond is True, addition_t_cond must be provided.")
+        # the per-clip modulation table holds ONE row per step (conditioning on t alone): the variants compute theirs per step
+        variant = bool(self.config.zero_cond_t or self.config.use_additional_t_cond)
         self.pack()
         B = hidden_states.shape[0]
         hs = hidden_states.to(self.storage_dtype)
@@ -391,7 +459,8 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
 
         def one(b):
             return self._forward_one(hs[b].contiguous(), enc[b].contiguous(), timestep[b:b + 1], shapes_of(b),
-                                     mod_row=self._sched_row(attention_kwargs, b, timestep[b:b + 1]))
+                                     mod_row=None if variant else self._sched_row(attention_kwargs, b, timestep[b:b + 1]),
+                                     addition_t_cond=additional_t_cond[b:b + 1] if self.config.use_additional_t_cond else None)
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda or any(shapes_of(b) != shapes_of(0) for b in range(1, B)):

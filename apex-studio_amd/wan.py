@@ -331,6 +331,11 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         self._sst = torch.stack([b.scale_shift_table.data.float().reshape(-1) for b in self.blocks]) \
             if len(self.blocks) else torch.empty(0, 6 * dim, device=dev)
         self._sst_out = self.scale_shift_table.data.float().reshape(-1).contiguous()
+        # patch_embedding as a GEMM needs K = C pt ph pw in multiples of 64: 64 for the 16-channel text-to-video experts; the
+        # image-to-video experts take 36 channels (K = 144) -> the weight gets zero columns up to 192 (exact zeros in the f32 sums)
+        w = self.patch_embedding.weight.data.reshape(dim, -1)
+        kp = (w.shape[1] + 63) // 64 * 64
+        self._pe_w = w if kp == w.shape[1] else torch.cat([w, w.new_zeros(dim, kp - w.shape[1])], dim=1).contiguous()
 
     def _workspace(self, S: int, s_txt: int):
         key = (S, s_txt)
@@ -391,7 +396,9 @@ class WanTransformer3DModel(LoraAdapterMixin, nn.Module):
         tok = hidden_states.to(self.storage_dtype).reshape(C, grid[0], pt, grid[1], ph, grid[2], pw) \
             .permute(1, 3, 5, 0, 2, 4, 6).reshape(S, C * pt * ph * pw).contiguous()
         pe = self.patch_embedding
-        ops.gemm(tok, pe.weight.reshape(dim, -1), pe.bias, out=X)
+        if self._pe_w.shape[1] != tok.shape[1]:
+            tok = torch.cat([tok, tok.new_zeros(S, self._pe_w.shape[1] - tok.shape[1])], dim=1)
+        ops.gemm(tok, self._pe_w, pe.bias, out=X)
 
         ce = self.condition_embedder
         tp = ops.timestep_embedding(timestep.float().reshape(1), cfg.freq_dim)

@@ -8,8 +8,9 @@ fp32 CPU restatement of the QwenImage MM-DiT forward (QwenImage-Edit-2509 uses t
   QwenTimestepProjEmbeddings               :154-184   (Timesteps scale=1000 on the engine's t/1000)
   apply_rotary_emb_qwen(use_real=False)    :100-151
 Leaves (Attention container, RMSNorm, FeedForward, AdaLayerNormContinuous, Timesteps, TimestepEmbedding)
-come from oracle.layers.  zero_cond_t / additional_t_cond / layer3d rope variants are not restated
-(off in the Edit-2509 configuration).  Pinned by tests/golden/qwen_hybrid.pt.
+come from oracle.layers.  `zero_cond_t` (a second conditioning row at t = 0 that modulates the CONDITION images' tokens:
+:692-702, :912-923, :980-981, `_modulate(index)` :640-677) and `use_additional_t_cond` (:164-182) are restated (round 6);
+the layer3d rope variant is not.  Pinned by tests/golden/qwen_hybrid.pt and qwen_variants.pt.
 """
 from __future__ import annotations
 
@@ -68,9 +69,16 @@ class QwenImageTransformerBlock(nn.Module):
         self.txt_mlp = L.FeedForward(dim, dim)
 
     @staticmethod
-    def _mod(x, p):
+    def _mod(x, p, index=None):
+        """`_modulate` (model.py:640-677).  index [B, L] (zero_cond_t): p holds 2 B rows — row b for tokens with index 0 (the
+        target image, conditioned on t), row B + b for tokens with index 1 (the condition images, conditioned on t = 0)."""
         shift, scale, gate = p.chunk(3, dim=-1)
-        return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1), gate.unsqueeze(1)
+        if index is None:
+            return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1), gate.unsqueeze(1)
+        B = shift.shape[0] // 2
+        sel = (index == 0).unsqueeze(-1)
+        pick = lambda v: torch.where(sel, v[:B].unsqueeze(1), v[B:].unsqueeze(1))      # noqa: E731
+        return x * (1 + pick(scale)) + pick(shift), pick(gate)
 
     def _attention(self, img, txt, rope, pol: Policy):
         a, H = self.attn, self.attn.heads
@@ -90,15 +98,17 @@ class QwenImageTransformerBlock(nn.Module):
     def _ff(ff, x, pol):
         return ff.net[2](pol.r(ff.net[0](x)))
 
-    def forward(self, img, txt, temb, rope, pol: Policy):
+    def forward(self, img, txt, temb, rope, pol: Policy, index=None):
         im1, im2 = self.img_mod(temb).chunk(2, dim=-1)
+        if index is not None:                  # zero_cond_t: the text stream sees the t rows only (model.py:692-693)
+            temb = temb.chunk(2, dim=0)[0]
         tm1, tm2 = self.txt_mod(temb).chunk(2, dim=-1)
-        im, ig1 = self._mod(self.img_norm1(img), im1)
+        im, ig1 = self._mod(self.img_norm1(img), im1, index)
         tm, tg1 = self._mod(self.txt_norm1(txt), tm1)
         ia, ta = self._attention(pol.r(im), pol.r(tm), rope, pol)
         img = pol.r(img + ig1 * ia)
         txt = pol.r(txt + tg1 * ta)
-        im, ig2 = self._mod(self.img_norm2(img), im2)
+        im, ig2 = self._mod(self.img_norm2(img), im2, index)
         img = pol.r(img + ig2 * self._ff(self.img_mlp, pol.r(im), pol))
         tm, tg2 = self._mod(self.txt_norm2(txt), tm2)
         txt = pol.r(txt + tg2 * self._ff(self.txt_mlp, pol.r(tm), pol))
@@ -106,25 +116,35 @@ class QwenImageTransformerBlock(nn.Module):
 
 
 class QwenTimestepProjEmbeddings(nn.Module):
-    def __init__(self, dim: int):
+    def __init__(self, dim: int, use_additional_t_cond: bool = False):
         super().__init__()
         self.time_proj = L.Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0, scale=1000)
         self.timestep_embedder = L.TimestepEmbedding(256, dim)
+        self.use_additional_t_cond = use_additional_t_cond
+        if use_additional_t_cond:
+            self.addition_t_embedding = nn.Embedding(2, dim)
 
-    def forward(self, timestep):
-        return self.timestep_embedder(self.time_proj(timestep))
+    def forward(self, timestep, addition_t_cond=None):
+        emb = self.timestep_embedder(self.time_proj(timestep))
+        if self.use_additional_t_cond:         # model.py:175-182
+            if addition_t_cond is None:
+                raise ValueError("When additional_t_cond is True, addition_t_cond must be provided.")
+            emb = emb + self.addition_t_embedding(addition_t_cond).to(emb.dtype)
+        return emb
 
 
 class QwenImageTransformer2DModel(nn.Module):
     def __init__(self, patch_size: int = 2, in_channels: int = 64, out_channels: Optional[int] = 16,
                  num_layers: int = 60, attention_head_dim: int = 128, num_attention_heads: int = 24,
                  joint_attention_dim: int = 3584, guidance_embeds: bool = False,
-                 axes_dims_rope: Tuple[int, int, int] = (16, 56, 56)):
+                 axes_dims_rope: Tuple[int, int, int] = (16, 56, 56), zero_cond_t: bool = False,
+                 use_additional_t_cond: bool = False):
         super().__init__()
         self.out_channels = out_channels or in_channels
         self.inner_dim = dim = num_attention_heads * attention_head_dim
         self.axes_dims_rope = tuple(axes_dims_rope)
-        self.time_text_embed = QwenTimestepProjEmbeddings(dim)
+        self.zero_cond_t = zero_cond_t
+        self.time_text_embed = QwenTimestepProjEmbeddings(dim, use_additional_t_cond)
         self.txt_norm = L.RMSNorm(joint_attention_dim, eps=1e-6)
         self.img_in = nn.Linear(in_channels, dim)
         self.txt_in = nn.Linear(joint_attention_dim, dim)
@@ -135,7 +155,7 @@ class QwenImageTransformer2DModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, timestep, img_shapes, txt_seq_lens=None,
-                policy: Policy = FP32):
+                policy: Policy = FP32, additional_t_cond=None):
         pol = policy
         shapes = img_shapes[0] if isinstance(img_shapes[0], (list, tuple)) and \
             isinstance(img_shapes[0][0], (list, tuple)) else img_shapes
@@ -143,10 +163,21 @@ class QwenImageTransformer2DModel(nn.Module):
         txt = pol.r(self.txt_in(pol.r(self.txt_norm(encoder_hidden_states))))
         # reference: `timestep = timestep.to(hidden_states.dtype)` (model.py:905) — bf16 with bf16 latents
         tdt = torch.bfloat16 if pol.emulate_bf16 else hidden_states.dtype
-        temb = self.time_text_embed(timestep.to(tdt).to(hidden_states.dtype))
+        timestep = timestep.to(tdt).to(hidden_states.dtype)
+        index = None
+        if self.zero_cond_t:                   # model.py:912-923: a second row at t = 0; tokens of images 1.. are marked 1
+            timestep = torch.cat([timestep, timestep * 0], dim=0)
+            per = [shapes] * hidden_states.shape[0] if not isinstance(img_shapes[0][0], (list, tuple)) else img_shapes
+            index = torch.tensor([[0] * (s[0][0] * s[0][1] * s[0][2]) + [1] * sum(a * b * c for a, b, c in s[1:]) for s in per],
+                                 dtype=torch.int)
+            if additional_t_cond is not None:
+                additional_t_cond = torch.cat([additional_t_cond, additional_t_cond], dim=0)
+        temb = self.time_text_embed(timestep, additional_t_cond)
         n_txt = encoder_hidden_states.shape[1]
         rope = qwen_rope_table(qwen_rope_positions(shapes, n_txt), self.axes_dims_rope)
         for blk in self.transformer_blocks:
-            txt, img = blk(img, txt, temb, rope, pol)
+            txt, img = blk(img, txt, temb, rope, pol, index)
+        if self.zero_cond_t:
+            temb = temb.chunk(2, dim=0)[0]
         img = pol.r(self.norm_out(img, temb))
         return pol.r(self.proj_out(img))

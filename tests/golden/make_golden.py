@@ -376,6 +376,37 @@ def gen_qwen_hybrid():
     print("qwen_hybrid.pt", tuple(out.shape), float(out.abs().mean()))
 
 
+def gen_qwen_variants():
+    """The reference QwenImageTransformer2DModel with `zero_cond_t` (a second conditioning row at t = 0 that modulates the tokens
+    of the condition images: transformer/qwenimage/base/model.py:640-677, :692-702, :912-923, :980-981) and
+    `use_additional_t_cond` (`addition_t_embedding`, :164-182), alone and together, on the edit layout (target + 2 condition
+    images) — pins oracle.qwenimage's restatement of both switches and, through it, `qwenimage.mi355`."""
+    import src.attention  # noqa: F401
+    from src.transformer.qwenimage.base.model import QwenImageTransformer2DModel as RefQwen
+    from oracle.qwenimage import QwenImageTransformer2DModel as OracleQwen
+    shapes = [[(1, 6, 8), (1, 4, 6), (1, 2, 4)]]
+    n_img = 6 * 8 + 4 * 6 + 2 * 4
+    inp = dict(hidden_states=seeded((1, n_img, 64), 53), encoder_hidden_states=seeded((1, 13, 64), 54),
+               timestep=torch.tensor([0.625]), img_shapes=shapes, txt_seq_lens=[13])
+    out = {}
+    for name, kw, atc in (("zero_cond_t", dict(zero_cond_t=True), None),
+                          ("additional_t_cond", dict(use_additional_t_cond=True), torch.tensor([1])),
+                          ("both", dict(zero_cond_t=True, use_additional_t_cond=True), torch.tensor([1]))):
+        cfg = dict(TINY_QWEN, **kw)
+        ref = RefQwen(**cfg).eval()
+        sd = synthetic_state_dict(OracleQwen(**cfg), 12)
+        assert sorted(sd.keys()) == sorted(ref.state_dict().keys()), set(sd) ^ set(ref.state_dict())
+        ref.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            y = ref(hidden_states=inp["hidden_states"], encoder_hidden_states=inp["encoder_hidden_states"],
+                    encoder_hidden_states_mask=torch.ones(1, 13), timestep=inp["timestep"], img_shapes=shapes, txt_seq_lens=[13],
+                    additional_t_cond=atc, return_dict=False)[0]
+        out[name] = dict(config=cfg, additional_t_cond=atc, out=y, keys=sorted(sd.keys()))
+    assert float((out["both"]["out"] - out["zero_cond_t"]["out"]).abs().max()) > 1e-3
+    torch.save(dict(seed=12, inputs=inp, cases=out), os.path.join(OUT, "qwen_variants.pt"))
+    print("qwen_variants.pt", {k: float(v["out"].abs().mean()) for k, v in out.items()})
+
+
 TINY_VAE = dict(base_dim=32, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=1,
                 temperal_downsample=[False, True, True])
 
@@ -1370,11 +1401,11 @@ def gen_leaf_pins2():
 
 
 # Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
-FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "hunyuan15_hybrid", "hunyuan15_meanflow",
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "hunyuan15_hybrid", "hunyuan15_meanflow",
             "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
             "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
 # the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
-FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
         "convert"]
 
 

@@ -836,6 +836,23 @@ def test_qwen_f32_storage_vs_reference_run_golden(golden_dir):
     _golden_report("qwen-image edit (2 blocks, two images)", out.cpu(), g["out"])
 
 
+@pytest.mark.parametrize("case", ["zero_cond_t", "additional_t_cond", "both"])
+def test_qwen_variants_f32_storage_vs_reference_run_golden(golden_dir, case):
+    """`qwen_variants.pt`: the reference class with `zero_cond_t` / `use_additional_t_cond` (target + two condition images)."""
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    g = _golden(golden_dir, "qwen_variants.pt")
+    c, i = g["cases"][case], g["inputs"]
+    sd = synthetic_state_dict(OQ.QwenImageTransformer2DModel(**c["config"]), g["seed"])
+    m = QwenImageTransformer2DModel(**c["config"], device=DEV, dtype=BF).set_storage_dtype(F32)
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    s_txt = i["txt_seq_lens"][0]
+    atc = None if c["additional_t_cond"] is None else c["additional_t_cond"].to(DEV)
+    out = m(hidden_states=i["hidden_states"].to(DEV), encoder_hidden_states=i["encoder_hidden_states"].to(DEV),
+            encoder_hidden_states_mask=torch.ones(1, s_txt, device=DEV), timestep=i["timestep"].to(DEV),
+            img_shapes=i["img_shapes"], txt_seq_lens=[s_txt], additional_t_cond=atc, return_dict=False)[0]
+    _golden_report(f"qwen-image {case} (2 blocks, three images)", out.cpu(), c["out"])
+
+
 def test_hunyuan15_f32_storage_vs_reference_run_golden(golden_dir):
     """`hunyuan15_hybrid.pt`: the reference's HunyuanVideo-1.5 classes run in float64, t2v and i2v token orders."""
     from oracle import hunyuan15 as OH

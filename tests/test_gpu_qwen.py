@@ -125,6 +125,39 @@ def test_qwen_matches_reference_wiring_golden(golden_dir):
     measured("qwen_hybrid.bf16_vs_reference_run", rel, 9e-3)       # measured 4.5e-3 (round 6)
 
 
+@pytest.mark.parametrize("case", ["zero_cond_t", "additional_t_cond", "both"])
+def test_qwen_variants_match_reference_run_and_oracle(golden_dir, case):
+    """`zero_cond_t` (condition-image tokens modulated by a second conditioning row at t = 0) and `use_additional_t_cond`: the HIP
+    model in production bf16 against the reference run (qwen_variants.pt) and, like for like, against the oracle's bf16-storage
+    policy; a config with the switch and a call without `additional_t_cond` raises as the reference does."""
+    g = torch.load(os.path.join(golden_dir, "qwen_variants.pt"), weights_only=False)
+    c, inp = g["cases"][case], g["inputs"]
+    cfg = c["config"]
+    orc = OQ.QwenImageTransformer2DModel(**cfg).eval()
+    sd = synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    from apex_studio_amd.qwenimage import QwenImageTransformer2DModel
+    m = QwenImageTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    assert sorted(m.state_dict().keys()) == c["keys"]
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    x, txt = inp["hidden_states"].to(torch.bfloat16), inp["encoder_hidden_states"].to(torch.bfloat16)
+    atc = c["additional_t_cond"]
+    kw = dict(hidden_states=x.to(DEV), encoder_hidden_states=txt.to(DEV), encoder_hidden_states_mask=torch.ones(1, 13, device=DEV),
+              timestep=inp["timestep"].to(DEV), img_shapes=inp["img_shapes"], txt_seq_lens=[13], return_dict=False)
+    out = m(additional_t_cond=None if atc is None else atc.to(DEV), **kw)[0].float().cpu()
+    assert torch.equal(out, m(additional_t_cond=None if atc is None else atc.to(DEV), **kw)[0].float().cpu())
+    ref16 = orc(x.float(), txt.float(), inp["timestep"], inp["img_shapes"], policy=OL.BF16_STORAGE, additional_t_cond=atc)
+    e_like = _rel(out, ref16)
+    e_gold = measured(f"qwen_variants.{case}.bf16_vs_reference_run", _rel(out, c["out"]), 1.2e-2)
+    print(f"[qwen {case}] hip vs bf16-storage oracle {e_like:.3e}; vs the reference run {e_gold:.3e}")
+    assert e_like < 6e-3, e_like
+    if atc is not None:
+        with pytest.raises(ValueError):
+            m(**kw)
+        other = m(additional_t_cond=(1 - atc).to(DEV), **kw)[0].float().cpu()
+        assert _rel(other, out) > 1e-3, "the embedding row must matter"
+
+
 def test_qwen_full_width_one_block_matches_oracle(host_threads):
     """QwenImage-Edit-2509 geometry (d 3072 = 24 x 128, text 3584, target 64x64 + one 64x64 condition image, 256 text
     tokens: S 8448) with ONE block against the fp32 CPU oracle (about a minute on the host cores)."""

@@ -416,3 +416,18 @@ def test_easycache_restatement_matches_the_reference_function(golden_dir):
             x = x - g["dt"] * (pair[1] + g["guidance"] * (pair[0] - pair[1]))
     assert computed == g["computed"] and not all(computed), "".join("C" if c else "-" for c in computed)
     assert float((x.float() - g["x_final"]).norm() / g["x_final"].norm()) < 5e-5
+
+
+@pytest.mark.parametrize("case", ["zero_cond_t", "additional_t_cond", "both"])
+def test_oracle_qwen_variants_match_the_reference_run(golden_dir, case):
+    """oracle.qwenimage with `zero_cond_t` / `use_additional_t_cond` against the reference class run here (qwen_variants.pt)."""
+    from oracle.qwenimage import QwenImageTransformer2DModel
+    g = torch.load(os.path.join(golden_dir, "qwen_variants.pt"), weights_only=False)
+    c, inp = g["cases"][case], g["inputs"]
+    m = QwenImageTransformer2DModel(**c["config"]).eval()
+    sd = synthetic_state_dict(m, g["seed"])
+    assert sorted(sd.keys()) == c["keys"]
+    m.load_state_dict(sd, strict=True)
+    out = m(inp["hidden_states"], inp["encoder_hidden_states"], inp["timestep"], inp["img_shapes"], additional_t_cond=c["additional_t_cond"])
+    rel = float((out - c["out"]).norm() / c["out"].norm())
+    assert rel < 1e-5, rel
