@@ -85,6 +85,7 @@ class _Attn(nn.Module):
         super().__init__()
         inner = heads * head_dim
         self.heads, self.head_dim = heads, head_dim
+        self.processor = None          # an _IPAdapterProcessor on the double blocks once IP adapters are loaded
         self.norm_q, self.norm_k = _Norm(head_dim, **kw), _Norm(head_dim, **kw)
         self.to_q, self.to_k, self.to_v = (_Linear(dim, inner, **kw), _Linear(dim, inner, **kw),
                                            _Linear(dim, inner, **kw))
@@ -95,6 +96,66 @@ class _Attn(nn.Module):
             self.add_q_proj, self.add_k_proj, self.add_v_proj = (
                 _Linear(dim, inner, **kw), _Linear(dim, inner, **kw), _Linear(dim, inner, **kw))
             self.to_add_out = _Linear(inner, dim, **kw)
+
+
+class _IPAdapterProcessor(nn.Module):
+    """Parameters of `FluxIPAdapterAttnProcessor` (R/src/transformer/flux/base/attention.py:115-173) on a double block's attention:
+    per adapter one key and one value projection of the image-prompt tokens (`...attn.processor.to_k_ip.M.weight`) and a scale."""
+
+    def __init__(self, hidden_size: int, cross_attention_dim: int, num_tokens=(4,), scale=1.0, **kw):
+        super().__init__()
+        num_tokens = list(num_tokens) if isinstance(num_tokens, (tuple, list)) else [num_tokens]
+        self.scale = list(scale) if isinstance(scale, (list, tuple)) else [float(scale)] * len(num_tokens)
+        if len(self.scale) != len(num_tokens):
+            raise ValueError("`scale` should be a list with the same length as `num_tokens`.")
+        self.to_k_ip = nn.ModuleList([_Linear(cross_attention_dim, hidden_size, **kw) for _ in num_tokens])
+        self.to_v_ip = nn.ModuleList([_Linear(cross_attention_dim, hidden_size, **kw) for _ in num_tokens])
+
+
+class _ImageProjection(nn.Module):
+    """diffusers `ImageProjection` (what `_load_ip_adapter_weights` builds for the Flux IP-adapter; the class is diffusers' and
+    absent from this image — restated from its definition, parity unpinned): Linear(image_embed_dim -> tokens x cross_attention_dim),
+    reshape to [B, tokens, cross_attention_dim], LayerNorm(cross_attention_dim, eps 1e-5)."""
+
+    def __init__(self, image_embed_dim: int, cross_attention_dim: int, num_image_text_embeds: int, **kw):
+        super().__init__()
+        self.num_image_text_embeds, self.cross_attention_dim = num_image_text_embeds, cross_attention_dim
+        self.image_embeds = _Linear(image_embed_dim, num_image_text_embeds * cross_attention_dim, **kw)
+        self.norm = nn.LayerNorm(cross_attention_dim, **kw)
+
+    def forward(self, image_embeds: torch.Tensor) -> torch.Tensor:
+        B = image_embeds.shape[0]
+        x = image_embeds.reshape(B, -1).to(self.image_embeds.weight.dtype).contiguous()
+        y = ops.gemm(x, self.image_embeds.weight, self.image_embeds.bias).reshape(B * self.num_image_text_embeds, -1)
+        y = ops.ln_modulate(y, gamma=self.norm.weight, beta=self.norm.bias, eps=self.norm.eps)
+        return y.reshape(B, self.num_image_text_embeds, self.cross_attention_dim)
+
+
+class _MultiIPAdapterImageProjection(nn.Module):
+    """diffusers `MultiIPAdapterImageProjection` (the model's `encoder_hid_proj` once IP adapters are loaded; engines read its
+    `num_ip_adapters`, R/src/engine/flux/shared.py:84-96): one `ImageProjection` per adapter; each entry of the input list is
+    [B, num_images, image_embed_dim] (or [B, image_embed_dim]) -> [B, num_images x tokens, cross_attention_dim]."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.image_projection_layers = nn.ModuleList(layers)
+
+    @property
+    def num_ip_adapters(self) -> int:
+        return len(self.image_projection_layers)
+
+    def forward(self, image_embeds):
+        if not isinstance(image_embeds, (list, tuple)):
+            image_embeds = [image_embeds.unsqueeze(1)]
+        if len(image_embeds) != len(self.image_projection_layers):
+            raise ValueError(f"image_embeds must have the same length as image_projection_layers, got {len(image_embeds)} and "
+                             f"{len(self.image_projection_layers)}")
+        out = []
+        for e, layer in zip(image_embeds, self.image_projection_layers):
+            e = e if e.dim() == 3 else e.unsqueeze(1)
+            B, n = e.shape[0], e.shape[1]
+            out.append(layer(e.reshape(B * n, -1)).reshape(B, n * layer.num_image_text_embeds, -1))
+        return out
 
 
 class _DoubleBlock(nn.Module):
@@ -471,7 +532,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
 
     @torch.no_grad()
     def _forward_one(self, hidden_states, encoder_hidden_states, pooled, timestep, img_ids, txt_ids,
-                     guidance, mod_row=None, cn_d=None, cn_s=None):
+                     guidance, mod_row=None, cn_d=None, cn_s=None, ip=None):
         cfg = self.config
         dim, H = self.inner_dim, cfg.num_attention_heads
         s_img, s_txt = hidden_states.shape[0], encoder_hidden_states.shape[0]
@@ -502,7 +563,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         # the [S, 3 dim] projection as a storage point (tests/stage_parity.py reads it)
         mixed = self.storage_dtype == torch.float32 and ops.shipped_verification()
         fuse = self.fuse_qkv and (self.storage_dtype == torch.bfloat16 or mixed) and self.transformer_blocks is not None
-        fuse_d = fuse and len(self.transformer_blocks) > 0 and ops.qkv_fusable(
+        # IP-adapter: the image queries are needed normalised but NOT rotated (attention.py:199) -> the two-pass q/k/v preparation
+        fuse_d = fuse and ip is None and len(self.transformer_blocks) > 0 and ops.qkv_fusable(
             [XNi, XNt], [self.transformer_blocks[0]._wqkv, self.transformer_blocks[0]._wqkv_c], [s_txt, 0], H)
         fuse_s = fuse and len(self.single_transformer_blocks) > 0 and ops.qkv_fusable(
             [XN, XN], [self.single_transformer_blocks[0]._wqkv, self.single_transformer_blocks[0].proj_mlp.weight], [0, 0], H)
@@ -541,6 +603,10 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 ops.qkv_prepare(q_in, k_in, v_in, H, Qp[0], Kp[0], VT[0], wq=a.norm_q.weight,
                                 wk=a.norm_k.weight, wq2=a.norm_added_q.weight, wk2=a.norm_added_k.weight,
                                 split=s_txt, eps=1e-6, rope=rope, rope_mode=_l.ROPE_INTERLEAVED)
+            if ip is not None:
+                if getattr(ws, "IPQ", None) is None:
+                    ws.IPQ = torch.empty(1, H, s_img, 128, device=X.device, dtype=self.storage_dtype)
+                ops.qkv_prepare(q_in[s_txt:], None, None, H, ws.IPQ[0], None, None, wq=a.norm_q.weight, eps=1e-6)
             ops.attention_prepared(Qp, Kp, VT, att_v, S)
             ops.gemm_grouped([att[s_txt:], att[:s_txt]], [a.to_out[0].weight, a.to_add_out.weight],
                              [a.to_out[0].bias, a.to_add_out.bias], [Xi, Xt], epilogue="gate_res",
@@ -553,6 +619,19 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             ops.gemm_grouped([FFH[s_txt:], FFH[:s_txt]], [ff[2].weight, ffc[2].weight],
                              [ff[2].bias, ffc[2].bias], [Xi, Xt], epilogue="gate_res",
                              gate_list=[mi(5), mt(5)], residual_list=[Xi, Xt])
+            if ip is not None:
+                # `hidden_states + ip_attn_output` AFTER the feed-forward (model.py:308-309); ip_attn_output = sum over adapters of
+                # scale x attention(image queries, to_k_ip(tokens), to_v_ip(tokens)) (attention.py:232-262): a few keys per adapter
+                proc = a.processor
+                for h_ip, sc, wk, wv in zip(ip, proc.scale, proc.to_k_ip, proc.to_v_ip):
+                    n = h_ip.shape[0]
+                    ik = ops.gemm(h_ip, wk.weight, wk.bias).view(1, n, H, 128).permute(0, 2, 1, 3)
+                    iv = ops.gemm(h_ip, wv.weight, wv.bias).view(1, n, H, 128).permute(0, 2, 1, 3)
+                    o = ops.attention(ws.IPQ, ik, iv).permute(0, 2, 1, 3).reshape(s_img, dim)
+                    if self.storage_dtype == torch.bfloat16:
+                        ops.euler_step(Xi, o, float(sc), out=Xi)      # x + scale x o in f32, one rounding
+                    else:
+                        Xi.add_(o, alpha=float(sc))                    # float-storage verification mode
             if cn_d is not None:
                 ops.add(Xi, cn_d[i], out=Xi)
 
@@ -603,6 +682,61 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
         ops.gemm(XNi, self.proj_out.weight, self.proj_out.bias, out=out)
         return out
 
+    # ---- IP-adapter (optional; off in every BASELINE config) ---------------------------------------------------------------
+    @torch.no_grad()
+    def load_ip_adapter_weights(self, state_dicts, scale=1.0):
+        """diffusers `FluxTransformer2DLoadersMixin._load_ip_adapter_weights(state_dicts)` for already-converted adapter files:
+        each state dict = {"image_proj": {"proj.weight", "proj.bias", "norm.weight", "norm.bias"}, "ip_adapter": {"<block>.to_k_ip.
+        weight", "<block>.to_k_ip.bias", "<block>.to_v_ip.weight", "<block>.to_v_ip.bias"}} (block = double-block index).  Builds
+        `encoder_hid_proj` and one `attn.processor` per double block; several adapters stack (one projection + one k / v pair each)."""
+        if not isinstance(state_dicts, (list, tuple)):
+            state_dicts = [state_dicts]
+        kw = dict(device=self.device, dtype=self.dtype)
+        dim, ctx = self.inner_dim, self.config.joint_attention_dim
+        layers, tokens = [], []
+        for sd in state_dicts:
+            pw = sd["image_proj"]["proj.weight"]
+            n_tok = pw.shape[0] // ctx
+            lay = _ImageProjection(pw.shape[1], ctx, n_tok, **kw)
+            lay.image_embeds.weight.data.copy_(pw)
+            lay.image_embeds.bias.data.copy_(sd["image_proj"]["proj.bias"])
+            lay.norm.weight.data.copy_(sd["image_proj"]["norm.weight"])
+            lay.norm.bias.data.copy_(sd["image_proj"]["norm.bias"])
+            layers.append(lay)
+            tokens.append(n_tok)
+        self.encoder_hid_proj = _MultiIPAdapterImageProjection(layers)
+        for i, blk in enumerate(self.transformer_blocks):
+            proc = _IPAdapterProcessor(dim, ctx, tokens, scale, **kw)
+            for j, sd in enumerate(state_dicts):
+                for name in ("to_k_ip", "to_v_ip"):
+                    lin = getattr(proc, name)[j]
+                    lin.weight.data.copy_(sd["ip_adapter"][f"{i}.{name}.weight"])
+                    lin.bias.data.copy_(sd["ip_adapter"][f"{i}.{name}.bias"])
+            blk.attn.processor = proc
+        return self
+
+    def set_ip_adapter(self, num_tokens=(4,), scale=1.0):
+        """Empty IP-adapter processors on every double block (their weights then arrive with `load_state_dict`: keys
+        `transformer_blocks.N.attn.processor.to_k_ip.M.weight`, as a diffusers model with adapters saves them)."""
+        kw = dict(device=self.device, dtype=self.dtype)
+        for blk in self.transformer_blocks:
+            blk.attn.processor = _IPAdapterProcessor(self.inner_dim, self.config.joint_attention_dim, num_tokens, scale, **kw)
+        return self
+
+    def set_ip_adapter_scale(self, scale):
+        for blk in self.transformer_blocks:
+            p = blk.attn.processor
+            if p is not None:
+                p.scale = list(scale) if isinstance(scale, (list, tuple)) else [float(scale)] * len(p.to_k_ip)
+        return self
+
+    def unload_ip_adapter(self):
+        for blk in self.transformer_blocks:
+            blk.attn.processor = None
+        if hasattr(self, "encoder_hid_proj"):
+            del self.encoder_hid_proj
+        return self
+
     @ops.on_model_device
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
@@ -626,8 +760,24 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             return [ss[j] for j in idx]
         cn_d = _cn(controlnet_block_samples, len(self.transformer_blocks), controlnet_blocks_repeat)
         cn_s = _cn(controlnet_single_block_samples, len(self.single_transformer_blocks), False)
-        if joint_attention_kwargs and "ip_adapter_image_embeds" in joint_attention_kwargs:
-            raise NotImplementedError("flux.mi355: IP-adapter is outside the hot-path scope")
+        # IP-adapter inputs (model.py:562-571): image embeddings through `encoder_hid_proj`, or the projected tokens directly
+        ip = None
+        if joint_attention_kwargs and ("ip_adapter_image_embeds" in joint_attention_kwargs or "ip_hidden_states" in joint_attention_kwargs):
+            if any(blk.attn.processor is None for blk in self.transformer_blocks) or not len(self.transformer_blocks):
+                raise _l.ApexMIError("flux.mi355: IP-adapter inputs were passed but no adapter is loaded (load_ip_adapter_weights / "
+                                     "set_ip_adapter)")
+            if "ip_adapter_image_embeds" in joint_attention_kwargs:
+                if not hasattr(self, "encoder_hid_proj"):
+                    raise _l.ApexMIError("flux.mi355: `ip_adapter_image_embeds` needs `encoder_hid_proj` (load_ip_adapter_weights)")
+                emb = joint_attention_kwargs["ip_adapter_image_embeds"]
+                emb = [e.to(self.device) for e in emb] if isinstance(emb, (list, tuple)) else emb.to(self.device)
+                ip = self.encoder_hid_proj(emb)
+            else:
+                ip = list(joint_attention_kwargs["ip_hidden_states"])
+            n_ad = len(self.transformer_blocks[0].attn.processor.to_k_ip)
+            if len(ip) != n_ad:
+                raise ValueError(f"{len(ip)} image-prompt tensors for {n_ad} IP adapters")
+            ip = [t.to(self.device, self.storage_dtype) for t in ip]
         self.pack()
         if txt_ids.ndim == 3:
             txt_ids = txt_ids[0]
@@ -642,7 +792,8 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
                 img_ids, txt_ids, None if guidance is None else guidance[b:b + 1],
                 mod_row=self._sched_row(pooled_projections, joint_attention_kwargs, b, timestep[b:b + 1],
                                         None if guidance is None else guidance[b:b + 1]),
-                cn_d=None if cn_d is None else [t[b] for t in cn_d], cn_s=None if cn_s is None else [t[b] for t in cn_s])
+                cn_d=None if cn_d is None else [t[b] for t in cn_d], cn_s=None if cn_s is None else [t[b] for t in cn_s],
+                ip=None if ip is None else [t[b if t.shape[0] > 1 else 0].contiguous() for t in ip])
 
         ns = min(int(self.batch_streams), B)
         if ns <= 1 or not hs.is_cuda:

@@ -23,9 +23,24 @@ from . import layers as L
 from .layers import Policy, FP32
 
 
+class FluxIPAdapterProcessor(nn.Module):
+    """The parameters of `FluxIPAdapterAttnProcessor` (reference transformer/flux/base/attention.py:115-173): one key and one value
+    projection of the image-prompt tokens per adapter, and a scale each.  State-dict keys as diffusers names them:
+    `transformer_blocks.N.attn.processor.to_k_ip.M.weight`."""
+
+    def __init__(self, hidden_size: int, cross_attention_dim: int, num_tokens=(4,), scale=1.0):
+        super().__init__()
+        num_tokens = list(num_tokens) if isinstance(num_tokens, (tuple, list)) else [num_tokens]
+        self.scale = list(scale) if isinstance(scale, (list, tuple)) else [scale] * len(num_tokens)
+        assert len(self.scale) == len(num_tokens)
+        self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size) for _ in num_tokens])
+        self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size) for _ in num_tokens])
+
+
 class FluxAttention(nn.Module):
     def __init__(self, dim: int, heads: int, head_dim: int, joint: bool, pre_only: bool, eps: float = 1e-6):
         super().__init__()
+        self.processor = None          # a FluxIPAdapterProcessor on the double blocks of a model with IP adapters
         self.heads, self.head_dim, self.joint = heads, head_dim, joint
         inner = heads * head_dim
         self.norm_q = nn.RMSNorm(head_dim, eps=eps)
@@ -43,12 +58,13 @@ class FluxAttention(nn.Module):
             self.add_v_proj = nn.Linear(dim, inner)
             self.to_add_out = nn.Linear(inner, dim)
 
-    def forward(self, x, ctx, rope, pol: Policy):
+    def forward(self, x, ctx, rope, pol: Policy, ip_hidden_states=None):
         H = self.heads
         q = pol.r(self.to_q(x)).unflatten(-1, (H, -1))
         k = pol.r(self.to_k(x)).unflatten(-1, (H, -1))
         v = pol.r(self.to_v(x)).unflatten(-1, (H, -1))
         q, k = self.norm_q(q), self.norm_k(k)
+        ip_q = pol.r(q)                # the image stream's normalised query BEFORE the rotary embedding (attention.py:199)
         if ctx is not None:
             cq = pol.r(self.add_q_proj(ctx)).unflatten(-1, (H, -1))
             ck = pol.r(self.add_k_proj(ctx)).unflatten(-1, (H, -1))
@@ -66,6 +82,18 @@ class FluxAttention(nn.Module):
         if ctx is not None:
             n_txt = ctx.shape[1]
             co, o = o[:, :n_txt], o[:, n_txt:]
+            if ip_hidden_states is not None and self.processor is not None:
+                # IP-adapter (attention.py:232-262): per adapter, attention of the image queries over the projected image-prompt
+                # tokens (no norm, no rotary embedding on those keys); returned per adapter with its scale — the block adds
+                # scale x output to the image stream AFTER its feed-forward (model.py:308-309)
+                B = x.shape[0]
+                ips = []
+                for h_ip, sc, wk, wv in zip(ip_hidden_states, self.processor.scale, self.processor.to_k_ip, self.processor.to_v_ip):
+                    ik = pol.r(wk(h_ip)).view(B, -1, H, self.head_dim)
+                    iv = pol.r(wv(h_ip)).view(B, -1, H, self.head_dim)
+                    io = L.sdpa(ip_q.permute(0, 2, 1, 3), ik.permute(0, 2, 1, 3), iv.permute(0, 2, 1, 3), policy=pol)
+                    ips.append((sc, pol.r(io.permute(0, 2, 1, 3).reshape(B, -1, H * self.head_dim))))
+                return self.to_out[0](o), self.to_add_out(co), ips
             return self.to_out[0](o), self.to_add_out(co)
         return o
 
@@ -86,13 +114,22 @@ class FluxTransformerBlock(nn.Module):
         h = pol.r(ff.net[0](x))
         return ff.net[2](h)
 
-    def forward(self, x, ctx, temb, rope, pol: Policy):
+    def forward(self, x, ctx, temb, rope, pol: Policy, ip_hidden_states=None):
         nx, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(x, temb)
         nc, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(ctx, temb)
-        a, ca = self.attn(pol.r(nx), pol.r(nc), rope, pol)
+        outs = self.attn(pol.r(nx), pol.r(nc), rope, pol, ip_hidden_states)
+        a, ca = outs[0], outs[1]
         x = pol.r(x + gate_msa.unsqueeze(1) * a)
         n2 = pol.r(self.norm2(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None])
         x = pol.r(x + gate_mlp.unsqueeze(1) * self._ff(self.ff, n2, pol))
+        if len(outs) == 3:
+            # `hidden_states = hidden_states + ip_attn_output` (model.py:308-309), ip_attn_output = sum of scale x adapter output.
+            # Storage policy: the HIP path adds adapter after adapter into the stream (f32 multiply-add, one rounding each)
+            if pol.emulate_bf16:
+                for sc, o in outs[2]:
+                    x = pol.r(x + sc * o)
+            else:
+                x = x + sum(sc * o for sc, o in outs[2])
         ctx = pol.r(ctx + c_gate_msa.unsqueeze(1) * ca)
         c2 = pol.r(self.norm2_context(ctx) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None])
         ctx = pol.r(ctx + c_gate_mlp.unsqueeze(1) * self._ff(self.ff_context, c2, pol))
@@ -157,8 +194,13 @@ class FluxTransformer2DModel(nn.Module):
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids,
                 txt_ids, guidance=None, policy: Policy = FP32, controlnet_block_samples=None,
-                controlnet_single_block_samples=None, controlnet_blocks_repeat: bool = False):
+                controlnet_single_block_samples=None, controlnet_blocks_repeat: bool = False, ip_hidden_states=None):
+        """`ip_hidden_states`: the IP-adapter image-prompt tokens, one [B, tokens, joint_attention_dim] tensor per adapter — what
+        `encoder_hid_proj(ip_adapter_image_embeds)` yields in the reference (model.py:562-571); the double blocks must carry a
+        FluxIPAdapterProcessor (`attn.processor`)."""
         pol = policy
+        if ip_hidden_states is not None:
+            ip_hidden_states = [pol.r(h) for h in ip_hidden_states]
         x = pol.r(self.x_embedder(hidden_states))
         # reference: `timestep.to(hidden_states.dtype) * 1000` (model.py:535-537) — with bf16 hidden
         # states that product is rounded to bf16 (SURVEY.md App. B-3); the bf16 policy reproduces it.
@@ -175,7 +217,7 @@ class FluxTransformer2DModel(nn.Module):
         # block // ceil(blocks / samples), or block % samples with `controlnet_blocks_repeat` (double blocks only)
         import math
         for i, blk in enumerate(self.transformer_blocks):
-            ctx, x = blk(x, ctx, temb, rope, pol)
+            ctx, x = blk(x, ctx, temb, rope, pol, ip_hidden_states)
             if controlnet_block_samples is not None:
                 n = len(controlnet_block_samples)
                 j = i % n if controlnet_blocks_repeat else i // int(math.ceil(len(self.transformer_blocks) / n))

@@ -279,6 +279,44 @@ def gen_flux_controlnet():
     print("flux_controlnet.pt", {k: float(v.abs().mean()) for k, v in outs.items()})
 
 
+def gen_flux_ip_adapter():
+    """The reference FluxTransformer2DModel whose double blocks run `FluxIPAdapterAttnProcessor` (transformer/flux/base/
+    attention.py:115-265; the block adds its third output to the image stream after the feed-forward, model.py:291-309), fed the
+    image-prompt tokens directly as `joint_attention_kwargs={"ip_hidden_states": [...]}` (what `encoder_hid_proj` would hand it,
+    model.py:562-571 — that projection class is diffusers' and absent here): one adapter, and two adapters with different scales."""
+    from src.transformer.flux.base.model import FluxTransformer2DModel as RefFlux
+    from src.transformer.flux.base.attention import FluxIPAdapterAttnProcessor
+    from oracle.flux import FluxTransformer2DModel as OracleFlux, FluxIPAdapterProcessor
+    cfg = dict(TINY_FLUX)
+    dim, ctx_dim = cfg["num_attention_heads"] * cfg["attention_head_dim"], cfg["joint_attention_dim"]
+    inp = tiny_flux_inputs()
+    cases = {}
+    for name, num_tokens, scale in (("one", (4,), 0.7), ("two", (4, 6), [0.7, 0.35])):
+        orc = OracleFlux(**cfg).eval()
+        for blk in orc.transformer_blocks:
+            blk.attn.processor = FluxIPAdapterProcessor(dim, ctx_dim, num_tokens, scale)
+        sd = synthetic_state_dict(orc, 21)
+        ref = RefFlux(**cfg).eval()
+        for blk in ref.transformer_blocks:
+            blk.attn.processor = FluxIPAdapterAttnProcessor(hidden_size=dim, cross_attention_dim=ctx_dim, num_tokens=num_tokens, scale=scale)
+        miss = ref.load_state_dict(sd, strict=False)
+        ip_keys = [k for k in sd if ".processor." in k]
+        assert not miss.unexpected_keys and len(ip_keys) == 4 * len(num_tokens) * cfg["num_layers"], (miss, ip_keys)
+        # `processor` is a plain attribute of the reference attention module when set this way: load its parameters explicitly
+        for i, blk in enumerate(ref.transformer_blocks):
+            blk.attn.processor.load_state_dict({k.split(".processor.")[1]: v for k, v in sd.items()
+                                                if k.startswith(f"transformer_blocks.{i}.attn.processor.")}, strict=True)
+        ips = [seeded((1, n, ctx_dim), 90 + j) for j, n in enumerate(num_tokens)]
+        with torch.no_grad():
+            out = ref(return_dict=False, joint_attention_kwargs={"ip_hidden_states": ips}, **dict(inp))[0]
+            plain = ref(return_dict=False, joint_attention_kwargs={"ip_hidden_states": [torch.zeros_like(t) for t in ips]}, **dict(inp))[0]
+        assert float((out - plain).abs().max()) > 1e-3
+        cases[name] = dict(num_tokens=num_tokens, scale=scale, ip_seeds=[90 + j for j in range(len(num_tokens))], out=out,
+                           keys=sorted(sd.keys()))
+    torch.save(dict(config=cfg, seed=21, inputs=inp, cases=cases), os.path.join(OUT, "flux_ip_adapter.pt"))
+    print("flux_ip_adapter.pt", {k: float(v["out"].abs().mean()) for k, v in cases.items()})
+
+
 TINY_WAN = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=16,
                 out_channels=16, text_dim=64, freq_dim=256, ffn_dim=512, num_layers=2, cross_attn_norm=True,
                 eps=1e-6)
@@ -1401,11 +1439,11 @@ def gen_leaf_pins2():
 
 
 # Every fixture this script owns, in generation order (one generator each; a generator may write more than one file).
-FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "hunyuan15_hybrid", "hunyuan15_meanflow",
+FIXTURES = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "flux_ip_adapter", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "hunyuan15_hybrid", "hunyuan15_meanflow",
             "vae_wan", "vae_wan_encode", "vae_hunyuan15", "vae_hunyuan15_encode", "vae_taehv", "vae_taehv_encode", "unipc", "lora",
             "fp_scaled", "text_encoders", "qwen2_5_vl", "leaf_pins", "leaf_pins2", "convert"]
 # the generators that finish in seconds: `--check fast` (tests/test_oracle_golden.py runs it where /root/reference exists)
-FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
+FAST = ["attention", "efficiency", "flux_hybrid", "flux_controlnet", "flux_ip_adapter", "wan_hybrid", "wan_easycache", "wan_i2v", "qwen_hybrid", "qwen_variants", "unipc", "lora", "fp_scaled", "leaf_pins", "leaf_pins2",
         "convert"]
 
 

@@ -433,3 +433,89 @@ def test_controlnet_residual_inputs_match_the_reference_run(golden_dir):
     plain = m(return_dict=False, **gin)[0].float().cpu()
     measured("flux_controlnet.none.bf16_vs_reference_run", _rel(plain, g["out"]["none"]), 1.2e-2)   # measured 6.1e-3
     assert _rel(plain, out) > 1e-3
+
+
+@pytest.mark.parametrize("case", ["one", "two"])
+def test_flux_ip_adapter_matches_reference_run_and_oracle(golden_dir, case):
+    """Flux IP-adapter (R/src/transformer/flux/base/attention.py:115-265, model.py:291-309, :562-571): the HIP model with
+    `attn.processor` parameters on its double blocks, fed the image-prompt tokens, against the reference model run with its
+    FluxIPAdapterAttnProcessor (flux_ip_adapter.pt) — production bf16 (and like for like against the oracle's bf16-storage policy),
+    and the float-storage verification mode at the 1e-4 bar."""
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    from oracle.flux import FluxIPAdapterProcessor
+    g = torch.load(os.path.join(golden_dir, "flux_ip_adapter.pt"), weights_only=False)
+    cfg, inp, c = g["config"], g["inputs"], g["cases"][case]
+    dim = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    orc = OF.FluxTransformer2DModel(**cfg).eval()
+    for blk in orc.transformer_blocks:
+        blk.attn.processor = FluxIPAdapterProcessor(dim, cfg["joint_attention_dim"], c["num_tokens"], c["scale"])
+    sd = synthetic_state_dict(orc, g["seed"])
+    orc.load_state_dict(sd, strict=True)
+    ips = [seeded((1, n, cfg["joint_attention_dim"]), s) for n, s in zip(c["num_tokens"], c["ip_seeds"])]
+    rin = {k: (v.to(torch.bfloat16).float() if k in ("hidden_states", "encoder_hidden_states", "pooled_projections") else v)
+           for k, v in inp.items()}
+    ref16 = orc(rin["hidden_states"], rin["encoder_hidden_states"], rin["pooled_projections"], rin["timestep"], rin["img_ids"],
+                rin["txt_ids"], rin["guidance"], policy=OL.BF16_STORAGE, ip_hidden_states=[t.to(torch.bfloat16).float() for t in ips])
+    outs = {}
+    for mode in ("bf16", "f32"):
+        m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+        m.set_ip_adapter(c["num_tokens"], c["scale"])
+        assert sorted(m.state_dict().keys()) == c["keys"]
+        m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+        if mode == "f32":
+            m.set_storage_dtype(torch.float32)
+        gi = {k: (v.to(DEV).to(torch.bfloat16) if mode == "bf16" and v.dtype == torch.float32 and k in
+                  ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV)) for k, v in inp.items()}
+        kw = {"ip_hidden_states": [t.to(DEV) for t in ips]}
+        outs[mode] = m(return_dict=False, joint_attention_kwargs=dict(kw), **gi)[0].float().cpu()
+        assert torch.equal(outs[mode], m(return_dict=False, joint_attention_kwargs=dict(kw), **gi)[0].float().cpu())
+        plain = m(return_dict=False, **gi)[0].float().cpu()
+        assert _rel(plain, outs[mode]) > 1e-3, "the adapter must change the output"
+    e_like = _rel(outs["bf16"], ref16)
+    e_gold = measured(f"flux_ip_adapter.{case}.bf16_vs_reference_run", _rel(outs["bf16"], c["out"]), 1.4e-2)
+    e_f32 = _rel(outs["f32"], c["out"])
+    print(f"[flux ip-adapter {case}] hip vs bf16-storage oracle {e_like:.3e}; vs the reference run {e_gold:.3e}; "
+          f"float-storage mode vs the reference run {e_f32:.3e}")
+    assert e_like < 6e-3 and e_f32 < 1e-4, (e_like, e_f32)
+
+
+def test_flux_ip_adapter_loader_and_image_projection():
+    """`load_ip_adapter_weights` (converted adapter files: image_proj + ip_adapter dicts) builds `encoder_hid_proj` and the per-block
+    processors; `ip_adapter_image_embeds` through the HIP image projection equals feeding the tokens a plain torch
+    Linear + LayerNorm makes of them; inputs without a loaded adapter raise."""
+    from apex_studio_amd import lib
+    from apex_studio_amd.flux import FluxTransformer2DModel
+    cfg, hw, s_txt = CONFIGS["tiny"]
+    orc = OF.FluxTransformer2DModel(**cfg)
+    sd = synthetic_state_dict(orc, 7)
+    inp = _inputs(cfg, hw, s_txt)
+    m = FluxTransformer2DModel(**cfg, device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    gi = {k: (v.to(DEV).to(torch.bfloat16) if v.dtype == torch.float32 and k in
+              ("hidden_states", "encoder_hidden_states", "pooled_projections") else v.to(DEV)) for k, v in inp.items()}
+    ctx, dim, emb_dim, n_tok = cfg["joint_attention_dim"], cfg["num_attention_heads"] * cfg["attention_head_dim"], 64, 4
+    with pytest.raises(lib.ApexMIError):
+        m(return_dict=False, joint_attention_kwargs={"ip_hidden_states": [torch.zeros(1, n_tok, ctx, device=DEV)]}, **gi)
+    ad = {"image_proj": {"proj.weight": seeded((n_tok * ctx, emb_dim), 1) * 0.1, "proj.bias": seeded((n_tok * ctx,), 2) * 0.1,
+                         "norm.weight": 1.0 + 0.1 * seeded((ctx,), 3), "norm.bias": 0.1 * seeded((ctx,), 4)},
+          "ip_adapter": {}}
+    for i in range(cfg["num_layers"]):
+        for j, name in enumerate(("to_k_ip", "to_v_ip")):
+            ad["ip_adapter"][f"{i}.{name}.weight"] = seeded((dim, ctx), 10 + 2 * i + j) * ctx ** -0.5
+            ad["ip_adapter"][f"{i}.{name}.bias"] = seeded((dim,), 30 + 2 * i + j) * 0.1
+    m.load_ip_adapter_weights([ad], scale=0.6)
+    assert m.encoder_hid_proj.num_ip_adapters == 1 and m.transformer_blocks[0].attn.processor.scale == [0.6]
+    emb = seeded((1, 1, emb_dim), 50).to(torch.bfloat16)
+    a = m(return_dict=False, joint_attention_kwargs={"ip_adapter_image_embeds": [emb.to(DEV)]}, **gi)[0].float().cpu()
+    w = {k: v.to(torch.bfloat16).float() for k, v in ad["image_proj"].items()}
+    tok = torch.nn.functional.linear(emb.float().reshape(1, -1), w["proj.weight"], w["proj.bias"]).to(torch.bfloat16).float()
+    tok = torch.nn.functional.layer_norm(tok.reshape(1, n_tok, ctx), (ctx,), w["norm.weight"], w["norm.bias"], 1e-5)
+    got = m.encoder_hid_proj([emb.to(DEV)])[0].float().cpu()
+    assert _rel(got, tok) < 5e-3, _rel(got, tok)
+    b = m(return_dict=False, joint_attention_kwargs={"ip_hidden_states": [got.to(DEV)]}, **gi)[0].float().cpu()
+    assert torch.equal(a, b)
+    m.set_ip_adapter_scale(0.0)
+    zero = m(return_dict=False, joint_attention_kwargs={"ip_hidden_states": [got.to(DEV)]}, **gi)[0].float().cpu()
+    m.unload_ip_adapter()
+    plain = m(return_dict=False, **gi)[0].float().cpu()
+    assert _rel(zero, plain) < 6e-3 and _rel(a, plain) > 1e-3      # scale 0: the two-pass q/k/v path, same numbers up to its rounding

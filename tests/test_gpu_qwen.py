@@ -148,7 +148,7 @@ def test_qwen_variants_match_reference_run_and_oracle(golden_dir, case):
     assert torch.equal(out, m(additional_t_cond=None if atc is None else atc.to(DEV), **kw)[0].float().cpu())
     ref16 = orc(x.float(), txt.float(), inp["timestep"], inp["img_shapes"], policy=OL.BF16_STORAGE, additional_t_cond=atc)
     e_like = _rel(out, ref16)
-    e_gold = measured(f"qwen_variants.{case}.bf16_vs_reference_run", _rel(out, c["out"]), 1.2e-2)
+    e_gold = measured(f"qwen_variants.{case}.bf16_vs_reference_run", _rel(out, c["out"]), 9.5e-3)   # measured 4.5e-3 .. 4.6e-3
     print(f"[qwen {case}] hip vs bf16-storage oracle {e_like:.3e}; vs the reference run {e_gold:.3e}")
     assert e_like < 6e-3, e_like
     if atc is not None:

@@ -385,7 +385,7 @@ def test_fixture_recipe_reproduces_the_committed_files():
                        capture_output=True, text=True, timeout=600, cwd=root)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
-    assert "23 generators -> 23 files compared, 0 mismatches" in r.stdout, tail
+    assert "26 generators -> 26 files compared, 0 mismatches" in r.stdout, tail
 
 
 def test_easycache_restatement_matches_the_reference_function(golden_dir):
@@ -429,5 +429,26 @@ def test_oracle_qwen_variants_match_the_reference_run(golden_dir, case):
     assert sorted(sd.keys()) == c["keys"]
     m.load_state_dict(sd, strict=True)
     out = m(inp["hidden_states"], inp["encoder_hidden_states"], inp["timestep"], inp["img_shapes"], additional_t_cond=c["additional_t_cond"])
+    rel = float((out - c["out"]).norm() / c["out"].norm())
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("case", ["one", "two"])
+def test_oracle_flux_ip_adapter_matches_the_reference_run(golden_dir, case):
+    """oracle.flux with IP-adapter processors on the double blocks against the reference model run with its
+    FluxIPAdapterAttnProcessor (flux_ip_adapter.pt)."""
+    from oracle.flux import FluxTransformer2DModel, FluxIPAdapterProcessor
+    g = torch.load(os.path.join(golden_dir, "flux_ip_adapter.pt"), weights_only=False)
+    cfg, inp, c = g["config"], g["inputs"], g["cases"][case]
+    dim = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    m = FluxTransformer2DModel(**cfg).eval()
+    for blk in m.transformer_blocks:
+        blk.attn.processor = FluxIPAdapterProcessor(dim, cfg["joint_attention_dim"], c["num_tokens"], c["scale"])
+    sd = synthetic_state_dict(m, g["seed"])
+    assert sorted(sd.keys()) == c["keys"]
+    m.load_state_dict(sd, strict=True)
+    ips = [seeded((1, n, cfg["joint_attention_dim"]), s) for n, s in zip(c["num_tokens"], c["ip_seeds"])]
+    out = m(inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"], inp["img_ids"],
+            inp["txt_ids"], inp["guidance"], ip_hidden_states=ips)
     rel = float((out - c["out"]).norm() / c["out"].norm())
     assert rel < 1e-5, rel

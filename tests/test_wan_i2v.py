@@ -147,11 +147,11 @@ def test_hip_condition_and_expert_match_the_reference_run(g):
     px, h, w = eng.preprocess_image(g["image"].numpy(), g["height"], g["width"])
     cond = eng.prepare_latent_condition(px, g["duration"], 1).float().cpu()
     assert cond.shape == g["latent_condition"].shape and torch.equal(cond[:, :4], g["latent_condition"][:, :4])
-    e = measured("wan_i2v.latent_condition.bf16_vs_reference_run", _rel(cond[:, 4:], g["latent_condition"][:, 4:]), 2e-2)
+    e = measured("wan_i2v.latent_condition.bf16_vs_reference_run", _rel(cond[:, 4:], g["latent_condition"][:, 4:]), 9e-3)   # measured 4.5e-3
     x = torch.cat([seeded(g["latents_shape"], g["latents_seed"]), g["latent_condition"]], dim=1)
     out = m(hidden_states=x.to(DEV).to(BF), timestep=torch.tensor([g["timestep"]], device=DEV),
             encoder_hidden_states=seeded((1, 20, 64), g["txt_seed"]).to(DEV).to(BF), return_dict=False)[0].float().cpu()
-    e2 = measured("wan_i2v.expert36.bf16_vs_reference_run", _rel(out, g["wan_out"]), 1.2e-2)
+    e2 = measured("wan_i2v.expert36.bf16_vs_reference_run", _rel(out, g["wan_out"]), 1.1e-2)   # measured 5.1e-3
     print(f"[wan i2v] condition latents vs the reference run {e:.2e}; 36-channel expert vs the reference model {e2:.2e}")
 
 
