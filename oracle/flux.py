@@ -64,7 +64,9 @@ class FluxAttention(nn.Module):
         k = pol.r(self.to_k(x)).unflatten(-1, (H, -1))
         v = pol.r(self.to_v(x)).unflatten(-1, (H, -1))
         q, k = self.norm_q(q), self.norm_k(k)
-        ip_q = pol.r(q)                # the image stream's normalised query BEFORE the rotary embedding (attention.py:199)
+        use_ip = ip_hidden_states is not None and self.processor is not None and ctx is not None
+        # the image stream's normalised query BEFORE the rotary embedding (attention.py:199) — a storage point of the IP path only
+        ip_q = pol.r(q) if use_ip else None
         if ctx is not None:
             cq = pol.r(self.add_q_proj(ctx)).unflatten(-1, (H, -1))
             ck = pol.r(self.add_k_proj(ctx)).unflatten(-1, (H, -1))
@@ -82,7 +84,7 @@ class FluxAttention(nn.Module):
         if ctx is not None:
             n_txt = ctx.shape[1]
             co, o = o[:, :n_txt], o[:, n_txt:]
-            if ip_hidden_states is not None and self.processor is not None:
+            if use_ip:
                 # IP-adapter (attention.py:232-262): per adapter, attention of the image queries over the projected image-prompt
                 # tokens (no norm, no rotary embedding on those keys); returned per adapter with its scale — the block adds
                 # scale x output to the image stream AFTER its feed-forward (model.py:308-309)

@@ -188,7 +188,10 @@ def test_wan_and_qwen_class_contracts_on_meta_device():
     with pytest.raises(NotImplementedError):
         WanTransformer3DModel(image_dim=1280, device="meta")
     with pytest.raises(NotImplementedError):
-        QwenImageTransformer2DModel(zero_cond_t=True, device="meta")
+        QwenImageTransformer2DModel(use_layer3d_rope=True, device="meta")
+    # the Edit-2511-style switches are served since round 6: the extra embedding table carries the reference's key
+    v = QwenImageTransformer2DModel(num_layers=1, zero_cond_t=True, use_additional_t_cond=True, device="meta")
+    assert "time_text_embed.addition_t_embedding.weight" in v.state_dict() and v.config.zero_cond_t
 
 
 def test_text_encoder_class_contracts_match_transformers():

@@ -472,7 +472,7 @@ def test_flux_ip_adapter_matches_reference_run_and_oracle(golden_dir, case):
         plain = m(return_dict=False, **gi)[0].float().cpu()
         assert _rel(plain, outs[mode]) > 1e-3, "the adapter must change the output"
     e_like = _rel(outs["bf16"], ref16)
-    e_gold = measured(f"flux_ip_adapter.{case}.bf16_vs_reference_run", _rel(outs["bf16"], c["out"]), 1.4e-2)
+    e_gold = measured(f"flux_ip_adapter.{case}.bf16_vs_reference_run", _rel(outs["bf16"], c["out"]), 1.2e-2)   # measured 5.5e-3 / 6.3e-3
     e_f32 = _rel(outs["f32"], c["out"])
     print(f"[flux ip-adapter {case}] hip vs bf16-storage oracle {e_like:.3e}; vs the reference run {e_gold:.3e}; "
           f"float-storage mode vs the reference run {e_f32:.3e}")

@@ -8,7 +8,8 @@
 #   py:<script and args>       python <script and args>
 #   sh:<command>               bash -c <command>
 #   profile:<tag> [cmd]        tools/gpu_profile.sh (rocprofv3 kernel stats + PMC passes + derived CSV)
-#   pmc_gemm[:qwen] | pmc_attn | pmc_vae[:flux]   the hash-matched PMC records (tools/gpu_pmc_*.sh)
+#   pmc_gemm[:qwen] | pmc_wan | pmc_vae[:flux]    the hash-matched PMC records bench.py reads (tools/gpu_pmc_*.sh -> copy to profiles/)
+#   pmc_attn                                      wave-state counters of the attention kernels
 # T=<seconds> in front of a job overrides its timeout (default 900):  "T=1800 suite".
 # Replaces the one-shot tools/gpu_r0N_*.sh launchers of rounds 3-5 (their measurements live on under profiles/).
 set -u
@@ -36,6 +37,7 @@ for job in "$@"; do
         profile) PROF_TIMEOUT=$T bash tools/gpu_profile.sh $arg > "$log.log" 2>&1 ;;
         pmc_gemm) WORKLOAD=${arg:-flux} PROF_TIMEOUT=$T bash tools/gpu_pmc_gemm.sh > "$log.log" 2>&1 ;;
         pmc_attn) PROF_TIMEOUT=$T bash tools/gpu_pmc_attn.sh $arg > "$log.log" 2>&1 ;;
+        pmc_wan)  PROF_TIMEOUT=$T bash tools/gpu_pmc_wan.sh > "$log.log" 2>&1 ;;
         pmc_vae)  VAE=${arg:-wan} PROF_TIMEOUT=$T bash tools/gpu_pmc_vae.sh > "$log.log" 2>&1 ;;
         *) echo "unknown job kind '$kind'" > "$log.log" ;;
     esac
