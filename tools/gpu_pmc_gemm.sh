@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic + MFMA-pipe occupancy of the dominant kernel of the Flux step (gemm_bf16_kernel) from separate
-# rocprofv3 --pmc passes (kernel-trace only beside the counters), on a DEPTH-REDUCED step (3 double + 6 single blocks:
-# the per-launch figures do not depend on the depth, and counter collection costs ~50 ms per dispatch).
+# rocprofv3 --pmc passes (kernel-trace only beside the counters) over the step (full depth for flux; LAYERS=3,6 = 3 double + 6 single
+# blocks: the per-launch figures do not depend on the depth, and counter collection costs ~50 ms per dispatch).
 # WORKLOAD=qwen: the same over a 3-block QwenImage-Edit step.
 # Writes gpurun_out/pmc_gemm/r03_pmc_gemm[_qwen].json (copy to profiles/): per-launch means over the step's GEMM launches,
 # FETCH_SIZE doubled per MI355X_MICROARCH.md, and the sha256 of csrc/gemm.hip the binary was built from.
@@ -13,7 +13,11 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 TAG=$([ "$W" = flux ] && echo ${ROUND:-r05}_pmc_gemm || echo ${ROUND:-r05}_pmc_gemm_$W)
 export TAG W
-CMD="python $R/bench.py --workload $W --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
+# LAYERS: empty = the FULL-depth step (flux default since round 6: ~1300 dispatches per pass, about a minute each); "3,6" = the
+# depth-reduced run of the same launches (qwen default: 60 blocks would be ~3000 dispatches per pass)
+LAYERS=${LAYERS-$([ "$W" = flux ] && echo "" || echo "3,6")}
+export LAYERS
+CMD="python $R/bench.py --workload $W ${LAYERS:+--layers $LAYERS} --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan"
 T=${PROF_TIMEOUT:-420}
 timeout $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o g -- $CMD > $OUT/fetch.log 2>&1; echo "fetch $?"
 timeout $T rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/write -o g -- $CMD > $OUT/write.log 2>&1; echo "write $?"
@@ -42,7 +46,8 @@ f, (n, ns_f) = means("fetch", "gemm_bf16_kernel")
 w, _ = means("write", "gemm_bf16_kernel")
 s, _ = means("sq", "gemm_bf16_kernel")
 res = {"kernel": "gemm_bf16_kernel<Cfg<256,256,2,4,5>> (ping-pong, v_mfma_f32_16x16x32_bf16) + gemm_bf16_x384_kernel (384 x 256 tiles), all epilogues",
-       "command": "python bench.py --workload %s --layers 3,6 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan" % os.environ["W"],
+       "command": "python bench.py --workload %s %s--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-wan" % (
+           os.environ["W"], ("--layers %s " % os.environ["LAYERS"]) if os.environ.get("LAYERS") else ""),
        "source_sha256": hashlib.sha256(open(root + "/apex-studio_amd/csrc/gemm.hip", "rb").read()).hexdigest(),
        "dispatches": n, "avg_duration_ns_under_pmc": ns_f}
 if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
