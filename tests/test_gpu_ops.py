@@ -397,7 +397,7 @@ def test_attention_reference_goldens(golden_dir):
             # bf16: P is rounded to bf16 before P V (as flash kernels do) -> ~1e-2 rel of |out|max
             _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attn {c['q_shape']}", ulp=3.0)
             assert torch.allclose(out.float().cpu(), c["out"].float(), atol=3e-2, rtol=3e-2)
-            measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.rel_vs_reference_run", _rel(out.cpu(), c["out"]), 5e-3)   # measured 2.3e-3
+            measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.rel_vs_reference_run", _rel(out.cpu(), c["out"]), 6.5e-3)   # measured 2.3e-3 … 3.1e-3 over the cases
             if c["q_shape"][-1] == 128:      # the flash kernels (other head sizes run the generic kernel, whose probabilities stay f32)
                 # like for like: the oracle rounding where the kernel rounds (bf16 P into P V, f32 row sums, bf16 store)
                 measured(f"attention_sdpa.bf16.{tuple(c['q_shape'])}.like_for_like",
