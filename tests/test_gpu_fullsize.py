@@ -14,6 +14,7 @@
 """
 import os
 import sys
+import time
 
 import pytest
 import torch
@@ -187,6 +188,47 @@ def test_render_queue_on_one_gpu():
     print(f"[full size] 1-GPU queue (2 flux 1024^2 + 2 wan 720p x 81f clips, reduced depth, 2 steps): per-clip s "
           f"{ {k: round(v, 2) for k, v in res['clip_seconds'].items()} }, makespan {res['makespan']:.2f} s, "
           f"{res['clips_per_hour']:.0f} clips/h")
+
+
+def test_wan_i2v_full_geometry_480p_81_frames():
+    """Wan-2.2 image-to-video at the reference's default geometry (`WanI2VEngine.run`: 480 x 832 x 81 frames,
+    R/src/engine/wan/i2v.py:20-22) with the depth cut to one block per expert: a PIL image resized on the reference's rule, the
+    81-frame condition video through the TILED HIP VAE encode (6 tiles), the 36-channel experts at S = 32 760 (patch embedding K = 144
+    zero-padded), CFG on both experts, the tiled decode to uint8 frames.  Checked: shapes, the mask the experts see, that the first
+    frame conditions the clip (another image -> other frames), determinism."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from PIL import Image
+    from bench import synth_vae_init
+    from apex_studio_amd.engine_wan import WanI2VEngine
+    from apex_studio_amd.vae_wan import AutoencoderKLWan
+    from apex_studio_amd.wan import WanTransformer3DModel
+    hi = WanTransformer3DModel(num_layers=1, in_channels=36, device=DEV, dtype=BF).init_synthetic(2)
+    lo = WanTransformer3DModel(num_layers=1, in_channels=36, device=DEV, dtype=BF).init_synthetic(3)
+    eng = WanI2VEngine(hi, lo, vae=synth_vae_init(AutoencoderKLWan(device=DEV, dtype=BF), 6), boundary_ratio=0.9)
+    seen = []
+    for m in (hi, lo):
+        m.register_forward_pre_hook(lambda mod, args, kwargs: seen.append(kwargs["hidden_states"][:, 16:20, :, ::8, ::8].float().cpu()),
+                                    with_kwargs=True)
+    rng = np.random.default_rng(7)
+    imgs = [Image.fromarray(rng.integers(0, 255, (540, 960, 3), dtype=np.uint8)) for _ in range(2)]
+    pe, ne = _randn((1, 512, 4096), 43), _randn((1, 512, 4096), 44)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, height=480, width=832, duration=81, num_inference_steps=2,
+              high_noise_guidance_scale=3.5, low_noise_guidance_scale=3.5, seed=5, output_type="np")
+    t0 = time.perf_counter()
+    a = eng.run(image=imgs[0], **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    h, w = eng.aspect_ratio_size(540, 960, 480 * 832, 16)
+    assert a.shape == (1, 81, h, w, 3) and a.dtype == np.uint8 and (h, w) == (464, 832)
+    assert len(seen) == 4, "cond + uncond on each of the two steps"
+    m = seen[0]
+    assert m.shape[1:3] == (4, 21) and bool((m[:, :, 0] == 1).all()) and bool((m[:, :, 1:] == 0).all()), "first-frame mask x 4"
+    b = eng.run(image=imgs[0], **kw)
+    c = eng.run(image=imgs[1], **kw)
+    assert np.array_equal(a, b), "deterministic"
+    assert float(np.abs(a.astype(np.int32) - c.astype(np.int32)).mean()) > 0.5, "the first frame must condition the clip"
+    print(f"[full size] wan i2v 480p x 81 f (1-block experts, 2 steps, CFG): {dt:.1f} s per run incl. the tiled VAE encode + decode")
 
 
 # ---- full-depth / full-length evidence inside the GPU tier (VERDICT r2 weak 3) ------------------------------------------------
