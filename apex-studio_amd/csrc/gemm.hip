@@ -39,7 +39,6 @@
 #include <cstring>
 #include <mutex>
 #include <tuple>
-#include <type_traits>
 #include <vector>
 
 namespace {
@@ -1837,6 +1836,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         clk_c0 = __builtin_readcyclecounter();
         clk_r0 = __builtin_amdgcn_s_memrealtime();
     }
+#if APEXMI_GEMM_TRACE
+    // per-workgroup timeline (tools/gemm_x384_trace.py): [kind, entry, K-loop end, epilogue stores acknowledged] in 10 ns ticks;
+    // kind = 0 q / 1 k / 2 v tile of a fused q/k/v problem, 3 any other epilogue
+    const unsigned long long y_t_in = G.trace != nullptr ? __builtin_amdgcn_s_memrealtime() : 0;
+    unsigned long long y_t_loop = 0;
+#define Y_TRACE_END(kind)                                                                                   \
+    do {                                                                                                    \
+        if (G.trace != nullptr) {                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+            __syncthreads();                                                                                \
+            if (tid == 0) {                                                                                 \
+                unsigned long long* o = G.trace + (size_t)blockIdx.x * 4;                                   \
+                o[0] = (unsigned long long)(kind);                                                          \
+                o[1] = y_t_in;                                                                              \
+                o[2] = y_t_loop;                                                                            \
+                o[3] = __builtin_amdgcn_s_memrealtime();                                                    \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#else
+#define Y_TRACE_END(kind) do { } while (0)
+#endif
 
     const int l15 = lane & 15, g4 = lane >> 4;
     const int sw16 = (l15 >> 1) & 7;
@@ -1952,9 +1973,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         }
     }
 
+#if APEXMI_GEMM_TRACE
+    if (G.trace != nullptr) y_t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (EPI == APEXMI_EPI_BIAS && QKV == 1) {
         if (P.qkv) {                                   // block-uniform: the fused q / k / v preparation (two passes for V^T)
             qkv_epilogue16<12, 192>(acc, P, G.qs, M, m0, n0, wave, wm, wn, lane, smem);
+            Y_TRACE_END(n0 / G.qs.inner);
             return;
         }
     }
@@ -1984,7 +2009,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
             }
         }
     }
+    Y_TRACE_END(3);
 }
+#undef Y_TRACE_END
 
 int g_group_m = GROUP_M;  // tiles per column group of the tile order (tune key gemm.group_m)
 #if APEXMI_GEMM_TRACE
@@ -2123,6 +2150,9 @@ int launch_x384(GemmGroup& G, const int* Ms, hipStream_t stream) {
     // 1365) — on the 75 600-row launches +2..4 % (profiles/r05_gemm_x384_group_m.log), the same on the 12-row-tile Flux launch
     G.group_m = g_x384_group_m;
     G.clk = apexmi_clk_ptr();
+#if APEXMI_GEMM_TRACE
+    G.trace = (unsigned long long*)g_gemm_trace;
+#endif
     G.wpacked = 0;
     G.sk_r = G.sk_tfull = 0;
     G.sk_slab = nullptr;
