@@ -1242,6 +1242,25 @@ extern "C" int apexmi_rope_table_axes(const float* ids, int S, int n_axes, const
     return apexmi_check_launch("rope_table_axes");
 }
 
+// [2, S, D] -> [2, S, D / 2]: every second entry of a rotary table whose entries come in equal pairs; a pair that is NOT equal bumps *mismatch
+__global__ __launch_bounds__(256) void rope_pairs_kernel(const float* __restrict__ rope, int64_t n_pairs, float* __restrict__ out,
+                                                         int* __restrict__ mismatch) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const float a = rope[2 * i], b = rope[2 * i + 1];
+    out[i] = a;
+    if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatch, 1);
+}
+
+extern "C" int apexmi_rope_pairs(const float* rope, int S, int D, float* pairs, int* mismatch, apexmi_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(rope && pairs && mismatch && S > 0 && D > 0 && D % 2 == 0, "rope_pairs: bad arguments");
+    const int64_t n = (int64_t)2 * S * (D / 2);
+    ApexmiProfScope prof(5, stream, 0.0, 12.0 * (double)n);
+    hipLaunchKernelGGL(rope_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rope, n, pairs, mismatch);
+    return apexmi_check_launch("rope_pairs");
+}
+
 extern "C" int apexmi_add_bcast_f32(const float* a, const float* b, float* out, int64_t rows, int64_t n,
                                     apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -39,6 +39,7 @@
 #include <cstring>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -94,6 +95,7 @@ struct QkvShared {           // outputs of the fused preparation, shared by the 
     const float* rope;       // [2, S_out, 128] f32 (cos | sin), interleaved pairs
     int S_out, Skp, inner;   // inner = H * 128
     float eps;
+    const float* rope_pairs; // optional [2, S_out, 64]: every second entry of `rope` when its entries come in equal pairs (half the bytes)
 };
 struct GemmGroup {
     GemmProblem p[MAX_GROUPS];
@@ -290,6 +292,11 @@ APEXMI_DEVICE void store_ntile(const f32x16 (&acc)[TM], const GemmProblem& P, in
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+// x[lane] + x[lane ^ 16]: with both operands a copy of x the swap leaves {r0, r0, r2, r2} and {r1, r1, r3, r3} (rows of 16 lanes)
+APEXMI_DEVICE float sum_xor16(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // v_permlane16_swap on a register pair: rows of 16 lanes, odd rows of `a` <-> even rows of `b`
 APEXMI_DEVICE void swap16(uint32_t& a, uint32_t& b) {
     auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -399,6 +406,11 @@ APEXMI_DEVICE void store_slab16(const f32x4_t (&x)[MT], const f32x4_t (&y)[MT], 
 // whose row range is not 8-aligned takes an element-wise (still coalesced) V^T store; q / k rows have no alignment to keep.
 // MT = 16-row m-tiles per wave, WROWS = rows per M-half of the block: <8, 128> on the 256 x 256 tiling, <12, 192> on the 384 x 256 one
 // (round 5), whose V^T tile (384 x 256 bf16 = 192 KiB) does not fit the LDS and goes out in two passes, one per M-half.
+// timing-only ablations of the q / k epilogue (side builds -DAPEXMI_QK_ABL=mask, results WRONG by construction; tools/gemm_qk_ablate.sh):
+// 1 no rotary-table loads | 2 no output store | 4 no sum-of-squares pass | 8 no norm factor | 16 no sched_barrier | 32 no main loop
+#ifndef APEXMI_QK_ABL
+#define APEXMI_QK_ABL 0
+#endif
 template <int MT = 8, int WROWS = 128>
 APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P, const QkvShared& Q, int M, int m0, int n0,
                                   int wave, int wm, int wn, int lane, char* smem) {
@@ -489,7 +501,7 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P,
     // ---- q / k: RMS norm over the head, rotation, [H, S_out, 128]
     float* red = (float*)smem;                          // [8 waves][2 MT = slab x m-tile][64 lanes]
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < ((APEXMI_QK_ABL & 4) ? 0 : 2); ++p) {
         load_bias(p);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -509,8 +521,11 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P,
         const float a0 = red[(wave * 2 * MT + mt) * 64 + lane] + red[((wave ^ 1) * 2 * MT + mt) * 64 + lane];          // chunk ^ 8: the partner wave
         const float a1 = red[(wave * 2 * MT + MT + mt) * 64 + lane] + red[((wave ^ 1) * 2 * MT + MT + mt) * 64 + lane];
         float sq = a0 + a1;                                                              // chunk ^ 4: the other slab
-        sq += __shfl_xor(sq, 16, 64);                                                    // chunk ^ 2
-        sq += __shfl_xor(sq, 32, 64);                                                    // chunk ^ 1
+        // chunk ^ 2 and chunk ^ 1: lane ^ 16 and lane ^ 32 through v_permlane16_swap / v_permlane32_swap — one instruction each where
+        // __shfl_xor is a ds_bpermute with its index arithmetic and an LDS round trip (round 6: the 384 x 256 form calls this 24 times
+        // per tile and wave); x + partner is commutative, so the bits are those of `sq += __shfl_xor(sq, ...)`
+        sq = sum_xor16(sq);
+        sq = sum_xor32(sq);
         return rsqrtf(sq * (1.0f / 128) + Q.eps);
     };
     // 256 x 256 tiling: the 8 factors once, in registers; 384 x 256 (192 accumulators): recomputed per (slab, m-tile) from the LDS sums
@@ -519,8 +534,118 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P,
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) rinv[mt] = rinv_of(mt);
     }
+    if constexpr (!(APEXMI_QK_ABL & 64)) {
+        if (Q.rope_pairs != nullptr) {
+            // ---- compact table (round 6): the rows of the rotary table travel through a per-wave LDS ring of NS slots of 2 KiB
+            // (cos pairs | sin pairs, 16 bytes per lane each), requested NS - 1 iterations ahead with register-free LDS-DMA.
+            // Why: the loads of this epilogue queue behind the K-loop staging traffic of the other 255 CUs, which saturates the
+            // L2 -> CU path; with one (or two) rows in flight every iteration of a wave waits that queue out (a q / k tile of
+            // 384 x 256: 31 us against 9-10 us for the V^T and GELU tiles; timing-only ablation: without the table loads the fused
+            // launch is as fast as the un-fused one).  Neither halving the bytes nor prefetching two iterations ahead moved it;
+            // four ahead does: +45..57 us -> +13 us on the 470 us single-block launch of Flux (profiles/r06_gemm_x384_epilogue_trace.log).
+            // The consumer waits on a counted vmcnt — vector-memory operations complete in issue order under one counter, so "at
+            // most 2 x (later iterations' DMAs)" outstanding means this iteration's two pieces have landed; the output stores
+            // issued in between only make the wait stronger — and reads the pieces back with ds_read_b128.  Same values into the
+            // same arithmetic in the same order: bit-identical to the direct loads below. ----
+            constexpr int NIT = 2 * MT, NS = 5;      // 384 x 256: 48 KiB sums + 8 x 10 KiB ring + 32 KiB weights = the 160 KiB of the CU
+            constexpr int RED_BYTES = 8 * 2 * MT * 64 * 4;
+            char* ring = smem + RED_BYTES + wave * (NS * 2048);
+            const unsigned ring_lane = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring + (unsigned)lane * 16u;
+            auto issue = [&](int it) {
+                const int p = it / MT, mt = it % MT;
+                const int d = (wn & 1) * 64 + p * 32 + cw;
+                int m = m0 + wm * WROWS + mt * 16 + c;
+                asm volatile("" : "+v"(m));        // opaque: the two slabs share their rows, and row pointers kept across them spill
+                const int srow = P.row0 + min(m, M - 1);
+                const float* cp = Q.rope_pairs + (int64_t)srow * 64 + (d >> 1);
+                char* dst = ring + (it % NS) * 2048;
+                glds16(cp, dst);
+                glds16(cp + (int64_t)Q.S_out * 64, dst + 1024);
+            };
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+            for (int it = 0; it < NS - 1; ++it) issue(it);
+            // 384 x 256: the norm weights of the lane's two 8-column groups wait in the wave's own LDS corner (8 registers fewer
+            // across the slab: with them live the compiler spills a value per iteration, and a scratch reload is a vmcnt(0) — which
+            // would wait for every prefetched piece); 256 x 256: registers
+            float* wtab = (float*)(smem + RED_BYTES + 8 * NS * 2048) + wave * 1024 + lane * 8;
+            float wv[MT > 8 ? 1 : 8];
+            if constexpr (MT > 8) {
+                if (nw != nullptr) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        float w8[8];
+                        unpack8(*(const u32x4*)(nw + (wn & 1) * 64 + p * 32 + cw), w8);
+                        *(f32x4*)(wtab + p * 512) = f32x4{w8[0], w8[1], w8[2], w8[3]};
+                        *(f32x4*)(wtab + p * 512 + 4) = f32x4{w8[4], w8[5], w8[6], w8[7]};
+                    }
+                }
+            }
+            auto body = [&](auto IT) {
+                constexpr int it = decltype(IT)::value;
+                if constexpr (it < NIT) {
+                    constexpr int p = it / MT, mt = it % MT;
+                    constexpr int later = (NIT - 1 - it) < (NS - 1) ? (NIT - 1 - it) : (NS - 1);     // DMA iterations issued behind this one
+                    if constexpr (it + NS - 1 < NIT) issue(it + NS - 1);
+                    const int d = (wn & 1) * 64 + p * 32 + cw;
+                    if constexpr (mt == 0) {
+                        load_bias(p);
+                        if constexpr (MT <= 8) {
+                            if (nw != nullptr) unpack8(*(const u32x4*)(nw + d), wv);
+                        }
+                    }
+                    float x[8], y[8];
+                    unpack8(rounded(p, mt), x);
+                    if (nw != nullptr) {
+                        if constexpr (MT > 8) {
+                            const float ri = rinv_of(mt);
+                            const f32x4 w0 = *(const f32x4*)(wtab + p * 512), w1 = *(const f32x4*)(wtab + p * 512 + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                x[j] = x[j] * ri * w0[j];
+                                x[j + 4] = x[j + 4] * ri * w1[j];
+                            }
+                        } else {
+                            const float ri = rinv[MT > 8 ? 0 : mt];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = x[j] * ri * wv[MT > 8 ? 0 : j];
+                        }
+                    }
+                    f32x4 cq, sq4;
+                    asm volatile("s_waitcnt vmcnt(%3)\n\t"
+                                 "ds_read_b128 %0, %2 offset:%4\n\t"
+                                 "ds_read_b128 %1, %2 offset:%5\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(cq), "=&v"(sq4)
+                                 : "v"(ring_lane), "n"(2 * later), "n"((it % NS) * 2048), "n"((it % NS) * 2048 + 1024)
+                                 : "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[2 * q] = fmaf(x[2 * q], cq[q], -(x[2 * q + 1] * sq4[q]));
+                        y[2 * q + 1] = fmaf(x[2 * q + 1], cq[q], x[2 * q] * sq4[q]);
+                    }
+                    int m = m0 + wm * WROWS + mt * 16 + c;
+                    asm volatile("" : "+v"(m));        // the store address is made HERE, behind the table read (hoisted above it, it spills)
+                    const int srow = P.row0 + min(m, M - 1);
+                    if (m < M)
+                        *(u32x4*)(dst_base + (int64_t)srow * 128 + d) =
+                            u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+#define APEXMI_QK_IT(i) body(std::integral_constant<int, (i)>{});
+            APEXMI_QK_IT(0) APEXMI_QK_IT(1) APEXMI_QK_IT(2) APEXMI_QK_IT(3) APEXMI_QK_IT(4) APEXMI_QK_IT(5)
+            APEXMI_QK_IT(6) APEXMI_QK_IT(7) APEXMI_QK_IT(8) APEXMI_QK_IT(9) APEXMI_QK_IT(10) APEXMI_QK_IT(11)
+            APEXMI_QK_IT(12) APEXMI_QK_IT(13) APEXMI_QK_IT(14) APEXMI_QK_IT(15) APEXMI_QK_IT(16) APEXMI_QK_IT(17)
+            APEXMI_QK_IT(18) APEXMI_QK_IT(19) APEXMI_QK_IT(20) APEXMI_QK_IT(21) APEXMI_QK_IT(22) APEXMI_QK_IT(23)
+#undef APEXMI_QK_IT
+            static_assert(NIT <= 24, "the unrolled call list above covers 24 iterations");
+            static_assert(MT > 8 ? RED_BYTES + 8 * NS * 2048 + 8 * 4096 <= 160 * 1024 : RED_BYTES + 8 * NS * 2048 <= 128 * 1024,
+                          "sums + ring (+ weights) must fit the tile's LDS");
+            return;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < ((APEXMI_QK_ABL & 32) ? 0 : 2); ++p) {
         const int d = (wn & 1) * 64 + p * 32 + cw;      // column inside the head
         load_bias(p);
         float wv[8];
@@ -532,32 +657,37 @@ APEXMI_DEVICE void qkv_epilogue16(f32x4_t (&acc16)[4][MT], const GemmProblem& P,
             float x[8], y[8];
             unpack8(rounded(p, mt), x);
             if (nw != nullptr) {
-                const float ri = MT > 8 ? rinv_of(mt) : rinv[MT > 8 ? 0 : mt];
+                const float ri = (APEXMI_QK_ABL & 8) ? 1.0f : MT > 8 ? rinv_of(mt) : rinv[MT > 8 ? 0 : mt];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = x[j] * ri * wv[j];
             }
             const float* cp = Q.rope + (int64_t)srow * 128 + d;
             const float* sp = Q.rope + (int64_t)Q.S_out * 128 + (int64_t)srow * 128 + d;
-            const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
-            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
             float cs[8], sn[8];
+            if constexpr (APEXMI_QK_ABL & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                cs[j] = c0[j];
-                cs[j + 4] = c1[j];
-                sn[j] = s0[j];
-                sn[j + 4] = s1[j];
+                for (int j = 0; j < 8; ++j) cs[j] = 1.f, sn[j] = 0.5f;
+            } else {
+                const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[j] = c0[j];
+                    cs[j + 4] = c1[j];
+                    sn[j] = s0[j];
+                    sn[j + 4] = s1[j];
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 y[2 * q] = fmaf(x[2 * q], cs[2 * q], -(x[2 * q + 1] * sn[2 * q]));
                 y[2 * q + 1] = fmaf(x[2 * q + 1], cs[2 * q + 1], x[2 * q] * sn[2 * q + 1]);
             }
-            if (m < M)
+            if ((APEXMI_QK_ABL & 2) ? (y[0] + y[3] + y[5] == 12345.678f) : (m < M))
                 *(u32x4*)(dst_base + (int64_t)srow * 128 + d) =
                     u32x4{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
             // rows' table loads in flight at a time: two on the 256 x 256 tiling, ONE where 192 accumulators leave 64 registers
-            if (MT > 8 || (mt & 1)) __builtin_amdgcn_sched_barrier(0);
+            if (!(APEXMI_QK_ABL & 16) && (MT > 8 || (mt & 1))) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -2437,7 +2567,18 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
                                             const void* const* norm_q, const void* const* norm_k, const int* row0, int H,
                                             float eps, const float* rope, void* q_out, void* k_out, void* vt_out, int S_out,
                                             int Skp, apexmi_stream_t stream_) {
+    return apexmi_gemm_bf16_grouped_qkv_pairs(count, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, is_qkv, norm_q, norm_k, row0, H,
+                                              eps, rope, nullptr, q_out, k_out, vt_out, S_out, Skp, stream_);
+}
+
+extern "C" int apexmi_gemm_bf16_grouped_qkv_pairs(int count, const void* const* A, const int64_t* lda, const void* const* W,
+                                                  const int64_t* ldw, const void* const* bias, void* const* C, const int64_t* ldc,
+                                                  const int* M, const int* N, int K, const int* epilogue, const int* is_qkv,
+                                                  const void* const* norm_q, const void* const* norm_k, const int* row0, int H,
+                                                  float eps, const float* rope, const float* rope_pairs, void* q_out, void* k_out,
+                                                  void* vt_out, int S_out, int Skp, apexmi_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    APEXMI_REQUIRE(((uintptr_t)rope_pairs % 16) == 0, "gemm_bf16_grouped_qkv: rope_pairs must be 16-byte aligned");
     APEXMI_REQUIRE(count >= 1 && count <= MAX_GROUPS, "gemm_bf16_grouped_qkv: count=%d not in [1,%d]", count, MAX_GROUPS);
     APEXMI_REQUIRE(is_qkv && row0 && rope && q_out && k_out && vt_out && H > 0, "gemm_bf16_grouped_qkv: null argument");
     APEXMI_REQUIRE(H % 2 == 0 && S_out > 0 && Skp >= S_out && Skp % 8 == 0, "gemm_bf16_grouped_qkv: H=%d must be even, Skp=%d a multiple of 8 >= S_out=%d",
@@ -2449,7 +2590,7 @@ extern "C" int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, con
     G.K = K;
     G.batch = 1;
     G.bsA = G.bsW = G.bsC_bytes = 0;
-    G.qs = QkvShared{(bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, rope, S_out, Skp, H * 128, eps};
+    G.qs = QkvShared{(bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, rope, S_out, Skp, H * 128, eps, rope_pairs};
     double flops = 0, bytes = 0;
     int64_t mtot = 0;
     int nmax = 0;

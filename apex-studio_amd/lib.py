@@ -44,6 +44,11 @@ SIGNATURES = {
                                                C.POINTER(vp), c_i64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp),
                                                C.POINTER(C.c_int), C.c_int, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "apexmi_gemm_bf16_grouped_qkv_pairs": (C.c_int, [C.c_int, C.POINTER(vp), c_i64p, C.POINTER(vp), c_i64p, C.POINTER(vp),
+                                                     C.POINTER(vp), c_i64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp),
+                                                     C.POINTER(C.c_int), C.c_int, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "apexmi_rope_pairs": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "apexmi_gemm_qkv_fusable": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "apexmi_gemm_uses_x288": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "apexmi_qk_rms_rope_rows": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp, C.c_float, vp, C.c_int, vp, vp, vp,

@@ -409,16 +409,44 @@ def gemm_grouped_qkv(a_list, w_list, bias_list, out_list, epilogue, is_qkv, norm
     INT = C.c_int * n
     none = [None] * n
     bias_list = bias_list or none
-    rc = _l.load().apexmi_gemm_bf16_grouped_qkv(
+    pairs = rope_pairs(rope)
+    rc = _l.load().apexmi_gemm_bf16_grouped_qkv_pairs(
         n, VP(*[a.data_ptr() for a in a_list]), I64(*[a.stride(0) for a in a_list]),
         VP(*[w.data_ptr() for w in w_list]), I64(*[w.stride(0) for w in w_list]), VP(*[_ptr(b) for b in bias_list]),
         VP(*[_ptr(o) if not f else None for o, f in zip(out_list, is_qkv)]),
         I64(*[(o.stride(0) if (o is not None and not f) else 0) for o, f in zip(out_list, is_qkv)]),
         INT(*[a.shape[0] for a in a_list]), INT(*[w.shape[0] for w in w_list]), K, INT(*[_EPI[e] for e in epis]),
         INT(*[1 if f else 0 for f in is_qkv]), VP(*[_ptr(t_) for t_ in (norm_q or none)]), VP(*[_ptr(t_) for t_ in (norm_k or none)]),
-        INT(*[int(r) for r in row0]), int(H), float(eps), rope.data_ptr(), qo.data_ptr(), ko.data_ptr(), vt.data_ptr(), S_out,
-        vt.shape[2], _stream())
+        INT(*[int(r) for r in row0]), int(H), float(eps), rope.data_ptr(), _ptr(pairs), qo.data_ptr(), ko.data_ptr(), vt.data_ptr(),
+        S_out, vt.shape[2], _stream())
     _l.check(rc, "gemm_bf16_grouped_qkv")
+
+
+rope_pairs_enabled = True      # A/B switch (tests, tools): False = the fused epilogue reads the full [2, S, 128] table
+
+
+def rope_pairs(rope: torch.Tensor) -> Optional[torch.Tensor]:
+    """The compact copy [2, S, D / 2] of a rotary table whose entries come in equal pairs (apexmi_rope_table_axes writes every
+    cos / sin twice), made ONCE per table (cached on the tensor; tables are cached per geometry by the models) — the fused q/k/v
+    epilogue reads half the bytes from it.  None for a table that is not pair-duplicated (checked on the device, one read)."""
+    if not rope_pairs_enabled:
+        return None
+    key = (rope.data_ptr(), tensor_version(rope))
+    hit = getattr(rope, "_apex_pairs", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    _req(rope, torch.float32, "rope_pairs.rope")
+    assert rope.dim() == 3 and rope.shape[0] == 2 and rope.is_contiguous() and rope.shape[2] % 2 == 0
+    S, D = rope.shape[1], rope.shape[2]
+    out = torch.empty((2, S, D // 2), dtype=torch.float32, device=rope.device)
+    bad = torch.zeros((), dtype=torch.int32, device=rope.device)
+    _l.check(_l.load().apexmi_rope_pairs(rope.data_ptr(), S, D, out.data_ptr(), bad.data_ptr(), _stream()), "rope_pairs")
+    res = out if int(bad.item()) == 0 else None
+    try:
+        rope._apex_pairs = (key, res)
+    except Exception:
+        pass
+    return res
 
 
 def gemv(w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None,

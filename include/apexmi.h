@@ -170,6 +170,21 @@ int apexmi_gemm_bf16_grouped_qkv(int count, const void* const* A, const int64_t*
                                  const void* const* norm_q, const void* const* norm_k, const int* row0, int H, float eps,
                                  const float* rope, void* q_out, void* k_out, void* vt_out, int S_out, int Skp,
                                  apexmi_stream_t stream);
+/* The same launch with the rotary table ALSO given as its compact copy `rope_pairs` (f32 [2, S_out, 64], may be NULL = the call
+ * above): tables written by apexmi_rope_table_axes hold every cos / sin twice (get_1d_rotary_pos_embed(repeat_interleave_real=True),
+ * flux model.py:338-359), and the q / k tiles of a launch pull their rows of the table through the L2 -> CU path once per (row, head) —
+ * where they queue behind the K-loop staging traffic of the other CUs (measured: +45..57 us on the ~490 us single-block launch of
+ * Flux).  With the compact copy the epilogue prefetches the rows four iterations ahead through a per-wave LDS ring (LDS-DMA, no
+ * registers): +12 us.  Results are bit-identical (the same values reach the same arithmetic in the same order). */
+int apexmi_gemm_bf16_grouped_qkv_pairs(int count, const void* const* A, const int64_t* lda, const void* const* W,
+                                       const int64_t* ldw, const void* const* bias, void* const* C, const int64_t* ldc,
+                                       const int* M, const int* N, int K, const int* epilogue, const int* is_qkv,
+                                       const void* const* norm_q, const void* const* norm_k, const int* row0, int H, float eps,
+                                       const float* rope, const float* rope_pairs, void* q_out, void* k_out, void* vt_out,
+                                       int S_out, int Skp, apexmi_stream_t stream);
+/* pairs[t][s][q] = rope[t][s][2 q] for a table rope f32 [2, S, D] (t = cos | sin); *mismatch (device int, zeroed by the caller) is
+ * incremented for every pair whose two entries differ bit-wise — such a table has no compact copy. */
+int apexmi_rope_pairs(const float* rope, int S, int D, float* pairs, int* mismatch, apexmi_stream_t stream);
 
 /* out[m][j K + k] (bf16, j = 0..2) = the j-th part of the exact split x = hi + mid + lo of the float x[m][k]:
  * hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (representable).  ldx in floats, ldo >= 3 K in bf16 elements,

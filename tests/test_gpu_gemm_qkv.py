@@ -273,3 +273,41 @@ def test_wan_forward_identical_with_and_without_the_fused_rows_pass():
         ops.qk_rms_rope_rows = orig
     assert n == 4 and len(calls) == 4                    # 2 blocks x (self + cross query side)
     assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
+def test_compact_rope_pairs_table_is_bit_identical_and_optional():
+    """Round 6: the fused epilogue reads the rotary table from its compact [2, S, 64] copy when the table's entries come in equal
+    pairs (`ops.rope_pairs`, `apexmi_rope_pairs` + `apexmi_gemm_bf16_grouped_qkv_pairs`): same outputs bit for bit as with the full
+    table, on both tilings; a table that is NOT pair-duplicated has no compact copy and takes the full-table path."""
+    from apex_studio_amd import lib as _l, ops
+    H, K, S = 4, 512, 1536
+    x, w, b = _rand((S, K), 1), _rand((3 * H * 128, K), 3, K ** -0.5), _rand((3 * H * 128,), 5, 0.1)
+    nq, nk = _rand((128,), 7) * 0.2 + 1, _rand((128,), 9) * 0.2 + 1
+    rope = _rope(S, 11)
+    pairs = ops.rope_pairs(rope)
+    assert pairs is not None and pairs.shape == (2, S, 64) and torch.equal(pairs, rope[:, :, ::2])
+    assert ops.rope_pairs(rope) is pairs, "made once per table"
+    odd = rope.clone()
+    odd[0, :, 3] += 0.5
+    assert ops.rope_pairs(odd) is None
+    outs = {}
+    try:
+        for tiling in (1, 2):
+            _l.tune_set("gemm.x384", tiling)
+            for on in (True, False):
+                ops.rope_pairs_enabled = on
+                q, k = (torch.full((H, S, 128), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+                vt = torch.zeros(H, 128, S, device=DEV, dtype=torch.bfloat16)
+                ops.gemm_grouped_qkv([x], [w], [b], [None], "bias", [1], [nq], [nk], [0], H, 1e-6, rope, q, k, vt)
+                outs[(tiling, on)] = (q, k, vt)
+    finally:
+        ops.rope_pairs_enabled = True
+        _l.tune_set("gemm.x384", 1)
+    torch.cuda.synchronize()
+    ref = outs[(1, False)]
+    for key, o in outs.items():
+        assert all(torch.equal(a, b_) for a, b_ in zip(o, ref)), key
+    q, k = (torch.full((H, S, 128), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    vt = torch.zeros(H, 128, S, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_grouped_qkv([x], [w], [b], [None], "bias", [1], [nq], [nk], [0], H, 1e-6, odd, q, k, vt)   # full-table path, other values
+    assert not torch.equal(q, ref[0])

@@ -65,11 +65,27 @@ arms = {
     "split": lambda: [(ops.gemm_grouped_qkv([a], [wq[l]], [bq], [None], "bias", [1], [nq], [nk], [0], H, 1e-6, rope, Q, Kk, VT),
                        ops.gemm(a, wm[l], bm, out=cat, epilogue="gelu")) for l in range(L)],
 }
+# the double block's grouped launch (image 4096 + text 512 rows, N 9216) on the 256 x 256 tiling: plain vs fused q/k/v
+ai, at = rnd(4096, K), rnd(512, K)
+wq2 = [rnd(3 * dim, K, scale=K ** -0.5) for _ in range(L)]
+qkv_i, qkv_t = torch.empty(4096, 3 * dim, device=DEV, dtype=torch.bfloat16), torch.empty(512, 3 * dim, device=DEV, dtype=torch.bfloat16)
+arms["dbl_plain"] = lambda: [ops.gemm_grouped([ai, at], [wq[l], wq2[l]], [bq, bq], [qkv_i, qkv_t]) for l in range(L)]
+arms["dbl_qkv"] = lambda: [ops.gemm_grouped_qkv([ai, at], [wq[l], wq2[l]], [bq, bq], [None, None], "bias", [1, 1], [nq, nq], [nk, nk], [512, 0],
+                                                H, 1e-6, rope, Q, Kk, VT) for l in range(L)]
 res = {}
+only = os.environ.get("ARMS")
+if only:
+    arms = {k: v for k, v in arms.items() if k in only.split(",")}
 for rnd_ in range(2):
     for name, fn in arms.items():
         res.setdefault(name, []).append(round(timeit(fn), 1))
-    lib.tune_set("gemm.x384_qkv", 0)
-    res.setdefault("qkv256", []).append(round(timeit(arms["qkv"]), 1))
-    lib.tune_set("gemm.x384_qkv", 1)
-print(json.dumps({"us_per_launch": res, "best": {k: min(v) for k, v in res.items()}}))
+    if not only:
+        lib.tune_set("gemm.x384_qkv", 0)
+        res.setdefault("qkv256", []).append(round(timeit(arms["qkv"]), 1))
+        lib.tune_set("gemm.x384_qkv", 1)
+res["pairs_off"] = []
+ops.rope_pairs_enabled = False        # the direct-load epilogue (full table), same binary
+for rnd_ in range(2):
+    res["pairs_off"].append({k: round(timeit(arms[k]), 1) for k in ("qkv", "dbl_qkv") if k in arms})
+ops.rope_pairs_enabled = True
+print(json.dumps({"us_per_launch": res, "best": {k: min(v) for k, v in res.items() if k != "pairs_off"}}))
