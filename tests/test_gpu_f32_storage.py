@@ -597,13 +597,13 @@ def test_flux_forward_through_shipped_flash_and_fused_qkv(shipped_kernels):
     ref32, ref16 = orc(*args), orc(*args, policy=OL.BF16_STORAGE)
     m = FluxTransformer2DModel(**cfg, device=DEV, dtype=BF).set_storage_dtype(F32)
     m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
-    names = ["apexmi_attn_fwd_prepared_f32", "apexmi_attn_fwd_prepared_ws", "apexmi_gemm_bf16_grouped_qkv", "apexmi_qkv_prepare_f32"]
+    names = ["apexmi_attn_fwd_prepared_f32", "apexmi_attn_fwd_prepared_ws", "apexmi_gemm_bf16_grouped_qkv_pairs", "apexmi_qkv_prepare_f32"]
     names = [n for n in names if hasattr(_Spy([]).lib, n)]
     with _Spy(names) as spy:
         out = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0]
         torch.cuda.synchronize()
     assert out.dtype == F32 and next(iter(m._ws.values())).X.dtype == F32
-    assert spy.count["apexmi_attn_fwd_prepared_ws"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv"] == 2, spy.count
+    assert spy.count["apexmi_attn_fwd_prepared_ws"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv_pairs"] == 2, spy.count
     assert spy.count["apexmi_attn_fwd_prepared_f32"] == 0 and spy.count.get("apexmi_qkv_prepare_f32", 0) == 0, spy.count
     e, e16 = _rel(out, ref32), _rel(ref16, ref32)
     print(f"[shipped-kernel verification] flux 1096 tokens, float storage, shipped flash + fused QKV epilogue: rel L2 {e:.2e} vs the fp32 "
@@ -613,7 +613,7 @@ def test_flux_forward_through_shipped_flash_and_fused_qkv(shipped_kernels):
     shipped_kernels.verify_through_shipped_kernels(False)
     with _Spy(names) as spy:
         out2 = m(return_dict=False, **{k: v.to(DEV) for k, v in inp.items()})[0]
-    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv"] == 0 and _rel(out2, ref32) <= TOL
+    assert spy.count["apexmi_attn_fwd_prepared_f32"] == 2 and spy.count["apexmi_gemm_bf16_grouped_qkv_pairs"] == 0 and _rel(out2, ref32) <= TOL
 
 
 @pytest.mark.parametrize("name", ["mid"])
