@@ -492,6 +492,7 @@ class FluxTransformer2DModel(LoraAdapterMixin, nn.Module):
             return rk[3]
         ids = torch.cat((txt_ids, img_ids), dim=0).float()
         rope = ops.rope_table_axes(ids, self.config.axes_dims_rope, 10000.0)
+        ops.rope_pairs(rope, trusted=True)      # the compact copy the fused q/k/v epilogue reads, made HERE with the table (before any stream forks)
         self._rope_cache = (txt_ids, img_ids, ver, rope, self.storage_dtype) if cacheable else None
         return rope
 

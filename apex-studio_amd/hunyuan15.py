@@ -300,6 +300,7 @@ class HunyuanVideo15Transformer3DModel(LoraAdapterMixin, nn.Module):
             ids = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3)
             ids = torch.cat([torch.zeros(s_txt, 3), ids], dim=0).to(self.device)      # condition rows: angle 0
             t = ops.rope_table_axes(ids.contiguous(), self.config.rope_axes_dim, float(self.config.rope_theta))
+            ops.rope_pairs(t, trusted=True)     # the compact copy the fused q/k/v epilogue reads, made with the table
             self._rope = {key: t}
         return t
 

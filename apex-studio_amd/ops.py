@@ -425,10 +425,12 @@ def gemm_grouped_qkv(a_list, w_list, bias_list, out_list, epilogue, is_qkv, norm
 rope_pairs_enabled = True      # A/B switch (tests, tools): False = the fused epilogue reads the full [2, S, 128] table
 
 
-def rope_pairs(rope: torch.Tensor) -> Optional[torch.Tensor]:
+def rope_pairs(rope: torch.Tensor, trusted: bool = False) -> Optional[torch.Tensor]:
     """The compact copy [2, S, D / 2] of a rotary table whose entries come in equal pairs (apexmi_rope_table_axes writes every
     cos / sin twice), made ONCE per table (cached on the tensor; tables are cached per geometry by the models) — the fused q/k/v
-    epilogue reads half the bytes from it.  None for a table that is not pair-duplicated (checked on the device, one read)."""
+    epilogue prefetches its rows from it.  None for a table that is not pair-duplicated (checked on the device, one host read per
+    table).  `trusted`: the caller made the table with `rope_table_axes` (pairs by construction): no check, no host read — the
+    models pass it, so a table rebuilt per call (ids that are inference tensors) costs one more small launch, not a sync."""
     if not rope_pairs_enabled:
         return None
     key = (rope.data_ptr(), tensor_version(rope))
@@ -441,7 +443,7 @@ def rope_pairs(rope: torch.Tensor) -> Optional[torch.Tensor]:
     out = torch.empty((2, S, D // 2), dtype=torch.float32, device=rope.device)
     bad = torch.zeros((), dtype=torch.int32, device=rope.device)
     _l.check(_l.load().apexmi_rope_pairs(rope.data_ptr(), S, D, out.data_ptr(), bad.data_ptr(), _stream()), "rope_pairs")
-    res = out if int(bad.item()) == 0 else None
+    res = out if (trusted or int(bad.item()) == 0) else None
     try:
         rope._apex_pairs = (key, res)
     except Exception:

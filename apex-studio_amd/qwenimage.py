@@ -251,6 +251,7 @@ class QwenImageTransformer2DModel(LoraAdapterMixin, nn.Module):
             tt = torch.arange(max_idx, max_idx + s_txt)
             ids = torch.cat([torch.stack([tt, tt, tt], dim=-1)] + vids, dim=0).float().to(self.device)
             t = ops.rope_table_axes(ids.contiguous(), self.config.axes_dims_rope, 10000.0)
+            ops.rope_pairs(t, trusted=True)     # the compact copy the fused q/k/v epilogue reads, made with the table on its stream
             while len(self._rope) >= 4:
                 self._rope.pop(next(iter(self._rope)))
             self._rope[key] = t
