@@ -37,7 +37,7 @@ if os.environ.get("APEXMI_DEBUG", "0") not in ("", "0"):
 # scratch in their loop.  The compiler places the asm's inputs around the clobbered ranges; if an upgrade cannot, it either fails
 # the build or spills — the second is silent, so every build parses `-Rpass-analysis=kernel-resource-usage` and refuses a binary
 # whose listed kernels use scratch or spill (source file -> substrings of the mangled kernel names).
-NO_SPILL = {"attention.hip": ["attn_fwd_d128_w64_kernel"]}
+NO_SPILL = {"attention.hip": ["attn_fwd_d128_w64_kernel", "attn_fwd_d128_w64r_kernel"]}
 REMARKS = "-Rpass-analysis=kernel-resource-usage"
 
 

@@ -35,6 +35,9 @@
 #include <stdlib.h>
 __device__ unsigned long long* d_attn_trace = nullptr;
 #endif
+// workgroups of attn_fwd_d128_w64_kernel that re-ran their tiles with the running-maximum loop (attn_w64_kernel.h); read and
+// cleared by apexmi_attn_w64_fallbacks
+__device__ unsigned int d_attn_w64_fallbacks = 0;
 
 
 #include <cstdint>
@@ -842,12 +845,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_d128_c4_kernel(
 // MFMA -> VALU hazards are the generator's): hipcc's allocator spilled 160-220 registers on every C++ form of it.
 APEXMI_DEVICE int w64_perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
+// Shipped (round 6): the loop WITHOUT a per-tile running maximum (attn_w64_first.inc: every row keeps the integer maximum of tile
+// 0), checked at the end, with the running-maximum loop (attn_w64_body.inc) as the workgroup's fallback — attn_w64_kernel.h.
 #define W64_NAME attn_fwd_d128_w64_kernel
+#define W64_BODY "attn_w64_first.inc"
+#define W64_FALLBACK "attn_w64_body.inc"
+#include "attn_w64_kernel.h"
+#undef W64_NAME
+#undef W64_BODY
+#undef W64_FALLBACK
+// the running-maximum loop alone (round 5's kernel; attn.w64 = 8): the A/B arm and the reference the fallback is tested against
+#define W64_NAME attn_fwd_d128_w64r_kernel
 #define W64_BODY "attn_w64_body.inc"
 #include "attn_w64_kernel.h"
 #undef W64_NAME
 #undef W64_BODY
 #ifdef APEXMI_ATTN_W64_ABLATE   // timing-only variants of the loop (WRONG results): tools/attn_w64_ablate.sh
+// attn.w64 = 9: the shipped loops behind round 5's 8-byte epilogue stores (A/B of the 16-byte stores)
+#define W64_NAME attn_fwd_d128_w64x2_kernel
+#define W64_BODY "attn_w64_first.inc"
+#define W64_FALLBACK "attn_w64_body.inc"
+#define W64_STORE_X2 1
+#include "attn_w64_kernel.h"
+#undef W64_NAME
+#undef W64_BODY
+#undef W64_FALLBACK
+#undef W64_STORE_X2
 #define W64_NAME attn_fwd_d128_w64_abl1_kernel
 #define W64_BODY "w64_ablate/v1.inc"
 #include "attn_w64_kernel.h"
@@ -1431,7 +1454,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 namespace {
 int g_attn_split = 1;   // apexmi_tune_set("attn.split", 0/1)
 int g_attn_stages = 2;  // apexmi_tune_set("attn.stages", 2/3): LDS stages of the shipped 4-cluster kernel
-int g_attn_w64 = 1;     // apexmi_tune_set("attn.w64", 0/1): main launch on attn_fwd_d128_w64_kernel (shipped) or on the 4-cluster kernel
+int g_attn_w64 = 1;     // apexmi_tune_set("attn.w64", 0/1/8): main launch on attn_fwd_d128_w64_kernel (1, shipped), on its running-maximum form attn_fwd_d128_w64r_kernel (8), or on the 4-cluster kernel (0)
 int g_attn_xv = 0;      // apexmi_tune_set("attn.xv", 0..7): experiment bits of the 4-cluster kernel (its comment)
 constexpr int ATT_NSPLIT = 4, ATT_NCU = 256;
 // the tail of an 8-wave launch worth splitting: a last round with at most a quarter of the CUs busy after 1..8 full ones
@@ -1562,7 +1585,8 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
         if (g_attn_w64) {
             // ---- shipped main launch: one wave per SIMD, 64 query rows per wave (attn_fwd_d128_w64_kernel); the split tail
             // below stays on the 4-cluster kernel ----
-            auto w64 = attn_fwd_d128_w64_kernel;
+            auto w64 = g_attn_w64 == 8 ? attn_fwd_d128_w64r_kernel : attn_fwd_d128_w64_kernel;
+            const int w64_lds = 4 * ATT_STAGE + 16;          // the rings + the fallback vote's word
 #ifdef APEXMI_ATTN_W64_ABLATE
             switch (g_attn_w64) {
                 case 2: w64 = attn_fwd_d128_w64_abl1_kernel; break;
@@ -1571,14 +1595,15 @@ static int attn_fwd_prepared_impl(const void* q, const void* k, const void* vt, 
                 case 5: w64 = attn_fwd_d128_w64_abl4_kernel; break;
                 case 6: w64 = attn_fwd_d128_w64_abl5_kernel; break;
                 case 7: w64 = attn_fwd_d128_w64_abl6_kernel; break;
+                case 9: w64 = attn_fwd_d128_w64x2_kernel; break;
                 default: break;
             }
-            (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
+            (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, w64_lds);
 #endif
-            static uint64_t w64_attr = 0;
-            APEXMI_SET_ATTR_ONCE(w64_attr,
-                (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE));
-            hipLaunchKernelGGL(w64, dim3(main_wgs), dim3(256), 4 * ATT_STAGE, stream, (const bf16_t*)q, (const bf16_t*)k,
+            static uint64_t w64_attr[2] = {};
+            APEXMI_SET_ATTR_ONCE(w64_attr[g_attn_w64 == 8],
+                (void)hipFuncSetAttribute((const void*)w64, hipFuncAttributeMaxDynamicSharedMemorySize, w64_lds));
+            hipLaunchKernelGGL(w64, dim3(main_wgs), dim3(256), w64_lds, stream, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)vt, (bf16_t*)out, H, Sq, Sk, Skp, nqb, main_wgs, o_strides[0], o_strides[1],
                                o_strides[2], c);
             if (int rc = apexmi_check_launch("attn_fwd_d128_w64")) return rc;
@@ -1627,6 +1652,17 @@ void apexmi_set_attn_c4(int v) { g_attn_c4 = v; }
 void apexmi_set_attn_stages(int v) { g_attn_stages = v; }
 void apexmi_set_attn_xv(int v) { g_attn_xv = v; }
 void apexmi_set_attn_w64(int v) { g_attn_w64 = v; }
+
+extern "C" int apexmi_attn_w64_fallbacks(uint64_t* count) {
+    APEXMI_REQUIRE(count, "attn_w64_fallbacks: null count");
+    unsigned int n = 0, zero = 0;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(d_attn_w64_fallbacks), sizeof(n));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(d_attn_w64_fallbacks), &zero, sizeof(zero));
+    APEXMI_REQUIRE(e == hipSuccess, "attn_w64_fallbacks: %s", hipGetErrorString(e));
+    *count = n;
+    return 0;
+}
 
 extern "C" size_t apexmi_attn_workspace_bytes(int B, int H, int Sq, int Sk, int D, int dtype) {
     if (dtype == APEXMI_BF16 && D != HD && D % 128 == 0 && D <= 1024 && (int64_t)Sq * Sk >= 256 * 256)

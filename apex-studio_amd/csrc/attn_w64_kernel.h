@@ -1,6 +1,16 @@
 // The C++ shell of attn_fwd_d128_w64_kernel (attention.hip): address set-up, ONE asm statement (the generated loop, W64_BODY), the
 // normalising epilogue.  Included once per loop body: the shipped one, and the timing-only ablations of tools/attn_w64_ablate.sh
 // (-DAPEXMI_ATTN_W64_ABLATE, side library).  W64_NAME = kernel name, W64_BODY = the generated include.
+// W64_FALLBACK (optional) = a second generated loop with the per-tile running maximum: W64_BODY is then the loop WITHOUT one (the
+// generator's max=first: every row keeps the integer maximum tile 0 gave it, so a tile carries no row-max chain, no raise test and
+// no rescale test).  An integer shift of the maximum scales every probability, row sum and numerator by the same power of two, so
+// as long as nothing leaves the f32 range the result has the rounding points of the running-maximum loop (and is that loop's bit
+// for bit wherever it would not have raised its maximum after tile 0; elsewhere the exponent's f32 argument s c - m is rounded at
+// another magnitude: a bf16 ulp on a few elements, neither closer to nor further from the exact softmax).  The shell checks the
+// range — every row sum <= 2^60, which bounds every exponent of the row by +60 while tile 0's own maximum keeps the sum >= 1/2 —
+// and a workgroup in which any row fails (scores that tower > 41 nats above the first 64 keys' best, inf, NaN) runs the
+// W64_FALLBACK loop from scratch.  The workgroups' vote goes through
+// one LDS word behind the rings (the launch allocates 4 * ATT_STAGE + 16 bytes); d_attn_w64_fallbacks counts the re-runs.
 __global__ __launch_bounds__(256, 1) void W64_NAME(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int H, int Sq, int Sk, int Skp, int nqb, int total, int64_t o_sb,
@@ -51,6 +61,10 @@ __global__ __launch_bounds__(256, 1) void W64_NAME(
 #endif
     f32x16 o0, o1, o2, o3, o4, o5, o6, o7;
     float la, lb;
+#ifdef W64_FALLBACK
+    const int flag_at = 4 * ATT_STAGE;                     // one LDS word behind the K / V^T rings
+    if (tid == 0) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_at), "v"(0) : "memory");
+#endif
     asm volatile(
 #include W64_BODY
         : "={a[0:15]}"(o0), "={a[16:31]}"(o1), "={a[32:47]}"(o2), "={a[48:63]}"(o3), "={a[64:79]}"(o4), "={a[80:95]}"(o5),
@@ -60,10 +74,38 @@ __global__ __launch_bounds__(256, 1) void W64_NAME(
         : "memory", "vcc", "scc",
 #include "attn_w64_clobbers.inc"
     );
+#ifdef W64_FALLBACK
+    {
+        // !(x <= 2^60) is true for x > 2^60, inf and NaN.  The partial sums of the two half-rows (lanes l, l ^ 32) are positive, so
+        // testing each half is testing the row.
+        const bool bad = !(la <= 0x1p60f) || !(lb <= 0x1p60f);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_at), "v"(1) : "memory");
+        __syncthreads();                                   // every wave has left the loop: the rings may be staged again
+        int again;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(again) : "v"(flag_at) : "memory");
+        if (__builtin_amdgcn_readfirstlane(again)) {       // workgroup-uniform
+            if (tid == 0) atomicAdd(&d_attn_w64_fallbacks, 1u);
+            asm volatile(
+#include W64_FALLBACK
+                : "={a[0:15]}"(o0), "={a[16:31]}"(o1), "={a[32:47]}"(o2), "={a[48:63]}"(o3), "={a[64:79]}"(o4), "={a[80:95]}"(o5),
+                  "={a[96:111]}"(o6), "={a[112:127]}"(o7), [la] "=&v"(la), [lb] "=&v"(lb)
+                : [qa] "v"(qa), [qb] "v"(qbp), [ka] "v"(ka), [va] "v"(va), [vk] "v"(voff_k), [vv] "v"(voff_v), [rk] "s"(rk),
+                  [rv] "s"(rv), [sc] "s"(scale_log2e), [nt] "s"(nt), [rem] "s"(rem), [vp] "s"(v_piece), [w] "s"(wbase), [tp] "s"(tp)
+                : "memory", "vcc", "scc",
+#include "attn_w64_clobbers.inc"
+            );
+        }
+    }
+#endif
 
-    // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3) ----
+    // ---- epilogue: O[q][d] = O^T / l ; lane holds d = 32 dt + 8 g + 4 hi + (0..3).  The two half-rows (lanes l, l ^ 32) exchange
+    // group pairs through v_permlane32_swap so that every lane stores 16 bytes (d = 32 dt + 8 g' .. + 7 with g' = 2 p + hi): 16
+    // dwordx4 stores per lane instead of 32 dwordx2 — the store tail of a workgroup is issue-bound, and a Flux-shape workgroup
+    // (72 tiles) pays it once per 72 tiles ----
     const int b = hb / H, h = hb % H;
     const f32x16* oo[2][4] = {{&o0, &o1, &o2, &o3}, {&o4, &o5, &o6, &o7}};
+#ifdef W64_STORE_X2   // A/B arm (side library): the 8-byte stores of round 5
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const float inv = 1.0f / sum_xor32(e ? lb : la);
@@ -82,5 +124,29 @@ __global__ __launch_bounds__(256, 1) void W64_NAME(
                 }
         }
     }
+#else
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float inv = 1.0f / sum_xor32(e ? lb : la);
+        const int qrow = row_a + 32 * e;
+        bf16_t* op = O + (int64_t)b * o_sb + (int64_t)min(qrow, Sq - 1) * o_ss + (int64_t)h * o_sh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f32x16& x = *oo[e][dt];
+                const int g0 = 2 * p, g1 = 2 * p + 1;
+                const uint32_t a0 = pack_bf16(x[4 * g0 + 0] * inv, x[4 * g0 + 1] * inv);
+                const uint32_t a1 = pack_bf16(x[4 * g0 + 2] * inv, x[4 * g0 + 3] * inv);
+                const uint32_t b0 = pack_bf16(x[4 * g1 + 0] * inv, x[4 * g1 + 1] * inv);
+                const uint32_t b1 = pack_bf16(x[4 * g1 + 2] * inv, x[4 * g1 + 3] * inv);
+                // swap(a, b): {a[0:31] | b[0:31]}, {a[32:63] | b[32:63]} -> low lanes: own g0 + partner's g0; high: partner's g1 + own g1
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (qrow < Sq) *(u32x4*)(op + dt * 32 + (2 * p + hi) * 8) = o;
+            }
+    }
+#endif
 }
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "apexmi_attn_prepared_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "apexmi_attn_fwd_prepared_ws": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, c_i64p, C.c_float, vp, C.c_size_t, vp]),
+    "apexmi_attn_w64_fallbacks": (C.c_int, [C.POINTER(C.c_uint64)]),
     "apexmi_attn_framecausal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "apexmi_attn_fwd_framecausal": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               c_i64p, c_i64p, c_i64p, c_i64p, C.c_float, vp, C.c_size_t, vp]),
@@ -188,6 +189,13 @@ def i64x3(vals):
 
 def tune_set(key: str, value: int) -> None:
     check(load().apexmi_tune_set(key.encode(), int(value)), "tune_set")
+
+
+def attn_w64_fallbacks() -> int:
+    """workgroups of the large-attention kernel that re-ran with the running-maximum loop since the last call (synchronises)"""
+    n = C.c_uint64(0)
+    check(load().apexmi_attn_w64_fallbacks(C.byref(n)), "attn_w64_fallbacks")
+    return int(n.value)
 
 
 def prof_enable(on: bool) -> None:

@@ -104,6 +104,15 @@ int apexmi_attn_fwd_prepared_ws(const void* q, const void* k, const void* vt, vo
                                 int Skp, const int64_t o_strides[3], float softmax_scale, void* workspace,
                                 size_t workspace_bytes, apexmi_stream_t stream);
 
+/* The main launch of a large prepared attention (>= 140 workgroups of 256 query rows: attn_fwd_d128_w64_kernel) keeps, for every
+ * query row, the INTEGER base-2 maximum its first 64 keys gave it and carries no per-tile running maximum (an integer shift of
+ * the maximum scales probabilities, row sum and numerator by one power of two: same rounding points as the running-maximum loop).  At the end every row sum
+ * is checked against 2^60; a workgroup in which one fails — a later score more than ~41 nats above the best of the first 64
+ * keys, inf, NaN — recomputes its 256 rows with the running-maximum loop (softmax as R/src/attention/functions.py:338-377 defines
+ * it for any input).  This returns the number of workgroups that took that second pass since the last call and clears the
+ * count; it synchronises the device (a test / diagnostics call, not part of a step). */
+int apexmi_attn_w64_fallbacks(uint64_t* count);
+
 /* HunyuanVideo15AttnBlock.forward (vae/hunyuanvideo15/model.py:130-214): one head of C channels over frames x (H W)
  * tokens with the frame-causal mask of prepare_causal_attention_mask (:143-165): token i attends the keys of frames
  * <= its own, `block` = tokens per frame.  bf16, D = C a multiple of 128 up to 1024, any S; materialised through the GEMM
@@ -235,6 +244,8 @@ int apexmi_attn_fwd_bias(const void* q, int64_t ldq, const void* k, int64_t ldk,
  *                  packed-f32 softmax (v_pk_fma_f32 / v_pk_add_f32), bit 2 static priority for waves 4..7.  Default 3
  *                  (= packed softmax: +0.5..0.9 % on the Flux / Qwen / Wan shapes; the other two bits measured neutral / -0.5 %)
  *   "attn.split"   1: a nearly empty last round runs as 4 key ranges + merge (needs the _ws entry point's scratch)
+ *   "attn.w64"     1 (default): main launch of >= 140 workgroups on the one-wave-per-SIMD kernel, first-tile maximum + checked
+ *                  fallback (apexmi_attn_w64_fallbacks) | 8: the same kernel with the per-tile running maximum | 0: 4-cluster kernel
  *   "qk.group"     1: q/k norm + RoPE four heads per lane group with the V transpose in the same launch | 2: without | 0: one head
  *   "ln.wave"      1: wave-per-row LayerNorm kernel for C in {3072, 3584, 5120}
  * Returns non-zero for an unknown key. */

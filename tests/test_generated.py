@@ -14,6 +14,12 @@ def test_attn_w64_loop_is_what_its_generator_writes(tmp_path):
                    capture_output=True)
     committed = open(os.path.join(ROOT, "apex-studio_amd", "csrc", "attn_w64_body.inc")).read()
     assert out.read_text() == committed
+    # the shipped first pass: the same generator with max=first (no per-tile running maximum; attn_w64_kernel.h)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_w64.py"), f"--out={out}", "--opt=max=first"], check=True,
+                   capture_output=True)
+    first = open(os.path.join(ROOT, "apex-studio_amd", "csrc", "attn_w64_first.inc")).read()
+    assert out.read_text() == first
+    assert "v_max3_f32" in committed and first.count("v_max3_f32") == 28      # only the prologue's tile 0 looks for a maximum
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_w64.py"), f"--out={out}", "--clobbers"], check=True,
                    capture_output=True)
     assert (tmp_path / "attn_w64_clobbers.inc").read_text() == \
@@ -25,7 +31,7 @@ def test_attn_w64_clobber_list_covers_the_registers_the_loop_names():
     (a[0:127] = O^T): hipcc keeps its own values out of exactly those registers."""
     import re
     csrc = os.path.join(ROOT, "apex-studio_amd", "csrc")
-    body = open(os.path.join(csrc, "attn_w64_body.inc")).read()
+    body = open(os.path.join(csrc, "attn_w64_body.inc")).read() + open(os.path.join(csrc, "attn_w64_first.inc")).read()
     clob = set(re.findall(r'"([vas]\d+)"', open(os.path.join(csrc, "attn_w64_clobbers.inc")).read()))
     used = set()
     for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]|\b([vas])(\d+)\b", body):
@@ -52,11 +58,16 @@ def test_build_refuses_a_w64_kernel_that_spills():
 ./attn_w64_kernel.h:7:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
 ./attn_w64_kernel.h:7:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
 ./attn_w64_kernel.h:7:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark: Function Name: _ZN12_GLOBAL__N_125attn_fwd_d128_w64r_kernelEPKtS1_S1_Ptiiiiiilllf [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+./attn_w64_kernel.h:7:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
 attention.hip:1103:1: remark: Function Name: _ZN12_GLOBAL__N_119softmax_rows_kernelEPKflifPtlii [-Rpass-analysis=kernel-resource-usage]
 attention.hip:1103:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]
 """
     res = b.parse_resource_remarks(ok)
-    k = next(x for x in res if "w64" in x)
+    k = next(x for x in res if "w64_kernel" in x)
     assert res[k]["VGPRs"] == 256 and res[k]["AGPRs"] == 196 and res[k]["ScratchSize"] == 0
     b.check_no_spill("attention.hip", ok)                     # another kernel's scratch is not its business
     for field in ("ScratchSize [bytes/lane]: 0", "VGPRs Spill: 0", "SGPRs Spill: 0"):

@@ -587,13 +587,21 @@ def test_attention_w64_kernel(shape):
     lib.tune_set("attn.waves", 8)
     try:
         lib.tune_set("attn.w64", 1)
+        lib.attn_w64_fallbacks()
         out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
         out2 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+        again = lib.attn_w64_fallbacks()
+        lib.tune_set("attn.w64", 8)
+        run = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
         lib.tune_set("attn.w64", 0)
         c4 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
     finally:
         lib.tune_set("attn.waves", 0)
         lib.tune_set("attn.w64", 1)
+    # the shipped loop keeps tile 0's integer maximum: no workgroup needed its second pass, and the result is the running-maximum
+    # loop's bit for bit (an integer shift of the maximum changes no mantissa)
+    assert again == 0, again
+    assert torch.equal(out.cpu(), run.cpu())
     _check(out, OL.sdpa(q.float(), k.float(), v.float()), 1e-2, f"attention w64 {shape}", ulp=3.0)
     # the assert that can fail: same inputs, the oracle rounding exactly where the kernel rounds -> the like-for-like bar (5e-4)
     measured(f"attention_w64.{shape}.like_for_like",      # measured 0 .. 1.1e-4 (round 6)
@@ -613,14 +621,74 @@ def test_attention_w64_running_max_rescale_and_flux_shape():
     q = seeded((1, H, S, 128), 811, torch.bfloat16)
     k = seeded((1, H, S, 128), 812, torch.bfloat16)
     v = seeded((1, H, S, 128), 813, torch.bfloat16)
-    k[0, :, 3000] = q[0, :, 100] * 4.0          # rows near 100 get a score far above everything seen in the first 46 tiles
+    k[0, :, 3000] = q[0, :, 100] * 6.0          # row 100 gets a score far above everything seen in the first 46 tiles
     k[0, :, 4500] = q[0, :, 2000] * 8.0
     lib.tune_set("attn.w64", 1)
-    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    lib.attn_w64_fallbacks()
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+    again = lib.attn_w64_fallbacks()
+    try:
+        lib.tune_set("attn.w64", 8)
+        run = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+    finally:
+        lib.tune_set("attn.w64", 1)
     rows = torch.cat([torch.arange(90, 110), torch.arange(1990, 2010), torch.arange(0, S, 257)])
     ref = OL.sdpa(q[:, :, rows].float(), k.float(), v.float())
     _check(out[:, :, rows], ref, 1e-2, "attention w64 rescale", ulp=3.0)
     assert torch.isfinite(out).all()
+    # row 100's score stands ~90 binades over its first tile's best (row sum > 2^60), row 2000's ~125: exactly the workgroups
+    # that hold those rows (one per head each) took the running-maximum pass and carry that loop's result bit for bit.  The other
+    # rows see the two planted keys 10-25 binades above their first tile: no second pass, same rounding points, but the
+    # exponent's f32 argument s c - m is rounded at another magnitude where the two loops hold different maxima -> a bf16 ulp on
+    # a few elements
+    assert again == 2 * H, again
+    a, b = out.cpu(), run.cpu()
+    for r0 in (0, 1792):
+        assert torch.equal(a[:, :, r0:r0 + 256], b[:, :, r0:r0 + 256]), r0
+    frac = float((a != b).float().mean())
+    rel = _rel(a, b)
+    assert frac < 2e-3 and rel < 2e-4, (frac, rel)
+    measured("attention_w64.first_vs_running.peaked", rel, 2e-4)
+
+
+def test_attention_w64_fallback_on_non_finite_and_uniform_rows():
+    """The first-tile-maximum loop's check is `!(row sum <= 2^60)`: inf / NaN scores take the running-maximum pass, so a launch
+    with poisoned rows returns what the running-maximum kernel returns (NaN rows included, nothing else touched); rows whose
+    scores are all equal (q = 0) and rows far BELOW their first tile never trigger it."""
+    from apex_studio_amd import lib
+    ops = _ops()
+    H, S = 3, 2048                          # 24 workgroups of 256 rows -> forced onto the w64 kernel through attn.waves
+    q = seeded((1, H, S, 128), 821, torch.bfloat16)
+    k = seeded((1, H, S, 128), 822, torch.bfloat16)
+    v = seeded((1, H, S, 128), 823, torch.bfloat16)
+    q[0, :, 300] = 0                        # uniform row
+    k[0, :, :64] *= 6.0                     # the first tile holds every row's best score by far: later tiles sit far below
+    q[0, 1, 700, 5] = float("inf")
+    q[0, 2, 1500, 9] = float("nan")
+    lib.tune_set("attn.waves", 8)
+    try:
+        lib.tune_set("attn.w64", 1)
+        lib.attn_w64_fallbacks()
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+        again = lib.attn_w64_fallbacks()
+        lib.tune_set("attn.w64", 8)
+        run = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).clone()
+    finally:
+        lib.tune_set("attn.waves", 0)
+        lib.tune_set("attn.w64", 1)
+    assert again == 2, again                # the two workgroups that hold the poisoned rows
+    a, b = out.cpu().float(), run.cpu().float()
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+    good = torch.ones(H, S, dtype=torch.bool)
+    good[1, 700] = False
+    good[2, 1500] = False
+    assert torch.isfinite(a[0][good]).all() and torch.isnan(a[0, 1, 700]).all() and torch.isnan(a[0, 2, 1500]).all()
+    qq = q.clone()
+    qq[0, 1, 700, 5] = 0
+    qq[0, 2, 1500, 9] = 0
+    ref = OL.sdpa(qq.float(), k.float(), v.float())
+    assert _rel(a[0][good], ref[0][good]) < 1e-2
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])

@@ -29,7 +29,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
+OPT = {"max": "run", "align": 6, "rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -442,7 +442,10 @@ def tile(em, sg, more, more2, dma):
     q = []
     if ABL["fill_y"]:
         adds = add_ops(st) if OPT["adds_in"] == "Y" else []
-        sm1 = sm1_ops(ns, inline_raise=False) if more else []
+        if OPT["max"] == "first":    # the running maximum stays what tile 0 made it (the kernel's shell checks the row sums at the end)
+            sm1 = scale_ops(ns) if more else []
+        else:
+            sm1 = sm1_ops(ns, inline_raise=False) if more else []
         q += adds + sm1
     _, gaps = spread(q, 32)
     raise_lbl, raise_ret = em.label("raise"), em.label("raised")
@@ -491,11 +494,11 @@ def tile(em, sg, more, more2, dma):
                 rowsum_mfma(em, qq >> 2, kk, (qq >> 1) & 1)
             if more2 and slot == 31 - OPT["kread_early"]:
                 k_first_reads(em, k2st)                  # first K fragments of tile t + 2, for phase X of the next tile
-    em.pending_rescale = rescale_test(em) if more else None
+    em.pending_rescale = rescale_test(em) if (more and OPT["max"] != "first") else None
     em.i("s_add_i32 s40, s40, 1")
     em.i("s_add_i32 s45, s45, 16384")                    # K / V^T byte offsets of the tile the NEXT body stages
     em.i("s_add_i32 s46, s46, 128")
-    em.pending_raise = (raise_lbl, raise_ret) if (more and ABL["fill_y"] and ABL["dec"]) else None
+    em.pending_raise = (raise_lbl, raise_ret) if (more and ABL["fill_y"] and ABL["dec"] and OPT["max"] != "first") else None
     if TRACE:   # s[64:65] += phase X, s[66:67] += phase Y (both halves), s[68:69] += DMA wait + barrier
         em.i("s_memtime s[88:89]")
         em.i("s_waitcnt lgkmcnt(0)")                     # (drains the early K reads too: the next body's counted waits stay valid)
@@ -647,6 +650,8 @@ def main():
     rare = []                            # (raise labels, rescale labels) of every body: emitted behind the bodies
 
     def body(k, sg, more, more2, dma):
+        if OPT["align"] and k == "f" and sg == 0:
+            em.i(f".p2align {OPT['align']}")        # the steady-state loop starts on a 2^align-byte boundary
         em.i(f"{labels[(k, sg)]}:")
         tile(em, sg, more, more2, dma)
         rare.append((em.pending_raise, em.pending_rescale))
