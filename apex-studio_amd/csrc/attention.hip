@@ -871,6 +871,9 @@ APEXMI_DEVICE int w64_perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i &
 #undef W64_BODY
 #undef W64_FALLBACK
 #undef W64_STORE_X2
+#ifdef APEXMI_ATTN_W64_VAR_DMA_WAVE   // the variants below were generated with --opt=dma=wave (tools/attn_w64_variants.sh, W64VAR_FLAGS)
+#define W64_DMA_WAVE 1
+#endif
 #define W64_NAME attn_fwd_d128_w64_abl1_kernel
 #define W64_BODY "w64_ablate/v1.inc"
 #include "attn_w64_kernel.h"
@@ -901,6 +904,7 @@ APEXMI_DEVICE int w64_perm32(int i) { return (i & ~0xC) | ((i & 4) << 1) | ((i &
 #include "attn_w64_kernel.h"
 #undef W64_NAME
 #undef W64_BODY
+#undef W64_DMA_WAVE
 #endif
 
 // ---- the same kernel on v_mfma_f32_16x16x32_bf16 -----------------------------------------------

@@ -41,12 +41,28 @@ __global__ __launch_bounds__(256, 1) void W64_NAME(
         rk[j] = __builtin_amdgcn_readfirstlane(rk[j]);
         rv[j] = __builtin_amdgcn_readfirstlane(rv[j]);
     }
+#ifdef W64_DMA_WAVE
+    // the generator's dma=wave: a wave's four pieces of a tile are contiguous in the image (K rows 16 wave + 4 i + (lane >> 4), V^T
+    // rows 32 wave + 8 i + (lane >> 3)): one M0 write per four loads, the instruction offset i * 1024 moves the LDS address.  That
+    // offset enters the global address too, so the K descriptor's base stands 1024 bytes low (piece 2's lane offset is its key
+    // offset MINUS 1024) and every lane offset carries + 1024; the range grows by the same 1024.
+    rk[0] = __builtin_amdgcn_readfirstlane((uint32_t)(kb - 1024));
+    rk[1] = __builtin_amdgcn_readfirstlane((uint32_t)((kb - 1024) >> 32) & 0xffffu);
+    rk[2] = __builtin_amdgcn_readfirstlane((uint32_t)(Sk * (HD * 2) + 1024));
+    const int krow0 = 16 * wave + (lane >> 4);
+    const int voff_k = krow0 * (HD * 2) + (((lane & 15) ^ (lane >> 4)) << 4) + 1024;
+    const int vrow0 = 32 * wave + (lane >> 3);
+    const int voff_v = vrow0 * Skp * 2 + (((lane & 7) ^ ((vrow0 >> 1) & 3)) << 4);
+    const int v_piece = __builtin_amdgcn_readfirstlane(8 * Skp * 2 - 1024);
+    const int wbase = wave * 4096;
+#else
     const int krow0 = 4 * wave + (lane >> 4);
     const int voff_k = w64_perm32(krow0) * (HD * 2) + (((lane & 15) ^ krow0) << 4);
     const int vrow0 = 8 * wave + (lane >> 3);
     const int voff_v = vrow0 * Skp * 2 + (((lane & 7) ^ ((vrow0 >> 1) & 7)) << 4);
     const int v_piece = __builtin_amdgcn_readfirstlane(32 * Skp * 2);
     const int wbase = wave * 1024;
+#endif
     // fragment reads: K image row l31 (+ 32 kt), chunk (2 ks + hi) ^ (row & 15) = ((hi ^ row) & 15) ^ 2 ks; V^T image row l31 (+ 32 dt),
     // chunk (2 kk + hi) ^ ((row >> 1) & 7)
     const int ka = l31 * 256 + (((hi ^ l31) & 15) << 4);

@@ -56,6 +56,11 @@ namespace {
 // Those figures are from the commit that built it (git log -S APEXMI_GEMM_STREAMK); since the epilogue rewrite later in round 4
 // (one instantiation per activation mode, both residual slabs pre-loaded) the persistent item loop spills 64-191 VGPRs and runs at
 // half the tile launch's rate (profiles/r04_gemm_persistent_probe_b.log) — the build flag is kept for the record, not maintained.
+// 2 (shipped, round 6): the pieces of the 256x256 ping-pong kernel go out in the scalar-base form of global_load_lds; 1: the builtin's
+// 64-bit vector addresses (round 5's form; the A/B arm of profiles/r06_gemm_peel_ab.log)
+#ifndef APEXMI_GEMM_PEEL
+#define APEXMI_GEMM_PEEL 2
+#endif
 #ifndef APEXMI_GEMM_STREAMK
 #define APEXMI_GEMM_STREAMK 0
 #endif
@@ -1216,6 +1221,51 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
                     rw_src[reg][j] += (int64_t)sk.kt0 * w_kstep;
                 }
         }
+#if APEXMI_GEMM_PEEL >= 2
+        // Round 6 (shipped): a piece's address = a UNIFORM base in scalar registers (the tile's first row at the segment's first
+        // K-tile, advanced per K-tile by scalar adds) + a 32-bit lane offset that never changes, issued as the scalar-base form of
+        // global_load_lds — no 64-bit vector add per piece (8 per K-tile and wave before).  The lane offsets stay inside the tile's
+        // 256 rows (row clamps included), so 32 bits hold them for any leading dimension below 2^22 elements.
+        // (the tile's coordinates are workgroup-uniform but not always provably so for the compiler — the persistent forms read
+        // them from an atomic —: v_readfirstlane pins the bases to scalar registers.  M0 is written inside the asm statement; hipcc
+        // itself sets M0 right in front of every LDS-DMA builtin and keeps nothing else in it.)
+        auto uniform_ptr = [](const char* p) {
+            const uint64_t u = (uint64_t)p;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            return (const char*)(((uint64_t)hi << 32) | lo);
+        };
+        const char* const a_base_u = uniform_ptr((G.wpacked & 2) ? (const char*)(P.A + (int64_t)pm * nkt_all * 256 * 64)
+                                                                 : (const char*)(P.A + (int64_t)min(m0, M - 1) * P.lda));
+        const char* const w_base_u = uniform_ptr((G.wpacked & 1) ? (const char*)(P.W + (int64_t)pn * nkt_all * 256 * 64)
+                                                                 : (const char*)(P.W + (int64_t)min(n0, N - 1) * P.ldw));
+        uint32_t ra_off[2][2], rw_off[2][2];
+#pragma unroll
+        for (int reg = 0; reg < 2; ++reg)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ra_off[reg][j] = (uint32_t)(ra_src[reg][j] - a_base_u);
+                rw_off[reg][j] = (uint32_t)(rw_src[reg][j] - w_base_u);
+            }
+        // hipcc selects the 64-bit vector-address form for the builtin whatever the pointer looks like: the scalar-base form by hand
+        // (M0 = the piece's LDS address, one state between the M0 write and the load)
+        const uint32_t smem_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+        auto glds16_s = [&](const char* sbase, uint32_t voff, uint32_t la) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(sbase), "s"(la) : "memory");
+        };
+        auto stage_a = [&](int buf, int kt, int reg) {
+            const uint32_t base = smem_lds + buf * CFG::STAGE;
+            const char* gb = a_base_u + (int64_t)kt * a_kstep;          // (ra_off holds the segment's first K-tile, sk.kt0)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16_s(gb, ra_off[reg][j], base + ra_row[reg][j] * 128);
+        };
+        auto stage_w = [&](int buf, int kt, int reg) {
+            const uint32_t base = smem_lds + buf * CFG::STAGE + CFG::A_BYTES;
+            const char* gb = w_base_u + (int64_t)kt * w_kstep;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16_s(gb, rw_off[reg][j], base + rw_row[reg][j] * 128);
+        };
+#else
         auto stage_a = [&](int buf, int kt, int reg) {
             char* base = smem + buf * CFG::STAGE;
 #pragma unroll
@@ -1230,6 +1280,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
                 glds16(rw_src[reg][j] + (int64_t)kt * w_kstep, base + rw_row[reg][j] * 128);
             }
         };
+#endif
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
         stage_a(0, 0, 0);
         stage_w(0, 0, 0);
@@ -1238,38 +1289,38 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         VMCNT(0);
         PP_BAR();
         if (wm == 1) PP_BAR();
-        for (int kt = 0; kt < nkt; ++kt) {
+        // The last K-tile is peeled off (round 6): the steady-state body carries no `more` test — the compiled loop had five branches
+        // and their scalar set-up per K-tile and wave; with the scalar-base pieces above: Flux GEMM sequence 45.7 -> 44.5 ms
+        // (profiles/r06_gemm_peel_ab.log).  Phase 4 needs no fragment read: n-tile 0's weight fragments of phase 1 are still in
+        // registers (-0.8 % per step against re-reading them).
+        auto ktile = [&](int kt, auto more_c) {
+            constexpr bool more = decltype(more_c)::value;
             const char* As = smem + (kt & 1) * CFG::STAGE;
             const char* Ws = As + CFG::A_BYTES;
-            const bool more = kt + 1 < nkt;
             const int nb = (kt + 1) & 1;
             rd_a(As, 0);
             rd_w(Ws, 0);
-            if (more) stage_a(nb, kt + 1, 0);
-            if (more) { VMCNT(4); } else { VMCNT(2); }
+            if constexpr (more) { stage_a(nb, kt + 1, 0); VMCNT(4); } else { VMCNT(2); }
             PP_SYNC();
             mma(0, 0);
             PP_BAR();
             rd_w(Ws, 1);
-            if (more) stage_w(nb, kt + 1, 0);
-            if (more) { VMCNT(4); } else { VMCNT(0); }
+            if constexpr (more) { stage_w(nb, kt + 1, 0); VMCNT(4); } else { VMCNT(0); }
             PP_SYNC();
             mma(0, 1);
             PP_BAR();
             rd_a(As, 1);
-            if (more) stage_w(nb, kt + 1, 1);
-            if (more) VMCNT(4);
+            if constexpr (more) { stage_w(nb, kt + 1, 1); VMCNT(4); }
             PP_SYNC();
             mma(1, 1);
             PP_BAR();
-            // phase 4 needs no fragment read: n-tile 0's weight fragments of phase 1 are still in registers
-            // (-0.8 % per step against re-reading them)
-            if (more) stage_a(nb, kt + 1, 1);
-            if (more) VMCNT(4);
+            if constexpr (more) { stage_a(nb, kt + 1, 1); VMCNT(4); }
             PP_SYNC();
             mma(1, 0);
             PP_BAR();
-        }
+        };
+        for (int kt = 0; kt + 1 < nkt; ++kt) ktile(kt, std::true_type{});
+        if (nkt > 0) ktile(nkt - 1, std::false_type{});
         if (wm == 0) PP_BAR();
 #undef VMCNT
 #undef PP_SYNC
@@ -2030,9 +2081,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
     Y_VMCNT(0);
     Y_BAR();
     if (wm == 1) Y_BAR();
-    for (int kt = 0; kt < nkt; ++kt) {
+    // last K-tile peeled off: no `more` test in the steady-state body (round 6)
+    auto ktile = [&](int kt, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         const char* St = smem + (kt & 1) * Y_STAGE;
-        const bool more = kt + 1 < nkt;
         const int nb = (kt + 1) & 1;
         // The wave's 10 pieces of the next K-tile go out over the four phases as 2 + 3 + 2 + 3 (DIST 1: the phases that read 10
         // fragments issue two pieces, those that read 6 issue three) or 3 + 3 + 2 + 2 (DIST 0).  A wave's wait covers what the NEXT
@@ -2041,7 +2093,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         // phase 0: k-step 0, m-half 0
         rd_w(St, 0);
         rd_a(St, 0, 0);
-        if (more) {
+        if constexpr (more) {
             stage(nb, kt + 1, 0);
             stage(nb, kt + 1, 1);
             if (DIST == 0) {
@@ -2058,7 +2110,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         Y_BAR();
         // phase 1: k-step 0, m-half 1
         rd_a(St, 1, 0);
-        if (more) {
+        if constexpr (more) {
             if (DIST != 0) stage(nb, kt + 1, 2);
             stage(nb, kt + 1, 3);
             stage(nb, kt + 1, 4);
@@ -2070,7 +2122,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         // phase 2: k-step 1, m-half 0
         rd_w(St, 1);
         rd_a(St, 0, 1);
-        if (more) {
+        if constexpr (more) {
             if (DIST != 0) stage(nb, kt + 1, 5);
             stage(nb, kt + 1, 6);
             if (DIST == 0) stage(nb, kt + 1, 7);
@@ -2080,7 +2132,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         Y_BAR();
         // phase 3: k-step 1, m-half 1
         rd_a(St, 1, 1);
-        if (more) {
+        if constexpr (more) {
             if (DIST != 0) stage(nb, kt + 1, 7);
             stage(nb, kt + 1, 8);
             stage(nb, kt + 1, 9);
@@ -2089,7 +2141,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x384_kernel(const GemmGroup 
         Y_SYNC();
         mma(1);
         Y_BAR();
-    }
+    };
+    for (int kt = 0; kt + 1 < nkt; ++kt) ktile(kt, std::true_type{});
+    if (nkt > 0) ktile(nkt - 1, std::false_type{});
     if (wm == 0) Y_BAR();
 #undef Y_VMCNT
 #undef Y_SYNC

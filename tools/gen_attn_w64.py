@@ -29,7 +29,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"max": "run", "align": 6, "rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
+OPT = {"max": "run", "align": 6, "dma": "piece", "rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -316,6 +316,23 @@ def dma_piece(em, j, stage, part=3):
     them: in the loop a gap's fillers stand there), 3 = both with an s_nop"""
     if not ABL["dma"] and em.in_loop:
         return
+    if OPT["dma"] == "wave":
+        # dma = "wave": a wave's four K (V^T) pieces are CONTIGUOUS in the LDS image (the wave owns image rows 16 wave + 4 i + .. /
+        # 32 wave + 8 i + ..), so one M0 write serves four loads through the instruction offset i * 1024 — 2 instead of 8 scalar
+        # writes per tile.  The offset also enters the global address: the per-piece lane offsets take it back (prologue), and the
+        # shell hands over a K descriptor whose base stands 1024 bytes low (attn_w64_kernel.h, W64_DMA_WAVE).  Same LDS image.
+        i = j & 3
+        if (part & 1) and i == 0:
+            em.i(f"s_add_i32 m0, %[w], {stage * 16384 + (0 if j < 4 else 65536)}")
+            if part == 3:
+                em.i("s_nop 0")
+        if part & 2:
+            io = f" offset:{i * 1024}" if i else ""
+            if j < 4:
+                em.i(f"buffer_load_dwordx4 {'%[vk]' if j == 0 else vr(237 + j)}, %[rk], s45 offen{io} lds")
+            else:
+                em.i(f"buffer_load_dwordx4 {'%[vv]' if j == 4 else vr(236 + j)}, %[rv], s46 offen{io} lds")
+        return
     if part & 1:
         off = stage * 16384 + (j * 4096 if j < 4 else 65536 + (j - 4) * 4096)
         em.i(f"s_add_i32 m0, %[w], {off}")
@@ -557,11 +574,27 @@ def main():
     for kk in range(4):
         em.i(f"v_xor_b32 {vr(VA(kk))}, {kk << 5}, %[va]")
         em.i(f"v_add_u32 {vr(VA(kk))}, 65536, {vr(VA(kk))}")     # the V^T ring starts at 64 KiB
-    for j in range(1, 4):                             # per-piece LDS-DMA offsets: no scalar offset arithmetic in the loop
-        em.i(f"v_add_u32 {vr(237 + j)}, {j * 4096}, %[vk]")
-    em.i(f"v_add_u32 {vr(241)}, %[vp], %[vv]")
-    em.i(f"v_add_u32 {vr(242)}, %[vp], {vr(241)}")
-    em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(242)}")
+    if OPT["dma"] == "wave":
+        # K piece i: image rows 16 wave + 4 i + (lane >> 4) <- keys 16 wave + 4 swap2(i) + (lane >> 4) (perm32 swaps bits 2, 3 of the
+        # row), chunk ^= 4 i; minus the instruction offset i * 1024.  %[vk] = piece 0's offset + 1024 (the descriptor's base is 1024 low)
+        em.i(f"v_xor_b32 {vr(238)}, 64, %[vk]")
+        em.i(f"v_add_u32 {vr(238)}, 1024, {vr(238)}")             # swap2(1) - 1 = +1
+        em.i(f"v_xor_b32 {vr(239)}, 128, %[vk]")
+        em.i(f"v_subrev_u32 {vr(239)}, 1024, {vr(239)}")          # swap2(2) - 2 = -1
+        em.i(f"v_xor_b32 {vr(240)}, 192, %[vk]")                  # swap2(3) - 3 = 0
+        # V^T piece i: image rows (d) 32 wave + 8 i + (lane >> 3), chunk ^= 4 (i & 1); %[vp] = 8 rows of V^T - 1024 bytes
+        em.i(f"v_xor_b32 {vr(241)}, 64, %[vv]")
+        em.i(f"v_add_u32 {vr(241)}, %[vp], {vr(241)}")
+        em.i(f"v_add_u32 {vr(242)}, %[vp], %[vv]")
+        em.i(f"v_add_u32 {vr(242)}, %[vp], {vr(242)}")
+        em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(241)}")
+        em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(243)}")
+    else:
+        for j in range(1, 4):                         # per-piece LDS-DMA offsets: no scalar offset arithmetic in the loop
+            em.i(f"v_add_u32 {vr(237 + j)}, {j * 4096}, %[vk]")
+        em.i(f"v_add_u32 {vr(241)}, %[vp], %[vv]")
+        em.i(f"v_add_u32 {vr(242)}, %[vp], {vr(241)}")
+        em.i(f"v_add_u32 {vr(243)}, %[vp], {vr(242)}")
     em.i("s_mov_b32 s78, %[sc]")                      # {scale, scale} for v_pk_fma_f32
     em.i("s_mov_b32 s79, 0x3f803f80" if OPT["rowsum"] == "dot2c" else "s_mov_b32 s79, %[sc]")     # dot2c: the bf16 pair {1.0, 1.0}
     for e in range(2):
