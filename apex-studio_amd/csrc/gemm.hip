@@ -1227,8 +1227,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         // global_load_lds — no 64-bit vector add per piece (8 per K-tile and wave before).  The lane offsets stay inside the tile's
         // 256 rows (row clamps included), so 32 bits hold them for any leading dimension below 2^22 elements.
         // (the tile's coordinates are workgroup-uniform but not always provably so for the compiler — the persistent forms read
-        // them from an atomic —: v_readfirstlane pins the bases to scalar registers.  M0 is written inside the asm statement; hipcc
-        // itself sets M0 right in front of every LDS-DMA builtin and keeps nothing else in it.)
+        // them from an atomic —: v_readfirstlane pins the bases to scalar registers.)
         auto uniform_ptr = [](const char* p) {
             const uint64_t u = (uint64_t)p;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
@@ -1249,10 +1248,15 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
         // hipcc selects the 64-bit vector-address form for the builtin whatever the pointer looks like: the scalar-base form by hand
         // (M0 = the piece's LDS address, one state between the M0 write and the load)
         const uint32_t smem_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+        // M0 is on the clobber list so that hipcc's own M0 bookkeeping (it merges and hoists identical M0 initialisations of its
+        // LDS-DMA builtins) sees a definition here; clang flags a reserved register on a clobber list, which is the point
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
         auto glds16_s = [&](const char* sbase, uint32_t voff, uint32_t la) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(voff), "s"(sbase), "s"(la) : "memory");
+                         :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
         };
+#pragma clang diagnostic pop
         auto stage_a = [&](int buf, int kt, int reg) {
             const uint32_t base = smem_lds + buf * CFG::STAGE;
             const char* gb = a_base_u + (int64_t)kt * a_kstep;          // (ra_off holds the segment's first K-tile, sk.kt0)

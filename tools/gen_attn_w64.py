@@ -29,7 +29,7 @@ import os
 import sys
 
 # timing-only ablations (WRONG results; tools/attn_w64_ablate.sh): which parts of the loop are emitted
-OPT = {"max": "run", "align": 6, "dma": "piece", "rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
+OPT = {"max": "run", "head": 0, "align": 6, "dma": "piece", "rowsum": "add", "mfma4_pos": "end", "pk_add": False, "pk_fma": False, "adds_in": "Y", "dma_in": "X", "vread_early": 8, "kread_early": 2, "pre_x": 0, "mix_y": 0, "drain": 2, "dummy_x": 0, "dummy_y": 0}   # schedule options (CLI --opt k=v)
 TRACE = False   # --trace: per-phase cycle accumulators (s_memtime), written through %[tp] at the end (side library)
 ABL = {"fill_x": True, "fill_y": True, "mfma": True, "drain": True, "dma": True, "reads": True, "barrier": True,
        "exp": True, "add": True, "cvt": True, "max": True, "fma": True, "dec": True}
@@ -647,8 +647,25 @@ def main():
     em.i(f"s_cbranch_scc1 {lm}")
     mask_block(em, 0)
     em.i(f"{lm}:")
-    for op in sm1_ops(0, inline_raise=True):
-        em.i(op.replace(' ;dec', ''))
+    if OPT["max"] == "first":
+        # max=first: the row keeps ceil(tile 0's scaled maximum) + head for the whole loop.  The head room costs no precision (it
+        # shifts every probability, the row sum and the numerator by the same power of two) and moves the window the f32 range
+        # leaves: a later score may stand 60 + head binades above tile 0's best before the row sum passes the shell's 2^60 test,
+        # and everything down to -(126 - 24 - head) binades below it keeps all its bits
+        pre = [op for op in sm1_ops(0, inline_raise=True)]
+        nscale = len(scale_ops(0))
+        for op in pre[:-nscale]:
+            em.i(op.replace(' ;dec', ''))
+        if OPT["head"]:
+            import struct
+            lit = "0x%08x" % struct.unpack("<I", struct.pack("<f", float(OPT["head"])))[0]
+            for e in range(2):
+                em.i(f"v_add_f32 {vr(M_(e))}, {lit}, {vr(M_(e))}")
+        for op in pre[-nscale:]:
+            em.i(op)
+    else:
+        for op in sm1_ops(0, inline_raise=True):
+            em.i(op.replace(' ;dec', ''))
     for e in range(2):
         em.i(f"v_mov_b32 {vr(AL_(e))}, 1.0")          # O is still zero: nothing to rescale
     l8, lw = em.label("w0"), em.label("waited2")
