@@ -34,6 +34,19 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.fixture(autouse=True)
+def no_attention_workgroup_takes_its_second_pass():
+    """Every full-size forward of this module runs its large attention launches on the first-tile-maximum loop: none of their
+    workgroups may need the running-maximum pass (apexmi_attn_w64_fallbacks; csrc/attn_w64_kernel.h) — a model whose scores
+    outgrow the checked range would silently pay twice for those workgroups."""
+    import apex_studio_amd  # noqa: F401
+    from apex_studio_amd import lib
+    lib.attn_w64_fallbacks()
+    yield
+    again = lib.attn_w64_fallbacks()
+    assert again == 0, f"{again} attention workgroups re-ran with the running-maximum loop"
+
+
 def _randn(shape, seed):
     g = torch.Generator(device=DEV).manual_seed(seed)
     return torch.randn(shape, generator=g, device=DEV).to(BF)
