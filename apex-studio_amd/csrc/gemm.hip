@@ -835,6 +835,37 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup& G, char* smem, int s,
     }
 
     if constexpr (CFG::SCHED == 0) {
+#if APEXMI_GEMM_PEEL >= 2 && !defined(APEXMI_GEMM_SMALL_VECTOR)   // (-DAPEXMI_GEMM_SMALL_VECTOR: the A/B arm with the builtin's vector addresses)
+        // the pieces in the scalar-base form of global_load_lds (as in the SCHED 5 loop below: uniform tile base in SGPRs + constant
+        // 32-bit lane offsets): these launches put at most a workgroup or two on a CU, and their K-tile is a chain of piece issues
+        const uint64_t a_u64 = (uint64_t)(P.A + (int64_t)min(m0, M - 1) * P.lda), w_u64 = (uint64_t)(P.W + (int64_t)min(n0, N - 1) * P.ldw);
+        const char* const a_u = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a_u64 >> 32)) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a_u64));
+        const char* const w_u = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_u64 >> 32)) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w_u64));
+        uint32_t a_o[CFG::A_LD], w_o[CFG::W_LD];
+#pragma unroll
+        for (int i = 0; i < CFG::A_LD; ++i) a_o[i] = (uint32_t)(a_src[i] - a_u);
+#pragma unroll
+        for (int i = 0; i < CFG::W_LD; ++i) w_o[i] = (uint32_t)(w_src[i] - w_u);
+        const uint32_t smem_lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        auto piece = [&](const char* sbase, uint32_t voff, uint32_t la) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+        };
+#pragma clang diagnostic pop
+        auto stage = [&](int buf, int kt) {
+            const uint32_t base = smem_lds0 + buf * CFG::STAGE + wave * 1024;
+            const char* ga = a_u + (int64_t)kt * (BK * 2);
+            const char* gw = w_u + (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < CFG::A_LD; ++i) piece(ga, a_o[i], base + i * (CFG::NW * 1024));
+#pragma unroll
+            for (int i = 0; i < CFG::W_LD; ++i) piece(gw, w_o[i], base + CFG::A_BYTES + i * (CFG::NW * 1024));
+        };
+#endif
         stage(0, 0);
         for (int kt = 0; kt < nkt; ++kt) {
             // tile kt's LDS-DMA landed (explicit: hipcc's __syncthreads() does not reliably wait for
