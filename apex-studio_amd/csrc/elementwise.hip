@@ -634,11 +634,50 @@ __global__ __launch_bounds__(512) void gemv_rows_kernel(const bf16_t* __restrict
     const int gw = blockIdx.x * 8 + (threadIdx.x >> 6);
     const int nw = gridDim.x * 8;
     const int nchunk = K >> 3;
+    // Round 6: the weight row of the NEXT output column is in flight while this one is multiplied (up to eight 16-byte chunks per
+    // lane, K <= 4096): a wave used to have one chunk in flight, 8 KiB per CU against the >= 50 KiB an HBM stream needs — the
+    // 20-row table of a Flux clip took 9.4 ms for three passes over 6.5 GB.  Same chunks per lane, same order of the sums.
+    constexpr int PF = 8;
+    const bool pf = nchunk <= PF * 64;
+    u32x4 wnext[PF];
+    auto load_row = [&](int n) {
+        const bf16_t* wp = W + (int64_t)n * ldw;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) wnext[i] = *(const u32x4*)(wp + c * 8);
+        }
+    };
+    if (pf && gw < N) load_row(gw);
     for (int n = gw; n < N; n += nw) {
         const bf16_t* wp = W + (int64_t)n * ldw;
         float acc[MB];
 #pragma unroll
         for (int r = 0; r < MB; ++r) acc[r] = 0.0f;
+        if (pf) {
+            u32x4 wcur[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) wcur[i] = wnext[i];
+            if (n + nw < N) load_row(n + nw);
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunk) {
+                    float w[8];
+                    unpack8(wcur[i], w);
+#pragma unroll
+                    for (int r = 0; r < MB; ++r) {
+                        const f32x4 x0 = *(const f32x4*)(xs + r * K + c * 4);
+                        const f32x4 x1 = *(const f32x4*)(xs + r * K + half + c * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[r] = fmaf(w[j], x0[j], acc[r]);
+                            acc[r] = fmaf(w[j + 4], x1[j], acc[r]);
+                        }
+                    }
+                }
+            }
+        } else {
         for (int c = lane; c < nchunk; c += 64) {
             float w[8];
             unpack8(*(const u32x4*)(wp + c * 8), w);
@@ -652,6 +691,7 @@ __global__ __launch_bounds__(512) void gemv_rows_kernel(const bf16_t* __restrict
                     acc[r] = fmaf(w[j + 4], x1[j], acc[r]);
                 }
             }
+        }
         }
         float mine = 0.0f;
 #pragma unroll
@@ -1190,7 +1230,7 @@ extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const f
                            ldw, (const bf16_t*)bias, x, ldx, y, ldy, N, K, flags);
         return apexmi_check_launch("gemv");
     }
-    // several rows of x: one pass over W per group of MB rows (MB x K floats of LDS <= 128 KiB), each row bit-identical to the
+    // several rows of x: one pass over W per group of MB rows (MB x K floats of LDS), each row bit-identical to the
     // single-row kernel
     int grid = (N + 7) / 8;
     if (grid > 2048) grid = 2048;
@@ -1203,6 +1243,7 @@ extern "C" int apexmi_gemv(const void* W, int64_t ldw, const void* bias, const f
                            (const bf16_t*)W, ldw, (const bf16_t*)bias, x, ldx, y, ldy, M, N, K, flags);                 \
     } while (0)
     const int cap = (128 * 1024) / (K * 4);
+    // (twelve rows per pass — 144 KiB of LDS at K = 3072, one pass fewer for 20 / 28 rows — measured 3x SLOWER: the wave's registers)
     if (cap >= 8 && M > 4) GEMV_ROWS(8);
     else if (cap >= 4 && M > 2) GEMV_ROWS(4);
     else GEMV_ROWS(2);

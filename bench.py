@@ -840,18 +840,33 @@ def main():
                  "rccl_ranks": dist.get_world_size()}
 
     begin = getattr(step, "begin", lambda i0, i1: None)   # the engine's per-clip setup (Flux: the modulation table), see build_flux
-    begin(0, args.warmup)
+    # the warm-up clip is SCHEDULED as long as the timed one (its per-clip table has the timed clip's size, so the allocator and the
+    # kernels' first launches are warm — a resident engine renders clip after clip of one length) and runs its first W steps
+    # — twice, so that the hand-over between two clips (end of the previous schedule, its consistency check) has run before the timed
+    # region does it
+    begin(0, min(total, max(args.warmup, args.steps)))
+    begin(0, min(total, max(args.warmup, args.steps)))
     for i in range(args.warmup):
         latents = step(i, latents)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_marks = [] if os.environ.get("APEX_BENCH_STEP_TIMES") == "1" else None   # diagnostics: an event after begin() and after every step
+    if step_marks is not None:
+        step_marks.append(torch.cuda.Event(enable_timing=True)); step_marks[-1].record()
     begin(args.warmup, total)                             # INSIDE the timed region: the K timed steps are one clip
+    if step_marks is not None:
+        step_marks.append(torch.cuda.Event(enable_timing=True)); step_marks[-1].record()
     for i in range(args.warmup, total):
         latents = step(i, latents)
+        if step_marks is not None:
+            step_marks.append(torch.cuda.Event(enable_timing=True)); step_marks[-1].record()
     enqueued = time.perf_counter() - t0                   # host side done: every launch of the K steps is in the queue
     torch.cuda.synchronize()
+    if step_marks is not None and rank == 0:
+        print("[step times] begin %.3f ms; steps %s" % (step_marks[0].elapsed_time(step_marks[1]),
+              " ".join("%.2f" % step_marks[k].elapsed_time(step_marks[k + 1]) for k in range(1, len(step_marks) - 1))), file=sys.stderr)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
