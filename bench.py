@@ -6,7 +6,10 @@ FluxTransformer2DModel forward (19 double + 38 single MM-DiT blocks, S_img 4096 
 heads, bf16, B=1, no CFG) + one FlowMatch-Euler scheduler.step on synthetic latents / prompt embeddings
 and random-init weights of the FLUX.1-dev architecture (no network for checkpoints).  Inputs are resident
 in HBM before the timed region.  After the timed steps one whole clip (28 steps + 2-D VAE decode to
-1024x1024, bf16) is timed as `sec_per_clip`.
+1024x1024, bf16) is timed as `sec_per_clip`.  The K timed steps are ONE clip: its per-clip set-up (the modulation table of its K
+steps, after the hand-over from the warm-up clip) runs inside the timed region; the warm-up clip is scheduled equally long and has
+itself been handed over once, so that set-up pays no first-use cost.  APEX_BENCH_STEP_TIMES=1 prints the set-up's and every timed
+step's GPU time to stderr (diagnostics: two events per step inside the timed region).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
