@@ -2281,6 +2281,15 @@ static int sk_workspace(hipStream_t stream, SkWorkspace* out) {
 
 template <typename CFG, int EPI>
 int launch_cfg(GemmGroup& G, const int* Ms, hipStream_t stream) {
+    if constexpr (APEXMI_GEMM_PEEL >= 2 && (CFG::SCHED == 0 || CFG::SCHED == 5)) {
+        // the scalar-base pieces carry 32-bit lane offsets inside a tile: 256 rows x leading dimension x 2 bytes must stay below 2^32
+        for (int i = 0; i < G.count; ++i)
+            if (G.p[i].lda > (1 << 22) || G.p[i].ldw > (1 << 22)) {
+                apexmi_set_error("gemm_bf16: leading dimensions above 2^22 elements are not supported (lda %lld, ldw %lld)",
+                                 (long long)G.p[i].lda, (long long)G.p[i].ldw);
+                return 1;
+            }
+    }
     static uint64_t attr_set = 0;
     APEXMI_SET_ATTR_ONCE(attr_set,
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<CFG, EPI>,

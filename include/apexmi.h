@@ -129,7 +129,7 @@ int apexmi_attn_fwd_framecausal(const void* q, const void* k, const void* v, voi
  *  transformer/flux/base/model.py:106-129,180-182,258-263; wan model.py:551-712).
  * C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N]);  A,W,C,R bf16 row-major with leading
  * dimensions lda/ldw/ldc/ldr (elements); bias bf16 [N] or NULL; gate f32 [N].
- * Requires K % 64 == 0 and 16-byte aligned rows.
+ * Requires K % 64 == 0, 16-byte aligned rows and lda, ldw <= 2^22 elements (the K-loops address a tile through 32-bit lane offsets).
  * ------------------------------------------------------------------------------------------- */
 int apexmi_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                      void* C, int64_t ldc, int M, int N, int K, int epilogue,

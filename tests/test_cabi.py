@@ -70,6 +70,9 @@ def test_argument_validation_is_host_side_and_reports_a_reason():
     bad(L.apexmi_gemm_bf16(P, 64, P, 64, None, P, 64, 8, 12, 64, 0, None, None, 0, None), "N=12")
     bad(L.apexmi_gemm_bf16(P, 64, P, 64, None, P, 64, 8, 8, 64, 9, None, None, 0, None), "epilogue")
     bad(L.apexmi_gemm_bf16(P, 64, P, 64, None, P, 64, 8, 8, 64, lib.EPI_BIAS_GATE_RES, None, None, 0, None), "gate")
+    # (round 6: the K-loops' LDS-DMA pieces carry 32-bit lane offsets inside a tile)
+    bad(L.apexmi_gemm_bf16(P, (1 << 22) + 64, P, 64, None, P, 64, 2048, 2048, 256, 0, None, None, 0, None), "leading dimensions above 2^22")
+    bad(L.apexmi_gemm_bf16(P, 64, P, (1 << 22) + 64, None, P, 64, 8, 8, 64, 0, None, None, 0, None), "leading dimensions above 2^22")
     bad(L.apexmi_gemm_bf16_batched(P, 64, 64, P, 64, 64, P, 64, 64, 0, 8, 8, 64, 0, None), "batch=0")
     bad(L.apexmi_gemm_bf16_batched(P, 64, 64, P, 64, 64, P, 64, 64, 2, 8, 8, 64, lib.EPI_BIAS_GELU, None), "epilogue")
     bad(L.apexmi_attn_fwd_bias(P, 64, P, 64, P, 64, P, 64, 4, 3, 8, 8, 128, 1.0, None, None, None, 0, P, 1 << 30, None),
